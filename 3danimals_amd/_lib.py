@@ -1,0 +1,87 @@
+"""ctypes binding of liba3d_hip.so (include/a3d.h).  No fallback: if the library is missing we say so and stop."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liba3d_hip.so")
+
+_c_int, _c_float, _c_size_t, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/a3d.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "a3d_version": (_c_int, []),
+    "a3d_last_error": (ctypes.c_char_p, []),
+    "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
+    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
+    "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p]),
+    "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p]),
+    "a3d_normals_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_normals_bwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_aa_hash_bytes": (_c_size_t, [_c_int]),
+    "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p]),
+    "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class A3DError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise A3DError(
+                f"{LIB_PATH} is missing: build it with `python 3danimals_amd/csrc/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for the HIP hot path."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == ABI drift
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise A3DError(f"{name} failed ({rc}): {lib().a3d_last_error().decode()}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors, what: str = "op"):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise A3DError(f"{what}: tensor on {t.device}; the HIP hot path only runs on a ROCm device (no CPU fallback)")
+
+
+def f32c(t):
+    """float32, contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

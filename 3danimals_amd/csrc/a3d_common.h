@@ -1,0 +1,48 @@
+// Shared helpers for the liba3d_hip kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/a3d.h"
+
+#define A3D_WAVE 64
+
+void a3d_set_error(const char* fmt, ...);
+
+#define A3D_CHECK_ARG(cond)                                                   \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            a3d_set_error("%s: invalid argument: %s", __func__, #cond);       \
+            return A3D_EINVAL;                                                \
+        }                                                                     \
+    } while (0)
+
+#define A3D_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            a3d_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_));       \
+            return A3D_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define A3D_LAUNCH_CHECK() A3D_HIP(hipGetLastError())
+
+static inline int a3d_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// lanes below me in the wave that have the bit set: ballot + mbcnt (wave64)
+__device__ __forceinline__ int a3d_lane_id() { return (int)__lane_id(); }
+
+__device__ __forceinline__ int a3d_wave_prefix(unsigned long long mask) {
+    // number of set bits among lanes strictly below the calling lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ float a3d_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif

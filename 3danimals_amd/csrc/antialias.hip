@@ -1,0 +1,328 @@
+// Analytic silhouette antialiasing on gfx950 -- replaces dr.antialias(color, rast, pos, tri)
+// (model/render/render.py:264-267; nvdiffrast, third party).  Specification: oracle/raster_ref.py::antialias.
+//
+//   topology : edge -> adjacent-triangle table built with a 64-bit-key open-addressing hash (atomicCAS claim,
+//              atomicMin on a (face*4+corner) code per traversal direction => deterministic), flattened to
+//              opp[F,3] so the per-pixel pass does ONE 12-byte read instead of three hash probes.
+//              Once per mesh topology (= once per DMTet call), shared by every image and colour buffer.
+//   analyze  : one thread per pixel inspects its right and lower neighbour; id discontinuities are analysed
+//              (3+3 vertex gathers) and the rare true silhouette crossings are appended to a compact work list
+//              with ONE atomicAdd per wave (ballot + mbcnt).  Once per (rast, clip): the reference repeats this
+//              for every colour buffer it antialiases (render.py:311-315).
+//   fwd/bwd  : out = color (+) blends over the work list; backward adds colour gradients and sends
+//              d(alpha)/d(clip) to the two vertices of the crossing edge.
+// HBM traffic: analyze reads 16 B/pixel; fwd/bwd copy 4C B/pixel in and out; the work list is a few thousand
+// 16-byte records per image.  Compiled with -ffp-contract=off so sign tests agree with the oracle.
+#include "a3d_common.h"
+
+#define AA_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define AA_NONE 0x7F7F7F7F
+
+struct AaRec {
+    int pix0;     // flat index (b*H + y)*W + x of the pair's first pixel
+    int tri;      // triangle that owns the crossing edge
+    float alpha;  // signed blend weight
+    int flags;    // bit0 d (0: right neighbour, 1: lower), bits1-2 edge, bit3 triangle belongs to 2nd pixel, bit4 dc clamped
+};
+
+static inline unsigned aa_slots(int F) {
+    unsigned n = 64;
+    while (n < (unsigned)(6 * (long long)F)) n <<= 1;  // load factor <= 1/2
+    return n;
+}
+
+__device__ __forceinline__ unsigned aa_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k;
+}
+
+__global__ __launch_bounds__(256) void aa_hash_insert_kernel(const int* __restrict__ tri, int F, unsigned mask,
+                                                             unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * F) return;
+    const int f = idx / 3, i = idx - 3 * f;
+    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
+    if (a == b) return;
+    const int d = a < b ? 0 : 1;
+    const unsigned long long key = a < b ? (((unsigned long long)(unsigned)a << 32) | (unsigned)b)
+                                         : (((unsigned long long)(unsigned)b << 32) | (unsigned)a);
+    unsigned h = aa_hash(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long old = atomicCAS(&keys[h], AA_EMPTY_KEY, key);
+        if (old == AA_EMPTY_KEY || old == key) {
+            atomicMin(&vals[2 * h + d], f * 4 + i);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_hash_lookup_kernel(const int* __restrict__ tri, int F, unsigned mask,
+                                                             const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                                             int* __restrict__ opp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * F) return;
+    const int f = idx / 3, i = idx - 3 * f;
+    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
+    int result = -1;
+    if (a != b) {
+        const int d = a < b ? 0 : 1;
+        const unsigned long long key = a < b ? (((unsigned long long)(unsigned)a << 32) | (unsigned)b)
+                                             : (((unsigned long long)(unsigned)b << 32) | (unsigned)a);
+        unsigned h = aa_hash(key) & mask;
+        for (unsigned probe = 0; probe <= mask; ++probe) {
+            const unsigned long long k = keys[h];
+            if (k == key) {
+                int other = vals[2 * h + (1 - d)];
+                if (other == AA_NONE) {
+                    const int same = vals[2 * h + d];
+                    if (same != AA_NONE && same != f * 4 + i) other = same;
+                }
+                if (other != AA_NONE) result = tri[3 * (other >> 2) + (other & 3)];
+                break;
+            }
+            if (k == AA_EMPTY_KEY) break;
+            h = (h + 1) & mask;
+        }
+    }
+    opp[idx] = result;
+}
+
+__device__ __forceinline__ bool aa_same_sign(float a, float b) { return ((__float_as_uint(a) ^ __float_as_uint(b)) >> 31) == 0u; }
+
+struct AaEdge {
+    float xa, ya, xb, yb;  // pair direction is the first coordinate
+    int va, vb;            // vertex indices of the edge
+};
+
+// Shared by analysis and backward: pixel-space vertices of triangle t relative to pixel (px,py).
+__device__ __forceinline__ void aa_project(const float4 p, float fx, float fy, float xh, float yh, float& X, float& Y) {
+    X = p.x / p.w * xh - fx;
+    Y = p.y / p.w * yh - fy;
+}
+
+__global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restrict__ rast, const float4* __restrict__ clip, int clip_batch,
+                                                         const int* __restrict__ tri, const int* __restrict__ opp, int V, int F, int H,
+                                                         int W, long long npix, AaRec* __restrict__ work, int capacity,
+                                                         int* __restrict__ count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inside = i < npix;
+    int b = 0, y = 0, x = 0, id0 = -1;
+    float z0 = 0.f;
+    if (inside) {
+        b = (int)(i / ((long long)H * W));
+        const int rem = (int)(i - (long long)b * H * W);
+        y = rem / W;
+        x = rem - y * W;
+        const float4 r0 = rast[i];
+        id0 = (int)r0.w - 1;
+        z0 = r0.z;
+    }
+    const float xh = 0.5f * W, yh = 0.5f * H;
+    const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
+    for (int d = 0; d < 2; ++d) {
+        AaRec rec;
+        bool emit = false;
+        const bool has_nb = inside && (d == 0 ? (x + 1 < W) : (y + 1 < H));
+        if (has_nb) {
+            const float4 r1 = rast[i + (d == 0 ? 1 : W)];
+            const int id1 = (int)r1.w - 1;
+            if (id0 != id1) {
+                int t = id0 >= 0 ? id0 : id1;
+                if (id0 >= 0 && id1 >= 0) t = (z0 < r1.z) ? id0 : id1;
+                const bool use1 = (t == id1);
+                if (t >= 0 && t < F) {
+                    const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
+                    const float ds = use1 ? -1.f : 1.f;
+                    const int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+                    int o0 = opp[3 * t], o1 = opp[3 * t + 1], o2 = opp[3 * t + 2];
+                    o0 = o0 >= 0 ? o0 : v0; o1 = o1 >= 0 ? o1 : v1; o2 = o2 >= 0 ? o2 : v2;
+                    const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
+                    float x0, y0, x1, y1, x2, y2, ox0, oy0, ox1, oy1, ox2, oy2;
+                    aa_project(pb[v0], fx, fy, xh, yh, x0, y0);
+                    aa_project(pb[v1], fx, fy, xh, yh, x1, y1);
+                    aa_project(pb[v2], fx, fy, xh, yh, x2, y2);
+                    aa_project(pb[o0], fx, fy, xh, yh, ox0, oy0);
+                    aa_project(pb[o1], fx, fy, xh, yh, ox1, oy1);
+                    aa_project(pb[o2], fx, fy, xh, yh, ox2, oy2);
+                    const float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+                    const float w0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
+                    const float w1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
+                    const float w2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
+                    const bool s0 = aa_same_sign(w0, bb), s1 = aa_same_sign(w1, bb), s2 = aa_same_sign(w2, bb);
+                    if (s0 || s1 || s2) {
+                        if (d == 1) {  // pair direction becomes the first coordinate
+                            float tmp;
+                            tmp = x0; x0 = y0; y0 = tmp;
+                            tmp = x1; x1 = y1; y1 = tmp;
+                            tmp = x2; x2 = y2; y2 = tmp;
+                        }
+                        // edge k joins vertices (k+1, k+2)
+                        const float exa[3] = {x1, x2, x0}, eya[3] = {y1, y2, y0}, exb[3] = {x2, x0, x1}, eyb[3] = {y2, y0, y1};
+                        const bool sil[3] = {s0, s1, s2};
+                        float best = -INFINITY, bdx = 0.f, bdy = 1.f;
+                        int di = 0;
+                        bool bstr = false;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float dxe = exb[k] - exa[k], dye = eyb[k] - eya[k];
+                            const bool str = !aa_same_sign(eya[k], eyb[k]);
+                            const float ratio = str ? (ds * (exa[k] * dye - eya[k] * dxe)) / dye : -INFINITY;
+                            const bool better = (k == 0) ? true : (ratio > best);
+                            if (better) { best = ratio; di = k; bdx = dxe; bdy = dye; bstr = str; }
+                        }
+                        const float dc = best;
+                        bool ok = sil[di] && bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f);
+                        if (ok) {
+                            const float dcc = fminf(fmaxf(dc, 0.f), 1.f);
+                            rec.pix0 = (int)i;
+                            rec.tri = t;
+                            rec.alpha = ds * (0.5f - dcc);
+                            rec.flags = d | (di << 1) | (use1 ? 8 : 0) | ((dc < 0.f || dc > 1.f) ? 16 : 0);
+                            emit = true;
+                        }
+                    }
+                }
+            }
+        }
+        // wave-aggregated append
+        const unsigned long long m = __ballot(emit);
+        if (m) {
+            int basei = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (a3d_lane_id() == leader) basei = atomicAdd(count, __popcll(m));
+            basei = __shfl(basei, leader);
+            if (emit) {
+                const int slot = basei + a3d_wave_prefix(m);
+                if (slot < capacity) work[slot] = rec;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, int C, const AaRec* __restrict__ work,
+                                                     const int* __restrict__ count, int capacity, int W, float* __restrict__ out) {
+    const int n = min(*count, capacity);
+    const long long total = (long long)n * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / C), c = (int)(idx - (long long)r * C);
+        const AaRec rec = work[r];
+        const long long p0 = rec.pix0, p1 = p0 + ((rec.flags & 1) ? W : 1);
+        const long long dst = rec.alpha > 0.f ? p0 : p1;
+        atomicAdd(out + dst * C + c, rec.alpha * (color[p1 * C + c] - color[p0 * C + c]));
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ color, int C,
+                                                     const AaRec* __restrict__ work, const int* __restrict__ count, int capacity,
+                                                     const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
+                                                     int H, int W, float* __restrict__ g_color, float* __restrict__ g_clip) {
+    const int n = min(*count, capacity);
+    const float xh = 0.5f * W, yh = 0.5f * H;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const AaRec rec = work[r];
+        const int d = rec.flags & 1, di = (rec.flags >> 1) & 3;
+        const bool use1 = rec.flags & 8, clamped = rec.flags & 16;
+        const long long p0 = rec.pix0, p1 = p0 + (d ? W : 1);
+        const long long dst = rec.alpha > 0.f ? p0 : p1;
+        float dd = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float gd = g_out[dst * C + c];
+            if (gd != 0.f) {
+                atomicAdd(g_color + p1 * C + c, rec.alpha * gd);
+                atomicAdd(g_color + p0 * C + c, -rec.alpha * gd);
+                dd += gd * (color[p1 * C + c] - color[p0 * C + c]);
+            }
+        }
+        if (clamped || dd == 0.f) continue;
+        // alpha = ds*0.5 - xint,  xint = (Xa*Yb - Ya*Xb)/(Yb - Ya) in the (pair-direction, other) frame
+        const int b = (int)(p0 / ((long long)H * W));
+        const int rem = (int)(p0 - (long long)b * H * W);
+        const int y = rem / W, x = rem - y * W;
+        const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
+        const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
+        const long long vb = clip_batch == 1 ? 0ll : (long long)b * V;
+        const int ia = tri[3 * rec.tri + (di + 1) % 3], ib = tri[3 * rec.tri + (di + 2) % 3];
+        const float4 pa = clip[vb + ia], pbv = clip[vb + ib];
+        float sxa, sya, sxb, syb;
+        aa_project(pa, fx, fy, xh, yh, sxa, sya);
+        aa_project(pbv, fx, fy, xh, yh, sxb, syb);
+        const float Xa = d ? sya : sxa, Ya = d ? sxa : sya, Xb = d ? syb : sxb, Yb = d ? sxb : syb;
+        const float D = Yb - Ya, iD = 1.f / D, iD2 = iD * iD;
+        const float gx = -dd;  // dL/dxint
+        const float gXa = gx * Yb * iD, gXb = -gx * Ya * iD;
+        const float gYa = gx * Yb * (Xa - Xb) * iD2, gYb = gx * Ya * (Xb - Xa) * iD2;
+        // back to screen x / y
+        const float gsxa = d ? gYa : gXa, gsya = d ? gXa : gYa, gsxb = d ? gYb : gXb, gsyb = d ? gXb : gYb;
+        float* oa = g_clip + (vb + ia) * 4;
+        float* ob = g_clip + (vb + ib) * 4;
+        const float iwa = 1.f / pa.w, iwb = 1.f / pbv.w;
+        atomicAdd(oa, gsxa * xh * iwa);
+        atomicAdd(oa + 1, gsya * yh * iwa);
+        atomicAdd(oa + 3, -(gsxa * pa.x * xh + gsya * pa.y * yh) * iwa * iwa);
+        atomicAdd(ob, gsxb * xh * iwb);
+        atomicAdd(ob + 1, gsyb * yh * iwb);
+        atomicAdd(ob + 3, -(gsxb * pbv.x * xh + gsyb * pbv.y * yh) * iwb * iwb);
+    }
+}
+
+extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * 16; }
+
+extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream) {
+    A3D_CHECK_ARG(F >= 0 && V > 0);
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri && hash && opp);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned n = aa_slots(F);
+    unsigned long long* keys = (unsigned long long*)hash;
+    int* vals = (int*)(keys + n);
+    A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * n, s));
+    A3D_HIP(hipMemsetAsync(vals, 0x7F, sizeof(int) * 2 * (size_t)n, s));
+    hipLaunchKernelGGL(aa_hash_insert_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, n - 1, keys, vals);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aa_hash_lookup_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, n - 1, keys, vals, opp);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
+                              int F, int H, int W, void* work, int capacity, int32_t* count, a3d_stream_t stream) {
+    A3D_CHECK_ARG(rast && clip && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
+    A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
+    hipStream_t s = (hipStream_t)stream;
+    A3D_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri && opp);
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up(npix, 256)), dim3(256), 0, s, (const float4*)rast, (const float4*)clip, clip_batch,
+                       tri, opp, V, F, H, W, npix, (AaRec*)work, capacity, count);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
+                          a3d_stream_t stream) {
+    A3D_CHECK_ARG(color && work && count && out && C > 0 && B > 0 && H > 0 && W > 0 && capacity > 0);
+    hipStream_t s = (hipStream_t)stream;
+    A3D_HIP(hipMemcpyAsync(out, color, sizeof(float) * (size_t)B * H * W * C, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(aa_fwd_kernel, dim3(512), dim3(256), 0, s, color, C, (const AaRec*)work, count, capacity, W, out);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,
+                          const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_color,
+                          float* g_clip, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && color && work && count && clip && g_color && g_clip && C > 0 && B > 0 && V > 0 && H > 0 && W > 0);
+    A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
+    hipStream_t s = (hipStream_t)stream;
+    A3D_HIP(hipMemcpyAsync(g_color, g_out, sizeof(float) * (size_t)B * H * W * C, hipMemcpyDeviceToDevice, s));
+    A3D_HIP(hipMemsetAsync(g_clip, 0, sizeof(float) * 4 * (size_t)clip_batch * V, s));
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri);
+    hipLaunchKernelGGL(aa_bwd_kernel, dim3(256), dim3(256), 0, s, g_out, color, C, (const AaRec*)work, count, capacity,
+                       (const float4*)clip, clip_batch, tri, V, H, W, g_color, g_clip);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

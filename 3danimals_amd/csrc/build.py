@@ -1,0 +1,74 @@
+"""Build liba3d_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python 3danimals_amd/csrc/build.py [--force]
+
+One object per .hip file, linked into 3danimals_amd/lib/liba3d_hip.so (in-tree, git-ignored, travels to the
+GPU box with the snapshot).  raster/dmtet/antialias are compiled with -ffp-contract=off: their arithmetic is
+specified operation by operation (oracle/raster_ref.c, reference dmtet.py:124-131).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "liba3d_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+SOURCES = {
+    "common.hip": [],
+    "dmtet.hip": ["-ffp-contract=off"],
+    "skin.hip": [],
+    "normals.hip": [],
+    "raster.hip": ["-ffp-contract=off"],
+    "interp.hip": [],
+    "antialias.hip": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",
+          "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,16 @@
+// Error string + version for the flat C ABI (include/a3d.h).
+#include <stdarg.h>
+
+#include "a3d_common.h"
+
+static thread_local char g_err[512] = "";
+
+void a3d_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* a3d_last_error(void) { return g_err; }
+extern "C" int a3d_version(void) { return 100; /* 0.1.0 */ }

@@ -1,0 +1,108 @@
+"""Stand-ins for the reference's *unchanged* PyTorch networks, for stand-alone use.
+
+The hot path calls three small coordinate MLPs that the reference keeps in
+``model/networks`` (north_star: "unchanged"): the SDF field inside
+``DMTetGeometry`` (``/root/reference/model/geometry/dmtet.py:187-212``), the
+texture field and the DINO-feature field sampled per pixel in ``shade``
+(``/root/reference/model/render/render.py:54,61``), plus the light MLP
+(``/root/reference/model/render/light.py:169-193``).  When this package is
+overlaid on the reference tree those classes are imported from there; when it
+runs alone (tests, ``bench.py``) it needs networks of the same architecture and
+with the same ``state_dict`` layout (``in_layer.*``, ``mlp.network.{0,2,..}.weight``,
+``min_max``) so reference checkpoints load.  Plain PyTorch; rocBLAS GEMMs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def _activation(name):
+    table = {"tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "relu": nn.ReLU}
+    if name not in table:
+        raise NotImplementedError(name)
+    return table[name]()
+
+
+class HarmonicEmbedding(nn.Module):
+    """[sin(2^k s x), cos(2^k s x)], k<n  (reference networks/HarmonicEmbedding.py:33-44)."""
+
+    def __init__(self, n_harmonic_functions=10, scalar=1.0):
+        super().__init__()
+        self.frequencies = scalar * (2.0 ** torch.arange(n_harmonic_functions))
+
+    def forward(self, x):
+        ang = (x[..., None] * self.frequencies.to(x.device)).reshape(*x.shape[:-1], -1)
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+class MLP(nn.Module):
+    """Bias-free Linear/ReLU stack (reference networks/MLPs.py:9-32)."""
+
+    def __init__(self, cin, cout, num_layers, nf=256, dropout=0, activation=None):
+        super().__init__()
+        assert num_layers >= 1
+        dims = [cin] + [nf] * (num_layers - 1) + [cout]
+        layers = []
+        for i in range(num_layers):
+            if i > 0:
+                layers.append(nn.ReLU(inplace=True))
+            layers.append(nn.Linear(dims[i], dims[i + 1], bias=False))
+            if dropout and 0 < i < num_layers - 1:
+                layers.append(nn.Dropout(dropout))
+        if activation is not None:
+            layers.append(_activation(activation))
+        self.network = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.network(x)
+
+
+class CoordMLP(nn.Module):
+    """Harmonic embedding -> in_layer (+feat concat) -> MLP (reference networks/MLPs.py:35-101)."""
+
+    def __init__(self, cin, cout, num_layers, nf=256, dropout=0, activation=None, min_max=None, n_harmonic_functions=10,
+                 embedder_scalar=1, embed_concat_pts=True, extra_feat_dim=0, symmetrize=False, in_layer_relu=False):
+        super().__init__()
+        self.extra_feat_dim = extra_feat_dim
+        if n_harmonic_functions > 0:
+            self.embedder = HarmonicEmbedding(n_harmonic_functions, embedder_scalar)
+            dim_in = cin * 2 * n_harmonic_functions + (cin if embed_concat_pts else 0)
+            self.embed_concat_pts = embed_concat_pts
+        else:
+            self.embedder = None
+            dim_in = cin
+        self.in_layer = nn.Linear(dim_in, nf)
+        self.relu = nn.ReLU(inplace=True)
+        self.mlp = MLP(nf + extra_feat_dim, cout, num_layers, nf, dropout, activation)
+        self.symmetrize = symmetrize
+        if min_max is not None:
+            self.register_buffer("min_max", min_max)
+        else:
+            self.min_max = None
+        self.bsdf = None
+        self.in_layer_relu = in_layer_relu
+
+    def forward(self, x, feat=None):
+        assert (feat is None and self.extra_feat_dim == 0) or (feat.shape[-1] == self.extra_feat_dim)
+        if self.symmetrize:
+            x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
+        h = x
+        if self.embedder is not None:
+            h = self.embedder(x)
+            if self.embed_concat_pts:
+                h = torch.cat([x, h], -1)
+        h = self.in_layer(h)
+        if self.in_layer_relu:
+            h = self.relu(h)
+        if feat is not None:
+            while feat.dim() < h.dim():
+                feat = feat.unsqueeze(1)
+            h = torch.cat([h, feat.expand(*h.shape[:-1], -1)], dim=-1)
+        out = self.mlp(self.relu(h))
+        if self.min_max is not None:
+            out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+        return out
+
+    def sample(self, x, feat=None):
+        return self.forward(x, feat)

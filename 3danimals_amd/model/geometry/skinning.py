@@ -1,0 +1,359 @@
+"""Bone estimation and linear-blend skinning -- public API of /root/reference/model/geometry/skinning.py.
+
+``skinning()`` (reference :369-439) spends its time in ~24k tiny torch ops: for each of the K bones it walks the
+kinematic chain composing 4x4 matrices one link at a time, then transforms a full copy of the vertex array.  Here
+
+* the K per-bone link transforms  L_i = Rest_i . Rot(euler_i) . Rest_i^-1  are built for all bones at once and
+  the chains are composed level by level with batched 4x4 matmuls (a handful of torch ops, autograd for free:
+  gradients reach ``deform_params`` through them);
+* the per-vertex work -- segment distances, softmax over bones, weighted sum of K affine maps, and its backward
+  incl. the reduction of the 3x4 transform gradients over the vertices -- is one HIP kernel each way
+  (csrc/skin.hip).
+
+``estimate_bones()`` (reference :50-248, @no_grad, once per epoch) is restated on torch and works on any device.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+from . import util  # noqa: F401  (public attribute of the reference module)
+
+
+# ------------------------------------------------------------------------------------------------ kinematic chains
+def build_kinematic_chain(n_bones, start_bone_idx):
+    """Leaf-to-root chain of ``n_bones`` bones starting at ``start_bone_idx`` (reference :25-37).
+
+    Returns (bones_to_joints, kinematic_chain, dependent_bones); parents come first in ``kinematic_chain``.
+    """
+    bones_to_joints, chain, below = [], [], []
+    for i in range(n_bones):
+        bone = start_bone_idx + i
+        bones_to_joints.append((i + 1, i))
+        chain.insert(0, (bone, below))
+        below = below + [bone]
+    return bones_to_joints, chain, below
+
+
+def update_body_kinematic_chain(kinematic_chain, leg_kinematic_chain, body_bone_idx, leg_bone_idxs, attach_legs_to_body=True):
+    """Hang a leg under the body bone it attaches to and every ancestor of it (reference :40-46; mutates the lists)."""
+    if attach_legs_to_body:
+        for bone_idx, dependents in kinematic_chain:
+            if bone_idx == body_bone_idx or body_bone_idx in dependents:
+                dependents += leg_bone_idxs
+    return kinematic_chain + leg_kinematic_chain
+
+
+def children_to_parents(kinematic_tree):
+    """[(bone, [children])] -> [(bone, [parents])] (reference :273-282)."""
+    return [(b, [p for p, ch in kinematic_tree if b in ch]) for b, _ in kinematic_tree]
+
+
+def _joints_to_bones(joints, pairs):
+    return torch.stack([torch.stack([joints[:, :, a], joints[:, :, b]], dim=2) for a, b in pairs], dim=2)
+
+
+# ------------------------------------------------------------------------------------------------ bone estimation
+@torch.no_grad()
+def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bones=0, body_bones_mode="z_minmax", compute_kinematic_chain=True,
+                   aux=None, attach_legs_to_body=True, legs_to_body_joint_indices=None, bone_y_threshold=None):
+    """Heuristic skeleton from the rest-pose vertices (reference :50-248).
+
+    seq_shape [B,F,V,3] -> bones [B,F,K,2,3] (+ kinematic_chain, aux when ``compute_kinematic_chain``).
+    Spine: the two extreme-z vertices (optionally only among those not far below the centroid), snapped to the
+    x=0 symmetry plane, joined through the (lifted) centroid by ``n_body_bones`` bones.  Legs: lowest vertex of
+    each top-view quadrant, joined to the nearest-in-z (or prescribed) body joint by ``n_leg_bones`` bones.
+    """
+    if resample:
+        b, _, n, _ = seq_shape.shape
+        pts = util.sample_farthest_points(seq_shape.reshape(-1, n, 3).transpose(1, 2), n // 4)
+        seq_shape = pts.transpose(1, 2).reshape(b, -1, n // 4, 3)
+
+    def pick(idx):
+        return seq_shape.gather(2, idx[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+
+    if body_bones_mode == "z_minmax":
+        point_a, point_b = pick(seq_shape[..., 2].argmax(dim=2)), pick(seq_shape[..., 2].argmin(dim=2))
+    elif body_bones_mode == "z_minmax_y+":
+        centroid = seq_shape.mean(2)
+        upper = (seq_shape[..., 1] > (centroid[:, :, None, 1] - 0.5)).float()
+        z = seq_shape[..., 2]
+        point_a = pick((z * upper + (-1e6) * (1 - upper)).argmax(2))
+        point_b = pick((z * upper + 1e6 * (1 - upper)).argmin(2))
+    else:
+        raise NotImplementedError
+    point_a[..., 0] = 0
+    point_b[..., 0] = 0
+    mid_point = seq_shape.mean(2)
+    mid_point[..., 0] = 0
+    if n_leg_bones > 0:
+        mid_point[..., 1] += 0.5
+
+    assert n_body_bones % 2 == 0
+    n_joints = n_body_bones + 1
+    blend = torch.linspace(0.0, 1.0, math.ceil(n_joints / 2), device=point_a.device)[None, None, :, None]
+    joints_a = point_a[:, :, None] * (1 - blend) + mid_point[:, :, None] * blend
+    joints_b = point_b[:, :, None] * blend + mid_point[:, :, None] * (1 - blend)
+    joints = torch.cat([joints_a[:, :, :-1], joints_b], 2)
+
+    if compute_kinematic_chain:
+        aux = {}
+        half = n_body_bones // 2
+        bones_to_joints, kinematic_chain, bone = [], [], 0
+        below = []
+        for i in range(half):  # point_a -> mid
+            bones_to_joints.append((i + 1, i))
+            kinematic_chain.insert(0, (bone, below))
+            below = below + [bone]
+            bone += 1
+        below = []
+        for i in range(n_body_bones - 1, half - 1, -1):  # point_b -> mid
+            bones_to_joints.append((i, i + 1))
+            kinematic_chain.insert(0, (bone, below))
+            below = below + [bone]
+            bone += 1
+        aux["bones_to_joints"] = bones_to_joints
+    else:
+        bones_to_joints, kinematic_chain = aux["bones_to_joints"], aux["kinematic_chain"]
+    bones_pred = _joints_to_bones(joints, bones_to_joints)
+
+    if n_leg_bones > 0:
+        assert n_legs == 4
+        xs, ys, zs = seq_shape.unbind(-1)
+        if bone_y_threshold is None:
+            margin = (xs.quantile(0.95) - xs.quantile(0.05)) * 0.2
+            quadrants = [(xs > margin) & (zs > 0), (xs > margin) & (zs < 0), (xs < -margin) & (zs < 0), (xs < -margin) & (zs > 0)]
+        else:  # Fauna variant: centre the quadrants on the lower part of the body
+            low = ys < ys.quantile(bone_y_threshold)
+            x0, z0 = xs[low].quantile(0.5), zs[low].quantile(0.5)
+            mx = (xs[low].quantile(0.95) - xs[low].quantile(0.05)) * 0.2
+            mz = (zs[low].quantile(0.95) - zs[low].quantile(0.05)) * 0.2
+            quadrants = [(xs - x0 > mx) & (zs - z0 > mz), (xs - x0 > mx) & (zs < z0), (xs - x0 < -mx) & (zs < z0),
+                         (xs - x0 < -mx) & (zs - z0 > mz)]
+
+        def leg_joints_in(quadrant, body_bone_idx):
+            out = torch.zeros([seq_shape.shape[0], seq_shape.shape[1], n_leg_bones + 1, 3], dtype=seq_shape.dtype, device=seq_shape.device)
+            ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[:, None]
+            for b in range(seq_shape.shape[0]):
+                for f in range(seq_shape.shape[1]):
+                    pts = seq_shape[b, f][quadrant[b, f]]
+                    if pts.numel() < 1:
+                        raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
+                    foot = pts[torch.argmin(pts[:, 1])]
+                    if body_bone_idx is None:
+                        body_bone_idx = int(torch.argmin((bones_pred[b, f, :, 1, 2] - foot[None, 2]).abs()))
+                    out[b, f] = foot[None] * (1 - ramp) + bones_pred[b, f, body_bone_idx, 1][None] * ramp
+            return out, body_bone_idx
+
+        if legs_to_body_joint_indices is None:
+            legs_to_body_joint_indices = [None, None, None, None]
+        start = n_body_bones
+        leg_bones_all = []
+        leg_auxs = [] if compute_kinematic_chain else aux["legs"]
+        for i, quadrant in enumerate(quadrants):
+            if compute_kinematic_chain:
+                body_bone_idx = legs_to_body_joint_indices[i]
+                if i == 2:
+                    body_bone_idx = legs_to_body_joint_indices[1]
+                elif i == 3:
+                    body_bone_idx = legs_to_body_joint_indices[0]
+                leg_joints, body_bone_idx = leg_joints_in(quadrant, body_bone_idx)
+                legs_to_body_joint_indices[i] = body_bone_idx  # written back into the caller's list, as the reference does (:220)
+                leg_b2j, leg_chain, leg_ids = build_kinematic_chain(n_leg_bones, start_bone_idx=start)
+                kinematic_chain = update_body_kinematic_chain(kinematic_chain, leg_chain, body_bone_idx, leg_ids, attach_legs_to_body)
+                leg_auxs.append({"body_bone_idx": body_bone_idx, "leg_bones_to_joints": leg_b2j})
+                start += n_leg_bones
+            else:
+                leg_joints, _ = leg_joints_in(quadrant, leg_auxs[i]["body_bone_idx"])
+                leg_b2j = leg_auxs[i]["leg_bones_to_joints"]
+            leg_bones_all.append(_joints_to_bones(leg_joints, leg_b2j))
+        all_bones = torch.cat([bones_pred] + leg_bones_all, dim=2)
+    else:
+        all_bones = bones_pred
+
+    if compute_kinematic_chain:
+        aux["kinematic_chain"] = kinematic_chain
+        if n_leg_bones > 0:
+            aux["legs"] = leg_auxs
+        return all_bones.detach(), kinematic_chain, aux
+    return all_bones.detach()
+
+
+# ------------------------------------------------------------------------------------------------ rotations (public API)
+def _axis_angle_rotation(axis: str, angle: torch.Tensor) -> torch.Tensor:
+    """Rotation about one coordinate axis, [...] -> [...,3,3] (PyTorch3D convention; reference :285-312)."""
+    c, s = torch.cos(angle), torch.sin(angle)
+    o, z = torch.ones_like(angle), torch.zeros_like(angle)
+    if axis == "X":
+        flat = (o, z, z, z, c, -s, z, s, c)
+    elif axis == "Y":
+        flat = (c, z, s, z, o, z, -s, z, c)
+    elif axis == "Z":
+        flat = (c, -s, z, s, c, z, z, z, o)
+    else:
+        raise ValueError("letter must be either X, Y or Z.")
+    return torch.stack(flat, -1).reshape(angle.shape + (3, 3))
+
+
+def euler_angles_to_matrix(euler_angles: torch.Tensor, convention: str) -> torch.Tensor:
+    """Euler angles (radians) [...,3] -> rotation matrices [...,3,3] (reference :315-340)."""
+    if euler_angles.dim() == 0 or euler_angles.shape[-1] != 3:
+        raise ValueError("Invalid input euler angles.")
+    if len(convention) != 3:
+        raise ValueError("Convention must have 3 letters.")
+    if convention[1] in (convention[0], convention[2]):
+        raise ValueError(f"Invalid convention {convention}.")
+    for letter in convention:
+        if letter not in ("X", "Y", "Z"):
+            raise ValueError(f"Invalid letter {letter} in convention string.")
+    m = [_axis_angle_rotation(c, e) for c, e in zip(convention, torch.unbind(euler_angles, -1))]
+    return m[0] @ m[1] @ m[2]
+
+
+def _estimate_bone_rotation(forward):
+    """Rest frame of a bone: columns (right, up, forward) with right ~ +x (reference :251-270)."""
+    forward = F.normalize(forward, p=2, dim=-1)
+    right = torch.tensor([1.0, 0.0, 0.0], dtype=forward.dtype, device=forward.device).expand_as(forward)
+    up = F.normalize(torch.cross(forward, right, dim=-1), p=2, dim=-1)
+    right = torch.cross(up, forward, dim=-1)
+    up = F.normalize(up, p=2, dim=-1)
+    return torch.stack([right, up, forward], dim=-1)
+
+
+def _prepare_transform_mtx(rotation=None, translation=None):
+    """4x4 from a rotation and/or translation batch (reference :343-357)."""
+    n = len(rotation) if rotation is not None else (len(translation) if translation is not None else 1)
+    ref = rotation if rotation is not None else translation
+    mtx = torch.eye(4, device=ref.device if ref is not None else None)[None].repeat(n, 1, 1)
+    if rotation is not None:
+        mtx[:, :3, :3] = rotation
+    if translation is not None:
+        mtx[:, :3, 3] = translation
+    return mtx
+
+
+def _invert_transform_mtx(mtx):
+    """Inverse of a rigid 4x4 batch (reference :360-366)."""
+    r, t = mtx[:, :3, :3], mtx[:, :3, 3]
+    inv = torch.eye(4, device=mtx.device)[None].repeat(len(mtx), 1, 1)
+    inv[:, :3, :3] = r.transpose(1, 2)
+    inv[:, :3, 3] = -(r.transpose(1, 2) @ t.unsqueeze(-1)).squeeze(-1)
+    return inv
+
+
+# ------------------------------------------------------------------------------------------------ skinning
+_chain_cache = {}
+
+
+def _chain_index(kinematic_tree, device):
+    """[K, D] long: for bone k (row k) the chain root -> ... -> k, front-padded with the identity slot K."""
+    key = (repr(kinematic_tree), str(device))
+    hit = _chain_cache.get(key)
+    if hit is None:
+        K = len(kinematic_tree)
+        chains = {}
+        for bone_id, _ in kinematic_tree:
+            parents = [p for p, ch in kinematic_tree if bone_id in ch]  # listed root first (reference :392-395)
+            chains[bone_id] = parents + [bone_id]
+        assert sorted(chains) == list(range(K)), "kinematic_tree must list every bone exactly once"
+        depth = max(len(c) for c in chains.values())
+        idx = torch.full((K, depth), K, dtype=torch.long)
+        for k, c in chains.items():
+            idx[k, depth - len(c):] = torch.tensor(c)
+        hit = idx.to(device)
+        if len(_chain_cache) > 64:
+            _chain_cache.clear()
+        _chain_cache[key] = hit
+    return hit
+
+
+def bone_transforms(bones, kinematic_tree, deform_params):
+    """World transform of every bone for every image: [B*F, K, 4, 4].
+
+    M_k = L_root ... L_parent(k) L_k with L_i = Rest_i . Rot_i . Rest_i^-1 (reference :389-417), i.e. a rotation by
+    the bone's Euler angles about its start joint expressed in its rest frame.  bones [1|B,1|F,K,2,3], deform_params [B,F,K,3].
+    """
+    B, Fr, K = deform_params.shape[:3]
+    dev = deform_params.device
+    if bones.shape[0] == 1 and bones.shape[1] == 1:
+        bb = bones.reshape(1, K, 2, 3)  # shared skeleton: broadcast over the batch below
+    else:
+        bb = bones.expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
+    joint_b = bb[:, :, 0]
+    rest_b = _estimate_bone_rotation((bb[:, :, 1] - bb[:, :, 0]).reshape(-1, 3)).reshape(bb.shape[0], K, 3, 3)
+    rot = euler_angles_to_matrix(deform_params.reshape(B * Fr * K, 3), "XYZ").reshape(B * Fr, K, 3, 3)
+    R = rest_b @ rot @ rest_b.transpose(-1, -2)
+    t = joint_b - (R @ joint_b[..., None])[..., 0]
+    L = torch.zeros(B * Fr, K + 1, 4, 4, dtype=rot.dtype, device=dev)
+    L[:, :K, :3, :3] = R
+    L[:, :K, :3, 3] = t
+    L[:, :, 3, 3] = 1.0
+    L[:, K, 0, 0] = L[:, K, 1, 1] = L[:, K, 2, 2] = 1.0  # identity slot for chain padding
+    idx = _chain_index(kinematic_tree, dev)
+    M = L[:, idx[:, 0]]
+    for d in range(1, idx.shape[1]):
+        M = M @ L[:, idx[:, d]]
+    return M
+
+
+class _LazyAux(dict):
+    """aux dict whose 'vertices_to_bones' ([K,B,F,V], unused by any caller on the training path) is computed on first access."""
+
+    def __init__(self, make_weights):
+        super().__init__()
+        self._make_weights = make_weights
+
+    def __missing__(self, key):
+        if key == "vertices_to_bones":
+            self[key] = self._make_weights()
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "vertices_to_bones" or super().__contains__(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
+def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bones=False, temperature=1):
+    """Linear-blend skinning (reference :369-439).
+
+    v_pos [1|B,1|F,V,3], bones_pred [1|B,1|F,K,2,3] (no gradient), deform_params [B,F,K,3] radians.
+    Returns (verts [B,F,V,3], aux{bones_pred, vertices_to_bones, posed_bones}).  Gradients flow to ``v_pos``
+    (through the affine maps; the weights see a detached copy, reference :377) and to ``deform_params``.
+    """
+    B, Fr = deform_params.shape[:2]
+    K, V = bones_pred.shape[2], v_pos.shape[-2]
+    M = bone_transforms(bones_pred.detach(), kinematic_tree, deform_params)  # [B*F,K,4,4]
+    T = M[:, :, :3, :].reshape(B * Fr, K, 12)
+
+    def flat(x, tail):
+        if x.shape[0] == 1 and x.shape[1] == 1:
+            return x.reshape(1, *tail)
+        return x.expand(B, Fr, *tail).reshape(B * Fr, *tail)
+
+    v_flat = flat(v_pos, (V, 3))
+    bones_flat = flat(bones_pred.detach(), (K, 2, 3))
+    out = ops.skin(v_flat, bones_flat, T, temperature).view(B, Fr, V, 3)
+
+    def weights():
+        w = ops.skin_weights(v_flat.detach(), bones_flat, B * Fr, temperature)  # [K,Bw,V]
+        if w.shape[1] == 1:
+            return w.view(K, 1, 1, V)
+        bx, fx = max(v_pos.shape[0], bones_pred.shape[0]), max(v_pos.shape[1], bones_pred.shape[1])
+        return w.view(K, B, Fr, V)[:, :bx, :fx]  # broadcast dims hold duplicates
+
+    aux = _LazyAux(weights)
+    aux["bones_pred"] = bones_pred
+    if output_posed_bones:
+        ends = bones_pred.detach().expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
+        posed = torch.einsum("nkij,nkej->nkei", M[:, :, :3, :3], ends) + M[:, :, None, :3, 3]
+        aux["posed_bones"] = posed.view(B, Fr, K, 2, 3)
+    return out, aux

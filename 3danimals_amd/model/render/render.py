@@ -1,0 +1,216 @@
+"""render_mesh / render_layer / shade / render_uv -- public API of /root/reference/model/render/render.py.
+
+Same signatures, same return contract (a list of NCHW tensors in ``render_modes`` order, ``None`` for unknown
+modes), same arithmetic; underneath, the nvdiffrast calls become HIP kernels:
+
+* one tiled rasterisation pass (csrc/raster.hip) instead of the OpenGL depth peeler;
+* interpolation of world position / smooth normal / canonical position (csrc/interp.hip); the geometric normal is
+  still the reference's per-face attribute, interpolated with a [[f,f,f]] index buffer (render.py:185-191);
+* tangents are neither computed nor interpolated unless the 'tangent' mode asks for them (dead otherwise, a4);
+* ONE silhouette analysis per render (csrc/antialias.hip), applied to every buffer that the reference antialiases
+  separately (render.py:311-315).
+
+The texture / DINO / light MLPs (``material.sample``, ``dino_net.sample``, ``lgt.shade``) stay PyTorch modules.
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from . import light, util
+from . import renderutils as ru
+
+ANTIALIASED_MODES = ("shaded", "flow", "dino_pred", "depth", "shading")  # reference render.py:311
+
+
+def interpolate(attr, rast, attr_idx, rast_db=None):
+    """dr.interpolate wrapper of the reference (render.py:23-24); returns (values, None)."""
+    if rast_db is not None:
+        raise NotImplementedError("pixel-differential attributes (rast_db) are not used on this path (spp=1)")
+    return ops.interpolate(attr.contiguous(), rast, attr_idx), None
+
+
+def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat=None, render_modes=None,
+          two_sided_shading=True, delta_xy_interp=None, dino_net=None, class_vector=None):
+    """Per-pixel shading (reference render.py:30-132): texture / DINO field lookups, shading normal, directional light."""
+    if material is not None:
+        all_tex = material.sample(gb_tex_pos, feat=feat)
+    else:
+        all_tex = torch.ones(*gb_pos.shape[:-1], 9, device=gb_pos.device)
+    kd, ks = all_tex[..., :3], all_tex[..., 3:6]
+    dino_pred = dino_net.sample(gb_tex_pos, feat=class_vector) if dino_net is not None else None
+    alpha = torch.ones_like(kd[..., 0:1])
+
+    # the reference discards the MLP's normal channels here (render.py:71): no perturbation
+    gb_normal = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal,
+                                          two_sided_shading=two_sided_shading, opengl=True, use_python=True)
+    b, h, w, _ = gb_normal.shape
+    cam_normal = util.safe_normalize(torch.matmul(gb_normal.view(b, -1, 3), w2c[:, :3, :3].transpose(2, 1))).view(b, h, w, 3)
+
+    assert bsdf is not None or material.bsdf is not None, "Material must specify a BSDF type"
+    bsdf = bsdf if bsdf is not None else material.bsdf
+    shading = None
+    if bsdf == "diffuse":
+        if lgt is None:
+            shaded_col = kd
+        elif isinstance(lgt, light.EnvironmentLight):
+            raise NotImplementedError("EnvironmentLight is outside the hot path")
+        else:
+            shaded_col, shading = lgt.shade(feat, kd, cam_normal)
+    elif bsdf == "pbr":
+        raise NotImplementedError("bsdf='pbr' needs an EnvironmentLight (reference render.py:83-87); no config uses it")
+    else:
+        assert False, "Invalid BSDF '%s'" % bsdf
+
+    depth = None
+    if render_modes is not None and "depth" in render_modes:
+        hom = torch.cat([gb_pos, torch.ones_like(gb_pos[..., :1])], dim=-1)
+        depth = torch.matmul(hom.view(b, -1, 4), w2c.transpose(-1, -2)).view(b, h, w, 4)[..., 2]
+        dmin, dmax = depth.amin(dim=(1, 2), keepdim=True), depth.amax(dim=(1, 2), keepdim=True)
+        depth = ((depth - dmin) / (dmax - dmin)).unsqueeze(-1)
+
+    wanted = set(render_modes) if render_modes is not None else {"shaded"}
+    buffers = {"shaded": shaded_col}
+    if "kd" in wanted:
+        buffers["kd"] = kd
+    if "ks" in wanted:
+        buffers["ks"] = ks
+    if "normal" in wanted:
+        buffers["normal"] = (gb_normal + 1.0) * 0.5
+    if "geo_normal" in wanted:
+        buffers["geo_normal"] = (gb_geometric_normal + 1.0) * 0.5
+    if "tangent" in wanted and gb_tangent is not None:
+        buffers["tangent"] = (gb_tangent + 1.0) * 0.5
+    if shading is not None:
+        buffers["shading"] = shading
+    if delta_xy_interp is not None:
+        buffers["flow"] = delta_xy_interp
+    if dino_pred is not None:
+        buffers["dino_pred"] = dino_pred
+    if depth is not None:
+        buffers["depth"] = depth
+    if render_modes is not None:
+        return {mode: torch.cat((buffers[mode], alpha), dim=-1) for mode in render_modes if mode in buffers}
+    return {"shaded": torch.cat((shaded_col, alpha), dim=-1)}
+
+
+def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
+                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None):
+    """G-buffer interpolation + shading of one depth layer (reference render.py:139-221)."""
+    full_res = [resolution[0] * spp, resolution[1] * spp]
+    if prior_mesh is None:
+        prior_mesh = mesh
+    render_modes = render_modes if render_modes is not None else ["shaded"]
+    rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
+
+    tri = mesh.t_pos_idx[0]
+    gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)
+    v0, v1, v2 = mesh.v_pos[:, tri[:, 0]], mesh.v_pos[:, tri[:, 1]], mesh.v_pos[:, tri[:, 2]]
+    face_normals = util.safe_normalize(torch.cross(v1 - v0, v2 - v0, dim=-1))
+    gb_geometric_normal, _ = interpolate(face_normals, rast_s, _face_index_buffer(tri))
+    assert mesh.v_nrm is not None
+    gb_normal, _ = interpolate(mesh.v_nrm, rast_s, mesh.t_nrm_idx[0])
+    gb_tangent = None
+    if "tangent" in render_modes:  # only then are tangents ever observable (perturbed_nrm is None, render.py:71)
+        gb_tangent, _ = interpolate(mesh.v_tng, rast_s, mesh.t_tng_idx[0])
+    delta_xy_interp = interpolate(delta_xy, rast_s, tri)[0] if "flow" in render_modes else None
+    gb_tex_pos, _ = interpolate(prior_mesh.v_pos, rast_s, tri)  # canonical position = texture coordinate (render.py:209)
+
+    buffers = shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat=feat,
+                    render_modes=render_modes, two_sided_shading=two_sided_shading, delta_xy_interp=delta_xy_interp, dino_net=dino_net,
+                    class_vector=class_vector)
+    if spp > 1 and msaa:
+        for key in buffers.keys():
+            buffers[key] = util.scale_img_nhwc(buffers[key], full_res, mag="nearest", min="nearest")
+    return buffers
+
+
+_face_idx_cache = ops._IdentityCache()
+
+
+def _face_index_buffer(tri):
+    """[[f,f,f]] int32 so a per-face attribute can go through interpolate (reference render.py:190); cached per topology."""
+    return _face_idx_cache.get(tri, lambda t: torch.arange(t.shape[0], dtype=torch.int32, device=t.device)[:, None].repeat(1, 3).contiguous())
+
+
+def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp=1, num_layers=1, msaa=False, background=None, bsdf=None,
+                feat=None, render_modes=None, prior_mesh=None, two_sided_shading=True, dino_net=None, num_frames=None, class_vector=None):
+    """Rasterise, shade, composite over the background and antialias (reference render.py:228-337).
+
+    ``ctx`` is accepted for signature compatibility (dr.RasterizeGLContext() in the reference, AnimalModel.py:235-236)
+    and unused: the HIP rasteriser keeps no context.
+    """
+    assert mesh.t_pos_idx.shape[1] > 0, "Got empty training triangle mesh (unrecoverable discontinuity)"
+    assert background is None or (background.shape[1] == resolution[0] and background.shape[2] == resolution[1])
+    if num_layers != 1:
+        raise NotImplementedError("depth peeling beyond the first layer is never used (num_layers=1, AnimalModel.py:247)")
+    render_modes = render_modes if render_modes is not None else ["shaded"]
+    dev = mesh.v_pos.device
+    full_res = [resolution[0] * spp, resolution[1] * spp]
+    mtx_in = torch.tensor(mtx_in, dtype=torch.float32, device=dev) if not torch.is_tensor(mtx_in) else mtx_in
+    view_pos = torch.tensor(view_pos, dtype=torch.float32, device=dev) if not torch.is_tensor(view_pos) else view_pos
+    view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
+
+    v_pos_clip = ru.xfm_points(mesh.v_pos, mtx_in, use_python=True)  # [B,V,4]
+
+    delta_xy = None
+    if "flow" in render_modes:  # 2-D motion of each vertex to the next frame (render.py:281-288)
+        ndc = v_pos_clip[..., :2] / v_pos_clip[..., -1:]
+        ndc = ndc.view(-1, num_frames, *ndc.shape[1:])
+        delta_xy = ndc[:, 1:] - ndc[:, :-1]
+        delta_xy = torch.cat([delta_xy, torch.zeros_like(delta_xy[:, :1])], dim=1).view(-1, *ndc.shape[2:])
+
+    tri = mesh.t_pos_idx[0]
+    clip_f = v_pos_clip.float()
+    rast = ops.rasterize(clip_f, tri, full_res)
+    rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
+                            prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
+                            class_vector=class_vector)
+
+    if background is not None:
+        if spp > 1:
+            background = util.scale_img_nhwc(background, full_res, mag="nearest", min="nearest")
+        background = torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
+    else:
+        background = torch.zeros(1, full_res[0], full_res[1], 4, dtype=torch.float32, device=dev)
+
+    analysis = None
+    coverage = (rast[..., -1:] > 0).float()
+    out_buffers = []
+    for key in render_modes:
+        if key not in rendered:
+            out_buffers.append(None)
+            continue
+        buf = rendered[key]
+        bg = background if key in ("shaded", "geo_normal", "shading") else torch.zeros_like(buf)
+        if key == "shading" and bg.shape[-1] == 4:
+            bg = bg[..., 2:]
+        alpha = coverage * buf[..., -1:]
+        accum = torch.lerp(bg, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)  # render.py:261-262
+        if key in ANTIALIASED_MODES:
+            if analysis is None:
+                tri32 = ops.tri_int32(tri)
+                analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))
+            accum = ops.antialias(accum.contiguous().float(), rast, clip_f, tri, analysis=analysis)
+        out = util.avg_pool_nhwc(accum, spp) if spp > 1 else accum
+        if key in ("kd", "ks", "normal", "geo_normal", "tangent"):
+            out = out[..., :3]
+        elif key in ("shading", "depth"):
+            out = out[..., :1]
+        elif key == "flow":
+            out = out[..., :2]
+        elif key == "dino_pred":
+            out = out[..., :-1]
+        out_buffers.append(out.permute(0, 3, 1, 2))
+    return out_buffers
+
+
+def render_uv(ctx, mesh, resolution, mlp_texture, feat=None):
+    """Texture-space bake used by the OBJ/MTL export (reference render.py:342-360)."""
+    uv_clip = mesh.v_tex * 2.0 - 1.0
+    uv_clip4 = torch.cat((uv_clip, torch.zeros_like(uv_clip[..., 0:1]), torch.ones_like(uv_clip[..., 0:1])), dim=-1)
+    rast = ops.rasterize(uv_clip4.contiguous(), mesh.t_tex_idx[0], resolution)
+    gb_pos, _ = interpolate(mesh.v_pos, rast, mesh.t_pos_idx[0])
+    all_tex = mlp_texture.sample(gb_pos, feat=feat)
+    assert all_tex.shape[-1] in (9, 10), "Combined kd_ks_normal must be 9 or 10 channels"
+    return (rast[..., -1:] > 0).float(), all_tex[..., :-6], all_tex[..., -6:-3], util.safe_normalize(all_tex[..., -3:])

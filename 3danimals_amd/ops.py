@@ -1,0 +1,304 @@
+"""torch.autograd.Function wrappers over the C ABI (include/a3d.h).
+
+Every Function allocates its outputs with torch (so PyTorch's caching allocator owns all device memory),
+launches on the current torch stream and returns real gradients for every differentiable input -- DDP runs
+with find_unused_parameters=False in the reference.  Nothing here runs on CPU.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import call, f32c, ptr, require_device, stream
+
+
+# ---------------------------------------------------------------------------------------------- index caches
+class _IdentityCache:
+    """Small LRU keyed by tensor identity (storage pointer, shape, version).
+
+    The keyed tensor is kept alive inside the entry, so its storage cannot be recycled while the entry exists.
+    """
+
+    def __init__(self, maxsize=8):
+        self.maxsize = maxsize
+        self.data = OrderedDict()
+
+    @staticmethod
+    def key(t):
+        return (t.data_ptr(), tuple(t.shape), t.dtype, t._version)
+
+    def get(self, t, make):
+        k = self.key(t)
+        hit = self.data.get(k)
+        if hit is not None:
+            self.data.move_to_end(k)
+            return hit[1]
+        val = make(t)
+        self.data[k] = (t, val)
+        while len(self.data) > self.maxsize:
+            self.data.popitem(last=False)
+        return val
+
+
+_tri32_cache = _IdentityCache()
+_topo_cache = _IdentityCache()
+
+
+def tri_int32(tri: torch.Tensor) -> torch.Tensor:
+    """[F,3] (or [1,F,3]) index tensor -> contiguous int32 [F,3]; converted once per topology and cached
+    (the reference converts with .int() at every dr.* call, render.py:182-209,292)."""
+    if tri.dim() == 3:
+        tri = tri[0]
+    if tri.dtype == torch.int32 and tri.is_contiguous():
+        return tri
+    return _tri32_cache.get(tri, lambda t: t.to(torch.int32).contiguous())
+
+
+class AATopology:
+    """opp[F,3] for one triangle list (nvdiffrast's topology hash), built by a3d_aa_topology."""
+
+    def __init__(self, tri32: torch.Tensor, num_vertices: int):
+        require_device(tri32, what="aa_topology")
+        F = tri32.shape[0]
+        self.tri = tri32
+        self.opp = torch.empty((F, 3), dtype=torch.int32, device=tri32.device)
+        if F > 0:
+            nbytes = _lib.lib().a3d_aa_hash_bytes(F)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=tri32.device)
+            call("a3d_aa_topology", ptr(tri32), F, int(num_vertices), ptr(scratch), ptr(self.opp), stream())
+
+
+def aa_topology(tri32: torch.Tensor, num_vertices: int) -> AATopology:
+    return _topo_cache.get(tri32, lambda t: AATopology(t, num_vertices))
+
+
+# ---------------------------------------------------------------------------------------------- DMTet
+class _DMTet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, sdf, grid):
+        require_device(pos, sdf, grid.edges32, what="dmtet")
+        sdf_shape = sdf.shape
+        pos_c, sdf_c = f32c(pos), f32c(sdf).reshape(-1)
+        Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
+        assert sdf_c.shape[0] == Nv, "sdf must have one value per grid vertex"
+        dev = pos_c.device
+        scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
+        counts = torch.empty(4, dtype=torch.int32, device=dev)
+        call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), stream())
+        V, n1, n2 = counts.tolist()[:3]  # the one host sync of the path (the reference syncs here too, dmtet.py:110)
+        F = n1 + 2 * n2
+        verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
+        edge2vert = torch.empty((Ne,), dtype=torch.int32, device=dev)
+        faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
+        uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
+        call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch),
+             V, n1, n2, ptr(edge2vert), ptr(verts), ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
+        ctx.save_for_backward(pos_c, sdf_c, vert_edge)
+        ctx.grid, ctx.sdf_shape = grid, sdf_shape
+        ctx.mark_non_differentiable(faces, uv_idx)
+        return verts, faces, uv_idx
+
+    @staticmethod
+    def backward(ctx, g_verts, _gf, _gu):
+        pos_c, sdf_c, vert_edge = ctx.saved_tensors
+        Nv, V = pos_c.shape[0], vert_edge.shape[0]
+        g_sdf = torch.empty_like(sdf_c)
+        g_pos = torch.empty_like(pos_c) if ctx.needs_input_grad[0] else None
+        g = f32c(g_verts) if V > 0 else None
+        call("a3d_dmtet_bwd", ptr(g), ptr(pos_c), ptr(sdf_c), ptr(ctx.grid.edges32), ptr(vert_edge), V, Nv, ptr(g_pos), ptr(g_sdf), stream())
+        return g_pos, g_sdf.reshape(ctx.sdf_shape), None
+
+
+def dmtet(pos, sdf, grid):
+    """(verts [V,3] differentiable w.r.t. sdf/pos, faces int64 [F,3], uv_idx int64 [F,3])."""
+    return _DMTet.apply(pos, sdf, grid)
+
+
+# ---------------------------------------------------------------------------------------------- skinning
+class _Skin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, bones, T, temperature):
+        require_device(v, bones, T, what="skinning")
+        v, bones, T = f32c(v), f32c(bones), f32c(T)
+        B, K = T.shape[0], T.shape[1]
+        V = v.shape[1]
+        assert v.shape[0] in (1, B) and bones.shape[0] in (1, B) and bones.shape[1] == K and T.shape[2] == 12
+        out = torch.empty((B, V, 3), dtype=torch.float32, device=v.device)
+        call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, float(temperature), ptr(out), None, stream())
+        ctx.save_for_backward(v, bones, T)
+        ctx.temperature = float(temperature)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        v, bones, T = ctx.saved_tensors
+        B, K, V = T.shape[0], T.shape[1], v.shape[1]
+        g_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        g_T = torch.empty_like(T)
+        call("a3d_skin_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, ctx.temperature, ptr(g_v),
+             ptr(g_T), stream())
+        return g_v, None, g_T, None
+
+
+def skin(v, bones, T, temperature):
+    """v [1|B,V,3], bones [1|B,K,2,3] (detached), T [B,K,12] -> [B,V,3]."""
+    return _Skin.apply(v, bones, T, temperature)
+
+
+def skin_weights(v, bones, B, temperature):
+    """aux['vertices_to_bones'] on demand: [K, Bw, V]."""
+    require_device(v, bones, what="skin_weights")
+    v, bones = f32c(v), f32c(bones)
+    K, V = bones.shape[1], v.shape[1]
+    Bw = max(v.shape[0], bones.shape[0])
+    T = torch.zeros((Bw, K, 12), dtype=torch.float32, device=v.device)
+    out = torch.empty((Bw, V, 3), dtype=torch.float32, device=v.device)
+    w = torch.empty((K, Bw, V), dtype=torch.float32, device=v.device)
+    call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), Bw, V, K, float(temperature), ptr(out), ptr(w), stream())
+    return w
+
+
+# ---------------------------------------------------------------------------------------------- normals
+class _Normals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, tri32):
+        require_device(v, tri32, what="vertex_normals")
+        v = f32c(v)
+        B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
+        acc = torch.empty_like(v)
+        nrm = torch.empty_like(v)
+        call("a3d_normals_fwd", ptr(v), ptr(tri32), B, V, F, ptr(acc), ptr(nrm), stream())
+        ctx.save_for_backward(v, acc, tri32)
+        return nrm
+
+    @staticmethod
+    def backward(ctx, g_nrm):
+        v, acc, tri32 = ctx.saved_tensors
+        B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
+        scratch = torch.empty_like(v)
+        g_v = torch.empty_like(v)
+        call("a3d_normals_bwd", ptr(f32c(g_nrm)), ptr(acc), ptr(v), ptr(tri32), B, V, F, ptr(scratch), ptr(g_v), stream())
+        return g_v, None
+
+
+def vertex_normals(v, tri):
+    """Area-weighted, normalised vertex normals [B,V,3] (auto_normals)."""
+    return _Normals.apply(v, tri_int32(tri))
+
+
+# ---------------------------------------------------------------------------------------------- rasterise
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, tri32, B, H, W):
+        require_device(clip, tri32, what="rasterize")
+        clip = f32c(clip)
+        V, F = clip.shape[1], tri32.shape[0]
+        rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=clip.device)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), stream())
+        ctx.save_for_backward(clip, tri32, rast)
+        return rast
+
+    @staticmethod
+    def backward(ctx, g_rast):
+        clip, tri32, rast = ctx.saved_tensors
+        B, H, W = rast.shape[:3]
+        g_clip = torch.empty_like(clip)
+        call("a3d_rast_bwd", ptr(f32c(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
+             ptr(g_clip), stream())
+        return g_clip, None, None, None, None
+
+
+def rasterize(clip, tri, resolution, batch=None):
+    """clip [B|1,V,4] -> rast [B,H,W,4] = (u, v, z/w, triangle_id+1); differentiable through (u,v)."""
+    if clip.dim() == 2:
+        clip = clip[None]
+    B = clip.shape[0] if batch is None else batch
+    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]))
+
+
+# ---------------------------------------------------------------------------------------------- interpolate
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri32):
+        require_device(attr, rast, tri32, what="interpolate")
+        attr, rast = f32c(attr), f32c(rast)
+        B, H, W = rast.shape[:3]
+        V, C = attr.shape[1], attr.shape[2]
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=rast.device)
+        call("a3d_interp_fwd", ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(out), stream())
+        ctx.save_for_backward(attr, rast, tri32)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        attr, rast, tri32 = ctx.saved_tensors
+        B, H, W = rast.shape[:3]
+        V, C = attr.shape[1], attr.shape[2]
+        g_attr = torch.empty_like(attr) if ctx.needs_input_grad[0] else None
+        g_rast = torch.empty_like(rast)
+        call("a3d_interp_bwd", ptr(f32c(g_out)), ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(g_attr),
+             ptr(g_rast), stream())
+        return g_attr, (g_rast if ctx.needs_input_grad[1] else None), None
+
+
+def interpolate(attr, rast, tri):
+    """attr [B|1,V,C] (or [V,C]) -> [B,H,W,C]."""
+    if attr.dim() == 2:
+        attr = attr[None]
+    return _Interpolate.apply(attr, rast, tri_int32(tri))
+
+
+# ---------------------------------------------------------------------------------------------- antialias
+class AAAnalysis:
+    """Silhouette-crossing work list for one (rast, clip, topology); shared by every colour buffer."""
+
+    def __init__(self, rast, clip, topo: AATopology):
+        require_device(rast, clip, what="antialias")
+        self.rast, self.clip, self.topo = f32c(rast.detach()), f32c(clip.detach()), topo
+        B, H, W = rast.shape[:3]
+        self.B, self.H, self.W = B, H, W
+        self.capacity = 2 * B * H * W
+        dev = rast.device
+        self.work = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
+        self.count = torch.empty((1,), dtype=torch.int32, device=dev)
+        call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), B, self.clip.shape[1],
+             topo.tri.shape[0], H, W, ptr(self.work), self.capacity, ptr(self.count), stream())
+
+
+class _Antialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, clip, analysis):
+        require_device(color, what="antialias")
+        color = f32c(color)
+        a = analysis
+        B, H, W, C = color.shape
+        assert (B, H, W) == (a.B, a.H, a.W)
+        out = torch.empty_like(color)
+        call("a3d_aa_fwd", ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, B, H, W, ptr(out), stream())
+        ctx.save_for_backward(color)
+        ctx.analysis = a
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (color,) = ctx.saved_tensors
+        a = ctx.analysis
+        B, H, W, C = color.shape
+        g_color = torch.empty_like(color)
+        g_clip = torch.empty_like(a.clip)
+        call("a3d_aa_bwd", ptr(f32c(g_out)), ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri),
+             B, a.clip.shape[1], a.topo.tri.shape[0], H, W, ptr(g_color), ptr(g_clip), stream())
+        return g_color, g_clip, None
+
+
+def antialias(color, rast, clip, tri, analysis=None):
+    """dr.antialias semantics; pass ``analysis`` (AAAnalysis) to share the geometry pass between buffers."""
+    if clip.dim() == 2:
+        clip = clip[None]
+    if analysis is None:
+        tri32 = tri_int32(tri)
+        analysis = AAAnalysis(rast, clip, aa_topology(tri32, clip.shape[1]))
+    return _Antialias.apply(color, clip, analysis)

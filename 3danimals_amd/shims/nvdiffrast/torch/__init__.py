@@ -1,0 +1,108 @@
+"""``nvdiffrast.torch``-compatible operator API on top of the HIP kernels.
+
+Put ``3danimals_amd/shims`` on ``sys.path`` and the reference's unchanged callers --
+``dr.RasterizeGLContext()`` (AnimalModel.py:235-236), ``dr.DepthPeeler`` / ``dr.interpolate`` / ``dr.antialias``
+(render.py:24,264-267,292-294), ``dr.rasterize`` (render.py:351, visualize_results.py:225-229) -- run on MI355X
+without OpenGL or CUDA.  ``dr.texture`` has no call site on the reconstruct-and-render path (only EnvironmentLight,
+Texture2D mips and image_grad use it, all dead code in every config) and raises.
+"""
+import importlib
+
+import torch
+
+_ops = importlib.import_module("3danimals_amd.ops")
+
+
+class _Context:
+    """Opaque rasteriser handle.  nvdiffrast's owns an EGL/GL (or CUDA) context; the HIP rasteriser is stateless."""
+
+    def __init__(self, output_db=True, mode="automatic", device=None):
+        self.output_db = output_db
+        self.device = device
+
+    def set_context(self):
+        pass
+
+    def release_context(self):
+        pass
+
+
+class RasterizeGLContext(_Context):
+    pass
+
+
+class RasterizeCudaContext(_Context):
+    def __init__(self, device=None):
+        super().__init__(output_db=True, device=device)
+
+
+def _check(pos, tri, resolution):
+    if not (torch.is_tensor(pos) and torch.is_tensor(tri)):
+        raise RuntimeError("pos and tri must be tensors")
+    if pos.dim() != 3 or pos.shape[-1] != 4:
+        raise RuntimeError("pos must have shape [minibatch, num_vertices, 4] (range mode is not supported)")
+    if tri.dim() != 2 or tri.shape[-1] != 3:
+        raise RuntimeError("tri must have shape [num_triangles, 3]")
+    if len(resolution) != 2:
+        raise RuntimeError("resolution must be [height, width]")
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db).  rast_db is returned as zeros: image-space
+    derivatives are only consumed with spp>1 texture filtering, which this path never uses (render.py:24)."""
+    if ranges is not None:
+        raise NotImplementedError("range mode")
+    _check(pos, tri, resolution)
+    rast = _ops.rasterize(pos, tri, resolution)
+    return rast, torch.zeros_like(rast)
+
+
+class DepthPeeler:
+    def __init__(self, glctx, pos, tri, resolution, ranges=None, grad_db=True):
+        if ranges is not None:
+            raise NotImplementedError("range mode")
+        _check(pos, tri, resolution)
+        self.pos, self.tri, self.resolution = pos, tri, resolution
+        self.layer = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        return False
+
+    def rasterize_next_layer(self):
+        if self.layer > 0:
+            raise NotImplementedError("only the first depth layer is implemented (the reference always uses num_layers=1)")
+        self.layer += 1
+        return rasterize(None, self.pos, self.tri, self.resolution)
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """-> (out [B,H,W,C], out_da).  Pixel-differential outputs (rast_db/diff_attrs) are not implemented."""
+    if rast_db is not None or diff_attrs is not None:
+        raise NotImplementedError("attribute pixel differentials (rast_db / diff_attrs)")
+    return _ops.interpolate(attr, rast, tri), torch.empty(0, device=rast.device)
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    out = _ops.antialias(color, rast, pos, tri)
+    if pos_gradient_boost != 1.0:
+        raise NotImplementedError("pos_gradient_boost")
+    return out
+
+
+def antialias_construct_topology_hash(tri):
+    return _ops.aa_topology(_ops.tri_int32(tri), int(tri.max().item()) + 1)
+
+
+def texture(*args, **kwargs):
+    raise NotImplementedError("dr.texture is not on the reconstruct-and-render path (SURVEY.md section 2 row 12)")
+
+
+def get_log_level():
+    return 1
+
+
+def set_log_level(level):
+    pass

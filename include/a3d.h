@@ -1,0 +1,131 @@
+/* a3d.h -- flat C ABI of liba3d_hip.so: the MI355X (gfx950) reconstruct-and-render hot path of 3DAnimals.
+ *
+ * Every entry point replaces an operator the reference reaches through Python (there is no FFI in the
+ * reference for this path -- it is pure PyTorch plus the third-party nvdiffrast extension); the
+ * reference-side interface each one stands in for is cited as /root/reference file:line.  The Python
+ * binding a maintainer adds is a ctypes stub, see INTEGRATION.md and 3danimals_amd/_lib.py.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers owned by the caller (PyTorch); row-major, densely packed;
+ *    float = IEEE fp32, indices int32 on the device side (the Python layer keeps the reference's
+ *    int64 index tensors and converts once per topology, as the reference does at the dr.* boundary,
+ *    render.py:182,292); DMTet face buffers are emitted as int64 because that is what callers index with.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *    enqueued on it; no entry point synchronises, allocates or frees device memory.
+ *  - return 0 on success, a negative A3D_E* code otherwise; a3d_last_error() gives a thread-local message.
+ *  - "zeroed by callee" = the function enqueues the hipMemsetAsync itself.
+ *  - Bx arguments named *_batch are 1 (shared, broadcast over the batch) or B.
+ */
+#ifndef A3D_H
+#define A3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3D_OK 0
+#define A3D_EINVAL (-1)  /* bad argument */
+#define A3D_EHIP (-2)    /* a HIP runtime call failed */
+
+typedef void* a3d_stream_t;
+
+int a3d_version(void);
+const char* a3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * DMTet marching tetrahedra -- replaces DMTet.__call__ + map_uv index part,
+ * /root/reference/model/geometry/dmtet.py:104-155, :86-96.
+ * Static per grid (caller precomputes once): edges[Ne,2] = lexicographically sorted unique (min,max)
+ * tet edges (== dmtet.py:283-288), tet2edge[Nt,6] = row in `edges` of each tet edge slot (dmtet.py:46).
+ * Two phases with one 16-byte read-back in between (output sizes are data dependent; the reference
+ * synchronises at the same place, dmtet.py:110):
+ *   a3d_dmtet_count : counts[0]=V crossing edges, counts[1]=n1 one-triangle tets, counts[2]=n2 two-triangle
+ *                     tets (F = n1 + 2 n2); block_scan = scratch of a3d_dmtet_scratch_bytes(Ne,Nt) bytes.
+ *   a3d_dmtet_emit  : verts[V,3] (vertex v = v-th crossing edge in `edges` order, placed at the SDF zero
+ *                     crossing with the reference's operation order), vert_edge[V] (edge row, for backward),
+ *                     edge2vert[Ne] (-1 if not crossing), faces[F,3] int64 (1-triangle tets first, then
+ *                     2-triangle tets, dmtet.py:140-143), uv_idx[F,3] int64 (dmtet.py:91-96).
+ *   a3d_dmtet_bwd   : g_sdf[Nv] (zeroed by callee) and optionally g_pos[Nv,3] (zeroed by callee) from g_verts.
+ */
+size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
+int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* block_scan,
+                    int32_t* counts /*[4] device*/, a3d_stream_t stream);
+int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tets, const int32_t* tet2edge,
+                   int Ne, int Nt, const void* block_scan, int V, int n1, int n2, int32_t* edge2vert, float* verts,
+                   int32_t* vert_edge, int64_t* faces, int64_t* uv_idx, a3d_stream_t stream);
+int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
+                  int V, int Nv, float* g_pos_or_null, float* g_sdf, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear-blend skinning -- replaces the per-vertex part of skinning(),
+ * /root/reference/model/geometry/skinning.py:377 (weights, :16-22 + geometry/util.py:30-53) and :419-431.
+ * T[B,K,12] = per-image, per-bone world transform (rows of the 3x4 affine), composed on the host side from
+ * the kinematic chain.  out[b,v] = sum_k softmax_k(-dist(v, bone_k)/temperature) * (T[b,k] . [v,1]).
+ * weights_or_null[K,max(Bv,Bb),V] optionally receives the softmax weights (aux['vertices_to_bones']).
+ * Backward: g_v[Bv,V,3] (zeroed by callee; may be null) through the affine maps only (weights are detached,
+ * skinning.py:377) and g_T[B,K,12] (zeroed by callee).
+ */
+int a3d_skin_fwd(const float* v, int v_batch, const float* bones /*[Bb,K,2,3]*/, int bones_batch, const float* T, int B, int V,
+                 int K, float temperature, float* out /*[B,V,3]*/, float* weights_or_null, a3d_stream_t stream);
+int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B,
+                 int V, int K, float temperature, float* g_v_or_null, float* g_T, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Area-weighted vertex normals -- replaces auto_normals, /root/reference/model/render/mesh.py:276-304.
+ * acc[B,V,3] receives the un-normalised sums (saved for backward), nrm[B,V,3] the result
+ * (zero sums -> (0,0,1), then safe_normalize, mesh.py:296-299).
+ */
+int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, int B, int V, int F, float* acc, float* nrm,
+                    a3d_stream_t stream);
+int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const int32_t* tri, int B, int V, int F,
+                    float* g_acc_scratch /*[B,V,3]*/, float* g_v /*[B,V,3] zeroed by callee*/, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rasterise -- replaces dr.DepthPeeler(...).rasterize_next_layer() layer 0 / dr.rasterize,
+ * /root/reference/model/render/render.py:292-294, :351 (nvdiffrast, third party).
+ * clip[clip_batch,V,4]; rast[B,H,W,4] = (u, v, z/w, triangle_id+1), empty = 0.  Per-fragment arithmetic is
+ * specified operation by operation in oracle/raster_ref.c.  Backward: gradient of (u,v) w.r.t. clip x,y,w
+ * (z/w and the id carry none); g_clip[clip_batch,V,4] zeroed by callee.
+ */
+int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
+                 a3d_stream_t stream);
+int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
+                 int F, int H, int W, float* g_clip, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Interpolate -- replaces dr.interpolate(attr, rast, tri) with rast_db=None,
+ * /root/reference/model/render/render.py:23-24 (call sites :182-209).
+ * attr[attr_batch,V,C]; out[B,H,W,C] = u*A0 + v*A1 + (1-u-v)*A2, 0 where empty.
+ * Backward: g_attr[attr_batch,V,C] (zeroed by callee; may be null), g_rast[B,H,W,4] (fully written: du, dv, 0, 0).
+ */
+int a3d_interp_fwd(const float* attr, int attr_batch, int C, const float* rast, const int32_t* tri, int B, int V, int F, int H,
+                   int W, float* out, a3d_stream_t stream);
+int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C, const float* rast, const int32_t* tri, int B,
+                   int V, int F, int H, int W, float* g_attr_or_null, float* g_rast, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Antialias -- replaces dr.antialias(color, rast, pos, tri), /root/reference/model/render/render.py:264-267.
+ *   a3d_aa_topology : once per mesh topology: opp[F,3] = vertex opposite edge i in the adjacent triangle, -1 on
+ *                     a boundary (nvdiffrast's topology hash).  hash = scratch of a3d_aa_hash_bytes(F) bytes.
+ *   a3d_aa_analyze  : once per (rast, clip): finds every silhouette crossing between adjacent pixels; work =
+ *                     scratch of capacity*16 bytes (capacity = 2*B*H*W is always enough), count[1] zeroed by callee.
+ *   a3d_aa_fwd      : out = color, then blends across each recorded crossing; any number of colour buffers can
+ *                     share one analysis (the reference re-analyses per buffer, render.py:311-315).
+ *   a3d_aa_bwd      : g_color[B,H,W,C] and g_clip[clip_batch,V,4] (both fully written / zeroed by callee).
+ */
+size_t a3d_aa_hash_bytes(int F);
+int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
+int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
+                   int F, int H, int W, void* work, int capacity, int32_t* count, a3d_stream_t stream);
+int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
+               a3d_stream_t stream);
+int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,
+               const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_color,
+               float* g_clip, a3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A3D_H */

@@ -1,0 +1,48 @@
+"""Oracle-side checker for one SyntheticScene step (used by __graft_entry__.smoke() and tests).  TEST INFRASTRUCTURE ONLY.
+
+Recomputes, on CPU with the oracle, every stage of the step the HIP path just ran -- from the very same SDF values,
+bones, angles, cameras and network weights -- and reports the largest deviations.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import dmtet_ref, mesh_ref, render_ref, skinning_ref
+
+
+def compare_step(scene, out):
+    geo = scene.netShape
+    cpu = lambda t: t.detach().float().cpu()
+    pos, sdf, tets = cpu(geo.current_pos), cpu(geo.current_sdf).reshape(-1), geo.indices.cpu()
+    verts, faces, _, uv_idx = dmtet_ref.marching_tets(pos, sdf, tets)
+    prior, shape = scene.last["prior"], scene.last["shape"]
+    rep = {}
+    rep["faces_equal"] = bool(np.array_equal(faces.numpy(), prior.t_pos_idx[0].cpu().numpy())
+                              and np.array_equal(uv_idx.numpy(), prior.t_tex_idx[0].cpu().numpy()))
+    rep["num_verts"], rep["num_faces"] = int(verts.shape[0]), int(faces.shape[0])
+    if not rep["faces_equal"]:
+        rep["max_abs_image_err"] = float("inf")
+        rep["loss"] = float(out["loss"])
+        return rep
+    rep["max_abs_vert_err"] = float((verts - cpu(prior.v_pos[0])).abs().max())
+    nrm = mesh_ref.vertex_normals(verts[None], faces)
+    rep["max_abs_prior_normal_err"] = float((nrm - cpu(prior.v_nrm)).abs().max())
+    bones, arti = cpu(scene.bones), cpu(scene.arti)
+    sk, _ = skinning_ref.skinning(verts[None, None], bones, scene.kinematic_tree, arti, scene.temperature)
+    sk = sk.view(scene.batch, -1, 3)
+    rep["max_abs_skin_err"] = float((sk - cpu(shape.v_pos)).abs().max())
+    snrm = mesh_ref.vertex_normals(sk, faces)
+    rep["max_abs_posed_normal_err"] = float((snrm - cpu(shape.v_nrm)).abs().max())
+    tex, dino, lgt = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))
+    with torch.no_grad():
+        shaded, dino_pred = render_ref.render_mesh(sk, faces, snrm, cpu(scene.mvp), cpu(scene.w2c), cpu(scene.campos), tex, lgt, scene.resolution,
+                                                   background=cpu(scene.background), feat=cpu(scene.feat), render_modes=("shaded", "dino_pred"),
+                                                   prior_v_pos=verts[None], dino_net=dino)
+    e1 = (shaded - cpu(out["shaded"])).abs()
+    e2 = (dino_pred - cpu(out["dino_pred"])).abs()
+    rep["max_abs_image_err"] = float(max(e1.max(), e2.max()))
+    rep["frac_pixels_gt_1e-4"] = float(((e1.amax(1) > 1e-4) | (e2.amax(1) > 1e-4)).float().mean())
+    rep["coverage"] = float((shaded[:, 3] > 0).float().mean())
+    rep["loss"] = float(out["loss"])
+    return rep

@@ -1,0 +1,427 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Bars: index buffers and triangle ids bit-exact; floating point within the tolerance written at each assert
+(north_star: rendered buffers within 1e-4 absolute).
+"""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden, kuhn, seeded
+
+pytestmark = pytest.mark.gpu
+
+DMTET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dmtet_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return importlib.import_module("3danimals_amd.ops")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    m = lambda n: importlib.import_module("3danimals_amd." + n)
+    return dict(dmtet=m("model.geometry.dmtet"), skinning=m("model.geometry.skinning"), mesh=m("model.render.mesh"),
+                render=m("model.render.render"), light=m("model.render.light"), nets=m("hostnets"), synthetic=m("synthetic"))
+
+
+def quadruped_mesh(res=16, leg_radius=0.3):
+    from oracle import dmtet_ref
+
+    synthetic = importlib.import_module("3danimals_amd.synthetic")
+    pos, tets = kuhn(res)
+    verts, faces, _, _ = dmtet_ref.marching_tets(pos, synthetic.quadruped_sdf(pos, leg_radius=leg_radius), tets)
+    return verts, faces
+
+
+# ------------------------------------------------------------------------------------------------ DMTet
+@pytest.mark.parametrize("name", DMTET_CASES)
+def test_dmtet_matches_reference_golden(name, dev, mods):
+    g = golden(name)
+    pos, tets = kuhn(int(g["res"]))
+    sdf = torch.from_numpy(g["sdf"]).to(dev).requires_grad_(True)
+    dm = mods["dmtet"].DMTet()
+    verts, faces, uvs, uv_idx = dm(pos.to(dev), sdf[:, None], tets.to(dev))
+    assert faces.dtype == torch.int64 and uv_idx.dtype == torch.int64
+    assert np.array_equal(faces.cpu().numpy(), g["faces"])  # bit-exact
+    assert np.array_equal(uv_idx.cpu().numpy(), g["uv_idx"])
+    assert np.array_equal(verts.detach().cpu().numpy(), g["verts"])  # same rounding sequence as the reference
+    assert tuple(uvs.shape) == tuple(g["uvs_shape"])
+    assert np.array_equal(uvs[:64].cpu().numpy(), g["uvs_head"]) and np.array_equal(uvs[-64:].cpu().numpy(), g["uvs_tail"])
+    if verts.numel():
+        wgt = seeded(verts.shape, int(g["grad_wgt_seed"]), -1, 1).to(dev)
+        (gs,) = torch.autograd.grad((verts * wgt).sum(), sdf)
+        np.testing.assert_allclose(gs.cpu().numpy(), g["grad_sdf"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("res,kind", [(24, "random"), (32, "quadruped"), (64, "quadruped")])
+def test_dmtet_matches_oracle_larger(res, kind, dev, mods):
+    from oracle import dmtet_ref
+
+    pos, tets = kuhn(res)
+    g = torch.Generator().manual_seed(res)
+    sdf = torch.randn(pos.shape[0], generator=g) if kind == "random" else mods["synthetic"].quadruped_sdf(pos, 0.2, noise=0.01, seed=res)
+    rv, rf, _, ru = dmtet_ref.marching_tets(pos, sdf, tets)
+    sdf_d = sdf.to(dev).requires_grad_(True)
+    pos_d = pos.to(dev).requires_grad_(True)
+    verts, faces, _, uv_idx = mods["dmtet"].DMTet()(pos_d, sdf_d, tets.to(dev))
+    assert np.array_equal(faces.cpu().numpy(), rf.numpy()) and np.array_equal(uv_idx.cpu().numpy(), ru.numpy())
+    assert np.array_equal(verts.detach().cpu().numpy(), rv.numpy())
+    # gradients w.r.t. sdf AND pos against autograd through the oracle
+    sdf_c, pos_c = sdf.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    rv2, _, _, _ = dmtet_ref.marching_tets(pos_c, sdf_c, tets)
+    wgt = seeded(rv.shape, 5, -1, 1)
+    gs_ref, gp_ref = torch.autograd.grad((rv2 * wgt).sum(), [sdf_c, pos_c])
+    gs, gp = torch.autograd.grad((verts * wgt.to(dev)).sum(), [sdf_d, pos_d])
+    np.testing.assert_allclose(gs.cpu().numpy(), gs_ref.numpy(), rtol=2e-4, atol=2e-4 * float(gs_ref.abs().max()))
+    np.testing.assert_allclose(gp.cpu().numpy(), gp_ref.numpy(), rtol=2e-4, atol=1e-5)
+
+
+def test_dmtet_full_size_properties(dev, mods):
+    """BASELINE-size grid (Kuhn R=64): size-independent invariants + run-to-run determinism."""
+    pos, tets = kuhn(64)
+    sdf = mods["synthetic"].quadruped_sdf(pos, 0.2, noise=0.01, seed=1).to(dev)
+    dm = mods["dmtet"].DMTet()
+    pos_d, tets_d = pos.to(dev), tets.to(dev)
+    v1, f1, _, u1 = dm(pos_d, sdf, tets_d)
+    v2, f2, _, u2 = dm(pos_d, sdf, tets_d)
+    assert torch.equal(v1, v2) and torch.equal(f1, f2) and torch.equal(u1, u2)
+    V, F = v1.shape[0], f1.shape[0]
+    assert F > 10000 and int(f1.min()) == 0 and int(f1.max()) == V - 1
+    assert len(torch.unique(f1)) == V  # every vertex referenced
+    # closed 2-manifold: each undirected edge shared by exactly two faces, traversed once in each direction
+    e = torch.cat([f1[:, [0, 1]], f1[:, [1, 2]], f1[:, [2, 0]]], 0)
+    key = e[:, 0] * V + e[:, 1]
+    assert len(torch.unique(key)) == key.numel()  # no directed edge twice -> consistent winding
+    und = torch.minimum(e[:, 0], e[:, 1]) * V + torch.maximum(e[:, 0], e[:, 1])
+    _, cnt = torch.unique(und, return_counts=True)
+    assert bool((cnt == 2).all())
+    # uv_idx rows: (4t, 4t+k+1, 4t+k+2)
+    assert bool(((u1[:, 0] % 4) == 0).all()) and bool(((u1[:, 2] - u1[:, 1]) == 1).all())
+    # vertices sit strictly inside the grid's bounding box
+    assert float(v1.abs().max()) <= 3.5
+
+
+# ------------------------------------------------------------------------------------------------ normals / mesh
+@pytest.mark.parametrize("B", [1, 4])
+def test_normals_match_reference_golden(B, dev, mods):
+    g = golden(f"mesh_b{B}.npz")
+    v = torch.from_numpy(g["v_pos"]).to(dev).requires_grad_(True)
+    faces, uv_idx = torch.from_numpy(g["faces"]).to(dev), torch.from_numpy(g["uv_idx"]).to(dev)
+    uvs = mods["dmtet"].TetGridTopology(kuhn(8)[1].to(dev)).uvs()
+    m = mods["mesh"].make_mesh(v, faces[None], uvs[None].expand(B, -1, -1), uv_idx[None], None)
+    np.testing.assert_allclose(m.v_nrm.detach().cpu().numpy(), g["v_nrm"], atol=2e-6)
+    np.testing.assert_allclose(m.v_tng.detach().cpu().numpy(), g["v_tng"], atol=5e-5)  # lazy torch path
+    wgt = seeded(m.v_nrm.shape, int(g["grad_wgt_seed"]), -1, 1).to(dev)
+    (gv,) = torch.autograd.grad((m.v_nrm * wgt).sum(), v)
+    np.testing.assert_allclose(gv.cpu().numpy(), g["grad_v"], rtol=1e-3, atol=2e-5)
+
+
+def test_normals_isolated_vertex_and_empty(dev, ops):
+    g = golden("mesh_isolated.npz")
+    nrm = ops.vertex_normals(torch.from_numpy(g["v_pos"]).to(dev), torch.from_numpy(g["faces"]).to(dev))
+    np.testing.assert_allclose(nrm.cpu().numpy(), g["v_nrm"], atol=2e-6)
+    assert np.array_equal(nrm[0, -1].cpu().numpy(), [0.0, 0.0, 1.0])
+    none = ops.vertex_normals(torch.rand(2, 5, 3, device=dev), torch.zeros(0, 3, dtype=torch.int64, device=dev))
+    assert np.array_equal(none.cpu().numpy(), np.tile([0.0, 0.0, 1.0], (2, 5, 1)))
+
+
+# ------------------------------------------------------------------------------------------------ skinning
+@pytest.mark.parametrize("tag", ["b1f1_t1", "b3f2_t005", "b2f2_inst"])
+def test_skinning_matches_reference_golden(tag, dev, mods):
+    g = golden(f"skinning_{tag}.npz")
+    chain = eval(str(g["chain"]))
+    v = torch.from_numpy(g["v_in"]).to(dev).requires_grad_(True)
+    ang = torch.from_numpy(g["angles"]).to(dev).requires_grad_(True)
+    out, aux = mods["skinning"].skinning(v, torch.from_numpy(g["bones"]).to(dev), chain, ang, output_posed_bones=True,
+                                         temperature=float(g["temperature"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], atol=5e-6)
+    np.testing.assert_allclose(aux["posed_bones"].detach().cpu().numpy(), g["posed_bones"], atol=5e-6)
+    w = aux["vertices_to_bones"]
+    assert tuple(w.shape) == tuple(g["weights"].shape)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], atol=2e-6)
+    wgt, wgt_b = seeded(out.shape, 77, -1, 1).to(dev), seeded(aux["posed_bones"].shape, 78, -1, 1).to(dev)
+    gv, ga = torch.autograd.grad((out * wgt).sum() + (aux["posed_bones"] * wgt_b).sum(), [v, ang])
+    np.testing.assert_allclose(gv.cpu().numpy(), g["grad_v"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(ga.cpu().numpy(), g["grad_angles"], rtol=1e-3, atol=1e-3)
+
+
+def test_skinning_identity_and_oracle_larger(dev, mods):
+    from oracle import skinning_ref
+
+    verts, _ = quadruped_mesh(24, 0.25)
+    sk = mods["skinning"]
+    bones, tree, _ = sk.estimate_bones(verts[None, None], n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")
+    B = 5
+    zero = torch.zeros(B, 1, 20, 3, device=dev)
+    out, _ = sk.skinning(verts[None, None].to(dev), bones.to(dev), tree, zero, temperature=0.05)
+    np.testing.assert_allclose(out.cpu().numpy(), verts[None, None].expand(B, 1, -1, -1).numpy(), atol=2e-6)  # zero angles -> identity
+    ang = seeded((B, 1, 20, 3), 9, -0.6, 0.6)
+    ref, _ = skinning_ref.skinning(verts[None, None], bones, tree, ang, 0.05)
+    out, _ = sk.skinning(verts[None, None].to(dev), bones.to(dev), tree, ang.to(dev), temperature=0.05)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ rasterise
+def _scene(B, res=16, seed=1):
+    from oracle import render_ref
+
+    synthetic = importlib.import_module("3danimals_amd.synthetic")
+    verts, faces = quadruped_mesh(res, 0.3)
+    mvp, w2c, campos = synthetic.random_cameras(B, seed=seed)
+    clip = render_ref.xfm_points(verts[None].expand(B, -1, -1), mvp)
+    return verts, faces, clip.contiguous(), (mvp, w2c, campos)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 64), (2, 50, 70), (4, 256, 256), (16, 256, 256)])
+def test_rasterize_bit_exact_vs_oracle(B, H, W, dev, ops):
+    """All three tile configurations (16x16, 32x32, 64x64 tiles) incl. a resolution that is no tile multiple."""
+    from oracle import raster_ref
+
+    _, faces, clip, _ = _scene(B)
+    ref = raster_ref.rasterize(clip, faces.int(), (H, W))
+    out = ops.rasterize(clip.to(dev), faces.to(dev), (H, W)).cpu()
+    assert np.array_equal(out[..., 3].numpy(), ref[..., 3].numpy())  # triangle ids bit-exact
+    assert np.array_equal(out.numpy(), ref.numpy())  # u, v, z/w: identical rounding sequence
+    assert float((out[..., 3] > 0).float().mean()) > 0.05
+
+
+def test_rasterize_edge_cases(dev, ops):
+    from oracle import raster_ref
+
+    H = W = 32
+    pos = torch.tensor([[[-1.5, -1.5, 0.2, 1.0], [1.5, -1.5, 0.2, 1.0], [0.0, 1.5, 0.2, 1.0],  # 0: covers most of the screen
+                         [-0.5, -0.5, -0.5, 1.0], [0.5, -0.5, -0.5, 1.0], [0.0, 0.5, -0.5, 1.0],  # 1: nearer, smaller
+                         [-0.2, -0.2, 0.0, -1.0], [0.2, -0.2, 0.0, -1.0], [0.0, 0.2, 0.0, -1.0],  # 2: behind the eye (all w<0)
+                         [-0.3, 0.1, 0.0, 1.0], [0.3, 0.1, 0.0, 1.0], [0.0, 0.1, 0.0, -0.5],  # 3: straddles w=0
+                         [0.1, 0.1, 0.0, 1.0], [0.1, 0.1, 0.0, 1.0], [0.1, 0.1, 0.0, 1.0],  # 4: degenerate
+                         [-0.5, -0.5, 2.0, 1.0], [0.5, -0.5, 2.0, 1.0], [0.0, 0.5, 2.0, 1.0]]])  # 5: beyond the far plane
+    tri = torch.arange(18, dtype=torch.int32).view(6, 3)
+    ref = raster_ref.rasterize(pos, tri, (H, W))
+    out = ops.rasterize(pos.to(dev), tri.to(dev), (H, W)).cpu()
+    assert np.array_equal(out.numpy(), ref.numpy())
+    ids = set(np.unique(out[..., 3].numpy()).astype(int))
+    assert {1, 2}.issubset(ids) and 3 not in ids and 5 not in ids and 6 not in ids
+    # exact barycentrics of a screen-aligned triangle at a known pixel: triangle 1, pixel centre (x=16.5,y=16.5)/32 -> ndc 0.03125
+    u, v = float(out[0, 16, 16, 0]), float(out[0, 16, 16, 1])
+    fx = fy = 0.03125
+    a0 = (0.5 - fx) * (0.5 - fy) - (-0.5 - fy) * (0.0 - fx)
+    a1 = (0.0 - fx) * (-0.5 - fy) - (0.5 - fy) * (-0.5 - fx)
+    a2 = (-0.5 - fx) * (-0.5 - fy) - (-0.5 - fy) * (0.5 - fx)
+    assert abs(u - a0 / (a0 + a1 + a2)) < 1e-6 and abs(v - a1 / (a0 + a1 + a2)) < 1e-6 and int(out[0, 16, 16, 3]) == 2
+    # empty mesh -> all zeros
+    empty = ops.rasterize(pos.to(dev), torch.zeros(0, 3, dtype=torch.int32, device=dev), (H, W))
+    assert float(empty.abs().max()) == 0.0
+
+
+def test_rasterize_watertight_and_deterministic(dev, ops):
+    """No pin-holes along shared edges of a closed mesh; identical output run to run (order-independent depth test)."""
+    from oracle import raster_ref
+
+    _, faces, clip, _ = _scene(4, res=24)
+    a = ops.rasterize(clip.to(dev), faces.to(dev), (256, 256))
+    b = ops.rasterize(clip.to(dev), faces.to(dev), (256, 256))
+    assert torch.equal(a, b)
+    cover = (a[..., 3] > 0).float()[:, None]
+    # a hole = uncovered pixel whose 4 neighbours are all covered
+    nb = torch.nn.functional.conv2d(cover, torch.tensor([[[[0, 1, 0], [1, 0, 1], [0, 1, 0.0]]]], device=dev), padding=1)
+    assert int(((cover == 0) & (nb == 4)).sum()) == 0
+
+
+def test_rasterize_backward_vs_oracle(dev, ops):
+    from oracle import raster_ref
+
+    _, faces, clip, _ = _scene(2)
+    H = W = 64
+    clip_d = clip.to(dev).requires_grad_(True)
+    rast = ops.rasterize(clip_d, faces.to(dev), (H, W))
+    wgt = seeded((2, H, W, 2), 3, -1, 1)
+    (g,) = torch.autograd.grad((rast[..., :2] * wgt.to(dev)).sum(), clip_d)
+    clip_c = clip.clone().requires_grad_(True)
+    uv = raster_ref.barycentrics(clip_c, faces.int(), rast.detach().cpu())
+    (g_ref,) = torch.autograd.grad((uv * wgt).sum(), clip_c)
+    scale = float(g_ref.abs().max())
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), rtol=1e-3, atol=2e-4 * scale)
+    assert float(g[..., 2].abs().max()) == 0.0  # z carries no gradient
+
+
+# ------------------------------------------------------------------------------------------------ interpolate
+@pytest.mark.parametrize("C,shared", [(3, False), (3, True), (2, False), (17, False)])
+def test_interpolate_fwd_bwd_vs_oracle(C, shared, dev, ops):
+    from oracle import raster_ref
+
+    B, H, W = 3, 64, 64
+    verts, faces, clip, _ = _scene(B)
+    rast = raster_ref.rasterize(clip, faces.int(), (H, W))
+    attr = seeded((1 if shared else B, verts.shape[0], C), 4, -1, 1)
+    a_c, r_c = attr.clone().requires_grad_(True), rast.clone().requires_grad_(True)
+    a_d, r_d = attr.to(dev).requires_grad_(True), rast.to(dev).requires_grad_(True)
+    ref = raster_ref.interpolate(a_c, r_c, faces.int())
+    out = ops.interpolate(a_d, r_d, faces.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-6)
+    wgt = seeded(ref.shape, 6, -1, 1)
+    ga_ref, gr_ref = torch.autograd.grad((ref * wgt).sum(), [a_c, r_c])
+    ga, gr = torch.autograd.grad((out * wgt.to(dev)).sum(), [a_d, r_d])
+    np.testing.assert_allclose(ga.cpu().numpy(), ga_ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gr.cpu().numpy()[..., :2], gr_ref.numpy()[..., :2], rtol=1e-4, atol=1e-5)
+    assert float(gr[..., 2:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ antialias
+def test_aa_topology_matches_oracle(dev, ops):
+    from oracle import raster_ref
+
+    _, faces = quadruped_mesh(16)
+    topo = ops.aa_topology(ops.tri_int32(faces.to(dev)), int(faces.max()) + 1)
+    assert np.array_equal(topo.opp.cpu().numpy(), raster_ref.edge_opposites(faces.numpy()))
+    # open mesh (drop some faces -> boundary edges), a degenerate face and a non-manifold fan
+    cut = torch.cat([faces[: len(faces) // 2], torch.tensor([[0, 0, 1], [0, 1, 2], [1, 0, 3], [0, 1, 4]])])
+    topo = ops.AATopology(cut.to(dev).int().contiguous(), int(cut.max()) + 1)
+    assert np.array_equal(topo.opp.cpu().numpy(), raster_ref.edge_opposites(cut.numpy()))
+
+
+@pytest.mark.parametrize("C", [4, 17])
+def test_antialias_fwd_bwd_vs_oracle(C, dev, ops):
+    from oracle import raster_ref
+
+    B, H, W = 2, 64, 64
+    _, faces, clip, _ = _scene(B)
+    rast = raster_ref.rasterize(clip, faces.int(), (H, W))
+    cover = (rast[..., 3:] > 0).float()
+    color = torch.lerp(seeded((B, H, W, C), 1, 0, 0.2), seeded((B, H, W, C), 2, 0.5, 1.0), cover)
+    c_c, p_c = color.clone().requires_grad_(True), clip.clone().requires_grad_(True)
+    ref = raster_ref.antialias(c_c, rast, p_c, faces.int())
+    c_d, p_d = color.to(dev).requires_grad_(True), clip.to(dev).requires_grad_(True)
+    out = ops.antialias(c_d, rast.to(dev), p_d, faces.to(dev))
+    assert float((ref - color).abs().max()) > 0.05  # the silhouette really was blended
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    wgt = seeded(ref.shape, 8, -1, 1)
+    gc_ref, gp_ref = torch.autograd.grad((ref * wgt).sum(), [c_c, p_c])
+    gc, gp = torch.autograd.grad((out * wgt.to(dev)).sum(), [c_d, p_d])
+    np.testing.assert_allclose(gc.cpu().numpy(), gc_ref.numpy(), atol=2e-6)
+    scale = float(gp_ref.abs().max())
+    assert scale > 0
+    np.testing.assert_allclose(gp.cpu().numpy(), gp_ref.numpy(), rtol=1e-3, atol=2e-4 * scale)
+
+
+def test_antialias_known_answer_vertical_edge(dev, ops):
+    """A surface covering x < k+0.3: pixel k (centre k+0.5, uncovered) takes 0.3 of its covered left neighbour."""
+    H = W = 16
+    k = 8
+    xe = (k + 0.3) / W * 2 - 1
+    pos = torch.tensor([[[-3.0, -3.0, 0.0, 1.0], [xe, -3.0, 0.0, 1.0], [xe, 3.0, 0.0, 1.0], [-3.0, 3.0, 0.0, 1.0]]])
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32)
+    rast = ops.rasterize(pos.to(dev), tri.to(dev), (H, W))
+    cover = (rast[..., 3:] > 0).float()
+    assert float(cover[0, 5, k - 1]) == 1.0 and float(cover[0, 5, k]) == 0.0
+    out = ops.antialias(cover.contiguous(), rast, pos.to(dev), tri.to(dev)).cpu()
+    np.testing.assert_allclose(out[0, 2:-2, k, 0].numpy(), 0.3, atol=1e-5)
+    np.testing.assert_allclose(out[0, 2:-2, k - 1, 0].numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(out[0, 2:-2, k + 1, 0].numpy(), 0.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ render_mesh end to end
+def _nets(mods, dev, feat_dim=16):
+    torch.manual_seed(0)
+    N, L = mods["nets"], mods["light"]
+    tex = N.CoordMLP(3, 9, 3, nf=32, activation="sigmoid", min_max=torch.tensor([[0.0, 1.0]] * 9), n_harmonic_functions=4, extra_feat_dim=feat_dim,
+                     symmetrize=True)
+    dino = N.CoordMLP(3, 16, 3, nf=32, activation="sigmoid", min_max=torch.tensor([[0.0, 1.0]] * 16), n_harmonic_functions=4)
+    lgt = L.DirectionalLight(feat_dim, 3, 32, intensity_min_max=torch.tensor([[0.0, 1.0], [0.5, 1.0]]))
+    return tex, dino, lgt
+
+
+@pytest.mark.parametrize("modes,with_nets", [(["shaded", "dino_pred"], True), (["geo_normal", "kd", "shading", "bogus", "normal", "depth"], True),
+                                             (["shaded"], False)])
+def test_render_mesh_matches_oracle(modes, with_nets, dev, mods):
+    import copy
+
+    from oracle import mesh_ref, render_ref
+
+    B, H, W = 2, 64, 64
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=3)
+    posed = verts[None] + 0.05 * seeded((B, *verts.shape), 11, -1, 1)
+    tex, dino, lgt = _nets(mods, dev)
+    feat = seeded((B, 16), 12, -1, 1)
+    bg = seeded((B, H, W, 3), 13, 0, 1)
+    nrm = mesh_ref.vertex_normals(posed, faces)
+    with torch.no_grad():
+        ref = render_ref.render_mesh(posed, faces, nrm, mvp, w2c, campos, tex if with_nets else None, lgt if with_nets else None, (H, W),
+                                     background=bg, feat=feat if with_nets else None, render_modes=modes, prior_v_pos=verts[None],
+                                     dino_net=dino if with_nets else None)
+    M = mods["mesh"]
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    shape = M.make_mesh(posed.to(dev), faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+    prior = M.make_mesh(verts[None].to(dev), faces[None].to(dev), uvs, uvi, None)
+    tex_d, dino_d, lgt_d = (copy.deepcopy(m).to(dev) for m in (tex, dino, lgt))
+    with torch.no_grad():
+        out = mods["render"].render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), tex_d if with_nets else None,
+                                         lgt_d if with_nets else None, (H, W), background=bg.to(dev), bsdf="diffuse",
+                                         feat=feat.to(dev) if with_nets else None, render_modes=modes, prior_mesh=prior,
+                                         dino_net=dino_d if with_nets else None)
+    assert len(out) == len(modes)
+    for m, o, r in zip(modes, out, ref):
+        if r is None:
+            assert o is None, m
+            continue
+        assert tuple(o.shape) == tuple(r.shape), m
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=1e-4, err_msg=m)  # north_star tolerance
+
+
+def test_render_mesh_flow_and_empty_mesh_assert(dev, mods):
+    from oracle import mesh_ref, render_ref
+
+    B, H, W = 4, 32, 32
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=5)
+    posed = verts[None] + 0.1 * seeded((B, *verts.shape), 21, -1, 1)
+    nrm = mesh_ref.vertex_normals(posed, faces)
+    ref = render_ref.render_mesh(posed, faces, nrm, mvp, w2c, campos, None, None, (H, W), render_modes=["shaded", "flow"], num_frames=2)
+    M = mods["mesh"]
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    shape = M.make_mesh(posed.to(dev), faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+    out = mods["render"].render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), bsdf="diffuse",
+                                     render_modes=["shaded", "flow"], num_frames=2)
+    for o, r in zip(out, ref):
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=1e-4)
+    empty = M.Mesh(posed.to(dev), torch.zeros(1, 0, 3, dtype=torch.int64, device=dev))
+    with pytest.raises(AssertionError, match="empty training triangle mesh"):
+        mods["render"].render_mesh(None, empty, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), render_modes=["shaded"])
+
+
+def test_full_step_against_oracle_and_grads_finite(dev):
+    """One fwd+bwd step of the synthetic training scene; every stage re-done by the oracle from the same numbers."""
+    from oracle import check
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    scene = pipeline.SyntheticScene(grid_res=16, batch=3, resolution=(64, 64), device=dev, seed=0, net_width=32, net_layers=3, feat_dim=16,
+                                    embedder_freq=4)
+    out = scene.step(backward=True, optimizer_step=False)
+    rep = check.compare_step(scene, out)
+    assert rep["faces_equal"], rep
+    assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 1e-5 and rep["max_abs_posed_normal_err"] < 1e-4, rep
+    assert rep["max_abs_image_err"] < 1e-4, rep
+    assert 0.02 < rep["coverage"] < 0.9, rep
+    for name, leaf in [("mvp", scene.mvp), ("campos", scene.campos), ("feat", scene.feat), ("arti", scene.arti)]:
+        assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().max()) > 0, name
+    for n, p in scene.named_parameters():  # DDP runs with find_unused_parameters=False: every parameter must get a gradient
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    A3DError = importlib.import_module("3danimals_amd._lib").A3DError
+    with pytest.raises(A3DError, match="no CPU fallback"):
+        ops.vertex_normals(torch.rand(1, 4, 3), torch.zeros(1, 3, dtype=torch.int64))

@@ -1,0 +1,296 @@
+"""CPU tests: ABI surface, host logic of the mirror modules (torch, any device), oracle known-answer tests."""
+import ctypes
+import importlib
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, kuhn, seeded
+from oracle import dmtet_ref, mesh_ref, raster_ref, skinning_ref
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "a3d.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 19
+    L = importlib.import_module("3danimals_amd._lib")
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.a3d_version() == 100
+    assert isinstance(lib.a3d_last_error(), bytes)
+    assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
+    assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    L = importlib.import_module("3danimals_amd._lib")
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/liba3d_hip.so")
+    with pytest.raises(L.A3DError, match="no CPU fallback"):
+        L.lib()
+
+
+def test_ops_refuse_cpu_tensors():
+    ops = importlib.import_module("3danimals_amd.ops")
+    A3DError = importlib.import_module("3danimals_amd._lib").A3DError
+    with pytest.raises(A3DError, match="no CPU fallback"):
+        ops.rasterize(torch.rand(1, 3, 4), torch.zeros(1, 3, dtype=torch.int32), (8, 8))
+    with pytest.raises(A3DError, match="no CPU fallback"):
+        ops.skin(torch.rand(1, 4, 3), torch.rand(1, 2, 2, 3), torch.rand(1, 2, 12), 1.0)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "3danimals_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "/root/reference" in re.sub(r'""".*?"""', "", src, flags=re.S).replace("#", "\n#").split("\n#")[0]:
+                    bad.append(f)
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ tet grids
+@pytest.mark.parametrize("res", [4, 8, 32])
+def test_kuhn_grid_counts_and_topology(res, a3d):
+    v, t = a3d.tetgrid.kuhn_grid(res)
+    assert v.shape == ((res + 1) ** 3, 3) and t.shape == (6 * res**3, 4)
+    edges, t2e = a3d.tetgrid.build_topology(t)
+    assert edges.shape[0] == 3 * res * (res + 1) ** 2 + 3 * res**2 * (res + 1) + res**3
+    assert np.all(edges[:, 0] < edges[:, 1])
+    key = edges[:, 0].astype(np.int64) * v.shape[0] + edges[:, 1]
+    assert np.all(np.diff(key) > 0)  # lexicographically sorted, unique
+    pairs = t[:, a3d.tetgrid.TET_EDGE_SLOTS]
+    assert np.array_equal(edges[t2e], np.stack([pairs.min(-1), pairs.max(-1)], -1))
+    p = v[t]
+    vol = np.einsum("ti,ti->t", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
+    assert np.all(vol < 0) and abs(abs(vol).sum() / 6 - 1.0) < 1e-5  # one orientation, tiles the unit cube
+
+
+def test_tets_npz_roundtrip_reference_format(tmp_path, a3d):
+    v, t = a3d.tetgrid.kuhn_grid(4)
+    p = str(tmp_path / "8_tets.npz")
+    a3d.tetgrid.save_tets_npz(p, v, t)
+    z = np.load(p)
+    assert set(z.files) == {"vertices", "indices"}  # reference data/tets/generate_tets.py:47
+    v2, t2 = a3d.tetgrid.load_tets_npz(p)
+    assert np.array_equal(v, v2) and np.array_equal(t, t2)
+
+
+def test_grid_topology_torch_equals_numpy(a3d):
+    dm = importlib.import_module("3danimals_amd.model.geometry.dmtet")
+    _, t = a3d.tetgrid.kuhn_grid(6)
+    topo = dm.TetGridTopology(torch.from_numpy(t))
+    edges, t2e = a3d.tetgrid.build_topology(t)
+    assert np.array_equal(topo.edges32.numpy(), edges) and np.array_equal(topo.tet2edge32.numpy(), t2e)
+    uvs_ref, _ = dmtet_ref.uv_atlas(t.shape[0])
+    assert torch.equal(topo.uvs(), uvs_ref)
+
+
+# ------------------------------------------------------------------------------------------------ oracle known answers
+def test_dmtet_table_symmetry_and_plane():
+    # complementary cases use the same edges with opposite winding (dmtet.py:26-43)
+    T, N = dmtet_ref.TRIANGLE_TABLE, dmtet_ref.NUM_TRIANGLES
+    for c in range(16):
+        assert N[c] == N[15 - c]
+        assert set(T[c][T[c] >= 0]) == set(T[15 - c][T[15 - c] >= 0])
+    # exact plane SDF: every vertex on the plane, face count closed-form for an axis-aligned cut between grid layers
+    pos, tets = kuhn(4, scale=1.0)
+    sdf = 0.1 - pos[:, 2]
+    verts, faces, _, _ = dmtet_ref.marching_tets(pos, sdf, tets)
+    assert torch.allclose(verts[:, 2], torch.full_like(verts[:, 2], 0.1), atol=1e-6)
+    assert faces.shape[0] > 0
+    area = torch.cross(verts[faces[:, 1]] - verts[faces[:, 0]], verts[faces[:, 2]] - verts[faces[:, 0]], dim=-1).norm(dim=-1).sum() / 2
+    assert abs(float(area) - 1.0) < 1e-5  # the plane section of the unit cube
+
+
+def test_oracle_rasterizer_known_answers():
+    H = W = 8
+    pos = torch.tensor([[[-1.0, -1.0, 0.5, 1.0], [1.0, -1.0, 0.5, 1.0], [-1.0, 1.0, 0.5, 1.0], [1.0, 1.0, 0.5, 1.0]]])
+    tri = torch.tensor([[0, 1, 2], [2, 1, 3]], dtype=torch.int32)
+    rast = raster_ref.rasterize(pos, tri, (H, W))
+    assert float((rast[..., 3] > 0).float().mean()) == 1.0  # two triangles tile the screen, no gap on the shared diagonal
+    ids = rast[0, :, :, 3]
+    assert set(np.unique(ids.numpy())) == {1.0, 2.0}
+    assert torch.allclose(rast[..., 2], torch.full_like(rast[..., 2], 0.5))
+    # barycentrics of pixel (0,0): centre ndc (-0.875,-0.875) inside triangle 0: u weights v0
+    u, v = float(rast[0, 0, 0, 0]), float(rast[0, 0, 0, 1])
+    assert abs(u - 0.875) < 1e-6 and abs(v - 0.0625) < 1e-6
+    # row 0 is y=-1 (OpenGL bottom-up)
+    low = torch.tensor([[[-1.0, -1.0, 0.0, 1.0], [1.0, -1.0, 0.0, 1.0], [0.0, -0.5, 0.0, 1.0]]])
+    r2 = raster_ref.rasterize(low, torch.tensor([[0, 1, 2]], dtype=torch.int32), (H, W))
+    assert float(r2[0, 0, :, 3].sum()) > 0 and float(r2[0, -1, :, 3].sum()) == 0
+    # nearer triangle wins; equal depth -> lower id
+    two = torch.cat([pos[:, :3], pos[:, :3] * torch.tensor([1, 1, 0.2, 1.0])], 1)
+    r3 = raster_ref.rasterize(two, torch.tensor([[0, 1, 2], [3, 4, 5]], dtype=torch.int32), (H, W))
+    assert set(np.unique(r3[..., 3].numpy())) == {0.0, 2.0}
+    same = torch.cat([pos[:, :3], pos[:, :3]], 1)
+    r4 = raster_ref.rasterize(same, torch.tensor([[3, 4, 5], [0, 1, 2]], dtype=torch.int32), (H, W))
+    assert set(np.unique(r4[..., 3].numpy())) == {0.0, 1.0}
+
+
+def test_oracle_antialias_known_answer():
+    H = W = 16
+    k = 8
+    xe = (k + 0.3) / W * 2 - 1
+    pos = torch.tensor([[[-3.0, -3.0, 0.0, 1.0], [xe, -3.0, 0.0, 1.0], [xe, 3.0, 0.0, 1.0], [-3.0, 3.0, 0.0, 1.0]]], requires_grad=True)
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32)
+    rast = raster_ref.rasterize(pos, tri, (H, W))
+    cover = (rast[..., 3:] > 0).float()
+    out = raster_ref.antialias(cover, rast, pos, tri)
+    np.testing.assert_allclose(out[0, 2:-2, k, 0].detach().numpy(), 0.3, atol=1e-5)
+    np.testing.assert_allclose(out[0, 2:-2, k - 1, 0].detach().numpy(), 1.0, atol=1e-6)
+    # moving the edge right by d(ndc) raises the blended coverage by d * W/2 per row
+    (g,) = torch.autograd.grad(out[0, 4, k, 0], pos)
+    assert abs(float(g[0, 1, 0] + g[0, 2, 0]) - W / 2) < 1e-3
+    # interior id changes (the shared diagonal) are not silhouettes: nothing else moves
+    assert float((out - cover).abs()[0, :, : k - 1].max()) == 0.0
+
+
+def test_oracle_edge_opposites_closed_and_open():
+    tri = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]])  # tetrahedron surface
+    opp = raster_ref.edge_opposites(tri)
+    assert (opp >= 0).all()
+    assert opp[0, 0] == 3  # edge (1,2) of face 0 -> face [1,3,2] -> opposite vertex 3
+    assert (raster_ref.edge_opposites(tri[:1]) == -1).all()
+
+
+# ------------------------------------------------------------------------------------------------ host logic (torch, CPU)
+def _chain_equal(a, b):
+    return repr(a) == repr(b)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", dict(attach_legs_to_body=True)), ("noattach", dict(attach_legs_to_body=False)),
+                                    ("fixed", dict(attach_legs_to_body=True, legs_to_body_joint_indices=[2, 7, 7, 2])),
+                                    ("fauna", dict(attach_legs_to_body=True, bone_y_threshold=0.4))])
+def test_estimate_bones_matches_reference_golden(tag, kw):
+    sk = importlib.import_module("3danimals_amd.model.geometry.skinning")
+    g = golden("bones_quadruped_r16.npz")
+    shape = torch.from_numpy(g["verts"])[None, None]
+    bones, chain, aux = sk.estimate_bones(shape.clone(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+",
+                                          compute_kinematic_chain=True, **kw)
+    np.testing.assert_allclose(bones.numpy(), g[f"{tag}_bones"], atol=1e-6)
+    assert repr(chain) == str(g[f"{tag}_chain"])
+    assert np.array_equal(np.array(aux["bones_to_joints"]), g[f"{tag}_bones_to_joints"])
+    assert [l["body_bone_idx"] for l in aux["legs"]] == list(g[f"{tag}_leg_body_idx"])
+    kw2 = {k: v for k, v in kw.items() if k != "attach_legs_to_body"}
+    cached = sk.estimate_bones(shape.clone() + 0.01, n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+",
+                               compute_kinematic_chain=False, aux=aux, **kw2)
+    np.testing.assert_allclose(cached.numpy(), g[f"{tag}_bones_cached"], atol=1e-6)
+
+
+def test_estimate_bones_no_legs_and_empty_quadrant():
+    sk = importlib.import_module("3danimals_amd.model.geometry.skinning")
+    g = golden("bones_quadruped_r16.npz")
+    shape = torch.from_numpy(g["verts"])[None, None]
+    bones, chain, _ = sk.estimate_bones(shape.clone(), n_body_bones=4, n_legs=4, n_leg_bones=0, body_bones_mode="z_minmax")
+    np.testing.assert_allclose(bones.numpy(), g["nolegs_bones"], atol=1e-6)
+    assert repr(chain) == str(g["nolegs_chain"])
+    half = shape[:, :, shape[0, 0, :, 0] > 0.0]  # no vertex on the -x side
+    with pytest.raises(RuntimeError, match="leg quadrant"):
+        sk.estimate_bones(half, n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")
+
+
+@pytest.mark.parametrize("tag", ["b1f1_t1", "b3f2_t005", "b2f2_inst"])
+def test_bone_transforms_and_posed_bones_match_reference(tag):
+    """The level-batched chain composition (torch, differentiable) against the reference's link-by-link loop."""
+    sk = importlib.import_module("3danimals_amd.model.geometry.skinning")
+    g = golden(f"skinning_{tag}.npz")
+    chain = eval(str(g["chain"]))
+    bones = torch.from_numpy(g["bones"])
+    ang = torch.from_numpy(g["angles"]).requires_grad_(True)
+    M = sk.bone_transforms(bones, chain, ang)
+    ref = skinning_ref.bone_transforms(bones, chain, ang.detach())
+    for k in range(20):
+        np.testing.assert_allclose(M[:, k].detach().numpy(), ref[k].expand(M.shape[0], 4, 4).numpy(), atol=2e-6)
+    B, Fr = ang.shape[:2]
+    ends = bones.expand(B, Fr, 20, 2, 3).reshape(B * Fr, 20, 2, 3)
+    posed = (torch.einsum("nkij,nkej->nkei", M[:, :, :3, :3], ends) + M[:, :, None, :3, 3]).view(B, Fr, 20, 2, 3)
+    np.testing.assert_allclose(posed.detach().numpy(), g["posed_bones"], atol=5e-6)
+    # zero angles -> identity transforms
+    M0 = sk.bone_transforms(bones, chain, torch.zeros_like(ang))
+    np.testing.assert_allclose(M0.numpy(), np.broadcast_to(np.eye(4, dtype=np.float32), M0.shape), atol=1e-6)
+
+
+def test_euler_and_rigid_helpers_match_reference():
+    sk = importlib.import_module("3danimals_amd.model.geometry.skinning")
+    g = golden("xfm.npz")
+    np.testing.assert_allclose(sk.euler_angles_to_matrix(torch.from_numpy(g["euler"]), "XYZ").numpy(), g["euler_mat"], atol=1e-6)
+    with pytest.raises(ValueError):
+        sk.euler_angles_to_matrix(torch.zeros(2, 3), "XXY")
+    R = sk.euler_angles_to_matrix(torch.from_numpy(g["euler"]), "ZYX")
+    m = sk._prepare_transform_mtx(rotation=R, translation=torch.ones(5, 3))
+    eye = sk._invert_transform_mtx(m) @ m
+    np.testing.assert_allclose(eye.numpy(), np.broadcast_to(np.eye(4, dtype=np.float32), eye.shape), atol=1e-6)
+
+
+def test_render_helpers_match_reference_golden():
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+    util = importlib.import_module("3danimals_amd.model.render.util")
+    gu = importlib.import_module("3danimals_amd.model.geometry.util")
+    g = golden("xfm.npz")
+    np.testing.assert_allclose(ru.xfm_points(torch.from_numpy(g["pts"]), torch.from_numpy(g["mvp"])).numpy(), g["clip"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(util.perspective(25 / 180 * np.pi, 1, 0.1, 1000.0).numpy(), g["proj"], rtol=1e-6)
+    gs = golden("skinning_b1f1_t1.npz")
+    bones, v = torch.from_numpy(gs["bones"]), torch.from_numpy(gs["v_in"])
+    d = torch.stack([gu.line_segment_distance(bones[:, :, k, 0], bones[:, :, k, 1], v) for k in range(20)])
+    np.testing.assert_allclose(torch.softmax(-d / 1.0, 0).numpy(), gs["weights"], atol=1e-6)
+
+
+def test_shade_product_matches_reference_golden_on_cpu():
+    """render.shade is plain torch around the caller's MLPs -> runs on CPU; pinned against the imported reference."""
+    render = importlib.import_module("3danimals_amd.model.render.render")
+    from test_oracle_golden import _load_nets
+
+    g = golden("shade.npz")
+    tex, dino, lgt = _load_nets(None, g)
+    gb = {k: torch.from_numpy(g[f"gb_{k}"]) for k in ("pos", "geo", "nrm", "tng", "tex")}
+    feat, w2c, campos = (torch.from_numpy(g[k]) for k in ("feat", "w2c", "campos"))
+    modes = ["shaded", "dino_pred", "kd", "normal", "geo_normal", "shading", "depth"]
+    with torch.no_grad():
+        buf = render.shade(gb["pos"], gb["geo"], gb["nrm"], gb["tng"], gb["tex"], w2c, campos[:, None, None, :], lgt, tex, "diffuse", feat=feat,
+                           render_modes=modes, two_sided_shading=True, dino_net=dino)
+    for m in modes:
+        np.testing.assert_allclose(buf[m].numpy(), g[f"out_{m}"], atol=2e-6, err_msg=m)
+
+
+def test_mesh_container_api(a3d):
+    M = importlib.import_module("3danimals_amd.model.render.mesh")
+    v = torch.rand(2, 5, 3)
+    f = torch.tensor([[[0, 1, 2], [2, 3, 4]]])
+    m = M.Mesh(v, f, v_nrm=torch.rand(2, 5, 3), t_nrm_idx=f, v_tex=torch.rand(2, 6, 2), t_tex_idx=f)
+    assert len(m) == 2 and m.v_tng is None
+    c = m.clone()
+    assert c.v_pos is not m.v_pos and torch.equal(c.v_pos, m.v_pos)
+    e = M.compute_edges(f)
+    assert e.shape == (6, 2) and bool((e[:, 0] < e[:, 1]).all())
+    assert M.compute_edge_to_face_mapping(f).shape == (6, 2)
+    lo, hi = M.aabb(M.Mesh(v[0]))
+    assert bool((lo <= hi).all())
+    with pytest.raises(AssertionError, match="share the same edge connectivity"):
+        M.make_mesh(v, f.repeat(2, 1, 1), torch.rand(2, 6, 2), f, None)
+
+
+def test_nvdiffrast_shim_surface():
+    shim = os.path.join(ROOT, "3danimals_amd", "shims")
+    sys.path.insert(0, shim)
+    try:
+        dr = importlib.import_module("nvdiffrast.torch")
+        ctx = dr.RasterizeGLContext()
+        assert isinstance(dr.RasterizeCudaContext(), type(ctx).__mro__[1])
+        for name in ("rasterize", "interpolate", "antialias", "DepthPeeler", "texture"):
+            assert hasattr(dr, name)
+        with pytest.raises(NotImplementedError):
+            dr.texture(None, None)
+        with pytest.raises(RuntimeError, match="num_vertices, 4"):
+            dr.rasterize(ctx, torch.rand(1, 3, 3), torch.zeros(1, 3, dtype=torch.int32), [8, 8])
+    finally:
+        sys.path.remove(shim)
