@@ -23,7 +23,8 @@ SIGNATURES = {
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p]),
     "a3d_normals_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_normals_bwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
@@ -58,9 +59,46 @@ def lib():
     return _lib
 
 
-def call(name: str, *args):
-    """Invoke an int-returning entry point and raise on a non-zero status."""
+class KernelTimer:
+    """Optional HIP-event timing of C-ABI entry points, on the stream they are launched on.
+
+    ``with KernelTimer() as t: ...`` brackets every ``call()`` with a pair of events recorded on the current torch
+    stream (the stream the kernels go to); ``t.summary()`` synchronises and returns name -> (launches, mean ms).
+    Used by bench.py for the live roofline figure; off (zero overhead) otherwise.
+    """
+
+    active = None
+
+    def __init__(self):
+        self.records = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
+def call(name: str, *args, tag: str = ""):
+    """Invoke an int-returning entry point and raise on a non-zero status (``tag`` only labels KernelTimer records)."""
+    timer = KernelTimer.active
+    if timer is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
     rc = getattr(lib(), name)(*args)
+    if timer is not None:
+        b.record()
+        timer.records.setdefault(name + tag, []).append((a, b))
     if rc != 0:
         raise A3DError(f"{name} failed ({rc}): {lib().a3d_last_error().decode()}")
 

@@ -1,25 +1,30 @@
-// Tiled rasteriser on gfx950: one workgroup owns a screen tile whose depth/id buffer lives in LDS.
+// Rasteriser on gfx950: triangle-parallel depth test with 64-bit atomics, then a pixel-parallel resolve.
 //
 // Replaces dr.DepthPeeler(...).rasterize_next_layer() / dr.rasterize (model/render/render.py:292-294, :351;
-// nvdiffrast, third party, goes through OpenGL).  The meshes on this path are marching-tets surfaces with
-// tens of thousands of 1-4 pixel triangles per 256x256 image, so the design is triangle-parallel inside a
-// pixel tile instead of pixel-parallel over per-tile bins:
-//   * workgroup = (image, tile); the tile's 64-bit (depth | triangle id) keys sit in LDS (64x64 px = 32 KiB);
-//   * every thread walks the triangle list with stride blockDim: sets up its triangle (3 x 16 B gathers that
-//     stay in the XCD's L2: blockIdx is laid out so all tiles of an image share an XCD), clips its pixel box to
-//     the tile and depth-tests the covered pixels with ds_min_u64 -- min over (z/w, id) is order independent,
-//     so the image is deterministic with no sorting and no global atomics;
-//   * triangles whose clipped box is large are detected with a wave ballot and rasterised cooperatively by
-//     all 64 lanes;
-//   * at the end the tile is resolved: winner's barycentrics recomputed and the float4 texels written as
-//     full, coalesced rows (64 px x 16 B = 1 KiB per row).
-// HBM traffic per image: 16 B/vertex + 12 B/face (read once per XCD, then L2) + 16 B/pixel written.
-// The per-fragment arithmetic mirrors oracle/raster_ref.c operation by operation; this TU is compiled with
-// -ffp-contract=off so that edge functions of a shared edge are exact negations (watertight) and ids match
-// the oracle bit for bit.
+// nvdiffrast, third party, goes through OpenGL).  The meshes on this path are marching-tets surfaces: tens of
+// thousands of triangles per 256x256 image whose pixel boxes hold ~10 candidates and ~2 covered pixels each.
+//
+//   clear   : keys[B,H,W] (u64) <- ~0                                              (hipMemsetAsync, 8 B/pixel)
+//   tri     : 4 lanes per (image, triangle): 12 B of indices + 3 x 16 B vertex gathers (L2 resident), the
+//             conservative pixel box, then the box's pixels are shared out over the 4 lanes; every covered pixel
+//             does atomicMin(keys[pixel], order(z/w) << 32 | id).  min over (depth, id) is order independent, so
+//             the image is deterministic with no sorting or binning, and the work is balanced over all 256 CUs
+//             no matter where on screen the object is.  A plain (possibly stale, hence only ever too large) read
+//             of the key skips atomics that cannot win.  Boxes above 64 px are found with a ballot and
+//             rasterised cooperatively by the whole wave.
+//   resolve : 1 thread per pixel: key -> winner's barycentrics recomputed -> float4 texel, fully coalesced.
+//
+// Two LDS-tile designs were measured first on the bench workload (B=16, F=11.5k, 256x256; rocprofv3):
+// workgroup-per-64x64-tile scanning all triangles 277 us; 32x32 tiles + per-triangle box pre-pass +
+// 4-lanes-per-survivor 108 us, of which 85 us was fragment work serialised in the quarter of the tiles the object
+// covers (4 waves each).  The triangle-parallel form removes that imbalance ("Rasteriser").
+// HBM traffic per image: 16 B/vertex + 12 B/face in, 16 B/pixel out, + 8 B/pixel of keys written, updated in L2
+// and read once.  The per-fragment arithmetic mirrors oracle/raster_ref.c operation by operation; this TU is
+// compiled with -ffp-contract=off so that the edge functions of a shared edge are exact negations (watertight)
+// and the triangle ids match the oracle bit for bit.
 #include "a3d_common.h"
 
-#define RS_SMALL_AREA 24  // clipped boxes up to this many pixels are walked by the owning lane alone
+#define RS_COOP_AREA 64  // boxes above this many pixels are rasterised by all 64 lanes of the wave
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 struct RsFrag {
@@ -27,6 +32,7 @@ struct RsFrag {
     bool hit;
 };
 
+// Fragment test; same operations in the same order as frag() in oracle/raster_ref.c (branch-light form).
 __device__ __forceinline__ RsFrag rs_frag(const float4 p0, const float4 p1, const float4 p2, float fx, float fy) {
     RsFrag r;
     r.u = 0.f; r.v = 0.f; r.zw = 0.f; r.hit = false;
@@ -37,33 +43,25 @@ __device__ __forceinline__ RsFrag rs_frag(const float4 p0, const float4 p1, cons
     const float a1 = q2x * q0y - q2y * q0x;
     const float a2 = q0x * q1y - q0y * q1x;
     const float s = (a0 + a1) + a2;
-    if (!(s != 0.f) || s != s) return r;
     const float sg = s > 0.f ? 1.f : -1.f;
-    // edge i is opposite vertex i and joins vertices (i+1, i+2)
-    {
-        const float e = a0 * sg;
-        if (!(e > 0.f)) {
-            if (e < 0.f || e != e) return r;
+    const float e0 = a0 * sg, e1 = a1 * sg, e2 = a2 * sg;
+    bool in = (s != 0.f) && (s == s) && (e0 >= 0.f) && (e1 >= 0.f) && (e2 >= 0.f);  // NaN fails every comparison
+    if (in && (e0 == 0.f || e1 == 0.f || e2 == 0.f)) {
+        // pixel centre exactly on an edge line (rare): the owner is decided by the sign of the line's normal
+        if (e0 == 0.f) {
             const float A = (p1.y * p2.w - p1.w * p2.y) * sg, B = (p1.w * p2.x - p1.x * p2.w) * sg;
-            if (!(A > 0.f || (A == 0.f && B > 0.f))) return r;
+            in = in && (A > 0.f || (A == 0.f && B > 0.f));
         }
-    }
-    {
-        const float e = a1 * sg;
-        if (!(e > 0.f)) {
-            if (e < 0.f || e != e) return r;
+        if (e1 == 0.f) {
             const float A = (p2.y * p0.w - p2.w * p0.y) * sg, B = (p2.w * p0.x - p2.x * p0.w) * sg;
-            if (!(A > 0.f || (A == 0.f && B > 0.f))) return r;
+            in = in && (A > 0.f || (A == 0.f && B > 0.f));
         }
-    }
-    {
-        const float e = a2 * sg;
-        if (!(e > 0.f)) {
-            if (e < 0.f || e != e) return r;
+        if (e2 == 0.f) {
             const float A = (p0.y * p1.w - p0.w * p1.y) * sg, B = (p0.w * p1.x - p0.x * p1.w) * sg;
-            if (!(A > 0.f || (A == 0.f && B > 0.f))) return r;
+            in = in && (A > 0.f || (A == 0.f && B > 0.f));
         }
     }
+    if (!in) return r;
     const float zn = (p0.z * a0 + p1.z * a1) + p2.z * a2;
     const float wn = (p0.w * a0 + p1.w * a1) + p2.w * a2;
     if (!(wn * sg > 0.f)) return r;
@@ -82,114 +80,101 @@ __device__ __forceinline__ unsigned rs_order(float f) {  // monotone float -> ui
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// conservative pixel box of a triangle with all w > 0, matching oracle/raster_ref.c; false if off screen
-__device__ __forceinline__ bool rs_bbox(const float4 p0, const float4 p1, const float4 p2, int W, int H, int& x0, int& y0, int& x1,
-                                        int& y1) {
-    const float sx0 = p0.x / p0.w, sx1 = p1.x / p1.w, sx2 = p2.x / p2.w;
-    const float sy0 = p0.y / p0.w, sy1 = p1.y / p1.w, sy2 = p2.y / p2.w;
-    const float mnx = fminf(sx0, fminf(sx1, sx2)), mxx = fmaxf(sx0, fmaxf(sx1, sx2));
-    const float mny = fminf(sy0, fminf(sy1, sy2)), mxy = fmaxf(sy0, fmaxf(sy1, sy2));
-    const float fx0 = (mnx + 1.f) * 0.5f * W - 1.5f, fx1 = (mxx + 1.f) * 0.5f * W + 0.5f;
-    const float fy0 = (mny + 1.f) * 0.5f * H - 1.5f, fy1 = (mxy + 1.f) * 0.5f * H + 0.5f;
-    if (!(fx1 >= 0.f) || !(fy1 >= 0.f) || !(fx0 <= (float)W) || !(fy0 <= (float)H)) return false;
-    x0 = fx0 < 0.f ? 0 : (int)fx0;
-    y0 = fy0 < 0.f ? 0 : (int)fy0;
-    x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
-    y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
-    return true;
+// conservative pixel box (same as oracle/raster_ref.c); returns the number of candidate pixels (0 = culled)
+__device__ __forceinline__ int rs_box(const float4 p0, const float4 p1, const float4 p2, int H, int W, int& x0, int& y0, int& bw) {
+    int x1, y1;
+    if (p0.w > 0.f && p1.w > 0.f && p2.w > 0.f) {
+        const float sx0 = p0.x / p0.w, sx1 = p1.x / p1.w, sx2 = p2.x / p2.w;
+        const float sy0 = p0.y / p0.w, sy1 = p1.y / p1.w, sy2 = p2.y / p2.w;
+        const float mnx = fminf(sx0, fminf(sx1, sx2)), mxx = fmaxf(sx0, fmaxf(sx1, sx2));
+        const float mny = fminf(sy0, fminf(sy1, sy2)), mxy = fmaxf(sy0, fmaxf(sy1, sy2));
+        // pixel centres px+0.5 inside [min,max], widened by 1/32 px (coverage itself is decided by rs_frag)
+        const float fx0 = ceilf((mnx + 1.f) * 0.5f * W - 0.53125f), fx1 = floorf((mxx + 1.f) * 0.5f * W - 0.46875f);
+        const float fy0 = ceilf((mny + 1.f) * 0.5f * H - 0.53125f), fy1 = floorf((mxy + 1.f) * 0.5f * H - 0.46875f);
+        if (!((fx1 >= 0.f) && (fy1 >= 0.f) && (fx0 <= (float)(W - 1)) && (fy0 <= (float)(H - 1)))) return 0;
+        x0 = fx0 < 0.f ? 0 : (int)fx0;
+        y0 = fy0 < 0.f ? 0 : (int)fy0;
+        x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
+        y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
+    } else if (p0.w <= 0.f && p1.w <= 0.f && p2.w <= 0.f) {
+        return 0;
+    } else {
+        x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;  // straddles the eye plane: every pixel is a candidate
+    }
+    bw = x1 - x0 + 1;
+    const int bh = y1 - y0 + 1;
+    return (bw > 0 && bh > 0) ? bw * bh : 0;
 }
 
-template <int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void rs_fwd_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
-                                                    int B, int Bpad, int V, int F, int H, int W, int tiles_x,
-                                                    float4* __restrict__ rast) {
-    __shared__ unsigned long long s_key[TW * TH];
-    const int b = blockIdx.x % Bpad;
-    if (b >= B) return;  // padding so that image b always lands on XCD b % 8
-    const int tile = blockIdx.x / Bpad;
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int tx1 = min(tx0 + TW, W) - 1, ty1 = min(ty0 + TH, H) - 1;
+__device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, const float4 p2, int px, int py, int W, float xs, float xo,
+                                              float ys, float yo, unsigned f, unsigned long long* __restrict__ keys) {
+    const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
+    if (fr.hit) {
+        const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | f;
+        unsigned long long* slot = keys + (long long)py * W + px;
+        // keys only ever decrease, so a stale read is an upper bound: skipping when we cannot beat it is safe
+        if (key < *(volatile unsigned long long*)slot) atomicMin(slot, key);
+    }
+}
+
+// 4 lanes per (image, triangle); blockDim = 256 = 64 triangles
+__global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
+                                                     int H, int W, unsigned long long* __restrict__ keys) {
+    const int b = blockIdx.y;
+    const int f = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int sub = threadIdx.x & 3, lane = threadIdx.x & 63;
     const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
+    unsigned long long* kb = keys + (long long)b * H * W;
     const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
     const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
-    for (int i = threadIdx.x; i < TW * TH; i += NT) s_key[i] = RS_EMPTY;
-    __syncthreads();
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    int x0 = 0, y0 = 0, bw = 1, area = 0;
+    if (f < F) {
+        const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+        if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+            p0 = pb[i0]; p1 = pb[i1]; p2 = pb[i2];
+            area = rs_box(p0, p1, p2, H, W, x0, y0, bw);
+        }
+    }
+    if (area <= RS_COOP_AREA) {
+        for (int i = sub; i < area; i += 4) rs_test_pixel(p0, p1, p2, x0 + i % bw, y0 + i / bw, W, xs, xo, ys, yo, (unsigned)f, kb);
+    }
+    // large boxes: one representative lane per triangle (sub == 0) votes, the whole wave walks the box
+    unsigned long long big = __ballot(area > RS_COOP_AREA && sub == 0);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        float4 c0, c1, c2;
+        c0.x = __shfl(p0.x, src); c0.y = __shfl(p0.y, src); c0.z = __shfl(p0.z, src); c0.w = __shfl(p0.w, src);
+        c1.x = __shfl(p1.x, src); c1.y = __shfl(p1.y, src); c1.z = __shfl(p1.z, src); c1.w = __shfl(p1.w, src);
+        c2.x = __shfl(p2.x, src); c2.y = __shfl(p2.y, src); c2.z = __shfl(p2.z, src); c2.w = __shfl(p2.w, src);
+        const int cx0 = __shfl(x0, src), cy0 = __shfl(y0, src), cbw = __shfl(bw, src), carea = __shfl(area, src);
+        const unsigned cf = (unsigned)__shfl(f, src);
+        for (int i = lane; i < carea; i += 64) rs_test_pixel(c0, c1, c2, cx0 + i % cbw, cy0 + i / cbw, W, xs, xo, ys, yo, cf, kb);
+    }
+}
 
-    const int lane = threadIdx.x & 63;
-    for (int f0 = 0; f0 < F; f0 += NT) {
-        const int f = f0 + threadIdx.x;
-        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-        if (f < F) {
-            const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
-            if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
-                p0 = pb[i0]; p1 = pb[i1]; p2 = pb[i2];
-                bool live = true;
-                if (p0.w > 0.f && p1.w > 0.f && p2.w > 0.f) live = rs_bbox(p0, p1, p2, W, H, x0, y0, x1, y1);
-                else if (p0.w <= 0.f && p1.w <= 0.f && p2.w <= 0.f) live = false;
-                else { x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1; }  // straddles the eye plane: test the whole tile
-                if (live) {
-                    x0 = max(x0, tx0); y0 = max(y0, ty0); x1 = min(x1, tx1); y1 = min(y1, ty1);
-                } else {
-                    x1 = -1; y1 = -1; x0 = 0; y0 = 0;
-                }
-            }
-        }
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        const int area = (bw > 0 && bh > 0) ? bw * bh : 0;
-        // ---- small boxes: the owning lane walks its own pixels
-        if (area > 0 && area <= RS_SMALL_AREA) {
-            for (int py = y0; py <= y1; ++py) {
-                const float fy = __builtin_fmaf(ys, (float)py, yo);
-                for (int px = x0; px <= x1; ++px) {
-                    const float fx = __builtin_fmaf(xs, (float)px, xo);
-                    const RsFrag fr = rs_frag(p0, p1, p2, fx, fy);
-                    if (fr.hit) {
-                        const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | (unsigned)f;
-                        atomicMin(&s_key[(py - ty0) * TW + (px - tx0)], key);
-                    }
-                }
-            }
-        }
-        // ---- large boxes: all 64 lanes of the wave share one triangle
-        unsigned long long big = __ballot(area > RS_SMALL_AREA);
-        while (big) {
-            const int src = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            float4 c0, c1, c2;
-            c0.x = __shfl(p0.x, src); c0.y = __shfl(p0.y, src); c0.z = __shfl(p0.z, src); c0.w = __shfl(p0.w, src);
-            c1.x = __shfl(p1.x, src); c1.y = __shfl(p1.y, src); c1.z = __shfl(p1.z, src); c1.w = __shfl(p1.w, src);
-            c2.x = __shfl(p2.x, src); c2.y = __shfl(p2.y, src); c2.z = __shfl(p2.z, src); c2.w = __shfl(p2.w, src);
-            const int cx0 = __shfl(x0, src), cy0 = __shfl(y0, src), cbw = __shfl(bw, src), carea = __shfl(area, src);
-            const int cf = f0 + (threadIdx.x & ~63) + src;
-            for (int i = lane; i < carea; i += 64) {
-                const int py = cy0 + i / cbw, px = cx0 + i % cbw;
-                const float fy = __builtin_fmaf(ys, (float)py, yo);
-                const float fx = __builtin_fmaf(xs, (float)px, xo);
-                const RsFrag fr = rs_frag(c0, c1, c2, fx, fy);
-                if (fr.hit) {
-                    const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | (unsigned)cf;
-                    atomicMin(&s_key[(py - ty0) * TW + (px - tx0)], key);
-                }
-            }
-        }
+__global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
+                                                         int H, int W, long long npix, const unsigned long long* __restrict__ keys,
+                                                         float4* __restrict__ rast) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const unsigned long long key = keys[i];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key != RS_EMPTY) {
+        const long long hw = (long long)H * W;
+        const int b = (int)(i / hw);
+        const int rem = (int)(i - b * hw);
+        const int py = rem / W, px = rem - py * W;
+        const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
+        const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
+        const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
+        const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+        const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+        const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
+        o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
     }
-    __syncthreads();
-    // ---- resolve: recompute the winner's fragment, write whole rows
-    float4* out = rast + (long long)b * H * W;
-    for (int i = threadIdx.x; i < TW * TH; i += NT) {
-        const int py = ty0 + i / TW, px = tx0 + i % TW;
-        if (px >= W || py >= H) continue;
-        const unsigned long long key = s_key[i];
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key != RS_EMPTY) {
-            const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
-            const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
-            const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
-            o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
-        }
-        out[(long long)py * W + px] = o;
-    }
+    rast[i] = o;
 }
 
 // backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; one thread per pixel
@@ -232,29 +217,25 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
     atomicAdd(o2, g2x); atomicAdd(o2 + 1, g2y); atomicAdd(o2 + 3, -fx * g2x - fy * g2y);
 }
 
+extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
+
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                            a3d_stream_t stream) {
+                            void* scratch, a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
-    A3D_CHECK_ARG(F == 0 || tri);
+    A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     hipStream_t s = (hipStream_t)stream;
+    const long long npix = (long long)B * H * W;
     if (F == 0) {
-        A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)B * H * W, s));
+        A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)npix, s));
         return A3D_OK;
     }
-    const int Bpad = (B + 7) & ~7;
-    auto tiles = [&](int t) { return a3d_div_up(W, t) * a3d_div_up(H, t); };
-    // biggest tile that still gives every CU a workgroup (256 CUs)
-    if ((long long)B * tiles(64) >= 256) {
-        hipLaunchKernelGGL((rs_fwd_kernel<64, 64, 1024>), dim3(tiles(64) * Bpad), dim3(1024), 0, s, (const float4*)clip, clip_batch, tri, B,
-                           Bpad, V, F, H, W, a3d_div_up(W, 64), (float4*)rast);
-    } else if ((long long)B * tiles(32) >= 256) {
-        hipLaunchKernelGGL((rs_fwd_kernel<32, 32, 256>), dim3(tiles(32) * Bpad), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, B,
-                           Bpad, V, F, H, W, a3d_div_up(W, 32), (float4*)rast);
-    } else {
-        hipLaunchKernelGGL((rs_fwd_kernel<16, 16, 256>), dim3(tiles(16) * Bpad), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, B,
-                           Bpad, V, F, H, W, a3d_div_up(W, 16), (float4*)rast);
-    }
+    unsigned long long* keys = (unsigned long long*)scratch;
+    A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
+    hipLaunchKernelGGL(rs_tri_kernel, dim3(a3d_div_up(F, 64), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W, keys);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rs_resolve_kernel, dim3(a3d_div_up(npix, 256)), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, H, W, npix, keys,
+                       (float4*)rast);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -21,6 +21,7 @@ from . import light, util
 from . import renderutils as ru
 
 ANTIALIASED_MODES = ("shaded", "flow", "dino_pred", "depth", "shading")  # reference render.py:311
+SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixels only (output-identical; see shade())
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
@@ -31,8 +32,17 @@ def interpolate(attr, rast, attr_idx, rast_db=None):
 
 
 def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat=None, render_modes=None,
-          two_sided_shading=True, delta_xy_interp=None, dino_net=None, class_vector=None):
-    """Per-pixel shading (reference render.py:30-132): texture / DINO field lookups, shading normal, directional light."""
+          two_sided_shading=True, delta_xy_interp=None, dino_net=None, class_vector=None, cover=None):
+    """Per-pixel shading (reference render.py:30-132): texture / DINO field lookups, shading normal, directional light.
+
+    ``cover`` (bool [B,H,W], optional, not in the reference signature): evaluate everything on the covered pixels only
+    and scatter into dense buffers.  Output-identical after compositing -- uncovered pixels are overwritten by
+    lerp(bg, ., 0) (render.py:261-262) and antialias only mixes composited colours -- but the two coordinate MLPs,
+    which dominate the FLOPs of the whole step, see 3-5x fewer points.
+    """
+    if cover is not None and (render_modes is None or "depth" not in render_modes):
+        return _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat,
+                              render_modes, two_sided_shading, delta_xy_interp, dino_net, class_vector, cover)
     if material is not None:
         all_tex = material.sample(gb_tex_pos, feat=feat)
     else:
@@ -47,20 +57,14 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
     b, h, w, _ = gb_normal.shape
     cam_normal = util.safe_normalize(torch.matmul(gb_normal.view(b, -1, 3), w2c[:, :3, :3].transpose(2, 1))).view(b, h, w, 3)
 
-    assert bsdf is not None or material.bsdf is not None, "Material must specify a BSDF type"
-    bsdf = bsdf if bsdf is not None else material.bsdf
+    bsdf = _resolve_bsdf(bsdf, material)
     shading = None
-    if bsdf == "diffuse":
-        if lgt is None:
-            shaded_col = kd
-        elif isinstance(lgt, light.EnvironmentLight):
-            raise NotImplementedError("EnvironmentLight is outside the hot path")
-        else:
-            shaded_col, shading = lgt.shade(feat, kd, cam_normal)
-    elif bsdf == "pbr":
-        raise NotImplementedError("bsdf='pbr' needs an EnvironmentLight (reference render.py:83-87); no config uses it")
+    if lgt is None:
+        shaded_col = kd
+    elif isinstance(lgt, light.EnvironmentLight):
+        raise NotImplementedError("EnvironmentLight is outside the hot path")
     else:
-        assert False, "Invalid BSDF '%s'" % bsdf
+        shaded_col, shading = lgt.shade(feat, kd, cam_normal)
 
     depth = None
     if render_modes is not None and "depth" in render_modes:
@@ -69,6 +73,23 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
         dmin, dmax = depth.amin(dim=(1, 2), keepdim=True), depth.amax(dim=(1, 2), keepdim=True)
         depth = ((depth - dmin) / (dmax - dmin)).unsqueeze(-1)
 
+    buffers = _collect(render_modes, shaded_col, kd, ks, gb_normal, gb_geometric_normal, gb_tangent, shading, delta_xy_interp, dino_pred, depth)
+    if render_modes is not None:
+        return {mode: torch.cat((buffers[mode], alpha), dim=-1) for mode in render_modes if mode in buffers}
+    return {"shaded": torch.cat((shaded_col, alpha), dim=-1)}
+
+
+def _resolve_bsdf(bsdf, material):
+    assert bsdf is not None or material.bsdf is not None, "Material must specify a BSDF type"
+    bsdf = bsdf if bsdf is not None else material.bsdf
+    if bsdf == "pbr":
+        raise NotImplementedError("bsdf='pbr' needs an EnvironmentLight (reference render.py:83-87); no config uses it")
+    assert bsdf == "diffuse", "Invalid BSDF '%s'" % bsdf
+    return bsdf
+
+
+def _collect(render_modes, shaded_col, kd, ks, normal, geo_normal, tangent, shading, flow, dino_pred, depth):
+    """The buffer dict of the reference (render.py:110-125), restricted to what was asked for."""
     wanted = set(render_modes) if render_modes is not None else {"shaded"}
     buffers = {"shaded": shaded_col}
     if "kd" in wanted:
@@ -76,22 +97,66 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
     if "ks" in wanted:
         buffers["ks"] = ks
     if "normal" in wanted:
-        buffers["normal"] = (gb_normal + 1.0) * 0.5
+        buffers["normal"] = (normal + 1.0) * 0.5
     if "geo_normal" in wanted:
-        buffers["geo_normal"] = (gb_geometric_normal + 1.0) * 0.5
-    if "tangent" in wanted and gb_tangent is not None:
-        buffers["tangent"] = (gb_tangent + 1.0) * 0.5
+        buffers["geo_normal"] = (geo_normal + 1.0) * 0.5
+    if "tangent" in wanted and tangent is not None:
+        buffers["tangent"] = (tangent + 1.0) * 0.5
     if shading is not None:
         buffers["shading"] = shading
-    if delta_xy_interp is not None:
-        buffers["flow"] = delta_xy_interp
+    if flow is not None:
+        buffers["flow"] = flow
     if dino_pred is not None:
         buffers["dino_pred"] = dino_pred
     if depth is not None:
         buffers["depth"] = depth
-    if render_modes is not None:
-        return {mode: torch.cat((buffers[mode], alpha), dim=-1) for mode in render_modes if mode in buffers}
-    return {"shaded": torch.cat((shaded_col, alpha), dim=-1)}
+    return buffers
+
+
+def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat, render_modes,
+                   two_sided_shading, delta_xy_interp, dino_net, class_vector, cover):
+    """shade() on the covered pixels only; dense [B,H,W,C+1] buffers out (zeros, alpha 0, where nothing was rasterised)."""
+    b, h, w, _ = gb_pos.shape
+    pix = torch.nonzero(cover.reshape(-1)).squeeze(1)  # [P]; one host sync for P
+    img = torch.div(pix, h * w, rounding_mode="floor")
+    take = lambda t: None if t is None else t.reshape(b * h * w, t.shape[-1]).index_select(0, pix)
+    per_img = lambda t: None if t is None else (t.index_select(0, img) if t.shape[0] == b else t.expand(pix.shape[0], -1))
+    pos, geo, nrm, tng, tex_pos, flow = map(take, (gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, delta_xy_interp))
+
+    if material is not None:
+        all_tex = material.sample(tex_pos, feat=per_img(feat))
+    else:
+        all_tex = torch.ones(pix.shape[0], 9, device=gb_pos.device)
+    kd, ks = all_tex[..., :3], all_tex[..., 3:6]
+    dino_pred = dino_net.sample(tex_pos, feat=per_img(class_vector)) if dino_net is not None else None
+
+    view = view_pos.reshape(-1, 3)
+    nrm = ru.prepare_shading_normal(pos, per_img(view), None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
+    rot = w2c[:, :3, :3].index_select(0, img)  # [P,3,3]
+    cam_normal = util.safe_normalize(torch.einsum("pj,pij->pi", nrm, rot))
+
+    _resolve_bsdf(bsdf, material)
+    shading = None
+    if lgt is None:
+        shaded_col = kd
+    elif isinstance(lgt, light.EnvironmentLight):
+        raise NotImplementedError("EnvironmentLight is outside the hot path")
+    else:
+        params = lgt(feat).index_select(0, img)  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+        shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
+        shaded_col = shading * kd
+
+    buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
+    modes = render_modes if render_modes is not None else ["shaded"]
+    out = {}
+    ones = torch.ones(pix.shape[0], 1, device=gb_pos.device)
+    for mode in modes:
+        if mode not in buffers:
+            continue
+        vals = torch.cat((buffers[mode], ones), dim=-1)
+        dense = torch.zeros(b * h * w, vals.shape[-1], dtype=vals.dtype, device=vals.device)
+        out[mode] = dense.index_copy(0, pix, vals).view(b, h, w, -1)
+    return out
 
 
 def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
@@ -118,7 +183,7 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
 
     buffers = shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat=feat,
                     render_modes=render_modes, two_sided_shading=two_sided_shading, delta_xy_interp=delta_xy_interp, dino_net=dino_net,
-                    class_vector=class_vector)
+                    class_vector=class_vector, cover=(rast_s[..., 3] > 0) if SHADE_COVERED_ONLY else None)
     if spp > 1 and msaa:
         for key in buffers.keys():
             buffers[key] = util.scale_img_nhwc(buffers[key], full_res, mag="nearest", min="nearest")

@@ -197,7 +197,8 @@ class _Rasterize(torch.autograd.Function):
         clip = f32c(clip)
         V, F = clip.shape[1], tri32.shape[0]
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=clip.device)
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), stream())
+        scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), stream())
         ctx.save_for_backward(clip, tri32, rast)
         return rast
 
@@ -228,7 +229,8 @@ class _Interpolate(torch.autograd.Function):
         B, H, W = rast.shape[:3]
         V, C = attr.shape[1], attr.shape[2]
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=rast.device)
-        call("a3d_interp_fwd", ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(out), stream())
+        call("a3d_interp_fwd", ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(out), stream(),
+             tag=f"[C{C}]")
         ctx.save_for_backward(attr, rast, tri32)
         return out
 
@@ -240,7 +242,7 @@ class _Interpolate(torch.autograd.Function):
         g_attr = torch.empty_like(attr) if ctx.needs_input_grad[0] else None
         g_rast = torch.empty_like(rast)
         call("a3d_interp_bwd", ptr(f32c(g_out)), ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(g_attr),
-             ptr(g_rast), stream())
+             ptr(g_rast), stream(), tag=f"[C{C}]")
         return g_attr, (g_rast if ctx.needs_input_grad[1] else None), None
 
 
@@ -277,7 +279,7 @@ class _Antialias(torch.autograd.Function):
         B, H, W, C = color.shape
         assert (B, H, W) == (a.B, a.H, a.W)
         out = torch.empty_like(color)
-        call("a3d_aa_fwd", ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, B, H, W, ptr(out), stream())
+        call("a3d_aa_fwd", ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, B, H, W, ptr(out), stream(), tag=f"[C{C}]")
         ctx.save_for_backward(color)
         ctx.analysis = a
         return out
@@ -290,7 +292,7 @@ class _Antialias(torch.autograd.Function):
         g_color = torch.empty_like(color)
         g_clip = torch.empty_like(a.clip)
         call("a3d_aa_bwd", ptr(f32c(g_out)), ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri),
-             B, a.clip.shape[1], a.topo.tri.shape[0], H, W, ptr(g_color), ptr(g_clip), stream())
+             B, a.clip.shape[1], a.topo.tri.shape[0], H, W, ptr(g_color), ptr(g_clip), stream(), tag=f"[C{C}]")
         return g_color, g_clip, None
 
 

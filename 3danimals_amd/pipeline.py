@@ -145,24 +145,30 @@ class SyntheticScene(torch.nn.Module):
         out["dino"] = (((dino_pred - self.dino_gt) ** 2) * both.unsqueeze(1)).flatten(1).mean(1)
         return out
 
-    def step(self, backward=True, optimizer_step=None, sdf_reg=True):
-        """One iteration.  Returns dict(shaded, dino_pred, loss, losses)."""
+    def forward(self, jitter=True, sdf_reg=True):
+        """Forward of one iteration -> dict(shaded, dino_pred, loss, losses).  (DDP wraps this module: its backward hooks
+        all-reduce the MLP gradients over RCCL while the HIP backward kernels are still running.)"""
+        shaded, dino_pred = self.forward_render(self.arti, jitter=jitter)
+        parts = self.losses(shaded, dino_pred)
+        total = sum(LOSS_WEIGHTS[k] * v.mean() for k, v in parts.items())
+        if sdf_reg and torch.is_grad_enabled():
+            eikonal = ((self.netShape.get_sdf_gradient().norm(dim=-1) - 1) ** 2).mean()  # dmtet.py:278-281
+            total = total + LOSS_WEIGHTS["sdf_gradient"] * eikonal
+        return dict(shaded=shaded, dino_pred=dino_pred, loss=total, losses=parts)
+
+    def step(self, backward=True, optimizer_step=None, sdf_reg=True, module=None):
+        """One iteration (forward, backward, Adam).  ``module`` = the DDP wrapper of this scene when data-parallel."""
         optimizer_step = backward if optimizer_step is None else optimizer_step
         with torch.set_grad_enabled(backward):
-            shaded, dino_pred = self.forward_render(self.arti, jitter=backward)
-            parts = self.losses(shaded, dino_pred)
-            total = sum(LOSS_WEIGHTS[k] * v.mean() for k, v in parts.items())
-            if sdf_reg and backward:
-                eikonal = ((self.netShape.get_sdf_gradient().norm(dim=-1) - 1) ** 2).mean()  # dmtet.py:278-281
-                total = total + LOSS_WEIGHTS["sdf_gradient"] * eikonal
+            out = (module if module is not None else self)(jitter=backward, sdf_reg=sdf_reg)
         if backward:
             self.optimizer.zero_grad(set_to_none=True)
             for leaf in (self.mvp, self.w2c, self.campos, self.feat, self.arti):
                 leaf.grad = None
-            total.backward()
+            out["loss"].backward()
             if optimizer_step:
                 self.optimizer.step()
-        return dict(shaded=shaded, dino_pred=dino_pred, loss=total, losses=parts)
+        return out
 
 
 def _distance_transforms(mask: torch.Tensor) -> torch.Tensor:

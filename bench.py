@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Benchmark of the reconstruct-and-render hot path:  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): train_magicpony_horse-like synthetic step,
+batch 16 per GPU @ 256x256, forward + backward + Adam -- DMTet on a Kuhn R=64 grid (the stand-in for the reference's
+"128" Quartet grid), skinning with 20 bones, rasterise / interpolate / antialias, the texture / DINO /
+light / SDF MLPs at the reference's sizes, photometric + mask + DINO-feature losses.  See 3danimals_amd/pipeline.py.
+
+N > 1: launched by the driver through torch.distributed.run, one rank per GPU, DDP over RCCL (gradient all-reduce of
+the MLP parameters; the hot-path kernels themselves exchange nothing: images shard over the batch) -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant hot-path HIP kernel: algorithmic bytes per launch / mean launch duration measured live
+                  with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (kind "port") timed on this box's host cores on a bounded sample of the batch.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(name, d):
+    """Algorithmic HBM bytes of ONE call of a C-ABI entry point (DESIGN.md 'Kernels').
+
+    ``name`` may carry a channel tag, e.g. 'a3d_interp_fwd[C3]'.  Index buffers shared over the batch count once.
+    """
+    B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
+    C = int(name.split("[C")[1].split("]")[0]) if "[C" in name else 0
+    base = name.split("[")[0]
+    table = {
+        "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt,
+        "a3d_dmtet_emit": 16 * Nv + 8 * Ne + 4 * Ne + 16 * Nt + 24 * Nt + 16 * V + 48 * F,
+        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
+        "a3d_skin_fwd": 12 * V + 12 * B * V,
+        "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
+        "a3d_normals_fwd": 12 * F + B * (36 * F + 36 * V),
+        "a3d_normals_bwd": 12 * F + B * (36 * F + 36 * F + 48 * V),
+        "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
+        "a3d_rast_bwd": B * (32 * HW + 16 * V),
+        "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
+        "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
+        "a3d_aa_topology": 12 * F + 12 * F,
+        "a3d_aa_analyze": B * 16 * HW,
+        "a3d_aa_fwd": B * 8 * C * HW,
+        "a3d_aa_bwd": B * 8 * C * HW + B * 16 * V,
+    }
+    return table.get(base)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--grid-res", type=int, default=64)
+    ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-images", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP hot path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    L = importlib.import_module("3danimals_amd._lib")
+    L.lib()  # fail loudly, now, if the HIP library is missing
+
+    scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(args.resolution, args.resolution), device=dev,
+                                    seed=1000 * rank)  # every rank renders different images
+    module = None
+    if world > 1:
+        module = torch.nn.parallel.DistributedDataParallel(scene, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
+
+    # W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides, MAX over ranks
+    du = importlib.import_module("3danimals_amd.dist_util")
+    elapsed = du.timed_steps(lambda: scene.step(module=module), args.steps, args.warmup, device=dev)
+    images = world * args.batch * args.steps
+
+    # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
+    roofline, kernels = None, {}
+    if rank == 0:
+        with L.KernelTimer() as timer:
+            for _ in range(min(args.steps, 10)):
+                scene.step(module=module) if world == 1 else scene.step(module=None, optimizer_step=False)
+        prior, shape = scene.last["prior"], scene.last["shape"]
+        dims = dict(B=args.batch, V=int(prior.v_pos.shape[1]), F=int(prior.t_pos_idx.shape[1]), H=args.resolution, W=args.resolution,
+                    Nv=int(scene.netShape.verts.shape[0]), Ne=int(scene.netShape.topology.edges32.shape[0]),
+                    Nt=int(scene.netShape.topology.tets32.shape[0]), K=int(scene.bones.shape[2]))
+        total_ms = 0.0
+        for name, (count, mean_ms) in sorted(timer.summary().items()):
+            per_step = count / min(args.steps, 10)
+            ab = algorithmic_bytes(name, dims)
+            kernels[name] = dict(launches_per_step=round(per_step, 2), mean_us=round(mean_ms * 1e3, 2),
+                                 algorithmic_MB=None if ab is None else round(ab / 1e6, 3),
+                                 GBps=None if ab is None else round(ab / (mean_ms * 1e-3) / 1e9, 1))
+            total_ms += mean_ms * per_step
+        # dominant = most time per step among the entry points that are a single streaming kernel with a byte model
+        cand = {k: v for k, v in kernels.items() if v["GBps"] is not None}
+        dom = max(cand, key=lambda k: cand[k]["mean_us"] * cand[k]["launches_per_step"])
+        roofline = dict(kernel=dom, bound="hbm", achieved=cand[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=None, launch_us=cand[dom]["mean_us"],
+                        algorithmic_MB_per_launch=cand[dom]["algorithmic_MB"], hip_path_ms_per_step=round(total_ms, 3), mesh=dims)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import step_ref
+
+        threads = min(os.cpu_count(), 32)  # torch-CPU stops scaling (and thrashes) far below the 256 logical cores of the GPU box
+        torch.set_num_threads(threads)
+        n = max(1, min(args.cpu_sample_images, args.batch))
+        st = step_ref.snapshot(scene, n)
+        res = step_ref.cpu_step(st, backward=True)
+        cpu_baseline = dict(value=round(n / res["seconds"], 4), unit="images/s", cores=threads, kind="port",
+                            sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {args.batch} images of this workload "
+                                   f"(Kuhn R={args.grid_res} DMTet, LBS, {args.resolution}x{args.resolution} raster+shade+antialias, losses), "
+                                   f"1 run, torch {threads} threads of {os.cpu_count()} logical cores, {res['seconds']:.1f} s")
+
+    if rank == 0:
+        line = {
+            "metric": "train images/sec fwd+bwd @256x256 b16",
+            "value": round(images / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+LBS(20 bones)+raster/interp/antialias "
+                                   "+ SDF/texture/DINO/light MLPs + photometric/mask/DINO losses, fwd+bwd+Adam" % args.grid_res,
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "resolution": [args.resolution, args.resolution],
+                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,8 +89,9 @@ int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const 
  * specified operation by operation in oracle/raster_ref.c.  Backward: gradient of (u,v) w.r.t. clip x,y,w
  * (z/w and the id carry none); g_clip[clip_batch,V,4] zeroed by callee.
  */
+size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                 a3d_stream_t stream);
+                 void* scratch, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 

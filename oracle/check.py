@@ -34,6 +34,7 @@ def compare_step(scene, out):
     rep["max_abs_skin_err"] = float((sk - cpu(shape.v_pos)).abs().max())
     snrm = mesh_ref.vertex_normals(sk, faces)
     rep["max_abs_posed_normal_err"] = float((snrm - cpu(shape.v_nrm)).abs().max())
+    scene.netLight.light_params = None  # non-leaf cache of the last forward; not deep-copyable
     tex, dino, lgt = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))
     with torch.no_grad():
         shaded, dino_pred = render_ref.render_mesh(sk, faces, snrm, cpu(scene.mvp), cpu(scene.w2c), cpu(scene.campos), tex, lgt, scene.resolution,

@@ -82,14 +82,14 @@ int a3d_ref_rasterize(const float* pos, int pos_batch, const int32_t* tri, int B
             const float *p0 = pb + 4 * (size_t)i0, *p1 = pb + 4 * (size_t)i1, *p2 = pb + 4 * (size_t)i2;
             int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
             if (p0[3] > 0.f && p1[3] > 0.f && p2[3] > 0.f) {
-                /* conservative pixel bounding box (one pixel of slack) */
+                /* conservative pixel bounding box: pixel centres px+0.5 inside [min,max] widened by 1/32 px */
                 float sx[3] = {p0[0] / p0[3], p1[0] / p1[3], p2[0] / p2[3]};
                 float sy[3] = {p0[1] / p0[3], p1[1] / p1[3], p2[1] / p2[3]};
                 float mnx = fminf(sx[0], fminf(sx[1], sx[2])), mxx = fmaxf(sx[0], fmaxf(sx[1], sx[2]));
                 float mny = fminf(sy[0], fminf(sy[1], sy[2])), mxy = fmaxf(sy[0], fmaxf(sy[1], sy[2]));
-                float fx0 = (mnx + 1.f) * 0.5f * W - 1.5f, fx1 = (mxx + 1.f) * 0.5f * W + 0.5f;
-                float fy0 = (mny + 1.f) * 0.5f * H - 1.5f, fy1 = (mxy + 1.f) * 0.5f * H + 0.5f;
-                if (!(fx1 >= 0.f) || !(fy1 >= 0.f) || !(fx0 <= (float)W) || !(fy0 <= (float)H)) continue;
+                float fx0 = ceilf((mnx + 1.f) * 0.5f * W - 0.53125f), fx1 = floorf((mxx + 1.f) * 0.5f * W - 0.46875f);
+                float fy0 = ceilf((mny + 1.f) * 0.5f * H - 0.53125f), fy1 = floorf((mxy + 1.f) * 0.5f * H - 0.46875f);
+                if (!(fx1 >= 0.f) || !(fy1 >= 0.f) || !(fx0 <= (float)(W - 1)) || !(fy0 <= (float)(H - 1))) continue;
                 x0 = fx0 < 0.f ? 0 : (int)fx0;
                 y0 = fy0 < 0.f ? 0 : (int)fy0;
                 x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
