@@ -24,6 +24,7 @@ SOURCES = {
     "normals.hip": [],
     "raster.hip": ["-ffp-contract=off"],
     "interp.hip": [],
+    "gbuffer.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",

@@ -1,0 +1,261 @@
+// Fused G-buffer over the covered-pixel list on gfx950.
+//
+// The reference builds its G-buffer with five dr.interpolate calls over the full image (world position, geometric
+// normal through a [[f,f,f]] index buffer, smooth normal, tangent, canonical position; model/render/render.py:182-209)
+// plus ~6 torch ops for the face normals (render.py:185-188), and in backward runs five interpolate-backward kernels
+// and the rasteriser's.  Shading only ever needs the covered pixels (everything else is overwritten by lerp(bg,.,0),
+// render.py:261-262), so here ONE kernel walks the compact list of covered pixels:
+//   fwd : texel (u,v,id) -> 3 vertex ids -> gathers of v_pos / v_nrm / canonical v_pos -> 12 floats per point
+//         [ world position | normalised face normal | smooth normal | canonical position ]
+//   bwd : the four attribute adjoints (bary-weighted float atomics onto the three vertices), the face-normal adjoint
+//         (normalise + cross product), and -- folded in -- the rasteriser's backward: d/du, d/dv of all attributes are
+//         pushed straight through u = a0/(a0+a1+a2), v = a1/(...) onto clip-space x, y, w.  No [B,H,W,4] gradient image
+//         is ever materialised.
+// The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller: 16 images hitting the same
+// vertex of a [1,V,3] buffer serialise their atomics (measured 128 us vs 9 us per interpolate backward).
+// HBM traffic per covered pixel: fwd 8 (index) + 16 (texel) + 48 (out) B; bwd 8 + 16 + 48 B in; vertex data lives in L2.
+#include "a3d_common.h"
+
+__device__ __forceinline__ void gb_load3(const float* __restrict__ p, float& x, float& y, float& z) { x = p[0]; y = p[1]; z = p[2]; }
+
+__global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ rast, const int* __restrict__ tri, const long long* __restrict__ pix,
+                                                     long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
+                                                     const float* __restrict__ prior, int prior_batch, int V, long long hw,
+                                                     float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const long long i = pix[p];
+    const float4 r = rast[i];
+    const int f = (int)r.w - 1;
+    float* o = out + p * 12;
+    if (f < 0) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) o[c] = 0.f;
+        return;
+    }
+    const long long b = i / hw;
+    const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+    const float u = r.x, v = r.y, w = 1.f - u - v;
+    const float* vp = v_pos + b * V * 3;
+    float ax, ay, az, bx, by, bz, cx, cy, cz;
+    gb_load3(vp + 3ll * i0, ax, ay, az);
+    gb_load3(vp + 3ll * i1, bx, by, bz);
+    gb_load3(vp + 3ll * i2, cx, cy, cz);
+    o[0] = u * ax + v * bx + w * cx;
+    o[1] = u * ay + v * by + w * cy;
+    o[2] = u * az + v * bz + w * cz;
+    // geometric normal: safe_normalize(cross(p1 - p0, p2 - p0))   (render.py:185-188, util.py:28-32)
+    const float e1x = bx - ax, e1y = by - ay, e1z = bz - az, e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const float inv = 1.f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
+    o[3] = nx * inv; o[4] = ny * inv; o[5] = nz * inv;
+    const float* vn = v_nrm + b * V * 3;
+    gb_load3(vn + 3ll * i0, ax, ay, az);
+    gb_load3(vn + 3ll * i1, bx, by, bz);
+    gb_load3(vn + 3ll * i2, cx, cy, cz);
+    o[6] = u * ax + v * bx + w * cx;
+    o[7] = u * ay + v * by + w * cy;
+    o[8] = u * az + v * bz + w * cz;
+    const float* pr = prior + (prior_batch == 1 ? 0ll : b * V * 3);
+    gb_load3(pr + 3ll * i0, ax, ay, az);
+    gb_load3(pr + 3ll * i1, bx, by, bz);
+    gb_load3(pr + 3ll * i2, cx, cy, cz);
+    o[9] = u * ax + v * bx + w * cx;
+    o[10] = u * ay + v * by + w * cy;
+    o[11] = u * az + v * bz + w * cz;
+}
+
+// ---- backward.  Scatter targets are aggregated per workgroup in an LDS hash table keyed by vertex row (b*V + v):
+// the 256 consecutive covered pixels of a block reference ~770 vertices but only ~150-200 distinct ones, so the 36
+// float atomics per pixel go to LDS (ds_add_f32) and each distinct vertex is flushed to HBM/L2 once (12 atomics).
+#define GB_SLOTS 1024
+#define GB_PROBES 16
+
+__device__ __forceinline__ int gb_slot(int* s_key, int key) {
+    unsigned h = ((unsigned)key * 2654435761u) >> 22;  // top 10 bits
+#pragma unroll 1
+    for (int t = 0; t < GB_PROBES; ++t) {
+        const int old = atomicCAS(&s_key[h], -1, key);
+        if (old == -1 || old == key) return (int)h;
+        h = (h + 1) & (GB_SLOTS - 1);
+    }
+    return -1;  // table crowded: the caller falls back to global atomics
+}
+
+struct GbTargets {
+    float* vpos; float* vnrm; float* prior; float* clip;
+};
+
+__device__ __forceinline__ void gb_accumulate(int* s_key, float (*s_acc)[12], const GbTargets& t, int row, const float c[12]) {
+    const int slot = gb_slot(s_key, row);
+    if (slot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicAdd(&s_acc[slot][k], c[k]);
+    } else {
+        float* a = t.vpos + 3ll * row;
+        float* n = t.vnrm + 3ll * row;
+        atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
+        atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
+        if (t.prior) { float* q = t.prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
+        if (t.clip) { float* q = t.clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g_out, const float4* __restrict__ rast, const int* __restrict__ tri,
+                                                     const long long* __restrict__ pix, long long P, const float* __restrict__ v_pos,
+                                                     const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
+                                                     const float4* __restrict__ clip, int V, int H, int W, float* __restrict__ g_vpos,
+                                                     float* __restrict__ g_vnrm, float* __restrict__ g_prior, float* __restrict__ g_clip) {
+    __shared__ int s_key[GB_SLOTS];
+    __shared__ float s_acc[GB_SLOTS][12];
+    for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) {
+        s_key[i] = -1;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_acc[i][k] = 0.f;
+    }
+    __syncthreads();
+    GbTargets tg;
+    tg.vpos = g_vpos; tg.vnrm = g_vnrm; tg.prior = g_prior; tg.clip = g_clip;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = p < P ? pix[p] : 0;
+    const float4 r = p < P ? rast[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int f = (int)r.w - 1;
+    if (p < P && f >= 0) {
+        const long long hw = (long long)H * W;
+        const long long b = i / hw;
+        const int rem = (int)(i - b * hw);
+        const int py = rem / W, px = rem - py * W;
+        const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+        const float u = r.x, v = r.y, w = 1.f - u - v;
+        const float* g = g_out + p * 12;
+        const long long vb = b * V * 3;
+        float c0[12], c1[12], c2[12];  // contributions to the three vertices: vpos(3) vnrm(3) prior(3) clip x,y,w
+        float gu = 0.f, gv = 0.f;
+        float ax, ay, az, bx, by, bz, cx, cy, cz;
+        {   // world position + face normal (both functions of the three positions)
+            const float* vp = v_pos + vb;
+            gb_load3(vp + 3ll * i0, ax, ay, az);
+            gb_load3(vp + 3ll * i1, bx, by, bz);
+            gb_load3(vp + 3ll * i2, cx, cy, cz);
+            const float gx = g[0], gy = g[1], gz = g[2];
+            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
+            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
+            const float e1x = bx - ax, e1y = by - ay, e1z = bz - az, e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+            const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+            const float d = nx * nx + ny * ny + nz * nz;
+            const float hx = g[3], hy = g[4], hz = g[5];
+            float qx, qy, qz;  // adjoint of the un-normalised face normal
+            if (d > 1e-20f) {
+                const float inv = 1.f / sqrtf(d);
+                const float fx = nx * inv, fy = ny * inv, fz = nz * inv;
+                const float dot = fx * hx + fy * hy + fz * hz;
+                qx = (hx - fx * dot) * inv; qy = (hy - fy * dot) * inv; qz = (hz - fz * dot) * inv;
+            } else {
+                qx = hx * 1e10f; qy = hy * 1e10f; qz = hz * 1e10f;
+            }
+            // n = e1 x e2:  g_e1 = e2 x q,  g_e2 = q x e1
+            const float g1x = e2y * qz - e2z * qy, g1y = e2z * qx - e2x * qz, g1z = e2x * qy - e2y * qx;
+            const float g2x = qy * e1z - qz * e1y, g2y = qz * e1x - qx * e1z, g2z = qx * e1y - qy * e1x;
+            c0[0] = u * gx - (g1x + g2x); c0[1] = u * gy - (g1y + g2y); c0[2] = u * gz - (g1z + g2z);
+            c1[0] = v * gx + g1x; c1[1] = v * gy + g1y; c1[2] = v * gz + g1z;
+            c2[0] = w * gx + g2x; c2[1] = w * gy + g2y; c2[2] = w * gz + g2z;
+        }
+        {   // smooth normal
+            const float* vn = v_nrm + vb;
+            gb_load3(vn + 3ll * i0, ax, ay, az);
+            gb_load3(vn + 3ll * i1, bx, by, bz);
+            gb_load3(vn + 3ll * i2, cx, cy, cz);
+            const float gx = g[6], gy = g[7], gz = g[8];
+            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
+            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
+            c0[3] = u * gx; c0[4] = u * gy; c0[5] = u * gz;
+            c1[3] = v * gx; c1[4] = v * gy; c1[5] = v * gz;
+            c2[3] = w * gx; c2[4] = w * gy; c2[5] = w * gz;
+        }
+        {   // canonical position (accumulated per image even when the canonical mesh is shared)
+            const float* pr = prior + (prior_batch == 1 ? 0ll : vb);
+            gb_load3(pr + 3ll * i0, ax, ay, az);
+            gb_load3(pr + 3ll * i1, bx, by, bz);
+            gb_load3(pr + 3ll * i2, cx, cy, cz);
+            const float gx = g[9], gy = g[10], gz = g[11];
+            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
+            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
+            c0[6] = u * gx; c0[7] = u * gy; c0[8] = u * gz;
+            c1[6] = v * gx; c1[7] = v * gy; c1[8] = v * gz;
+            c2[6] = w * gx; c2[7] = w * gy; c2[8] = w * gz;
+        }
+        c0[9] = c0[10] = c0[11] = c1[9] = c1[10] = c1[11] = c2[9] = c2[10] = c2[11] = 0.f;
+        if (g_clip && (gu != 0.f || gv != 0.f)) {  // rasteriser backward (same algebra as rs_bwd_kernel)
+            const long long cb = b * V;
+            const float4 p0 = clip[cb + i0], p1 = clip[cb + i1], p2 = clip[cb + i2];
+            const float fx = ((float)px + 0.5f) * (2.f / (float)W) - 1.f;
+            const float fy = ((float)py + 0.5f) * (2.f / (float)H) - 1.f;
+            const float q0x = p0.x - fx * p0.w, q0y = p0.y - fy * p0.w;
+            const float q1x = p1.x - fx * p1.w, q1y = p1.y - fy * p1.w;
+            const float q2x = p2.x - fx * p2.w, q2y = p2.y - fy * p2.w;
+            const float a0 = q1x * q2y - q1y * q2x, a1 = q2x * q0y - q2y * q0x, a2 = q0x * q1y - q0y * q1x;
+            const float s = a0 + a1 + a2;
+            if (s != 0.f) {
+                const float is = 1.f / s;
+                const float uu = a0 * is, vv = a1 * is;
+                const float t = gu * uu + gv * vv;
+                const float ga0 = (gu - t) * is, ga1 = (gv - t) * is, ga2 = -t * is;
+                c0[9] = -ga1 * q2y + ga2 * q1y; c0[10] = ga1 * q2x - ga2 * q1x;
+                c1[9] = ga0 * q2y - ga2 * q0y;  c1[10] = -ga0 * q2x + ga2 * q0x;
+                c2[9] = -ga0 * q1y + ga1 * q0y; c2[10] = ga0 * q1x - ga1 * q0x;
+                c0[11] = -fx * c0[9] - fy * c0[10];
+                c1[11] = -fx * c1[9] - fy * c1[10];
+                c2[11] = -fx * c2[9] - fy * c2[10];
+            }
+        }
+        const int rowb = (int)(b * V);
+        gb_accumulate(s_key, s_acc, tg, rowb + i0, c0);
+        gb_accumulate(s_key, s_acc, tg, rowb + i1, c1);
+        gb_accumulate(s_key, s_acc, tg, rowb + i2, c2);
+    }
+    __syncthreads();
+    // flush: one set of global atomics per distinct vertex touched by this block
+    for (int sidx = threadIdx.x; sidx < GB_SLOTS; sidx += blockDim.x) {
+        const int row = s_key[sidx];
+        if (row < 0) continue;
+        const float* c = s_acc[sidx];
+        float* a = g_vpos + 3ll * row;
+        float* n = g_vnrm + 3ll * row;
+        atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
+        atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
+        if (g_prior) { float* q = g_prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
+        if (g_clip) { float* q = g_clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
+    }
+}
+
+extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
+                               const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream) {
+    A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
+    A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
+    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
+    hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
+                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, (long long)H * W, out);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
+                               const float* v_nrm, const float* prior, int prior_batch, const float* clip, int B, int V, int F, int H, int W,
+                               float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
+    A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
+    A3D_CHECK_ARG(g_vpos && g_vnrm);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n3 = sizeof(float) * 3 * (size_t)B * V;
+    A3D_HIP(hipMemsetAsync(g_vpos, 0, n3, s));
+    A3D_HIP(hipMemsetAsync(g_vnrm, 0, n3, s));
+    if (g_prior_or_null) A3D_HIP(hipMemsetAsync(g_prior_or_null, 0, n3, s));
+    if (g_clip_or_null) A3D_HIP(hipMemsetAsync(g_clip_or_null, 0, sizeof(float) * 4 * (size_t)B * V, s));
+    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior && (!g_clip_or_null || clip));
+    hipLaunchKernelGGL(gb_bwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P,
+                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip, V, H, W, g_vpos, g_vnrm, g_prior_or_null, g_clip_or_null);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

@@ -10,7 +10,6 @@
 
 #define SK_THREADS 256
 #define SK_MAXK 64
-#define SK_VPT 4  // vertices per thread in the g_T reduction
 
 struct SkBone {
     float ax, ay, az, dx, dy, dz, inv_len2;
@@ -73,76 +72,96 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     }
 }
 
-// backward: g_v (through the affine maps only) and the per-bone 3x4 gradient reduced over the vertices
-__global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
-                                                            const float* __restrict__ bones, int bones_batch,
-                                                            const float* __restrict__ T, int V, int K, float neg_inv_temp,
-                                                            float* __restrict__ g_v, float* __restrict__ g_T) {
+// ---- backward, two kernels.
+// (1) g_v = sum_k w_k R_k^T g : one thread per (image, vertex), no reduction (mirror of the forward).
+__global__ __launch_bounds__(SK_THREADS) void sk_bwd_v_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
+                                                              const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
+                                                              int V, int K, float neg_inv_temp, float* __restrict__ g_v) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
-    __shared__ float s_gT[SK_MAXK * 12];
     const int b = blockIdx.y;
     sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
-    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) s_gT[i] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    float px[SK_VPT], py[SK_VPT], pz[SK_VPT], gx[SK_VPT], gy[SK_VPT], gz[SK_VPT], mx[SK_VPT], is[SK_VPT];
-    const int base = (blockIdx.x * blockDim.x) * SK_VPT + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < SK_VPT; ++j) {
-        const int i = base + j * SK_THREADS;
-        const bool ok = i < V;
-        const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + (ok ? i : 0)) * 3;
-        const float* g = g_out + ((long long)b * V + (ok ? i : 0)) * 3;
-        px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-        gx[j] = ok ? g[0] : 0.f; gy[j] = ok ? g[1] : 0.f; gz[j] = ok ? g[2] : 0.f;
-        float m = -INFINITY;
-        for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px[j], py[j], pz[j], neg_inv_temp));
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += __expf(sk_logit(s_bone[k], px[j], py[j], pz[j], neg_inv_temp) - m);
-        mx[j] = m;
-        is[j] = 1.f / s;
-    }
-    float dvx[SK_VPT] = {0}, dvy[SK_VPT] = {0}, dvz[SK_VPT] = {0};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + i) * 3;
+    const float* g = g_out + ((long long)b * V + i) * 3;
+    const float px = p[0], py = p[1], pz = p[2], gx = g[0], gy = g[1], gz = g[2];
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
+    float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
     for (int k = 0; k < K; ++k) {
+        const float e = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
         const float* t = s_T + 12 * k;
-        float a[12];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) a[q] = 0.f;
-#pragma unroll
-        for (int j = 0; j < SK_VPT; ++j) {
-            float w = __expf(sk_logit(s_bone[k], px[j], py[j], pz[j], neg_inv_temp) - mx[j]) * is[j];
-            float wx = w * gx[j], wy = w * gy[j], wz = w * gz[j];
-            a[0] += wx * px[j]; a[1] += wx * py[j]; a[2] += wx * pz[j]; a[3] += wx;
-            a[4] += wy * px[j]; a[5] += wy * py[j]; a[6] += wy * pz[j]; a[7] += wy;
-            a[8] += wz * px[j]; a[9] += wz * py[j]; a[10] += wz * pz[j]; a[11] += wz;
-            // R^T (w g)
-            dvx[j] += t[0] * wx + t[4] * wy + t[8] * wz;
-            dvy[j] += t[1] * wx + t[5] * wy + t[9] * wz;
-            dvz[j] += t[2] * wx + t[6] * wy + t[10] * wz;
-        }
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            float r = a3d_wave_sum(a[q]);
-            if (lane == 0) atomicAdd(&s_gT[12 * k + q], r);  // 4 waves per block -> LDS
+        s += e;
+        ox += e * (t[0] * gx + t[4] * gy + t[8] * gz);
+        oy += e * (t[1] * gx + t[5] * gy + t[9] * gz);
+        oz += e * (t[2] * gx + t[6] * gy + t[10] * gz);
+    }
+    const float inv = 1.f / s;
+    float* o = g_v + ((long long)b * V + i) * 3;  // per image; a shared canonical mesh is summed over the batch by the caller
+    o[0] = ox * inv; o[1] = oy * inv; o[2] = oz * inv;
+}
+
+// (2) g_T[b,k] = sum_v w_k(v) * g(v) (x) [v,1]  -- a [K x V] . [V x 12] product per image.  Wave w of the block owns the
+// bones [w*KG, (w+1)*KG); every lane keeps KG x 12 partial sums in registers while it strides over the vertices, and
+// the cross-lane reduction happens ONCE per block (KG*12 butterfly sums) instead of once per vertex.
+template <int KG>
+__global__ __launch_bounds__(SK_THREADS) void sk_bwd_T_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
+                                                              const float* __restrict__ bones, int bones_batch, int V, int K,
+                                                              float neg_inv_temp, float* __restrict__ g_T) {
+    __shared__ SkBone s_bone[SK_MAXK];
+    const int b = blockIdx.y;
+    {
+        const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6);
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float* q = bb + 6 * k;
+            SkBone sb;
+            sb.ax = q[0]; sb.ay = q[1]; sb.az = q[2];
+            sb.dx = q[3] - q[0]; sb.dy = q[4] - q[1]; sb.dz = q[5] - q[2];
+            sb.inv_len2 = 1.f / fmaxf(sb.dx * sb.dx + sb.dy * sb.dy + sb.dz * sb.dz, 1e-6f);
+            s_bone[k] = sb;
         }
     }
-    if (g_v) {
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = wave * KG;
+    float acc[KG][12];
 #pragma unroll
-        for (int j = 0; j < SK_VPT; ++j) {
-            const int i = base + j * SK_THREADS;
-            if (i >= V) continue;
-            if (v_batch == 1) {
-                float* o = g_v + 3ll * i;
-                atomicAdd(o, dvx[j]); atomicAdd(o + 1, dvy[j]); atomicAdd(o + 2, dvz[j]);
-            } else {
-                float* o = g_v + ((long long)b * V + i) * 3;
-                o[0] = dvx[j]; o[1] = dvy[j]; o[2] = dvz[j];
+    for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc[kk][q] = 0.f;
+    const float* vb = v + (v_batch == 1 ? 0ll : (long long)b * V * 3);
+    const float* gb = g_out + (long long)b * V * 3;
+    for (int i = blockIdx.x * 64 + lane; i < V; i += 64 * gridDim.x) {
+        const float px = vb[3ll * i], py = vb[3ll * i + 1], pz = vb[3ll * i + 2];
+        const float gx = gb[3ll * i], gy = gb[3ll * i + 1], gz = gb[3ll * i + 2];
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            const int k = k0 + kk;
+            if (k < K) {
+                const float w = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m) * inv;
+                const float wx = w * gx, wy = w * gy, wz = w * gz;
+                acc[kk][0] += wx * px; acc[kk][1] += wx * py; acc[kk][2] += wx * pz; acc[kk][3] += wx;
+                acc[kk][4] += wy * px; acc[kk][5] += wy * py; acc[kk][6] += wy * pz; acc[kk][7] += wy;
+                acc[kk][8] += wz * px; acc[kk][9] += wz * py; acc[kk][10] += wz * pz; acc[kk][11] += wz;
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) atomicAdd(g_T + (long long)b * K * 12 + i, s_gT[i]);
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) {
+        const int k = k0 + kk;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float r = a3d_wave_sum(acc[kk][q]);
+            if (lane == 0 && k < K) atomicAdd(g_T + ((long long)b * K + k) * 12 + q, r);
+        }
+    }
 }
 
 extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B, int V, int K,
@@ -162,10 +181,21 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     hipStream_t s = (hipStream_t)stream;
+    const float nit = -1.f / temperature;
     A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
-    if (g_v_or_null && v_batch == 1) A3D_HIP(hipMemsetAsync(g_v_or_null, 0, sizeof(float) * 3 * (size_t)V, s));
-    hipLaunchKernelGGL(sk_bwd_kernel, dim3(a3d_div_up(V, SK_THREADS * SK_VPT), B), dim3(SK_THREADS), 0, s, g_out, v, v_batch, bones,
-                       bones_batch, T, V, K, -1.f / temperature, g_v_or_null, g_T);
+    if (g_v_or_null) {
+        hipLaunchKernelGGL(sk_bwd_v_kernel, dim3(a3d_div_up(V, SK_THREADS), B), dim3(SK_THREADS), 0, s, g_out, v, v_batch, bones, bones_batch, T, V,
+                           K, nit, g_v_or_null);
+        A3D_LAUNCH_CHECK();
+    }
+    // enough blocks per image to occupy the chip, but >= ~8 vertices per lane so the block-level reduction amortises
+    int nb = a3d_div_up(V, 64 * 8);
+    const int cap = (1024 + B - 1) / B;
+    nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+    const dim3 grid(nb, B), block(SK_THREADS);
+    if (K <= 20) hipLaunchKernelGGL((sk_bwd_T_kernel<5>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
+    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_T_kernel<8>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
+    else hipLaunchKernelGGL((sk_bwd_T_kernel<16>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

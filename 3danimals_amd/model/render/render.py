@@ -22,6 +22,8 @@ from . import renderutils as ru
 
 ANTIALIASED_MODES = ("shaded", "flow", "dino_pred", "depth", "shading")  # reference render.py:311
 SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixels only (output-identical; see shade())
+LAST_RAST = [None]
+FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
@@ -115,18 +117,28 @@ def _collect(render_modes, shaded_col, kd, ks, normal, geo_normal, tangent, shad
 
 def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat, render_modes,
                    two_sided_shading, delta_xy_interp, dino_net, class_vector, cover):
-    """shade() on the covered pixels only; dense [B,H,W,C+1] buffers out (zeros, alpha 0, where nothing was rasterised)."""
+    """shade() on the covered pixels only, from dense G-buffers (generic path: any mode, any attribute set)."""
     b, h, w, _ = gb_pos.shape
     pix = torch.nonzero(cover.reshape(-1)).squeeze(1)  # [P]; one host sync for P
-    img = torch.div(pix, h * w, rounding_mode="floor")
     take = lambda t: None if t is None else t.reshape(b * h * w, t.shape[-1]).index_select(0, pix)
-    per_img = lambda t: None if t is None else (t.index_select(0, img) if t.shape[0] == b else t.expand(pix.shape[0], -1))
     pos, geo, nrm, tng, tex_pos, flow = map(take, (gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, delta_xy_interp))
+    return _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat, render_modes,
+                         two_sided_shading, dino_net, class_vector)
+
+
+def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lgt, material, bsdf, feat, render_modes, two_sided_shading,
+                  dino_net, class_vector):
+    """The arithmetic of shade() (reference render.py:30-132) on compact [P,.] arrays; scatters into dense [B,H,W,C+1]
+    buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points."""
+    b, h, w = bhw
+    dev = pos.device
+    img = torch.div(pix, h * w, rounding_mode="floor")
+    per_img = lambda t: None if t is None else (t.index_select(0, img) if t.shape[0] == b else t.expand(pix.shape[0], -1))
 
     if material is not None:
         all_tex = material.sample(tex_pos, feat=per_img(feat))
     else:
-        all_tex = torch.ones(pix.shape[0], 9, device=gb_pos.device)
+        all_tex = torch.ones(pix.shape[0], 9, device=dev)
     kd, ks = all_tex[..., :3], all_tex[..., 3:6]
     dino_pred = dino_net.sample(tex_pos, feat=per_img(class_vector)) if dino_net is not None else None
 
@@ -149,7 +161,7 @@ def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_po
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
     out = {}
-    ones = torch.ones(pix.shape[0], 1, device=gb_pos.device)
+    ones = torch.ones(pix.shape[0], 1, device=dev)
     for mode in modes:
         if mode not in buffers:
             continue
@@ -159,21 +171,38 @@ def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_po
     return out
 
 
+FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred"))
+
+
 def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
-                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None):
-    """G-buffer interpolation + shading of one depth layer (reference render.py:139-221)."""
+                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None, clip=None):
+    """G-buffer interpolation + shading of one depth layer (reference render.py:139-221).
+
+    ``clip`` (the [B,V,4] clip-space vertices, not in the reference signature) enables the fused path: one HIP kernel builds
+    the G-buffer of the covered pixels and its backward also carries the rasteriser's gradient (csrc/gbuffer.hip).  Without
+    it, or for modes that need other attributes (flow, tangent, depth) or spp > 1, the generic interpolate path runs.
+    """
     full_res = [resolution[0] * spp, resolution[1] * spp]
     if prior_mesh is None:
         prior_mesh = mesh
     render_modes = render_modes if render_modes is not None else ["shaded"]
-    rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
-
     tri = mesh.t_pos_idx[0]
+    assert mesh.v_nrm is not None
+
+    fused = (clip is not None and SHADE_COVERED_ONLY and spp == 1 and not ({"flow", "tangent", "depth"} & set(render_modes))
+             and clip.shape[0] == mesh.v_pos.shape[0] and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr())
+    if fused:
+        b, h, w = rast.shape[:3]
+        pix = torch.nonzero(rast[..., 3].reshape(-1) > 0).squeeze(1)  # one host sync for the number of covered pixels
+        gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
+        return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], None, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
+                             render_modes, two_sided_shading, dino_net, class_vector)
+
+    rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
     gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)
     v0, v1, v2 = mesh.v_pos[:, tri[:, 0]], mesh.v_pos[:, tri[:, 1]], mesh.v_pos[:, tri[:, 2]]
     face_normals = util.safe_normalize(torch.cross(v1 - v0, v2 - v0, dim=-1))
     gb_geometric_normal, _ = interpolate(face_normals, rast_s, _face_index_buffer(tri))
-    assert mesh.v_nrm is not None
     gb_normal, _ = interpolate(mesh.v_nrm, rast_s, mesh.t_nrm_idx[0])
     gb_tangent = None
     if "tangent" in render_modes:  # only then are tangents ever observable (perturbed_nrm is None, render.py:71)
@@ -228,9 +257,10 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     tri = mesh.t_pos_idx[0]
     clip_f = v_pos_clip.float()
     rast = ops.rasterize(clip_f, tri, full_res)
+    LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
                             prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
-                            class_vector=class_vector)
+                            class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None)
 
     if background is not None:
         if spp > 1:

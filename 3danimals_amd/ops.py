@@ -136,10 +136,12 @@ class _Skin(torch.autograd.Function):
     def backward(ctx, g_out):
         v, bones, T = ctx.saved_tensors
         B, K, V = T.shape[0], T.shape[1], v.shape[1]
-        g_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        g_v = torch.empty((B, V, 3), dtype=torch.float32, device=v.device) if ctx.needs_input_grad[0] else None
         g_T = torch.empty_like(T)
         call("a3d_skin_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, ctx.temperature, ptr(g_v),
              ptr(g_T), stream())
+        if g_v is not None and v.shape[0] == 1 and B > 1:
+            g_v = g_v.sum(0, keepdim=True)  # shared canonical mesh: per-image partials, reduced here (no 16-way atomic contention)
         return g_v, None, g_T, None
 
 
@@ -251,6 +253,46 @@ def interpolate(attr, rast, tri):
     if attr.dim() == 2:
         attr = attr[None]
     return _Interpolate.apply(attr, rast, tri_int32(tri))
+
+
+# ---------------------------------------------------------------------------------------------- fused G-buffer
+class _GBuffer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix):
+        require_device(clip, v_pos, v_nrm, prior, rast, tri32, pix, what="gbuffer")
+        clip, v_pos, v_nrm, prior, rast = f32c(clip), f32c(v_pos), f32c(v_nrm), f32c(prior), f32c(rast)
+        B, H, W = rast.shape[:3]
+        V, P = v_pos.shape[1], pix.shape[0]
+        assert clip.shape[:2] == (B, V) and v_pos.shape[0] == B and v_nrm.shape == v_pos.shape and prior.shape[0] in (1, B)
+        assert pix.dtype == torch.int64 and pix.is_contiguous()
+        out = torch.empty((P, 12), dtype=torch.float32, device=rast.device)
+        call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
+             ptr(out), stream())
+        ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        clip, v_pos, v_nrm, prior, rast, tri32, pix = ctx.saved_tensors
+        B, H, W = rast.shape[:3]
+        V, P = v_pos.shape[1], pix.shape[0]
+        g_vpos, g_vnrm = torch.empty_like(v_pos), torch.empty_like(v_nrm)
+        g_prior = torch.empty_like(v_pos) if ctx.needs_input_grad[3] else None
+        g_clip = torch.empty_like(clip) if ctx.needs_input_grad[0] else None
+        call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], ptr(clip),
+             B, V, tri32.shape[0], H, W, ptr(g_vpos), ptr(g_vnrm), ptr(g_prior), ptr(g_clip), stream())
+        if g_prior is not None and prior.shape[0] == 1:
+            g_prior = g_prior.sum(0, keepdim=True)
+        return g_clip, g_vpos, g_vnrm, g_prior, None, None, None
+
+
+def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix):
+    """[P,12] = world position | face normal | smooth normal | canonical position at the covered pixels ``pix``.
+
+    Differentiable w.r.t. v_pos, v_nrm, prior_v_pos and -- through the barycentrics -- clip (x, y, w); pass ``rast.detach()``
+    semantics are implied: the gradient to ``clip`` is produced here, not through ``rast``.
+    """
+    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix)
 
 
 # ---------------------------------------------------------------------------------------------- antialias

@@ -128,10 +128,12 @@ class SyntheticScene(torch.nn.Module):
         verts = verts.view(B, *verts.shape[2:])
         shape = mesh_mod.make_mesh(verts, prior.t_pos_idx, prior.v_tex.expand(B, -1, -1), prior.t_tex_idx, None)
         self.last.update(prior=prior, shape=shape, posed_bones=aux["posed_bones"])
-        return render_mod.render_mesh(None, shape, self.mvp, self.w2c, self.campos, self.netTexture if with_nets else None,
+        out = render_mod.render_mesh(None, shape, self.mvp, self.w2c, self.campos, self.netTexture if with_nets else None,
                                       self.netLight if with_nets else None, self.resolution, background=self.background, bsdf="diffuse",
                                       feat=self.feat if with_nets else None, render_modes=list(modes), prior_mesh=prior,
                                       dino_net=self.netDINO if with_nets else None)
+        self.last["rast"] = render_mod.LAST_RAST[0]
+        return out
 
     def losses(self, shaded, dino_pred):
         """compute_reconstruction_losses (AnimalModel.py:260-307), F=1, background_mode 'none'."""

@@ -50,6 +50,8 @@ def algorithmic_bytes(name, d):
         "a3d_rast_bwd": B * (32 * HW + 16 * V),
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
+        "a3d_gbuffer_fwd": int(d.get("P", 0)) * (8 + 16 + 48),
+        "a3d_gbuffer_bwd": int(d.get("P", 0)) * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_aa_topology": 12 * F + 12 * F,
         "a3d_aa_analyze": B * 16 * HW,
         "a3d_aa_fwd": B * 8 * C * HW,
@@ -105,7 +107,8 @@ def main():
         prior, shape = scene.last["prior"], scene.last["shape"]
         dims = dict(B=args.batch, V=int(prior.v_pos.shape[1]), F=int(prior.t_pos_idx.shape[1]), H=args.resolution, W=args.resolution,
                     Nv=int(scene.netShape.verts.shape[0]), Ne=int(scene.netShape.topology.edges32.shape[0]),
-                    Nt=int(scene.netShape.topology.tets32.shape[0]), K=int(scene.bones.shape[2]))
+                    Nt=int(scene.netShape.topology.tets32.shape[0]), K=int(scene.bones.shape[2]),
+                    P=int((scene.last["rast"][..., 3] > 0).sum()) if "rast" in scene.last else 0)
         total_ms = 0.0
         for name, (count, mean_ms) in sorted(timer.summary().items()):
             per_step = count / min(args.steps, 10)

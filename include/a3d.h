@@ -64,8 +64,8 @@ int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, cons
  * T[B,K,12] = per-image, per-bone world transform (rows of the 3x4 affine), composed on the host side from
  * the kinematic chain.  out[b,v] = sum_k softmax_k(-dist(v, bone_k)/temperature) * (T[b,k] . [v,1]).
  * weights_or_null[K,max(Bv,Bb),V] optionally receives the softmax weights (aux['vertices_to_bones']).
- * Backward: g_v[Bv,V,3] (zeroed by callee; may be null) through the affine maps only (weights are detached,
- * skinning.py:377) and g_T[B,K,12] (zeroed by callee).
+ * Backward: g_v[B,V,3] (fully written; per image even when v is shared -- the caller sums over B; may be null)
+ * through the affine maps only (weights are detached, skinning.py:377) and g_T[B,K,12] (zeroed by callee).
  */
 int a3d_skin_fwd(const float* v, int v_batch, const float* bones /*[Bb,K,2,3]*/, int bones_batch, const float* T, int B, int V,
                  int K, float temperature, float* out /*[B,V,3]*/, float* weights_or_null, a3d_stream_t stream);
@@ -105,6 +105,21 @@ int a3d_interp_fwd(const float* attr, int attr_batch, int C, const float* rast, 
                    int W, float* out, a3d_stream_t stream);
 int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C, const float* rast, const int32_t* tri, int B,
                    int V, int F, int H, int W, float* g_attr_or_null, float* g_rast, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused G-buffer over the covered-pixel list -- replaces the five dr.interpolate calls + face-normal torch ops of
+ * render_layer, /root/reference/model/render/render.py:182-209, and in backward also dr.rasterize's gradient.
+ * pix[P] = flat indices (b*H + y)*W + x of the covered pixels (int64, ascending); out[P,12] =
+ * [world position | normalised face normal | interpolated vertex normal | interpolated canonical position].
+ * Backward (all zeroed by callee): g_vpos[B,V,3], g_vnrm[B,V,3], g_prior[B,V,3] (per image even when the canonical
+ * mesh is shared: the caller sums over B; may be null), g_clip[B,V,4] (x, y, w gradients through the barycentrics;
+ * may be null).  clip is [B,V,4].
+ */
+int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
+                    const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream);
+int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
+                    const float* v_nrm, const float* prior, int prior_batch, const float* clip, int B, int V, int F, int H, int W,
+                    float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Antialias -- replaces dr.antialias(color, rast, pos, tri), /root/reference/model/render/render.py:264-267.

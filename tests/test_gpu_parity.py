@@ -453,3 +453,67 @@ def test_full_step_loss_and_gradients_vs_oracle_step(dev):
     for name, mod in (("sdf_mlp", scene.netShape.mlp), ("tex", scene.netTexture), ("dino", scene.netDINO), ("lgt", scene.netLight)):
         for pn, p in mod.named_parameters():
             close(p.grad, ref["grads"][f"{name}.{pn}"], f"{name}.{pn}")
+
+
+def test_fused_gbuffer_matches_generic_path_and_gradients(dev, mods, ops):
+    """csrc/gbuffer.hip (one kernel, rasteriser backward folded in) against the modular rasterise/interpolate kernels."""
+    B, H, W = 3, 64, 64
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=7)
+    posed = (verts[None] + 0.05 * seeded((B, *verts.shape), 31, -1, 1)).to(dev)
+    tri = faces.to(dev)
+    R = mods["render"]
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+
+    def run(fused):
+        v = posed.clone().requires_grad_(True)
+        pv = verts[None].to(dev).clone().requires_grad_(True)
+        m = mvp.to(dev).clone().requires_grad_(True)
+        nrm = ops.vertex_normals(v, tri)
+        clip = ru.xfm_points(v, m)
+        rast = ops.rasterize(clip, tri, (H, W))
+        pix = torch.nonzero(rast[..., 3].reshape(-1) > 0).squeeze(1)
+        if fused:
+            gb = ops.gbuffer(clip, v, nrm, pv, rast, tri, pix)
+        else:
+            fn = R.util.safe_normalize(torch.cross(v[:, tri[:, 1]] - v[:, tri[:, 0]], v[:, tri[:, 2]] - v[:, tri[:, 0]], dim=-1))
+            parts = [ops.interpolate(v, rast, tri), ops.interpolate(fn, rast, R._face_index_buffer(tri)), ops.interpolate(nrm, rast, tri),
+                     ops.interpolate(pv, rast, tri)]
+            gb = torch.cat([t.reshape(-1, 3).index_select(0, pix) for t in parts], -1)
+        wgt = seeded(gb.shape, 41, -1, 1).to(dev)
+        gv, gp, gm = torch.autograd.grad((gb * wgt).sum(), [v, pv, m])
+        return gb.detach(), gv, gp, gm
+
+    a, b = run(True), run(False)
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=2e-6)
+    for x, y, name in zip(a[1:], b[1:], ("v_pos", "prior", "mvp")):
+        scale = float(y.abs().max())
+        assert scale > 0, name
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
+
+
+def test_ddp_wrapped_step_single_rank_nccl(dev):
+    """bench.py's N>1 code path (DistributedDataParallel over RCCL) exercised with a 1-rank process group: the wrapped
+    step must give exactly the gradients of the plain step (custom Functions return grads for every parameter)."""
+    import socket
+
+    import torch.distributed as dist
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        kw = dict(grid_res=16, batch=2, resolution=(64, 64), device=dev, seed=5, net_width=32, net_layers=3, feat_dim=16, embedder_freq=4, jitter_grid=0.0)
+        plain, wrapped = pipeline.SyntheticScene(**kw), pipeline.SyntheticScene(**kw)
+        ddp = torch.nn.parallel.DistributedDataParallel(wrapped, device_ids=[dev.index], broadcast_buffers=False, gradient_as_bucket_view=True)
+        a = plain.step(backward=True, optimizer_step=False, sdf_reg=False)
+        b = wrapped.step(backward=True, optimizer_step=False, sdf_reg=False, module=ddp)
+        assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-5)
+        for (n, p), (_, q) in zip(plain.named_parameters(), wrapped.named_parameters()):
+            assert q.grad is not None, n
+            scale = float(p.grad.abs().max()) + 1e-12
+            assert float((p.grad - q.grad).abs().max()) <= 2e-3 * scale, n  # atomics reorder float sums run to run
+    finally:
+        dist.destroy_process_group()
