@@ -94,7 +94,7 @@ def sdf_bce_reg_loss(sdf, all_edges):
 class DMTetGeometry(torch.nn.Module):
     def __init__(self, grid_res, spatial_scale, num_layers=None, hidden_size=None, embedder_freq=None, embed_concat_pts=True,
                  init_sdf=None, jitter_grid=0.0, symmetrize=False, condition_choice=None, device="cuda", tets_dir="data/tets", tet_grid=None,
-                 **kwargs):
+                 surface_only_backward=True, **kwargs):
         super().__init__()
         self.grid_res = grid_res
         self.marching_tets = DMTet()
@@ -104,6 +104,7 @@ class DMTetGeometry(torch.nn.Module):
         self.symmetrize = symmetrize
         self._device = device
         self._tets_dir = tets_dir
+        self.surface_only_backward = surface_only_backward
         self._tet_grid = tet_grid  # optional (vertices [Nv,3] in (-0.5,0.5), indices [Nt,4]) instead of an npz file
         self.load_tets(self.grid_res, self.grid_scale)
         embedder_scalar = 2 * np.pi / self.grid_scale * 0.9  # (-0.5 s, 0.5 s) -> (-pi, pi) * 0.9  (dmtet.py:186)
@@ -182,6 +183,25 @@ class DMTetGeometry(torch.nn.Module):
         return {"sdf_bce_reg_loss": sdf_bce_reg_loss(self.current_sdf, self.all_edges).mean(),
                 "sdf_gradient_reg_loss": ((self.get_sdf_gradient(feats=feats).norm(dim=-1) - 1) ** 2).mean()}
 
+    def _get_mesh_surface_backward(self, pos, total_iter, feats):
+        """Same values and gradients as the plain path, ~2/3 less MLP work.
+
+        Only grid vertices at the ends of sign-crossing edges (a few thousand of the ~3e5) ever receive a gradient from the
+        mesh (dmtet.py:123-131); every other SDF value only decides a sign.  So the field is evaluated on the whole grid WITHOUT
+        a graph, the surface is extracted, and the graph is built by re-evaluating the field on the surface-adjacent vertices
+        alone.  The re-evaluated values enter as (x - x.detach()), i.e. exactly zero in forward, so the vertex positions are
+        bit-identical to the single-pass result while autograd sees the dependency.
+        """
+        with torch.no_grad():
+            sdf0 = self.get_sdf(pos, total_iter=total_iter, feats=feats)
+        verts0, faces, uv_idx, vert_edge = ops.dmtet_extract(pos, sdf0, self.topology)
+        mask = torch.zeros(pos.shape[0], dtype=torch.bool, device=pos.device)
+        mask[self.topology.edges32[vert_edge.long()].reshape(-1).long()] = True
+        idx = torch.nonzero(mask).squeeze(1)  # sorted, unique
+        sdf_sub = self.get_sdf(pos[idx], total_iter=total_iter, feats=feats)
+        self.current_sdf = sdf0.index_add(0, idx, sdf_sub - sdf_sub.detach())
+        return ops.dmtet_verts(pos, self.current_sdf, verts0, vert_edge, self.topology), faces, uv_idx
+
     # ---- mesh extraction (reference dmtet.py:294-310) ---------------------------------------------
     def getMesh(self, material=None, total_iter=0, jitter_grid=True, feats=None):
         v_deformed = self.verts
@@ -189,7 +209,11 @@ class DMTetGeometry(torch.nn.Module):
             jitter = (torch.rand(1, device=v_deformed.device) * 2 - 1) * self.jitter_grid * self.grid_scale
             v_deformed = v_deformed + jitter
         self.current_pos = v_deformed  # (extra attribute: the jittered grid this mesh was extracted on)
-        self.current_sdf = self.get_sdf(v_deformed, total_iter=total_iter, feats=feats)
-        verts, faces, uvs, uv_idx = self.marching_tets(v_deformed, self.current_sdf, self.indices, topology=self.topology)
+        if self.surface_only_backward and torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()):
+            verts, faces, uv_idx = self._get_mesh_surface_backward(v_deformed, total_iter, feats)
+            uvs = self.topology.uvs()
+        else:
+            self.current_sdf = self.get_sdf(v_deformed, total_iter=total_iter, feats=feats)
+            verts, faces, uvs, uv_idx = self.marching_tets(v_deformed, self.current_sdf, self.indices, topology=self.topology)
         self.mesh_verts = verts
         return mesh.make_mesh(verts[None], faces[None], uvs[None], uv_idx[None], material)

@@ -75,46 +75,59 @@ def aa_topology(tri32: torch.Tensor, num_vertices: int) -> AATopology:
 
 
 # ---------------------------------------------------------------------------------------------- DMTet
-class _DMTet(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pos, sdf, grid):
-        require_device(pos, sdf, grid.edges32, what="dmtet")
-        sdf_shape = sdf.shape
-        pos_c, sdf_c = f32c(pos), f32c(sdf).reshape(-1)
-        Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
-        assert sdf_c.shape[0] == Nv, "sdf must have one value per grid vertex"
-        dev = pos_c.device
-        scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
-        counts = torch.empty(4, dtype=torch.int32, device=dev)
-        call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), stream())
-        V, n1, n2 = counts.tolist()[:3]  # the one host sync of the path (the reference syncs here too, dmtet.py:110)
-        F = n1 + 2 * n2
-        verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
-        vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
-        edge2vert = torch.empty((Ne,), dtype=torch.int32, device=dev)
-        faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
-        uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
-        call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch),
-             V, n1, n2, ptr(edge2vert), ptr(verts), ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
-        ctx.save_for_backward(pos_c, sdf_c, vert_edge)
-        ctx.grid, ctx.sdf_shape = grid, sdf_shape
-        ctx.mark_non_differentiable(faces, uv_idx)
-        return verts, faces, uv_idx
+def dmtet_extract(pos, sdf, grid):
+    """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V])."""
+    require_device(pos, sdf, grid.edges32, what="dmtet")
+    pos_c, sdf_c = f32c(pos.detach()), f32c(sdf.detach()).reshape(-1)
+    Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
+    assert sdf_c.shape[0] == Nv, "sdf must have one value per grid vertex"
+    dev = pos_c.device
+    scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), stream())
+    V, n1, n2 = counts.tolist()[:3]  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
+    F = n1 + 2 * n2
+    verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
+    edge2vert = torch.empty((Ne,), dtype=torch.int32, device=dev)
+    faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
+    uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
+    call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch),
+         V, n1, n2, ptr(edge2vert), ptr(verts), ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
+    return verts, faces, uv_idx, vert_edge
+
+
+class _DMTetVerts(torch.autograd.Function):
+    """Attaches the gradient of already-extracted surface vertices to (pos, sdf): forward returns ``verts0`` as is."""
 
     @staticmethod
-    def backward(ctx, g_verts, _gf, _gu):
+    def forward(ctx, pos, sdf, verts0, vert_edge, grid):
+        pos_c, sdf_c = f32c(pos), f32c(sdf).reshape(-1)
+        ctx.save_for_backward(pos_c, sdf_c, vert_edge)
+        ctx.grid, ctx.sdf_shape = grid, sdf.shape
+        return verts0.clone()
+
+    @staticmethod
+    def backward(ctx, g_verts):
         pos_c, sdf_c, vert_edge = ctx.saved_tensors
         Nv, V = pos_c.shape[0], vert_edge.shape[0]
         g_sdf = torch.empty_like(sdf_c)
         g_pos = torch.empty_like(pos_c) if ctx.needs_input_grad[0] else None
         g = f32c(g_verts) if V > 0 else None
         call("a3d_dmtet_bwd", ptr(g), ptr(pos_c), ptr(sdf_c), ptr(ctx.grid.edges32), ptr(vert_edge), V, Nv, ptr(g_pos), ptr(g_sdf), stream())
-        return g_pos, g_sdf.reshape(ctx.sdf_shape), None
+        return g_pos, g_sdf.reshape(ctx.sdf_shape), None, None, None
+
+
+def dmtet_verts(pos, sdf, verts0, vert_edge, grid):
+    return _DMTetVerts.apply(pos, sdf, verts0, vert_edge, grid)
 
 
 def dmtet(pos, sdf, grid):
     """(verts [V,3] differentiable w.r.t. sdf/pos, faces int64 [F,3], uv_idx int64 [F,3])."""
-    return _DMTet.apply(pos, sdf, grid)
+    verts0, faces, uv_idx, vert_edge = dmtet_extract(pos, sdf, grid)
+    if torch.is_grad_enabled() and (pos.requires_grad or sdf.requires_grad):
+        return _DMTetVerts.apply(pos, sdf, verts0, vert_edge, grid), faces, uv_idx
+    return verts0, faces, uv_idx
 
 
 # ---------------------------------------------------------------------------------------------- skinning

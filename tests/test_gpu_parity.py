@@ -517,3 +517,25 @@ def test_ddp_wrapped_step_single_rank_nccl(dev):
             assert float((p.grad - q.grad).abs().max()) <= 2e-3 * scale, n  # atomics reorder float sums run to run
     finally:
         dist.destroy_process_group()
+
+
+def test_surface_only_sdf_backward_is_output_identical(dev, mods):
+    """DMTetGeometry evaluates the SDF MLP with a graph only on surface-adjacent grid vertices: same mesh, same gradients."""
+    a3d = importlib.import_module("3danimals_amd")
+    grid = a3d.tetgrid.kuhn_grid(16)
+
+    def run(flag):
+        torch.manual_seed(0)
+        geo = mods["dmtet"].DMTetGeometry(32, 7.0, num_layers=3, hidden_size=32, embedder_freq=4, init_sdf="ellipsoid", jitter_grid=0.0,
+                                          symmetrize=True, device=dev, tet_grid=grid, surface_only_backward=flag).to(dev)
+        m = geo.getMesh(jitter_grid=False)
+        wgt = seeded(m.v_pos.shape, 3, -1, 1).to(dev)
+        loss = (m.v_pos * wgt).sum() + (m.v_nrm * wgt).sum()
+        loss.backward()
+        return m, [p.grad.clone() for p in geo.mlp.parameters()], geo.current_sdf.detach()
+
+    (m1, g1, s1), (m0, g0, s0) = run(True), run(False)
+    assert torch.equal(m1.v_pos, m0.v_pos) and torch.equal(m1.t_pos_idx, m0.t_pos_idx) and torch.equal(s1, s0)
+    for a, b in zip(g1, g0):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale
