@@ -28,6 +28,9 @@ except Exception:  # stand-alone
     CoordMLP_Mod = None
 
 
+SURFACE_BUCKET = 1024  # row padding of the surface-adjacent SDF re-evaluation (0 = off)
+
+
 class TetGridTopology:
     """Static per-grid device buffers the kernels stream: tets/edges/tet2edge as int32."""
 
@@ -198,7 +201,11 @@ class DMTetGeometry(torch.nn.Module):
         mask = torch.zeros(pos.shape[0], dtype=torch.bool, device=pos.device)
         mask[self.topology.edges32[vert_edge.long()].reshape(-1).long()] = True
         idx = torch.nonzero(mask).squeeze(1)  # sorted, unique
-        sdf_sub = self.get_sdf(pos[idx], total_iter=total_iter, feats=feats)
+        pts = pos[idx]
+        n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0
+        if n_pad:  # pad (zeros, sliced off again) so the MLP's GEMM shapes repeat from step to step
+            pts = torch.nn.functional.pad(pts, (0, 0, 0, n_pad))
+        sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)[: idx.shape[0]]
         self.current_sdf = sdf0.index_add(0, idx, sdf_sub - sdf_sub.detach())
         return ops.dmtet_verts(pos, self.current_sdf, verts0, vert_edge, self.topology), faces, uv_idx
 

@@ -22,6 +22,7 @@ from . import renderutils as ru
 
 ANTIALIASED_MODES = ("shaded", "flow", "dino_pred", "depth", "shading")  # reference render.py:311
 SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixels only (output-identical; see shade())
+POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple of this (0 = off)
 LAST_RAST = [None]
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
 
@@ -135,17 +136,27 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     img = torch.div(pix, h * w, rounding_mode="floor")
     per_img = lambda t: None if t is None else (t.index_select(0, img) if t.shape[0] == b else t.expand(pix.shape[0], -1))
 
-    if material is not None:
-        all_tex = material.sample(tex_pos, feat=per_img(feat))
+    # The two coordinate MLPs see the point list padded to a multiple of POINT_BUCKET rows (zeros; outputs sliced off again):
+    # the GEMM shapes then repeat from step to step, which is what rocBLAS/hipBLASLt kernel selection and TunableOp key on.
+    n_pts = pix.shape[0]
+    n_pad = (-n_pts) % POINT_BUCKET if POINT_BUCKET else 0
+    if n_pad:
+        img_p = torch.cat((img, img.new_zeros(n_pad)))
+        tex_in = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))
+        per_img_p = lambda t: None if t is None else (t.index_select(0, img_p) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
     else:
-        all_tex = torch.ones(pix.shape[0], 9, device=dev)
+        tex_in, per_img_p = tex_pos, per_img
+    if material is not None:
+        all_tex = material.sample(tex_in, feat=per_img_p(feat))[:n_pts]
+    else:
+        all_tex = torch.ones(n_pts, 9, device=dev)
     kd, ks = all_tex[..., :3], all_tex[..., 3:6]
-    dino_pred = dino_net.sample(tex_pos, feat=per_img(class_vector)) if dino_net is not None else None
+    dino_pred = dino_net.sample(tex_in, feat=per_img_p(class_vector))[:n_pts] if dino_net is not None else None
 
     view = view_pos.reshape(-1, 3)
     nrm = ru.prepare_shading_normal(pos, per_img(view), None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
     rot = w2c[:, :3, :3].index_select(0, img)  # [P,3,3]
-    cam_normal = util.safe_normalize(torch.einsum("pj,pij->pi", nrm, rot))
+    cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs
 
     _resolve_bsdf(bsdf, material)
     shading = None

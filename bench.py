@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--grid-res", type=int, default=64)
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="do not load the shipped TunableOp results for the torch MLPs")
     ap.add_argument("--cpu-sample-images", type=int, default=4)
     args = ap.parse_args()
 
@@ -86,6 +87,7 @@ def main():
     pipeline = importlib.import_module("3danimals_amd.pipeline")
     L = importlib.import_module("3danimals_amd._lib")
     L.lib()  # fail loudly, now, if the HIP library is missing
+    tuned = importlib.import_module("3danimals_amd.gemm_tuning").enable() if not args.no_tuned_gemms else False
 
     scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(args.resolution, args.resolution), device=dev,
                                     seed=1000 * rank)  # every rank renders different images
@@ -155,7 +157,7 @@ def main():
             "config": {"workload": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+LBS(20 bones)+raster/interp/antialias "
                                    "+ SDF/texture/DINO/light MLPs + photometric/mask/DINO losses, fwd+bwd+Adam" % args.grid_res,
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "resolution": [args.resolution, args.resolution],
-                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}"},
+                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}", "tuned_mlp_gemms": bool(tuned)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,
