@@ -25,6 +25,7 @@ SOURCES = {
     "raster.hip": ["-ffp-contract=off"],
     "interp.hip": [],
     "gbuffer.hip": [],
+    "segsum.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",

@@ -134,7 +134,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     b, h, w = bhw
     dev = pos.device
     img = torch.div(pix, h * w, rounding_mode="floor")
-    per_img = lambda t: None if t is None else (t.index_select(0, img) if t.shape[0] == b else t.expand(pix.shape[0], -1))
+    per_img = lambda t: None if t is None else (_rows_per_point(t, img, b) if t.shape[0] == b else t.expand(pix.shape[0], -1))
 
     # The two coordinate MLPs see the point list padded to a multiple of POINT_BUCKET rows (zeros; outputs sliced off again):
     # the GEMM shapes then repeat from step to step, which is what rocBLAS/hipBLASLt kernel selection and TunableOp key on.
@@ -143,7 +143,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     if n_pad:
         img_p = torch.cat((img, img.new_zeros(n_pad)))
         tex_in = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))
-        per_img_p = lambda t: None if t is None else (t.index_select(0, img_p) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
+        per_img_p = lambda t: None if t is None else (_rows_per_point(t, img_p, b) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
     else:
         tex_in, per_img_p = tex_pos, per_img
     if material is not None:
@@ -155,7 +155,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
 
     view = view_pos.reshape(-1, 3)
     nrm = ru.prepare_shading_normal(pos, per_img(view), None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
-    rot = w2c[:, :3, :3].index_select(0, img)  # [P,3,3]
+    rot = _rows_per_point(w2c[:, :3, :3].reshape(b, 9), img, b).view(-1, 3, 3) if w2c.shape[0] == b else w2c[:, :3, :3].expand(img.shape[0], 3, 3)
     cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs
 
     _resolve_bsdf(bsdf, material)
@@ -165,7 +165,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     elif isinstance(lgt, light.EnvironmentLight):
         raise NotImplementedError("EnvironmentLight is outside the hot path")
     else:
-        params = lgt(feat).index_select(0, img)  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+        params = _rows_per_point(lgt(feat), img, b)  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
         shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
         shaded_col = shading * kd
 
@@ -180,6 +180,10 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
         dense = torch.zeros(b * h * w, vals.shape[-1], dtype=vals.dtype, device=vals.device)
         out[mode] = dense.index_copy(0, pix, vals).view(b, h, w, -1)
     return out
+
+
+def _rows_per_point(t, img, b):
+    return ops.rows_per_point(t, img)
 
 
 FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred"))

@@ -6,6 +6,7 @@ with find_unused_parameters=False in the reference.  Noth
 """
 from __future__ import annotations
 
+import math
 from collections import OrderedDict
 
 import torch
@@ -306,6 +307,33 @@ def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix):
     semantics are implied: the gradient to ``clip`` is produced here, not through ``rast``.
     """
     return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix)
+
+
+# ---------------------------------------------------------------------------------------------- per-image rows <-> points
+class _RowsPerPoint(torch.autograd.Function):
+    """t[img] for a per-image tensor t [B,C] and a point -> image map img [P]; backward = per-image segment sums (csrc/segsum.hip)
+    instead of index_add's P x C float atomics onto B rows."""
+
+    @staticmethod
+    def forward(ctx, t, img):
+        ctx.save_for_backward(img)
+        ctx.b = t.shape[0]
+        return t.index_select(0, img)
+
+    @staticmethod
+    def backward(ctx, g):
+        (img,) = ctx.saved_tensors
+        g = f32c(g)
+        P, C = g.shape[0], int(math.prod(g.shape[1:]))
+        out = torch.empty((ctx.b,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
+        call("a3d_rows_segsum", ptr(g), ptr(img), P, C, ctx.b, ptr(out), stream())
+        return out, None
+
+
+def rows_per_point(t, img):
+    """t [B,...] -> [P,...] rows gathered by img [P] (int64, contiguous)."""
+    require_device(t, img, what="rows_per_point")
+    return _RowsPerPoint.apply(t, img) if (t.requires_grad and torch.is_grad_enabled()) else t.index_select(0, img)
 
 
 # ---------------------------------------------------------------------------------------------- antialias

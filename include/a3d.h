@@ -122,6 +122,12 @@ int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, c
                     float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of
+ * broadcasting per-image rows (feat / light / w2c, render.py:53-94) to the covered pixels.  Replaces torch index_add.
+ */
+int a3d_rows_segsum(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Antialias -- replaces dr.antialias(color, rast, pos, tri), /root/reference/model/render/render.py:264-267.
  *   a3d_aa_topology : once per mesh topology: opp[F,3] = vertex opposite edge i in the adjacent triangle, -1 on
  *                     a boundary (nvdiffrast's topology hash).  hash = scratch of a3d_aa_hash_bytes(F) bytes.
