@@ -119,12 +119,23 @@ def main():
                                  algorithmic_MB=None if ab is None else round(ab / 1e6, 3),
                                  GBps=None if ab is None else round(ab / (mean_ms * 1e-3) / 1e9, 1))
             total_ms += mean_ms * per_step
-        # dominant = most time per step among the entry points that are a single streaming kernel with a byte model
+        # dominant = most time per step among the C-ABI entry points (all have a byte model)
         cand = {k: v for k, v in kernels.items() if v["GBps"] is not None}
         dom = max(cand, key=lambda k: cand[k]["mean_us"] * cand[k]["launches_per_step"])
+        # bytes-weighted aggregate over the whole HIP path: sum(algorithmic bytes) / sum(time), per step
+        tot_b = sum(v["algorithmic_MB"] * v["launches_per_step"] for v in cand.values()) * 1e6
+        tot_t = sum(v["mean_us"] * v["launches_per_step"] for v in cand.values()) * 1e-6
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed)
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))["per_call"].get(dom.split("[")[0])
+            traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
         roofline = dict(kernel=dom, bound="hbm", achieved=cand[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=None, launch_us=cand[dom]["mean_us"],
-                        algorithmic_MB_per_launch=cand[dom]["algorithmic_MB"], hip_path_ms_per_step=round(total_ms, 3), mesh=dims)
+                        frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
+                        algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6),
+                        hip_path=dict(ms_per_step=round(total_ms, 3), algorithmic_MB_per_step=round(tot_b / 1e6, 1),
+                                      GBps=round(tot_b / tot_t / 1e9, 1), frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4)),
+                        mesh=dims)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
