@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
 // ---- backward.  Scatter targets are aggregated per workgroup in an LDS hash table keyed by vertex row (b*V + v):
 // the 256 consecutive covered pixels of a block reference ~770 vertices but only ~150-200 distinct ones, so the 36
 // float atomics per pixel go to LDS (ds_add_f32) and each distinct vertex is flushed to HBM/L2 once (12 atomics).
-#define GB_SLOTS 1024
+#define GB_SLOTS 512
 #define GB_PROBES 16
 
 __device__ __forceinline__ int gb_slot(int* s_key, int key) {
-    unsigned h = ((unsigned)key * 2654435761u) >> 22;  // top 10 bits
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;  // top 9 bits
 #pragma unroll 1
     for (int t = 0; t < GB_PROBES; ++t) {
         const int old = atomicCAS(&s_key[h], -1, key);

@@ -103,9 +103,13 @@ def main():
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
     if rank == 0:
-        with L.KernelTimer() as timer:
+        import contextlib
+
+        # rank 0 alone re-runs a few steps under HIP-event timers; with DDP that must not enqueue collectives the other ranks
+        # never join, hence no_sync() (local gradients only) and no optimizer step
+        with L.KernelTimer() as timer, (module.no_sync() if module is not None else contextlib.nullcontext()):
             for _ in range(min(args.steps, 10)):
-                scene.step(module=module) if world == 1 else scene.step(module=None, optimizer_step=False)
+                scene.step(module=module, optimizer_step=(world == 1))
         prior, shape = scene.last["prior"], scene.last["shape"]
         dims = dict(B=args.batch, V=int(prior.v_pos.shape[1]), F=int(prior.t_pos_idx.shape[1]), H=args.resolution, W=args.resolution,
                     Nv=int(scene.netShape.verts.shape[0]), Ne=int(scene.netShape.topology.edges32.shape[0]),
