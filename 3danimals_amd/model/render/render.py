@@ -127,8 +127,23 @@ def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_po
                          two_sided_shading, dino_net, class_vector)
 
 
+class SparseBuffers(dict):
+    """mode -> [P,C] values at the covered pixels ``pix`` (flat indices into [B,H,W]); what the fused path hands to the compositor."""
+
+    def __init__(self, pix, bhw):
+        super().__init__()
+        self.pix, self.bhw = pix, bhw
+
+    def dense(self, mode):
+        """[B,H,W,C+1] with alpha 1 on covered pixels, zeros elsewhere (the layout render_layer returns in the reference)."""
+        b, h, w = self.bhw
+        vals = self[mode]
+        out = torch.zeros(b * h * w, vals.shape[-1] + 1, dtype=vals.dtype, device=vals.device)
+        return out.index_copy(0, self.pix, torch.cat((vals, torch.ones_like(vals[:, :1])), dim=-1)).view(b, h, w, -1)
+
+
 def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lgt, material, bsdf, feat, render_modes, two_sided_shading,
-                  dino_net, class_vector):
+                  dino_net, class_vector, sparse=False):
     """The arithmetic of shade() (reference render.py:30-132) on compact [P,.] arrays; scatters into dense [B,H,W,C+1]
     buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points."""
     b, h, w = bhw
@@ -171,15 +186,11 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
 
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
-    out = {}
-    ones = torch.ones(pix.shape[0], 1, device=dev)
+    out = SparseBuffers(pix, (b, h, w))
     for mode in modes:
-        if mode not in buffers:
-            continue
-        vals = torch.cat((buffers[mode], ones), dim=-1)
-        dense = torch.zeros(b * h * w, vals.shape[-1], dtype=vals.dtype, device=vals.device)
-        out[mode] = dense.index_copy(0, pix, vals).view(b, h, w, -1)
-    return out
+        if mode in buffers:
+            out[mode] = buffers[mode]
+    return out if sparse else {mode: out.dense(mode) for mode in out}
 
 
 def _rows_per_point(t, img, b):
@@ -190,7 +201,7 @@ FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "
 
 
 def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
-                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None, clip=None):
+                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None, clip=None, sparse=False):
     """G-buffer interpolation + shading of one depth layer (reference render.py:139-221).
 
     ``clip`` (the [B,V,4] clip-space vertices, not in the reference signature) enables the fused path: one HIP kernel builds
@@ -211,7 +222,7 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
         pix = torch.nonzero(rast[..., 3].reshape(-1) > 0).squeeze(1)  # one host sync for the number of covered pixels
         gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], None, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
-                             render_modes, two_sided_shading, dino_net, class_vector)
+                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse)
 
     rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
     gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)
@@ -275,7 +286,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
                             prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
-                            class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None)
+                            class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
 
     if background is not None:
         if spp > 1:
@@ -291,12 +302,24 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         if key not in rendered:
             out_buffers.append(None)
             continue
-        buf = rendered[key]
-        bg = background if key in ("shaded", "geo_normal", "shading") else torch.zeros_like(buf)
-        if key == "shading" and bg.shape[-1] == 4:
-            bg = bg[..., 2:]
-        alpha = coverage * buf[..., -1:]
-        accum = torch.lerp(bg, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)  # render.py:261-262
+        if isinstance(rendered, SparseBuffers):
+            # coverage is 0 or 1, for which lerp(bg, [rgb,1], alpha) (render.py:261-262) returns exactly bg or exactly [rgb,1]:
+            # start from the background and overwrite the covered pixels -- same bits, a third of the passes over the image
+            vals = rendered[key]
+            c1 = vals.shape[-1] + 1
+            if key in ("shaded", "geo_normal", "shading"):
+                bgk = background[..., 2:] if (key == "shading" and background.shape[-1] == 4) else background
+                accum = bgk.expand(rast.shape[0], -1, -1, -1).clone()
+            else:
+                accum = torch.zeros(*rast.shape[:3], c1, dtype=torch.float32, device=dev)
+            accum.view(-1, c1).index_copy_(0, rendered.pix, torch.cat((vals, torch.ones_like(vals[:, :1])), dim=-1))
+        else:
+            buf = rendered[key]
+            bg = background if key in ("shaded", "geo_normal", "shading") else torch.zeros_like(buf)
+            if key == "shading" and bg.shape[-1] == 4:
+                bg = bg[..., 2:]
+            alpha = coverage * buf[..., -1:]
+            accum = torch.lerp(bg, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)  # render.py:261-262
         if key in ANTIALIASED_MODES:
             if analysis is None:
                 tri32 = ops.tri_int32(tri)
