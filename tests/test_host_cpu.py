@@ -294,3 +294,18 @@ def test_nvdiffrast_shim_surface():
             dr.rasterize(ctx, torch.rand(1, 3, 3), torch.zeros(1, 3, dtype=torch.int32), [8, 8])
     finally:
         sys.path.remove(shim)
+
+
+def test_write_obj_format(tmp_path):
+    """The exported text matches what the reference's per-element writes produce (obj.py:128-177)."""
+    M = importlib.import_module("3danimals_amd.model.render.mesh")
+    obj = importlib.import_module("3danimals_amd.model.render.obj")
+    v = torch.tensor([[[0.0, 0.5, 1.0], [1.0, 0.0, 0.25], [0.0, 1.0, 0.125]]])
+    f = torch.tensor([[[0, 1, 2]]])
+    m = M.Mesh(v, f, v_nrm=torch.tensor([[[0.0, 0.0, 1.0]] * 3]), t_nrm_idx=f, v_tex=torch.tensor([[[0.0, 0.0], [1.0, 0.0], [0.0, 0.25]]]), t_tex_idx=f)
+    obj.write_obj(str(tmp_path), "m", m, 0, save_material=True)
+    text = open(tmp_path / "m.obj").read().splitlines()
+    assert text[0] == "mtllib m.mtl" and text[1] == "g default"
+    assert text[2] == "v 0.0 0.5 1.0 " and text[5] == "vt 0.0 1.0 " and text[7] == "vt 0.0 0.75 "
+    assert text[8] == "vn 0.0 0.0 1.0"
+    assert text[-1] == "f  1/1/1 2/2/2 3/3/3" and "usemtl defaultMat" in text
