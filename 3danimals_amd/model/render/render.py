@@ -168,19 +168,24 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     kd, ks = all_tex[..., :3], all_tex[..., 3:6]
     dino_pred = dino_net.sample(tex_in, feat=per_img_p(class_vector))[:n_pts] if dino_net is not None else None
 
+    # the narrow per-image quantities (camera rotation 9, view position 3, light parameters 5) travel to the points as ONE gather
+    _resolve_bsdf(bsdf, material)
+    if lgt is not None and isinstance(lgt, light.EnvironmentLight):
+        raise NotImplementedError("EnvironmentLight is outside the hot path")
     view = view_pos.reshape(-1, 3)
-    nrm = ru.prepare_shading_normal(pos, per_img(view), None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
-    rot = _rows_per_point(w2c[:, :3, :3].reshape(b, 9), img, b).view(-1, 3, 3) if w2c.shape[0] == b else w2c[:, :3, :3].expand(img.shape[0], 3, 3)
+    cols = [w2c[:, :3, :3].reshape(-1, 9).expand(b, 9), view.expand(b, 3)]
+    if lgt is not None:
+        cols.append(lgt(feat))  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+    per_point = _rows_per_point(torch.cat(cols, dim=-1), img, b)
+    rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
+    nrm = ru.prepare_shading_normal(pos, view_p, None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
     cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs
 
-    _resolve_bsdf(bsdf, material)
     shading = None
     if lgt is None:
         shaded_col = kd
-    elif isinstance(lgt, light.EnvironmentLight):
-        raise NotImplementedError("EnvironmentLight is outside the hot path")
     else:
-        params = _rows_per_point(lgt(feat), img, b)  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+        params = per_point[:, 12:17]
         shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
         shaded_col = shading * kd
 
