@@ -72,58 +72,23 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     }
 }
 
-// ---- backward, two kernels.
-// (1) g_v = sum_k w_k R_k^T g : one thread per (image, vertex), no reduction (mirror of the forward).
-__global__ __launch_bounds__(SK_THREADS) void sk_bwd_v_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
-                                                              const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
-                                                              int V, int K, float neg_inv_temp, float* __restrict__ g_v) {
+// ---- backward, one kernel, two phases per 256-vertex chunk.
+// phase 1 (thread = vertex): softmax weights once (into LDS, [K][256]) and g_v = sum_k w_k R_k^T g (written per image; a shared
+//          canonical mesh is summed over the batch by the caller).
+// phase 2 (wave = bone group): g_T[b,k] = sum_v w_k(v) * g(v) (x) [v,1] -- a [K x V].[V x 12] product per image.  Wave w owns the bones
+//          [w*KG, (w+1)*KG); every lane keeps KG x 12 partial sums in registers while it strides over the chunk's vertices in LDS, and
+//          the cross-lane reduction happens once per block (KG*12 butterfly sums), not once per vertex.
+template <int KG>
+__global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
+                                                            const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
+                                                            int V, int K, float neg_inv_temp, int chunks_per_block, float* __restrict__ g_v,
+                                                            float* __restrict__ g_T) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
+    __shared__ float s_w[4 * KG][SK_THREADS];
+    __shared__ float s_x[6][SK_THREADS];  // px py pz gx gy gz
     const int b = blockIdx.y;
     sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
-    __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + i) * 3;
-    const float* g = g_out + ((long long)b * V + i) * 3;
-    const float px = p[0], py = p[1], pz = p[2], gx = g[0], gy = g[1], gz = g[2];
-    float m = -INFINITY;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
-    float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float e = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
-        const float* t = s_T + 12 * k;
-        s += e;
-        ox += e * (t[0] * gx + t[4] * gy + t[8] * gz);
-        oy += e * (t[1] * gx + t[5] * gy + t[9] * gz);
-        oz += e * (t[2] * gx + t[6] * gy + t[10] * gz);
-    }
-    const float inv = 1.f / s;
-    float* o = g_v + ((long long)b * V + i) * 3;  // per image; a shared canonical mesh is summed over the batch by the caller
-    o[0] = ox * inv; o[1] = oy * inv; o[2] = oz * inv;
-}
-
-// (2) g_T[b,k] = sum_v w_k(v) * g(v) (x) [v,1]  -- a [K x V] . [V x 12] product per image.  Wave w of the block owns the
-// bones [w*KG, (w+1)*KG); every lane keeps KG x 12 partial sums in registers while it strides over the vertices, and
-// the cross-lane reduction happens ONCE per block (KG*12 butterfly sums) instead of once per vertex.
-template <int KG>
-__global__ __launch_bounds__(SK_THREADS) void sk_bwd_T_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
-                                                              const float* __restrict__ bones, int bones_batch, int V, int K,
-                                                              float neg_inv_temp, float* __restrict__ g_T) {
-    __shared__ SkBone s_bone[SK_MAXK];
-    const int b = blockIdx.y;
-    {
-        const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6);
-        for (int k = threadIdx.x; k < K; k += blockDim.x) {
-            const float* q = bb + 6 * k;
-            SkBone sb;
-            sb.ax = q[0]; sb.ay = q[1]; sb.az = q[2];
-            sb.dx = q[3] - q[0]; sb.dy = q[4] - q[1]; sb.dz = q[5] - q[2];
-            sb.inv_len2 = 1.f / fmaxf(sb.dx * sb.dx + sb.dy * sb.dy + sb.dz * sb.dz, 1e-6f);
-            s_bone[k] = sb;
-        }
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = wave * KG;
     float acc[KG][12];
@@ -133,19 +98,48 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_T_kernel(const float* __res
         for (int q = 0; q < 12; ++q) acc[kk][q] = 0.f;
     const float* vb = v + (v_batch == 1 ? 0ll : (long long)b * V * 3);
     const float* gb = g_out + (long long)b * V * 3;
-    for (int i = blockIdx.x * 64 + lane; i < V; i += 64 * gridDim.x) {
-        const float px = vb[3ll * i], py = vb[3ll * i + 1], pz = vb[3ll * i + 2];
-        const float gx = gb[3ll * i], gy = gb[3ll * i + 1], gz = gb[3ll * i + 2];
-        float m = -INFINITY;
-        for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
-        const float inv = 1.f / s;
+    for (int ch = 0; ch < chunks_per_block; ++ch) {
+        const int base = (blockIdx.x * chunks_per_block + ch) * SK_THREADS;
+        if (base >= V) break;  // uniform
+        __syncthreads();       // previous chunk's LDS fully consumed (also orders sk_stage on the first trip)
+        {
+            const int i = base + threadIdx.x;
+            float px = 0.f, py = 0.f, pz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+            const bool ok = i < V;
+            if (ok) {
+                px = vb[3ll * i]; py = vb[3ll * i + 1]; pz = vb[3ll * i + 2];
+                gx = gb[3ll * i]; gy = gb[3ll * i + 1]; gz = gb[3ll * i + 2];
+            }
+            float m = -INFINITY;
+            for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
+            const float inv = 1.f / s;
+            float ox = 0.f, oy = 0.f, oz = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float w = ok ? __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m) * inv : 0.f;
+                s_w[k][threadIdx.x] = w;
+                const float* t = s_T + 12 * k;
+                ox += w * (t[0] * gx + t[4] * gy + t[8] * gz);
+                oy += w * (t[1] * gx + t[5] * gy + t[9] * gz);
+                oz += w * (t[2] * gx + t[6] * gy + t[10] * gz);
+            }
+            s_x[0][threadIdx.x] = px; s_x[1][threadIdx.x] = py; s_x[2][threadIdx.x] = pz;
+            s_x[3][threadIdx.x] = gx; s_x[4][threadIdx.x] = gy; s_x[5][threadIdx.x] = gz;
+            if (ok && g_v) {
+                float* o = g_v + ((long long)b * V + i) * 3;
+                o[0] = ox; o[1] = oy; o[2] = oz;
+            }
+        }
+        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < KG; ++kk) {
-            const int k = k0 + kk;
-            if (k < K) {
-                const float w = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m) * inv;
+        for (int j = 0; j < SK_THREADS / 64; ++j) {
+            const int t = j * 64 + lane;
+            const float px = s_x[0][t], py = s_x[1][t], pz = s_x[2][t], gx = s_x[3][t], gy = s_x[4][t], gz = s_x[5][t];
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                const int k = k0 + kk;
+                const float w = k < K ? s_w[k < K ? k : 0][t] : 0.f;
                 const float wx = w * gx, wy = w * gy, wz = w * gz;
                 acc[kk][0] += wx * px; acc[kk][1] += wx * py; acc[kk][2] += wx * pz; acc[kk][3] += wx;
                 acc[kk][4] += wy * px; acc[kk][5] += wy * py; acc[kk][6] += wy * pz; acc[kk][7] += wy;
@@ -183,19 +177,14 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
     A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
-    if (g_v_or_null) {
-        hipLaunchKernelGGL(sk_bwd_v_kernel, dim3(a3d_div_up(V, SK_THREADS), B), dim3(SK_THREADS), 0, s, g_out, v, v_batch, bones, bones_batch, T, V,
-                           K, nit, g_v_or_null);
-        A3D_LAUNCH_CHECK();
-    }
-    // enough blocks per image to occupy the chip, but >= ~8 vertices per lane so the block-level reduction amortises
-    int nb = a3d_div_up(V, 64 * 8);
-    const int cap = (1024 + B - 1) / B;
-    nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
-    const dim3 grid(nb, B), block(SK_THREADS);
-    if (K <= 20) hipLaunchKernelGGL((sk_bwd_T_kernel<5>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
-    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_T_kernel<8>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
-    else hipLaunchKernelGGL((sk_bwd_T_kernel<16>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, V, K, nit, g_T);
+    // one 256-vertex chunk per block while that already gives >= 1024 blocks; more chunks per block for very large meshes
+    const int chunks = a3d_div_up(V, SK_THREADS);
+    int cpb = a3d_div_up((long long)chunks * B, 4096);
+    if (cpb < 1) cpb = 1;
+    const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
+    if (K <= 20) hipLaunchKernelGGL((sk_bwd_kernel<5>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
+    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_kernel<8>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
+    else hipLaunchKernelGGL((sk_bwd_kernel<16>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
