@@ -202,6 +202,27 @@ def _rows_per_point(t, img, b):
     return ops.rows_per_point(t, img)
 
 
+PIXEL_TILE = 8  # covered pixels are listed tile by tile (0 = plain row-major order)
+
+
+def _covered_pixels(rast):
+    """Flat indices (b*H + y)*W + x of the covered pixels, image-major and, inside an image, in 8x8-tile order: consecutive
+    entries then touch the same few triangles, which is what the G-buffer kernels' gathers and LDS scatter aggregation like."""
+    b, h, w = rast.shape[:3]
+    cover = rast[..., 3] > 0
+    t = PIXEL_TILE
+    if not t or h % t or w % t:
+        return torch.nonzero(cover.reshape(-1)).squeeze(1)
+    tiled = cover.view(b, h // t, t, w // t, t).permute(0, 1, 3, 2, 4).reshape(-1)
+    k = torch.nonzero(tiled).squeeze(1)
+    ix = k % t
+    iy = (k // t) % t
+    tx = (k // (t * t)) % (w // t)
+    ty = (k // (t * t * (w // t))) % (h // t)
+    bb = k // (h * w)
+    return (bb * h + ty * t + iy) * w + tx * t + ix
+
+
 FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred"))
 
 
@@ -224,7 +245,7 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
              and clip.shape[0] == mesh.v_pos.shape[0] and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr())
     if fused:
         b, h, w = rast.shape[:3]
-        pix = torch.nonzero(rast[..., 3].reshape(-1) > 0).squeeze(1)  # one host sync for the number of covered pixels
+        pix = _covered_pixels(rast)  # one host sync for the number of covered pixels
         gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], None, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
                              render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse)
