@@ -1,0 +1,211 @@
+// Per-bone world transforms from the kinematic chain on gfx950: one thread per (image, bone).
+//
+// Replaces the inner loops of skinning() (model/geometry/skinning.py:389-417): for every bone the reference walks its
+// kinematic chain leaf -> root composing Rest_i . Rot(euler_i) . Rest_i^-1 one 4x4 torch op at a time (~24k aten calls
+// per forward at K=20, B=16).  Here thread (n,k) rebuilds the <= 8 links of its chain in registers:
+//     L_i = [ R_i Rot_i R_i^T | t_i - R_i Rot_i R_i^T t_i ],   M_k = L_root ... L_parent(k) L_k        (3x4 affine)
+// with R_i the rest frame from the bone direction (columns right, up, forward; right ~ +x; skinning.py:251-270), t_i the
+// bone's start joint and Rot_i = Rx Ry Rz (PyTorch3D 'XYZ', skinning.py:285-340).
+// Backward: g_L_j = P_j^T g_M S_j^T with prefix/suffix products of the chain, pushed through the conjugation and the Euler
+// factors onto the three angles (float atomics: a link is shared by every bone below it).  Bones carry no gradient.
+// A few hundred threads in total; the point is 2 launches instead of ~80 tiny ones on a host-bound stretch of the step.
+#include "a3d_common.h"
+
+#define BN_MAXD 8
+
+struct A34 {  // row-major 3x4 affine (last row 0 0 0 1 implied)
+    float m[12];
+};
+
+__device__ __forceinline__ A34 bn_identity() {
+    A34 a;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.m[i] = 0.f;
+    a.m[0] = a.m[5] = a.m[10] = 1.f;
+    return a;
+}
+
+__device__ __forceinline__ A34 bn_mul(const A34& a, const A34& b) {  // a . b
+    A34 c;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            float s = a.m[4 * r] * b.m[col] + a.m[4 * r + 1] * b.m[4 + col] + a.m[4 * r + 2] * b.m[8 + col];
+            if (col == 3) s += a.m[4 * r + 3];
+            c.m[4 * r + col] = s;
+        }
+    }
+    return c;
+}
+
+__device__ __forceinline__ void bn_normalize(float& x, float& y, float& z) {  // torch.nn.functional.normalize, eps 1e-12
+    const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    x /= n; y /= n; z /= n;
+}
+
+// rest frame R (row-major 3x3, columns right | up | forward) of a bone a -> b   (skinning.py:251-270)
+__device__ __forceinline__ void bn_rest(const float* __restrict__ bone, float R[9], float t[3]) {
+    float fx = bone[3] - bone[0], fy = bone[4] - bone[1], fz = bone[5] - bone[2];
+    bn_normalize(fx, fy, fz);
+    // up = normalize(forward x (1,0,0)) = normalize(0, fz, -fy)
+    float ux = 0.f, uy = fz, uz = -fy;
+    bn_normalize(ux, uy, uz);
+    // right = up x forward
+    const float rx = uy * fz - uz * fy, ry = uz * fx - ux * fz, rz = ux * fy - uy * fx;
+    bn_normalize(ux, uy, uz);
+    R[0] = rx; R[1] = ux; R[2] = fx;
+    R[3] = ry; R[4] = uy; R[5] = fy;
+    R[6] = rz; R[7] = uz; R[8] = fz;
+    t[0] = bone[0]; t[1] = bone[1]; t[2] = bone[2];
+}
+
+__device__ __forceinline__ void bn_euler(const float* __restrict__ ang, float Rot[9]) {  // Rx(x) Ry(y) Rz(z)
+    const float cx = cosf(ang[0]), sx = sinf(ang[0]), cy = cosf(ang[1]), sy = sinf(ang[1]), cz = cosf(ang[2]), sz = sinf(ang[2]);
+    Rot[0] = cy * cz;                 Rot[1] = -cy * sz;                Rot[2] = sy;
+    Rot[3] = sx * sy * cz + cx * sz;  Rot[4] = -sx * sy * sz + cx * cz; Rot[5] = -sx * cy;
+    Rot[6] = -cx * sy * cz + sx * sz; Rot[7] = cx * sy * sz + sx * cz;  Rot[8] = cx * cy;
+}
+
+__device__ __forceinline__ void bn_mat3(const float A[9], const float B[9], float C[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+__device__ __forceinline__ A34 bn_link(const float* __restrict__ bone, const float* __restrict__ ang) {
+    float R[9], t[3], Rot[9], T1[9], Lr[9];
+    bn_rest(bone, R, t);
+    bn_euler(ang, Rot);
+    bn_mat3(R, Rot, T1);
+    // Lr = T1 . R^T
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Lr[3 * r + c] = T1[3 * r] * R[3 * c] + T1[3 * r + 1] * R[3 * c + 1] + T1[3 * r + 2] * R[3 * c + 2];
+    A34 L;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        L.m[4 * r] = Lr[3 * r]; L.m[4 * r + 1] = Lr[3 * r + 1]; L.m[4 * r + 2] = Lr[3 * r + 2];
+        L.m[4 * r + 3] = t[r] - (Lr[3 * r] * t[0] + Lr[3 * r + 1] * t[1] + Lr[3 * r + 2] * t[2]);
+    }
+    return L;
+}
+
+__global__ __launch_bounds__(64) void bn_fwd_kernel(const float* __restrict__ bones, int bones_batch, const float* __restrict__ angles,
+                                                    const int* __restrict__ chain, int N, int K, int D, float* __restrict__ M) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * K) return;
+    const int n = idx / K, k = idx - n * K;
+    const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)n * K * 6);
+    const float* aa = angles + (long long)n * K * 3;
+    A34 acc = bn_identity();
+    for (int j = 0; j < D; ++j) {
+        const int i = chain[k * D + j];
+        if (i < 0) continue;
+        acc = bn_mul(acc, bn_link(bb + 6 * i, aa + 3 * i));
+    }
+    float* o = M + (long long)idx * 12;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) o[q] = acc.m[q];
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_kernel(const float* __restrict__ g_M, const float* __restrict__ bones, int bones_batch,
+                                                    const float* __restrict__ angles, const int* __restrict__ chain, int N, int K, int D,
+                                                    float* __restrict__ g_angles) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * K) return;
+    const int n = idx / K, k = idx - n * K;
+    const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)n * K * 6);
+    const float* aa = angles + (long long)n * K * 3;
+    const float* g = g_M + (long long)idx * 12;
+    // prefix products P_j = L_0 ... L_{j-1}
+    A34 P[BN_MAXD];
+    A34 run = bn_identity();
+#pragma unroll
+    for (int j = 0; j < BN_MAXD; ++j) {
+        P[j] = run;
+        if (j < D) {
+            const int i = chain[k * D + j];
+            if (i >= 0) run = bn_mul(run, bn_link(bb + 6 * i, aa + 3 * i));
+        }
+    }
+    A34 S = bn_identity();  // suffix product L_{j+1} ... L_{D-1}
+#pragma unroll
+    for (int jj = 0; jj < BN_MAXD; ++jj) {
+        const int j = BN_MAXD - 1 - jj;
+        if (j >= D) continue;
+        const int i = chain[k * D + j];
+        if (i < 0) continue;
+        // G = P_j^T (3x3 part) . g_M . S^T   restricted to the 3x4 block of L_j:
+        //   M = P L S  =>  dL = P_r^T dM_full S_full^T, with dM's implied last row zero
+        float T1[12];  // P_r^T . g   (3x4)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T1[4 * r + c] = P[j].m[r] * g[c] + P[j].m[4 + r] * g[4 + c] + P[j].m[8 + r] * g[8 + c];
+        float GL[12];  // T1 . S_full^T, S_full = [S; 0 0 0 1]
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                GL[4 * r + c] = T1[4 * r] * S.m[4 * c] + T1[4 * r + 1] * S.m[4 * c + 1] + T1[4 * r + 2] * S.m[4 * c + 2] + T1[4 * r + 3] * S.m[4 * c + 3];
+            GL[4 * r + 3] = T1[4 * r + 3];
+        }
+        // link: Lr = R Rot R^T, Lt = t - Lr t   =>  g_Lr_total = g_Lr - g_Lt (x) t ;  g_Rot = R^T g_Lr_total R
+        float R[9], t[3];
+        bn_rest(bb + 6 * i, R, t);
+        float GLr[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) GLr[3 * r + c] = GL[4 * r + c] - GL[4 * r + 3] * t[c];
+        float T2[9], GRot[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) T2[3 * r + c] = R[r] * GLr[c] + R[3 + r] * GLr[3 + c] + R[6 + r] * GLr[6 + c];  // R^T . GLr
+        bn_mat3(T2, R, GRot);
+        // d Rot / d angles for Rot = Rx Ry Rz
+        const float x = aa[3 * i], y = aa[3 * i + 1], z = aa[3 * i + 2];
+        const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
+        const float dX[9] = {0.f, 0.f, 0.f,
+                             cx * sy * cz - sx * sz, -cx * sy * sz - sx * cz, -cx * cy,
+                             sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy};
+        const float dY[9] = {-sy * cz, sy * sz, cy,
+                             sx * cy * cz, -sx * cy * sz, sx * sy,
+                             -cx * cy * cz, cx * cy * sz, -cx * sy};
+        const float dZ[9] = {-cy * sz, -cy * cz, 0.f,
+                             -sx * sy * sz + cx * cz, -sx * sy * cz - cx * sz, 0.f,
+                             cx * sy * sz + sx * cz, cx * sy * cz - sx * sz, 0.f};
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { gx += GRot[q] * dX[q]; gy += GRot[q] * dY[q]; gz += GRot[q] * dZ[q]; }
+        float* o = g_angles + ((long long)n * K + i) * 3;
+        atomicAdd(o, gx); atomicAdd(o + 1, gy); atomicAdd(o + 2, gz);
+        S = bn_mul(bn_link(bb + 6 * i, aa + 3 * i), S);
+    }
+}
+
+extern "C" int a3d_bone_transforms_fwd(const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N, int K, int D,
+                                       float* M, a3d_stream_t stream) {
+    A3D_CHECK_ARG(bones && angles && chain && M && N > 0 && K > 0 && D > 0 && D <= BN_MAXD);
+    A3D_CHECK_ARG(bones_batch == 1 || bones_batch == N);
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(a3d_div_up((long long)N * K, 64)), dim3(64), 0, (hipStream_t)stream, bones, bones_batch, angles, chain, N,
+                       K, D, M);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N,
+                                       int K, int D, float* g_angles, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_M && bones && angles && chain && g_angles && N > 0 && K > 0 && D > 0 && D <= BN_MAXD);
+    A3D_CHECK_ARG(bones_batch == 1 || bones_batch == N);
+    hipStream_t s = (hipStream_t)stream;
+    A3D_HIP(hipMemsetAsync(g_angles, 0, sizeof(float) * 3 * (size_t)N * K, s));
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(a3d_div_up((long long)N * K, 64)), dim3(64), 0, s, g_M, bones, bones_batch, angles, chain, N, K, D,
+                       g_angles);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

@@ -21,6 +21,7 @@ SOURCES = {
     "common.hip": [],
     "dmtet.hip": ["-ffp-contract=off"],
     "skin.hip": [],
+    "bones.hip": [],
     "normals.hip": [],
     "raster.hip": ["-ffp-contract=off"],
     "interp.hip": [],

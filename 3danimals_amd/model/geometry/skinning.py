@@ -270,8 +270,26 @@ def _chain_index(kinematic_tree, device):
     return hit
 
 
-def bone_transforms(bones, kinematic_tree, deform_params):
-    """World transform of every bone for every image: [B*F, K, 4, 4].
+_chain32_cache = {}
+
+
+def _chain_index32(kinematic_tree, device):
+    """int32 [K,D] chain table for the HIP kernel: root -> leaf, front-padded with -1."""
+    key = (repr(kinematic_tree), str(device))
+    hit = _chain32_cache.get(key)
+    if hit is None:
+        idx = _chain_index(kinematic_tree, device)
+        K = idx.shape[0]
+        hit = torch.where(idx == K, torch.full_like(idx, -1), idx).to(torch.int32).contiguous()
+        if len(_chain32_cache) > 64:
+            _chain32_cache.clear()
+        _chain32_cache[key] = hit
+    return hit
+
+
+def bone_transforms_torch(bones, kinematic_tree, deform_params):
+    """(torch formulation; skinning() itself uses the HIP kernel csrc/bones.hip, this one documents and cross-checks it.)
+    World transform of every bone for every image: [B*F, K, 4, 4].
 
     M_k = L_root ... L_parent(k) L_k with L_i = Rest_i . Rot_i . Rest_i^-1 (reference :389-417), i.e. a rotation by
     the bone's Euler angles about its start joint expressed in its rest frame.  bones [1|B,1|F,K,2,3], deform_params [B,F,K,3].
@@ -331,8 +349,11 @@ def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bone
     """
     B, Fr = deform_params.shape[:2]
     K, V = bones_pred.shape[2], v_pos.shape[-2]
-    M = bone_transforms(bones_pred.detach(), kinematic_tree, deform_params)  # [B*F,K,4,4]
-    T = M[:, :, :3, :].reshape(B * Fr, K, 12)
+    # per-bone world transforms from the kinematic chain: one HIP launch (csrc/bones.hip), gradients reach deform_params
+    chain32 = _chain_index32(kinematic_tree, deform_params.device)
+    bones_nk = bones_pred.detach().reshape(-1, K, 2, 3) if (bones_pred.shape[0] == 1 and bones_pred.shape[1] == 1) else \
+        bones_pred.detach().expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
+    T = ops.bone_transforms(bones_nk, deform_params.reshape(B * Fr, K, 3), chain32)  # [B*F,K,12]
 
     def flat(x, tail):
         if x.shape[0] == 1 and x.shape[1] == 1:
@@ -354,6 +375,7 @@ def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bone
     aux["bones_pred"] = bones_pred
     if output_posed_bones:
         ends = bones_pred.detach().expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
-        posed = torch.einsum("nkij,nkej->nkei", M[:, :, :3, :3], ends) + M[:, :, None, :3, 3]
+        T34 = T.view(B * Fr, K, 3, 4)
+        posed = torch.einsum("nkij,nkej->nkei", T34[..., :3], ends) + T34[:, :, None, :, 3]
         aux["posed_bones"] = posed.view(B, Fr, K, 2, 3)
     return out, aux

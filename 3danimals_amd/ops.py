@@ -131,6 +131,34 @@ def dmtet(pos, sdf, grid):
     return verts0, faces, uv_idx
 
 
+# ---------------------------------------------------------------------------------------------- bone transforms
+class _BoneTransforms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bones, angles, chain):
+        require_device(bones, angles, chain, what="bone_transforms")
+        bones, angles = f32c(bones), f32c(angles)
+        N, K = angles.shape[0], angles.shape[1]
+        assert bones.shape[0] in (1, N) and bones.shape[1] == K and chain.shape[0] == K and chain.dtype == torch.int32
+        M = torch.empty((N, K, 12), dtype=torch.float32, device=angles.device)
+        call("a3d_bone_transforms_fwd", ptr(bones), bones.shape[0], ptr(angles), ptr(chain), N, K, chain.shape[1], ptr(M), stream())
+        ctx.save_for_backward(bones, angles, chain)
+        return M
+
+    @staticmethod
+    def backward(ctx, g_M):
+        bones, angles, chain = ctx.saved_tensors
+        N, K = angles.shape[0], angles.shape[1]
+        g_angles = torch.empty_like(angles)
+        call("a3d_bone_transforms_bwd", ptr(f32c(g_M)), ptr(bones), bones.shape[0], ptr(angles), ptr(chain), N, K, chain.shape[1], ptr(g_angles),
+             stream())
+        return None, g_angles, None
+
+
+def bone_transforms(bones, angles, chain):
+    """bones [1|N,K,2,3] (no grad), angles [N,K,3], chain int32 [K,D] (root -> leaf, -1 padded) -> M [N,K,12]."""
+    return _BoneTransforms.apply(bones, angles, chain)
+
+
 # ---------------------------------------------------------------------------------------------- skinning
 class _Skin(torch.autograd.Function):
     @staticmethod

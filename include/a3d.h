@@ -73,6 +73,19 @@ int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, const float* b
                  int V, int K, float temperature, float* g_v_or_null, float* g_T, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-bone world transforms from the kinematic chain -- replaces the chain-composition loops of skinning(),
+ * /root/reference/model/geometry/skinning.py:389-417 (+ _estimate_bone_rotation :251-270, euler_angles_to_matrix :315-340,
+ * _prepare/_invert_transform_mtx :343-366).  bones[bones_batch,K,2,3] (no gradient), angles[N,K,3] radians (Euler 'XYZ'),
+ * chain[K,D] int32: for bone k the bones of its chain root -> ... -> k, front-padded with -1 (D <= 8).
+ * M[N,K,12] = rows of the 3x4 affine  L_root ... L_k,  L_i = rotation by angles_i about bone i's start joint in its rest frame.
+ * Backward: g_angles[N,K,3] (zeroed by callee) from g_M.
+ */
+int a3d_bone_transforms_fwd(const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N, int K, int D, float* M,
+                            a3d_stream_t stream);
+int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N, int K,
+                            int D, float* g_angles, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Area-weighted vertex normals -- replaces auto_normals, /root/reference/model/render/mesh.py:276-304.
  * acc[B,V,3] receives the un-normalised sums (saved for backward), nrm[B,V,3] the result
  * (zero sums -> (0,0,1), then safe_normalize, mesh.py:296-299).

@@ -618,3 +618,23 @@ def test_dmtet_geometry_loads_reference_npz_and_sequence_skinning(tmp_path, dev,
     (shaded.sum() + flow.sum()).backward()
     assert ang.grad is not None and bool(torch.isfinite(ang.grad).all())
     assert all(p.grad is not None for p in geo.mlp.parameters())
+
+
+@pytest.mark.parametrize("tag", ["b1f1_t1", "b3f2_t005", "b2f2_inst"])
+def test_bone_transforms_kernel_vs_torch_chain(tag, dev, mods):
+    """csrc/bones.hip (one launch) against the level-batched torch composition that is itself pinned to the reference goldens."""
+    ops = importlib.import_module("3danimals_amd.ops")
+    sk = mods["skinning"]
+    g = golden(f"skinning_{tag}.npz")
+    chain = eval(str(g["chain"]))
+    bones = torch.from_numpy(g["bones"]).to(dev)
+    ang = torch.from_numpy(g["angles"]).to(dev)
+    B, Fr, K = ang.shape[:3]
+    a1, a2 = ang.clone().requires_grad_(True), ang.clone().requires_grad_(True)
+    ref = sk.bone_transforms_torch(bones, chain, a1)[:, :, :3, :].reshape(B * Fr, K, 12)
+    out = ops.bone_transforms(bones.reshape(-1, K, 2, 3), a2.reshape(B * Fr, K, 3), sk._chain_index32(chain, dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=3e-6)
+    wgt = seeded(ref.shape, 17, -1, 1).to(dev)
+    (g1,) = torch.autograd.grad((ref * wgt).sum(), a1)
+    (g2,) = torch.autograd.grad((out * wgt).sum(), a2)
+    np.testing.assert_allclose(g2.cpu().numpy(), g1.cpu().numpy(), rtol=1e-4, atol=1e-4)

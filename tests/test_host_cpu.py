@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "a3d.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 23
+    assert len(declared) >= 25
     L = importlib.import_module("3danimals_amd._lib")
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
@@ -207,7 +207,7 @@ def test_bone_transforms_and_posed_bones_match_reference(tag):
     chain = eval(str(g["chain"]))
     bones = torch.from_numpy(g["bones"])
     ang = torch.from_numpy(g["angles"]).requires_grad_(True)
-    M = sk.bone_transforms(bones, chain, ang)
+    M = sk.bone_transforms_torch(bones, chain, ang)
     ref = skinning_ref.bone_transforms(bones, chain, ang.detach())
     for k in range(20):
         np.testing.assert_allclose(M[:, k].detach().numpy(), ref[k].expand(M.shape[0], 4, 4).numpy(), atol=2e-6)
@@ -216,7 +216,7 @@ def test_bone_transforms_and_posed_bones_match_reference(tag):
     posed = (torch.einsum("nkij,nkej->nkei", M[:, :, :3, :3], ends) + M[:, :, None, :3, 3]).view(B, Fr, 20, 2, 3)
     np.testing.assert_allclose(posed.detach().numpy(), g["posed_bones"], atol=5e-6)
     # zero angles -> identity transforms
-    M0 = sk.bone_transforms(bones, chain, torch.zeros_like(ang))
+    M0 = sk.bone_transforms_torch(bones, chain, torch.zeros_like(ang))
     np.testing.assert_allclose(M0.numpy(), np.broadcast_to(np.eye(4, dtype=np.float32), M0.shape), atol=1e-6)
 
 
