@@ -638,3 +638,32 @@ def test_bone_transforms_kernel_vs_torch_chain(tag, dev, mods):
     (g1,) = torch.autograd.grad((ref * wgt).sum(), a1)
     (g2,) = torch.autograd.grad((out * wgt).sum(), a2)
     np.testing.assert_allclose(g2.cpu().numpy(), g1.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_max_size_grid_and_raster_properties(dev, mods, ops):
+    """Kuhn R=128 (the reference's grid_res=256 regime: 2.1M grid vertices, 12.6M tets) and a 512x512 render of its mesh."""
+    from oracle import raster_ref, render_ref
+
+    pos, tets = kuhn(128)
+    sdf = mods["synthetic"].quadruped_sdf(pos, 0.2).to(dev)
+    dm = mods["dmtet"].DMTet()
+    pos_d, tets_d = pos.to(dev), tets.to(dev)
+    v1, f1, _, u1 = dm(pos_d, sdf, tets_d)
+    v2, f2, _, u2 = dm(pos_d, sdf, tets_d)
+    assert torch.equal(v1, v2) and torch.equal(f1, f2) and torch.equal(u1, u2)  # deterministic
+    V, F = v1.shape[0], f1.shape[0]
+    assert F > 40000 and int(f1.max()) == V - 1 and len(torch.unique(f1)) == V
+    e = torch.cat([f1[:, [0, 1]], f1[:, [1, 2]], f1[:, [2, 0]]], 0)
+    und = torch.minimum(e[:, 0], e[:, 1]) * V + torch.maximum(e[:, 0], e[:, 1])
+    _, cnt = torch.unique(und, return_counts=True)
+    assert bool((cnt == 2).all())  # closed manifold
+    # 512x512 render of the 47k-face mesh: bit-exact ids against the oracle, deterministic, watertight
+    mvp, _, _ = mods["synthetic"].random_cameras(2, seed=8)
+    clip = render_ref.xfm_points(v1.cpu()[None].expand(2, -1, -1), mvp).contiguous()
+    ref = raster_ref.rasterize(clip, f1.cpu().int(), (512, 512))
+    a = ops.rasterize(clip.to(dev), f1, (512, 512))
+    b = ops.rasterize(clip.to(dev), f1, (512, 512))
+    assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), ref.numpy())
+    cover = (a[..., 3] > 0).float()[:, None]
+    nb = torch.nn.functional.conv2d(cover, torch.tensor([[[[0, 1, 0], [1, 0, 1], [0, 1, 0.0]]]], device=dev), padding=1)
+    assert int(((cover == 0) & (nb == 4)).sum()) == 0
