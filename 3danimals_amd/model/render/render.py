@@ -77,8 +77,8 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
         depth = ((depth - dmin) / (dmax - dmin)).unsqueeze(-1)
 
     buffers = _collect(render_modes, shaded_col, kd, ks, gb_normal, gb_geometric_normal, gb_tangent, shading, delta_xy_interp, dino_pred, depth)
-    if render_modes is not None:
-        return {mode: torch.cat((buffers[mode], alpha), dim=-1) for mode in render_modes if mode in buffers}
+    if render_modes is not None:  # an unknown or unavailable mode raises KeyError here, exactly like the reference (render.py:127-128)
+        return {mode: torch.cat((buffers[mode], alpha), dim=-1) for mode in render_modes}
     return {"shaded": torch.cat((shaded_col, alpha), dim=-1)}
 
 
@@ -193,8 +193,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     modes = render_modes if render_modes is not None else ["shaded"]
     out = SparseBuffers(pix, (b, h, w))
     for mode in modes:
-        if mode in buffers:
-            out[mode] = buffers[mode]
+        out[mode] = buffers[mode]  # KeyError for an unknown / unavailable mode, like the reference (render.py:127-128)
     return out if sparse else {mode: out.dense(mode) for mode in out}
 
 

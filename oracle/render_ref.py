@@ -76,7 +76,7 @@ def shade(gb_pos, gb_geo_nrm, gb_nrm, gb_tex_pos, w2c, view_pos, lgt, material, 
         buffers["dino_pred"] = dino
     if depth is not None:
         buffers["depth"] = depth
-    return {m: torch.cat((buffers[m], alpha), -1) for m in render_modes if m in buffers}
+    return {m: torch.cat((buffers[m], alpha), -1) for m in render_modes}  # KeyError for unknown modes (render.py:127-128)
 
 
 def render_mesh(v_pos, faces, v_nrm, mtx, w2c, view_pos, material, lgt, resolution, background=None, feat=None,

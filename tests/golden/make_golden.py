@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 
-STUBS = ["nvdiffrast", "imageio", "torchvision", "cv2", "pytorch3d", "hydra", "omegaconf", "trimesh", "wandb",
+STUBS = ["imageio", "torchvision", "cv2", "pytorch3d", "hydra", "omegaconf", "trimesh", "wandb",
          "tensorboard", "xatlas", "glfw", "OpenGL", "tinycudann", "kaolin", "lpips", "configargparse", "ipdb", "faiss",
          "clip"]
 
@@ -40,6 +40,48 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+def _inject_oracle_nvdiffrast():
+    """G7: let the reference's own render_mesh run here by giving it a ``nvdiffrast.torch`` made of the CPU oracle.
+
+    The goldens produced this way are self-referential for the three dr.* operators (parity unpinned, see oracle/raster_ref.py)
+    but pin everything the reference does around them: clip transform, which attributes are interpolated with which index
+    buffers, shading normal, light, compositing, antialias call pattern, channel slicing, NCHW layout, mode ordering.
+    """
+    import types
+
+    sys.path.insert(0, ROOT)
+    from oracle import raster_ref
+
+    dr = types.ModuleType("nvdiffrast.torch")
+
+    class RasterizeGLContext:
+        pass
+
+    class DepthPeeler:
+        def __init__(self, ctx, pos, tri, resolution):
+            self.pos, self.tri, self.res = pos, tri, resolution
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def rasterize_next_layer(self):
+            rast = raster_ref.rasterize(self.pos, self.tri, self.res)
+            uv = raster_ref.barycentrics(self.pos, self.tri, rast)  # keep the gradient path like the real op
+            return torch.cat([uv.clamp(0, 1), rast[..., 2:]], -1), torch.zeros_like(rast)
+
+    dr.RasterizeGLContext = RasterizeGLContext
+    dr.DepthPeeler = DepthPeeler
+    dr.rasterize = lambda ctx, pos, tri, resolution: (raster_ref.rasterize(pos, tri, resolution), None)
+    dr.interpolate = lambda attr, rast, tri, rast_db=None, diff_attrs=None: (raster_ref.interpolate(attr, rast, tri), None)
+    dr.antialias = lambda color, rast, pos, tri: raster_ref.antialias(color, rast, pos, tri)
+    pkg = types.ModuleType("nvdiffrast")
+    pkg.torch = dr
+    sys.modules["nvdiffrast"], sys.modules["nvdiffrast.torch"] = pkg, dr
+
+
 def import_reference():
     sys.meta_path.insert(0, _StubFinder())
     sys.path.insert(0, REF)
@@ -52,6 +94,16 @@ def import_reference():
 
     torch.tensor = cpu_tensor
     torch.Tensor.cuda = lambda self, *a, **k: self
+    for name in ("arange", "zeros"):  # render.py:190,304 hard-code device='cuda'
+        orig = getattr(torch, name)
+
+        def patched(*a, _orig=orig, **k):
+            if str(k.get("device")) == "cuda":
+                k["device"] = "cpu"
+            return _orig(*a, **k)
+
+        setattr(torch, name, patched)
+    _inject_oracle_nvdiffrast()
     from model.geometry import skinning as ref_skin
     from model.geometry.dmtet import DMTet
     from model.networks import MLPs as ref_mlps
@@ -200,6 +252,41 @@ def main():
     sd.update({f"lgt.{k}": v.numpy() for k, v in lgt.state_dict().items()})
     save("shade.npz", **{f"gb_{k}": v.numpy() for k, v in gb.items()}, feat=feat.numpy(), w2c=w2c2.numpy(), campos=campos2.numpy(),
          **{f"out_{k}": v.numpy() for k, v in buf.items()}, out_nolight_shaded=buf_nolight["shaded"].numpy(), **sd)
+    # ------------------------------------------------------------------ G7: reference render_mesh end to end (oracle as nvdiffrast)
+    rmesh, rrender = R["mesh"], R["render"]
+    B, H, W = 4, 32, 32
+    mvp7, w2c7, campos7 = synthetic.random_cameras(B, seed=21)
+    posed = (qv[None] + 0.05 * synthetic.seeded((B, *qv.shape), 22, -1, 1))
+    uvs7 = torch.zeros(1, 4, 2)
+    uvi7 = torch.zeros(1, qf.shape[0], 3, dtype=torch.long)
+    shape7 = rmesh.make_mesh(posed, qf[None], uvs7.repeat(B, 1, 1), uvi7, None)
+    prior7 = rmesh.make_mesh(qv[None], qf[None], uvs7, uvi7, None)
+    feat7 = synthetic.seeded((B, 16), 23, -1, 1)
+    bg7 = synthetic.seeded((B, H, W, 3), 24, 0, 1)
+    g7 = dict(v_pos=posed.numpy(), prior_v_pos=qv.numpy(), faces=qf.numpy(), mvp=mvp7.numpy(), w2c=w2c7.numpy(), campos=campos7.numpy(),
+              feat=feat7.numpy(), background=bg7.numpy())
+    ctx = sys.modules["nvdiffrast.torch"].RasterizeGLContext()
+    cases7 = {
+        "a": dict(modes=["shaded", "dino_pred"], nets=True, kw={}),
+        "b": dict(modes=["geo_normal", "kd", "shading", "normal"], nets=True, kw={}),
+        "c": dict(modes=["shaded", "flow"], nets=False, kw=dict(num_frames=2)),
+        "d": dict(modes=["shaded"], nets=False, kw=dict(two_sided_shading=False)),
+    }
+    with torch.no_grad():
+        for tag, c in cases7.items():
+            outs = rrender.render_mesh(ctx, shape7, mvp7, w2c7, campos7, tex if c["nets"] else None, lgt if c["nets"] else None, (H, W), spp=1,
+                                       num_layers=1, msaa=True, background=bg7, bsdf="diffuse", feat=feat7 if c["nets"] else None,
+                                       render_modes=c["modes"], prior_mesh=prior7, dino_net=dino if c["nets"] else None, **c["kw"])
+            for m, o in zip(c["modes"], outs):
+                if o is not None:
+                    g7[f"{tag}_{m}"] = o.contiguous().numpy()
+            g7[f"{tag}_modes"] = np.array(",".join(c["modes"]))
+    try:  # unknown / unavailable modes: the dict comprehension at render.py:128 raises before render.py:308-309 can return None
+        rrender.render_mesh(ctx, shape7, mvp7, w2c7, campos7, None, None, (H, W), background=bg7, bsdf="diffuse", render_modes=["shaded", "bogus"])
+        g7["unknown_mode_error"] = np.array("none")
+    except Exception as e:
+        g7["unknown_mode_error"] = np.array(type(e).__name__)
+    save("render_mesh_e2e.npz", **g7, **sd)
     print("golden vectors written to", HERE)
 
 

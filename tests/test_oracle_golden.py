@@ -105,3 +105,31 @@ def test_shade_oracle_matches_reference(a3d):
     for m in modes:
         np.testing.assert_allclose(buf[m].numpy(), g[f"out_{m}"], atol=2e-6, err_msg=m)
     np.testing.assert_allclose(nolight["shaded"].numpy(), g["out_nolight_shaded"], atol=1e-6)
+
+
+E2E_CASES = {"a": dict(nets=True, kw={}), "b": dict(nets=True, kw={}), "c": dict(nets=False, kw=dict(num_frames=2)), "d": dict(nets=False, kw=dict(two_sided=False))}
+
+
+@pytest.mark.parametrize("tag", sorted(E2E_CASES))
+def test_render_mesh_oracle_matches_reference_render_mesh(tag, a3d):
+    """G7: the REFERENCE's render_mesh (run with the oracle operators standing in for nvdiffrast) against the oracle's own
+    render_mesh: pins clip transform, attribute/index-buffer choice, shading normal, light, compositing, antialias call pattern,
+    channel slicing, NCHW layout and mode ordering (the three dr.* operators themselves stay unpinned)."""
+    g = golden("render_mesh_e2e.npz")
+    c = E2E_CASES[tag]
+    tex, dino, lgt = _load_nets(a3d, g)
+    t = lambda k: torch.from_numpy(g[k])
+    v_pos, faces = t("v_pos"), t("faces")
+    modes = str(g[f"{tag}_modes"]).split(",")
+    with torch.no_grad():
+        outs = render_ref.render_mesh(v_pos, faces, mesh_ref.vertex_normals(v_pos, faces), t("mvp"), t("w2c"), t("campos"), tex if c["nets"] else None,
+                                      lgt if c["nets"] else None, (32, 32), background=t("background"), feat=t("feat") if c["nets"] else None,
+                                      render_modes=modes, prior_v_pos=t("prior_v_pos")[None], dino_net=dino if c["nets"] else None, **c["kw"])
+    assert len(outs) == len(modes)
+    for m, o in zip(modes, outs):
+        assert tuple(o.shape) == tuple(g[f"{tag}_{m}"].shape), m
+        np.testing.assert_allclose(o.numpy(), g[f"{tag}_{m}"], atol=2e-6, err_msg=m)
+    assert str(g["unknown_mode_error"]) == "KeyError"
+    with pytest.raises(KeyError):
+        render_ref.render_mesh(v_pos, faces, mesh_ref.vertex_normals(v_pos, faces), t("mvp"), t("w2c"), t("campos"), None, None, (32, 32),
+                               render_modes=["shaded", "bogus"])
