@@ -23,8 +23,9 @@ SIGNATURES = {
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p]),
     "a3d_bone_transforms_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_bone_transforms_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
-    "a3d_normals_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_normals_bwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_normals_bwd": (_c_int, [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),

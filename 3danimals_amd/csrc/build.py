@@ -3,8 +3,8 @@
     python 3danimals_amd/csrc/build.py [--force]
 
 One object per .hip file, linked into 3danimals_amd/lib/liba3d_hip.so (in-tree, git-ignored, travels to the
-GPU box with the snapshot).  raster/dmtet/antialias are compiled with -ffp-contract=off: their arithmetic is
-specified operation by operation (oracle/raster_ref.c, reference dmtet.py:124-131).
+GPU box with the snapshot).  raster/dmtet/antialias/normals are compiled with -ffp-contract=off: their arithmetic is
+specified operation by operation (oracle/raster_ref.c, reference dmtet.py:124-131, mesh.py:276-304).
 """
 import os
 import subprocess
@@ -22,7 +22,7 @@ SOURCES = {
     "dmtet.hip": ["-ffp-contract=off"],
     "skin.hip": [],
     "bones.hip": [],
-    "normals.hip": [],
+    "normals.hip": ["-ffp-contract=off"],
     "raster.hip": ["-ffp-contract=off"],
     "interp.hip": [],
     "gbuffer.hip": [],

@@ -206,16 +206,40 @@ def skin_weights(v, bones, B, temperature):
 
 
 # ---------------------------------------------------------------------------------------------- normals
+class VertexFaceAdjacency:
+    """CSR vertex -> incident (corner, face) entries of one triangle list, built by a3d_normals_adjacency."""
+
+    def __init__(self, tri32: torch.Tensor, num_vertices: int):
+        require_device(tri32, what="normals_adjacency")
+        F, V = tri32.shape[0], int(num_vertices)
+        self.tri, self.num_vertices = tri32, V
+        self.off = torch.empty(V + 1, dtype=torch.int32, device=tri32.device)
+        self.adj = torch.empty(max(3 * F, 1), dtype=torch.int32, device=tri32.device)
+        cursor = torch.empty(V, dtype=torch.int32, device=tri32.device)
+        call("a3d_normals_adjacency", ptr(tri32), V, F, ptr(self.off), ptr(self.adj), ptr(cursor), stream())
+
+
+_adj_cache = _IdentityCache()
+
+
+def vertex_face_adjacency(tri32: torch.Tensor, num_vertices: int) -> VertexFaceAdjacency:
+    adj = _adj_cache.get(tri32, lambda t: VertexFaceAdjacency(t, num_vertices))
+    if adj.num_vertices != num_vertices:  # same triangle list used with another vertex count: rebuild, do not trust the cache
+        adj = VertexFaceAdjacency(tri32, num_vertices)
+    return adj
+
+
 class _Normals(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, tri32):
+    def forward(ctx, v, tri32, adjacency):
         require_device(v, tri32, what="vertex_normals")
         v = f32c(v)
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         acc = torch.empty_like(v)
         nrm = torch.empty_like(v)
-        call("a3d_normals_fwd", ptr(v), ptr(tri32), B, V, F, ptr(acc), ptr(nrm), stream())
+        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), stream())
         ctx.save_for_backward(v, acc, tri32)
+        ctx.adjacency = adjacency
         return nrm
 
     @staticmethod
@@ -224,13 +248,15 @@ class _Normals(torch.autograd.Function):
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         scratch = torch.empty_like(v)
         g_v = torch.empty_like(v)
-        call("a3d_normals_bwd", ptr(f32c(g_nrm)), ptr(acc), ptr(v), ptr(tri32), B, V, F, ptr(scratch), ptr(g_v), stream())
-        return g_v, None
+        call("a3d_normals_bwd", ptr(f32c(g_nrm)), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
+             ptr(scratch), ptr(g_v), stream())
+        return g_v, None, None
 
 
 def vertex_normals(v, tri):
-    """Area-weighted, normalised vertex normals [B,V,3] (auto_normals)."""
-    return _Normals.apply(v, tri_int32(tri))
+    """Area-weighted, normalised vertex normals [B,V,3] (auto_normals); the adjacency is built once per triangle list."""
+    tri32 = tri_int32(tri)
+    return _Normals.apply(v, tri32, vertex_face_adjacency(tri32, v.shape[1]))
 
 
 # ---------------------------------------------------------------------------------------------- rasterise

@@ -184,3 +184,23 @@ def _distance_transforms(mask: torch.Tensor) -> torch.Tensor:
         out[b, 0] = distance_transform_edt(~m[b]) / max(m.shape[1:])
         out[b, 1] = distance_transform_edt(m[b]) / max(m.shape[1:])
     return torch.from_numpy(out)
+
+
+def geometry_config1_step(inp, topology, backward=True):
+    """BASELINE config 1 on the HIP path (same inputs / same loss as oracle/geometry_ref.cpu_step): DMTet -> normals -> bones ->
+    skinning -> normals -> backward.  ``inp`` tensors on the GPU, ``topology`` = dmtet.TetGridTopology of the grid."""
+    from . import ops
+
+    sdf = inp["sdf"].clone().requires_grad_(backward)
+    arti = inp["arti"].clone().requires_grad_(backward)
+    verts, faces, uv_idx = ops.dmtet(inp["pos"], sdf, topology)
+    uvs = topology.uvs()
+    prior = mesh_mod.make_mesh(verts[None], faces[None], uvs[None], uv_idx[None], None)
+    bones, tree, _ = skinning_mod.estimate_bones(verts[None, None].detach(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")
+    posed, _ = skinning_mod.skinning(verts[None, None], bones, tree, arti, temperature=inp["temperature"])
+    posed = posed.view(inp["batch"], -1, 3)
+    shape = mesh_mod.make_mesh(posed, prior.t_pos_idx, prior.v_tex.expand(inp["batch"], -1, -1), prior.t_tex_idx, None)
+    loss = (posed ** 2).mean() + (shape.v_nrm[..., 1]).mean() + (prior.v_nrm[..., 2]).mean()
+    if backward:
+        loss.backward()
+    return dict(loss=loss, V=int(verts.shape[0]), F=int(faces.shape[0]), grad_sdf=sdf.grad, grad_arti=arti.grad)

@@ -87,13 +87,16 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
 
 /* ------------------------------------------------------------------------------------------------
  * Area-weighted vertex normals -- replaces auto_normals, /root/reference/model/render/mesh.py:276-304.
- * acc[B,V,3] receives the un-normalised sums (saved for backward), nrm[B,V,3] the result
- * (zero sums -> (0,0,1), then safe_normalize, mesh.py:296-299).
+ * a3d_normals_adjacency: once per triangle list, CSR vertex -> incident corners: off[V+1], adj[3F] (entry = corner*F + face, each
+ *   list sorted, i.e. in the order the reference's three scatter_add_ passes visit them, mesh.py:291-293); cursor[V] = scratch.
+ * fwd: acc[B,V,3] receives the un-normalised sums (saved for backward), nrm[B,V,3] the result (zero sums -> (0,0,1), then
+ *   safe_normalize, mesh.py:296-299).  No float atomics: results are bit-reproducible.
  */
-int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, int B, int V, int F, float* acc, float* nrm,
-                    a3d_stream_t stream);
-int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const int32_t* tri, int B, int V, int F,
-                    float* g_acc_scratch /*[B,V,3]*/, float* g_v /*[B,V,3] zeroed by callee*/, a3d_stream_t stream);
+int a3d_normals_adjacency(const int32_t* tri /*[F,3]*/, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream);
+int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, const int32_t* off, const int32_t* adj, int B, int V, int F,
+                    float* acc, float* nrm, a3d_stream_t stream);
+int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const int32_t* tri, const int32_t* off, const int32_t* adj, int B,
+                    int V, int F, float* g_acc_scratch /*[B,V,3]*/, float* g_v /*[B,V,3]*/, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rasterise -- replaces dr.DepthPeeler(...).rasterize_next_layer() layer 0 / dr.rasterize,

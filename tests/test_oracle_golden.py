@@ -133,3 +133,13 @@ def test_render_mesh_oracle_matches_reference_render_mesh(tag, a3d):
     with pytest.raises(KeyError):
         render_ref.render_mesh(v_pos, faces, mesh_ref.vertex_normals(v_pos, faces), t("mvp"), t("w2c"), t("campos"), None, None, (32, 32),
                                render_modes=["shaded", "bogus"])
+
+
+def test_config1_geometry_oracle_runs_and_matches_survey_mesh():
+    """BASELINE config 1 on the CPU oracle: same mesh size the survey measured on the reference (2,174 verts / 4,344 faces)."""
+    from oracle import geometry_ref
+
+    torch.set_num_threads(4)
+    out = geometry_ref.cpu_step(geometry_ref.make_inputs(res=32, batch=2, seed=0))
+    assert (out["V"], out["F"]) == (2174, 4344)
+    assert np.isfinite(out["loss"]) and float(out["grad_sdf"].abs().max()) > 0 and float(out["grad_arti"].abs().max()) > 0
