@@ -24,6 +24,8 @@ SOURCES = {
     "bones.hip": [],
     "normals.hip": ["-ffp-contract=off"],
     "raster.hip": ["-ffp-contract=off"],
+    "cover.hip": [],
+    "shade.hip": ["-ffp-contract=off"],
     "interp.hip": [],
     "gbuffer.hip": [],
     "segsum.hip": [],

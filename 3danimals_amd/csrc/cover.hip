@@ -1,0 +1,115 @@
+// Covered-pixel list on gfx950: stream compaction of (rast.w > 0) into flat pixel indices, image-major and, inside an image,
+// 8x8 tile by tile -- the point list the G-buffer kernel, the texture/DINO fields and the compositing scatter run over.
+// (The reference shades every pixel of the frame, render.py:30-132; evaluating only the covered ones is output-identical
+//  because uncovered pixels are composited with alpha 0, render.py:261-262.)
+//
+// Same three-step shape as the DMTet extraction: per-work-group ballot counts -> one-work-group scan -> ordered emit.
+// One wave covers one 8x8 tile, so a work-group of 256 threads covers 4 tiles; entry k of the tile-ordered pixel space is
+//   k = ((b*H/8 + ty)*W/8 + tx)*64 + iy*8 + ix        (tile = 8)      or      k = flat index      (tile = 0, row-major).
+#include "a3d_common.h"
+
+namespace {
+
+constexpr int CV_BLOCK = 256;
+constexpr int CV_SCAN_THREADS = 1024;
+
+__device__ __forceinline__ long long cv_flat(long long k, int H, int W, int tile) {
+    if (tile == 0) return k;
+    const int in_tile = (int)(k & 63);
+    long long t = k >> 6;
+    const int tw = W >> 3, th = H >> 3;
+    const int tx = (int)(t % tw); t /= tw;
+    const int ty = (int)(t % th); t /= th;  // t = image
+    return (t * H + (ty * 8 + (in_tile >> 3))) * W + tx * 8 + (in_tile & 7);
+}
+
+__global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
+                                                            int* __restrict__ block_count) {
+    __shared__ int wave_n[CV_BLOCK / 64];
+    const long long k = (long long)blockIdx.x * CV_BLOCK + threadIdx.x;
+    const bool on = k < n && rast[cv_flat(k, H, W, tile)].w > 0.f;
+    const unsigned long long m = __ballot(on);
+    if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+
+// exclusive scan of block_count[nb] in place; total[0] = number of covered pixels
+__global__ __launch_bounds__(CV_SCAN_THREADS) void cv_scan_kernel(int* __restrict__ block_count, int nb, long long* __restrict__ total) {
+    __shared__ int wave_tot[CV_SCAN_THREADS / 64];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += CV_SCAN_THREADS) {
+        const int i = base + threadIdx.x;
+        const int c = i < nb ? block_count[i] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (i < nb) block_count[i] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == CV_SCAN_THREADS - 1) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry_s;
+}
+
+__global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
+                                                           const int* __restrict__ block_off, long long* __restrict__ pix) {
+    __shared__ int wave_n[CV_BLOCK / 64];
+    const long long k = (long long)blockIdx.x * CV_BLOCK + threadIdx.x;
+    const long long flat = k < n ? cv_flat(k, H, W, tile) : 0;
+    const bool on = k < n && rast[flat].w > 0.f;
+    const unsigned long long m = __ballot(on);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    if (!on) return;
+    int o = block_off[blockIdx.x] + a3d_wave_prefix(m);
+    for (int w = 0; w < wave; ++w) o += wave_n[w];
+    pix[o] = flat;
+}
+
+}  // namespace
+
+extern "C" size_t a3d_cover_scratch_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return sizeof(int) * (size_t)a3d_div_up((long long)B * H * W, CV_BLOCK);
+}
+
+static int cv_check(const float* rast, int B, int H, int W, int tile, const void* scratch) {
+    A3D_CHECK_ARG(rast && scratch && B > 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
+    A3D_CHECK_ARG(tile == 0 || (tile == 8 && H % 8 == 0 && W % 8 == 0));
+    return A3D_OK;
+}
+
+extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile, void* scratch, int64_t* total, a3d_stream_t stream) {
+    if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
+    A3D_CHECK_ARG(total);
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * H * W;
+    const int nb = a3d_div_up(n, CV_BLOCK);
+    hipLaunchKernelGGL(cv_count_kernel, dim3(nb), dim3(CV_BLOCK), 0, s, (const float4*)rast, n, H, W, tile, (int*)scratch);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cv_scan_kernel, dim3(1), dim3(CV_SCAN_THREADS), 0, s, (int*)scratch, nb, (long long*)total);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix, a3d_stream_t stream) {
+    if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
+    A3D_CHECK_ARG(pix);
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(cv_emit_kernel, dim3(a3d_div_up(n, CV_BLOCK)), dim3(CV_BLOCK), 0, (hipStream_t)stream, (const float4*)rast, n, H, W,
+                       tile, (const int*)scratch, (long long*)pix);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

@@ -1,0 +1,162 @@
+// Per-point shading arithmetic on gfx950 -- the part of shade() between the field look-ups and the buffers
+// (/root/reference/model/render/render.py:71-93): shading normal (renderutils/ops.py:194-227 -> bsdf.py:28-51 with the (0,0,1)
+// perturbation), camera-space normal (render.py:73-74), directional light (light.py:186-190).
+//
+// One thread per covered pixel; everything lives in registers.  The reference runs ~30 elementwise torch kernels forward and
+// ~70 backward over dense [B,H,W,3] frames for this; here it is one launch each way over the covered-pixel list, and the backward
+// recomputes the forward instead of saving intermediates.
+//   in : gb[P,12] (world position | face normal | smooth normal | canonical position, from a3d_gbuffer_fwd),
+//        par[P,ncol] per-point rows of the per-image quantities: w2c rotation (9, row-major) | view position (3) | light (5:
+//        direction 3, ambient, diffuse) -- ncol 12 (no light) or 17,  kd[P,3] (row stride kd_stride floats)
+//   out: nrm[P,3] shading normal, shading[P] = amb + diff*max(L.n_cam, 0), shaded[P,3] = shading*kd   (last two only with a light)
+#include "a3d_common.h"
+
+namespace {
+
+constexpr float SH_NORMAL_THRESHOLD = 0.1f;  // bsdf.py:13
+constexpr float SH_EPS_NORMALIZE = 1e-12f;   // torch.nn.functional.normalize
+constexpr float SH_EPS_SAFE = 1e-20f;        // render/util.py:28-32
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// y = x / max(|x|, eps)
+__device__ __forceinline__ V3 normalize_f(V3 x, float* len_out) {
+    const float len = fmaxf(sqrtf(dot(x, x)), SH_EPS_NORMALIZE);
+    *len_out = len;
+    return {x.x / len, x.y / len, x.z / len};
+}
+__device__ __forceinline__ V3 normalize_b(V3 gy, V3 y, float len) {
+    // clamp_min passes no gradient to the norm when it is below eps
+    return len > SH_EPS_NORMALIZE ? (gy - y * dot(y, gy)) * (1.f / len) : gy * (1.f / len);
+}
+
+struct ShFwd {
+    V3 n1, n2, v, ns, g, N, q, cam, L;
+    float len1, len2, lenv, sigma, t_raw, t, qq, lenq, l, amb, diff, shading;
+};
+
+__device__ __forceinline__ ShFwd sh_forward(const float* __restrict__ gbp, const float* __restrict__ pr, int ncol, int two_sided) {
+    ShFwd f;
+    const V3 pos = ld3(gbp), geo = ld3(gbp + 3), a = ld3(gbp + 6), view = ld3(pr + 9);
+    f.n1 = normalize_f(a, &f.len1);
+    f.n2 = normalize_f(f.n1, &f.len2);
+    f.v = normalize_f(view - pos, &f.lenv);
+    f.sigma = (two_sided && !(dot(geo, f.v) > 0.f)) ? -1.f : 1.f;
+    f.ns = f.n2 * f.sigma;
+    f.g = geo * f.sigma;
+    f.t_raw = dot(f.v, f.ns) / SH_NORMAL_THRESHOLD;
+    f.t = fminf(fmaxf(f.t_raw, 0.f), 1.f);
+    const V3 d = f.ns - f.g;  // torch.lerp: start + w*(end-start) below 0.5, end - (end-start)*(1-w) above
+    f.N = f.t < 0.5f ? f.g + d * f.t : f.ns - d * (1.f - f.t);
+    f.shading = 0.f;
+    if (ncol >= 17) {
+        f.q = {pr[0] * f.N.x + pr[1] * f.N.y + pr[2] * f.N.z, pr[3] * f.N.x + pr[4] * f.N.y + pr[5] * f.N.z,
+               pr[6] * f.N.x + pr[7] * f.N.y + pr[8] * f.N.z};
+        f.qq = dot(f.q, f.q);
+        f.lenq = sqrtf(fmaxf(f.qq, SH_EPS_SAFE));
+        f.cam = {f.q.x / f.lenq, f.q.y / f.lenq, f.q.z / f.lenq};
+        f.L = ld3(pr + 12);
+        f.amb = pr[15];
+        f.diff = pr[16];
+        f.l = dot(f.L, f.cam);
+        f.shading = f.amb + f.diff * fmaxf(f.l, 0.f);
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ gb, const float* __restrict__ par, int ncol,
+                                                     const float* __restrict__ kd, int kd_stride, long long P, int two_sided,
+                                                     float* __restrict__ nrm, float* __restrict__ shading, float* __restrict__ shaded) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const ShFwd f = sh_forward(gb + 12 * p, par + (long long)ncol * p, ncol, two_sided);
+    st3(nrm + 3 * p, f.N);
+    if (ncol >= 17) {
+        shading[p] = f.shading;
+        st3(shaded + 3 * p, ld3(kd + (long long)kd_stride * p) * f.shading);
+    }
+}
+
+__global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g_nrm, const float* __restrict__ g_shading,
+                                                     const float* __restrict__ g_shaded, const float* __restrict__ gb,
+                                                     const float* __restrict__ par, int ncol, const float* __restrict__ kd, int kd_stride,
+                                                     long long P, int two_sided, float* __restrict__ g_gb, float* __restrict__ g_par,
+                                                     float* __restrict__ g_kd) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* pr = par + (long long)ncol * p;
+    const ShFwd f = sh_forward(gb + 12 * p, pr, ncol, two_sided);
+    V3 gN = g_nrm ? ld3(g_nrm + 3 * p) : V3{0.f, 0.f, 0.f};
+    float* gpr = g_par + (long long)ncol * p;
+    if (ncol >= 17) {
+        const V3 k = ld3(kd + (long long)kd_stride * p);
+        const V3 gs = g_shaded ? ld3(g_shaded + 3 * p) : V3{0.f, 0.f, 0.f};
+        const float g_sh = (g_shading ? g_shading[p] : 0.f) + dot(gs, k);
+        st3(g_kd + 3 * p, gs * f.shading);
+        const float g_l = f.l >= 0.f ? g_sh * f.diff : 0.f;  // clamp(min=0) passes the gradient at l == 0
+        st3(gpr + 12, f.cam * g_l);
+        gpr[15] = g_sh;
+        gpr[16] = g_sh * fmaxf(f.l, 0.f);
+        const V3 g_cam = f.L * g_l;
+        const float inv = 1.f / f.lenq;
+        const V3 g_q = f.qq >= SH_EPS_SAFE ? (g_cam - f.cam * dot(f.cam, g_cam)) * inv : g_cam * inv;
+        gpr[0] = g_q.x * f.N.x; gpr[1] = g_q.x * f.N.y; gpr[2] = g_q.x * f.N.z;
+        gpr[3] = g_q.y * f.N.x; gpr[4] = g_q.y * f.N.y; gpr[5] = g_q.y * f.N.z;
+        gpr[6] = g_q.z * f.N.x; gpr[7] = g_q.z * f.N.y; gpr[8] = g_q.z * f.N.z;
+        gN = gN + V3{pr[0] * g_q.x + pr[3] * g_q.y + pr[6] * g_q.z, pr[1] * g_q.x + pr[4] * g_q.y + pr[7] * g_q.z,
+                     pr[2] * g_q.x + pr[5] * g_q.y + pr[8] * g_q.z};
+    }
+    // lerp(g, ns, t)
+    const V3 g_g = gN * (1.f - f.t);
+    V3 g_ns = gN * f.t;
+    const float g_t = dot(gN, f.ns - f.g);
+    const float g_c = (f.t_raw >= 0.f && f.t_raw <= 1.f) ? g_t / SH_NORMAL_THRESHOLD : 0.f;
+    V3 g_v = f.ns * g_c;
+    g_ns = g_ns + f.v * g_c;
+    const V3 g_n2 = g_ns * f.sigma;
+    const V3 g_n1 = normalize_b(g_n2, f.n2, f.len2);
+    const V3 g_a = normalize_b(g_n1, f.n1, f.len1);
+    const V3 g_d = normalize_b(g_v, f.v, f.lenv);  // d = view - pos
+    float* go = g_gb + 12 * p;
+    st3(go, g_d * -1.f);
+    st3(go + 3, g_g * f.sigma);
+    st3(go + 6, g_a);
+    st3(go + 9, V3{0.f, 0.f, 0.f});
+    st3(gpr + 9, g_d);
+    if (ncol < 17) {
+        gpr[0] = gpr[1] = gpr[2] = gpr[3] = gpr[4] = gpr[5] = gpr[6] = gpr[7] = gpr[8] = 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int a3d_shade_fwd(const float* gb, const float* par, int ncol, const float* kd, int kd_stride, int64_t P, int two_sided, float* nrm,
+                             float* shading, float* shaded, a3d_stream_t stream) {
+    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17));
+    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(gb && par && nrm);
+    A3D_CHECK_ARG(ncol == 12 || (kd && kd_stride >= 3 && shading && shaded));
+    hipLaunchKernelGGL(sh_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, gb, par, ncol, kd, kd_stride, (long long)P,
+                       two_sided, nrm, shading, shaded);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
+                             const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par, float* g_kd,
+                             a3d_stream_t stream) {
+    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17));
+    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(gb && par && g_gb && g_par);
+    A3D_CHECK_ARG(ncol == 12 || (kd && kd_stride >= 3 && g_kd));
+    hipLaunchKernelGGL(sh_bwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, g_nrm, g_shading, g_shaded, gb, par, ncol,
+                       kd, kd_stride, (long long)P, two_sided, g_gb, g_par, g_kd);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

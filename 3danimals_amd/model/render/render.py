@@ -25,6 +25,7 @@ SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixe
 POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple of this (0 = off)
 LAST_RAST = [None]
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
+FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
@@ -143,7 +144,7 @@ class SparseBuffers(dict):
 
 
 def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lgt, material, bsdf, feat, render_modes, two_sided_shading,
-                  dino_net, class_vector, sparse=False):
+                  dino_net, class_vector, sparse=False, gb=None):
     """The arithmetic of shade() (reference render.py:30-132) on compact [P,.] arrays; scatters into dense [B,H,W,C+1]
     buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points."""
     b, h, w = bhw
@@ -177,17 +178,22 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     if lgt is not None:
         cols.append(lgt(feat))  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
     per_point = _rows_per_point(torch.cat(cols, dim=-1), img, b)
-    rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
-    nrm = ru.prepare_shading_normal(pos, view_p, None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
-    cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs
-
     shading = None
-    if lgt is None:
-        shaded_col = kd
+    if gb is not None and FUSED_SHADING:  # one HIP kernel each way for the ~30 (+~70 backward) elementwise launches below
+        if lgt is None:
+            nrm, shaded_col = ops.shade_points(gb, per_point, None, two_sided_shading), kd
+        else:
+            nrm, shading, shaded_col = ops.shade_points(gb, per_point, kd, two_sided_shading)
     else:
-        params = per_point[:, 12:17]
-        shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
-        shaded_col = shading * kd
+        rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
+        nrm = ru.prepare_shading_normal(pos, view_p, None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
+        cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs
+        if lgt is None:
+            shaded_col = kd
+        else:
+            params = per_point[:, 12:17]
+            shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
+            shaded_col = shading * kd
 
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
@@ -206,20 +212,9 @@ PIXEL_TILE = 8  # covered pixels are listed tile by tile (0 = plain row-major or
 
 def _covered_pixels(rast):
     """Flat indices (b*H + y)*W + x of the covered pixels, image-major and, inside an image, in 8x8-tile order: consecutive
-    entries then touch the same few triangles, which is what the G-buffer kernels' gathers and LDS scatter aggregation like."""
-    b, h, w = rast.shape[:3]
-    cover = rast[..., 3] > 0
-    t = PIXEL_TILE
-    if not t or h % t or w % t:
-        return torch.nonzero(cover.reshape(-1)).squeeze(1)
-    tiled = cover.view(b, h // t, t, w // t, t).permute(0, 1, 3, 2, 4).reshape(-1)
-    k = torch.nonzero(tiled).squeeze(1)
-    ix = k % t
-    iy = (k // t) % t
-    tx = (k // (t * t)) % (w // t)
-    ty = (k // (t * t * (w // t))) % (h // t)
-    bb = k // (h * w)
-    return (bb * h + ty * t + iy) * w + tx * t + ix
+    entries then touch the same few triangles, which is what the G-buffer kernels' gathers and LDS scatter aggregation like.
+    Ballot/prefix-sum compaction on the GPU (csrc/cover.hip)."""
+    return ops.covered_pixels(rast, tile=PIXEL_TILE)
 
 
 FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred"))
@@ -247,7 +242,7 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
         pix = _covered_pixels(rast)  # one host sync for the number of covered pixels
         gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], None, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
-                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse)
+                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb)
 
     rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
     gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)

@@ -259,6 +259,25 @@ def vertex_normals(v, tri):
     return _Normals.apply(v, tri32, vertex_face_adjacency(tri32, v.shape[1]))
 
 
+# ---------------------------------------------------------------------------------------------- covered pixels
+def covered_pixels(rast, tile=8):
+    """int64 [P] flat indices of the pixels with rast[...,3] > 0, image-major, 8x8-tile order inside an image (``tile=8``; falls back
+    to row-major when H or W is not a multiple of 8).  One 8-byte read-back (P) between the count and the emit launches."""
+    require_device(rast, what="covered_pixels")
+    rast = f32c(rast.detach())
+    B, H, W = rast.shape[:3]
+    if tile != 8 or H % 8 or W % 8:
+        tile = 0
+    dev = rast.device
+    scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), ptr(total), stream())
+    pix = torch.empty(int(total.item()), dtype=torch.int64, device=dev)
+    if pix.shape[0]:
+        call("a3d_cover_emit", ptr(rast), B, H, W, tile, ptr(scratch), ptr(pix), stream())
+    return pix
+
+
 # ---------------------------------------------------------------------------------------------- rasterise
 class _Rasterize(torch.autograd.Function):
     @staticmethod
@@ -361,6 +380,53 @@ def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix):
     semantics are implied: the gradient to ``clip`` is produced here, not through ``rast``.
     """
     return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix)
+
+
+# ---------------------------------------------------------------------------------------------- per-point shading
+class _ShadePoints(torch.autograd.Function):
+    """(shading normal [P,3], shading [P,1], shaded [P,3]) from the G-buffer rows, the per-point camera/light rows and kd."""
+
+    @staticmethod
+    def forward(ctx, gb, par, kd, two_sided):
+        require_device(gb, par, what="shade_points")
+        gb, par = f32c(gb), f32c(par)
+        P, ncol = gb.shape[0], par.shape[1]
+        assert gb.shape == (P, 12) and par.shape[0] == P and ncol in (12, 17) and (kd is not None) == (ncol == 17)
+        nrm = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
+        shading = shaded = None
+        kd_stride = 0
+        if kd is not None:
+            assert kd.shape == (P, 3) and kd.dtype == torch.float32
+            if kd.stride(1) != 1:
+                kd = kd.contiguous()
+            kd_stride = kd.stride(0)
+            shading = torch.empty((P, 1), dtype=torch.float32, device=gb.device)
+            shaded = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
+        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded), stream())
+        ctx.save_for_backward(gb, par, kd)
+        ctx.two_sided, ctx.kd_stride = int(two_sided), kd_stride
+        if kd is None:
+            return nrm
+        return nrm, shading, shaded
+
+    @staticmethod
+    def backward(ctx, g_nrm, g_shading=None, g_shaded=None):
+        gb, par, kd = ctx.saved_tensors
+        P, ncol = gb.shape[0], par.shape[1]
+        g_gb, g_par = torch.empty_like(gb), torch.empty_like(par)
+        g_kd = torch.empty((P, 3), dtype=torch.float32, device=gb.device) if kd is not None else None
+        opt = lambda t: None if t is None else f32c(t)
+        call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(kd), ctx.kd_stride, P,
+             ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), stream())
+        return g_gb, g_par, g_kd, None
+
+
+def shade_points(gb, par, kd=None, two_sided=True):
+    """Shading normal, Lambert shading and shaded colour at the covered pixels (csrc/shade.hip).
+
+    gb [P,12] from :func:`gbuffer`; par [P,12|17] per-point rows (w2c rotation 9, view position 3[, light direction 3, ambient,
+    diffuse]); kd [P,3] (any row stride).  Returns nrm, or (nrm, shading [P,1], shaded [P,3]) when a light is given."""
+    return _ShadePoints.apply(gb, par, kd, two_sided)
 
 
 # ---------------------------------------------------------------------------------------------- per-image rows <-> points

@@ -53,6 +53,12 @@ def algorithmic_bytes(name, d):
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
         "a3d_gbuffer_fwd": int(d.get("P", 0)) * (8 + 16 + 48),
         "a3d_gbuffer_bwd": int(d.get("P", 0)) * (8 + 16 + 48) + B * V * (36 + 16),
+        "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
+        "a3d_cover_emit": 4 * B * HW + 8 * int(d.get("P", 0)),
+        "a3d_shade_fwd": int(d.get("P", 0)) * (48 + 68 + 12 + 12 + 4 + 12),
+        "a3d_shade_bwd": int(d.get("P", 0)) * (48 + 68 + 12 + 28 + 48 + 68 + 12),
+        "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,
+        "a3d_bone_transforms_bwd": B * K * (12 + 48 + 12) + 24 * K,
         "a3d_aa_topology": 12 * F + 12 * F,
         "a3d_aa_analyze": B * 16 * HW,
         "a3d_aa_fwd": B * 8 * C * HW,

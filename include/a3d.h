@@ -99,6 +99,31 @@ int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const 
                     int V, int F, float* g_acc_scratch /*[B,V,3]*/, float* g_v /*[B,V,3]*/, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-point shading arithmetic -- replaces the elementwise part of shade(), /root/reference/model/render/render.py:71-93:
+ * prepare_shading_normal with perturbed_nrm=None (renderutils/ops.py:194-227 -> bsdf.py:28-51), camera-space normal
+ * (render.py:73-74) and DirectionalLight.shade (light.py:186-190), on the covered-pixel list.
+ * gb[P,12] as written by a3d_gbuffer_fwd; par[P,ncol] = per-point rows of w2c rotation (9) | view position (3) | light
+ * direction, ambient, diffuse (5) -- ncol 12 without a light, 17 with; kd[P,3] with row stride kd_stride floats.
+ * fwd: nrm[P,3]; with a light also shading[P] and shaded[P,3] = shading*kd.   bwd: g_nrm / g_shading / g_shaded may be NULL
+ * (= zero); writes g_gb[P,12] (canonical-position columns zero), g_par[P,ncol], g_kd[P,3] (contiguous).
+ */
+int a3d_shade_fwd(const float* gb, const float* par, int ncol, const float* kd, int kd_stride, int64_t P, int two_sided, float* nrm,
+                  float* shading, float* shaded, a3d_stream_t stream);
+int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
+                  const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par, float* g_kd, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Covered-pixel list: flat indices (b*H + y)*W + x of the pixels with rast.w > 0 (triangle_id + 1, as dr.rasterize returns it),
+ * image-major and inside an image 8x8-tile by tile (tile = 8; H, W multiples of 8) or row-major (tile = 0).  The list the fused
+ * G-buffer / shading path runs over instead of the reference's dense [B,H,W] frame (/root/reference/model/render/render.py:
+ * 139-221 shades every pixel; uncovered ones are composited with alpha 0, :261-262).
+ * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device); the caller reads total back to size pix; emit writes pix.
+ */
+size_t a3d_cover_scratch_bytes(int B, int H, int W);
+int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, int64_t* total, a3d_stream_t stream);
+int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix /*[total]*/, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Rasterise -- replaces dr.DepthPeeler(...).rasterize_next_layer() layer 0 / dr.rasterize,
  * /root/reference/model/render/render.py:292-294, :351 (nvdiffrast, third party).
  * clip[clip_batch,V,4]; rast[B,H,W,4] = (u, v, z/w, triangle_id+1), empty = 0.  Per-fragment arithmetic is

@@ -743,3 +743,67 @@ def test_config1_geometry_path_matches_oracle():
     assert float(d.max()) <= 1e-3 * scale
     assert float((d > 1e-5 * scale).float().mean()) < 0.01 * float((rs != 0).float().mean())
     assert torch.equal(gs != 0, rs != 0)
+
+
+@pytest.mark.parametrize("shape,tile", [((3, 64, 64), 8), ((2, 24, 40), 8), ((2, 30, 20), 8), ((1, 16, 16), 0), ((2, 8, 8), 8)])
+def test_covered_pixels_compaction_is_exact(shape, tile, dev, ops):
+    """a3d_cover_count/emit against the plain torch expression of the same list (integer work: bit-exact)."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * w + b)
+    for density in (0.0, 0.03, 0.5, 1.0):
+        tri_id = torch.where(torch.rand(b, h, w, generator=g) < density, torch.randint(1, 1000, (b, h, w), generator=g), 0).float()
+        rast = torch.cat((torch.rand(b, h, w, 3, generator=g), tri_id[..., None]), -1).to(dev)
+        pix = ops.covered_pixels(rast, tile=tile)
+        cover = rast[..., 3] > 0
+        if tile == 8 and h % 8 == 0 and w % 8 == 0:
+            flat = torch.arange(b * h * w, device=dev).view(b, h // 8, 8, w // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)
+            want = flat[cover.view(b, h // 8, 8, w // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)]
+        else:
+            want = torch.nonzero(cover.reshape(-1)).squeeze(1)
+        assert pix.dtype == torch.int64 and torch.equal(pix, want), (shape, tile, density)
+
+
+@pytest.mark.parametrize("light,two_sided", [(True, True), (True, False), (False, True)])
+def test_shade_points_kernel_matches_oracle(light, two_sided, dev, ops):
+    """csrc/shade.hip against oracle/render_ref (pinned on the reference's shade goldens): values and all input gradients."""
+    from oracle import mesh_ref, render_ref
+
+    P = 5000
+    g = torch.Generator().manual_seed(11 + light + 2 * two_sided)
+    r = lambda *s: torch.rand(*s, generator=g) * 2 - 1
+    gb = torch.cat((r(P, 3), torch.nn.functional.normalize(r(P, 3), dim=-1), r(P, 3), r(P, 3)), -1)
+    gb[:7, 6:9] = 0.0  # zero smooth normals: the eps branches of normalize
+    par = torch.cat((r(P, 9), r(P, 3) * 3, torch.nn.functional.normalize(r(P, 3), dim=-1), torch.rand(P, 2, generator=g)), -1)[:, : 17 if light else 12]
+    tex = torch.rand(P, 9, generator=g)
+    w_n, w_s, w_c = r(P, 3), r(P, 1), r(P, 3)
+
+    def run(device, fused):
+        gb_, par_, tex_ = (t.clone().to(device).requires_grad_(True) for t in (gb, par, tex))
+        kd = tex_[:, :3]
+        if fused:
+            out = ops.shade_points(gb_, par_, kd if light else None, two_sided)
+            nrm, shading, shaded = out if light else (out, None, None)
+        else:
+            nrm = render_ref.shading_normal(gb_[:, 0:3], par_[:, 9:12], gb_[:, 6:9], gb_[:, 3:6], two_sided)
+            shading = shaded = None
+            if light:
+                cam = mesh_ref.safe_normalize((par_[:, 0:9].reshape(-1, 3, 3) * nrm[:, None, :]).sum(-1))
+                shading = par_[:, 15:16] + par_[:, 16:17] * torch.clamp((par_[:, 12:15] * cam).sum(-1, keepdim=True), min=0.0)
+                shaded = shading * kd
+        loss = (nrm * w_n.to(device)).sum()
+        if light:
+            loss = loss + (shading * w_s.to(device)).sum() + (shaded * w_c.to(device)).sum()
+        loss.backward()
+        outs = [nrm] + ([shading, shaded] if light else [])
+        return [t.detach().cpu() for t in outs], [t.grad.cpu() if t.grad is not None else None for t in (gb_, par_, tex_)]
+
+    (vals, grads), (vals_ref, grads_ref) = run(dev, True), run("cpu", False)
+    for a, b_ in zip(vals, vals_ref):
+        assert torch.allclose(a, b_, atol=2e-6, rtol=1e-5), float((a - b_).abs().max())
+    for a, b_, name in zip(grads, grads_ref, ("gb", "par", "tex")):
+        if b_ is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        # gradients through normalize() of near-zero vectors are huge and ill-conditioned: compare relative to each row's scale
+        scale = b_.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert float(((a - b_).abs() / scale).max()) < 2e-4, (name, float(((a - b_).abs() / scale).max()))
