@@ -29,10 +29,19 @@ class HarmonicEmbedding(nn.Module):
 
     def __init__(self, n_harmonic_functions=10, scalar=1.0):
         super().__init__()
-        self.frequencies = scalar * (2.0 ** torch.arange(n_harmonic_functions))
+        self.frequencies = scalar * (2.0 ** torch.arange(n_harmonic_functions))  # plain attribute, not in the state_dict
+        self._on_device = {}
+
+    def _frequencies(self, device):
+        # the reference copies the table host->device in every forward (HarmonicEmbedding.py:41): a pageable copy that blocks the
+        # host until the stream drains.  Same values, copied once per device.
+        f = self._on_device.get(device)
+        if f is None:
+            f = self._on_device[device] = self.frequencies.to(device)
+        return f
 
     def forward(self, x):
-        ang = (x[..., None] * self.frequencies.to(x.device)).reshape(*x.shape[:-1], -1)
+        ang = (x[..., None] * self._frequencies(x.device)).reshape(*x.shape[:-1], -1)
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 

@@ -199,7 +199,7 @@ class DMTetGeometry(torch.nn.Module):
             sdf0 = self.get_sdf(pos, total_iter=total_iter, feats=feats)
         verts0, faces, uv_idx, vert_edge = ops.dmtet_extract(pos, sdf0, self.topology)
         mask = torch.zeros(pos.shape[0], dtype=torch.bool, device=pos.device)
-        mask[self.topology.edges32[vert_edge.long()].reshape(-1).long()] = True
+        mask.index_fill_(0, self.topology.edges32[vert_edge.long()].reshape(-1).long(), True)  # (mask[idx] = True uploads the scalar: a sync)
         idx = torch.nonzero(mask).squeeze(1)  # sorted, unique
         pts = pos[idx]
         n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0

@@ -47,20 +47,33 @@ class _SyntheticGeometry(dmtet_mod.DMTetGeometry):
         return super().get_sdf(pts, total_iter=total_iter, feats=feats) * self._mlp_gain + prior[..., None]
 
 
+_QUADRUPED_CONSTANTS = {}
+
+
+def _quadruped_constants(device, leg_radius):
+    """Capsule end points / radii of synthetic.quadruped_sdf as device tensors, uploaded once (a per-call new_tensor is a pageable
+    host->device copy that blocks the host until the stream drains)."""
+    key = (device, float(leg_radius))
+    if key not in _QUADRUPED_CONSTANTS:
+        caps = [((0, 0.7, 1.0), (0, 1.3, 1.55), 0.27), ((0, 1.3, 1.55), (0, 1.25, 1.95), 0.22)]
+        for sx in (-1, 1):
+            for sz in (-1, 1):
+                caps.append(((0.3 * sx, 0.3, 0.85 * sz), (0.33 * sx, -1.15, 0.9 * sz), leg_radius))
+        t = lambda v: torch.tensor(v, dtype=torch.float32, device=device)
+        _QUADRUPED_CONSTANTS[key] = dict(a=t([c[0] for c in caps]), b=t([c[1] for c in caps]), r=t([c[2] for c in caps]),
+                                         centre=t([0.0, 0.45, 0.0]), radii=t([0.5, 0.55, 1.25]))
+    return _QUADRUPED_CONSTANTS[key]
+
+
 def synthetic_quadruped_device(pts, leg_radius):
     """synthetic.quadruped_sdf evaluated on the tensor's own device."""
-    def capsule(a, b, r):
-        a, b = pts.new_tensor(a), pts.new_tensor(b)
-        ab = b - a
-        t = ((pts - a) @ ab / (ab @ ab)).clamp(0, 1)
-        return r - (pts - (a + t[..., None] * ab)).norm(dim=-1)
-
-    body = (1.0 - ((pts - pts.new_tensor([0.0, 0.45, 0.0])) / pts.new_tensor([0.5, 0.55, 1.25])).norm(dim=-1)) * 0.5
-    parts = [body, capsule((0, 0.7, 1.0), (0, 1.3, 1.55), 0.27), capsule((0, 1.3, 1.55), (0, 1.25, 1.95), 0.22)]
-    for sx in (-1, 1):
-        for sz in (-1, 1):
-            parts.append(capsule((0.3 * sx, 0.3, 0.85 * sz), (0.33 * sx, -1.15, 0.9 * sz), leg_radius))
-    return torch.stack(parts, 0).amax(0)
+    c = _quadruped_constants(pts.device, leg_radius)
+    body = (1.0 - ((pts - c["centre"]) / c["radii"]).norm(dim=-1)) * 0.5
+    ab = c["b"] - c["a"]  # [6,3]
+    rel = pts[..., None, :] - c["a"]  # [...,6,3]
+    t = ((rel * ab).sum(-1) / (ab * ab).sum(-1)).clamp(0, 1)
+    capsules = c["r"] - (rel - t[..., None] * ab).norm(dim=-1)  # [...,6]
+    return torch.maximum(body, capsules.amax(-1))
 
 
 class SyntheticScene(torch.nn.Module):
