@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 def _activation(name):
@@ -45,6 +46,45 @@ class HarmonicEmbedding(nn.Module):
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 
+SPLITK_MIN_ROWS = 65536  # point lists at least this long take the split-K weight gradient below
+SPLITK_PARTS = 16
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x @ W^T for a long point list x [M,K] (M ~ 2e5) and a small weight W [N,K].
+
+    Forward and the input gradient are the GEMMs autograd would issue.  The weight gradient g^T x is a [N,M] x [M,K] product with
+    a tiny output and a huge reduction: as ONE GEMM rocBLAS/hipBLASLt reach 65 TFLOP/s on gfx950 (409 us tuned, 606 us untuned at
+    M=204800, N=K=256); cut into SPLITK_PARTS row blocks and issued as a batched GEMM + a sum of the partial products it takes
+    222 us (tools/scratch/wgrad_split.py).  Same sum, different association: equal to fp32 rounding (7e-6 relative).
+    The backward is written with differentiable torch ops, so double backward (create_graph=True) still works.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x.mm(weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            s, m = SPLITK_PARTS, x.shape[0]
+            g = g.contiguous()
+            gw = torch.bmm(g.view(s, m // s, g.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+        return gx, gw
+
+
+def linear(x, weight, bias=None):
+    """F.linear, with the split-K weight gradient for long point lists on the GPU."""
+    if (bias is None and x.is_cuda and x.dim() == 2 and x.shape[0] >= SPLITK_MIN_ROWS and x.shape[0] % SPLITK_PARTS == 0
+            and x.is_contiguous() and torch.is_grad_enabled() and weight.requires_grad):
+        return _LinearSplitK.apply(x, weight)
+    return F.linear(x, weight, bias)
+
+
 class MLP(nn.Module):
     """Bias-free Linear/ReLU stack (reference networks/MLPs.py:9-32)."""
 
@@ -64,7 +104,9 @@ class MLP(nn.Module):
         self.network = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.network(x)
+        for layer in self.network:
+            x = linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+        return x
 
 
 class CoordMLP(nn.Module):

@@ -23,7 +23,7 @@ def short(name):
 def category(name):
     if name.startswith("Cijk_") or "rocblas" in name:
         return "torch GEMM (MLPs)"
-    for tag in ("rs_", "ip_", "aa_", "dm_", "sk_", "nr_", "gb_"):
+    for tag in ("rs_", "ip_", "aa_", "dm_", "sk_", "nr_", "gb_", "bn_", "cv_", "sh_", "ss_"):
         if name.startswith(tag) or name.startswith("void " + tag):
             return "a3d HIP kernels"
     if "rocclr" in name or "fillBuffer" in name.lower():
