@@ -8,10 +8,19 @@
 
 #define SS_ROWS 128
 
-template <int VEC>
+// MASK: the summand is g * (y > 0) -- the ReLU adjoint -- and is also stored to g_pre (a3d_rows_add_relu_bwd)
+template <int VEC, bool MASK>
 __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, const long long* __restrict__ img, long long P, int C, int B,
-                                                 int CP, float* __restrict__ out) {
+                                                 int CP, float* __restrict__ out, const float* __restrict__ y, float* __restrict__ g_pre) {
     __shared__ float s_part[256 * VEC];
+    auto val = [&](long long i) -> float {
+        float v = g[i];
+        if (MASK) {
+            v = y[i] > 0.f ? v : 0.f;
+            g_pre[i] = v;
+        }
+        return v;
+    };
     const int RL = 256 / CP;
     const int c = threadIdx.x % CP, rl = threadIdx.x / CP;
     const int CV = C / VEC;  // columns in units of VEC floats
@@ -30,13 +39,13 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
                 for (; r + RL < r1; r += 2 * RL) {  // two independent row streams per thread
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        acc[0][k] += g[r * C + (long long)cc * VEC + k];
-                        acc[1][k] += g[(r + RL) * C + (long long)cc * VEC + k];
+                        acc[0][k] += val(r * C + (long long)cc * VEC + k);
+                        acc[1][k] += val((r + RL) * C + (long long)cc * VEC + k);
                     }
                 }
                 if (r < r1) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[0][k] += g[r * C + (long long)cc * VEC + k];
+                    for (int k = 0; k < VEC; ++k) acc[0][k] += val(r * C + (long long)cc * VEC + k);
                 }
             }
 #pragma unroll
@@ -54,25 +63,74 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
         } else if (active) {  // block straddles an image boundary (at most B-1 blocks do): plain per-row atomics
             for (long long r = r0 + rl; r < r1; r += RL) {
                 const long long b = img[r];
-                if ((unsigned long long)b < (unsigned long long)B)
-                    for (int k = 0; k < VEC; ++k) atomicAdd(out + b * C + (long long)cc * VEC + k, g[r * C + (long long)cc * VEC + k]);
+                for (int k = 0; k < VEC; ++k) {
+                    const float v = val(r * C + (long long)cc * VEC + k);
+                    if ((unsigned long long)b < (unsigned long long)B) atomicAdd(out + b * C + (long long)cc * VEC + k, v);
+                }
             }
         }
     }
 }
 
-extern "C" int a3d_rows_segsum(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, a3d_stream_t stream) {
-    A3D_CHECK_ARG(out && B > 0 && C > 0 && P >= 0);
-    hipStream_t s = (hipStream_t)stream;
+// y[p,:] = max(y[p,:] + rows[img[p],:], 0) in place: a per-image addend folded into the ReLU pass that follows a GEMM
+template <int VEC>
+__global__ __launch_bounds__(256) void ss_add_relu_kernel(float* __restrict__ y, const float* __restrict__ rows, const long long* __restrict__ img,
+                                                          long long n, int CV, int B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long p = i / CV;
+    const int c = (int)(i - p * CV);
+    const long long b = img[p];
+    const bool ok = (unsigned long long)b < (unsigned long long)B;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float add = ok ? rows[b * CV * VEC + (long long)c * VEC + k] : 0.f;
+        y[i * VEC + k] = fmaxf(y[i * VEC + k] + add, 0.f);
+    }
+}
+
+static int ss_launch(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, const float* y, float* g_pre, hipStream_t s) {
     A3D_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C, s));
     if (P == 0) return A3D_OK;
-    A3D_CHECK_ARG(g && img);
     const int vec = (C % 4 == 0 && C >= 64) ? 4 : 1;
     int CP = 1;
     while (CP < C / vec && CP < 256) CP <<= 1;
     const dim3 grid(a3d_div_up(P, SS_ROWS)), block(256);
-    if (vec == 4) hipLaunchKernelGGL(ss_kernel<4>, grid, block, 0, s, g, (const long long*)img, (long long)P, C, B, CP, out);
-    else hipLaunchKernelGGL(ss_kernel<1>, grid, block, 0, s, g, (const long long*)img, (long long)P, C, B, CP, out);
+    const long long* im = (const long long*)img;
+    if (y) {
+        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+        else hipLaunchKernelGGL((ss_kernel<1, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+        else hipLaunchKernelGGL((ss_kernel<1, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+    }
     A3D_LAUNCH_CHECK();
     return A3D_OK;
+}
+
+extern "C" int a3d_rows_segsum(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, a3d_stream_t stream) {
+    A3D_CHECK_ARG(out && B > 0 && C > 0 && P >= 0);
+    A3D_CHECK_ARG(P == 0 || (g && img));
+    return ss_launch(g, img, P, C, B, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int a3d_rows_add_relu_fwd(float* y, const float* rows, const int64_t* img, int64_t P, int C, int B, a3d_stream_t stream) {
+    A3D_CHECK_ARG(B > 0 && C > 0 && P >= 0);
+    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(y && rows && img);
+    const int vec = C % 4 == 0 ? 4 : 1;
+    const long long n = (long long)P * (C / vec);
+    if (vec == 4) hipLaunchKernelGGL(ss_add_relu_kernel<4>, dim3(a3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, y, rows,
+                                     (const long long*)img, n, C / 4, B);
+    else hipLaunchKernelGGL(ss_add_relu_kernel<1>, dim3(a3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, y, rows, (const long long*)img,
+                            n, C, B);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, int64_t P, int C, int B, float* g_pre, float* g_rows,
+                                     a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_rows && B > 0 && C > 0 && P >= 0);
+    A3D_CHECK_ARG(P == 0 || (g && y && img && g_pre));
+    return ss_launch(g, img, P, C, B, g_rows, y, g_pre, (hipStream_t)stream);
 }

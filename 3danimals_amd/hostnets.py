@@ -103,8 +103,23 @@ class MLP(nn.Module):
             layers.append(_activation(activation))
         self.network = nn.Sequential(*layers)
 
-    def forward(self, x):
-        for layer in self.network:
+    def forward(self, x, first_weight=None, per_image=None, index=None):
+        """Plain stack; or, with ``first_weight`` [nf,K], ``per_image`` [B,nf] and ``index`` [P] (CoordMLP's per-image feature
+        path), the first Linear is evaluated as x @ first_weight^T + per_image[index], the addend folded into the ReLU pass."""
+        layers = list(self.network)
+        i = 0
+        if first_weight is not None:
+            assert isinstance(layers[0], nn.Linear) and layers[0].bias is None
+            x = linear(x, first_weight)
+            if len(layers) > 1 and isinstance(layers[1], nn.ReLU) and x.is_cuda:
+                from . import ops
+
+                x = ops.rows_add_relu_(x, per_image, index)  # one in-place pass: + per_image[index], ReLU
+                i = 2
+            else:
+                x = x + per_image[index]
+                i = 1
+        for layer in layers[i:]:
             x = linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
         return x
 
@@ -134,8 +149,20 @@ class CoordMLP(nn.Module):
         self.bsdf = None
         self.in_layer_relu = in_layer_relu
 
-    def forward(self, x, feat=None):
+    indexed_feat = True  # sample(x, feat=[B,C], feat_index=[P]) is understood
+
+    def forward(self, x, feat=None, feat_index=None):
+        """``feat_index`` (int64 [P], optional, not in the reference signature): ``feat`` is then one row per IMAGE and point p uses
+        row feat_index[p].  The reference concatenates the per-point copy of the feature to the hidden vector and multiplies by
+        the [nf, nf+C] weight (MLPs.py:84-90); with W = [W_h | W_f] that product is relu(h) W_h^T + (relu(feat) W_f^T)[index]:
+        the feature half becomes a [B,C] x [C,nf] GEMM and a row gather instead of a [P,C] x [C,nf] GEMM over 2e5 points
+        (and its two backward GEMMs), and the [P, nf+C] concatenation disappears.  Same sum, equal to fp32 rounding."""
         assert (feat is None and self.extra_feat_dim == 0) or (feat.shape[-1] == self.extra_feat_dim)
+        if feat_index is not None and feat is not None and x.dim() == 2 and isinstance(self.mlp.network[0], nn.Linear) \
+                and self.mlp.network[0].bias is None:
+            return self._forward_indexed(x, feat, feat_index)
+        if feat_index is not None and feat is not None:
+            feat = feat[feat_index]
         if self.symmetrize:
             x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
         h = x
@@ -155,5 +182,24 @@ class CoordMLP(nn.Module):
             out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
         return out
 
-    def sample(self, x, feat=None):
-        return self.forward(x, feat)
+    def _forward_indexed(self, x, feat, feat_index):
+        if self.symmetrize:
+            x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
+        h = x
+        if self.embedder is not None:
+            h = self.embedder(x)
+            if self.embed_concat_pts:
+                h = torch.cat([x, h], -1)
+        h = self.in_layer(h)
+        if self.in_layer_relu:
+            h = self.relu(h)
+        nf = h.shape[-1]
+        weight = self.mlp.network[0].weight
+        per_image = F.linear(torch.relu(feat), weight[:, nf:])  # [B, nf]
+        out = self.mlp(self.relu(h), first_weight=weight[:, :nf].contiguous(), per_image=per_image, index=feat_index)
+        if self.min_max is not None:
+            out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+        return out
+
+    def sample(self, x, feat=None, feat_index=None):
+        return self.forward(x, feat, feat_index)

@@ -162,12 +162,18 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
         per_img_p = lambda t: None if t is None else (_rows_per_point(t, img_p, b) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
     else:
         tex_in, per_img_p = tex_pos, per_img
+    def field(net, x, f):
+        # networks that understand (per-image rows, point -> image index) get that instead of a [P,C] per-point copy of the feature
+        if f is not None and f.shape[0] == b and getattr(net, "indexed_feat", False):
+            return net.sample(x, feat=f, feat_index=img_p if n_pad else img)
+        return net.sample(x, feat=per_img_p(f))
+
     if material is not None:
-        all_tex = material.sample(tex_in, feat=per_img_p(feat))[:n_pts]
+        all_tex = field(material, tex_in, feat)[:n_pts]
     else:
         all_tex = torch.ones(n_pts, 9, device=dev)
     kd, ks = all_tex[..., :3], all_tex[..., 3:6]
-    dino_pred = dino_net.sample(tex_in, feat=per_img_p(class_vector))[:n_pts] if dino_net is not None else None
+    dino_pred = field(dino_net, tex_in, class_vector)[:n_pts] if dino_net is not None else None
 
     # the narrow per-image quantities (camera rotation 9, view position 3, light parameters 5) travel to the points as ONE gather
     _resolve_bsdf(bsdf, material)

@@ -456,6 +456,35 @@ def rows_per_point(t, img):
     return _RowsPerPoint.apply(t, img) if (t.requires_grad and torch.is_grad_enabled()) else t.index_select(0, img)
 
 
+class _RowsAddReLU(torch.autograd.Function):
+    """relu(y + rows[img]) computed in place on y (the output of a GEMM over the point list)."""
+
+    @staticmethod
+    def forward(ctx, y, rows, img):
+        require_device(y, rows, img, what="rows_add_relu")
+        assert y.is_contiguous() and y.dtype == torch.float32 and y.dim() == 2 and rows.shape[1] == y.shape[1] and img.shape[0] == y.shape[0]
+        rows = f32c(rows)
+        call("a3d_rows_add_relu_fwd", ptr(y), ptr(rows), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream())
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y, img)
+        ctx.b = rows.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, img = ctx.saved_tensors
+        g = f32c(g)
+        g_pre = torch.empty_like(g)
+        g_rows = torch.empty((ctx.b, y.shape[1]), dtype=torch.float32, device=g.device)
+        call("a3d_rows_add_relu_bwd", ptr(g), ptr(y), ptr(img), y.shape[0], y.shape[1], ctx.b, ptr(g_pre), ptr(g_rows), stream())
+        return g_pre, g_rows, None
+
+
+def rows_add_relu_(y, rows, img):
+    """In place: y[p] = relu(y[p] + rows[img[p]]);  y [P,C] fresh GEMM output, rows [B,C], img int64 [P]."""
+    return _RowsAddReLU.apply(y, rows, img)
+
+
 # ---------------------------------------------------------------------------------------------- antialias
 class AAAnalysis:
     """Silhouette-crossing work list for one (rast, clip, topology); shared by every colour buffer."""

@@ -167,6 +167,13 @@ int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, c
  * broadcasting per-image rows (feat / light / w2c, render.py:53-94) to the covered pixels.  Replaces torch index_add.
  */
 int a3d_rows_segsum(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, a3d_stream_t stream);
+/* y[p,:] = max(y[p,:] + rows[img[p],:], 0) in place -- a per-image addend folded into the ReLU that follows a GEMM over the point
+ * list (the per-image feature path of the texture field: /root/reference/model/networks/MLPs.py:84-90 concatenates the feature to
+ * every point instead).  bwd: g_pre = g * (y > 0) (the gradient of the GEMM output) and g_rows[B,C] = its per-image sums, one pass. */
+int a3d_rows_add_relu_fwd(float* y /*[P,C] in/out*/, const float* rows /*[B,C]*/, const int64_t* img /*[P]*/, int64_t P, int C, int B,
+                          a3d_stream_t stream);
+int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, int64_t P, int C, int B, float* g_pre /*[P,C]*/,
+                          float* g_rows /*[B,C], zeroed by callee*/, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Antialias -- replaces dr.antialias(color, rast, pos, tri), /root/reference/model/render/render.py:264-267.

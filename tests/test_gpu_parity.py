@@ -807,3 +807,37 @@ def test_shade_points_kernel_matches_oracle(light, two_sided, dev, ops):
         # gradients through normalize() of near-zero vectors are huge and ill-conditioned: compare relative to each row's scale
         scale = b_.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
         assert float(((a - b_).abs() / scale).max()) < 2e-4, (name, float(((a - b_).abs() / scale).max()))
+
+
+def test_rows_add_relu_and_indexed_feature_field(dev, ops):
+    """a3d_rows_add_relu_fwd/bwd against torch, and CoordMLP's per-image feature path (HIP add+ReLU, split-K weight gradient)
+    against the reference formulation (feature concatenated per point) on the GPU."""
+    hostnets = importlib.import_module("3danimals_amd.hostnets")
+    g = torch.Generator().manual_seed(5)
+    P, C, B = 70000, 64, 5
+    img = torch.randint(0, B, (P,), generator=g).sort().values.to(dev)
+    img[-100:] = 0  # padded tail rows map to image 0, unsorted (render.POINT_BUCKET padding)
+    y0 = torch.randn(P, C, generator=g).to(dev).requires_grad_(True)
+    rows = torch.randn(B, C, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(P, C, generator=g).to(dev)
+    out = ops.rows_add_relu_(y0 * 1.0, rows, img)
+    ga = torch.autograd.grad((out * w).sum(), [y0, rows])
+    ref = torch.relu(y0 + rows[img])
+    gb = torch.autograd.grad((ref * w).sum(), [y0, rows])
+    assert torch.equal(out, ref) and torch.equal(ga[0], gb[0])
+    assert torch.allclose(ga[1], gb[1], rtol=1e-4, atol=1e-3)
+
+    torch.manual_seed(0)
+    net = hostnets.CoordMLP(3, 9, 5, nf=256, n_harmonic_functions=10, extra_feat_dim=256, min_max=torch.tensor([[0.0, 1.0]] * 9),
+                            activation="sigmoid", symmetrize=True).to(dev)
+    P = hostnets.SPLITK_MIN_ROWS + 8192
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    feat = torch.randn(B, 256, generator=g).to(dev).requires_grad_(True)
+    idx = torch.randint(0, B, (P,), generator=g).sort().values.to(dev)
+    a = net.sample(x, feat=feat, feat_index=idx)
+    ga = torch.autograd.grad(a.square().sum(), [feat] + list(net.parameters()))
+    b_ = net.sample(x, feat=feat[idx])
+    gb = torch.autograd.grad(b_.square().sum(), [feat] + list(net.parameters()))
+    assert torch.allclose(a, b_, atol=2e-6)
+    for u, v in zip(ga, gb):
+        assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-6

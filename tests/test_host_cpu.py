@@ -309,3 +309,24 @@ def test_write_obj_format(tmp_path):
     assert text[2] == "v 0.0 0.5 1.0 " and text[5] == "vt 0.0 1.0 " and text[7] == "vt 0.0 0.75 "
     assert text[8] == "vn 0.0 0.0 1.0"
     assert text[-1] == "f  1/1/1 2/2/2 3/3/3" and "usemtl defaultMat" in text
+
+
+def test_coordmlp_per_image_feature_path_equals_concatenation():
+    """CoordMLP.sample(x, feat=[B,C], feat_index=[P]) == the reference formulation with the per-point feature concatenated
+    (networks/MLPs.py:84-90), values and gradients (same sum, other association -> fp32 rounding)."""
+    import importlib
+
+    hostnets = importlib.import_module("3danimals_amd.hostnets")
+    torch.manual_seed(0)
+    net = hostnets.CoordMLP(3, 9, 4, nf=32, n_harmonic_functions=4, extra_feat_dim=16, min_max=torch.tensor([[0.0, 1.0]] * 9),
+                            activation="sigmoid", symmetrize=True)
+    x = torch.rand(500, 3) * 2 - 1
+    feat = torch.randn(4, 16, requires_grad=True)
+    idx = torch.randint(0, 4, (500,)).sort().values
+    a = net.sample(x, feat=feat, feat_index=idx)
+    ga = torch.autograd.grad(a.square().sum(), [feat] + list(net.parameters()))
+    b = net.sample(x, feat=feat[idx])
+    gb = torch.autograd.grad(b.square().sum(), [feat] + list(net.parameters()))
+    assert torch.allclose(a, b, atol=1e-6)
+    for u, v in zip(ga, gb):
+        assert torch.allclose(u, v, atol=1e-5, rtol=1e-4)
