@@ -71,18 +71,62 @@ class _LinearSplitK(torch.autograd.Function):
         gx = g.mm(weight) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            s, m = SPLITK_PARTS, x.shape[0]
-            g = g.contiguous()
-            gw = torch.bmm(g.view(s, m // s, g.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+            gw = _split_k_weight_grad(g.contiguous(), x)
         return gx, gw
+
+
+def _split_k_weight_grad(g, x):
+    s, m = SPLITK_PARTS, x.shape[0]
+    return torch.bmm(g.view(s, m // s, g.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+
+
+_ZERO_BIAS = {}
+
+
+class _LinearReLUSplitK(torch.autograd.Function):
+    """relu(x @ W^T + b) for a long point list: the bias add and the ReLU ride in the GEMM epilogue (hipBLASLt through
+    torch._addmm_activation: 235 us against 215 + 85 us for GEMM + a separate ReLU pass at M=204800, N=K=256; bit-identical
+    values), the weight gradient is the split-K batched GEMM of _LinearSplitK."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        b = bias
+        if b is None:
+            key = (x.device, weight.shape[0])
+            b = _ZERO_BIAS.get(key)
+            if b is None:
+                b = _ZERO_BIAS[key] = torch.zeros(weight.shape[0], dtype=x.dtype, device=x.device)
+        y = torch._addmm_activation(b, x, weight.t(), use_gelu=False)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gw = _split_k_weight_grad(g, x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _long_list(x, weight):
+    return (x.is_cuda and x.dim() == 2 and x.shape[0] >= SPLITK_MIN_ROWS and x.shape[0] % SPLITK_PARTS == 0 and x.is_contiguous()
+            and x.dtype == torch.float32 and torch.is_grad_enabled() and weight.requires_grad)
 
 
 def linear(x, weight, bias=None):
     """F.linear, with the split-K weight gradient for long point lists on the GPU."""
-    if (bias is None and x.is_cuda and x.dim() == 2 and x.shape[0] >= SPLITK_MIN_ROWS and x.shape[0] % SPLITK_PARTS == 0
-            and x.is_contiguous() and torch.is_grad_enabled() and weight.requires_grad):
+    if bias is None and _long_list(x, weight):
         return _LinearSplitK.apply(x, weight)
     return F.linear(x, weight, bias)
+
+
+def linear_relu(x, weight, bias=None):
+    """relu(F.linear(x, weight, bias)); epilogue-fused with the split-K weight gradient for long point lists on the GPU."""
+    if _long_list(x, weight):
+        return _LinearReLUSplitK.apply(x, weight, bias)
+    return torch.relu_(F.linear(x, weight, bias))
 
 
 class MLP(nn.Module):
@@ -119,8 +163,14 @@ class MLP(nn.Module):
             else:
                 x = x + per_image[index]
                 i = 1
-        for layer in layers[i:]:
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, nn.Linear) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                x = linear_relu(x, layer.weight, layer.bias)
+                i += 2
+                continue
             x = linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+            i += 1
         return x
 
 
@@ -170,14 +220,16 @@ class CoordMLP(nn.Module):
             h = self.embedder(x)
             if self.embed_concat_pts:
                 h = torch.cat([x, h], -1)
-        h = self.in_layer(h)
-        if self.in_layer_relu:
-            h = self.relu(h)
-        if feat is not None:
+        if feat is None:  # relu(in_layer(.)) feeds the stack directly: one fused Linear+ReLU
+            out = self.mlp(linear_relu(h, self.in_layer.weight, self.in_layer.bias))
+        else:
+            h = self.in_layer(h)
+            if self.in_layer_relu:
+                h = self.relu(h)
             while feat.dim() < h.dim():
                 feat = feat.unsqueeze(1)
             h = torch.cat([h, feat.expand(*h.shape[:-1], -1)], dim=-1)
-        out = self.mlp(self.relu(h))
+            out = self.mlp(self.relu(h))
         if self.min_max is not None:
             out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
         return out
@@ -190,13 +242,11 @@ class CoordMLP(nn.Module):
             h = self.embedder(x)
             if self.embed_concat_pts:
                 h = torch.cat([x, h], -1)
-        h = self.in_layer(h)
-        if self.in_layer_relu:
-            h = self.relu(h)
+        h = linear_relu(h, self.in_layer.weight, self.in_layer.bias)
         nf = h.shape[-1]
         weight = self.mlp.network[0].weight
         per_image = F.linear(torch.relu(feat), weight[:, nf:])  # [B, nf]
-        out = self.mlp(self.relu(h), first_weight=weight[:, :nf].contiguous(), per_image=per_image, index=feat_index)
+        out = self.mlp(h, first_weight=weight[:, :nf].contiguous(), per_image=per_image, index=feat_index)
         if self.min_max is not None:
             out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
         return out
