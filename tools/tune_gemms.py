@@ -42,8 +42,9 @@ def main():
     feat = scene.feat.detach()
     for m in range(args.lo, args.hi + 1, render.POINT_BUCKET):
         x = torch.rand(m, 3, device=dev, requires_grad=True)
-        f = feat[torch.randint(0, feat.shape[0], (m,), device=dev)].requires_grad_(True)
-        (scene.netTexture.sample(x, feat=f).sum() + scene.netDINO.sample(x).sum()).backward()
+        idx = torch.randint(0, feat.shape[0], (m,), device=dev).sort().values
+        f = feat.clone().requires_grad_(True)  # per-image rows + point->image index, as render._shade_points passes them
+        (scene.netTexture.sample(x, feat=f, feat_index=idx).sum() + scene.netDINO.sample(x).sum()).backward()
         print(f"bucket {m}: {time.time() - t0:.0f}s", flush=True)
     geo = scene.netShape
     with torch.no_grad():
