@@ -21,6 +21,21 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
         }
         return v;
     };
+    // VEC floats at element offset i (16-byte aligned when VEC == 4: C % 4 == 0 and torch allocations are 256 B aligned)
+    auto add_group = [&](long long i, float* acc) {
+        if constexpr (VEC == 4) {
+            float4 v = *reinterpret_cast<const float4*>(g + i);
+            if (MASK) {
+                const float4 t = *reinterpret_cast<const float4*>(y + i);
+                v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4*>(g_pre + i) = v;
+            }
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += val(i + k);
+        }
+    };
     const int RL = 256 / CP;
     const int c = threadIdx.x % CP, rl = threadIdx.x / CP;
     const int CV = C / VEC;  // columns in units of VEC floats
@@ -37,16 +52,10 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
             if (active) {
                 long long r = r0 + rl;
                 for (; r + RL < r1; r += 2 * RL) {  // two independent row streams per thread
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        acc[0][k] += val(r * C + (long long)cc * VEC + k);
-                        acc[1][k] += val((r + RL) * C + (long long)cc * VEC + k);
-                    }
+                    add_group(r * C + (long long)cc * VEC, acc[0]);
+                    add_group((r + RL) * C + (long long)cc * VEC, acc[1]);
                 }
-                if (r < r1) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[0][k] += val(r * C + (long long)cc * VEC + k);
-                }
+                if (r < r1) add_group(r * C + (long long)cc * VEC, acc[0]);
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) s_part[threadIdx.x * VEC + k] = acc[0][k] + acc[1][k];
@@ -72,21 +81,31 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
     }
 }
 
-// y[p,:] = max(y[p,:] + rows[img[p],:], 0) in place: a per-image addend folded into the ReLU pass that follows a GEMM
-template <int VEC>
-__global__ __launch_bounds__(256) void ss_add_relu_kernel(float* __restrict__ y, const float* __restrict__ rows, const long long* __restrict__ img,
-                                                          long long n, int CV, int B) {
+// y[p,:] = max(y[p,:] + rows[img[p],:], 0) in place: a per-image addend folded into the ReLU pass that follows a GEMM.
+// Pure streaming (read + write of y); rows[B,C] stays in L2.  One thread per 16 B (or per float when C % 4 != 0).
+__global__ __launch_bounds__(256) void ss_add_relu4_kernel(float4* __restrict__ y, const float4* __restrict__ rows,
+                                                           const long long* __restrict__ img, unsigned n, unsigned CV, int B) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned p = i / CV, c = i - p * CV;
+    const long long b = img[p];
+    float4 v = y[i];
+    if ((unsigned long long)b < (unsigned long long)B) {
+        const float4 a = rows[(unsigned)b * CV + c];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    y[i] = v;
+}
+
+__global__ __launch_bounds__(256) void ss_add_relu1_kernel(float* __restrict__ y, const float* __restrict__ rows, const long long* __restrict__ img,
+                                                           long long n, int C, int B) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long p = i / CV;
-    const int c = (int)(i - p * CV);
+    const long long p = i / C;
     const long long b = img[p];
-    const bool ok = (unsigned long long)b < (unsigned long long)B;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const float add = ok ? rows[b * CV * VEC + (long long)c * VEC + k] : 0.f;
-        y[i * VEC + k] = fmaxf(y[i * VEC + k] + add, 0.f);
-    }
+    const float add = (unsigned long long)b < (unsigned long long)B ? rows[b * C + (i - p * C)] : 0.f;
+    y[i] = fmaxf(y[i] + add, 0.f);
 }
 
 static int ss_launch(const float* g, const int64_t* img, int64_t P, int C, int B, float* out, const float* y, float* g_pre, hipStream_t s) {
@@ -118,12 +137,12 @@ extern "C" int a3d_rows_add_relu_fwd(float* y, const float* rows, const int64_t*
     A3D_CHECK_ARG(B > 0 && C > 0 && P >= 0);
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(y && rows && img);
-    const int vec = C % 4 == 0 ? 4 : 1;
-    const long long n = (long long)P * (C / vec);
-    if (vec == 4) hipLaunchKernelGGL(ss_add_relu_kernel<4>, dim3(a3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, y, rows,
-                                     (const long long*)img, n, C / 4, B);
-    else hipLaunchKernelGGL(ss_add_relu_kernel<1>, dim3(a3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, y, rows, (const long long*)img,
-                            n, C, B);
+    const long long n = (long long)P * C;
+    if (C % 4 == 0 && n / 4 < 0xffffffffll && (long long)B * C / 4 < 0xffffffffll)
+        hipLaunchKernelGGL(ss_add_relu4_kernel, dim3(a3d_div_up(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)y, (const float4*)rows,
+                           (const long long*)img, (unsigned)(n / 4), (unsigned)(C / 4), B);
+    else
+        hipLaunchKernelGGL(ss_add_relu1_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, y, rows, (const long long*)img, n, C, B);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -841,3 +841,33 @@ def test_rows_add_relu_and_indexed_feature_field(dev, ops):
     assert torch.allclose(a, b_, atol=2e-6)
     for u, v in zip(ga, gb):
         assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-6
+
+
+def test_ddp_wrapper_over_rccl_gives_the_same_gradients(dev):
+    """The scene under DistributedDataParallel (backend nccl = RCCL, world size 1 on this box): custom autograd Functions, in-place
+    HIP ops and the split-K weight gradients behind DDP's hooks give the gradients of the bare module; no parameter is unused."""
+    import socket
+    import torch.distributed as dist
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    kw = dict(grid_res=16, batch=2, resolution=(64, 64), device=dev, seed=3, net_width=32, net_layers=3, feat_dim=16, embedder_freq=4)
+    bare = pipeline.SyntheticScene(**kw)
+    torch.manual_seed(7)  # the step jitters the grid with the global generator
+    bare.step(optimizer_step=False)
+    want = {n: p.grad.clone() for n, p in bare.named_parameters()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        scene = pipeline.SyntheticScene(**kw)
+        module = torch.nn.parallel.DistributedDataParallel(scene, device_ids=[torch.device(dev).index or 0], broadcast_buffers=False,
+                                                           gradient_as_bucket_view=True)
+        for _ in range(2):  # twice: the second backward runs with DDP's rebuilt buckets
+            torch.manual_seed(7)
+            scene.step(module=module, optimizer_step=False)
+        for n, p in scene.named_parameters():
+            assert p.grad is not None, n
+            assert float((p.grad - want[n]).abs().max()) <= 1e-5 * float(want[n].abs().max()) + 1e-7, n
+    finally:
+        dist.destroy_process_group()
