@@ -46,19 +46,22 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
         const int cc = cbase + c;
         const bool active = cc < CV;
         if (first == last) {  // the whole block belongs to one image (the list is sorted): branch-free accumulation
-            float acc[2][VEC];
+            constexpr int NS = 4;  // independent row streams per thread (loads in flight)
+            float acc[NS][VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0.f;
+            for (int q = 0; q < NS; ++q)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[q][k] = 0.f;
             if (active) {
                 long long r = r0 + rl;
-                for (; r + RL < r1; r += 2 * RL) {  // two independent row streams per thread
-                    add_group(r * C + (long long)cc * VEC, acc[0]);
-                    add_group((r + RL) * C + (long long)cc * VEC, acc[1]);
+                for (; r + (long long)(NS - 1) * RL < r1; r += (long long)NS * RL) {
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) add_group((r + (long long)q * RL) * C + (long long)cc * VEC, acc[q]);
                 }
-                if (r < r1) add_group(r * C + (long long)cc * VEC, acc[0]);
+                for (; r < r1; r += RL) add_group(r * C + (long long)cc * VEC, acc[0]);
             }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) s_part[threadIdx.x * VEC + k] = acc[0][k] + acc[1][k];
+            for (int k = 0; k < VEC; ++k) s_part[threadIdx.x * VEC + k] = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
             __syncthreads();
             if (rl == 0 && active && (unsigned long long)first < (unsigned long long)B) {
 #pragma unroll

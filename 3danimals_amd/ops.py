@@ -446,7 +446,7 @@ class _RowsPerPoint(torch.autograd.Function):
         g = f32c(g)
         P, C = g.shape[0], int(math.prod(g.shape[1:]))
         out = torch.empty((ctx.b,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
-        call("a3d_rows_segsum", ptr(g), ptr(img), P, C, ctx.b, ptr(out), stream())
+        call("a3d_rows_segsum", ptr(g), ptr(img), P, C, ctx.b, ptr(out), stream(), tag=f"[C{C}]")
         return out, None
 
 
@@ -464,7 +464,7 @@ class _RowsAddReLU(torch.autograd.Function):
         require_device(y, rows, img, what="rows_add_relu")
         assert y.is_contiguous() and y.dtype == torch.float32 and y.dim() == 2 and rows.shape[1] == y.shape[1] and img.shape[0] == y.shape[0]
         rows = f32c(rows)
-        call("a3d_rows_add_relu_fwd", ptr(y), ptr(rows), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream())
+        call("a3d_rows_add_relu_fwd", ptr(y), ptr(rows), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream(), tag=f"[C{y.shape[1]}]")
         ctx.mark_dirty(y)
         ctx.save_for_backward(y, img)
         ctx.b = rows.shape[0]
@@ -476,7 +476,8 @@ class _RowsAddReLU(torch.autograd.Function):
         g = f32c(g)
         g_pre = torch.empty_like(g)
         g_rows = torch.empty((ctx.b, y.shape[1]), dtype=torch.float32, device=g.device)
-        call("a3d_rows_add_relu_bwd", ptr(g), ptr(y), ptr(img), y.shape[0], y.shape[1], ctx.b, ptr(g_pre), ptr(g_rows), stream())
+        call("a3d_rows_add_relu_bwd", ptr(g), ptr(y), ptr(img), y.shape[0], y.shape[1], ctx.b, ptr(g_pre), ptr(g_rows), stream(),
+             tag=f"[C{y.shape[1]}]")
         return g_pre, g_rows, None
 
 

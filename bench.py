@@ -38,6 +38,7 @@ def algorithmic_bytes(name, d):
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
     C = int(name.split("[C")[1].split("]")[0]) if "[C" in name else 0
     base = name.split("[")[0]
+    Pp = -(-int(d.get("P", 0)) // 8192) * 8192  # render.POINT_BUCKET
     table = {
         "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt,
         "a3d_dmtet_emit": 16 * Nv + 8 * Ne + 4 * Ne + 16 * Nt + 24 * Nt + 16 * V + 48 * F,
@@ -53,6 +54,9 @@ def algorithmic_bytes(name, d):
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
         "a3d_gbuffer_fwd": int(d.get("P", 0)) * (8 + 16 + 48),
         "a3d_gbuffer_bwd": int(d.get("P", 0)) * (8 + 16 + 48) + B * V * (36 + 16),
+        "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
+        "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
+        "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums
         "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
         "a3d_cover_emit": 4 * B * HW + 8 * int(d.get("P", 0)),
         "a3d_shade_fwd": int(d.get("P", 0)) * (48 + 68 + 12 + 12 + 4 + 12),
@@ -76,6 +80,7 @@ def main():
     ap.add_argument("--grid-res", type=int, default=64)
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="do not load the shipped TunableOp results for the torch MLPs")
     ap.add_argument("--cpu-sample-images", type=int, default=4)
     args = ap.parse_args()
@@ -109,7 +114,7 @@ def main():
 
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
-    if rank == 0:
+    if rank == 0 and not args.no_kernel_timing:
         import contextlib
 
         # rank 0 alone re-runs a few steps under HIP-event timers; with DDP that must not enqueue collectives the other ranks

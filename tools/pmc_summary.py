@@ -19,7 +19,7 @@ for f in files:
         name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
         if not any(s in name for s in subs):
             continue
-        acc[name.split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[name.replace("(anonymous namespace)::", "").split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"{'kernel':42s} {'calls':>5s} {'FETCH MB (raw..x2)':>22s} {'WRITE MB':>10s}")
 for k, v in sorted(acc.items()):
     fe, wr = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])

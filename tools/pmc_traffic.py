@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch) into HBM traffic per C-ABI call.
+
+usage: python tools/pmc_traffic.py <fetch-dir> <write-dir> <out.json>
+
+gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced
+streaming reads, so traffic = 2*FETCH + WRITE (an upper bound for narrow gathers); WRITE_SIZE is uncalibrated (float atomics count
+as writes).  Infinity-Cache hits are counted, i.e. this is memory-side traffic of the L2s, not DRAM traffic.
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+# entry point -> (kernels of one call, kernel whose dispatch count = number of calls)
+ENTRY = {
+    "a3d_dmtet_count": (["dm_count_kernel", "dm_scan_kernel"], "dm_count_kernel"),
+    "a3d_dmtet_emit": (["dm_emit_edges_kernel", "dm_emit_tets_kernel"], "dm_emit_tets_kernel"),
+    "a3d_dmtet_bwd": (["dm_bwd_kernel"], "dm_bwd_kernel"),
+    "a3d_skin_fwd": (["sk_fwd_kernel"], "sk_fwd_kernel"),
+    "a3d_skin_bwd": (["sk_bwd_kernel"], "sk_bwd_kernel"),
+    "a3d_bone_transforms_fwd": (["bn_fwd_kernel"], "bn_fwd_kernel"),
+    "a3d_bone_transforms_bwd": (["bn_bwd_kernel"], "bn_bwd_kernel"),
+    "a3d_normals_adjacency": (["nr_adj_count_kernel", "nr_adj_scan_kernel", "nr_adj_fill_kernel", "nr_adj_sort_kernel"], "nr_adj_scan_kernel"),
+    "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
+    "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel"], "nr_bwd_kernel"),
+    "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
+    "a3d_cover_count": (["cv_count_kernel", "cv_scan_kernel"], "cv_count_kernel"),
+    "a3d_cover_emit": (["cv_emit_kernel"], "cv_emit_kernel"),
+    "a3d_gbuffer_fwd": (["gb_fwd_kernel"], "gb_fwd_kernel"),
+    "a3d_gbuffer_bwd": (["gb_bwd_kernel"], "gb_bwd_kernel"),
+    "a3d_shade_fwd": (["sh_fwd_kernel"], "sh_fwd_kernel"),
+    "a3d_shade_bwd": (["sh_bwd_kernel"], "sh_bwd_kernel"),
+    "a3d_rows_add_relu_fwd": (["ss_add_relu4_kernel", "ss_add_relu1_kernel"], "ss_add_relu4_kernel"),
+    "a3d_rows_add_relu_bwd": (["ss_kernel<4, true>", "ss_kernel<1, true>"], "ss_kernel<4, true>"),
+    "a3d_rows_segsum": (["ss_kernel<4, false>", "ss_kernel<1, false>"], None),
+    "a3d_aa_topology": (["aa_hash_insert_kernel", "aa_hash_lookup_kernel"], "aa_hash_insert_kernel"),
+    "a3d_aa_analyze": (["aa_analyze_kernel"], "aa_analyze_kernel"),
+    "a3d_aa_fwd": (["aa_fwd_kernel"], "aa_fwd_kernel"),
+    "a3d_aa_bwd": (["aa_bwd_kernel"], "aa_bwd_kernel"),
+}
+
+
+def load(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+            key = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+            tot[key] += float(r["Counter_Value"]) * 1024.0  # KiB -> bytes
+            cnt[key] += 1
+    return tot, cnt
+
+
+def main():
+    fetch, fcnt = load(sys.argv[1], "FETCH_SIZE")
+    write, wcnt = load(sys.argv[2], "WRITE_SIZE")
+    per_call = {}
+    for entry, (kernels, main_k) in ENTRY.items():
+        def pick(tot, cnt):
+            ks = [k for k in tot if any(k.startswith(s) or k == s for s in kernels)]
+            if not ks:
+                return None
+            calls = cnt.get(main_k, 0) if main_k else sum(cnt[k] for k in ks)
+            calls = calls or sum(cnt[k] for k in ks)
+            return sum(tot[k] for k in ks) / calls
+        fe, wr = pick(fetch, fcnt), pick(write, wcnt)
+        if fe is None and wr is None:
+            continue
+        fe, wr = fe or 0.0, wr or 0.0
+        per_call[entry] = dict(fetch_MB_raw=round(fe / 1e6, 2), write_MB=round(wr / 1e6, 2), traffic_MB=round((2 * fe + wr) / 1e6, 2))
+    out = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
+                    "MB per C-ABI call; traffic = 2*FETCH (gfx950 correction for wide reads, upper bound for gathers) + WRITE; "
+                    "the copy/memset helpers of an entry point (hipMemcpyAsync / hipMemsetAsync) are not included", per_call=per_call)
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in per_call.items():
+        print(f"{k:28s} fetch {v['fetch_MB_raw']:9.2f} MB (x2 = {2 * v['fetch_MB_raw']:9.2f})  write {v['write_MB']:9.2f} MB  traffic {v['traffic_MB']:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

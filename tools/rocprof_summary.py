@@ -21,6 +21,7 @@ def short(name):
 
 
 def category(name):
+    name = name.replace("(anonymous namespace)::", "")
     if name.startswith("Cijk_") or "rocblas" in name:
         return "torch GEMM (MLPs)"
     for tag in ("rs_", "ip_", "aa_", "dm_", "sk_", "nr_", "gb_", "bn_", "cv_", "sh_", "ss_"):
