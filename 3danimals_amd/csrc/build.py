@@ -29,6 +29,7 @@ SOURCES = {
     "interp.hip": [],
     "gbuffer.hip": [],
     "segsum.hip": [],
+    "losses.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",

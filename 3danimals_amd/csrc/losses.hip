@@ -1,0 +1,172 @@
+// Reconstruction losses on gfx950 -- the image-space consumers of the renderer's outputs, fused
+// (/root/reference/model/models/AnimalModel.py:260-307, compute_reconstruction_losses with F = 1, background_mode 'none'):
+//   mask        = mean((m*valid - mask_gt)^2)                    m = shaded alpha (antialiased coverage)
+//   mask_inv_dt = mean((1 - m) * dt0)                            dt0 = distance transform of the target mask
+//   both        = erode3x3((m*valid > 0) * mask_gt)              avg_pool2d(3, stride 1, pad 1) > 0.99, zero padded
+//   rgb         = mean(|rgb - image_gt| * both)     over 3 channels
+//   dino        = mean((dino - dino_gt)^2 * both)   over D channels
+// The reference runs ~15 elementwise/reduction passes over 4- and 17-channel full-resolution images forward and about twice that
+// backward; here one thread per pixel reads the renderer's NHWC buffers once (20 contiguous floats) and the dataset's planar NCHW
+// targets once, per-image sums are reduced wave -> block -> a second tiny kernel (fixed order: bit-reproducible), and the backward
+// writes both image gradients in one pass.
+#include "a3d_common.h"
+
+namespace {
+
+constexpr int LS_BLOCK = 256;
+
+__device__ __forceinline__ float ls_q(const float* __restrict__ shaded, const float* __restrict__ valid, const float* __restrict__ mask_gt,
+                                      long long img_px, int x, int y, int H, int W) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;  // zero padding of avg_pool2d
+    const long long p = img_px + (long long)y * W + x;
+    return (shaded[4 * p + 3] * valid[p] > 0.f ? 1.f : 0.f) * mask_gt[p];
+}
+
+__device__ __forceinline__ float ls_both(const float* __restrict__ shaded, const float* __restrict__ valid, const float* __restrict__ mask_gt,
+                                         long long img_px, int x, int y, int H, int W) {
+    float s = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) s += ls_q(shaded, valid, mask_gt, img_px, x + dx, y + dy, H, W);
+    return s / 9.f > 0.99f ? 1.f : 0.f;
+}
+
+// partial[(b*nblk + blk)*4 + k]: per-block sums of the four summands
+__global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D,
+                                                          const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
+                                                          const float* __restrict__ mask_gt, const float* __restrict__ dt0, long long dt_stride,
+                                                          const float* __restrict__ valid, int H, int W, float* __restrict__ partial) {
+    __shared__ float red[LS_BLOCK / 64][4];
+    const int b = blockIdx.y, HW = H * W;
+    const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < HW) {
+        const long long img_px = (long long)b * HW, p = img_px + i;
+        const int y = i / W, x = i - y * W;
+        const float4 s = reinterpret_cast<const float4*>(shaded)[p];
+        const float m = s.w, t = m * valid[p] - mask_gt[p];
+        v[0] = t * t;
+        v[1] = (1.f - m) * dt0[(long long)b * dt_stride + i];
+        const float both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+        const float* g = image_gt + (long long)b * 3 * HW + i;
+        v[2] = (fabsf(s.x - g[0]) + fabsf(s.y - g[HW]) + fabsf(s.z - g[2ll * HW])) * both;
+        if (dino) {
+            const float* dp = dino + p * D;
+            const float* dg = dino_gt + (long long)b * D * HW + i;
+            float acc = 0.f;
+            if ((D & 3) == 0) {  // 16-byte loads of the pixel's feature vector
+                for (int c = 0; c < D; c += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(dp + c);
+                    const float e0 = q.x - dg[(long long)c * HW], e1 = q.y - dg[(long long)(c + 1) * HW];
+                    const float e2 = q.z - dg[(long long)(c + 2) * HW], e3 = q.w - dg[(long long)(c + 3) * HW];
+                    acc += e0 * e0; acc += e1 * e1; acc += e2 * e2; acc += e3 * e3;
+                }
+            } else {
+                for (int c = 0; c < D; ++c) {
+                    const float e = dp[c] - dg[(long long)c * HW];
+                    acc += e * e;
+                }
+            }
+            v[3] = acc * both;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = a3d_wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.f;
+        for (int w = 0; w < LS_BLOCK / 64; ++w) t += red[w][threadIdx.x];
+        partial[((long long)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = t;
+    }
+}
+
+// loss[b,k] = (sum over blocks) / normaliser_k ; one wave per (image, k)
+__global__ __launch_bounds__(64) void ls_finish_kernel(const float* __restrict__ partial, int nblk, int HW, int D, float* __restrict__ loss) {
+    const int b = blockIdx.x, k = blockIdx.y;
+    float t = 0.f;
+    for (int j = threadIdx.x; j < nblk; j += 64) t += partial[((long long)b * nblk + j) * 4 + k];
+    t = a3d_wave_sum(t);
+    if (threadIdx.x == 0) {
+        const float n = k < 2 ? (float)HW : (k == 2 ? 3.f * (float)HW : (float)D * (float)HW);
+        loss[b * 4 + k] = D == 0 && k == 3 ? 0.f : t / n;
+    }
+}
+
+__global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ shaded,
+                                                          const float* __restrict__ dino, int D, const float* __restrict__ image_gt,
+                                                          const float* __restrict__ dino_gt, const float* __restrict__ mask_gt,
+                                                          const float* __restrict__ dt0, long long dt_stride, const float* __restrict__ valid,
+                                                          int H, int W, float* __restrict__ g_shaded, float* __restrict__ g_dino) {
+    const int b = blockIdx.y, HW = H * W;
+    const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const long long img_px = (long long)b * HW, p = img_px + i;
+    const int y = i / W, x = i - y * W;
+    const float gm = g_loss[4 * b] / (float)HW, gd = g_loss[4 * b + 1] / (float)HW, gr = g_loss[4 * b + 2] / (3.f * (float)HW);
+    const float4 s = reinterpret_cast<const float4*>(shaded)[p];
+    const float both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+    const float* g = image_gt + (long long)b * 3 * HW + i;
+    auto sgn = [](float e) { return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); };
+    float4 o;
+    o.x = gr * sgn(s.x - g[0]) * both;
+    o.y = gr * sgn(s.y - g[HW]) * both;
+    o.z = gr * sgn(s.z - g[2ll * HW]) * both;
+    const float va = valid[p];
+    o.w = gm * 2.f * (s.w * va - mask_gt[p]) * va - gd * dt0[(long long)b * dt_stride + i];
+    reinterpret_cast<float4*>(g_shaded)[p] = o;
+    if (dino) {
+        const float gq = g_loss[4 * b + 3] / ((float)D * (float)HW) * 2.f * both;
+        const float* dp = dino + p * D;
+        const float* dg = dino_gt + (long long)b * D * HW + i;
+        float* go = g_dino + p * D;
+        if ((D & 3) == 0) {
+            for (int c = 0; c < D; c += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(dp + c);
+                float4 o4;
+                o4.x = gq * (q.x - dg[(long long)c * HW]);
+                o4.y = gq * (q.y - dg[(long long)(c + 1) * HW]);
+                o4.z = gq * (q.z - dg[(long long)(c + 2) * HW]);
+                o4.w = gq * (q.w - dg[(long long)(c + 3) * HW]);
+                *reinterpret_cast<float4*>(go + c) = o4;
+            }
+        } else {
+            for (int c = 0; c < D; ++c) go[c] = gq * (dp[c] - dg[(long long)c * HW]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t a3d_recon_losses_scratch_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return sizeof(float) * 4 * (size_t)B * a3d_div_up((long long)H * W, LS_BLOCK);
+}
+
+extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
+                                    const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W,
+                                    void* scratch, float* loss, a3d_stream_t stream) {
+    A3D_CHECK_ARG(shaded && image_gt && mask_gt && dt0 && valid && scratch && loss && B > 0 && H > 0 && W > 0 && D >= 0);
+    A3D_CHECK_ARG(D == 0 || (dino && dino_gt));
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = a3d_div_up((long long)H * W, LS_BLOCK);
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0,
+                       (long long)dt_stride, valid, H, W, (float*)scratch);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ls_finish_kernel, dim3(B, 4), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt,
+                                    const float* dino_gt, const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B,
+                                    int H, int W, float* g_shaded, float* g_dino, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
+    A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino));
+    hipLaunchKernelGGL(ls_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
+                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, (long long)dt_stride, valid, H, W, g_shaded, g_dino);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}

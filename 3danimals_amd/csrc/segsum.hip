@@ -11,7 +11,8 @@
 // MASK: the summand is g * (y > 0) -- the ReLU adjoint -- and is also stored to g_pre (a3d_rows_add_relu_bwd)
 template <int VEC, bool MASK>
 __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, const long long* __restrict__ img, long long P, int C, int B,
-                                                 int CP, float* __restrict__ out, const float* __restrict__ y, float* __restrict__ g_pre) {
+                                                 int CP, float* __restrict__ out, const float* __restrict__ y, float* __restrict__ g_pre,
+                                                 int rows_per_block) {
     __shared__ float s_part[256 * VEC];
     auto val = [&](long long i) -> float {
         float v = g[i];
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
     const int RL = 256 / CP;
     const int c = threadIdx.x % CP, rl = threadIdx.x / CP;
     const int CV = C / VEC;  // columns in units of VEC floats
-    const long long r0 = (long long)blockIdx.x * SS_ROWS;
-    const long long r1 = min(r0 + (long long)SS_ROWS, P);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(r0 + (long long)rows_per_block, P);
     const long long first = img[r0], last = img[r1 - 1];
     for (int cbase = 0; cbase < CV; cbase += CP) {  // uniform trip count (barriers inside)
         const int cc = cbase + c;
@@ -117,14 +118,16 @@ static int ss_launch(const float* g, const int64_t* img, int64_t P, int C, int B
     const int vec = (C % 4 == 0 && C >= 64) ? 4 : 1;
     int CP = 1;
     while (CP < C / vec && CP < 256) CP <<= 1;
-    const dim3 grid(a3d_div_up(P, SS_ROWS)), block(256);
+    int rows = SS_ROWS;
+    if (const char* e = getenv("A3D_SS_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;  // experiment knob
+    const dim3 grid(a3d_div_up(P, rows)), block(256);
     const long long* im = (const long long*)img;
     if (y) {
-        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
-        else hipLaunchKernelGGL((ss_kernel<1, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
+        else hipLaunchKernelGGL((ss_kernel<1, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
     } else {
-        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
-        else hipLaunchKernelGGL((ss_kernel<1, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre);
+        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
+        else hipLaunchKernelGGL((ss_kernel<1, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
     }
     A3D_LAUNCH_CHECK();
     return A3D_OK;

@@ -537,3 +537,48 @@ def antialias(color, rast, clip, tri, analysis=None):
         tri32 = tri_int32(tri)
         analysis = AAAnalysis(rast, clip, aa_topology(tri32, clip.shape[1]))
     return _Antialias.apply(color, clip, analysis)
+
+
+# ---------------------------------------------------------------------------------------------- reconstruction losses
+class _ReconLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid):
+        require_device(shaded, image_gt, mask_gt, dt0, valid, what="reconstruction_losses")
+        B, H, W = shaded.shape[:3]
+        D = 0 if dino is None else dino.shape[3]
+        assert shaded.shape == (B, H, W, 4) and shaded.is_contiguous() and image_gt.shape == (B, 3, H, W)
+        assert dt0.shape == (B, H, W) and dt0.stride(2) == 1 and dt0.stride(1) == W
+        image_gt, mask_gt, valid = f32c(image_gt), f32c(mask_gt), f32c(valid)
+        if D:
+            assert dino.is_contiguous() and dino_gt.shape == (B, D, H, W)
+            dino_gt = f32c(dino_gt)
+        loss = torch.empty((B, 4), dtype=torch.float32, device=shaded.device)
+        scratch = torch.empty(_lib.lib().a3d_recon_losses_scratch_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
+        call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0), ptr(valid), B, H, W,
+             ptr(scratch), ptr(loss), stream())
+        ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid = ctx.saved_tensors
+        B, H, W = shaded.shape[:3]
+        D = 0 if dino is None else dino.shape[3]
+        g_shaded = torch.empty_like(shaded)
+        g_dino = torch.empty_like(dino) if D else None
+        call("a3d_recon_losses_bwd", ptr(f32c(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0),
+             ptr(valid), B, H, W, ptr(g_shaded), ptr(g_dino), stream())
+        return g_shaded, g_dino, None, None, None, None, None
+
+
+def reconstruction_losses(shaded_nchw, dino_nchw, image_gt, dino_gt, mask_gt, mask_dt, mask_valid):
+    """Per-image [B,4] = (mask, mask_inv_dt, rgb, dino) losses of compute_reconstruction_losses (AnimalModel.py:260-307; F=1,
+    background_mode 'none') from render_mesh's outputs: ``shaded_nchw`` [B,4,H,W] and ``dino_nchw`` [B,D,H,W] (or None) are the NCHW
+    views render_mesh returns (NHWC in memory -- read in place, no copy); targets in the dataset's NCHW layout; mask_dt [B,2,H,W]."""
+    shaded = shaded_nchw.permute(0, 2, 3, 1)
+    shaded = shaded if shaded.is_contiguous() else shaded.contiguous()
+    dino = None
+    if dino_nchw is not None:
+        dino = dino_nchw.permute(0, 2, 3, 1)
+        dino = dino if dino.is_contiguous() else dino.contiguous()
+    return _ReconLosses.apply(shaded, dino, image_gt, dino_gt, mask_gt, mask_dt[:, 0], mask_valid)

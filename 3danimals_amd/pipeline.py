@@ -76,6 +76,9 @@ def synthetic_quadruped_device(pts, leg_radius):
     return torch.maximum(body, capsules.amax(-1))
 
 
+FUSED_LOSSES = True  # reconstruction losses as one HIP kernel each way (csrc/losses.hip) instead of ~45 torch launches
+
+
 class SyntheticScene(torch.nn.Module):
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
                  embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4):
@@ -150,6 +153,15 @@ class SyntheticScene(torch.nn.Module):
 
     def losses(self, shaded, dino_pred):
         """compute_reconstruction_losses (AnimalModel.py:260-307), F=1, background_mode 'none'."""
+        if FUSED_LOSSES and shaded.is_cuda:
+            from . import ops
+
+            per_image = ops.reconstruction_losses(shaded, dino_pred, self.image_gt, self.dino_gt, self.mask_gt, self.mask_dt, self.mask_valid)
+            return {k: per_image[:, i] for i, k in enumerate(("mask", "mask_inv_dt", "rgb", "dino"))}
+        return self.losses_torch(shaded, dino_pred)
+
+    def losses_torch(self, shaded, dino_pred):
+        """The same four terms as plain torch expressions (the reference's formulation)."""
         image_pred, mask_pred = shaded[:, :3], shaded[:, 3]
         out = {}
         out["mask"] = ((mask_pred * self.mask_valid - self.mask_gt) ** 2).flatten(1).mean(1)

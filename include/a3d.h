@@ -195,6 +195,21 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
                const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_color,
                float* g_clip, a3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction losses -- the image-space consumers of render_mesh's outputs, fused:
+ * /root/reference/model/models/AnimalModel.py:260-307 (compute_reconstruction_losses; F = 1, background_mode 'none').
+ * shaded[B,H,W,4] / dino[B,H,W,D] = the renderer's NHWC buffers (D = 0: no DINO term); image_gt[B,3,H,W], dino_gt[B,D,H,W],
+ * mask_gt / valid [B,H,W], dt0 = mask_dt[:,0] with image stride dt_stride floats.  loss[B,4] = per-image mask, mask_inv_dt, rgb,
+ * dino.  bwd: g_loss[B,4] -> g_shaded[B,H,W,4], g_dino[B,H,W,D] (every element written).
+ */
+size_t a3d_recon_losses_scratch_bytes(int B, int H, int W);
+int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt, const float* mask_gt,
+                         const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch, float* loss,
+                         a3d_stream_t stream);
+int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
+                         const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, float* g_shaded,
+                         float* g_dino, a3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -871,3 +871,48 @@ def test_ddp_wrapper_over_rccl_gives_the_same_gradients(dev):
             assert float((p.grad - want[n]).abs().max()) <= 1e-5 * float(want[n].abs().max()) + 1e-7, n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_dino,hw", [(True, (64, 64)), (False, (40, 24)), (True, (17, 33))])
+def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev, ops):
+    """csrc/losses.hip against the four torch expressions of compute_reconstruction_losses (AnimalModel.py:260-307), values and
+    both image gradients; the eroded 'both' mask is integer logic and must agree exactly."""
+    B, (H, W), D = 3, hw, 16
+    g = torch.Generator().manual_seed(H * W + with_dino)
+    shaded_nhwc = torch.rand(B, H, W, 4, generator=g)
+    shaded_nhwc[..., 3] = (torch.rand(B, H, W, generator=g) > 0.4).float() * torch.rand(B, H, W, generator=g).clamp(min=0.2)
+    shaded_nhwc[:, 5:12, 3:15, 3] = 1.0
+    dino_nhwc = torch.rand(B, H, W, D, generator=g)
+    image_gt, dino_gt = torch.rand(B, 3, H, W, generator=g), torch.rand(B, D, H, W, generator=g)
+    mask_gt = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    mask_gt[:, 4:13, 2:16] = 1.0
+    mask_dt, valid = torch.rand(B, 2, H, W, generator=g), (torch.rand(B, H, W, generator=g) > 0.1).float()
+    w = torch.rand(B, 4, generator=g) + 0.5
+
+    def torch_losses(shaded, dino):
+        image_pred, mask_pred = shaded[:, :3], shaded[:, 3]
+        out = [((mask_pred * valid_d - mask_gt_d) ** 2).flatten(1).mean(1), ((1 - mask_pred) * mask_dt_d[:, 0]).flatten(1).mean(1)]
+        both = ((mask_pred * valid_d > 0.0).float() * mask_gt_d).detach()
+        both = (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
+        out.append(((image_pred - image_gt_d).abs() * both.unsqueeze(1)).flatten(1).mean(1))
+        out.append((((dino - dino_gt_d) ** 2) * both.unsqueeze(1)).flatten(1).mean(1) if dino is not None else torch.zeros_like(out[0]))
+        return torch.stack(out, 1), both
+
+    image_gt_d, dino_gt_d, mask_gt_d, mask_dt_d, valid_d = (t.to(dev) for t in (image_gt, dino_gt, mask_gt, mask_dt, valid))
+    res = []
+    for fused in (True, False):
+        s = shaded_nhwc.clone().to(dev).requires_grad_(True)
+        d = dino_nhwc.clone().to(dev).requires_grad_(True) if with_dino else None
+        s_nchw, d_nchw = s.permute(0, 3, 1, 2), (d.permute(0, 3, 1, 2) if with_dino else None)
+        if fused:
+            loss = ops.reconstruction_losses(s_nchw, d_nchw, image_gt_d, dino_gt_d if with_dino else None, mask_gt_d, mask_dt_d, valid_d)
+        else:
+            loss, both = torch_losses(s_nchw, d_nchw)
+            assert 0 < float(both.mean()) < 1  # the eroded mask is neither empty nor full
+        (loss * w.to(dev)).sum().backward()
+        res.append((loss.detach(), s.grad, d.grad if with_dino else None))
+    (la, gsa, gda), (lb, gsb, gdb) = res
+    assert torch.allclose(la, lb, rtol=2e-5, atol=1e-7), (la, lb)
+    assert torch.allclose(gsa, gsb, rtol=1e-5, atol=1e-9)
+    if with_dino:
+        assert torch.allclose(gda, gdb, rtol=1e-5, atol=1e-9)

@@ -35,6 +35,8 @@ ENTRY = {
     "a3d_rows_add_relu_fwd": (["ss_add_relu4_kernel", "ss_add_relu1_kernel"], "ss_add_relu4_kernel"),
     "a3d_rows_add_relu_bwd": (["ss_kernel<4, true>", "ss_kernel<1, true>"], "ss_kernel<4, true>"),
     "a3d_rows_segsum": (["ss_kernel<4, false>", "ss_kernel<1, false>"], None),
+    "a3d_recon_losses_fwd": (["ls_fwd_kernel", "ls_finish_kernel"], "ls_fwd_kernel"),
+    "a3d_recon_losses_bwd": (["ls_bwd_kernel"], "ls_bwd_kernel"),
     "a3d_aa_topology": (["aa_hash_insert_kernel", "aa_hash_lookup_kernel"], "aa_hash_insert_kernel"),
     "a3d_aa_analyze": (["aa_analyze_kernel"], "aa_analyze_kernel"),
     "a3d_aa_fwd": (["aa_fwd_kernel"], "aa_fwd_kernel"),
