@@ -56,6 +56,21 @@ def _joints_to_bones(joints, pairs):
     return torch.stack([torch.stack([joints[:, :, a], joints[:, :, b]], dim=2) for a, b in pairs], dim=2)
 
 
+def _masked_quantiles(x, mask, qs):
+    """torch.quantile(x[mask], q) (linear interpolation) for each q, without boolean indexing: no host sync, static shapes."""
+    flat = torch.where(mask, x, torch.full_like(x, float("inf"))).reshape(-1).sort().values
+    n = mask.sum()
+    out = []
+    for q in qs:
+        pos = q * (n - 1).to(x.dtype)
+        lo = pos.floor()
+        hi = pos.ceil()
+        idx = torch.stack((lo, hi)).long().clamp(min=0)  # (a 0-dim tensor index would be read back to the host)
+        ab = flat.index_select(0, idx)
+        out.append(torch.lerp(ab[0], ab[1], pos - lo))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ bone estimation
 @torch.no_grad()
 def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bones=0, body_bones_mode="z_minmax", compute_kinematic_chain=True,
@@ -128,24 +143,28 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
             quadrants = [(xs > margin) & (zs > 0), (xs > margin) & (zs < 0), (xs < -margin) & (zs < 0), (xs < -margin) & (zs > 0)]
         else:  # Fauna variant: centre the quadrants on the lower part of the body
             low = ys < ys.quantile(bone_y_threshold)
-            x0, z0 = xs[low].quantile(0.5), zs[low].quantile(0.5)
-            mx = (xs[low].quantile(0.95) - xs[low].quantile(0.05)) * 0.2
-            mz = (zs[low].quantile(0.95) - zs[low].quantile(0.05)) * 0.2
+            xq, zq = _masked_quantiles(xs, low, (0.5, 0.95, 0.05)), _masked_quantiles(zs, low, (0.5, 0.95, 0.05))
+            x0, z0 = xq[0], zq[0]  # == xs[low].quantile(.) of the reference (:160-166), without the data-dependent shape
+            mx, mz = (xq[1] - xq[2]) * 0.2, (zq[1] - zq[2]) * 0.2
             quadrants = [(xs - x0 > mx) & (zs - z0 > mz), (xs - x0 > mx) & (zs < z0), (xs - x0 < -mx) & (zs < z0),
                          (xs - x0 < -mx) & (zs - z0 > mz)]
 
         def leg_joints_in(quadrant, body_bone_idx):
-            out = torch.zeros([seq_shape.shape[0], seq_shape.shape[1], n_leg_bones + 1, 3], dtype=seq_shape.dtype, device=seq_shape.device)
-            ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[:, None]
-            for b in range(seq_shape.shape[0]):
-                for f in range(seq_shape.shape[1]):
-                    pts = seq_shape[b, f][quadrant[b, f]]
-                    if pts.numel() < 1:
-                        raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
-                    foot = pts[torch.argmin(pts[:, 1])]
-                    if body_bone_idx is None:
-                        body_bone_idx = int(torch.argmin((bones_pred[b, f, :, 1, 2] - foot[None, 2]).abs()))
-                    out[b, f] = foot[None] * (1 - ramp) + bones_pred[b, f, body_bone_idx, 1][None] * ramp
+            """Foot = lowest vertex of the quadrant (first one on ties, like indexing the masked subset), leg joints = linear blend
+            from the foot to the attachment joint of the body (skinning.py:177-199).  All (b, f) at once on the tensor's device: no
+            Python loop over instances and, once ``body_bone_idx`` is known (cached chain), no host synchronisation; the empty-
+            quadrant check is a device-side assert on the GPU."""
+            populated = quadrant.any(dim=-1)
+            if seq_shape.is_cuda:
+                torch._assert_async(populated.all(), "estimate_bones: no vertex in a leg quadrant (skinning.py:183)")
+            elif not bool(populated.all()):
+                raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
+            y_in = torch.where(quadrant, ys, torch.full_like(ys, float("inf")))
+            foot = torch.gather(seq_shape, 2, y_in.argmin(dim=-1)[..., None, None].expand(-1, -1, 1, 3))  # [B,F,1,3]
+            if body_bone_idx is None:  # fixed by the first instance and shared by all, as in the reference (:187-189)
+                body_bone_idx = int(torch.argmin((bones_pred[0, 0, :, 1, 2] - foot[0, 0, 0, 2]).abs()))
+            ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[None, None, :, None]
+            out = foot * (1 - ramp) + bones_pred[:, :, body_bone_idx, 1][:, :, None, :] * ramp
             return out, body_bone_idx
 
         if legs_to_body_joint_indices is None:

@@ -916,3 +916,22 @@ def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev,
     assert torch.allclose(gsa, gsb, rtol=1e-5, atol=1e-9)
     if with_dino:
         assert torch.allclose(gda, gdb, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("bone_y_threshold", [None, 0.4])
+def test_estimate_bones_on_device_matches_golden_without_host_sync(bone_y_threshold, dev, mods):
+    """with the kinematic chain cached (every iteration after the first; Fauna recomputes the bones per iteration) the
+    bone estimate runs on the device without a single host synchronisation, and equals the CPU result."""
+    sk = mods["skinning"]
+    verts, _, _, _ = _scene(1, seed=5)
+    seq = (verts[None, None] + 0.02 * seeded((3, 2, *verts.shape), 9, -1, 1))
+    kw = dict(n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+", bone_y_threshold=bone_y_threshold)
+    bones_cpu, chain, aux = sk.estimate_bones(seq, compute_kinematic_chain=True, **kw)
+    seq_d = seq.to(dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        bones_dev = sk.estimate_bones(seq_d, compute_kinematic_chain=False, aux=aux, **kw)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.allclose(bones_dev.cpu(), bones_cpu, atol=1e-6)
