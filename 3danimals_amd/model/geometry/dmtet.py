@@ -94,6 +94,32 @@ def sdf_bce_reg_loss(sdf, all_edges):
     return bce(pair[..., 0], (pair[..., 1] > 0).float()) + bce(pair[..., 1], (pair[..., 0] > 0).float())
 
 
+GRAPH_SDF_GRADIENT = True  # replay the eikonal regulariser's launch-bound chain from HIP graphs (DMTetGeometry._graphed_sdf_gradient)
+
+
+def _single_process():
+    """Graph capture happens lazily inside the first training step; under multi-process DDP that is after RCCL's watchdog threads
+    exist, a combination that cannot be exercised on the single-GPU boxes this round was developed on -- so it stays eager there."""
+    import torch.distributed as dist
+
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def _sdf_gradient_callable(geometry, names):
+    """(pts [N,3], *field parameters) -> d sdf / d pts [N,3], differentiable w.r.t. the parameters: the function the HIP graphs
+    capture.  The parameters come in as explicit arguments (and are swapped into the field for the call) so that the captured
+    backward ends at plain graph inputs rather than at the Parameters' own AccumulateGrad nodes, which live on the training stream."""
+    from torch.nn.utils import stateless
+
+    def fn(pts, *weights):
+        pts = pts.detach().requires_grad_(True)
+        with stateless._reparametrize_module(geometry.mlp, dict(zip(names, weights))):
+            y = geometry.get_sdf(pts=pts)
+        return torch.autograd.grad([y], pts, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True, only_inputs=True)[0]
+
+    return fn
+
+
 class DMTetGeometry(torch.nn.Module):
     def __init__(self, grid_res, spatial_scale, num_layers=None, hidden_size=None, embedder_freq=None, embed_concat_pts=True,
                  init_sdf=None, jitter_grid=0.0, symmetrize=False, condition_choice=None, device="cuda", tets_dir="data/tets", tet_grid=None,
@@ -101,6 +127,7 @@ class DMTetGeometry(torch.nn.Module):
         super().__init__()
         self.grid_res = grid_res
         self.marching_tets = DMTet()
+        self._sdf_gradient_graphs = {}
         self.grid_scale = spatial_scale
         self.init_sdf = init_sdf
         self.jitter_grid = jitter_grid
@@ -175,12 +202,34 @@ class DMTetGeometry(torch.nn.Module):
         pts = (torch.rand(num_samples, 3, device=self.verts.device) - 0.5) * self.grid_scale
         mv = self.mesh_verts.detach() + (torch.rand_like(self.mesh_verts) - 0.5) * 0.1 * self.grid_scale
         mv = mv[torch.randperm(len(mv), device=mv.device)[:5000]]
-        pts = torch.cat([pts, mv], 0).requires_grad_(True)
+        pts = torch.cat([pts, mv], 0)
+        if (GRAPH_SDF_GRADIENT and feats is None and pts.is_cuda and torch.is_grad_enabled() and _single_process()
+                and any(p.requires_grad for p in self.mlp.parameters())):
+            return self._graphed_sdf_gradient(pts)
+        pts = pts.requires_grad_(True)
         y = self.get_sdf(pts=pts, feats=feats)
         try:
             return torch.autograd.grad([y], pts, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True, only_inputs=True)[0]
         except RuntimeError:  # validation runs under no_grad
             return torch.zeros_like(pts)
+
+    def _graphed_sdf_gradient(self, pts):
+        """d sdf / d pts with its (double) backward replayed from two HIP graphs.
+
+        The regulariser differentiates a 5-layer MLP twice over 1e4 points: ~300 launches of 5-15 us of GPU work each, i.e. the
+        chain is bound by launch latency, not by the GPU.  The point count is static, so the forward (field + autograd.grad) and the
+        backward (gradient of that w.r.t. the MLP parameters) are captured once per point count by torch.cuda.make_graphed_callables
+        and replayed as two graph launches.  Same kernels, same order, same values.
+        """
+        key = (pts.shape[0], pts.device)
+        names = [n for n, _ in self.mlp.named_parameters()]
+        params = [p for _, p in self.mlp.named_parameters()]
+        graphed = self._sdf_gradient_graphs.get(key)
+        if graphed is None:
+            sample = (pts.detach().clone(),) + tuple(p.detach().clone().requires_grad_(p.requires_grad) for p in params)
+            graphed = self._sdf_gradient_graphs[key] = torch.cuda.make_graphed_callables(_sdf_gradient_callable(self, names), sample,
+                                                                                          allow_unused_input=True)
+        return graphed(pts.detach(), *params)
 
     def get_sdf_reg_loss(self, feats=None):
         return {"sdf_bce_reg_loss": sdf_bce_reg_loss(self.current_sdf, self.all_edges).mean(),
