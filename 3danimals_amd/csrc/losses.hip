@@ -36,7 +36,8 @@ __device__ __forceinline__ float ls_both(const float* __restrict__ shaded, const
 __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D,
                                                           const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
                                                           const float* __restrict__ mask_gt, const float* __restrict__ dt0, long long dt_stride,
-                                                          const float* __restrict__ valid, int H, int W, float* __restrict__ partial) {
+                                                          const float* __restrict__ valid, int H, int W, float* __restrict__ partial,
+                                                          unsigned char* __restrict__ both_out) {
     __shared__ float red[LS_BLOCK / 64][4];
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
         v[0] = t * t;
         v[1] = (1.f - m) * dt0[(long long)b * dt_stride + i];
         const float both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+        both_out[p] = both > 0.f ? 1 : 0;  // saved for the backward: 1 byte instead of 27 neighbourhood loads per pixel
         const float* g = image_gt + (long long)b * 3 * HW + i;
         v[2] = (fabsf(s.x - g[0]) + fabsf(s.y - g[HW]) + fabsf(s.z - g[2ll * HW])) * both;
         if (dino) {
@@ -99,15 +101,15 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dino, int D, const float* __restrict__ image_gt,
                                                           const float* __restrict__ dino_gt, const float* __restrict__ mask_gt,
                                                           const float* __restrict__ dt0, long long dt_stride, const float* __restrict__ valid,
-                                                          int H, int W, float* __restrict__ g_shaded, float* __restrict__ g_dino) {
+                                                          int H, int W, const unsigned char* __restrict__ both_in,
+                                                          float* __restrict__ g_shaded, float* __restrict__ g_dino) {
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
     if (i >= HW) return;
-    const long long img_px = (long long)b * HW, p = img_px + i;
-    const int y = i / W, x = i - y * W;
+    const long long p = (long long)b * HW + i;
     const float gm = g_loss[4 * b] / (float)HW, gd = g_loss[4 * b + 1] / (float)HW, gr = g_loss[4 * b + 2] / (3.f * (float)HW);
     const float4 s = reinterpret_cast<const float4*>(shaded)[p];
-    const float both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+    const float both = both_in[p] ? 1.f : 0.f;
     const float* g = image_gt + (long long)b * 3 * HW + i;
     auto sgn = [](float e) { return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); };
     float4 o;
@@ -145,15 +147,20 @@ extern "C" size_t a3d_recon_losses_scratch_bytes(int B, int H, int W) {
     return sizeof(float) * 4 * (size_t)B * a3d_div_up((long long)H * W, LS_BLOCK);
 }
 
+extern "C" size_t a3d_recon_losses_mask_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * H * W;
+}
+
 extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
                                     const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W,
-                                    void* scratch, float* loss, a3d_stream_t stream) {
-    A3D_CHECK_ARG(shaded && image_gt && mask_gt && dt0 && valid && scratch && loss && B > 0 && H > 0 && W > 0 && D >= 0);
+                                    void* scratch, uint8_t* both, float* loss, a3d_stream_t stream) {
+    A3D_CHECK_ARG(shaded && image_gt && mask_gt && dt0 && valid && scratch && both && loss && B > 0 && H > 0 && W > 0 && D >= 0);
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt));
     hipStream_t s = (hipStream_t)stream;
     const int nblk = a3d_div_up((long long)H * W, LS_BLOCK);
     hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0,
-                       (long long)dt_stride, valid, H, W, (float*)scratch);
+                       (long long)dt_stride, valid, H, W, (float*)scratch, both);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ls_finish_kernel, dim3(B, 4), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
     A3D_LAUNCH_CHECK();
@@ -162,11 +169,11 @@ extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int 
 
 extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt,
                                     const float* dino_gt, const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B,
-                                    int H, int W, float* g_shaded, float* g_dino, a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
+                                    int H, int W, const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && both && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino));
     hipLaunchKernelGGL(ls_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
-                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, (long long)dt_stride, valid, H, W, g_shaded, g_dino);
+                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

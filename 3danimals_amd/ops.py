@@ -554,20 +554,21 @@ class _ReconLosses(torch.autograd.Function):
             dino_gt = f32c(dino_gt)
         loss = torch.empty((B, 4), dtype=torch.float32, device=shaded.device)
         scratch = torch.empty(_lib.lib().a3d_recon_losses_scratch_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
+        both = torch.empty(_lib.lib().a3d_recon_losses_mask_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
         call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0), ptr(valid), B, H, W,
-             ptr(scratch), ptr(loss), stream())
-        ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid)
+             ptr(scratch), ptr(both), ptr(loss), stream())
+        ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid, both)
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
-        shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid = ctx.saved_tensors
+        shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid, both = ctx.saved_tensors
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
         g_shaded = torch.empty_like(shaded)
         g_dino = torch.empty_like(dino) if D else None
         call("a3d_recon_losses_bwd", ptr(f32c(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0),
-             ptr(valid), B, H, W, ptr(g_shaded), ptr(g_dino), stream())
+             ptr(valid), B, H, W, ptr(both), ptr(g_shaded), ptr(g_dino), stream())
         return g_shaded, g_dino, None, None, None, None, None
 
 

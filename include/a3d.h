@@ -203,12 +203,13 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
  * dino.  bwd: g_loss[B,4] -> g_shaded[B,H,W,4], g_dino[B,H,W,D] (every element written).
  */
 size_t a3d_recon_losses_scratch_bytes(int B, int H, int W);
+size_t a3d_recon_losses_mask_bytes(int B, int H, int W); /* the eroded 'both' mask, written by fwd and read by bwd */
 int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt, const float* mask_gt,
-                         const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch, float* loss,
-                         a3d_stream_t stream);
+                         const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch, uint8_t* both,
+                         float* loss, a3d_stream_t stream);
 int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
-                         const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, float* g_shaded,
-                         float* g_dino, a3d_stream_t stream);
+                         const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W,
+                         const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }
