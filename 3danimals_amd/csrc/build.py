@@ -30,6 +30,7 @@ SOURCES = {
     "gbuffer.hip": [],
     "segsum.hip": [],
     "losses.hip": [],
+    "embed.hip": ["-ffp-contract=off"],
     "antialias.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",

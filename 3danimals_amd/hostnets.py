@@ -218,6 +218,11 @@ class CoordMLP(nn.Module):
             return self._forward_indexed(x, feat, feat_index)
         if feat_index is not None and feat is not None:
             feat = feat[feat_index]
+        if feat is None and self._fused_input_ok(x):
+            out = self.mlp(self._fused_input(x))
+            if self.min_max is not None:
+                out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+            return out
         if self.symmetrize:
             x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
         h = x
@@ -239,15 +244,32 @@ class CoordMLP(nn.Module):
             out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
         return out
 
+    def _fused_input_ok(self, x):
+        """Long point list on the GPU with the standard input stage (embedding + concatenated points): one HIP kernel builds
+        [x, sin, cos, 1] and the in_layer's bias rides as the weight column that multiplies the ones (K = 64 for 10 frequencies)."""
+        return (x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.shape[0] >= SPLITK_MIN_ROWS and x.dtype == torch.float32
+                and self.embedder is not None and self.embed_concat_pts and self.in_layer.bias is not None)
+
+    def _fused_input(self, x):
+        """relu(in_layer([x, embed(x)])) for a long point list (first-order differentiable)."""
+        from . import ops
+
+        h = ops.harmonic_embed(x, self.embedder._frequencies(x.device), symmetrize=self.symmetrize, ones=True)
+        weight = torch.cat([self.in_layer.weight, self.in_layer.bias[:, None]], dim=1)
+        return linear_relu(h, weight, None)
+
     def _forward_indexed(self, x, feat, feat_index):
-        if self.symmetrize:
-            x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
-        h = x
-        if self.embedder is not None:
-            h = self.embedder(x)
-            if self.embed_concat_pts:
-                h = torch.cat([x, h], -1)
-        h = linear_relu(h, self.in_layer.weight, self.in_layer.bias)
+        if self._fused_input_ok(x):
+            h = self._fused_input(x)
+        else:
+            if self.symmetrize:
+                x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
+            h = x
+            if self.embedder is not None:
+                h = self.embedder(x)
+                if self.embed_concat_pts:
+                    h = torch.cat([x, h], -1)
+            h = linear_relu(h, self.in_layer.weight, self.in_layer.bias)
         nf = h.shape[-1]
         weight = self.mlp.network[0].weight
         per_image = F.linear(torch.relu(feat), weight[:, nf:])  # [B, nf]

@@ -583,3 +583,32 @@ def reconstruction_losses(shaded_nchw, dino_nchw, image_gt, dino_gt, mask_gt, ma
         dino = dino_nchw.permute(0, 2, 3, 1)
         dino = dino if dino.is_contiguous() else dino.contiguous()
     return _ReconLosses.apply(shaded, dino, image_gt, dino_gt, mask_gt, mask_dt[:, 0], mask_valid)
+
+
+# ---------------------------------------------------------------------------------------------- harmonic embedding
+class _HarmonicEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, freq, symmetrize, ones):
+        require_device(x, freq, what="harmonic_embed")
+        x, freq = f32c(x), f32c(freq)
+        P, n = x.shape[0], freq.shape[0]
+        assert x.shape == (P, 3)
+        out = torch.empty((P, 3 + 6 * n + int(ones)), dtype=torch.float32, device=x.device)
+        call("a3d_harmonic_embed_fwd", ptr(x), ptr(freq), n, int(symmetrize), int(ones), P, ptr(out), stream())
+        ctx.save_for_backward(x, freq)
+        ctx.cfg = (int(symmetrize), int(ones))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, freq = ctx.saved_tensors
+        g_x = torch.empty_like(x)
+        call("a3d_harmonic_embed_bwd", ptr(f32c(g)), ptr(x), ptr(freq), freq.shape[0], ctx.cfg[0], ctx.cfg[1], x.shape[0], ptr(g_x), stream())
+        return g_x, None, None, None
+
+
+def harmonic_embed(x, freq, symmetrize=False, ones=False):
+    """[P,3] -> [P, 3 + 6n (+1)] = [x (|x_0| if symmetrize), sin(x_c f_k), cos(x_c f_k), (1)] (csrc/embed.hip).  First-order
+    differentiable only (double backward raises): the SDF regulariser, which differentiates the field twice, takes the torch path."""
+    return _HarmonicEmbed.apply(x, freq, symmetrize, ones)

@@ -196,6 +196,16 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
                float* g_clip, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Harmonic embedding of the field inputs -- /root/reference/model/networks/HarmonicEmbedding.py:33-44 as CoordMLP applies it
+ * (networks/MLPs.py:73-83): out[P, 3+6n(+1)] = [x (|x_0| if symmetrize), sin(x_c f_k), cos(x_c f_k) (c-major), (1)].
+ * The optional ones column folds the first Linear's bias into its weight.  bwd: g_x[P,3].
+ */
+int a3d_harmonic_embed_fwd(const float* x /*[P,3]*/, const float* freq /*[n]*/, int n, int symmetrize, int ones, int64_t P, float* out,
+                           a3d_stream_t stream);
+int a3d_harmonic_embed_bwd(const float* g_out, const float* x, const float* freq, int n, int symmetrize, int ones, int64_t P, float* g_x,
+                           a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reconstruction losses -- the image-space consumers of render_mesh's outputs, fused:
  * /root/reference/model/models/AnimalModel.py:260-307 (compute_reconstruction_losses; F = 1, background_mode 'none').
  * shaded[B,H,W,4] / dino[B,H,W,D] = the renderer's NHWC buffers (D = 0: no DINO term); image_gt[B,3,H,W], dino_gt[B,D,H,W],

@@ -965,3 +965,24 @@ def test_graphed_sdf_gradient_equals_eager(dev):
         for p in params:
             p.mul_(1.01)
     assert torch.equal(eager(pts), geo._graphed_sdf_gradient(pts))
+
+
+@pytest.mark.parametrize("n,symmetrize,ones", [(10, True, True), (8, False, True), (4, True, False)])
+def test_harmonic_embed_kernel_matches_reference_formulation(n, symmetrize, ones, dev, ops):
+    """csrc/embed.hip against the torch expressions of HarmonicEmbedding.py:33-44 + MLPs.py:73-83: forward bit-identical (same
+    libm, no contraction), input gradient to fp32 rounding."""
+    hostnets = importlib.import_module("3danimals_amd.hostnets")
+    emb = hostnets.HarmonicEmbedding(n, 2 * np.pi / 7 * 0.9)
+    P = 5000
+    x = (seeded((P, 3), 3 + n, -3.5, 3.5)).to(dev)
+    x[:5, 0] = 0.0  # |x| is not differentiable at 0: torch.abs gives 0 there
+    w = seeded((P, 3 + 6 * n + int(ones)), 17, -1, 1).to(dev)
+    xa = x.clone().requires_grad_(True)
+    got = ops.harmonic_embed(xa, emb._frequencies(x.device), symmetrize=symmetrize, ones=ones)
+    (ga,) = torch.autograd.grad((got * w).sum(), xa)
+    xb = x.clone().requires_grad_(True)
+    xs = torch.cat([xb[..., :1].abs(), xb[..., 1:]], -1) if symmetrize else xb
+    want = torch.cat([xs, emb(xs)] + ([torch.ones(P, 1, device=dev)] if ones else []), -1)
+    (gb,) = torch.autograd.grad((want * w).sum(), xb)
+    assert torch.equal(got, want)
+    assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())  # gradients reach 2^(n-1) * scalar * sum|w|: compare to scale

@@ -16,7 +16,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 ka = prof.key_averages(group_by_input_shape=True)
 skip = ("aten::mm", "aten::bmm", "aten::addmm", "aten::_addmm_activation")
 rows = [e for e in ka if e.self_device_time_total > 0 and e.key not in skip]
-rows.sort(key=lambda e: -e.self_device_time_total)
+rows = [e for e in rows if e.key.startswith("aten::") or e.key.startswith("_") or "Backward" in e.key]
+rows.sort(key=lambda e: -e.count)
 print("non-GEMM device ms/step %.2f in %.0f launches" % (sum(e.self_device_time_total for e in rows) / 3e3, sum(e.count for e in rows) / 3))
-for e in rows[:70]:
+for e in rows[:60]:
     print("%-34s n/step %5.1f  us/call %7.1f  ms/step %6.3f  %s" % (e.key[:34], e.count / 3, e.self_device_time_total / max(e.count, 1), e.self_device_time_total / 3e3, str(e.input_shapes)[:100]))
