@@ -42,6 +42,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float both = 0.f;  // of this thread's own pixel
     if (i < HW) {
         const long long img_px = (long long)b * HW, p = img_px + i;
         const int y = i / W, x = i - y * W;
@@ -49,26 +50,39 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
         const float m = s.w, t = m * valid[p] - mask_gt[p];
         v[0] = t * t;
         v[1] = (1.f - m) * dt0[(long long)b * dt_stride + i];
-        const float both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+        both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
         both_out[p] = both > 0.f ? 1 : 0;  // saved for the backward: 1 byte instead of 27 neighbourhood loads per pixel
         const float* g = image_gt + (long long)b * 3 * HW + i;
         v[2] = (fabsf(s.x - g[0]) + fabsf(s.y - g[HW]) + fabsf(s.z - g[2ll * HW])) * both;
-        if (dino) {
+    }
+    if (dino) {
+        if ((D & 3) == 0) {
+            // wave-cooperative: the wave's 64 pixels own 64*D contiguous floats of the NHWC buffer; lane l takes float4 number
+            // t*64 + l of that chunk (fully coalesced 1 KB loads) -- it belongs to pixel f / (D/4), channel group f % (D/4)
+            const int D4 = D >> 2, lane = threadIdx.x & 63;
+            const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);  // first pixel of this wave inside image b
+            const long long img_px = (long long)b * HW;
+            const float4* chunk = reinterpret_cast<const float4*>(dino + (img_px + px0) * D);
+            float acc = 0.f;
+            for (int t = 0; t < D4; ++t) {
+                const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
+                const float both_pl = __shfl(both, pl, 64);  // pixel pl's mask lives in lane pl (all lanes take part)
+                if (px < HW) {
+                    const float4 q = chunk[f];
+                    const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
+                    const float e0 = q.x - dg[0], e1 = q.y - dg[HW], e2 = q.z - dg[2ll * HW], e3 = q.w - dg[3ll * HW];
+                    acc += (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3) * both_pl;
+                }
+            }
+            v[3] = acc;
+        } else if (i < HW) {
+            const long long p = (long long)b * HW + i;
             const float* dp = dino + p * D;
             const float* dg = dino_gt + (long long)b * D * HW + i;
             float acc = 0.f;
-            if ((D & 3) == 0) {  // 16-byte loads of the pixel's feature vector
-                for (int c = 0; c < D; c += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(dp + c);
-                    const float e0 = q.x - dg[(long long)c * HW], e1 = q.y - dg[(long long)(c + 1) * HW];
-                    const float e2 = q.z - dg[(long long)(c + 2) * HW], e3 = q.w - dg[(long long)(c + 3) * HW];
-                    acc += e0 * e0; acc += e1 * e1; acc += e2 * e2; acc += e3 * e3;
-                }
-            } else {
-                for (int c = 0; c < D; ++c) {
-                    const float e = dp[c] - dg[(long long)c * HW];
-                    acc += e * e;
-                }
+            for (int c = 0; c < D; ++c) {
+                const float e = dp[c] - dg[(long long)c * HW];
+                acc += e * e;
             }
             v[3] = acc * both;
         }
@@ -105,38 +119,51 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
                                                           float* __restrict__ g_shaded, float* __restrict__ g_dino) {
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
-    if (i >= HW) return;
-    const long long p = (long long)b * HW + i;
-    const float gm = g_loss[4 * b] / (float)HW, gd = g_loss[4 * b + 1] / (float)HW, gr = g_loss[4 * b + 2] / (3.f * (float)HW);
-    const float4 s = reinterpret_cast<const float4*>(shaded)[p];
-    const float both = both_in[p] ? 1.f : 0.f;
-    const float* g = image_gt + (long long)b * 3 * HW + i;
-    auto sgn = [](float e) { return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); };
-    float4 o;
-    o.x = gr * sgn(s.x - g[0]) * both;
-    o.y = gr * sgn(s.y - g[HW]) * both;
-    o.z = gr * sgn(s.z - g[2ll * HW]) * both;
-    const float va = valid[p];
-    o.w = gm * 2.f * (s.w * va - mask_gt[p]) * va - gd * dt0[(long long)b * dt_stride + i];
-    reinterpret_cast<float4*>(g_shaded)[p] = o;
-    if (dino) {
-        const float gq = g_loss[4 * b + 3] / ((float)D * (float)HW) * 2.f * both;
+    const long long img_px = (long long)b * HW;
+    float both = 0.f;
+    if (i < HW) {
+        const long long p = img_px + i;
+        const float gm = g_loss[4 * b] / (float)HW, gd = g_loss[4 * b + 1] / (float)HW, gr = g_loss[4 * b + 2] / (3.f * (float)HW);
+        const float4 s = reinterpret_cast<const float4*>(shaded)[p];
+        both = both_in[p] ? 1.f : 0.f;
+        const float* g = image_gt + (long long)b * 3 * HW + i;
+        auto sgn = [](float e) { return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); };
+        float4 o;
+        o.x = gr * sgn(s.x - g[0]) * both;
+        o.y = gr * sgn(s.y - g[HW]) * both;
+        o.z = gr * sgn(s.z - g[2ll * HW]) * both;
+        const float va = valid[p];
+        o.w = gm * 2.f * (s.w * va - mask_gt[p]) * va - gd * dt0[(long long)b * dt_stride + i];
+        reinterpret_cast<float4*>(g_shaded)[p] = o;
+    }
+    if (!dino) return;
+    const float gq0 = g_loss[4 * b + 3] / ((float)D * (float)HW) * 2.f;
+    if ((D & 3) == 0) {  // wave-cooperative, fully coalesced float4 loads and stores (see ls_fwd_kernel)
+        const int D4 = D >> 2, lane = threadIdx.x & 63;
+        const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);
+        const float4* chunk = reinterpret_cast<const float4*>(dino + (img_px + px0) * D);
+        float4* gchunk = reinterpret_cast<float4*>(g_dino + (img_px + px0) * D);
+        for (int t = 0; t < D4; ++t) {
+            const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
+            const float gq = gq0 * __shfl(both, pl, 64);
+            if (px < HW) {
+                const float4 q = chunk[f];
+                const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
+                float4 o4;
+                o4.x = gq * (q.x - dg[0]);
+                o4.y = gq * (q.y - dg[HW]);
+                o4.z = gq * (q.z - dg[2ll * HW]);
+                o4.w = gq * (q.w - dg[3ll * HW]);
+                gchunk[f] = o4;
+            }
+        }
+    } else if (i < HW) {
+        const long long p = img_px + i;
+        const float gq = gq0 * both;
         const float* dp = dino + p * D;
         const float* dg = dino_gt + (long long)b * D * HW + i;
         float* go = g_dino + p * D;
-        if ((D & 3) == 0) {
-            for (int c = 0; c < D; c += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(dp + c);
-                float4 o4;
-                o4.x = gq * (q.x - dg[(long long)c * HW]);
-                o4.y = gq * (q.y - dg[(long long)(c + 1) * HW]);
-                o4.z = gq * (q.z - dg[(long long)(c + 2) * HW]);
-                o4.w = gq * (q.w - dg[(long long)(c + 3) * HW]);
-                *reinterpret_cast<float4*>(go + c) = o4;
-            }
-        } else {
-            for (int c = 0; c < D; ++c) go[c] = gq * (dp[c] - dg[(long long)c * HW]);
-        }
+        for (int c = 0; c < D; ++c) go[c] = gq * (dp[c] - dg[(long long)c * HW]);
     }
 }
 
