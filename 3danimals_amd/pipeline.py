@@ -81,8 +81,11 @@ FUSED_LOSSES = True  # reconstruction losses as one HIP kernel each way (csrc/lo
 
 class SyntheticScene(torch.nn.Module):
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
-                 embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4):
+                 embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None):
+        """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
+        data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter."""
         super().__init__()
+        data_seed = seed if data_seed is None else data_seed
         self.batch, self.resolution, self.temperature = batch, tuple(resolution), temperature
         self.last = {}
         dev = torch.device(device)
@@ -114,7 +117,7 @@ class SyntheticScene(torch.nn.Module):
         self.mvp = mvp.to(dev).requires_grad_(True)
         self.w2c = w2c.to(dev).requires_grad_(True)
         self.campos = campos.to(dev).requires_grad_(True)
-        self.feat = torch.randn(B, feat_dim, generator=torch.Generator().manual_seed(seed + 2)).to(dev).requires_grad_(True)
+        self.feat = torch.randn(B, feat_dim, generator=torch.Generator().manual_seed(data_seed + 2)).to(dev).requires_grad_(True)
         self.arti = synthetic.seeded((B, 1, 20, 3), seed + 3, -0.25, 0.25).to(dev).requires_grad_(True)
         # ---- bones once per "epoch" from the un-jittered prior (InstancePredictorBase.py:316-335)
         with torch.no_grad():
@@ -123,7 +126,7 @@ class SyntheticScene(torch.nn.Module):
                 prior.v_pos[None].detach(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+", compute_kinematic_chain=True,
                 attach_legs_to_body=True)
         # ---- targets shaped like ImageDataset batches (model/dataset/ImageDataset.py:57-90)
-        g = torch.Generator().manual_seed(seed + 4)
+        g = torch.Generator().manual_seed(data_seed + 4)
         self.image_gt = torch.rand(B, 3, H, W, generator=g).to(dev)
         self.dino_gt = torch.rand(B, 16, H, W, generator=g).to(dev)
         self.background = torch.zeros(B, H, W, 3, device=dev)

@@ -104,7 +104,9 @@ def main():
     tuned = importlib.import_module("3danimals_amd.gemm_tuning").enable() if not args.no_tuned_gemms else False
 
     scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(args.resolution, args.resolution), device=dev,
-                                    seed=1000 * rank)  # every rank renders different images
+                                    seed=0, data_seed=1000 * rank)
+    # weak scaling = fixed work per GPU: every rank renders the same 16 poses / cameras (hence the same number of covered pixels and
+    # the same GEMM shapes) against its own image features and target images, so the all-reduced gradients differ per rank.
     module = None
     if world > 1:
         module = torch.nn.parallel.DistributedDataParallel(scene, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
@@ -211,7 +213,8 @@ def main():
             "config": {"workload": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+LBS(20 bones)+raster/interp/antialias "
                                    "+ SDF/texture/DINO/light MLPs + photometric/mask/DINO losses, fwd+bwd+Adam" % args.grid_res,
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "resolution": [args.resolution, args.resolution],
-                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}", "tuned_mlp_gemms": bool(tuned)},
+                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}", "tuned_mlp_gemms": bool(tuned),
+                       "per_rank_data": "same poses/cameras on every rank (equal work per GPU), per-rank image features and targets"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "config1_geometry": config1,
