@@ -98,8 +98,9 @@ GRAPH_SDF_GRADIENT = True  # replay the eikonal regulariser's launch-bound chain
 
 
 def _single_process():
-    """Graph capture happens lazily inside the first training step; under multi-process DDP that is after RCCL's watchdog threads
-    exist, a combination that cannot be exercised on the single-GPU boxes this round was developed on -- so it stays eager there."""
+    """Lazy graph capture inside a training step is allowed in single-process runs only: under multi-process DDP it would happen
+    while RCCL's watchdog threads exist, a combination that cannot be exercised on the single-GPU boxes this round was developed
+    on.  Multi-process runs capture up front (DMTetGeometry.capture_sdf_gradient_graph, before init_process_group) and only replay."""
     import torch.distributed as dist
 
     return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
@@ -203,7 +204,8 @@ class DMTetGeometry(torch.nn.Module):
         mv = self.mesh_verts.detach() + (torch.rand_like(self.mesh_verts) - 0.5) * 0.1 * self.grid_scale
         mv = mv[torch.randperm(len(mv), device=mv.device)[:5000]]
         pts = torch.cat([pts, mv], 0)
-        if (GRAPH_SDF_GRADIENT and feats is None and pts.is_cuda and torch.is_grad_enabled() and _single_process()
+        if (GRAPH_SDF_GRADIENT and feats is None and pts.is_cuda and torch.is_grad_enabled()
+                and ((pts.shape[0], pts.device) in self._sdf_gradient_graphs or _single_process())
                 and any(p.requires_grad for p in self.mlp.parameters())):
             return self._graphed_sdf_gradient(pts)
         pts = pts.requires_grad_(True)
@@ -212,6 +214,17 @@ class DMTetGeometry(torch.nn.Module):
             return torch.autograd.grad([y], pts, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True, only_inputs=True)[0]
         except RuntimeError:  # validation runs under no_grad
             return torch.zeros_like(pts)
+
+    def capture_sdf_gradient_graph(self, num_points=None):
+        """Capture the regulariser's HIP graphs now (e.g. before torch.distributed is initialised: a multi-process run only replays
+        graphs that already exist, it never captures inside a step).  ``num_points`` defaults to what get_sdf_gradient will sample
+        for the current mesh (5000 random + up to 5000 surface points).  No-op off the GPU."""
+        if num_points is None:
+            mv = getattr(self, "mesh_verts", None)
+            num_points = 5000 + (min(5000, len(mv)) if mv is not None else 5000)
+        if GRAPH_SDF_GRADIENT and self.verts.is_cuda and any(p.requires_grad for p in self.mlp.parameters()):
+            with torch.enable_grad():
+                self._graphed_sdf_gradient((torch.rand(num_points, 3, device=self.verts.device) - 0.5) * self.grid_scale)
 
     def _graphed_sdf_gradient(self, pts):
         """d sdf / d pts with its (double) backward replayed from two HIP graphs.

@@ -94,10 +94,6 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP hot path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-
     pipeline = importlib.import_module("3danimals_amd.pipeline")
     L = importlib.import_module("3danimals_amd._lib")
     L.lib()  # fail loudly, now, if the HIP library is missing
@@ -105,6 +101,10 @@ def main():
 
     scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(args.resolution, args.resolution), device=dev,
                                     seed=0, data_seed=1000 * rank)
+    scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
     # weak scaling = fixed work per GPU: every rank renders the same 16 poses / cameras (hence the same number of covered pixels and
     # the same GEMM shapes) against its own image features and target images, so the all-reduced gradients differ per rank.
     module = None

@@ -986,3 +986,29 @@ def test_harmonic_embed_kernel_matches_reference_formulation(n, symmetrize, ones
     (gb,) = torch.autograd.grad((want * w).sum(), xb)
     assert torch.equal(got, want)
     assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())  # gradients reach 2^(n-1) * scalar * sum|w|: compare to scale
+
+
+def test_two_process_ddp_on_one_gpu_replays_captured_graphs(tmp_path):
+    """Two data-parallel processes (gloo; both on the one GPU of the box) in bench.py's order -- scene, HIP-graph capture, then
+    init_process_group, DDP: the steps replay the captured graphs (no capture inside a step), every rank ends with the same
+    all-reduced gradients and the same weights, and the ranks' losses differ (different targets)."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ddp_gpu_worker.py")
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), outs[r]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(l[-2000:] for l in logs)
+    import json
+
+    a, b_ = (json.load(open(o)) for o in outs)
+    assert a["n_graphs"] == b_["n_graphs"] == 1 and a["graphs_after"] == b_["graphs_after"] == 1
+    assert all(np.isfinite(v) for v in a["losses"] + b_["losses"]) and a["losses"] != b_["losses"]
+    for n in a["grad_sums"]:
+        assert abs(a["grad_sums"][n] - b_["grad_sums"][n]) <= 1e-6 * max(1.0, abs(a["grad_sums"][n])), n
+        assert abs(a["weight_sums"][n] - b_["weight_sums"][n]) <= 1e-9 * max(1.0, abs(a["weight_sums"][n])), n
