@@ -57,6 +57,8 @@ def algorithmic_bytes(name, d):
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums
+        "a3d_harmonic_embed_fwd": Pp * (12 + 4 * 64),  # texture field's input stage (n = 10: 64 columns); the DINO field's is 52 wide
+        "a3d_harmonic_embed_bwd": Pp * (4 * 64 + 12 + 12),
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
         "a3d_recon_losses_bwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1 + 16 + 64),
         "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
