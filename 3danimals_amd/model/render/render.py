@@ -223,7 +223,7 @@ def _covered_pixels(rast):
     return ops.covered_pixels(rast, tile=PIXEL_TILE)
 
 
-FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred"))
+FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "shading", "dino_pred", "flow"))
 
 
 def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
@@ -241,13 +241,16 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
     tri = mesh.t_pos_idx[0]
     assert mesh.v_nrm is not None
 
-    fused = (clip is not None and SHADE_COVERED_ONLY and spp == 1 and not ({"flow", "tangent", "depth"} & set(render_modes))
+    fused = (clip is not None and SHADE_COVERED_ONLY and spp == 1 and not ({"tangent", "depth"} & set(render_modes))
              and clip.shape[0] == mesh.v_pos.shape[0] and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr())
     if fused:
         b, h, w = rast.shape[:3]
         pix = _covered_pixels(rast)  # one host sync for the number of covered pixels
         gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
-        return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], None, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
+        flow = None
+        if "flow" in render_modes:  # the one extra attribute of the sequence models: modular interpolate (its gradient reaches clip
+            flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)  # through the rasteriser's own backward)
+        return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
                              render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb)
 
     rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast

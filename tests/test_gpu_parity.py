@@ -420,6 +420,19 @@ def test_render_mesh_flow_and_empty_mesh_assert(dev, mods):
                                      render_modes=["shaded", "flow"], num_frames=2)
     for o, r in zip(out, ref):
         np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=1e-4)
+    # gradient of the flow image w.r.t. the posed vertices: fused path (flow through the modular interpolate / rasteriser backward,
+    # everything else through the fused G-buffer) against torch autograd through the oracle
+    wgt = seeded(tuple(ref[1].shape), 33, -1, 1)
+    pc = posed.clone().requires_grad_(True)
+    ref2 = render_ref.render_mesh(pc, faces, mesh_ref.vertex_normals(pc, faces), mvp, w2c, campos, None, None, (H, W), render_modes=["shaded", "flow"],
+                                  num_frames=2)
+    (g_ref,) = torch.autograd.grad((ref2[1] * wgt).sum(), pc)
+    pd = posed.to(dev).requires_grad_(True)
+    shape2 = M.make_mesh(pd, faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+    out2 = mods["render"].render_mesh(None, shape2, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), bsdf="diffuse",
+                                      render_modes=["shaded", "flow"], num_frames=2)
+    (g_hip,) = torch.autograd.grad((out2[1] * wgt.to(dev)).sum(), pd)
+    assert float((g_hip.cpu() - g_ref).abs().max()) <= 2e-3 * float(g_ref.abs().max())
     empty = M.Mesh(posed.to(dev), torch.zeros(1, 0, 3, dtype=torch.int64, device=dev))
     with pytest.raises(AssertionError, match="empty training triangle mesh"):
         mods["render"].render_mesh(None, empty, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), render_modes=["shaded"])
