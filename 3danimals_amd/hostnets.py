@@ -9,7 +9,14 @@ texture field and the DINO-feature field sampled per pixel in ``shade``
 overlaid on the reference tree those classes are imported from there; when it
 runs alone (tests, ``bench.py``) it needs networks of the same architecture and
 with the same ``state_dict`` layout (``in_layer.*``, ``mlp.network.{0,2,..}.weight``,
-``min_max``) so reference checkpoints load.  Plain PyTorch; rocBLAS GEMMs.
+``min_max``) so reference checkpoints load.  Plain PyTorch; rocBLAS / hipBLASLt GEMMs.
+
+Same mathematics as the reference classes, evaluated faster for long point lists on the GPU (all equal to fp32 rounding, see
+DESIGN.md "What is not a HIP kernel"): split-K weight gradients (``_LinearSplitK``), ReLU in the GEMM epilogue
+(``_LinearReLUSplitK``), the per-image feature as a [B,C] GEMM plus a per-point add folded into the ReLU pass
+(``CoordMLP._forward_indexed``), the input stage [x, sin, cos, 1] from one HIP kernel with the first bias as a weight column
+(``CoordMLP._fused_input``), and the frequency table kept on the device.  Short lists (the SDF regulariser, which needs double
+backward) take the plain torch path.
 """
 from __future__ import annotations
 

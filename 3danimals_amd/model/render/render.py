@@ -1,11 +1,16 @@
 """render_mesh / render_layer / shade / render_uv -- public API of /root/reference/model/render/render.py.
 
-Same signatures, same return contract (a list of NCHW tensors in ``render_modes`` order, ``None`` for unknown
-modes), same arithmetic; underneath, the nvdiffrast calls become HIP kernels:
+Same signatures, same return contract (a list of NCHW tensors in ``render_modes`` order; an unknown mode raises KeyError
+inside shade like the reference, render.py:127-128), same arithmetic; underneath, the nvdiffrast calls become HIP kernels:
 
-* one tiled rasterisation pass (csrc/raster.hip) instead of the OpenGL depth peeler;
-* interpolation of world position / smooth normal / canonical position (csrc/interp.hip); the geometric normal is
-  still the reference's per-face attribute, interpolated with a [[f,f,f]] index buffer (render.py:185-191);
+* one triangle-parallel rasterisation pass (csrc/raster.hip: 64-bit atomicMin on depth|id, then a resolve) instead of the OpenGL
+  depth peeler;
+* on the training path (spp 1, no tangent/depth mode) ONE fused kernel builds the G-buffer of the covered pixels only
+  (csrc/cover.hip + csrc/gbuffer.hip: world position, face normal, smooth normal, canonical position; its backward also carries
+  the rasteriser's gradient), ONE kernel does the shading arithmetic (csrc/shade.hip), and the texture / DINO fields see the
+  covered pixels only -- output-identical, because uncovered pixels are composited with alpha 0 (render.py:261-262);
+* otherwise the modular path: interpolation of each attribute (csrc/interp.hip), the geometric normal as the reference's
+  per-face attribute with a [[f,f,f]] index buffer (render.py:185-191);
 * tangents are neither computed nor interpolated unless the 'tangent' mode asks for them (dead otherwise, a4);
 * ONE silhouette analysis per render (csrc/antialias.hip), applied to every buffer that the reference antialiases
   separately (render.py:311-315).
