@@ -9,7 +9,7 @@
 #define SS_ROWS 128
 
 // MASK: the summand is g * (y > 0) -- the ReLU adjoint -- and is also stored to g_pre (a3d_rows_add_relu_bwd)
-template <int VEC, bool MASK>
+template <int VEC, bool MASK, bool NT = false>
 __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, const long long* __restrict__ img, long long P, int C, int B,
                                                  int CP, float* __restrict__ out, const float* __restrict__ y, float* __restrict__ g_pre,
                                                  int rows_per_block) {
@@ -25,9 +25,20 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
     // VEC floats at element offset i (16-byte aligned when VEC == 4: C % 4 == 0 and torch allocations are 256 B aligned)
     auto add_group = [&](long long i, float* acc) {
         if constexpr (VEC == 4) {
-            float4 v = *reinterpret_cast<const float4*>(g + i);
+            float4 v, t;
+            if (NT) {  // streamed once: do not keep in the caches
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g + i));
+                v = make_float4(a.x, a.y, a.z, a.w);
+                if (MASK) {
+                    const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(y + i));
+                    t = make_float4(c.x, c.y, c.z, c.w);
+                }
+            } else {
+                v = *reinterpret_cast<const float4*>(g + i);
+                if (MASK) t = *reinterpret_cast<const float4*>(y + i);
+            }
             if (MASK) {
-                const float4 t = *reinterpret_cast<const float4*>(y + i);
                 v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
                 *reinterpret_cast<float4*>(g_pre + i) = v;
             }
@@ -123,7 +134,9 @@ static int ss_launch(const float* g, const int64_t* img, int64_t P, int C, int B
     const dim3 grid(a3d_div_up(P, rows)), block(256);
     const long long* im = (const long long*)img;
     if (y) {
-        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
+        // g and y are read exactly once: non-temporal loads (5.0 -> 5.8 TB/s cold, tools/scratch/segsum_bench.py); g_pre is stored
+        // normally, the two GEMMs that follow read it
+        if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, true, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
         else hipLaunchKernelGGL((ss_kernel<1, true>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
     } else {
         if (vec == 4) hipLaunchKernelGGL((ss_kernel<4, false>), grid, block, 0, s, g, im, (long long)P, C, B, CP, out, y, g_pre, rows);
