@@ -40,6 +40,14 @@ __device__ __forceinline__ int a3d_wave_prefix(unsigned long long mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// 16-byte load of data that is read exactly once (streamed): non-temporal, so it does not displace what the next kernels reuse
+__device__ __forceinline__ float4 a3d_load_stream4(const float* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(a.x, a.y, a.z, a.w);
+}
+__device__ __forceinline__ float a3d_load_stream(const float* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float a3d_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

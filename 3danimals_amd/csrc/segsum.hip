@@ -27,13 +27,8 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
         if constexpr (VEC == 4) {
             float4 v, t;
             if (NT) {  // streamed once: do not keep in the caches
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g + i));
-                v = make_float4(a.x, a.y, a.z, a.w);
-                if (MASK) {
-                    const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(y + i));
-                    t = make_float4(c.x, c.y, c.z, c.w);
-                }
+                v = a3d_load_stream4(g + i);
+                if (MASK) t = a3d_load_stream4(y + i);
             } else {
                 v = *reinterpret_cast<const float4*>(g + i);
                 if (MASK) t = *reinterpret_cast<const float4*>(y + i);
