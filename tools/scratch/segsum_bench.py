@@ -28,3 +28,14 @@ def bw():
     k = cnt[0] % NB; cnt[0] += 1
     return torch.autograd.grad(outs[k], rows, gs[k], retain_graph=True)
 print("A3D_SS_ROWS", os.environ.get("A3D_SS_ROWS"), "NT", os.environ.get("A3D_SS_NT"), "bwd us %.1f  -> %.2f TB/s" % (t(bw), 12 * P * C / t(bw) / 1e6))
+# torch's own ReLU adjoint on the same (cold) buffers, for comparison: the same 3 x 210 MB of traffic without the reduction
+cnt2 = [0]
+def thr():
+    k = cnt2[0] % NB; cnt2[0] += 1
+    return torch.ops.aten.threshold_backward(gs[k], ys[k], 0)
+print("torch threshold_backward us %.1f -> %.2f TB/s" % (t(thr), 12 * P * C / t(thr) / 1e6))
+def thr_sum():
+    k = cnt2[0] % NB; cnt2[0] += 1
+    o = torch.ops.aten.threshold_backward(gs[k], ys[k], 0)
+    return o, o.view(16, -1, C).sum(1)
+print("torch threshold_backward + per-image sum us %.1f" % t(thr_sum))
