@@ -9,28 +9,31 @@
 
 namespace {
 
+// one thread per (point, slot): slots 0..3n-1 are the (coordinate, frequency) pairs -- one sincosf, two stores -- and the last
+// 3 (+1) slots copy x (and write the ones column)
 __global__ __launch_bounds__(256) void he_fwd_kernel(const float* __restrict__ x, const float* __restrict__ freq, int n, int symmetrize,
                                                      int ones, long long total, int C, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const long long p = i / C;
-    const int j = (int)(i - p * C);
-    float v;
-    if (j < 3) {
-        v = x[3 * p + j];
-        if (symmetrize && j == 0) v = fabsf(v);
-    } else if (j < 3 + 6 * n) {
-        const int q = j - 3, is_cos = q >= 3 * n, r = is_cos ? q - 3 * n : q;
-        const int c = r / n, k = r - c * n;
+    const int slots = 3 * n + 3 + ones;
+    const long long p = i / slots;
+    const int q = (int)(i - p * slots);
+    float* o = out + p * C;
+    if (q < 3 * n) {
+        const int c = q / n, k = q - c * n;
         float xv = x[3 * p + c];
         if (symmetrize && c == 0) xv = fabsf(xv);
-        const float a = xv * freq[k];
-        v = is_cos ? cosf(a) : sinf(a);
+        float sn, cs;
+        sincosf(xv * freq[k], &sn, &cs);
+        o[3 + q] = sn;
+        o[3 + 3 * n + q] = cs;
+    } else if (q < 3 * n + 3) {
+        const int j = q - 3 * n;
+        const float v = x[3 * p + j];
+        o[j] = (symmetrize && j == 0) ? fabsf(v) : v;
     } else {
-        v = 1.f;
+        o[C - 1] = 1.f;
     }
-    out[i] = v;
-    (void)ones;
 }
 
 __global__ __launch_bounds__(256) void he_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ freq,
@@ -46,8 +49,10 @@ __global__ __launch_bounds__(256) void he_bwd_kernel(const float* __restrict__ g
     const float* gs = gp + 3 + c * n;
     const float* gc = gs + 3 * n;
     for (int k = 0; k < n; ++k) {
-        const float f = freq[k], a = xv * f;
-        acc += f * (gs[k] * cosf(a) - gc[k] * sinf(a));
+        const float f = freq[k];
+        float sn, cs;
+        sincosf(xv * f, &sn, &cs);
+        acc += f * (gs[k] * cs - gc[k] * sn);
     }
     if (symmetrize && c == 0) acc *= raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);  // d|x|/dx, 0 at 0 like torch.abs
     g_x[i] = acc;
@@ -61,7 +66,7 @@ extern "C" int a3d_harmonic_embed_fwd(const float* x, const float* freq, int n, 
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(x && freq && out);
     const int C = 3 + 6 * n + ones;
-    const long long total = (long long)P * C;
+    const long long total = (long long)P * (3 * n + 3 + ones);
     hipLaunchKernelGGL(he_fwd_kernel, dim3(a3d_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, freq, n, symmetrize, ones, total, C, out);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
