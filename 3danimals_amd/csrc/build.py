@@ -31,6 +31,7 @@ SOURCES = {
     "segsum.hip": [],
     "losses.hip": [],
     "embed.hip": ["-ffp-contract=off"],
+    "gemm.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",

@@ -612,3 +612,16 @@ def harmonic_embed(x, freq, symmetrize=False, ones=False):
     """[P,3] -> [P, 3 + 6n (+1)] = [x (|x_0| if symmetrize), sin(x_c f_k), cos(x_c f_k), (1)] (csrc/embed.hip).  First-order
     differentiable only (double backward raises): the SDF regulariser, which differentiates the field twice, takes the torch path."""
     return _HarmonicEmbed.apply(x, freq, symmetrize, ones)
+
+
+# ---------------------------------------------------------------------------------------------- fp32 MFMA GEMM + ReLU adjoint
+def gemm_nn_relumask(a, b, x=None):
+    """(a [M,K] @ b [K,256]) * (x [M,256] > 0)  (x None: plain product) -- csrc/gemm.hip, fp32 MFMA.  No autograd: it is the
+    input-gradient GEMM inside hostnets' stack backward."""
+    require_device(a, b, what="gemm_nn_relumask")
+    a, b = f32c(a), f32c(b)
+    M, K = a.shape
+    assert b.shape == (K, 256) and K % 32 == 0 and (x is None or (x.shape == (M, 256) and x.is_contiguous() and x.dtype == torch.float32))
+    c = torch.empty((M, 256), dtype=torch.float32, device=a.device)
+    call("a3d_gemm_nn_relumask", ptr(a), ptr(b), ptr(x), M, 256, K, ptr(c), stream())
+    return c

@@ -196,6 +196,14 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
                float* g_clip, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM with the ReLU adjoint in the epilogue: C[M,N] = (A[M,K] . B[K,N]) * (X[M,N] > 0), row-major, N = 256,
+ * K % 32 == 0, X may be NULL (plain product).  The input-gradient GEMM of a 256-wide Linear over a long point list whose input
+ * X is the previous layer's ReLU output (/root/reference/model/networks/MLPs.py:9-32, the Linear/ReLU stack): the mask is that
+ * layer's ReLU backward, which the reference (PyTorch autograd) runs as a separate pass.
+ */
+int a3d_gemm_nn_relumask(const float* A, const float* B, const float* X, int64_t M, int N, int K, float* C, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Harmonic embedding of the field inputs -- /root/reference/model/networks/HarmonicEmbedding.py:33-44 as CoordMLP applies it
  * (networks/MLPs.py:73-83): out[P, 3+6n(+1)] = [x (|x_0| if symmetrize), sin(x_c f_k), cos(x_c f_k) (c-major), (1)].
  * The optional ones column folds the first Linear's bias into its weight.  bwd: g_x[P,3].

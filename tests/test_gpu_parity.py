@@ -1025,3 +1025,20 @@ def test_two_process_ddp_on_one_gpu_replays_captured_graphs(tmp_path):
     for n in a["grad_sums"]:
         assert abs(a["grad_sums"][n] - b_["grad_sums"][n]) <= 1e-6 * max(1.0, abs(a["grad_sums"][n])), n
         assert abs(a["weight_sums"][n] - b_["weight_sums"][n]) <= 1e-9 * max(1.0, abs(a["weight_sums"][n])), n
+
+
+@pytest.mark.parametrize("M", [4096, 128 * 37 + 32])
+def test_mfma_gemm_with_relu_adjoint_epilogue(M, dev, ops):
+    """csrc/gemm.hip (fp32 MFMA, hand-written): (A . B) * (X > 0) against torch mm + threshold_backward; exact fp32 products, so
+    only the summation order differs (1e-6 relative), and the zero pattern must be identical."""
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, 256, generator=g).to(dev)
+    b = (torch.randn(256, 256, generator=g) * 0.05).to(dev)
+    x = torch.randn(M, 256, generator=g).to(dev)
+    ref = a.mm(b)
+    plain = ops.gemm_nn_relumask(a, b, None)
+    assert float((plain - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    masked = ops.gemm_nn_relumask(a, b, x)
+    want = torch.ops.aten.threshold_backward(ref, x, 0)
+    assert torch.equal(masked != 0, want != 0)
+    assert float((masked - want).abs().max()) <= 2e-5 * float(ref.abs().max())
