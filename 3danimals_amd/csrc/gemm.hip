@@ -132,6 +132,101 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gm_nn_kernel(const float* _
     }
 }
 
+
+// ---- persistent variant: the weight half lives in LDS, A goes straight to registers, no barrier in the main loop ------------------
+// One work-group per CU (16 waves = 4 per SIMD) keeps W[:, n0:n0+128] (256 x 128 floats = 128 KB of the CU's 160 KB LDS) for its
+// whole life and walks 32-row tiles of A.  A never touches LDS: for the 32x32x2 MFMA lane l = (row l&31, half kh = l>>5) needs one
+// value per k-pair, and since the contraction order is free the pairing is chosen so that a lane's 16-byte global load is exactly its
+// next four operands: group g of 8 k -> lane loads A[row][8g + 4kh .. +3]; k-pair u of the group multiplies A's k = 8g + u (kh 0) /
+// 8g + 4 + u (kh 1) with the same rows of W.  Every byte of A is loaded once, by one lane.  B operands are ds_read_b32 (conflict
+// free).  Tiles are dealt so that every SIMD gets 12 or 13 of the 12.5 average (its four waves share one MFMA pipe).
+constexpr int G3_BN = 128, G3_WAVES = 16;
+
+template <bool MASK>
+__global__ __launch_bounds__(64 * G3_WAVES, 1) void gm_nn3_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                  const float* __restrict__ X, int M, float* __restrict__ C) {
+    constexpr int K = 256, TN = 4;
+    extern __shared__ float Bs[];  // [K][G3_BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = blockIdx.x & 1, bid = blockIdx.x >> 1, nb = gridDim.x >> 1;
+    const int n0 = half * G3_BN;
+    // W half -> LDS: K*G3_BN/4 = 8192 float4, 1024 threads -> 8 each (rows of 32 float4)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = tid + 1024 * i, k = f >> 5, q = f & 31;
+        *reinterpret_cast<f32x4*>(Bs + k * G3_BN + 4 * q) = *reinterpret_cast<const f32x4*>(B + (long long)k * GM_N + n0 + 4 * q);
+    }
+    __syncthreads();
+
+    const int row = lane & 31, kh = lane >> 5;
+    const int n_tiles = (M + 31) >> 5;
+    const int stride = nb * G3_WAVES;
+    const float* b_lane = Bs + 4 * kh * G3_BN + row;  // + (8g + u) * G3_BN + 32 j
+    for (int t = (wave >> 2) * (nb * 4) + bid * 4 + (wave & 3); t < n_tiles; t += stride) {
+        const long long m0 = 32ll * t;
+        const long long mr = m0 + row < M ? m0 + row : M - 1;  // ragged last tile: clamp the loads, skip the stores
+        const float* a_lane = A + mr * K + 4 * kh;
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        unsigned long long xmask = 0ull;
+        const long long mrow = m0 + 4 * kh;
+        const float* x_lane = MASK ? X + (mrow + 27 < M ? mrow : (M >= 32 ? M - 32 + 4 * kh : 0)) * GM_N + n0 + row : nullptr;
+
+        f32x4 an[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const f32x4*>(a_lane + 8 * i);
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {  // 8 chunks of 32 k = 4 groups of 8
+            f32x4 av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = an[i];
+            {
+                const int cn = c + 1 < 8 ? c + 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const f32x4*>(a_lane + 32 * cn + 8 * i);
+            }
+            float xv[MASK ? 8 : 1];
+            if (MASK) {
+                const float* xb = x_lane + 32 * (c >> 1) + (long long)(16 * (c & 1)) * GM_N;
+#pragma unroll
+                for (int dq = 0; dq < 2; ++dq)
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) xv[4 * dq + sx] = xb[(8 * dq + sx) * GM_N];
+            }
+            const float* bc = b_lane + (32 * c) * G3_BN;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* bp = bc + (8 * g + u) * G3_BN;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][u], bp[32 * j], acc[j], 0, 0, 0);
+                }
+            if (MASK) {
+                unsigned byte = 0u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) byte |= (unsigned)(xv[i] > 0.f) << i;
+                xmask |= (unsigned long long)byte << (8 * c);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = mrow + (r & 3) + 8 * (r >> 2);
+            if (m < M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[j][r];
+                    if (MASK) v = (xmask >> (16 * j + r)) & 1ull ? v : 0.f;
+                    C[m * GM_N + n0 + 32 * j + row] = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int a3d_gemm_nn_relumask(const float* A, const float* B, const float* X, int64_t M, int N, int K, float* C, a3d_stream_t stream) {
@@ -140,8 +235,23 @@ extern "C" int a3d_gemm_nn_relumask(const float* A, const float* B, const float*
     if (M == 0) return A3D_OK;
     A3D_CHECK_ARG(A && B && C);
     hipStream_t s = (hipStream_t)stream;
-    static const int variant = getenv("A3D_GEMM_VARIANT") ? atoi(getenv("A3D_GEMM_VARIANT")) : 2;  // tile-shape experiment knob
+    static const int variant = getenv("A3D_GEMM_VARIANT") ? atoi(getenv("A3D_GEMM_VARIANT")) : 3;  // experiment knob; 3 = persistent
     const dim3 block256(256);
+    if (variant == 3 && K == 256) {  // persistent, weight half resident in LDS
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            A3D_HIP(hipGetDevice(&dev));
+            A3D_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * G3_BN * 4));
+            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * G3_BN * 4));
+        }
+        const dim3 grid(n_cu & ~1), block(64 * G3_WAVES);
+        if (X) hipLaunchKernelGGL(gm_nn3_kernel<true>, grid, block, 256 * G3_BN * 4, s, A, B, X, (int)M, C);
+        else hipLaunchKernelGGL(gm_nn3_kernel<false>, grid, block, 256 * G3_BN * 4, s, A, B, X, (int)M, C);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
     if (variant == 1) {  // 64 x 256 tile, wave 32 x 128, 3 work-groups per CU
         const dim3 grid(a3d_div_up(M, 64), 1);
         if (X) hipLaunchKernelGGL((gm_nn_kernel<2, 2, 256, 3, true>), grid, block256, 0, s, A, B, X, (int)M, K, C);

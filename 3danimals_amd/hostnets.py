@@ -53,6 +53,7 @@ class HarmonicEmbedding(nn.Module):
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 
+USE_FIELD_STACK = True  # the hidden stack of a field as one autograd node with MFMA input-gradient GEMMs (_FieldStack)
 SPLITK_MIN_ROWS = 65536  # point lists at least this long take the split-K weight gradient below
 SPLITK_PARTS = 16
 
@@ -117,6 +118,60 @@ class _LinearReLUSplitK(torch.autograd.Function):
         gw = _split_k_weight_grad(g, x) if ctx.needs_input_grad[1] else None
         gb = g.sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+class _FieldStack(torch.autograd.Function):
+    """The hidden stack of a coordinate field over a long point list as ONE autograd node:
+
+        y0 = relu(x_emb W_in^T)                                   in_layer (bias folded into W_in's last column)
+        y1 = relu(y0 W_first^T + per_image[index])                only for fields with a per-image feature
+        y_i = relu(y_{i-1} W_i^T)                                 the 256 -> 256 hidden layers
+
+    Forward as before (ReLU in the GEMM epilogue).  Backward: every input-gradient GEMM is csrc/gemm.hip (hand-written fp32 MFMA)
+    with the previous layer's ReLU adjoint in its epilogue, g_{i-1} = (g_i W_i) * (y_{i-1} > 0), so of the n+1 threshold_backward
+    passes over [M,256] only the first (for the stack's own output) is left, and the per-image layer needs a plain segment sum instead
+    of the masked one.  Weight gradients are the split-K batched GEMMs.  First-order only (the regulariser's short lists never get here).
+    """
+
+    @staticmethod
+    def forward(ctx, x_emb, w_in, per_image, index, w_first, *hidden):
+        from . import ops
+
+        zero = _zero_bias(x_emb, w_in)
+        ys = [torch._addmm_activation(zero, x_emb, w_in.t(), use_gelu=False)]
+        if w_first is not None:
+            y = ys[0].mm(w_first.t())
+            ops.rows_add_relu_raw_(y, per_image, index)
+            ys.append(y)
+        for w in hidden:
+            ys.append(torch._addmm_activation(zero, ys[-1], w.t(), use_gelu=False))
+        ctx.save_for_backward(x_emb, w_in, index, w_first, *hidden, *ys)
+        ctx.n_hidden, ctx.n_images = len(hidden), (per_image.shape[0] if per_image is not None else 0)
+        return ys[-1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import ops
+
+        saved = ctx.saved_tensors
+        x_emb, w_in, index, w_first = saved[:4]
+        hidden, ys = saved[4:4 + ctx.n_hidden], saved[4 + ctx.n_hidden:]
+        g = torch.ops.aten.threshold_backward(g.contiguous(), ys[-1], 0)
+        g_hidden = []
+        for i in range(ctx.n_hidden - 1, -1, -1):
+            y_prev = ys[len(ys) - ctx.n_hidden - 1 + i]
+            g_hidden.append(_split_k_weight_grad(g, y_prev))
+            g = ops.gemm_nn_relumask(g, hidden[i], y_prev)
+        g_hidden.reverse()
+        g_rows = g_first = None
+        if w_first is not None:
+            g_rows = ops.rows_segsum_raw(g, index, ctx.n_images)
+            g_first = _split_k_weight_grad(g, ys[0])
+            g = ops.gemm_nn_relumask(g, w_first, ys[0])
+        g_in = _split_k_weight_grad(g, x_emb)
+        g_x = g.mm(w_in) if ctx.needs_input_grad[0] else None
+        return (g_x, g_in, g_rows, None, g_first, *g_hidden)
 
 
 def _long_list(x, weight):
@@ -225,6 +280,8 @@ class CoordMLP(nn.Module):
             return self._forward_indexed(x, feat, feat_index)
         if feat_index is not None and feat is not None:
             feat = feat[feat_index]
+        if feat is None and self._stack_ok(x, False):
+            return self._stacked(x, None, None)
         if feat is None and self._fused_input_ok(x):
             out = self.mlp(self._fused_input(x))
             if self.min_max is not None:
@@ -265,7 +322,46 @@ class CoordMLP(nn.Module):
         weight = torch.cat([self.in_layer.weight, self.in_layer.bias[:, None]], dim=1)
         return linear_relu(h, weight, None)
 
+    def _stack_ok(self, x, with_feat):
+        """The whole hidden stack as one autograd node (_FieldStack): long list, training, 256-wide bias-free Linear/ReLU pairs."""
+        if not (USE_FIELD_STACK and self._fused_input_ok(x) and torch.is_grad_enabled() and x.shape[0] % SPLITK_PARTS == 0
+                and self.in_layer.weight.requires_grad and self.in_layer.weight.shape[0] == 256):
+            return False
+        layers = list(self.mlp.network)
+        n_pairs = 0
+        while 2 * n_pairs + 1 < len(layers) and isinstance(layers[2 * n_pairs], nn.Linear) and isinstance(layers[2 * n_pairs + 1], nn.ReLU):
+            lin = layers[2 * n_pairs]
+            want_in = 256 + (self.extra_feat_dim if (with_feat and n_pairs == 0) else 0)
+            if lin.bias is not None or tuple(lin.weight.shape) != (256, want_in):
+                return False
+            n_pairs += 1
+        return n_pairs >= 1
+
+    def _stacked(self, x, feat, feat_index):
+        from . import ops
+
+        layers = list(self.mlp.network)
+        pairs, i = [], 0
+        while i + 1 < len(layers) and isinstance(layers[i], nn.Linear) and isinstance(layers[i + 1], nn.ReLU):
+            pairs.append(layers[i])
+            i += 2
+        x_emb = ops.harmonic_embed(x, self.embedder._frequencies(x.device), symmetrize=self.symmetrize, ones=True)
+        w_in = torch.cat([self.in_layer.weight, self.in_layer.bias[:, None]], dim=1)
+        if feat is not None:
+            first = pairs[0].weight
+            per_image = F.linear(torch.relu(feat), first[:, 256:])  # [B, 256]
+            h = _FieldStack.apply(x_emb, w_in, per_image, feat_index, first[:, :256].contiguous(), *[l.weight for l in pairs[1:]])
+        else:
+            h = _FieldStack.apply(x_emb, w_in, None, None, None, *[l.weight for l in pairs])
+        for layer in layers[i:]:
+            h = linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
+        if self.min_max is not None:
+            h = h * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+        return h
+
     def _forward_indexed(self, x, feat, feat_index):
+        if self._stack_ok(x, True):
+            return self._stacked(x, feat, feat_index)
         if self._fused_input_ok(x):
             h = self._fused_input(x)
         else:

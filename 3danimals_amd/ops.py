@@ -481,6 +481,20 @@ class _RowsAddReLU(torch.autograd.Function):
         return g_pre, g_rows, None
 
 
+def rows_add_relu_raw_(y, rows, img):
+    """In place, no autograd: y[p] = relu(y[p] + rows[img[p]]) (used inside hostnets' stack Function)."""
+    call("a3d_rows_add_relu_fwd", ptr(y), ptr(f32c(rows)), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream(), tag=f"[C{y.shape[1]}]")
+    return y
+
+
+def rows_segsum_raw(g, img, b):
+    """[B,C] per-image sums of g [P,C] (no autograd)."""
+    g = f32c(g)
+    out = torch.empty((b, g.shape[1]), dtype=torch.float32, device=g.device)
+    call("a3d_rows_segsum", ptr(g), ptr(img), g.shape[0], g.shape[1], b, ptr(out), stream(), tag=f"[C{g.shape[1]}]")
+    return out
+
+
 def rows_add_relu_(y, rows, img):
     """In place: y[p] = relu(y[p] + rows[img[p]]);  y [P,C] fresh GEMM output, rows [B,C], img int64 [P]."""
     return _RowsAddReLU.apply(y, rows, img)
