@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
 
 
 def algorithmic_bytes(name, d):
@@ -57,6 +58,7 @@ def algorithmic_bytes(name, d):
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums
+        "a3d_gemm_nn_relumask": Pp * 256 * 4 * 3 + 256 * 256 * 4,  # A in, X (mask) in, C out; weight from L2.  Compute bound: see flops below
         "a3d_harmonic_embed_fwd": Pp * (12 + 4 * 64),  # texture field's input stage (n = 10: 64 columns); the DINO field's is 52 wide
         "a3d_harmonic_embed_bwd": Pp * (4 * 64 + 12 + 12),
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
@@ -73,6 +75,12 @@ def algorithmic_bytes(name, d):
         "a3d_aa_bwd": B * 8 * C * HW + B * 16 * V,
     }
     return table.get(base)
+
+
+def algorithmic_flops(name, d):
+    """Flops of ONE call for the compute-bound entry points (None for the bandwidth-bound ones)."""
+    Pp = -(-int(d.get("P", 0)) // 8192) * 8192
+    return {"a3d_gemm_nn_relumask": 2 * Pp * 256 * 256}.get(name.split("[")[0])
 
 
 def main():
@@ -152,12 +160,25 @@ def main():
         if os.path.exists(pmc):
             rec = json.load(open(pmc))["per_call"].get(dom.split("[")[0])
             traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
-        roofline = dict(kernel=dom, bound="hbm", achieved=cand[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
-                        algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6),
-                        hip_path=dict(ms_per_step=round(total_ms, 3), algorithmic_MB_per_step=round(tot_b / 1e6, 1),
-                                      GBps=round(tot_b / tot_t / 1e9, 1), frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4)),
-                        mesh=dims)
+        hip_path = dict(ms_per_step=round(total_ms, 3), algorithmic_MB_per_step=round(tot_b / 1e6, 1),
+                        GBps=round(tot_b / tot_t / 1e9, 1), frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4))
+        flops = algorithmic_flops(dom, dims)
+        if flops is not None:  # the one compute-bound kernel of the path: fp32 MFMA GEMM (157.3 TFLOP/s dense fp32 MFMA peak, MI355X guide)
+            tf = flops / (cand[dom]["mean_us"] * 1e-6) / 1e12
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(tf, 1), peak=MFMA_FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(tf / MFMA_FP32_PEAK_TFLOPS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
+                            algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6),
+                            hbm_GBps=cand[dom]["GBps"], hip_path=hip_path, mesh=dims)
+        else:
+            roofline = dict(kernel=dom, bound="hbm", achieved=cand[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
+                            algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6), hip_path=hip_path, mesh=dims)
+        # the streaming kernel with the most time per step, for the HBM side of the picture
+        mem = {k: v for k, v in cand.items() if algorithmic_flops(k, dims) is None}
+        if mem:
+            top = max(mem, key=lambda k: mem[k]["mean_us"] * mem[k]["launches_per_step"])
+            roofline["top_hbm_kernel"] = dict(kernel=top, achieved=mem[top]["GBps"], unit="GB/s", frac=round(mem[top]["GBps"] / HBM_PEAK_GBS, 4),
+                                              launch_us=mem[top]["mean_us"])
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

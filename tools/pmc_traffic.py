@@ -35,6 +35,7 @@ ENTRY = {
     "a3d_rows_add_relu_fwd": (["ss_add_relu4_kernel", "ss_add_relu1_kernel"], "ss_add_relu4_kernel"),
     "a3d_rows_add_relu_bwd": (["ss_kernel<4, true", "ss_kernel<1, true"], None),
     "a3d_rows_segsum": (["ss_kernel<4, false>", "ss_kernel<1, false>"], None),
+    "a3d_gemm_nn_relumask": (["gm_nn3_kernel", "gm_nn_kernel"], None),
     "a3d_harmonic_embed_fwd": (["he_fwd_kernel"], "he_fwd_kernel"),
     "a3d_harmonic_embed_bwd": (["he_bwd_kernel"], "he_bwd_kernel"),
     "a3d_recon_losses_fwd": (["ls_fwd_kernel", "ls_finish_kernel"], "ls_fwd_kernel"),
