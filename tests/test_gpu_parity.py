@@ -1042,3 +1042,12 @@ def test_mfma_gemm_with_relu_adjoint_epilogue(M, dev, ops):
     want = torch.ops.aten.threshold_backward(ref, x, 0)
     assert torch.equal(masked != 0, want != 0)
     assert float((masked - want).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # other K take the block-tiled kernel (K % 32 == 0; the mask needs K >= 256)
+    for K, with_mask in ((64, False), (512, True)):
+        a2 = torch.randn(M, K, generator=g).to(dev)
+        b2 = (torch.randn(K, 256, generator=g) * 0.05).to(dev)
+        ref2 = a2.mm(b2)
+        got = ops.gemm_nn_relumask(a2, b2, x if with_mask else None)
+        want2 = torch.ops.aten.threshold_backward(ref2, x, 0) if with_mask else ref2
+        assert float((got - want2).abs().max()) <= 2e-5 * float(ref2.abs().max()), K
+        assert torch.equal(got != 0, want2 != 0)
