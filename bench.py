@@ -243,10 +243,12 @@ def main():
             "config1_geometry": config1,
             "kernels": kernels,
         }
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:  # the ONE json line is the last thing written to stdout (after RCCL's own start-up / tear-down chatter)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
