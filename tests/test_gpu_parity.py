@@ -1051,3 +1051,35 @@ def test_mfma_gemm_with_relu_adjoint_epilogue(M, dev, ops):
         want2 = torch.ops.aten.threshold_backward(ref2, x, 0) if with_mask else ref2
         assert float((got - want2).abs().max()) <= 2e-5 * float(ref2.abs().max()), K
         assert torch.equal(got != 0, want2 != 0)
+
+
+@pytest.mark.parametrize("with_feat", [False, True])
+def test_field_stack_matches_layer_by_layer_path(with_feat, dev):
+    """hostnets._FieldStack (one autograd node, MFMA input-gradient GEMMs with the ReLU adjoint fused) against the same network
+    evaluated layer by layer (USE_FIELD_STACK off): outputs, input gradient and every parameter gradient."""
+    hostnets = importlib.import_module("3danimals_amd.hostnets")
+    torch.manual_seed(1)
+    net = hostnets.CoordMLP(3, 16, 5, nf=256, n_harmonic_functions=8, extra_feat_dim=256 if with_feat else 0, activation="sigmoid",
+                            min_max=torch.tensor([[0.0, 1.0]] * 16), symmetrize=not with_feat).to(dev)
+    g = torch.Generator().manual_seed(3)
+    P, B = hostnets.SPLITK_MIN_ROWS + 8192, 4
+    x0 = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    feat0 = torch.randn(B, 256, generator=g).to(dev)
+    idx = torch.randint(0, B, (P,), generator=g).sort().values.to(dev)
+    w = torch.rand(P, 16, generator=g).to(dev)
+
+    def run(use_stack):
+        hostnets.USE_FIELD_STACK = use_stack
+        try:
+            x = x0.clone().requires_grad_(True)
+            feat = feat0.clone().requires_grad_(True) if with_feat else None
+            out = net.sample(x, feat=feat, feat_index=idx) if with_feat else net.sample(x)
+            leaves = [x] + ([feat] if with_feat else []) + list(net.parameters())
+            return out.detach(), torch.autograd.grad((out * w).sum(), leaves)
+        finally:
+            hostnets.USE_FIELD_STACK = True
+
+    (oa, ga), (ob, gb) = run(True), run(False)
+    assert torch.allclose(oa, ob, atol=2e-6)
+    for u, v in zip(ga, gb):
+        assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7
