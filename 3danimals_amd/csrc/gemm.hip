@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gm_nn_kernel(const float* _
     const int col0 = n0 + wn * (BN / WN) + (lane & 31);
     const long long mrow = m0 + 32 * wm + 4 * (lane >> 5);
     // rows past M are never stored; clamp the mask reads of a ragged last tile to the last full 32-row group
-    const float* x_lane = MASK ? X + (mrow + 27 < M ? mrow : (M >= 32 ? M - 32 + 4 * (lane >> 5) : 0)) * GM_N + col0 : nullptr;
+    const float* x_lane = MASK ? X + col0 : nullptr;  // + X-row * GM_N (rows clamped to M - 1: outputs past M are never stored)
     const int a_row = tid >> 3, a_kq = tid & 7, b_row = tid / (BN / 4), b_nq = tid - b_row * (BN / 4);
     const float* a_src = A + (m0 + a_row) * K + 4 * a_kq;
     const float* b_src = B + (long long)b_row * GM_N + n0 + 4 * b_nq;
@@ -83,11 +83,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gm_nn_kernel(const float* _
         float xv[MASK ? 8 : 1];
         if (MASK) {
             const int c = (k0 / GM_BK) & 7;  // (chunks past the 8th re-read the first ones, harmless)
-            const float* xb = x_lane + 32 * (c >> 1) + (long long)(16 * (c & 1)) * GM_N;
+            const float* xb = x_lane + 32 * (c >> 1);
+            const long long r0 = mrow + 16 * (c & 1);
 #pragma unroll
             for (int dq = 0; dq < 2; ++dq)
 #pragma unroll
-                for (int sx = 0; sx < 4; ++sx) xv[4 * dq + sx] = xb[(8 * dq + sx) * GM_N];
+                for (int sx = 0; sx < 4; ++sx) {
+                    const long long rr = r0 + 8 * dq + sx;
+                    xv[4 * dq + sx] = xb[(rr < M ? rr : M - 1) * GM_N];
+                }
         }
         const float* a_base = As + (32 * wm + (lane & 31)) * GM_APAD + (lane >> 5);
         const float* b_base = Bs + (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
@@ -146,7 +150,8 @@ template <bool MASK>
 __global__ __launch_bounds__(64 * G3_WAVES, 1) void gm_nn3_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                   const float* __restrict__ X, int M, float* __restrict__ C) {
     constexpr int K = 256, TN = 4;
-    extern __shared__ float Bs[];  // [K][G3_BN]
+    extern __shared__ float Bs[];  // [K][G3_BN], then 16 waves x 64 sign words (512 B each)
+    unsigned long long* sign_w = reinterpret_cast<unsigned long long*>(Bs + 256 * G3_BN) + 64 * (threadIdx.x >> 6);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = blockIdx.x & 1, bid = blockIdx.x >> 1, nb = gridDim.x >> 1;
     const int n0 = half * G3_BN;
@@ -171,9 +176,8 @@ __global__ __launch_bounds__(64 * G3_WAVES, 1) void gm_nn3_kernel(const float* _
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        unsigned long long xmask = 0ull;
         const long long mrow = m0 + 4 * kh;
-        const float* x_lane = MASK ? X + (mrow + 27 < M ? mrow : (M >= 32 ? M - 32 + 4 * kh : 0)) * GM_N + n0 + row : nullptr;
+        const float* x_wave = MASK ? X + n0 + 4 * row : nullptr;  // + X-row * GM_N
 
         f32x4 an[4];
 #pragma unroll
@@ -188,13 +192,14 @@ __global__ __launch_bounds__(64 * G3_WAVES, 1) void gm_nn3_kernel(const float* _
 #pragma unroll
                 for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const f32x4*>(a_lane + 32 * cn + 8 * i);
             }
-            float xv[MASK ? 8 : 1];
-            if (MASK) {
-                const float* xb = x_lane + 32 * (c >> 1) + (long long)(16 * (c & 1)) * GM_N;
+            f32x4 xw[MASK ? 2 : 1];
+            if (MASK) {  // 2 of the tile's 16 row pairs per chunk: lane -> row 2 i + (l>>5), columns 4 (l&31) .. +3 (512 B per row)
 #pragma unroll
-                for (int dq = 0; dq < 2; ++dq)
-#pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) xv[4 * dq + sx] = xb[(8 * dq + sx) * GM_N];
+                for (int q = 0; q < 2; ++q) {
+                    long long rr = m0 + 2 * (2 * c + q) + kh;
+                    rr = rr < M ? rr : M - 1;  // rows past M are never stored
+                    xw[q] = *reinterpret_cast<const f32x4*>(x_wave + rr * GM_N);
+                }
             }
             const float* bc = b_lane + (32 * c) * G3_BN;
 #pragma unroll
@@ -205,21 +210,29 @@ __global__ __launch_bounds__(64 * G3_WAVES, 1) void gm_nn3_kernel(const float* _
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][u], bp[32 * j], acc[j], 0, 0, 0);
                 }
-            if (MASK) {
-                unsigned byte = 0u;
+            if (MASK) {  // sign ballots of the two row pairs -> this wave's 16 x 4 words of LDS (word [i][k]: bit l = sign of lane l's k-th value)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) byte |= (unsigned)(xv[i] > 0.f) << i;
-                xmask |= (unsigned long long)byte << (8 * c);
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const unsigned long long bal = __ballot(xw[q][k4] > 0.f);
+                        if (lane == 0) sign_w[(2 * c + q) * 4 + k4] = bal;
+                    }
             }
         }
+        if (MASK) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's own LDS writes above are read below
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long m = mrow + (r & 3) + 8 * (r >> 2);
+            // mask word for this register: X row 4 kh + (r&3) + 8 (r>>2) = pair i = 2 kh + ((r&3)>>1) + 4 (r>>2), half r&1; column row + 32 j
+            // = float4 (row>>2) + 8 j, component row&3  ->  bit (r&1)*32 + (row>>2) + 8 j of word [i][row&3]
+            unsigned long long wv = 0ull;
+            if (MASK) wv = sign_w[(2 * kh + ((r & 3) >> 1) + 4 * (r >> 2)) * 4 + (row & 3)] >> ((r & 1) * 32 + (row >> 2));
             if (m < M) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     float v = acc[j][r];
-                    if (MASK) v = (xmask >> (16 * j + r)) & 1ull ? v : 0.f;
+                    if (MASK) v = (wv >> (8 * j)) & 1ull ? v : 0.f;
                     C[m * GM_N + n0 + 32 * j + row] = v;
                 }
             }
@@ -243,12 +256,12 @@ extern "C" int a3d_gemm_nn_relumask(const float* A, const float* B, const float*
             int dev = 0;
             A3D_HIP(hipGetDevice(&dev));
             A3D_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * G3_BN * 4));
-            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * G3_BN * 4));
+            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 * G3_BN * 4 + 16 * 64 * 8)));
+            A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 * G3_BN * 4 + 16 * 64 * 8)));
         }
         const dim3 grid(n_cu & ~1), block(64 * G3_WAVES);
-        if (X) hipLaunchKernelGGL(gm_nn3_kernel<true>, grid, block, 256 * G3_BN * 4, s, A, B, X, (int)M, C);
-        else hipLaunchKernelGGL(gm_nn3_kernel<false>, grid, block, 256 * G3_BN * 4, s, A, B, X, (int)M, C);
+        if (X) hipLaunchKernelGGL(gm_nn3_kernel<true>, grid, block, (256 * G3_BN * 4 + 16 * 64 * 8), s, A, B, X, (int)M, C);
+        else hipLaunchKernelGGL(gm_nn3_kernel<false>, grid, block, (256 * G3_BN * 4 + 16 * 64 * 8), s, A, B, X, (int)M, C);
         A3D_LAUNCH_CHECK();
         return A3D_OK;
     }

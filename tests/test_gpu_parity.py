@@ -1027,7 +1027,7 @@ def test_two_process_ddp_on_one_gpu_replays_captured_graphs(tmp_path):
         assert abs(a["weight_sums"][n] - b_["weight_sums"][n]) <= 1e-9 * max(1.0, abs(a["weight_sums"][n])), n
 
 
-@pytest.mark.parametrize("M", [4096, 128 * 37 + 32])
+@pytest.mark.parametrize("M", [4096, 128 * 37 + 32, 32 * 77 + 9])
 def test_mfma_gemm_with_relu_adjoint_epilogue(M, dev, ops):
     """csrc/gemm.hip (fp32 MFMA, hand-written): (A . B) * (X > 0) against torch mm + threshold_backward; exact fp32 products, so
     only the summation order differs (1e-6 relative), and the zero pattern must be identical."""
