@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liba3d_hip.so")
 
 _c_int, _c_float, _c_size_t, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
-# name -> (restype, argtypes); must list every symbol declared in include/a3d.h (tests/test_abi.py checks)
+# name -> (restype, argtypes); must list every symbol declared in include/a3d.h (tests/test_host_cpu.py::test_abi_table_matches_header checks)
 SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),
@@ -36,6 +36,7 @@ SIGNATURES = {
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_mesh_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p,
                                  _p]),
@@ -51,7 +52,7 @@ SIGNATURES = {
     "a3d_rows_add_relu_bwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p, _p]),
     "a3d_aa_hash_bytes": (_c_size_t, [_c_int]),
     "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
-    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p]),
+    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
 }

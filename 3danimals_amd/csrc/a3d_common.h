@@ -31,6 +31,9 @@ void a3d_set_error(const char* fmt, ...);
 
 static inline int a3d_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// experiment knob for kernel bisection (tools/kernel_lab.py): integer value of the environment variable A3D_EXP, 0 when unset
+int a3d_exp(void);
+
 #ifdef __HIPCC__
 // lanes below me in the wave that have the bit set: ballot + mbcnt (wave64)
 __device__ __forceinline__ int a3d_lane_id() { return (int)__lane_id(); }

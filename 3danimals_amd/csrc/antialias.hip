@@ -5,8 +5,9 @@
 //              atomicMin on a (face*4+corner) code per traversal direction => deterministic), flattened to
 //              opp[F,3] so the per-pixel pass does ONE 12-byte read instead of three hash probes.
 //              Once per mesh topology (= once per DMTet call), shared by every image and colour buffer.
-//   analyze  : one thread per pixel inspects its right and lower neighbour; id discontinuities are analysed
-//              (3+3 vertex gathers) and the rare true silhouette crossings are appended to a compact work list
+//   analyze  : pixel-space vertex positions once per (image, vertex); then one thread per (pixel, direction) inspects the
+//              right / lower neighbour; id discontinuities are analysed (3+3 8-byte gathers, no divisions) and the rare
+//              true silhouette crossings are appended to a compact work list
 //              with ONE atomicAdd per wave (ballot + mbcnt).  Once per (rast, clip): the reference repeats this
 //              for every colour buffer it antialiases (render.py:311-315).
 //   fwd/bwd  : out = color (+) blends over the work list; backward adds colour gradients and sends
@@ -14,9 +15,7 @@
 // HBM traffic: analyze reads 16 B/pixel; fwd/bwd copy 4C B/pixel in and out; the work list is a few thousand
 // 16-byte records per image.  Compiled with -ffp-contract=off so sign tests agree with the oracle.
 #include "a3d_common.h"
-
-#define AA_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
-#define AA_NONE 0x7F7F7F7F
+#include "topo_common.h"
 
 struct AaRec {
     int pix0;     // flat index (b*H + y)*W + x of the pair's first pixel
@@ -25,67 +24,17 @@ struct AaRec {
     int flags;    // bit0 d (0: right neighbour, 1: lower), bits1-2 edge, bit3 triangle belongs to 2nd pixel, bit4 dc clamped
 };
 
-static inline unsigned aa_slots(int F) {
-    unsigned n = 64;
-    while (n < (unsigned)(6 * (long long)F)) n <<= 1;  // load factor <= 1/2
-    return n;
-}
-
-__device__ __forceinline__ unsigned aa_hash(unsigned long long k) {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (unsigned)k;
-}
-
 __global__ __launch_bounds__(256) void aa_hash_insert_kernel(const int* __restrict__ tri, int F, unsigned mask,
                                                              unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * F) return;
-    const int f = idx / 3, i = idx - 3 * f;
-    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
-    if (a == b) return;
-    const int d = a < b ? 0 : 1;
-    const unsigned long long key = a < b ? (((unsigned long long)(unsigned)a << 32) | (unsigned)b)
-                                         : (((unsigned long long)(unsigned)b << 32) | (unsigned)a);
-    unsigned h = aa_hash(key) & mask;
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        const unsigned long long old = atomicCAS(&keys[h], AA_EMPTY_KEY, key);
-        if (old == AA_EMPTY_KEY || old == key) {
-            atomicMin(&vals[2 * h + d], f * 4 + i);
-            return;
-        }
-        h = (h + 1) & mask;
-    }
+    if (idx < 3 * F) aa_insert_edge(tri, idx, mask, keys, vals);
 }
 
 __global__ __launch_bounds__(256) void aa_hash_lookup_kernel(const int* __restrict__ tri, int F, unsigned mask,
                                                              const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
                                                              int* __restrict__ opp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * F) return;
-    const int f = idx / 3, i = idx - 3 * f;
-    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
-    int result = -1;
-    if (a != b) {
-        const int d = a < b ? 0 : 1;
-        const unsigned long long key = a < b ? (((unsigned long long)(unsigned)a << 32) | (unsigned)b)
-                                             : (((unsigned long long)(unsigned)b << 32) | (unsigned)a);
-        unsigned h = aa_hash(key) & mask;
-        for (unsigned probe = 0; probe <= mask; ++probe) {
-            const unsigned long long k = keys[h];
-            if (k == key) {
-                int other = vals[2 * h + (1 - d)];
-                if (other == AA_NONE) {
-                    const int same = vals[2 * h + d];
-                    if (same != AA_NONE && same != f * 4 + i) other = same;
-                }
-                if (other != AA_NONE) result = tri[3 * (other >> 2) + (other & 3)];
-                break;
-            }
-            if (k == AA_EMPTY_KEY) break;
-            h = (h + 1) & mask;
-        }
-    }
-    opp[idx] = result;
+    if (idx < 3 * F) opp[idx] = aa_lookup_edge(tri, idx, mask, keys, vals);
 }
 
 __device__ __forceinline__ bool aa_same_sign(float a, float b) { return ((__float_as_uint(a) ^ __float_as_uint(b)) >> 31) == 0u; }
@@ -101,50 +50,49 @@ __device__ __forceinline__ void aa_project(const float4 p, float fx, float fy, f
     Y = p.y / p.w * yh - fy;
 }
 
-__global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restrict__ rast, const float4* __restrict__ clip, int clip_batch,
-                                                         const int* __restrict__ tri, const int* __restrict__ opp, int V, int F, int H,
-                                                         int W, long long npix, AaRec* __restrict__ work, int capacity,
-                                                         int* __restrict__ count) {
+// pixel-space position of every vertex relative to the image centre: the two divisions of aa_project, once per (image, vertex)
+// instead of 12 times per pixel pair.  (p.x / p.w * xh) - fx is evaluated unfused (this TU is built with -ffp-contract=off), so
+// subtracting fx from the stored product gives the same bits as aa_project.
+__global__ __launch_bounds__(256) void aa_screen_kernel(const float4* __restrict__ clip, long long n, float xh, float yh,
+                                                        float2* __restrict__ screen) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inside = i < npix;
-    int b = 0, y = 0, x = 0, id0 = -1;
-    float z0 = 0.f;
-    if (inside) {
-        b = (int)(i / ((long long)H * W));
-        const int rem = (int)(i - (long long)b * H * W);
-        y = rem / W;
-        x = rem - y * W;
-        const float4 r0 = rast[i];
-        id0 = (int)r0.w - 1;
-        z0 = r0.z;
-    }
-    const float xh = 0.5f * W, yh = 0.5f * H;
-    const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
-    for (int d = 0; d < 2; ++d) {
-        AaRec rec;
-        bool emit = false;
-        const bool has_nb = inside && (d == 0 ? (x + 1 < W) : (y + 1 < H));
-        if (has_nb) {
+    if (i >= n) return;
+    const float4 p = clip[i];
+    screen[i] = make_float2(p.x / p.w * xh, p.y / p.w * yh);
+}
+
+// one thread per (pixel, direction): blockIdx.y = d (0: right neighbour, 1: lower neighbour)
+__global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restrict__ rast, const float2* __restrict__ screen, int clip_batch,
+                                                         const int* __restrict__ tri, const int* __restrict__ opp, int V, int F, int H,
+                                                         int W, AaRec* __restrict__ work, int capacity, int* __restrict__ count) {
+    const unsigned hw = (unsigned)H * (unsigned)W;
+    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y, b = blockIdx.z;
+    const long long i = (long long)b * hw + rem;
+    AaRec rec;
+    bool emit = false;
+    if (rem < hw) {
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);  // (a 64-bit division costs ~150 instructions)
+        if (d == 0 ? (x + 1 < W) : (y + 1 < H)) {
+            const float4 r0 = rast[i];
             const float4 r1 = rast[i + (d == 0 ? 1 : W)];
-            const int id1 = (int)r1.w - 1;
+            const int id0 = (int)r0.w - 1, id1 = (int)r1.w - 1;
             if (id0 != id1) {
                 int t = id0 >= 0 ? id0 : id1;
-                if (id0 >= 0 && id1 >= 0) t = (z0 < r1.z) ? id0 : id1;
+                if (id0 >= 0 && id1 >= 0) t = (r0.z < r1.z) ? id0 : id1;
                 const bool use1 = (t == id1);
                 if (t >= 0 && t < F) {
+                    const float xh = 0.5f * W, yh = 0.5f * H;
+                    const float2* sb = screen + (clip_batch == 1 ? 0ll : (long long)b * V);
                     const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
                     const float ds = use1 ? -1.f : 1.f;
                     const int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
                     int o0 = opp[3 * t], o1 = opp[3 * t + 1], o2 = opp[3 * t + 2];
                     o0 = o0 >= 0 ? o0 : v0; o1 = o1 >= 0 ? o1 : v1; o2 = o2 >= 0 ? o2 : v2;
                     const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
-                    float x0, y0, x1, y1, x2, y2, ox0, oy0, ox1, oy1, ox2, oy2;
-                    aa_project(pb[v0], fx, fy, xh, yh, x0, y0);
-                    aa_project(pb[v1], fx, fy, xh, yh, x1, y1);
-                    aa_project(pb[v2], fx, fy, xh, yh, x2, y2);
-                    aa_project(pb[o0], fx, fy, xh, yh, ox0, oy0);
-                    aa_project(pb[o1], fx, fy, xh, yh, ox1, oy1);
-                    aa_project(pb[o2], fx, fy, xh, yh, ox2, oy2);
+                    const float2 a0 = sb[v0], a1 = sb[v1], a2 = sb[v2], b0 = sb[o0], b1 = sb[o1], b2 = sb[o2];
+                    float x0 = a0.x - fx, y0 = a0.y - fy, x1 = a1.x - fx, y1 = a1.y - fy, x2 = a2.x - fx, y2 = a2.y - fy;
+                    const float ox0 = b0.x - fx, oy0 = b0.y - fy, ox1 = b1.x - fx, oy1 = b1.y - fy, ox2 = b2.x - fx, oy2 = b2.y - fy;
                     const float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
                     const float w0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
                     const float w1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
@@ -172,7 +120,7 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
                             if (better) { best = ratio; di = k; bdx = dxe; bdy = dye; bstr = str; }
                         }
                         const float dc = best;
-                        bool ok = sil[di] && bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f);
+                        const bool ok = sil[di] && bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f);
                         if (ok) {
                             const float dcc = fminf(fmaxf(dc, 0.f), 1.f);
                             rec.pix0 = (int)i;
@@ -185,17 +133,17 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
                 }
             }
         }
-        // wave-aggregated append
-        const unsigned long long m = __ballot(emit);
-        if (m) {
-            int basei = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (a3d_lane_id() == leader) basei = atomicAdd(count, __popcll(m));
-            basei = __shfl(basei, leader);
-            if (emit) {
-                const int slot = basei + a3d_wave_prefix(m);
-                if (slot < capacity) work[slot] = rec;
-            }
+    }
+    // wave-aggregated append
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+        int basei = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (a3d_lane_id() == leader) basei = atomicAdd(count, __popcll(m));
+        basei = __shfl(basei, leader);
+        if (emit) {
+            const int slot = basei + a3d_wave_prefix(m);
+            if (slot < capacity) work[slot] = rec;
         }
     }
 }
@@ -286,17 +234,21 @@ extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int
 }
 
 extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
-                              int F, int H, int W, void* work, int capacity, int32_t* count, a3d_stream_t stream) {
-    A3D_CHECK_ARG(rast && clip && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
+                              int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, a3d_stream_t stream) {
+    A3D_CHECK_ARG(rast && clip && screen && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
     hipStream_t s = (hipStream_t)stream;
     A3D_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri && opp);
-    const long long npix = (long long)B * H * W;
-    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up(npix, 256)), dim3(256), 0, s, (const float4*)rast, (const float4*)clip, clip_batch,
-                       tri, opp, V, F, H, W, npix, (AaRec*)work, capacity, count);
+    const long long nvert = (long long)clip_batch * V;
+    A3D_CHECK_ARG(B <= 65535);
+    hipLaunchKernelGGL(aa_screen_kernel, dim3(a3d_div_up(nvert, 256)), dim3(256), 0, s, (const float4*)clip, nvert, 0.5f * W, 0.5f * H,
+                       (float2*)screen);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, (const float4*)rast, (const float2*)screen,
+                       clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

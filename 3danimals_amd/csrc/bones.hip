@@ -1,13 +1,13 @@
-// Per-bone world transforms from the kinematic chain on gfx950: one thread per (image, bone).
+// Per-bone world transforms from the kinematic chain on gfx950: one work-group per instance, links built once in LDS.
 //
 // Replaces the inner loops of skinning() (model/geometry/skinning.py:389-417): for every bone the reference walks its
 // kinematic chain leaf -> root composing Rest_i . Rot(euler_i) . Rest_i^-1 one 4x4 torch op at a time (~24k aten calls
-// per forward at K=20, B=16).  Here thread (n,k) rebuilds the <= 8 links of its chain in registers:
+// per forward at K=20, B=16).  Here the K links of an instance are built once and bone k multiplies the <= 8 links of its chain:
 //     L_i = [ R_i Rot_i R_i^T | t_i - R_i Rot_i R_i^T t_i ],   M_k = L_root ... L_parent(k) L_k        (3x4 affine)
 // with R_i the rest frame from the bone direction (columns right, up, forward; right ~ +x; skinning.py:251-270), t_i the
 // bone's start joint and Rot_i = Rx Ry Rz (PyTorch3D 'XYZ', skinning.py:285-340).
 // Backward: g_L_j = P_j^T g_M S_j^T with prefix/suffix products of the chain, pushed through the conjugation and the Euler
-// factors onto the three angles (float atomics: a link is shared by every bone below it).  Bones carry no gradient.
+// factors onto the three angles (summed per link in a fixed order: bit-reproducible).  Bones carry no gradient.
 // A few hundred threads in total; the point is 2 launches instead of ~80 tiny ones on a host-bound stretch of the step.
 #include "a3d_common.h"
 
@@ -93,119 +93,174 @@ __device__ __forceinline__ A34 bn_link(const float* __restrict__ bone, const flo
     return L;
 }
 
-__global__ __launch_bounds__(64) void bn_fwd_kernel(const float* __restrict__ bones, int bones_batch, const float* __restrict__ angles,
-                                                    const int* __restrict__ chain, int N, int K, int D, float* __restrict__ M) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * K) return;
-    const int n = idx / K, k = idx - n * K;
-    const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)n * K * 6);
-    const float* aa = angles + (long long)n * K * 3;
-    A34 acc = bn_identity();
-    for (int j = 0; j < D; ++j) {
-        const int i = chain[k * D + j];
-        if (i < 0) continue;
-        acc = bn_mul(acc, bn_link(bb + 6 * i, aa + 3 * i));
-    }
-    float* o = M + (long long)idx * 12;
+// ---- one work-group per instance: the K link matrices are built ONCE (one thread each) into LDS, then every bone walks its
+// chain over LDS copies (<= 8 products of 3x4 affines).  The first version rebuilt every link of every chain per thread
+// (8 x sincos/normalise chains in series, 13 us / 44 us for 320 threads of work); this form is a few hundred flops deep.
+#define BN_THREADS 256
+#define BN_MAXK 64
+
+__device__ __forceinline__ void bn_store(float* __restrict__ dst, const A34& a) {
 #pragma unroll
-    for (int q = 0; q < 12; ++q) o[q] = acc.m[q];
+    for (int q = 0; q < 12; ++q) dst[q] = a.m[q];
+}
+__device__ __forceinline__ A34 bn_load(const float* __restrict__ src) {
+    A34 a;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) a.m[q] = src[q];
+    return a;
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_kernel(const float* __restrict__ g_M, const float* __restrict__ bones, int bones_batch,
-                                                    const float* __restrict__ angles, const int* __restrict__ chain, int N, int K, int D,
-                                                    float* __restrict__ g_angles) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * K) return;
-    const int n = idx / K, k = idx - n * K;
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_kernel(const float* __restrict__ bones, int bones_batch, const float* __restrict__ angles,
+                                                            const int* __restrict__ chain, int K, int D, float* __restrict__ M) {
+    __shared__ float s_L[BN_MAXK][13];  // 13: odd stride, conflict-free row access
+    __shared__ int s_chain[BN_MAXK * BN_MAXD];  // a serial walk over global memory costs ~0.2 us per dependent load
+    const int n = blockIdx.x;
     const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)n * K * 6);
     const float* aa = angles + (long long)n * K * 3;
-    const float* g = g_M + (long long)idx * 12;
-    // prefix products P_j = L_0 ... L_{j-1}
-    A34 P[BN_MAXD];
-    A34 run = bn_identity();
-#pragma unroll
-    for (int j = 0; j < BN_MAXD; ++j) {
-        P[j] = run;
-        if (j < D) {
-            const int i = chain[k * D + j];
-            if (i >= 0) run = bn_mul(run, bn_link(bb + 6 * i, aa + 3 * i));
+    for (int w = threadIdx.x; w < K * D; w += blockDim.x) s_chain[w] = chain[w];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) bn_store(s_L[i], bn_link(bb + 6 * i, aa + 3 * i));
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        A34 acc = bn_identity();
+        for (int j = 0; j < D; ++j) {
+            const int i = s_chain[k * D + j];
+            if (i >= 0) acc = bn_mul(acc, bn_load(s_L[i]));
         }
-    }
-    A34 S = bn_identity();  // suffix product L_{j+1} ... L_{D-1}
-#pragma unroll
-    for (int jj = 0; jj < BN_MAXD; ++jj) {
-        const int j = BN_MAXD - 1 - jj;
-        if (j >= D) continue;
-        const int i = chain[k * D + j];
-        if (i < 0) continue;
-        // G = P_j^T (3x3 part) . g_M . S^T   restricted to the 3x4 block of L_j:
-        //   M = P L S  =>  dL = P_r^T dM_full S_full^T, with dM's implied last row zero
-        float T1[12];  // P_r^T . g   (3x4)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) T1[4 * r + c] = P[j].m[r] * g[c] + P[j].m[4 + r] * g[4 + c] + P[j].m[8 + r] * g[8 + c];
-        float GL[12];  // T1 . S_full^T, S_full = [S; 0 0 0 1]
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                GL[4 * r + c] = T1[4 * r] * S.m[4 * c] + T1[4 * r + 1] * S.m[4 * c + 1] + T1[4 * r + 2] * S.m[4 * c + 2] + T1[4 * r + 3] * S.m[4 * c + 3];
-            GL[4 * r + 3] = T1[4 * r + 3];
-        }
-        // link: Lr = R Rot R^T, Lt = t - Lr t   =>  g_Lr_total = g_Lr - g_Lt (x) t ;  g_Rot = R^T g_Lr_total R
-        float R[9], t[3];
-        bn_rest(bb + 6 * i, R, t);
-        float GLr[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) GLr[3 * r + c] = GL[4 * r + c] - GL[4 * r + 3] * t[c];
-        float T2[9], GRot[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) T2[3 * r + c] = R[r] * GLr[c] + R[3 + r] * GLr[3 + c] + R[6 + r] * GLr[6 + c];  // R^T . GLr
-        bn_mat3(T2, R, GRot);
-        // d Rot / d angles for Rot = Rx Ry Rz
-        const float x = aa[3 * i], y = aa[3 * i + 1], z = aa[3 * i + 2];
-        const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
-        const float dX[9] = {0.f, 0.f, 0.f,
-                             cx * sy * cz - sx * sz, -cx * sy * sz - sx * cz, -cx * cy,
-                             sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy};
-        const float dY[9] = {-sy * cz, sy * sz, cy,
-                             sx * cy * cz, -sx * cy * sz, sx * sy,
-                             -cx * cy * cz, cx * cy * sz, -cx * sy};
-        const float dZ[9] = {-cy * sz, -cy * cz, 0.f,
-                             -sx * sy * sz + cx * cz, -sx * sy * cz - cx * sz, 0.f,
-                             cx * sy * sz + sx * cz, cx * sy * cz - sx * sz, 0.f};
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { gx += GRot[q] * dX[q]; gy += GRot[q] * dY[q]; gz += GRot[q] * dZ[q]; }
-        float* o = g_angles + ((long long)n * K + i) * 3;
-        atomicAdd(o, gx); atomicAdd(o + 1, gy); atomicAdd(o + 2, gz);
-        S = bn_mul(bn_link(bb + 6 * i, aa + 3 * i), S);
+        bn_store(M + ((long long)n * K + k) * 12, acc);
     }
 }
+
+// backward: phase 1 links -> LDS; phase 2 (thread = bone, two threads per bone) prefix products P_j = L_0..L_{j-1} and suffix
+// products S_j = L_{j+1}..L_{D-1} of its chain -> LDS; phase 3 (thread = (bone, chain position)) the adjoint of one link pushed
+// through the conjugation and the Euler factors -> 3 floats in LDS; phase 4 (thread = (link, component)) sums the contributions of
+// every bone whose chain holds the link, in bone order: no atomics, no memset, bit-reproducible.
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_kernel(const float* __restrict__ g_M, const float* __restrict__ bones, int bones_batch,
+                                                            const float* __restrict__ angles, const int* __restrict__ chain, int K, int D,
+                                                            float* __restrict__ g_angles) {
+    extern __shared__ float s_dyn[];
+    float (*s_L)[13] = (float (*)[13])s_dyn;                    // [K][13]
+    float (*s_P)[13] = (float (*)[13])(s_dyn + 13 * K);         // [K*D][13]
+    float (*s_S)[13] = (float (*)[13])(s_dyn + 13 * K * (1 + D));  // [K*D][13]
+    float (*s_c)[3] = (float (*)[3])(s_dyn + 13 * K * (1 + 2 * D));  // [K*D][3]
+    int* s_chain = (int*)(s_dyn + 13 * K * (1 + 2 * D) + 3 * K * D);     // [K*D]
+    int* s_pos = s_chain + K * D;                                        // [K*K]: chain slot of link i in bone k's chain, or -1
+    const int n = blockIdx.x;
+    for (int w = threadIdx.x; w < K * D; w += blockDim.x) s_chain[w] = chain[w];
+    for (int w = threadIdx.x; w < K * K; w += blockDim.x) s_pos[w] = -1;
+    const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)n * K * 6);
+    const float* aa = angles + (long long)n * K * 3;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) bn_store(s_L[i], bn_link(bb + 6 * i, aa + 3 * i));
+    __syncthreads();
+    for (int w = threadIdx.x; w < K * D; w += blockDim.x) {  // a link occurs at most once in a chain: no write conflicts
+        const int i = s_chain[w];
+        if (i >= 0) s_pos[(w / D) * K + i] = w;
+    }
+    for (int w = threadIdx.x; w < 2 * K; w += blockDim.x) {
+        const int k = w >> 1;
+        if ((w & 1) == 0) {
+            A34 run = bn_identity();
+            for (int j = 0; j < D; ++j) {
+                bn_store(s_P[k * D + j], run);
+                const int i = s_chain[k * D + j];
+                if (i >= 0) run = bn_mul(run, bn_load(s_L[i]));
+            }
+        } else {
+            A34 run = bn_identity();
+            for (int j = D - 1; j >= 0; --j) {
+                bn_store(s_S[k * D + j], run);
+                const int i = s_chain[k * D + j];
+                if (i >= 0) run = bn_mul(bn_load(s_L[i]), run);
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < K * D; w += blockDim.x) {
+        const int k = w / D;
+        const int i = s_chain[w];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (i >= 0) {
+            const float* g = g_M + ((long long)n * K + k) * 12;
+            const float* P = s_P[w];
+            const float* S = s_S[w];
+            // M = P L S  =>  dL = P_r^T dM S_full^T  (dM's implied last row is zero; S_full = [S; 0 0 0 1])
+            float T1[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) T1[4 * r + c] = P[r] * g[c] + P[4 + r] * g[4 + c] + P[8 + r] * g[8 + c];
+            float GL[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    GL[4 * r + c] = T1[4 * r] * S[4 * c] + T1[4 * r + 1] * S[4 * c + 1] + T1[4 * r + 2] * S[4 * c + 2] + T1[4 * r + 3] * S[4 * c + 3];
+                GL[4 * r + 3] = T1[4 * r + 3];
+            }
+            // link: Lr = R Rot R^T, Lt = t - Lr t   =>  g_Lr_total = g_Lr - g_Lt (x) t ;  g_Rot = R^T g_Lr_total R
+            float R[9], t[3];
+            bn_rest(bb + 6 * i, R, t);
+            float GLr[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) GLr[3 * r + c] = GL[4 * r + c] - GL[4 * r + 3] * t[c];
+            float T2[9], GRot[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T2[3 * r + c] = R[r] * GLr[c] + R[3 + r] * GLr[3 + c] + R[6 + r] * GLr[6 + c];  // R^T . GLr
+            bn_mat3(T2, R, GRot);
+            // d Rot / d angles for Rot = Rx Ry Rz
+            const float x = aa[3 * i], y = aa[3 * i + 1], z = aa[3 * i + 2];
+            const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
+            const float dX[9] = {0.f, 0.f, 0.f,
+                                 cx * sy * cz - sx * sz, -cx * sy * sz - sx * cz, -cx * cy,
+                                 sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy};
+            const float dY[9] = {-sy * cz, sy * sz, cy,
+                                 sx * cy * cz, -sx * cy * sz, sx * sy,
+                                 -cx * cy * cz, cx * cy * sz, -cx * sy};
+            const float dZ[9] = {-cy * sz, -cy * cz, 0.f,
+                                 -sx * sy * sz + cx * cz, -sx * sy * cz - cx * sz, 0.f,
+                                 cx * sy * sz + sx * cz, cx * sy * cz - sx * sz, 0.f};
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { gx += GRot[q] * dX[q]; gy += GRot[q] * dY[q]; gz += GRot[q] * dZ[q]; }
+        }
+        s_c[w][0] = gx; s_c[w][1] = gy; s_c[w][2] = gz;
+    }
+    __syncthreads();
+    // phase 4: thread = (link, component); the contributions of the bones whose chain holds the link, in bone order
+    for (int t = threadIdx.x; t < 3 * K; t += blockDim.x) {
+        const int i = t / 3, comp = t - 3 * i;
+        float g = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const int w = s_pos[k * K + i];
+            g += w >= 0 ? s_c[w][comp] : 0.f;
+        }
+        g_angles[((long long)n * K + i) * 3 + comp] = g;
+    }
+}
+
+static size_t bn_bwd_lds(int K, int D) { return sizeof(float) * ((size_t)13 * K * (1 + 2 * D) + (size_t)4 * K * D + (size_t)K * K); }
 
 extern "C" int a3d_bone_transforms_fwd(const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N, int K, int D,
                                        float* M, a3d_stream_t stream) {
-    A3D_CHECK_ARG(bones && angles && chain && M && N > 0 && K > 0 && D > 0 && D <= BN_MAXD);
+    A3D_CHECK_ARG(bones && angles && chain && M && N > 0 && K > 0 && K <= BN_MAXK && D > 0 && D <= BN_MAXD);
     A3D_CHECK_ARG(bones_batch == 1 || bones_batch == N);
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3(a3d_div_up((long long)N * K, 64)), dim3(64), 0, (hipStream_t)stream, bones, bones_batch, angles, chain, N,
-                       K, D, M);
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(N), dim3(BN_THREADS), 0, (hipStream_t)stream, bones, bones_batch, angles, chain, K, D, M);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int N,
                                        int K, int D, float* g_angles, a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_M && bones && angles && chain && g_angles && N > 0 && K > 0 && D > 0 && D <= BN_MAXD);
+    A3D_CHECK_ARG(g_M && bones && angles && chain && g_angles && N > 0 && K > 0 && K <= BN_MAXK && D > 0 && D <= BN_MAXD);
     A3D_CHECK_ARG(bones_batch == 1 || bones_batch == N);
-    hipStream_t s = (hipStream_t)stream;
-    A3D_HIP(hipMemsetAsync(g_angles, 0, sizeof(float) * 3 * (size_t)N * K, s));
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(a3d_div_up((long long)N * K, 64)), dim3(64), 0, s, g_M, bones, bones_batch, angles, chain, N, K, D,
-                       g_angles);
+    // every g_angles element is written by its owner thread: no memset, no atomics
+    if (bn_bwd_lds(K, D) > 64 * 1024)  // K > ~48 with the deepest chains: opt in to the large-LDS launch (cheap, per call: no cached state)
+        A3D_HIP(hipFuncSetAttribute((const void*)bn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bn_bwd_lds(K, D)));
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(N), dim3(BN_THREADS), bn_bwd_lds(K, D), (hipStream_t)stream, g_M, bones, bones_batch, angles, chain, K,
+                       D, g_angles);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -33,6 +33,7 @@ SOURCES = {
     "embed.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
+    "topology.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",
           "-Wno-unused-function"]
@@ -56,7 +57,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(HERE, "topo_common.h"), os.path.join(HERE, "raster_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -1,5 +1,6 @@
 // Error string + version for the flat C ABI (include/a3d.h).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "a3d_common.h"
 
@@ -14,3 +15,8 @@ void a3d_set_error(const char* fmt, ...) {
 
 extern "C" const char* a3d_last_error(void) { return g_err; }
 extern "C" int a3d_version(void) { return 100; /* 0.1.0 */ }
+
+int a3d_exp(void) {
+    const char* e = getenv("A3D_EXP");
+    return e ? atoi(e) : 0;
+}

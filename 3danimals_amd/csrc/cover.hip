@@ -13,14 +13,16 @@ namespace {
 constexpr int CV_BLOCK = 256;
 constexpr int CV_SCAN_THREADS = 1024;
 
-__device__ __forceinline__ long long cv_flat(long long k, int H, int W, int tile) {
-    if (tile == 0) return k;
-    const int in_tile = (int)(k & 63);
-    long long t = k >> 6;
-    const int tw = W >> 3, th = H >> 3;
-    const int tx = (int)(t % tw); t /= tw;
-    const int ty = (int)(t % th); t /= th;  // t = image
-    return (t * H + (ty * 8 + (in_tile >> 3))) * W + tx * 8 + (in_tile & 7);
+// (all 32-bit: B*H*W < 2^31 is checked by the entry points, and a 64-bit division costs ~150 instructions per thread)
+__device__ __forceinline__ long long cv_flat(long long k64, int H, int W, int tile) {
+    if (tile == 0) return k64;
+    const unsigned k = (unsigned)k64;
+    const unsigned in_tile = k & 63u;
+    unsigned t = k >> 6;
+    const unsigned tw = (unsigned)W >> 3, th = (unsigned)H >> 3;
+    const unsigned tx = t % tw; t /= tw;
+    const unsigned ty = t % th; t /= th;  // t = image
+    return (long long)((t * (unsigned)H + (ty * 8u + (in_tile >> 3))) * (unsigned)W + tx * 8u + (in_tile & 7u));
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,

@@ -5,7 +5,7 @@
 // grid's unique edge list is static and already lexicographically sorted (dmtet.py:283-288), that rank is
 // an exclusive prefix sum of the "sign crossing" flag over the static list.  So:
 //   count : wave-ballot popcounts of the crossing flag per 1024-edge block and of the 1-/2-triangle case
-//           per 1024-tet block, then one single-block scan of the block sums  (-> V, n1, n2)
+//           per 1024-tet block, then one work-group scan per block-sum array  (-> V, n1, n2)
 //   emit  : edges re-evaluate the flag, ballot/mbcnt gives the in-wave rank, LDS the cross-wave offset;
 //           tets look their 3-4 surface vertices up through tet2edge -> edge2vert and write int64 faces.
 // Integer/byte work, HBM-bound: 8 B/edge + 16 B/tet (count) and 8 B/edge + 40 B/tet (emit) of streaming
@@ -73,40 +73,40 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
     }
 }
 
-// single block: in-place exclusive scan of the three block-sum arrays, totals to counts[0..2]
+// three work-groups, one per block-sum array: in-place exclusive scan, totals to counts[0..2]
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int which = 0; which < 3; ++which) {
-        int* arr = which == 0 ? blk_e : (which == 1 ? blk_t1 : blk_t2);
-        const int n = which == 0 ? nbe : nbt;
-        if (tid == 0) s_carry = 0;
-        __syncthreads();
-        for (int base = 0; base < n; base += 1024) {
-            int i = base + tid;
-            int v = i < n ? arr[i] : 0;
-            int incl = v;
+    const int which = blockIdx.x;
+    int* arr = which == 0 ? blk_e : (which == 1 ? blk_t1 : blk_t2);
+    const int n = which == 0 ? nbe : nbt;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        int v = i < n ? arr[i] : 0;
+        int incl = v;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-            if (lane == 63) s_wave[wave] = incl;
-            __syncthreads();
-            int woff = 0;
-            for (int w = 0; w < wave; ++w) woff += s_wave[w];
-            int carry = s_carry;
-            if (i < n) arr[i] = carry + woff + incl - v;
-            __syncthreads();
-            if (tid == 1023) s_carry = carry + woff + incl;
-            __syncthreads();
+        for (int o = 1; o < 64; o <<= 1) {
+            int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
-        if (tid == 0) counts[which] = s_carry;
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wave[w];
+        int carry = s_carry;
+        if (i < n) arr[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) counts[3] = 0;
+    if (tid == 0) {
+        counts[which] = s_carry;
+        if (which == 0) counts[3] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ emit
@@ -268,7 +268,7 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     hipLaunchKernelGGL(dm_count_kernel, dim3(nbe + nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
                        nbe, be, b1, b2);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dm_scan_kernel, dim3(1), dim3(1024), 0, s, be, b1, b2, nbe, nbt, counts);
+    hipLaunchKernelGGL(dm_scan_kernel, dim3(3), dim3(1024), 0, s, be, b1, b2, nbe, nbt, counts);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -7,12 +7,22 @@
 // render.py:261-262), so here ONE kernel walks the compact list of covered pixels:
 //   fwd : texel (u,v,id) -> 3 vertex ids -> gathers of v_pos / v_nrm / canonical v_pos -> 12 floats per point
 //         [ world position | normalised face normal | smooth normal | canonical position ]
-//   bwd : the four attribute adjoints (bary-weighted float atomics onto the three vertices), the face-normal adjoint
-//         (normalise + cross product), and -- folded in -- the rasteriser's backward: d/du, d/dv of all attributes are
-//         pushed straight through u = a0/(a0+a1+a2), v = a1/(...) onto clip-space x, y, w.  No [B,H,W,4] gradient image
-//         is ever materialised.
-// The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller: 16 images hitting the same
-// vertex of a [1,V,3] buffer serialise their atomics (measured 128 us vs 9 us per interpolate backward).
+//   bwd : one thread per covered pixel: the adjoint of the pixel onto the three corners of its triangle -- the four attribute
+//         adjoints (bary weighted), the face-normal adjoint (normalise + cross product) and, folded in, the rasteriser's
+//         backward: d/du, d/dv of all attributes pushed straight through u = a0/(a0+a1+a2), v = a1/(...) onto clip-space x, y, w.
+//         The 36 scatter-adds per pixel are aggregated per work-group in an LDS hash table keyed by vertex and every distinct
+//         vertex is flushed once (12 device-scope atomics).  No [B,H,W,4] gradient image is ever materialised.
+//         What bounds it (bisected on the bench workload, B=16, 2e5 covered pixels): the LDS float atomics -- a wave's 64 pixels
+//         reference ~25 distinct vertices, so every ds_add_f32 instruction serialises on shared addresses.  Neighbouring list
+//         entries that hit the same triangle are therefore merged through DPP first (70 -> 61 us); replicating the table rows to
+//         spread the collisions cost more in table set-up and flush than it saved (2 replicas 70 us, 4 replicas 85 us).
+//         Designs measured and dropped (rocprofv3, same workload; the single hash table took 72 us): per-triangle pixel slots
+//         filled by the forward with one returning atomic per pixel + a gather per (vertex, face) 38 (fwd) + 55 + 59 us; an
+//         atomic-free face pass over each triangle's pixel box + vertex gather 83 + 9 us (176 VGPRs, serial load chains);
+//         screen-aligned 16x16 regions with an LDS table written out to per-vertex slots + vertex pass 131 + 6 us (same LDS
+//         atomics, 4096 work-groups of 57 KB).  Device-scope atomics are fabric transactions on gfx950 (~30/ns fire-and-forget,
+//         ~7/ns returning); LDS atomics ~7 cycles per lane when lanes collide.
+// The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller.
 // HBM traffic per covered pixel: fwd 8 (index) + 16 (texel) + 48 (out) B; bwd 8 + 16 + 48 B in; vertex data lives in L2.
 #include "a3d_common.h"
 
@@ -20,7 +30,7 @@ __device__ __forceinline__ void gb_load3(const float* __restrict__ p, float& x, 
 
 __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ rast, const int* __restrict__ tri, const long long* __restrict__ pix,
                                                      long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
-                                                     const float* __restrict__ prior, int prior_batch, int V, long long hw,
+                                                     const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
                                                      float* __restrict__ out) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -28,7 +38,7 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     const float4 r = rast[i];
     const int f = (int)r.w - 1;
     float* o = out + p * 12;
-    if (f < 0) {
+    if (f < 0 || f >= F) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) o[c] = 0.f;
         return;
@@ -65,10 +75,96 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     o[11] = u * az + v * bz + w * cz;
 }
 
-// ---- backward.  Scatter targets are aggregated per workgroup in an LDS hash table keyed by vertex row (b*V + v):
-// the 256 consecutive covered pixels of a block reference ~770 vertices but only ~150-200 distinct ones, so the 36
-// float atomics per pixel go to LDS (ds_add_f32) and each distinct vertex is flushed to HBM/L2 once (12 atomics).
-#define GB_SLOTS 512
+// ---- backward -------------------------------------------------------------------------------------------------------------
+// Vertex data of one triangle of one image, loaded once and reused by every pixel of the triangle.
+struct GbTri {
+    float pos[3][3], nrm[3][3], pri[3][3];
+    // adjoint helpers of the face normal that do not depend on the pixel
+    float e1[3], e2[3], fn[3], inv_len;
+    bool degenerate;
+};
+
+__device__ __forceinline__ void gb_load_tri(GbTri& t, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
+                                            const float* __restrict__ prior, long long vb3, long long pb3, int i0, int i1, int i2) {
+    const int idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gb_load3(v_pos + vb3 + 3ll * idx[k], t.pos[k][0], t.pos[k][1], t.pos[k][2]);
+        gb_load3(v_nrm + vb3 + 3ll * idx[k], t.nrm[k][0], t.nrm[k][1], t.nrm[k][2]);
+        gb_load3(prior + pb3 + 3ll * idx[k], t.pri[k][0], t.pri[k][1], t.pri[k][2]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.e1[c] = t.pos[1][c] - t.pos[0][c]; t.e2[c] = t.pos[2][c] - t.pos[0][c]; }
+    const float nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1], ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2], nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
+    const float d = nx * nx + ny * ny + nz * nz;
+    t.degenerate = !(d > 1e-20f);
+    t.inv_len = t.degenerate ? 1e10f : 1.f / sqrtf(d);
+    t.fn[0] = nx * t.inv_len; t.fn[1] = ny * t.inv_len; t.fn[2] = nz * t.inv_len;
+}
+
+// Adjoint of one covered pixel onto the three corners of its triangle, ADDED to acc[corner][0..11]: [0..2] d/d v_pos, [3..5]
+// d/d v_nrm, [6..8] d/d canonical position, [9..11] d/d clip x, y, w.  (u, v) = barycentrics of the texel, g = the 12 incoming
+// gradients of the G-buffer row, p0..p2 = clip-space vertices.
+__device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0, const float4 p1, const float4 p2, float u, float v,
+                                                 const float g[12], int px, int py, int H, int W, bool want_clip, float acc[3][12]) {
+    const float w = 1.f - u - v;
+    float gu = 0.f, gv = 0.f;
+    // world position
+    const float gx = g[0], gy = g[1], gz = g[2];
+    gu += gx * (t.pos[0][0] - t.pos[2][0]) + gy * (t.pos[0][1] - t.pos[2][1]) + gz * (t.pos[0][2] - t.pos[2][2]);
+    gv += gx * (t.pos[1][0] - t.pos[2][0]) + gy * (t.pos[1][1] - t.pos[2][1]) + gz * (t.pos[1][2] - t.pos[2][2]);
+    // face normal n = e1 x e2, normalised: q = adjoint of the un-normalised normal; g_e1 = e2 x q, g_e2 = q x e1
+    const float hx = g[3], hy = g[4], hz = g[5];
+    float qx, qy, qz;
+    if (!t.degenerate) {
+        const float dot = t.fn[0] * hx + t.fn[1] * hy + t.fn[2] * hz;
+        qx = (hx - t.fn[0] * dot) * t.inv_len; qy = (hy - t.fn[1] * dot) * t.inv_len; qz = (hz - t.fn[2] * dot) * t.inv_len;
+    } else {
+        qx = hx * 1e10f; qy = hy * 1e10f; qz = hz * 1e10f;
+    }
+    const float g1x = t.e2[1] * qz - t.e2[2] * qy, g1y = t.e2[2] * qx - t.e2[0] * qz, g1z = t.e2[0] * qy - t.e2[1] * qx;
+    const float g2x = qy * t.e1[2] - qz * t.e1[1], g2y = qz * t.e1[0] - qx * t.e1[2], g2z = qx * t.e1[1] - qy * t.e1[0];
+    acc[0][0] += u * gx - (g1x + g2x); acc[0][1] += u * gy - (g1y + g2y); acc[0][2] += u * gz - (g1z + g2z);
+    acc[1][0] += v * gx + g1x; acc[1][1] += v * gy + g1y; acc[1][2] += v * gz + g1z;
+    acc[2][0] += w * gx + g2x; acc[2][1] += w * gy + g2y; acc[2][2] += w * gz + g2z;
+    // smooth normal
+    const float mx = g[6], my = g[7], mz = g[8];
+    gu += mx * (t.nrm[0][0] - t.nrm[2][0]) + my * (t.nrm[0][1] - t.nrm[2][1]) + mz * (t.nrm[0][2] - t.nrm[2][2]);
+    gv += mx * (t.nrm[1][0] - t.nrm[2][0]) + my * (t.nrm[1][1] - t.nrm[2][1]) + mz * (t.nrm[1][2] - t.nrm[2][2]);
+    acc[0][3] += u * mx; acc[0][4] += u * my; acc[0][5] += u * mz;
+    acc[1][3] += v * mx; acc[1][4] += v * my; acc[1][5] += v * mz;
+    acc[2][3] += w * mx; acc[2][4] += w * my; acc[2][5] += w * mz;
+    // canonical position
+    const float cx = g[9], cy = g[10], cz = g[11];
+    gu += cx * (t.pri[0][0] - t.pri[2][0]) + cy * (t.pri[0][1] - t.pri[2][1]) + cz * (t.pri[0][2] - t.pri[2][2]);
+    gv += cx * (t.pri[1][0] - t.pri[2][0]) + cy * (t.pri[1][1] - t.pri[2][1]) + cz * (t.pri[1][2] - t.pri[2][2]);
+    acc[0][6] += u * cx; acc[0][7] += u * cy; acc[0][8] += u * cz;
+    acc[1][6] += v * cx; acc[1][7] += v * cy; acc[1][8] += v * cz;
+    acc[2][6] += w * cx; acc[2][7] += w * cy; acc[2][8] += w * cz;
+    if (want_clip && (gu != 0.f || gv != 0.f)) {  // rasteriser backward (same algebra as rs_bwd_kernel)
+        const float fx = ((float)px + 0.5f) * (2.f / (float)W) - 1.f;
+        const float fy = ((float)py + 0.5f) * (2.f / (float)H) - 1.f;
+        const float q0x = p0.x - fx * p0.w, q0y = p0.y - fy * p0.w;
+        const float q1x = p1.x - fx * p1.w, q1y = p1.y - fy * p1.w;
+        const float q2x = p2.x - fx * p2.w, q2y = p2.y - fy * p2.w;
+        const float a0 = q1x * q2y - q1y * q2x, a1 = q2x * q0y - q2y * q0x, a2 = q0x * q1y - q0y * q1x;
+        const float s = a0 + a1 + a2;
+        if (s != 0.f) {
+            const float is = 1.f / s;
+            const float uu = a0 * is, vv = a1 * is;
+            const float tt = gu * uu + gv * vv;
+            const float ga0 = (gu - tt) * is, ga1 = (gv - tt) * is, ga2 = -tt * is;
+            const float o0x = -ga1 * q2y + ga2 * q1y, o0y = ga1 * q2x - ga2 * q1x;
+            const float o1x = ga0 * q2y - ga2 * q0y, o1y = -ga0 * q2x + ga2 * q0x;
+            const float o2x = -ga0 * q1y + ga1 * q0y, o2y = ga0 * q1x - ga1 * q0x;
+            acc[0][9] += o0x; acc[0][10] += o0y; acc[0][11] += -fx * o0x - fy * o0y;
+            acc[1][9] += o1x; acc[1][10] += o1y; acc[1][11] += -fx * o1x - fy * o1y;
+            acc[2][9] += o2x; acc[2][10] += o2y; acc[2][11] += -fx * o2x - fy * o2y;
+        }
+    }
+}
+
+#define GB_SLOTS 512  // vertices per work-group table (256 pixels reference ~150-200 distinct ones)
 #define GB_PROBES 16
 
 __device__ __forceinline__ int gb_slot(int* s_key, int key) {
@@ -86,145 +182,87 @@ struct GbTargets {
     float* vpos; float* vnrm; float* prior; float* clip;
 };
 
-__device__ __forceinline__ void gb_accumulate(int* s_key, float (*s_acc)[12], const GbTargets& t, int row, const float c[12]) {
-    const int slot = gb_slot(s_key, row);
-    if (slot >= 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) atomicAdd(&s_acc[slot][k], c[k]);
-    } else {
-        float* a = t.vpos + 3ll * row;
-        float* n = t.vnrm + 3ll * row;
-        atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
-        atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
-        if (t.prior) { float* q = t.prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
-        if (t.clip) { float* q = t.clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
-    }
+__device__ __forceinline__ void gb_flush_row(const GbTargets& t, long long row, const float c[12]) {
+    float* a = t.vpos + 3ll * row;
+    float* n = t.vnrm + 3ll * row;
+    atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
+    atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
+    if (t.prior) { float* q = t.prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
+    if (t.clip) { float* q = t.clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
 }
 
 __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g_out, const float4* __restrict__ rast, const int* __restrict__ tri,
                                                      const long long* __restrict__ pix, long long P, const float* __restrict__ v_pos,
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
-                                                     const float4* __restrict__ clip, int V, int H, int W, float* __restrict__ g_vpos,
-                                                     float* __restrict__ g_vnrm, float* __restrict__ g_prior, float* __restrict__ g_clip) {
+                                                     const float4* __restrict__ clip, int V, int F, int H, int W, GbTargets tg) {
     __shared__ int s_key[GB_SLOTS];
-    __shared__ float s_acc[GB_SLOTS][12];
+    __shared__ float s_acc[GB_SLOTS][13];  // 13: odd stride
     for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) {
         s_key[i] = -1;
 #pragma unroll
         for (int k = 0; k < 12; ++k) s_acc[i][k] = 0.f;
     }
     __syncthreads();
-    GbTargets tg;
-    tg.vpos = g_vpos; tg.vnrm = g_vnrm; tg.prior = g_prior; tg.clip = g_clip;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long i = p < P ? pix[p] : 0;
     const float4 r = p < P ? rast[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int f = (int)r.w - 1;
-    if (p < P && f >= 0) {
-        const long long hw = (long long)H * W;
-        const long long b = i / hw;
-        const int rem = (int)(i - b * hw);
-        const int py = rem / W, px = rem - py * W;
-        const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
-        const float u = r.x, v = r.y, w = 1.f - u - v;
-        const float* g = g_out + p * 12;
-        const long long vb = b * V * 3;
-        float c0[12], c1[12], c2[12];  // contributions to the three vertices: vpos(3) vnrm(3) prior(3) clip x,y,w
-        float gu = 0.f, gv = 0.f;
-        float ax, ay, az, bx, by, bz, cx, cy, cz;
-        {   // world position + face normal (both functions of the three positions)
-            const float* vp = v_pos + vb;
-            gb_load3(vp + 3ll * i0, ax, ay, az);
-            gb_load3(vp + 3ll * i1, bx, by, bz);
-            gb_load3(vp + 3ll * i2, cx, cy, cz);
-            const float gx = g[0], gy = g[1], gz = g[2];
-            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
-            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
-            const float e1x = bx - ax, e1y = by - ay, e1z = bz - az, e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
-            const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-            const float d = nx * nx + ny * ny + nz * nz;
-            const float hx = g[3], hy = g[4], hz = g[5];
-            float qx, qy, qz;  // adjoint of the un-normalised face normal
-            if (d > 1e-20f) {
-                const float inv = 1.f / sqrtf(d);
-                const float fx = nx * inv, fy = ny * inv, fz = nz * inv;
-                const float dot = fx * hx + fy * hy + fz * hz;
-                qx = (hx - fx * dot) * inv; qy = (hy - fy * dot) * inv; qz = (hz - fz * dot) * inv;
-            } else {
-                qx = hx * 1e10f; qy = hy * 1e10f; qz = hz * 1e10f;
-            }
-            // n = e1 x e2:  g_e1 = e2 x q,  g_e2 = q x e1
-            const float g1x = e2y * qz - e2z * qy, g1y = e2z * qx - e2x * qz, g1z = e2x * qy - e2y * qx;
-            const float g2x = qy * e1z - qz * e1y, g2y = qz * e1x - qx * e1z, g2z = qx * e1y - qy * e1x;
-            c0[0] = u * gx - (g1x + g2x); c0[1] = u * gy - (g1y + g2y); c0[2] = u * gz - (g1z + g2z);
-            c1[0] = v * gx + g1x; c1[1] = v * gy + g1y; c1[2] = v * gz + g1z;
-            c2[0] = w * gx + g2x; c2[1] = w * gy + g2y; c2[2] = w * gz + g2z;
+    const bool live = p < P && f >= 0 && f < F;
+    float acc[3][12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[c][k] = 0.f;
+    int i0 = 0, i1 = 0, i2 = 0;
+    long long b = 0;
+    if (live) {
+        const unsigned hw = (unsigned)H * (unsigned)W;
+        b = (long long)((unsigned)i / hw);
+        const unsigned rem = (unsigned)i - (unsigned)b * hw;
+        const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
+        i0 = tri[3 * f]; i1 = tri[3 * f + 1]; i2 = tri[3 * f + 2];
+        const long long vb3 = b * V * 3, pb3 = prior_batch == 1 ? 0ll : vb3;
+        GbTri t;
+        gb_load_tri(t, v_pos, v_nrm, prior, vb3, pb3, i0, i1, i2);
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 1.f), p1 = p0, p2 = p0;
+        if (tg.clip) { const float4* cb = clip + b * V; p0 = cb[i0]; p1 = cb[i1]; p2 = cb[i2]; }
+        const float4* gp = reinterpret_cast<const float4*>(g_out + p * 12);
+        const float4 ga = gp[0], gb4 = gp[1], gc = gp[2];
+        const float g[12] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z, gc.w};
+        gb_pixel_adjoint(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, tg.clip != nullptr, acc);
+    }
+    // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums (DPP), so a third
+    // fewer table updates (measured 70 -> 61 us)
+    const long long tkey = live ? b * F + f : -1 - (long long)threadIdx.x;
+    const bool same = live && __shfl_xor(tkey, 1, 64) == tkey;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float o = __shfl_xor(acc[c][k], 1, 64);
+            if (same) acc[c][k] += o;
         }
-        {   // smooth normal
-            const float* vn = v_nrm + vb;
-            gb_load3(vn + 3ll * i0, ax, ay, az);
-            gb_load3(vn + 3ll * i1, bx, by, bz);
-            gb_load3(vn + 3ll * i2, cx, cy, cz);
-            const float gx = g[6], gy = g[7], gz = g[8];
-            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
-            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
-            c0[3] = u * gx; c0[4] = u * gy; c0[5] = u * gz;
-            c1[3] = v * gx; c1[4] = v * gy; c1[5] = v * gz;
-            c2[3] = w * gx; c2[4] = w * gy; c2[5] = w * gz;
-        }
-        {   // canonical position (accumulated per image even when the canonical mesh is shared)
-            const float* pr = prior + (prior_batch == 1 ? 0ll : vb);
-            gb_load3(pr + 3ll * i0, ax, ay, az);
-            gb_load3(pr + 3ll * i1, bx, by, bz);
-            gb_load3(pr + 3ll * i2, cx, cy, cz);
-            const float gx = g[9], gy = g[10], gz = g[11];
-            gu += gx * (ax - cx) + gy * (ay - cy) + gz * (az - cz);
-            gv += gx * (bx - cx) + gy * (by - cy) + gz * (bz - cz);
-            c0[6] = u * gx; c0[7] = u * gy; c0[8] = u * gz;
-            c1[6] = v * gx; c1[7] = v * gy; c1[8] = v * gz;
-            c2[6] = w * gx; c2[7] = w * gy; c2[8] = w * gz;
-        }
-        c0[9] = c0[10] = c0[11] = c1[9] = c1[10] = c1[11] = c2[9] = c2[10] = c2[11] = 0.f;
-        if (g_clip && (gu != 0.f || gv != 0.f)) {  // rasteriser backward (same algebra as rs_bwd_kernel)
-            const long long cb = b * V;
-            const float4 p0 = clip[cb + i0], p1 = clip[cb + i1], p2 = clip[cb + i2];
-            const float fx = ((float)px + 0.5f) * (2.f / (float)W) - 1.f;
-            const float fy = ((float)py + 0.5f) * (2.f / (float)H) - 1.f;
-            const float q0x = p0.x - fx * p0.w, q0y = p0.y - fy * p0.w;
-            const float q1x = p1.x - fx * p1.w, q1y = p1.y - fy * p1.w;
-            const float q2x = p2.x - fx * p2.w, q2y = p2.y - fy * p2.w;
-            const float a0 = q1x * q2y - q1y * q2x, a1 = q2x * q0y - q2y * q0x, a2 = q0x * q1y - q0y * q1x;
-            const float s = a0 + a1 + a2;
-            if (s != 0.f) {
-                const float is = 1.f / s;
-                const float uu = a0 * is, vv = a1 * is;
-                const float t = gu * uu + gv * vv;
-                const float ga0 = (gu - t) * is, ga1 = (gv - t) * is, ga2 = -t * is;
-                c0[9] = -ga1 * q2y + ga2 * q1y; c0[10] = ga1 * q2x - ga2 * q1x;
-                c1[9] = ga0 * q2y - ga2 * q0y;  c1[10] = -ga0 * q2x + ga2 * q0x;
-                c2[9] = -ga0 * q1y + ga1 * q0y; c2[10] = ga0 * q1x - ga1 * q0x;
-                c0[11] = -fx * c0[9] - fy * c0[10];
-                c1[11] = -fx * c1[9] - fy * c1[10];
-                c2[11] = -fx * c2[9] - fy * c2[10];
-            }
-        }
+    if (live && !(same && (threadIdx.x & 1))) {
         const int rowb = (int)(b * V);
-        gb_accumulate(s_key, s_acc, tg, rowb + i0, c0);
-        gb_accumulate(s_key, s_acc, tg, rowb + i1, c1);
-        gb_accumulate(s_key, s_acc, tg, rowb + i2, c2);
+        const int idx[3] = {i0, i1, i2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int slot = gb_slot(s_key, rowb + idx[c]);
+            if (slot >= 0) {
+                float* dst = s_acc[slot];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) atomicAdd(dst + k, acc[c][k]);
+            } else {
+                gb_flush_row(tg, rowb + idx[c], acc[c]);
+            }
+        }
     }
     __syncthreads();
     // flush: one set of global atomics per distinct vertex touched by this block
     for (int sidx = threadIdx.x; sidx < GB_SLOTS; sidx += blockDim.x) {
         const int row = s_key[sidx];
         if (row < 0) continue;
-        const float* c = s_acc[sidx];
-        float* a = g_vpos + 3ll * row;
-        float* n = g_vnrm + 3ll * row;
-        atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
-        atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
-        if (g_prior) { float* q = g_prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
-        if (g_clip) { float* q = g_clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
+        gb_flush_row(tg, row, s_acc[sidx]);
     }
 }
 
@@ -235,7 +273,7 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
-                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, (long long)H * W, out);
+                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -243,19 +281,32 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                                const float* v_nrm, const float* prior, int prior_batch, const float* clip, int B, int V, int F, int H, int W,
                                float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream) {
-    A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
+    A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(g_vpos && g_vnrm);
     hipStream_t s = (hipStream_t)stream;
-    const size_t n3 = sizeof(float) * 3 * (size_t)B * V;
-    A3D_HIP(hipMemsetAsync(g_vpos, 0, n3, s));
-    A3D_HIP(hipMemsetAsync(g_vnrm, 0, n3, s));
-    if (g_prior_or_null) A3D_HIP(hipMemsetAsync(g_prior_or_null, 0, n3, s));
-    if (g_clip_or_null) A3D_HIP(hipMemsetAsync(g_clip_or_null, 0, sizeof(float) * 4 * (size_t)B * V, s));
+    const size_t n3 = 3 * (size_t)B * V;
+    // the four gradient buffers are zeroed here; when the caller carved them out of one allocation (vpos | vnrm | prior | clip,
+    // what ops.py does) that is ONE memset launch instead of four
+    float* nxt = g_vpos + n3;
+    bool one = g_vnrm == nxt;
+    nxt = g_vnrm + n3;
+    if (g_prior_or_null) { one = one && g_prior_or_null == nxt; nxt = g_prior_or_null + n3; }
+    if (g_clip_or_null) { one = one && g_clip_or_null == nxt; nxt = g_clip_or_null + 4 * (size_t)B * V; }
+    if (one) {
+        A3D_HIP(hipMemsetAsync(g_vpos, 0, sizeof(float) * (size_t)(nxt - g_vpos), s));
+    } else {
+        A3D_HIP(hipMemsetAsync(g_vpos, 0, sizeof(float) * n3, s));
+        A3D_HIP(hipMemsetAsync(g_vnrm, 0, sizeof(float) * n3, s));
+        if (g_prior_or_null) A3D_HIP(hipMemsetAsync(g_prior_or_null, 0, sizeof(float) * n3, s));
+        if (g_clip_or_null) A3D_HIP(hipMemsetAsync(g_clip_or_null, 0, sizeof(float) * 4 * (size_t)B * V, s));
+    }
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior && (!g_clip_or_null || clip));
+    GbTargets tg;
+    tg.vpos = g_vpos; tg.vnrm = g_vnrm; tg.prior = g_prior_or_null; tg.clip = g_clip_or_null;
     hipLaunchKernelGGL(gb_bwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P,
-                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip, V, H, W, g_vpos, g_vnrm, g_prior_or_null, g_clip_or_null);
+                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, tg);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -11,42 +11,13 @@
 // The reference materialises three [B,F,3] gathers, a [B,F,3] cross product and three index.repeat(B,1,3) int64 tensors per
 // call; here 16 B/entry of indices (L2 resident, shared over the batch) + 36 B/entry position gathers + 24 B/vertex.
 #include "a3d_common.h"
+#include "topo_common.h"
 
 namespace {
-
-constexpr int NR_SCAN_THREADS = 1024;
 
 __global__ __launch_bounds__(256) void nr_adj_count_kernel(const int* __restrict__ tri, int n3, int* __restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n3) atomicAdd(cnt + tri[i], 1);
-}
-
-// single work-group exclusive scan of cnt[V] -> off[V+1]; cnt is reset to 0 (it becomes the fill cursor)
-__global__ __launch_bounds__(NR_SCAN_THREADS) void nr_adj_scan_kernel(int* __restrict__ cnt, int V, int* __restrict__ off) {
-    __shared__ int wave_tot[NR_SCAN_THREADS / 64];
-    __shared__ int carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < V; base += NR_SCAN_THREADS) {
-        const int i = base + threadIdx.x;
-        const int c = i < V ? cnt[i] : 0;
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        if (i < V) { off[i] = before + incl - c; cnt[i] = 0; }
-        __syncthreads();
-        if (threadIdx.x == NR_SCAN_THREADS - 1) carry_s = before + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off[V] = carry_s;
 }
 
 __global__ __launch_bounds__(256) void nr_adj_fill_kernel(const int* __restrict__ tri, int F, const int* __restrict__ off,
@@ -55,19 +26,6 @@ __global__ __launch_bounds__(256) void nr_adj_fill_kernel(const int* __restrict_
     if (i >= 3 * F) return;
     const int f = i / 3, c = i - 3 * f, v = tri[i];
     adj[off[v] + atomicAdd(cursor + v, 1)] = c * F + f;
-}
-
-// lists are short (valence ~6): insertion sort in place makes the summation order independent of the atomics above
-__global__ __launch_bounds__(256) void nr_adj_sort_kernel(const int* __restrict__ off, int V, int* __restrict__ adj) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    const int lo = off[v], hi = off[v + 1];
-    for (int i = lo + 1; i < hi; ++i) {
-        const int key = adj[i];
-        int j = i - 1;
-        while (j >= lo && adj[j] > key) { adj[j + 1] = adj[j]; --j; }
-        adj[j + 1] = key;
-    }
 }
 
 struct NrFace { int i0, i1, i2, c; };

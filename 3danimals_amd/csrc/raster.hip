@@ -23,6 +23,7 @@
 // compiled with -ffp-contract=off so that the edge functions of a shared edge are exact negations (watertight)
 // and the triangle ids match the oracle bit for bit.
 #include "a3d_common.h"
+#include "raster_common.h"
 
 #define RS_COOP_AREA 64  // boxes above this many pixels are rasterised by all 64 lanes of the wave
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -80,32 +81,6 @@ __device__ __forceinline__ unsigned rs_order(float f) {  // monotone float -> ui
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// conservative pixel box (same as oracle/raster_ref.c); returns the number of candidate pixels (0 = culled)
-__device__ __forceinline__ int rs_box(const float4 p0, const float4 p1, const float4 p2, int H, int W, int& x0, int& y0, int& bw) {
-    int x1, y1;
-    if (p0.w > 0.f && p1.w > 0.f && p2.w > 0.f) {
-        const float sx0 = p0.x / p0.w, sx1 = p1.x / p1.w, sx2 = p2.x / p2.w;
-        const float sy0 = p0.y / p0.w, sy1 = p1.y / p1.w, sy2 = p2.y / p2.w;
-        const float mnx = fminf(sx0, fminf(sx1, sx2)), mxx = fmaxf(sx0, fmaxf(sx1, sx2));
-        const float mny = fminf(sy0, fminf(sy1, sy2)), mxy = fmaxf(sy0, fmaxf(sy1, sy2));
-        // pixel centres px+0.5 inside [min,max], widened by 1/32 px (coverage itself is decided by rs_frag)
-        const float fx0 = ceilf((mnx + 1.f) * 0.5f * W - 0.53125f), fx1 = floorf((mxx + 1.f) * 0.5f * W - 0.46875f);
-        const float fy0 = ceilf((mny + 1.f) * 0.5f * H - 0.53125f), fy1 = floorf((mxy + 1.f) * 0.5f * H - 0.46875f);
-        if (!((fx1 >= 0.f) && (fy1 >= 0.f) && (fx0 <= (float)(W - 1)) && (fy0 <= (float)(H - 1)))) return 0;
-        x0 = fx0 < 0.f ? 0 : (int)fx0;
-        y0 = fy0 < 0.f ? 0 : (int)fy0;
-        x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
-        y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
-    } else if (p0.w <= 0.f && p1.w <= 0.f && p2.w <= 0.f) {
-        return 0;
-    } else {
-        x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;  // straddles the eye plane: every pixel is a candidate
-    }
-    bw = x1 - x0 + 1;
-    const int bh = y1 - y0 + 1;
-    return (bw > 0 && bh > 0) ? bw * bh : 0;
-}
-
 __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, const float4 p2, int px, int py, int W, float xs, float xo,
                                               float ys, float yo, unsigned f, unsigned long long* __restrict__ keys) {
     const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
@@ -136,8 +111,15 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
             area = rs_box(p0, p1, p2, H, W, x0, y0, bw);
         }
     }
-    if (area <= RS_COOP_AREA) {
-        for (int i = sub; i < area; i += 4) rs_test_pixel(p0, p1, p2, x0 + i % bw, y0 + i / bw, W, xs, xo, ys, yo, (unsigned)f, kb);
+    if (area > 0 && area <= RS_COOP_AREA) {  // (a culled box may carry bw <= 0)
+        // candidate i of the box is (x0 + i % bw, y0 + i / bw); walked incrementally (an integer division costs ~40 instructions)
+        int cx = sub, cy = 0;
+        while (cx >= bw) { cx -= bw; ++cy; }
+        for (int i = sub; i < area; i += 4) {
+            rs_test_pixel(p0, p1, p2, x0 + cx, y0 + cy, W, xs, xo, ys, yo, (unsigned)f, kb);
+            cx += 4;
+            while (cx >= bw) { cx -= bw; ++cy; }
+        }
     }
     // large boxes: one representative lane per triangle (sub == 0) votes, the whole wave walks the box
     unsigned long long big = __ballot(area > RS_COOP_AREA && sub == 0);
@@ -154,18 +136,19 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     }
 }
 
+// grid (ceil(H*W / 256), B): the image comes from blockIdx.y and the row/column from one 32-bit division
 __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
-                                                         int H, int W, long long npix, const unsigned long long* __restrict__ keys,
+                                                         int H, int W, const unsigned long long* __restrict__ keys,
                                                          float4* __restrict__ rast) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
+    const unsigned hw = (unsigned)H * (unsigned)W;
+    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= hw) return;
+    const int b = blockIdx.y;
+    const long long i = (long long)b * hw + rem;
     const unsigned long long key = keys[i];
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (key != RS_EMPTY) {
-        const long long hw = (long long)H * W;
-        const int b = (int)(i / hw);
-        const int rem = (int)(i - b * hw);
-        const int py = rem / W, px = rem - py * W;
+        const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
         const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
         const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
         const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
@@ -224,6 +207,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
+    A3D_CHECK_ARG((long long)H * W < 0x7fffffffll && B <= 65535);
     hipStream_t s = (hipStream_t)stream;
     const long long npix = (long long)B * H * W;
     if (F == 0) {
@@ -234,8 +218,8 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     hipLaunchKernelGGL(rs_tri_kernel, dim3(a3d_div_up(F, 64), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W, keys);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rs_resolve_kernel, dim3(a3d_div_up(npix, 256)), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, H, W, npix, keys,
-                       (float4*)rast);
+    hipLaunchKernelGGL(rs_resolve_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, H, W,
+                       keys, (float4*)rast);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

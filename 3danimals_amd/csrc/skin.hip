@@ -4,7 +4,7 @@
 // weights from point-to-segment distances (skinning.py:16-22, geometry/util.py:30-53) and the weighted sum
 // of the K per-bone affine maps.  The reference materialises K copies of the [B,V,3] vertex array; here a
 // vertex is read once (12 B), the image's bones (K x 7 floats) and transforms (K x 12 floats) sit in LDS,
-// and the softmax runs online in registers.  Weights are recomputed in backward instead of stored.
+// and the softmax runs in registers over the K cached logits.  Weights are recomputed in backward instead of stored.
 // HBM traffic: 12 B/vertex in (shared prior: once per image from L2), 12 B/vertex out.
 #include "a3d_common.h"
 
@@ -38,6 +38,9 @@ __device__ __forceinline__ float sk_logit(const SkBone& b, float px, float py, f
     return sqrtf(sx * sx + sy * sy + sz * sz + 1e-6f) * neg_inv_temp;
 }
 
+// KMAX = compile-time bound on K: the K logits of a vertex (a sqrt each) are computed ONCE and stay in registers for the
+// max / sum / blend passes (the first version recomputed them per pass: 3 sqrt chains per bone per vertex).
+template <int KMAX>
 __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restrict__ v, int v_batch, const float* __restrict__ bones,
                                                             int bones_batch, const float* __restrict__ T, int V, int K,
                                                             float neg_inv_temp, float* __restrict__ out, float* __restrict__ weights) {
@@ -50,25 +53,36 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     if (i >= V) return;
     const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + i) * 3;
     const float px = p[0], py = p[1], pz = p[2];
+    float lg[KMAX];
     float m = -INFINITY;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        lg[k] = k < K ? sk_logit(s_bone[k], px, py, pz, neg_inv_temp) : -INFINITY;
+        m = fmaxf(m, lg[k]);
+    }
     float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-    for (int k = 0; k < K; ++k) {
-        float e = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
-        const float* t = s_T + 12 * k;
-        s += e;
-        ox += e * (t[0] * px + t[1] * py + t[2] * pz + t[3]);
-        oy += e * (t[4] * px + t[5] * py + t[6] * pz + t[7]);
-        oz += e * (t[8] * px + t[9] * py + t[10] * pz + t[11]);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            const float e = __expf(lg[k] - m);
+            lg[k] = e;
+            const float* t = s_T + 12 * k;
+            s += e;
+            ox += e * (t[0] * px + t[1] * py + t[2] * pz + t[3]);
+            oy += e * (t[4] * px + t[5] * py + t[6] * pz + t[7]);
+            oz += e * (t[8] * px + t[9] * py + t[10] * pz + t[11]);
+        }
     }
     const float inv = 1.f / s;
     float* o = out + ((long long)b * V + i) * 3;
     o[0] = ox * inv; o[1] = oy * inv; o[2] = oz * inv;
     if (weights) {  // [K, Bw, V]; only images that own distinct weights write
         const int Bw = (v_batch == 1 && bones_batch == 1) ? 1 : (int)gridDim.y;
-        if (b < Bw)
-            for (int k = 0; k < K; ++k)
-                weights[((long long)k * Bw + b) * V + i] = __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m) * inv;
+        if (b < Bw) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) weights[((long long)k * Bw + b) * V + i] = lg[k] * inv;
+        }
     }
 }
 
@@ -110,19 +124,31 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
                 px = vb[3ll * i]; py = vb[3ll * i + 1]; pz = vb[3ll * i + 2];
                 gx = gb[3ll * i]; gy = gb[3ll * i + 1]; gz = gb[3ll * i + 2];
             }
+            float lg[4 * KG];  // the logits (a sqrt each) once, in registers
             float m = -INFINITY;
-            for (int k = 0; k < K; ++k) m = fmaxf(m, sk_logit(s_bone[k], px, py, pz, neg_inv_temp));
+#pragma unroll
+            for (int k = 0; k < 4 * KG; ++k) {
+                lg[k] = k < K ? sk_logit(s_bone[k], px, py, pz, neg_inv_temp) : -INFINITY;
+                m = fmaxf(m, lg[k]);
+            }
             float s = 0.f;
-            for (int k = 0; k < K; ++k) s += __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m);
+#pragma unroll
+            for (int k = 0; k < 4 * KG; ++k) {
+                lg[k] = k < K ? __expf(lg[k] - m) : 0.f;
+                s += lg[k];
+            }
             const float inv = 1.f / s;
             float ox = 0.f, oy = 0.f, oz = 0.f;
-            for (int k = 0; k < K; ++k) {
-                const float w = ok ? __expf(sk_logit(s_bone[k], px, py, pz, neg_inv_temp) - m) * inv : 0.f;
-                s_w[k][threadIdx.x] = w;
-                const float* t = s_T + 12 * k;
-                ox += w * (t[0] * gx + t[4] * gy + t[8] * gz);
-                oy += w * (t[1] * gx + t[5] * gy + t[9] * gz);
-                oz += w * (t[2] * gx + t[6] * gy + t[10] * gz);
+#pragma unroll
+            for (int k = 0; k < 4 * KG; ++k) {
+                if (k < K) {
+                    const float w = ok ? lg[k] * inv : 0.f;
+                    s_w[k][threadIdx.x] = w;
+                    const float* t = s_T + 12 * k;
+                    ox += w * (t[0] * gx + t[4] * gy + t[8] * gz);
+                    oy += w * (t[1] * gx + t[5] * gy + t[9] * gz);
+                    oz += w * (t[2] * gx + t[6] * gy + t[10] * gz);
+                }
             }
             s_x[0][threadIdx.x] = px; s_x[1][threadIdx.x] = py; s_x[2][threadIdx.x] = pz;
             s_x[3][threadIdx.x] = gx; s_x[4][threadIdx.x] = gy; s_x[5][threadIdx.x] = gz;
@@ -163,8 +189,12 @@ extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int
     A3D_CHECK_ARG(v && bones && T && out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
-    hipLaunchKernelGGL(sk_fwd_kernel, dim3(a3d_div_up(V, SK_THREADS), B), dim3(SK_THREADS), 0, (hipStream_t)stream, v, v_batch, bones,
-                       bones_batch, T, V, K, -1.f / temperature, out, weights_or_null);
+    const dim3 grid(a3d_div_up(V, SK_THREADS), B), block(SK_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    const float nit = -1.f / temperature;
+    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
+    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
+    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

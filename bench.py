@@ -55,6 +55,7 @@ def algorithmic_bytes(name, d):
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
         "a3d_gbuffer_fwd": int(d.get("P", 0)) * (8 + 16 + 48),
         "a3d_gbuffer_bwd": int(d.get("P", 0)) * (8 + 16 + 48) + B * V * (36 + 16),
+        "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums

@@ -148,13 +148,23 @@ int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C,
                    int V, int F, int H, int W, float* g_attr_or_null, float* g_rast, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Both topology tables of one triangle list in one entry point (5 launches instead of 9): the vertex -> (corner, face) CSR of
+ * a3d_normals_adjacency (off[V+1], adj[3F], cursor[V] scratch) and the opposite-vertex table opp[F,3] of a3d_aa_topology
+ * (hash = a3d_aa_hash_bytes(F) bytes of scratch).  Same outputs, bit for bit, as the two separate calls.  Once per DMTet call:
+ * replaces the per-call index.repeat / scatter_add_ bookkeeping of /root/reference/model/render/mesh.py:276-304 and the
+ * topology hash nvdiffrast builds inside dr.antialias (render.py:264-267).
+ */
+int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
+                      a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused G-buffer over the covered-pixel list -- replaces the five dr.interpolate calls + face-normal torch ops of
  * render_layer, /root/reference/model/render/render.py:182-209, and in backward also dr.rasterize's gradient.
- * pix[P] = flat indices (b*H + y)*W + x of the covered pixels (int64, ascending); out[P,12] =
+ * pix[P] = flat indices (b*H + y)*W + x of the covered pixels (int64); out[P,12] =
  * [world position | normalised face normal | interpolated vertex normal | interpolated canonical position].
- * Backward (all zeroed by callee): g_vpos[B,V,3], g_vnrm[B,V,3], g_prior[B,V,3] (per image even when the canonical
- * mesh is shared: the caller sums over B; may be null), g_clip[B,V,4] (x, y, w gradients through the barycentrics;
- * may be null).  clip is [B,V,4].
+ * Backward (all zeroed by callee -- one memset when the four buffers are consecutive in one allocation, vpos | vnrm | prior | clip):
+ * g_vpos[B,V,3], g_vnrm[B,V,3], g_prior[B,V,3] (per image even when the canonical mesh is shared: the caller sums over B; may be
+ * null), g_clip[B,V,4] (x, y, w gradients through the barycentrics; may be null).  clip is [B,V,4].
  */
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                     const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream);
@@ -180,7 +190,8 @@ int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, in
  *   a3d_aa_topology : once per mesh topology: opp[F,3] = vertex opposite edge i in the adjacent triangle, -1 on
  *                     a boundary (nvdiffrast's topology hash).  hash = scratch of a3d_aa_hash_bytes(F) bytes.
  *   a3d_aa_analyze  : once per (rast, clip): finds every silhouette crossing between adjacent pixels; work =
- *                     scratch of capacity*16 bytes (capacity = 2*B*H*W is always enough), count[1] zeroed by callee.
+ *                     scratch of capacity*16 bytes (capacity = 2*B*H*W is always enough), count[1] zeroed by callee,
+ *                     screen = scratch of clip_batch*V*2 floats (pixel-space vertex positions).
  *   a3d_aa_fwd      : out = color, then blends across each recorded crossing; any number of colour buffers can
  *                     share one analysis (the reference re-analyses per buffer, render.py:311-315).
  *   a3d_aa_bwd      : g_color[B,H,W,C] and g_clip[clip_batch,V,4] (both fully written / zeroed by callee).
@@ -188,7 +199,7 @@ int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, in
 size_t a3d_aa_hash_bytes(int F);
 int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
 int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
-                   int F, int H, int W, void* work, int capacity, int32_t* count, a3d_stream_t stream);
+                   int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, a3d_stream_t stream);
 int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
                a3d_stream_t stream);
 int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,

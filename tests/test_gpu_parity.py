@@ -451,7 +451,8 @@ def test_full_step_against_oracle_and_grads_finite(dev):
     # posed normals: a near-degenerate vertex (incident face normals nearly cancel) amplifies the 1e-6 skinning difference when
     # normalising -- measured 2.6e-4 on one vertex; the rendered buffers below are the bar that counts
     assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 1e-5 and rep["max_abs_posed_normal_err"] < 2e-3, rep
-    assert rep["max_abs_image_err"] < 1e-4, rep
+    assert rep["max_abs_image_err"] < 1e-4, rep  # renderer on the same posed vertices
+    assert rep["frac_pixels_gt_1e-4_end_to_end"] < 1e-3, rep  # from the oracle's own skinning: a silhouette pixel or two may flip
     assert 0.02 < rep["coverage"] < 0.9, rep
     for name, leaf in [("mvp", scene.mvp), ("campos", scene.campos), ("feat", scene.feat), ("arti", scene.arti)]:
         assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().max()) > 0, name
@@ -491,10 +492,12 @@ def test_full_step_loss_and_gradients_vs_oracle_step(dev):
             close(p.grad, ref["grads"][f"{name}.{pn}"], f"{name}.{pn}")
 
 
-def test_fused_gbuffer_matches_generic_path_and_gradients(dev, mods, ops):
-    """csrc/gbuffer.hip (one kernel, rasteriser backward folded in) against the modular rasterise/interpolate kernels."""
-    B, H, W = 3, 64, 64
-    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=7)
+@pytest.mark.parametrize("res,H,W", [(16, 64, 64), (8, 160, 128), (16, 256, 256)])
+def test_fused_gbuffer_matches_generic_path_and_gradients(res, H, W, dev, mods, ops):
+    """csrc/gbuffer.hip (one kernel forward; gather backward with the rasteriser backward folded in) against the modular
+    rasterise/interpolate kernels.  (8, 160, 128): triangles of hundreds of pixels (long same-triangle runs in the pixel list)."""
+    B = 3
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, res=res, seed=7)
     posed = (verts[None] + 0.05 * seeded((B, *verts.shape), 31, -1, 1)).to(dev)
     tri = faces.to(dev)
     R = mods["render"]
@@ -525,6 +528,36 @@ def test_fused_gbuffer_matches_generic_path_and_gradients(dev, mods, ops):
         scale = float(y.abs().max())
         assert scale > 0, name
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
+    c = run(True)  # run to run: only the order of the float atomics differs
+    for x, y in zip(a[1:], c[1:]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(y.abs().max()))
+    # the product's own pixel list (tile order: neighbouring entries on one triangle are merged before the LDS table) gives the
+    # same gradients as the ad-hoc row-major list
+    v = posed.clone().requires_grad_(True)
+    nrm = ops.vertex_normals(v, tri)
+    clip = ru.xfm_points(v, mvp.to(dev))
+    rast = ops.rasterize(clip, tri, (H, W))
+    pix = ops.covered_pixels(rast)
+    gb = ops.gbuffer(clip, v, nrm, verts[None].to(dev), rast, tri, pix)
+    order = torch.argsort(pix)
+    wgt = seeded((pix.shape[0], 12), 41, -1, 1).to(dev)
+    (gv,) = torch.autograd.grad((gb[order] * wgt).sum(), [v])
+    np.testing.assert_allclose(gv.cpu().numpy(), a[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a[1].abs().max()))
+
+
+def test_mesh_topology_fused_entry_point_equals_the_two_separate_ones(dev, ops):
+    """a3d_mesh_topology against a3d_normals_adjacency + a3d_aa_topology, bit for bit (incl. an empty list and isolated vertices)."""
+    verts, faces = quadruped_mesh(16, 0.3)
+    for tri, V in ((faces, verts.shape[0]), (faces[:37], verts.shape[0] + 5), (faces[:0], 4)):
+        tri32 = tri.to(dev).to(torch.int32).contiguous()
+        a1, t1 = ops.VertexFaceAdjacency(tri32, V), ops.AATopology(tri32, V)
+        a2, t2 = ops.mesh_topology(tri32.clone(), V)
+        F = tri32.shape[0]
+        assert torch.equal(a1.off, a2.off) and torch.equal(a1.adj[: 3 * F], a2.adj[: 3 * F]) and torch.equal(t1.opp, t2.opp)
+    # and the caches hand the fused result to both consumers
+    tri32 = faces.to(dev).to(torch.int32).contiguous()
+    adj = ops.vertex_face_adjacency(tri32, verts.shape[0])
+    assert ops.aa_topology(tri32, verts.shape[0]) is ops._topo_cache.peek(tri32) and adj is ops._adj_cache.peek(tri32)
 
 
 def test_ddp_wrapped_step_single_rank_nccl(dev):
@@ -751,9 +784,10 @@ def test_config1_geometry_path_matches_oracle():
     # d(vertex)/d(sdf) ~ 1/(s_a - s_b)^2 spans orders of magnitude on a noisy field: compare relative to the gradient's scale
     gs, rs = out["grad_sdf"].cpu(), ref["grad_sdf"]
     # (a handful of sliver faces of the noisy field have ill-conditioned normal gradients: fp32 cancellation in the cross product
-    #  differs with operation order -- measured 6 of 1144 entries beyond 1e-6, worst 5.4e-5 against a gradient scale of 8.9e-2)
+    #  differs with operation order, and the order of dm_bwd's float atomics varies from run to run -- measured 6 of 1144 entries
+    #  beyond 1e-6, worst 5.4e-5 ... 1.1e-4 against a gradient scale of 8.9e-2)
     d, scale = (gs - rs).abs(), float(rs.abs().max())
-    assert float(d.max()) <= 1e-3 * scale
+    assert float(d.max()) <= 3e-3 * scale
     assert float((d > 1e-5 * scale).float().mean()) < 0.01 * float((rs != 0).float().mean())
     assert torch.equal(gs != 0, rs != 0)
 

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Kernel bisection on the bench workload's own tensors (GPU box):  python tools/kernel_lab.py gbuffer_bwd 0 1 2 3
+
+For each value of the A3D_EXP knob (read by the C side on every call) the named entry point is enqueued 20 times between two
+HIP events, 5 rounds, best average reported.  Knobs are temporary instrumentation inside the kernels under study.
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def best_us(fn, reps=20, rounds=5):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) * 1e3 / reps)
+    return best
+
+
+def main():
+    what, knobs = sys.argv[1], [int(x) for x in sys.argv[2:]] or [0]
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    ops = importlib.import_module("3danimals_amd.ops")
+    L = importlib.import_module("3danimals_amd._lib")
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+    dev = torch.device("cuda:0")
+    scene = pipeline.SyntheticScene(grid_res=64, batch=16, resolution=(256, 256), device=dev, seed=0, net_width=32, net_layers=3, feat_dim=16,
+                                    embedder_freq=4)
+    scene.step(backward=False)
+    prior, shape = scene.last["prior"], scene.last["shape"]
+    B, V, F, H, W = 16, prior.v_pos.shape[1], prior.t_pos_idx.shape[1], 256, 256
+    tri = prior.t_pos_idx[0]
+    tri32 = ops.tri_int32(tri)
+    clip = ru.xfm_points(shape.v_pos, scene.mvp).detach().contiguous()
+    rast = ops.rasterize(clip, tri, (H, W)).detach()
+    pix = ops.covered_pixels(rast)
+    P = pix.shape[0]
+    nrm = ops.vertex_normals(shape.v_pos.detach(), tri)
+    vpos, pv = shape.v_pos.detach().contiguous(), prior.v_pos.detach().contiguous()
+    print(f"V={V} F={F} P={P}")
+    ptr, stream = L.ptr, L.stream
+    if what == "gbuffer_bwd":
+        g = torch.rand(P, 12, device=dev)
+        flat = torch.empty(B * V * 13, device=dev)
+        n3 = B * V * 3
+        gv, gn, gp, gc = flat[:n3], flat[n3:2 * n3], flat[2 * n3:3 * n3], flat[3 * n3:]
+        fn = lambda: L.call("a3d_gbuffer_bwd", ptr(g), ptr(rast), ptr(tri32), ptr(pix), P, ptr(vpos), ptr(nrm), ptr(pv), 1, ptr(clip), B, V, F, H, W,
+                            ptr(gv), ptr(gn), ptr(gp), ptr(gc), stream())
+    elif what == "rast_fwd":
+        out = torch.empty(B, H, W, 4, device=dev)
+        scratch = torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
+        fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), stream())
+    elif what == "aa_analyze":
+        topo = ops.aa_topology(tri32, V)
+        work = torch.empty(2 * B * H * W, 4, dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        screen = torch.empty(B, V, 2, device=dev)
+        fn = lambda: L.call("a3d_aa_analyze", ptr(rast), ptr(clip), B, ptr(tri32), ptr(topo.opp), B, V, F, H, W, ptr(screen), ptr(work),
+                            2 * B * H * W, ptr(count), stream())
+    else:
+        raise SystemExit("unknown entry point")
+    for k in knobs:
+        os.environ["A3D_EXP"] = str(k)
+        print(f"{what} A3D_EXP={k}: {best_us(fn):8.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -97,14 +97,32 @@ def main():
         oc = ops.antialias(col, rast, clip_g, tri, analysis=an)
         gc = torch.rand_like(oc)
         add(f"a3d_aa_bwd[C{C}]", lambda: torch.autograd.grad(oc, [col, clip_g], gc, retain_graph=True))
-    M = sk.bone_transforms(scene.bones, scene.kinematic_tree, scene.arti.detach())
+    M = sk.bone_transforms_torch(scene.bones, scene.kinematic_tree, scene.arti.detach())
     T = M[:, :, :3, :].reshape(B, 20, 12).contiguous().requires_grad_(True)
     bones = scene.bones.reshape(1, 20, 2, 3)
     add("a3d_skin_fwd", lambda: ops.skin(pv.detach(), bones, T.detach(), 0.05))
     so = ops.skin(pv, bones, T, 0.05)
     gs = torch.rand_like(so)
     add("a3d_skin_bwd", lambda: torch.autograd.grad(so, [pv, T], gs, retain_graph=True))
-    add("torch bone_transforms", lambda: sk.bone_transforms(scene.bones, scene.kinematic_tree, scene.arti.detach()))
+    add("torch bone_transforms", lambda: sk.bone_transforms_torch(scene.bones, scene.kinematic_tree, scene.arti.detach()))
+    chain = sk._chain_index32(scene.kinematic_tree, dev)
+    if chain is not None:
+        ang = scene.arti.detach().reshape(B, 20, 3).clone().requires_grad_(True)
+        add("a3d_bone_transforms_fwd", lambda: ops.bone_transforms(bones.reshape(1, 20, 6), ang.detach(), chain))
+        Mo = ops.bone_transforms(bones.reshape(1, 20, 6), ang, chain)
+        gM = torch.rand_like(Mo)
+        add("a3d_bone_transforms_bwd", lambda: torch.autograd.grad(Mo, ang, gM, retain_graph=True))
+    add("a3d_mesh_topology", lambda: ops.mesh_topology(tri32, V))
+    add("a3d_normals_adjacency", lambda: ops.VertexFaceAdjacency(tri32, V))
+    pix = ops.covered_pixels(rast)
+    dims["P"] = int(pix.shape[0])
+    add("a3d_cover_count+emit", lambda: ops.covered_pixels(rast))
+    nrm = ops.vertex_normals(shape.v_pos.detach(), tri)
+    gin = [t.detach().clone().requires_grad_(True) for t in (clip, shape.v_pos, nrm, prior.v_pos)]
+    add("a3d_gbuffer_fwd", lambda: ops.gbuffer(clip, shape.v_pos.detach(), nrm, prior.v_pos.detach(), rast, tri, pix))
+    gb = ops.gbuffer(*gin, rast, tri, pix)
+    ggb = torch.rand_like(gb)
+    add("a3d_gbuffer_bwd", lambda: torch.autograd.grad(gb, gin, ggb, retain_graph=True))
     print(f"{'op':40s} {'us':>9s} {'alg MB':>9s} {'GB/s':>9s} {'% of 8TB/s':>10s}")
     for name, us, ab in rows:
         if "+" in name:
