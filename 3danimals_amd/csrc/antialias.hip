@@ -7,8 +7,8 @@
 //              Once per mesh topology (= once per DMTet call), shared by every image and colour buffer.
 //   analyze  : pixel-space vertex positions once per (image, vertex); then one thread per (pixel, direction) inspects the
 //              right / lower neighbour; id discontinuities are analysed (3+3 8-byte gathers, no divisions) and the rare
-//              true silhouette crossings are appended to a compact work list
-//              with ONE atomicAdd per wave (ballot + mbcnt).  Once per (rast, clip): the reference repeats this
+//              true silhouette crossings are appended to a work list of AA_SHARDS segments
+//              with ONE atomicAdd per wave (ballot + mbcnt) on the segment's own counter.  Once per (rast, clip): the reference repeats this
 //              for every colour buffer it antialiases (render.py:311-315).
 //   fwd/bwd  : out = color (+) blends over the work list; backward adds colour gradients and sends
 //              d(alpha)/d(clip) to the two vertices of the crossing edge.
@@ -16,6 +16,8 @@
 // 16-byte records per image.  Compiled with -ffp-contract=off so sign tests agree with the oracle.
 #include "a3d_common.h"
 #include "topo_common.h"
+
+#define AA_SHARDS 64  // segments of the crossing work list (wave size: one wave scans their fill counts)
 
 struct AaRec {
     int pix0;     // flat index (b*H + y)*W + x of the pair's first pixel
@@ -134,27 +136,59 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
             }
         }
     }
-    // wave-aggregated append
+    // wave-aggregated append into one of AA_SHARDS segments of the work list: a single append counter serialises every wave of the
+    // launch on one address (~12 ns per returning atomic: 31 of this kernel's 46 us on the bench workload)
     const unsigned long long m = __ballot(emit);
     if (m) {
+        const int shard = (int)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (AA_SHARDS - 1));
+        const int seg_cap = capacity / AA_SHARDS;
         int basei = 0;
         const int leader = __ffsll((long long)m) - 1;
-        if (a3d_lane_id() == leader) basei = atomicAdd(count, __popcll(m));
+        if (a3d_lane_id() == leader) basei = atomicAdd(count + shard, __popcll(m));
         basei = __shfl(basei, leader);
         if (emit) {
             const int slot = basei + a3d_wave_prefix(m);
-            if (slot < capacity) work[slot] = rec;
+            if (slot < seg_cap) work[(long long)shard * seg_cap + slot] = rec;
         }
     }
 }
 
+// consumers: exclusive prefix of the segment fills into LDS (call with all threads of the block), then record r -> its slot
+__device__ __forceinline__ int aa_segment_offsets(const int* __restrict__ count, int capacity, int* s_off) {
+    const int seg_cap = capacity / AA_SHARDS;
+    if (threadIdx.x < AA_SHARDS) {
+        const int c = min(count[threadIdx.x], seg_cap);
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < AA_SHARDS; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += o;
+        }
+        s_off[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    return s_off[AA_SHARDS];
+}
+
+__device__ __forceinline__ long long aa_record_slot(int r, const int* s_off, int capacity) {
+    int lo = 0, hi = AA_SHARDS;  // largest seg with s_off[seg] <= r
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    return (long long)lo * (capacity / AA_SHARDS) + (r - s_off[lo]);
+}
+
 __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, int C, const AaRec* __restrict__ work,
                                                      const int* __restrict__ count, int capacity, int W, float* __restrict__ out) {
-    const int n = min(*count, capacity);
+    __shared__ int s_off[AA_SHARDS + 1];
+    const int n = aa_segment_offsets(count, capacity, s_off);
     const long long total = (long long)n * C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / C), c = (int)(idx - (long long)r * C);
-        const AaRec rec = work[r];
+        const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
         const long long p0 = rec.pix0, p1 = p0 + ((rec.flags & 1) ? W : 1);
         const long long dst = rec.alpha > 0.f ? p0 : p1;
         atomicAdd(out + dst * C + c, rec.alpha * (color[p1 * C + c] - color[p0 * C + c]));
@@ -165,10 +199,11 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
                                                      const AaRec* __restrict__ work, const int* __restrict__ count, int capacity,
                                                      const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
                                                      int H, int W, float* __restrict__ g_color, float* __restrict__ g_clip) {
-    const int n = min(*count, capacity);
+    __shared__ int s_off[AA_SHARDS + 1];
+    const int n = aa_segment_offsets(count, capacity, s_off);
     const float xh = 0.5f * W, yh = 0.5f * H;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const AaRec rec = work[r];
+        const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
         const int d = rec.flags & 1, di = (rec.flags >> 1) & 3;
         const bool use1 = rec.flags & 8, clamped = rec.flags & 16;
         const long long p0 = rec.pix0, p1 = p0 + (d ? W : 1);
@@ -214,6 +249,8 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
     }
 }
 
+extern "C" int a3d_aa_shards(void) { return AA_SHARDS; }
+
 extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * 16; }
 
 extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream) {
@@ -239,7 +276,8 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
     hipStream_t s = (hipStream_t)stream;
-    A3D_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    A3D_CHECK_ARG(capacity >= AA_SHARDS);
+    A3D_HIP(hipMemsetAsync(count, 0, sizeof(int) * AA_SHARDS, s));
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri && opp);
     const long long nvert = (long long)clip_batch * V;

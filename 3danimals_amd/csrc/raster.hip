@@ -9,8 +9,7 @@
 //             conservative pixel box, then the box's pixels are shared out over the 4 lanes; every covered pixel
 //             does atomicMin(keys[pixel], order(z/w) << 32 | id).  min over (depth, id) is order independent, so
 //             the image is deterministic with no sorting or binning, and the work is balanced over all 256 CUs
-//             no matter where on screen the object is.  A plain (possibly stale, hence only ever too large) read
-//             of the key skips atomics that cannot win.  Boxes above 64 px are found with a ballot and
+//             no matter where on screen the object is.  Boxes above 64 px are found with a ballot and
 //             rasterised cooperatively by the whole wave.
 //   resolve : 1 thread per pixel: key -> winner's barycentrics recomputed -> float4 texel, fully coalesced.
 //
@@ -87,8 +86,9 @@ __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, 
     if (fr.hit) {
         const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | f;
         unsigned long long* slot = keys + (long long)py * W + px;
-        // keys only ever decrease, so a stale read is an upper bound: skipping when we cannot beat it is safe
-        if (key < *(volatile unsigned long long*)slot) atomicMin(slot, key);
+        // fire and forget.  (Reading the key first to skip atomics that cannot win looked like a saving and measured as a loss: the
+        // dependent 8-byte read costs more than the ~50 % of atomics it removes -- 42.7 us with the filter, 33.0 us without.)
+        atomicMin(slot, key);
     }
 }
 

@@ -551,10 +551,11 @@ class AAAnalysis:
         self.rast, self.clip, self.topo = f32c(rast.detach()), f32c(clip.detach()), topo
         B, H, W = rast.shape[:3]
         self.B, self.H, self.W = B, H, W
-        self.capacity = 2 * B * H * W
+        shards = _lib.lib().a3d_aa_shards()  # the work list is kept in segments, each with its own append counter
+        self.capacity = -(-2 * B * H * W // shards) * shards
         dev = rast.device
         self.work = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
-        self.count = torch.empty((1,), dtype=torch.int32, device=dev)
+        self.count = torch.empty((shards,), dtype=torch.int32, device=dev)
         screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
         call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), B, self.clip.shape[1],
              topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), stream())

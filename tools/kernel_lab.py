@@ -65,7 +65,7 @@ def main():
     elif what == "aa_analyze":
         topo = ops.aa_topology(tri32, V)
         work = torch.empty(2 * B * H * W, 4, dtype=torch.int32, device=dev)
-        count = torch.empty(1, dtype=torch.int32, device=dev)
+        count = torch.empty(L.lib().a3d_aa_shards(), dtype=torch.int32, device=dev)
         screen = torch.empty(B, V, 2, device=dev)
         fn = lambda: L.call("a3d_aa_analyze", ptr(rast), ptr(clip), B, ptr(tri32), ptr(topo.opp), B, V, F, H, W, ptr(screen), ptr(work),
                             2 * B * H * W, ptr(count), stream())

@@ -90,7 +90,7 @@ def main():
     add("a3d_aa_topology", lambda: ops.AATopology(tri32, V))
     add("a3d_aa_analyze", lambda: ops.AAAnalysis(rast, clip, topo))
     an = ops.AAAnalysis(rast, clip, topo)
-    print("aa records:", int(an.count.item()))
+    print("aa records:", int(an.count.sum().item()))
     for C in (4, 17):
         col = torch.rand(B, H, W, C, device=dev, requires_grad=True)
         add(f"a3d_aa_fwd[C{C}]", lambda: ops.antialias(col.detach(), rast, clip, tri, analysis=an))
