@@ -52,6 +52,7 @@ SIGNATURES = {
     "a3d_rows_add_relu_bwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p, _p]),
     "a3d_aa_hash_bytes": (_c_size_t, [_c_int]),
     "a3d_aa_shards": (_c_int, []),
+    "a3d_aa_capacity": (_c_int, [_c_int, _c_int, _c_int]),
     "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
     "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),

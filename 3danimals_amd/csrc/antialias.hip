@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
     // launch on one address (~12 ns per returning atomic: 31 of this kernel's 46 us on the bench workload)
     const unsigned long long m = __ballot(emit);
     if (m) {
-        const int shard = (int)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (AA_SHARDS - 1));
+        // work-group L of the launch appends to segment L % AA_SHARDS; a segment holds 256 records for each of its work-groups
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int shard = (int)(lin & (AA_SHARDS - 1));
         const int seg_cap = capacity / AA_SHARDS;
         int basei = 0;
         const int leader = __ffsll((long long)m) - 1;
@@ -251,6 +253,13 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
 
 extern "C" int a3d_aa_shards(void) { return AA_SHARDS; }
 
+// records the work list must hold for a [B,H,W] frame: AA_SHARDS segments of 256 records per analysis work-group mapped to them
+extern "C" int a3d_aa_capacity(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return AA_SHARDS;
+    const long long groups = 2ll * B * a3d_div_up((long long)H * W, 256);
+    return (int)(a3d_div_up(groups, AA_SHARDS) * 256 * AA_SHARDS);
+}
+
 extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * 16; }
 
 extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream) {
@@ -276,7 +285,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
     hipStream_t s = (hipStream_t)stream;
-    A3D_CHECK_ARG(capacity >= AA_SHARDS);
+    A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W));
     A3D_HIP(hipMemsetAsync(count, 0, sizeof(int) * AA_SHARDS, s));
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri && opp);

@@ -552,7 +552,7 @@ class AAAnalysis:
         B, H, W = rast.shape[:3]
         self.B, self.H, self.W = B, H, W
         shards = _lib.lib().a3d_aa_shards()  # the work list is kept in segments, each with its own append counter
-        self.capacity = -(-2 * B * H * W // shards) * shards
+        self.capacity = _lib.lib().a3d_aa_capacity(B, H, W)
         dev = rast.device
         self.work = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
         self.count = torch.empty((shards,), dtype=torch.int32, device=dev)

@@ -190,8 +190,8 @@ int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, in
  *   a3d_aa_topology : once per mesh topology: opp[F,3] = vertex opposite edge i in the adjacent triangle, -1 on
  *                     a boundary (nvdiffrast's topology hash).  hash = scratch of a3d_aa_hash_bytes(F) bytes.
  *   a3d_aa_analyze  : once per (rast, clip): finds every silhouette crossing between adjacent pixels; work =
- *                     scratch of capacity*16 bytes (capacity = 2*B*H*W rounded up to a multiple of a3d_aa_shards() is always
- *                     enough: the list is kept in that many segments), count[a3d_aa_shards()] zeroed by callee,
+ *                     scratch of capacity*16 bytes with capacity >= a3d_aa_capacity(B, H, W) (the list is kept in
+ *                     a3d_aa_shards() segments, each with its own append counter), count[a3d_aa_shards()] zeroed by callee,
  *                     screen = scratch of clip_batch*V*2 floats (pixel-space vertex positions).
  *   a3d_aa_fwd      : out = color, then blends across each recorded crossing; any number of colour buffers can
  *                     share one analysis (the reference re-analyses per buffer, render.py:311-315).
@@ -199,6 +199,7 @@ int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, in
  */
 size_t a3d_aa_hash_bytes(int F);
 int a3d_aa_shards(void);
+int a3d_aa_capacity(int B, int H, int W);
 int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
 int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
                    int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, a3d_stream_t stream);

@@ -451,8 +451,8 @@ def test_full_step_against_oracle_and_grads_finite(dev):
     # posed normals: a near-degenerate vertex (incident face normals nearly cancel) amplifies the 1e-6 skinning difference when
     # normalising -- measured 2.6e-4 on one vertex; the rendered buffers below are the bar that counts
     assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 1e-5 and rep["max_abs_posed_normal_err"] < 2e-3, rep
-    assert rep["max_abs_image_err"] < 1e-4, rep  # renderer on the same posed vertices
-    assert rep["frac_pixels_gt_1e-4_end_to_end"] < 1e-3, rep  # from the oracle's own skinning: a silhouette pixel or two may flip
+    assert rep["max_abs_image_err"] < 1e-4, rep  # renderer on the same posed vertices, outside pixels whose owner flipped
+    assert rep["frac_pixels_owner_flip"] < 1e-3 and rep["frac_pixels_gt_1e-4_end_to_end"] < 2e-3, rep  # a silhouette pixel or two
     assert 0.02 < rep["coverage"] < 0.9, rep
     for name, leaf in [("mvp", scene.mvp), ("campos", scene.campos), ("feat", scene.feat), ("arti", scene.arti)]:
         assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().max()) > 0, name

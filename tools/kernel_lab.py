@@ -64,11 +64,12 @@ def main():
         fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), stream())
     elif what == "aa_analyze":
         topo = ops.aa_topology(tri32, V)
-        work = torch.empty(2 * B * H * W, 4, dtype=torch.int32, device=dev)
+        cap = L.lib().a3d_aa_capacity(B, H, W)
+        work = torch.empty(cap, 4, dtype=torch.int32, device=dev)
         count = torch.empty(L.lib().a3d_aa_shards(), dtype=torch.int32, device=dev)
         screen = torch.empty(B, V, 2, device=dev)
         fn = lambda: L.call("a3d_aa_analyze", ptr(rast), ptr(clip), B, ptr(tri32), ptr(topo.opp), B, V, F, H, W, ptr(screen), ptr(work),
-                            2 * B * H * W, ptr(count), stream())
+                            cap, ptr(count), stream())
     else:
         raise SystemExit("unknown entry point")
     for k in knobs:
