@@ -25,6 +25,19 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# When True every class below evaluates exactly the way the reference's model/networks classes do -- per-point feature
+# concatenation (MLPs.py:84-90), one plain Linear per layer, the frequency table copied host -> device in every forward
+# (HarmonicEmbedding.py:41), no HIP input stage, no split-K, no fused ReLU epilogues, no per-image feature path: what a maintainer
+# gets who overlays only model/geometry + model/render and keeps the reference's own networks.  bench.py --networks reference.
+REFERENCE_FORMULATION = False
+
+
+def reference_formulation(enable=True):
+    global REFERENCE_FORMULATION
+    REFERENCE_FORMULATION = bool(enable)
+    return REFERENCE_FORMULATION
+
+
 def _activation(name):
     table = {"tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "relu": nn.ReLU}
     if name not in table:
@@ -49,7 +62,8 @@ class HarmonicEmbedding(nn.Module):
         return f
 
     def forward(self, x):
-        ang = (x[..., None] * self._frequencies(x.device)).reshape(*x.shape[:-1], -1)
+        freq = self.frequencies.to(x.device) if REFERENCE_FORMULATION else self._frequencies(x.device)
+        ang = (x[..., None] * freq).reshape(*x.shape[:-1], -1)
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 
@@ -217,6 +231,8 @@ class MLP(nn.Module):
     def forward(self, x, first_weight=None, per_image=None, index=None):
         """Plain stack; or, with ``first_weight`` [nf,K], ``per_image`` [B,nf] and ``index`` [P] (CoordMLP's per-image feature
         path), the first Linear is evaluated as x @ first_weight^T + per_image[index], the addend folded into the ReLU pass."""
+        if REFERENCE_FORMULATION and first_weight is None:
+            return self.network(x)
         layers = list(self.network)
         i = 0
         if first_weight is not None:
@@ -266,7 +282,9 @@ class CoordMLP(nn.Module):
         self.bsdf = None
         self.in_layer_relu = in_layer_relu
 
-    indexed_feat = True  # sample(x, feat=[B,C], feat_index=[P]) is understood
+    @property
+    def indexed_feat(self):  # sample(x, feat=[B,C], feat_index=[P]) is understood (not in the reference formulation)
+        return not REFERENCE_FORMULATION
 
     def forward(self, x, feat=None, feat_index=None):
         """``feat_index`` (int64 [P], optional, not in the reference signature): ``feat`` is then one row per IMAGE and point p uses
@@ -275,6 +293,8 @@ class CoordMLP(nn.Module):
         the feature half becomes a [B,C] x [C,nf] GEMM and a row gather instead of a [P,C] x [C,nf] GEMM over 2e5 points
         (and its two backward GEMMs), and the [P, nf+C] concatenation disappears.  Same sum, equal to fp32 rounding."""
         assert (feat is None and self.extra_feat_dim == 0) or (feat.shape[-1] == self.extra_feat_dim)
+        if REFERENCE_FORMULATION:
+            return self._forward_reference(x, feat if feat_index is None or feat is None else feat[feat_index])
         if feat_index is not None and feat is not None and x.dim() == 2 and isinstance(self.mlp.network[0], nn.Linear) \
                 and self.mlp.network[0].bias is None:
             return self._forward_indexed(x, feat, feat_index)
@@ -304,6 +324,28 @@ class CoordMLP(nn.Module):
                 feat = feat.unsqueeze(1)
             h = torch.cat([h, feat.expand(*h.shape[:-1], -1)], dim=-1)
             out = self.mlp(self.relu(h))
+        if self.min_max is not None:
+            out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+        return out
+
+    def _forward_reference(self, x, feat):
+        """The reference's own evaluation order (MLPs.py:73-98)."""
+        if self.symmetrize:
+            xs, ys, zs = x.unbind(-1)
+            x = torch.stack([xs.abs(), ys, zs], -1)
+        x_in = x
+        if self.embedder is not None:
+            x_in = self.embedder(x)
+            if self.embed_concat_pts:
+                x_in = torch.cat([x, x_in], -1)
+        x_in = self.in_layer(x_in)
+        if self.in_layer_relu:
+            x_in = self.relu(x_in)
+        if feat is not None:
+            for _ in range(x_in.dim() - feat.dim()):
+                feat = feat.unsqueeze(1)
+            x_in = torch.cat([x_in, feat.expand(*x_in.shape[:-1], -1)], dim=-1)
+        out = self.mlp(self.relu(x_in))
         if self.min_max is not None:
             out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
         return out
@@ -383,3 +425,94 @@ class CoordMLP(nn.Module):
 
     def sample(self, x, feat=None, feat_index=None):
         return self.forward(x, feat, feat_index)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Weight-modulated field of the pan-category model (Fauna): same classes and state_dict layout as the reference's
+# CoordMLP_Mod / MLP_Mod / Linear_Mod (networks/MLPs.py:104-247).  One 128-d embedding per batch modulates and demodulates every
+# layer's weight (StyleGAN2 style); plain torch.
+class Linear_Mod(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty((out_features, in_features)))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / fan_in ** 0.5 if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, style):
+        if style.dim() > 1:  # one style per batch: the first row (MLPs.py:233-235)
+            style = style.reshape(-1, style.shape[-1])[0]
+        weight = self.weight * style.unsqueeze(0)
+        weight = weight / ((weight * weight).sum(dim=-1, keepdim=True) + 1e-5).sqrt()
+        return F.linear(x, weight, self.bias)
+
+
+class MLP_Mod(nn.Module):
+    def __init__(self, cin, cout, num_layers, nf=256, dropout=0, activation=None):
+        super().__init__()
+        assert num_layers >= 1
+        self.num_layers = num_layers
+        if num_layers == 1:
+            self.network = Linear_Mod(cin, cout, bias=False)
+        else:
+            self.relu = nn.ReLU(inplace=True)
+            for i in range(num_layers):
+                setattr(self, f"linear_{i}", Linear_Mod(cin if i == 0 else nf, cout if i == num_layers - 1 else nf, bias=False))
+
+    def forward(self, x, style):
+        if self.num_layers == 1:
+            return self.network(x, style)
+        for i in range(self.num_layers):
+            x = getattr(self, f"linear_{i}")(x, style)
+            if i < self.num_layers - 1:
+                x = self.relu(x)
+        return x
+
+
+class CoordMLP_Mod(nn.Module):
+    def __init__(self, cin, cout, num_layers, nf=256, dropout=0, activation=None, min_max=None, n_harmonic_functions=10, embedder_scalar=1,
+                 embed_concat_pts=True, extra_feat_dim=0, symmetrize=False, condition_dim=128):
+        super().__init__()
+        self.extra_feat_dim, self.condition_dim = extra_feat_dim, condition_dim
+        if n_harmonic_functions > 0:
+            self.embedder = HarmonicEmbedding(n_harmonic_functions, embedder_scalar)
+            dim_in = cin * 2 * n_harmonic_functions + (cin if embed_concat_pts else 0)
+            self.embed_concat_pts = embed_concat_pts
+        else:
+            self.embedder = None
+            dim_in = cin
+        self.in_layer = nn.Linear(dim_in, nf)
+        self.relu = nn.ReLU(inplace=True)
+        self.mlp = MLP_Mod(nf, cout, num_layers, nf, dropout, activation)
+        self.style_mlp = MLP(condition_dim, nf, 2, nf, dropout, None)
+        self.symmetrize = symmetrize
+        if min_max is not None:
+            self.register_buffer("min_max", min_max)
+        else:
+            self.min_max = None
+        self.bsdf = None
+
+    def forward(self, x, feat=None):
+        assert feat is not None and feat.shape[-1] == self.condition_dim
+        if self.symmetrize:
+            x = torch.cat([x[..., :1].abs(), x[..., 1:]], -1)
+        x_in = x
+        if self.embedder is not None:
+            x_in = self.embedder(x)
+            if self.embed_concat_pts:
+                x_in = torch.cat([x, x_in], -1)
+        x_in = self.relu(self.in_layer(x_in))
+        out = self.mlp(x_in, self.style_mlp(feat))
+        if self.min_max is not None:
+            out = out * (self.min_max[:, 1] - self.min_max[:, 0]) + self.min_max[:, 0]
+        return out
+
+    def sample(self, x, feat=None):
+        return self.forward(x, feat)

@@ -22,10 +22,12 @@ from ..render import mesh
 
 try:  # overlaid on the reference tree: use its (unchanged) networks
     from model.networks import CoordMLP, CoordMLP_Mod  # type: ignore
-except Exception:  # stand-alone
-    from ...hostnets import CoordMLP
 
-    CoordMLP_Mod = None
+    NETWORKS = "model.networks (reference tree)"
+except ImportError:  # stand-alone: same classes / state_dict layout from hostnets (any other error in the overlay must surface)
+    from ...hostnets import CoordMLP, CoordMLP_Mod
+
+    NETWORKS = "3danimals_amd.hostnets (stand-alone)"
 
 
 SURFACE_BUCKET = 1024  # row padding of the surface-adjacent SDF re-evaluation (0 = off)
@@ -78,6 +80,28 @@ class DMTet:
         if self._topo_key != key:
             self._topo, self._topo_key, self._tets_ref = TetGridTopology(tet_fx4), key, tet_fx4
         return self._topo
+
+    def sort_edges(self, edges_ex2):
+        """(min, max) order per edge (reference dmtet.py:59-67; kept for API parity -- the HIP path never needs it)."""
+        with torch.no_grad():
+            order = (edges_ex2[:, 0] > edges_ex2[:, 1]).long().unsqueeze(dim=1)
+            a = torch.gather(input=edges_ex2, index=order, dim=1)
+            b = torch.gather(input=edges_ex2, index=1 - order, dim=1)
+        return torch.stack([a, b], -1)
+
+    def map_uv(self, faces, face_gidx, max_idx):
+        """(uvs, uv_idx) of the reference's per-tet texture atlas (dmtet.py:69-98): an N x N grid of quads, N = ceil(sqrt((max_idx+1)//2)),
+        tet t owns quad t, its first / second triangle use corners (0,1,2) / (0,2,3).  Kept for API parity: __call__ takes the same
+        values from the per-grid cache (TetGridTopology.uvs) and from the emit kernel."""
+        n = int(np.ceil(np.sqrt((max_idx + 1) // 2)))
+        lin = torch.linspace(0, 1 - (1 / n), n, dtype=torch.float32, device=faces.device)
+        ty, tx = torch.meshgrid(lin, lin, indexing="ij")
+        pad = 0.9 / n
+        uvs = torch.stack([tx, ty, tx + pad, ty, tx + pad, ty + pad, tx, ty + pad], dim=-1).view(-1, 2)
+        quad = torch.div(face_gidx, 2, rounding_mode="trunc")
+        second = face_gidx % 2
+        uv_idx = torch.stack((quad * 4, quad * 4 + second + 1, quad * 4 + second + 2), dim=-1).view(-1, 3)
+        return uvs, uv_idx
 
     def __call__(self, pos_nx3, sdf_n, tet_fx4, topology: TetGridTopology = None):
         topo = topology if topology is not None else self.topology(tet_fx4)
@@ -141,9 +165,7 @@ class DMTetGeometry(torch.nn.Module):
         embedder_scalar = 2 * np.pi / self.grid_scale * 0.9  # (-0.5 s, 0.5 s) -> (-pi, pi) * 0.9  (dmtet.py:186)
         common = dict(dropout=0, activation=None, min_max=None, n_harmonic_functions=embedder_freq, embedder_scalar=embedder_scalar,
                       embed_concat_pts=embed_concat_pts)
-        if condition_choice == "mod":
-            if CoordMLP_Mod is None:
-                raise NotImplementedError("CoordMLP_Mod lives in the reference's model/networks; overlay on the reference tree to use it")
+        if condition_choice == "mod":  # pan-category model: SDF conditioned on the batch's class embedding (dmtet.py:187-189)
             self.mlp = CoordMLP_Mod(3, 1, num_layers, nf=hidden_size, condition_dim=128, **common)
         else:
             self.mlp = CoordMLP(3, 1, num_layers, nf=hidden_size, **common)
@@ -183,7 +205,9 @@ class DMTetGeometry(torch.nn.Module):
         if self.symmetrize:
             pts = torch.cat([pts[..., :1].abs(), pts[..., 1:]], -1)
         if feats is not None:
-            feats = feats.unsqueeze(0).repeat(pts.shape[0], 1)
+            # the reference repeats the embedding for every point (dmtet.py:231-233); the weight-modulated field only ever reads the
+            # first row (Linear_Mod, MLPs.py:233-235), so one row gives the same values without a [Nv,128] x [128,256] style GEMM
+            feats = feats.unsqueeze(0) if hasattr(self.mlp, "style_mlp") else feats.unsqueeze(0).repeat(pts.shape[0], 1)
         sdf = self.mlp(pts, feat=feats)
         if self.init_sdf is None:
             pass
@@ -204,16 +228,32 @@ class DMTetGeometry(torch.nn.Module):
         mv = self.mesh_verts.detach() + (torch.rand_like(self.mesh_verts) - 0.5) * 0.1 * self.grid_scale
         mv = mv[torch.randperm(len(mv), device=mv.device)[:5000]]
         pts = torch.cat([pts, mv], 0)
-        if (GRAPH_SDF_GRADIENT and feats is None and pts.is_cuda and torch.is_grad_enabled()
+        if (GRAPH_SDF_GRADIENT and feats is None and pts.is_cuda and torch.is_grad_enabled() and self._graph_safe(pts.shape[0])
                 and ((pts.shape[0], pts.device) in self._sdf_gradient_graphs or _single_process())
                 and any(p.requires_grad for p in self.mlp.parameters())):
-            return self._graphed_sdf_gradient(pts)
+            try:
+                return self._graphed_sdf_gradient(pts)
+            except RuntimeError as err:  # capture refused (e.g. a field that synchronises inside forward): eager from now on
+                warnings.warn(f"SDF-gradient graph capture failed ({err}); using the eager path")
+                self._graph_capture_failed = True
         pts = pts.requires_grad_(True)
         y = self.get_sdf(pts=pts, feats=feats)
         try:
             return torch.autograd.grad([y], pts, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True, only_inputs=True)[0]
         except RuntimeError:  # validation runs under no_grad
             return torch.zeros_like(pts)
+
+    def _graph_safe(self, num_points):
+        """Replay from HIP graphs only where that is safe and pays: a field whose embedding keeps its frequency table on the device
+        (the reference's HarmonicEmbedding copies it host -> device inside every forward, HarmonicEmbedding.py:41 -- a blocking
+        copy that cannot be captured), the full-size sample (5000 + 5000 points: a surface with fewer vertices changes the count
+        from step to step, and every new count would re-capture and pin another graph memory pool), no earlier capture failure."""
+        from ... import hostnets
+
+        embedder = getattr(self.mlp, "embedder", None)
+        known = any(k[0] == num_points for k in self._sdf_gradient_graphs)  # captured up front by capture_sdf_gradient_graph()
+        return (not getattr(self, "_graph_capture_failed", False) and not hostnets.REFERENCE_FORMULATION and (num_points == 10000 or known)
+                and (embedder is None or hasattr(embedder, "_frequencies")))
 
     def capture_sdf_gradient_graph(self, num_points=None):
         """Capture the regulariser's HIP graphs now (e.g. before torch.distributed is initialised: a multi-process run only replays
@@ -222,7 +262,8 @@ class DMTetGeometry(torch.nn.Module):
         if num_points is None:
             mv = getattr(self, "mesh_verts", None)
             num_points = 5000 + (min(5000, len(mv)) if mv is not None else 5000)
-        if GRAPH_SDF_GRADIENT and self.verts.is_cuda and any(p.requires_grad for p in self.mlp.parameters()):
+        if (GRAPH_SDF_GRADIENT and self.verts.is_cuda and self._graph_safe(10000) and any(p.requires_grad for p in self.mlp.parameters())
+                and not hasattr(self.mlp, "style_mlp")):  # (an explicit capture may ask for any point count; the conditioned field runs eagerly)
             with torch.enable_grad():
                 self._graphed_sdf_gradient((torch.rand(num_points, 3, device=self.verts.device) - 0.5) * self.grid_scale)
 
@@ -240,6 +281,8 @@ class DMTetGeometry(torch.nn.Module):
         graphed = self._sdf_gradient_graphs.get(key)
         if graphed is None:
             sample = (pts.detach().clone(),) + tuple(p.detach().clone().requires_grad_(p.requires_grad) for p in params)
+            while len(self._sdf_gradient_graphs) >= 2:  # bounded: each entry pins a private graph memory pool
+                self._sdf_gradient_graphs.pop(next(iter(self._sdf_gradient_graphs)))
             graphed = self._sdf_gradient_graphs[key] = torch.cuda.make_graphed_callables(_sdf_gradient_callable(self, names), sample,
                                                                                           allow_unused_input=True)
         return graphed(pts.detach(), *params)

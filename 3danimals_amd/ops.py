@@ -271,7 +271,7 @@ class _Normals(torch.autograd.Function):
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         acc = torch.empty_like(v)
         nrm = torch.empty_like(v)
-        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), stream())
+        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), stream(), tag=f"[B{B}]")
         ctx.save_for_backward(v, acc, tri32)
         ctx.adjacency = adjacency
         return nrm
@@ -283,7 +283,7 @@ class _Normals(torch.autograd.Function):
         scratch = torch.empty_like(v)
         g_v = torch.empty_like(v)
         call("a3d_normals_bwd", ptr(f32c(g_nrm)), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-             ptr(scratch), ptr(g_v), stream())
+             ptr(scratch), ptr(g_v), stream(), tag=f"[B{B}]")
         return g_v, None, None
 
 

@@ -78,23 +78,46 @@ def synthetic_quadruped_device(pts, leg_radius):
 
 FUSED_LOSSES = True  # reconstruction losses as one HIP kernel each way (csrc/losses.hip) instead of ~45 torch launches
 
+WORKLOADS = ("magicpony", "fauna", "ponymation")
+REG_WEIGHTS = dict(arti_reg=0.1, deform_reg=10.0, prior_normal_reg=0.0, mask_random=0.1, flow=1.0)  # magicpony.yaml:136-140; fauna / ponymation
+
 
 class SyntheticScene(torch.nn.Module):
+    """One training iteration of the hot path on synthetic inputs.  ``workload`` selects what surrounds it:
+
+    magicpony  -- train_magicpony_horse, BASELINE configs[2]: one category-level SDF, bones once per epoch, one render per iteration.
+                  ``deform=True`` adds the instance deformation of the post-90k regime (InstancePredictorBase.py:306-313: a coordinate
+                  MLP on the prior vertices -> Mesh.deform -> a THIRD make_mesh per iteration over the B deformed meshes) and the
+                  articulation / deformation regularisers (AnimalModel.py:309-328).
+    fauna      -- train_fauna per rank, configs[3]: the SDF is a weight-modulated field conditioned on the batch's 128-d class
+                  embedding (CoordMLP_Mod, dmtet.py:187-189), bones and kinematic chain are re-estimated EVERY iteration with
+                  bone_y_threshold 0.4 (InstancePredictorFauna.py:79-100), and a second, texture-less one-sided render of the posed
+                  meshes from random azimuths feeds the mask discriminator (Fauna.py:111-173; the discriminator itself is
+                  model/networks and is replaced by a fixed quadratic on the mask).
+    ponymation -- train_ponymation stage 2 with rendering, configs[4]: B sequences x ``num_frames`` frames, [B,F] skinning of the shared
+                  prior, B*F meshes and frames rendered with the 'flow' mode next to 'shaded' / 'dino_pred' (render.py:281-288), flow
+                  loss between consecutive frames (AnimalModel.py:285-298).
+    """
+
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
-                 embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None):
+                 embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None,
+                 workload="magicpony", num_frames=1, deform=False):
         """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
         data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter."""
         super().__init__()
+        assert workload in WORKLOADS, workload
+        assert num_frames == 1 or workload == "ponymation"
         data_seed = seed if data_seed is None else data_seed
+        self.workload, self.num_frames, self.deform = workload, int(num_frames), bool(deform)
         self.batch, self.resolution, self.temperature = batch, tuple(resolution), temperature
         self.last = {}
         dev = torch.device(device)
         self.dev = dev
         torch.manual_seed(seed)
-        layers = dict(sdf=5, texture=8, dino=5, light=5)
+        layers = dict(sdf=5, texture=8, dino=5, light=5, deform=5)
         if net_layers is not None:
             layers = {k: net_layers for k in layers}
-        freq = dict(sdf=8, texture=10, dino=8)
+        freq = dict(sdf=8, texture=10, dino=8, deform=10)
         if embedder_freq is not None:
             freq = {k: embedder_freq for k in freq}
         if leg_radius is None:  # keep the legs a few cells thick on coarse grids
@@ -102,60 +125,105 @@ class SyntheticScene(torch.nn.Module):
         scalar = 2 * math.pi / spatial_scale * 0.9
         grid = tetgrid.kuhn_grid(grid_res)
         self.netShape = _SyntheticGeometry(grid_res, spatial_scale, num_layers=layers["sdf"], hidden_size=net_width, embedder_freq=freq["sdf"],
-                                           jitter_grid=jitter_grid, symmetrize=True, device=dev, tet_grid=grid, leg_radius=leg_radius)
+                                           jitter_grid=jitter_grid, symmetrize=True, device=dev, tet_grid=grid, leg_radius=leg_radius,
+                                           condition_choice="mod" if workload == "fauna" else None)
         self.netTexture = hostnets.CoordMLP(3, 9, layers["texture"], nf=net_width, activation="sigmoid", min_max=torch.tensor([[0.0, 1.0]] * 9),
                                             n_harmonic_functions=freq["texture"], embedder_scalar=scalar, extra_feat_dim=feat_dim, symmetrize=True)
         self.netDINO = hostnets.CoordMLP(3, 16, layers["dino"], nf=net_width, activation="sigmoid", min_max=torch.tensor([[0.0, 1.0]] * 16),
                                          n_harmonic_functions=freq["dino"], embedder_scalar=scalar)
         self.netLight = light_mod.DirectionalLight(feat_dim, layers["light"], net_width, intensity_min_max=torch.tensor([[0.0, 1.0], [0.5, 1.0]]))
+        if self.deform:  # cfg_deform (magicpony.yaml:89-95)
+            self.netDeform = hostnets.CoordMLP(3, 3, layers["deform"], nf=net_width, n_harmonic_functions=freq["deform"], embedder_scalar=scalar,
+                                               extra_feat_dim=feat_dim, symmetrize=True)
         self.to(dev)
-        self.optimizer = torch.optim.Adam(self.parameters(), lr=lr)
 
         # ---- synthetic stand-ins for the (unchanged) predictors' outputs: leaves that require grad
-        B, (H, W) = batch, self.resolution
-        mvp, w2c, campos = synthetic.random_cameras(B, seed=seed + 1)
+        B, F, (H, W) = batch, self.num_frames, self.resolution
+        N = B * F  # rendered frames per iteration
+        self.frames = N
+        mvp, w2c, campos = synthetic.random_cameras(N, seed=seed + 1)
         self.mvp = mvp.to(dev).requires_grad_(True)
         self.w2c = w2c.to(dev).requires_grad_(True)
         self.campos = campos.to(dev).requires_grad_(True)
-        self.feat = torch.randn(B, feat_dim, generator=torch.Generator().manual_seed(data_seed + 2)).to(dev).requires_grad_(True)
-        self.arti = synthetic.seeded((B, 1, 20, 3), seed + 3, -0.25, 0.25).to(dev).requires_grad_(True)
-        # ---- bones once per "epoch" from the un-jittered prior (InstancePredictorBase.py:316-335)
+        self.feat = torch.randn(N, feat_dim, generator=torch.Generator().manual_seed(data_seed + 2)).to(dev).requires_grad_(True)
+        self.arti = synthetic.seeded((B, F, 20, 3), seed + 3, -0.25, 0.25).to(dev).requires_grad_(True)
+        self.class_emb = None
+        if workload == "fauna":  # the memory bank's batch embedding (BasePredictorBank.py:98-102)
+            self.class_emb = (0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 6))).to(dev).requires_grad_(True)
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=lr)
+        # ---- bones from the un-jittered prior (once per "epoch", InstancePredictorBase.py:316-335; Fauna redoes this every iteration)
         with torch.no_grad():
-            prior = self.netShape.getMesh(jitter_grid=False)
-            self.bones, self.kinematic_tree, self.bone_aux = skinning_mod.estimate_bones(
-                prior.v_pos[None].detach(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+", compute_kinematic_chain=True,
-                attach_legs_to_body=True)
+            prior = self.netShape.getMesh(jitter_grid=False, feats=self.class_emb)
+            self._estimate_bones(prior)
         # ---- targets shaped like ImageDataset batches (model/dataset/ImageDataset.py:57-90)
         g = torch.Generator().manual_seed(data_seed + 4)
-        self.image_gt = torch.rand(B, 3, H, W, generator=g).to(dev)
-        self.dino_gt = torch.rand(B, 16, H, W, generator=g).to(dev)
-        self.background = torch.zeros(B, H, W, 3, device=dev)
+        self.image_gt = torch.rand(N, 3, H, W, generator=g).to(dev)
+        self.dino_gt = torch.rand(N, 16, H, W, generator=g).to(dev)
+        self.flow_gt = (0.05 * torch.randn(B, max(F - 1, 1), 2, H, W, generator=g)).to(dev) if F > 1 else None
+        self.background = torch.zeros(N, H, W, 3, device=dev)
         with torch.no_grad():  # mask of the same animal under a perturbed articulation, + its distance transforms
-            arti0 = synthetic.seeded((B, 1, 20, 3), seed + 5, -0.25, 0.25).to(dev)
+            arti0 = synthetic.seeded((B, F, 20, 3), seed + 5, -0.25, 0.25).to(dev)
             mask = self.forward_render(arti0, prior=prior, modes=["shaded"], with_nets=False)[0][:, 3]
             self.mask_gt = (mask > 0.5).float()
             self.mask_dt = _distance_transforms(self.mask_gt).to(dev)
-        self.mask_valid = torch.ones(B, H, W, device=dev)
+        self.mask_valid = torch.ones(N, H, W, device=dev)
+        self._eye4, self._proj = torch.eye(4, device=dev), synthetic.perspective(25.0).to(dev)
 
     # ------------------------------------------------------------------------------------------------
+    def _estimate_bones(self, prior):
+        kw = dict(n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+", compute_kinematic_chain=True, attach_legs_to_body=True)
+        if self.workload == "fauna":
+            kw["bone_y_threshold"] = 0.4  # config/model/fauna.yaml
+        self.bones, self.kinematic_tree, self.bone_aux = skinning_mod.estimate_bones(prior.v_pos[None].detach(), **kw)
+
     def forward_render(self, arti, prior=None, modes=("shaded", "dino_pred"), with_nets=True, jitter=False):
-        B = self.batch
+        B, F, N = self.batch, self.num_frames, self.frames
         if prior is None:
-            prior = self.netShape.getMesh(jitter_grid=jitter)
-        verts, aux = skinning_mod.skinning(prior.v_pos[None], self.bones, self.kinematic_tree, arti, output_posed_bones=True,
-                                           temperature=self.temperature)
-        verts = verts.view(B, *verts.shape[2:])
-        shape = mesh_mod.make_mesh(verts, prior.t_pos_idx, prior.v_tex.expand(B, -1, -1), prior.t_tex_idx, None)
-        self.last.update(prior=prior, shape=shape, posed_bones=aux["posed_bones"])
+            prior = self.netShape.getMesh(jitter_grid=jitter, feats=self.class_emb)
+            if self.workload == "fauna":  # "estimate bones every iteration for fauna" (InstancePredictorFauna.py:91-92)
+                self._estimate_bones(prior)
+        rest, deformation = prior.v_pos[None], None  # [1,1,V,3]
+        if self.deform and with_nets:
+            V = prior.v_pos.shape[1]
+            if getattr(self, "_frame_of_vertex", None) is None or self._frame_of_vertex.shape[0] != N * V:
+                self._frame_of_vertex = torch.arange(N, device=self.dev).repeat_interleave(V)
+            # netDeform(verts, feat) * 0.1 (InstancePredictorBase.py:309-312): the feature enters as one row per frame + an index
+            deformation = self.netDeform.sample(prior.v_pos.expand(N, -1, -1).reshape(N * V, 3), feat=self.feat,
+                                                feat_index=self._frame_of_vertex).view(N, V, 3) * 0.1
+            deformed = prior.deform(deformation)  # make_mesh over the N deformed meshes (InstancePredictorBase.py:313)
+            rest = deformed.v_pos.view(B, F, V, 3)
+            self.last["deformed"] = deformed
+        verts, aux = skinning_mod.skinning(rest, self.bones, self.kinematic_tree, arti, output_posed_bones=True, temperature=self.temperature)
+        verts = verts.view(N, *verts.shape[2:])
+        shape = mesh_mod.make_mesh(verts, prior.t_pos_idx, prior.v_tex.expand(N, -1, -1), prior.t_tex_idx, None)
+        self.last.update(prior=prior, shape=shape, posed_bones=aux["posed_bones"], deformation=deformation)
         out = render_mod.render_mesh(None, shape, self.mvp, self.w2c, self.campos, self.netTexture if with_nets else None,
                                       self.netLight if with_nets else None, self.resolution, background=self.background, bsdf="diffuse",
                                       feat=self.feat if with_nets else None, render_modes=list(modes), prior_mesh=prior,
-                                      dino_net=self.netDINO if with_nets else None)
+                                      dino_net=self.netDINO if with_nets else None, num_frames=F)
         self.last["rast"] = render_mod.LAST_RAST[0]
         return out
 
+    def random_view_mask(self, shape, prior):
+        """Fauna.get_random_view_mask (Fauna.py:111-173): the posed meshes seen from a random azimuth, no texture, no light,
+        one-sided shading normal; the alpha channel is the mask the discriminator sees."""
+        N, dev = self.frames, self.dev
+        bins = 360
+        deg = torch.randint(bins, [N], device=dev)  # on the device: no host round trip inside the step
+        ang = (2 * math.pi / bins) * deg.float()
+        c, s_, z, o = ang.cos(), ang.sin(), torch.zeros_like(ang), torch.ones_like(ang)
+        rot = torch.stack([c, z, s_, z, z, o, z, z, -s_, z, c, z, z, z, z, o], -1).view(N, 4, 4)
+        w2c = self._eye4.repeat(N, 1, 1)
+        w2c[:, :3, 3] = self.w2c.detach()[:, :3, 3]  # "use the predicted transition"
+        mvp = (self._proj @ w2c) @ rot
+        campos = (rot[:, :3, :3].transpose(2, 1) @ (-w2c[:, :3, 3])[:, :, None])[:, :, 0]
+        self.last["random_view"] = dict(mvp=mvp, w2c=w2c, campos=campos, deg=deg)
+        out = render_mod.render_mesh(None, shape, mvp, w2c, campos, None, None, self.resolution, background=None, bsdf="diffuse", feat=None,
+                                      render_modes=["shaded"], prior_mesh=prior, dino_net=None, two_sided_shading=False, num_frames=self.num_frames)
+        return out[0][:, 3:].clamp(0, 1)
+
     def losses(self, shaded, dino_pred):
-        """compute_reconstruction_losses (AnimalModel.py:260-307), F=1, background_mode 'none'."""
+        """compute_reconstruction_losses (AnimalModel.py:260-307), background_mode 'none' (per frame)."""
         if FUSED_LOSSES and shaded.is_cuda:
             from . import ops
 
@@ -169,22 +237,53 @@ class SyntheticScene(torch.nn.Module):
         out = {}
         out["mask"] = ((mask_pred * self.mask_valid - self.mask_gt) ** 2).flatten(1).mean(1)
         out["mask_inv_dt"] = ((1 - mask_pred) * self.mask_dt[:, 0]).flatten(1).mean(1)
-        both = ((mask_pred * self.mask_valid > 0.0).float() * self.mask_gt).detach()
-        both = (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
+        both = self.eroded_mask(mask_pred)
         out["rgb"] = ((image_pred - self.image_gt).abs() * both.unsqueeze(1)).flatten(1).mean(1)
         out["dino"] = (((dino_pred - self.dino_gt) ** 2) * both.unsqueeze(1)).flatten(1).mean(1)
         return out
 
+    def eroded_mask(self, mask_pred):
+        both = ((mask_pred * self.mask_valid > 0.0).float() * self.mask_gt).detach()
+        return (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
+
+    def flow_loss(self, flow_pred, mask_pred):
+        """AnimalModel.py:285-298: squared flow error on the eroded common mask between consecutive frames, frames whose target
+        flow exceeds 0.5 anywhere on the mask dropped, normalised by the mask's pixel count.  flow_pred [B*F,2,H,W]."""
+        B, F = self.batch, self.num_frames
+        H, W = self.resolution
+        pred = flow_pred.view(B, F, 2, H, W)[:, :-1]
+        both = self.eroded_mask(mask_pred).view(B, F, H, W)[:, :-1].unsqueeze(2).expand_as(self.flow_gt)
+        large = ((self.flow_gt.abs() > 0.5).float() * both).reshape(B, F - 1, -1).sum(2) > 0
+        err = (pred - self.flow_gt) ** 2 * both * (~large).float()[:, :, None, None, None]
+        return err.reshape(B, F - 1, -1).sum(2) / both.reshape(B, F - 1, -1).sum(2).clamp(min=1)
+
     def forward(self, jitter=True, sdf_reg=True):
         """Forward of one iteration -> dict(shaded, dino_pred, loss, losses).  (DDP wraps this module: its backward hooks
         all-reduce the MLP gradients over RCCL while the HIP backward kernels are still running.)"""
-        shaded, dino_pred = self.forward_render(self.arti, jitter=jitter)
+        modes = ["shaded", "dino_pred"] + (["flow"] if self.workload == "ponymation" and self.num_frames > 1 else [])
+        rendered = self.forward_render(self.arti, jitter=jitter, modes=modes)
+        shaded, dino_pred = rendered[0], rendered[1]
         parts = self.losses(shaded, dino_pred)
         total = sum(LOSS_WEIGHTS[k] * v.mean() for k, v in parts.items())
+        out = dict(shaded=shaded, dino_pred=dino_pred)
+        if len(rendered) > 2:
+            out["flow"] = rendered[2]
+            parts["flow"] = self.flow_loss(rendered[2], shaded[:, 3])
+            total = total + REG_WEIGHTS["flow"] * parts["flow"].mean()
+        if self.deform:  # R_art, R_def (AnimalModel.py:313-316)
+            parts["arti_reg"] = (self.arti ** 2).mean()
+            parts["deform_reg"] = (self.last["deformation"] ** 2).mean()
+            total = total + REG_WEIGHTS["arti_reg"] * parts["arti_reg"] + REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+        if self.workload == "fauna":
+            mask_random = self.random_view_mask(self.last["shape"], self.last["prior"])
+            out["mask_random"] = mask_random
+            parts["mask_random"] = ((mask_random - 0.5) ** 2).flatten(1).mean(1)  # stand-in for the mask discriminator's generator loss
+            total = total + REG_WEIGHTS["mask_random"] * parts["mask_random"].mean()
         if sdf_reg and torch.is_grad_enabled():
-            eikonal = ((self.netShape.get_sdf_gradient().norm(dim=-1) - 1) ** 2).mean()  # dmtet.py:278-281
+            eikonal = ((self.netShape.get_sdf_gradient(feats=self.class_emb).norm(dim=-1) - 1) ** 2).mean()  # dmtet.py:278-281
             total = total + LOSS_WEIGHTS["sdf_gradient"] * eikonal
-        return dict(shaded=shaded, dino_pred=dino_pred, loss=total, losses=parts)
+        out.update(loss=total, losses=parts)
+        return out
 
     def step(self, backward=True, optimizer_step=None, sdf_reg=True, module=None):
         """One iteration (forward, backward, Adam).  ``module`` = the DDP wrapper of this scene when data-parallel."""
@@ -193,8 +292,9 @@ class SyntheticScene(torch.nn.Module):
             out = (module if module is not None else self)(jitter=backward, sdf_reg=sdf_reg)
         if backward:
             self.optimizer.zero_grad(set_to_none=True)
-            for leaf in (self.mvp, self.w2c, self.campos, self.feat, self.arti):
-                leaf.grad = None
+            for leaf in (self.mvp, self.w2c, self.campos, self.feat, self.arti, self.class_emb):
+                if leaf is not None:
+                    leaf.grad = None
             out["loss"].backward()
             if optimizer_step:
                 self.optimizer.step()

@@ -3,18 +3,26 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): train_magicpony_horse-like synthetic step,
 batch 16 per GPU @ 256x256, forward + backward + Adam -- DMTet on a Kuhn R=64 grid (the stand-in for the reference's
-"128" Quartet grid), skinning with 20 bones, rasterise / interpolate / antialias, the texture / DINO /
-light / SDF MLPs at the reference's sizes, photometric + mask + DINO-feature losses.  See 3danimals_amd/pipeline.py.
+"128" Quartet grid), instance deformation, skinning with 20 bones, three make_mesh passes, rasterise /
+interpolate / antialias, the SDF / texture / DINO / light / deformation MLPs at the reference's sizes, photometric + mask +
+DINO-feature losses and the shape regularisers.  See 3danimals_amd/pipeline.py.  `--workload fauna|ponymation` runs the per-rank
+steps of configs[3] / configs[4] instead (same JSON contract; `config.workload` says which).
 
 N > 1: launched by the driver through torch.distributed.run, one rank per GPU, DDP over RCCL (gradient all-reduce of
 the MLP parameters; the hot-path kernels themselves exchange nothing: images shard over the batch) -> weak scaling.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant hot-path HIP kernel: algorithmic bytes per launch / mean launch duration measured live
-                  with HIP events on the launch stream, against the 8 TB/s HBM peak;
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     -- the dominant IN-SCOPE entry point of the hot path (DMTet, skinning, normals, topology,
+                  rasterise, covered pixels, G-buffer, shading, antialias): algorithmic bytes per launch / mean launch duration measured
+                  live with HIP events on the launch stream, against the 8 TB/s HBM peak; `in_scope` = the bytes-weighted aggregate
+                  over all of them per step; `with_f3_losses` adds the fused reconstruction losses; `networks_side`
+                  = the kernels that serve model/networks (out of scope, reported for completeness);
+  parity       -- the step the CPU oracle re-runs for `cpu_baseline` compared with the HIP step it was snapshotted from;
+  dropin       -- the same step with the networks evaluated exactly as the reference's model/networks does (--networks reference);
   cpu_baseline -- the CPU oracle (kind "port") timed on this box's host cores on a bounded sample of the batch.
 """
 import argparse
+import contextlib
 import importlib
 import json
 import os
@@ -29,17 +37,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+
+# what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
+# (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
+IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_")
+F3 = ("a3d_recon_losses_",)
 
 
 def algorithmic_bytes(name, d):
     """Algorithmic HBM bytes of ONE call of a C-ABI entry point (DESIGN.md 'Kernels').
 
-    ``name`` may carry a channel tag, e.g. 'a3d_interp_fwd[C3]'.  Index buffers shared over the batch count once.
+    ``name`` may carry a channel tag, e.g. 'a3d_interp_fwd[C3]'.  Index buffers shared over the batch count once.  B = frames
+    rendered per step (images x frames), V / F = surface vertices / faces, P = covered pixels, K = bones.
     """
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
     C = int(name.split("[C")[1].split("]")[0]) if "[C" in name else 0
+    Bn = int(name.split("[B")[1].split("]")[0]) if "[B" in name else B  # batch tag of the normals calls (prior mesh: 1)
     base = name.split("[")[0]
-    Pp = -(-int(d.get("P", 0)) // 8192) * 8192  # render.POINT_BUCKET
+    P = int(d.get("P", 0))
+    Pp = -(-P // 8192) * 8192  # render.POINT_BUCKET
     table = {
         "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt,
         "a3d_dmtet_emit": 16 * Nv + 8 * Ne + 4 * Ne + 16 * Nt + 24 * Nt + 16 * V + 48 * F,
@@ -47,15 +65,15 @@ def algorithmic_bytes(name, d):
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
         "a3d_normals_adjacency": 24 * F + 4 * V,  # triangle list in, CSR out
-        "a3d_normals_fwd": 4 * V + 24 * F + B * (36 * F + 24 * V),  # CSR + indices once; per image position gathers, acc + nrm out
-        "a3d_normals_bwd": 4 * V + 24 * F + B * (36 * F + 36 * F + 60 * V),
+        "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
+        "a3d_normals_fwd": 4 * V + 24 * F + Bn * (36 * F + 24 * V),  # CSR + indices once; per image position gathers, acc + nrm out
+        "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 36 * F + 60 * V),
         "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
         "a3d_rast_bwd": B * (32 * HW + 16 * V),
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
-        "a3d_gbuffer_fwd": int(d.get("P", 0)) * (8 + 16 + 48),
-        "a3d_gbuffer_bwd": int(d.get("P", 0)) * (8 + 16 + 48) + B * V * (36 + 16),
-        "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
+        "a3d_gbuffer_fwd": P * (8 + 16 + 48),
+        "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums
@@ -65,13 +83,13 @@ def algorithmic_bytes(name, d):
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
         "a3d_recon_losses_bwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1 + 16 + 64),
         "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
-        "a3d_cover_emit": 4 * B * HW + 8 * int(d.get("P", 0)),
-        "a3d_shade_fwd": int(d.get("P", 0)) * (48 + 68 + 12 + 12 + 4 + 12),
-        "a3d_shade_bwd": int(d.get("P", 0)) * (48 + 68 + 12 + 28 + 48 + 68 + 12),
+        "a3d_cover_emit": 4 * B * HW + 8 * P,
+        "a3d_shade_fwd": P * (48 + 68 + 12 + 12 + 4 + 12),
+        "a3d_shade_bwd": P * (48 + 68 + 12 + 28 + 48 + 68 + 12),
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,
         "a3d_bone_transforms_bwd": B * K * (12 + 48 + 12) + 24 * K,
         "a3d_aa_topology": 12 * F + 12 * F,
-        "a3d_aa_analyze": B * 16 * HW,
+        "a3d_aa_analyze": B * 16 * HW + B * 16 * V,
         "a3d_aa_fwd": B * 8 * C * HW,
         "a3d_aa_bwd": B * 8 * C * HW + B * 16 * V,
     }
@@ -84,18 +102,127 @@ def algorithmic_flops(name, d):
     return {"a3d_gemm_nn_relumask": 2 * Pp * 256 * 256}.get(name.split("[")[0])
 
 
+def _aggregate(kernels, prefixes):
+    sel = {k: v for k, v in kernels.items() if k.startswith(prefixes) and v["GBps"] is not None}
+    tot_b = sum(v["algorithmic_MB"] * v["launches_per_step"] for v in sel.values()) * 1e6
+    tot_t = sum(v["mean_us"] * v["launches_per_step"] for v in sel.values()) * 1e-6
+    if tot_t <= 0:
+        return None
+    return dict(us_per_step=round(tot_t * 1e6, 1), algorithmic_MB_per_step=round(tot_b / 1e6, 1), GBps=round(tot_b / tot_t / 1e9, 1),
+                frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4), entry_point_calls_per_step=round(sum(v["launches_per_step"] for v in sel.values()), 1))
+
+
+def kernel_pass(scene, module, L, steps, world, dims_of):
+    """Per-entry-point timing of a few steps under HIP events (same workload, separate from the headline timing)."""
+    # with DDP, rank 0 alone re-runs a few steps: that must not enqueue collectives the other ranks never join, hence no_sync()
+    with L.KernelTimer() as timer, (module.no_sync() if module is not None else contextlib.nullcontext()):
+        for _ in range(steps):
+            scene.step(module=module, optimizer_step=(world == 1))
+    dims = dims_of(scene)
+    kernels = {}
+    for name, (count, mean_ms) in sorted(timer.summary().items()):
+        ab = algorithmic_bytes(name, dims)
+        kernels[name] = dict(launches_per_step=round(count / steps, 2), mean_us=round(mean_ms * 1e3, 2),
+                             algorithmic_MB=None if ab is None else round(ab / 1e6, 3),
+                             GBps=None if ab is None else round(ab / (mean_ms * 1e-3) / 1e9, 1))
+    return kernels, dims
+
+
+def roofline_of(kernels, dims):
+    scope = {k: v for k, v in kernels.items() if k.startswith(IN_SCOPE) and v["GBps"] is not None}
+    dom = max(scope, key=lambda k: scope[k]["mean_us"] * scope[k]["launches_per_step"])  # most time per step among the in-scope entry points
+    traffic, traffic_note = None, "no PMC file for this round yet"
+    if os.path.exists(PMC_TRAFFIC_FILE):
+        rec = json.load(open(PMC_TRAFFIC_FILE))["per_call"].get(dom.split("[")[0])
+        traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
+        traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as " + os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+    roof = dict(kernel=dom, bound="hbm", achieved=scope[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(scope[dom]["GBps"] / HBM_PEAK_GBS, 4),
+                traffic=traffic, traffic_source=traffic_note, launch_us=scope[dom]["mean_us"], launches_per_step=scope[dom]["launches_per_step"],
+                algorithmic_bytes_per_launch=round(scope[dom]["algorithmic_MB"] * 1e6), in_scope=_aggregate(kernels, IN_SCOPE),
+                with_f3_losses=_aggregate(kernels, IN_SCOPE + F3), mesh=dims)
+    # the best-fed streaming kernel of the path, for the other end of the picture
+    top = max(scope, key=lambda k: scope[k]["GBps"])
+    roof["fastest_in_scope"] = dict(kernel=top, achieved=scope[top]["GBps"], unit="GB/s", frac=round(scope[top]["GBps"] / HBM_PEAK_GBS, 4),
+                                    launch_us=scope[top]["mean_us"])
+    # model/networks side (out of scope): the field kernels, incl. the one compute-bound kernel of the library
+    net = {k: v for k, v in kernels.items() if not k.startswith(IN_SCOPE + F3)}
+    side = dict(us_per_step=round(sum(v["mean_us"] * v["launches_per_step"] for v in net.values()), 1))
+    gemm = next((k for k in net if k.startswith("a3d_gemm_nn_relumask")), None)
+    if gemm is not None:
+        fl = algorithmic_flops(gemm, dims)
+        tf = fl / (net[gemm]["mean_us"] * 1e-6) / 1e12
+        side["mfma_gemm"] = dict(kernel=gemm, bound="mfma", achieved=round(tf, 1), peak=MFMA_FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                                 frac=round(tf / MFMA_FP32_PEAK_TFLOPS, 4), launch_us=net[gemm]["mean_us"], launches_per_step=net[gemm]["launches_per_step"])
+    roof["networks_side"] = side
+    return roof
+
+
+def parity_and_cpu_baseline(scene, args, threads):
+    """One HIP step (weights untouched) -> snapshot -> the CPU oracle on the first images of the SAME step: full-size parity figures,
+    and the oracle's wall clock as the CPU baseline (1 warm-up + median of ``--cpu-runs``)."""
+    from oracle import raster_ref, render_ref, step_ref
+
+    torch.set_num_threads(threads)
+    out = scene.step(backward=True, optimizer_step=False)
+    torch.cuda.synchronize()
+    n = max(1, min(args.cpu_sample_images, scene.frames))
+    st = step_ref.snapshot(scene, n)
+    n = st["n"]
+    runs = [step_ref.cpu_step(st, backward=True) for _ in range(1 + args.cpu_runs)]
+    res = runs[-1]
+    secs = sorted(r["seconds"] for r in runs[1:])
+    sec = secs[len(secs) // 2]
+    cpu = lambda t: t.detach().float().cpu()
+    faces_equal = bool(torch.equal(res["faces"], scene.last["prior"].t_pos_idx[0].cpu()))
+    parity = dict(images=n, resolution=list(scene.resolution), faces_equal=faces_equal, num_faces=res["num_faces"])
+    if faces_equal:
+        # pixels whose owner differs between the two id buffers (the clip transform is a GPU matmul on one side, a CPU matmul on the
+        # other) and their antialiasing neighbours are excluded, and counted -- see oracle/check.py
+        clip = render_ref.xfm_points(res["posed"], st["mvp"]).contiguous()
+        rast_o = raster_ref.rasterize(clip, res["faces"].int(), scene.resolution)
+        flip = rast_o[..., 3] != cpu(scene.last["rast"])[:n, ..., 3]
+        keep = ~(torch.nn.functional.max_pool2d(flip.float()[:, None], 3, 1, 1)[:, 0] > 0)
+        err = 0.0
+        for name in ("shaded", "dino_pred", "flow"):
+            if name in res and name in out:
+                err = max(err, float(((cpu(out[name])[:n] - res[name]).abs() * keep[:, None]).max()))
+        parity.update(max_abs_image_err=err, frac_pixels_owner_flip=round(float(flip.float().mean()), 7),
+                      max_abs_vertex_err=float((res["verts"] - cpu(scene.last["prior"].v_pos[0])).abs().max()),
+                      max_abs_posed_vertex_err=float((res["posed"] - cpu(scene.last["shape"].v_pos)[:n]).abs().max()))
+        rel = {}
+        for k, v in res["losses"].items():
+            if k in out["losses"] and v.dim() >= 1 and v.shape[0] in (n, st["nb"]):
+                a, b = float(cpu(out["losses"][k])[: v.shape[0]].mean()), float(v.mean())
+                rel[k] = round(abs(a - b) / max(abs(b), 1e-12), 7)
+        parity["loss_rel_err"] = rel
+        parity["pass"] = bool(err < 1e-4 and parity["frac_pixels_owner_flip"] < 2e-3)
+    cpu_baseline = dict(value=round(n / sec, 4), unit="images/s", cores=threads, kind="port",
+                        sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {scene.frames} frames of this workload ({scene.workload}: Kuhn R={args.grid_res} "
+                               f"DMTet, LBS, {args.resolution}x{args.resolution} raster+shade+antialias, losses), 1 warm-up + median of {args.cpu_runs} runs, "
+                               f"torch {threads} threads of {os.cpu_count()} logical cores, {sec:.1f} s per run")
+    return parity, cpu_baseline
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=None, help="images (sequences for ponymation) per GPU; default 16 (8 sequences)")
+    ap.add_argument("--frames", type=int, default=8, help="frames per sequence (ponymation only)")
     ap.add_argument("--grid-res", type=int, default=64)
     ap.add_argument("--resolution", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("magicpony", "fauna", "ponymation"), default="magicpony")
+    ap.add_argument("--networks", choices=("fast", "reference", "both"), default="both",
+                    help="fast: the output-identical field evaluation of hostnets (headline); reference: model/networks' own formulation "
+                         "(per-point feature concat, per-call frequency upload, no TunableOp, no fused kernels); both: headline = fast, and "
+                         "the reference formulation is measured too (single GPU only) and reported under 'dropin'")
+    ap.add_argument("--no-deform", action="store_true", help="magicpony without the instance deformation (the round-1 step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (parity and cpu_baseline = null)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="do not load the shipped TunableOp results for the torch MLPs")
     ap.add_argument("--cpu-sample-images", type=int, default=4)
+    ap.add_argument("--cpu-runs", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -106,17 +233,29 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pipeline = importlib.import_module("3danimals_amd.pipeline")
+    hostnets = importlib.import_module("3danimals_amd.hostnets")
     L = importlib.import_module("3danimals_amd._lib")
     L.lib()  # fail loudly, now, if the HIP library is missing
-    tuned = importlib.import_module("3danimals_amd.gemm_tuning").enable() if not args.no_tuned_gemms else False
+    headline_networks = "reference" if args.networks == "reference" else "fast"
+    tuned = False
+    if headline_networks == "fast" and not args.no_tuned_gemms:
+        tuned = importlib.import_module("3danimals_amd.gemm_tuning").enable()
+    hostnets.reference_formulation(headline_networks == "reference")
 
-    scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(args.resolution, args.resolution), device=dev,
-                                    seed=0, data_seed=1000 * rank)
+    batch = args.batch if args.batch is not None else (8 if args.workload == "ponymation" else 16)
+    frames = args.frames if args.workload == "ponymation" else 1
+
+    def make_scene():
+        return pipeline.SyntheticScene(grid_res=args.grid_res, batch=batch, resolution=(args.resolution, args.resolution), device=dev, seed=0,
+                                       data_seed=1000 * rank, workload=args.workload, num_frames=frames,
+                                       deform=(args.workload == "magicpony" and not args.no_deform))
+
+    scene = make_scene()
     scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    # weak scaling = fixed work per GPU: every rank renders the same 16 poses / cameras (hence the same number of covered pixels and
+    # weak scaling = fixed work per GPU: every rank renders the same poses / cameras (hence the same number of covered pixels and
     # the same GEMM shapes) against its own image features and target images, so the all-reduced gradients differ per rank.
     module = None
     if world > 1:
@@ -125,78 +264,45 @@ def main():
     # W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides, MAX over ranks
     du = importlib.import_module("3danimals_amd.dist_util")
     elapsed = du.timed_steps(lambda: scene.step(module=module), args.steps, args.warmup, device=dev)
-    images = world * args.batch * args.steps
+    images = world * scene.frames * args.steps
+
+    def dims_of(sc):
+        prior = sc.last["prior"]
+        return dict(B=sc.frames, V=int(prior.v_pos.shape[1]), F=int(prior.t_pos_idx.shape[1]), H=args.resolution, W=args.resolution,
+                    Nv=int(sc.netShape.verts.shape[0]), Ne=int(sc.netShape.topology.edges32.shape[0]),
+                    Nt=int(sc.netShape.topology.tets32.shape[0]), K=int(sc.bones.shape[2]),
+                    P=int((sc.last["rast"][..., 3] > 0).sum()) if "rast" in sc.last else 0)
 
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
     if rank == 0 and not args.no_kernel_timing:
-        import contextlib
+        kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of)
+        roofline = roofline_of(kernels, dims)
 
-        # rank 0 alone re-runs a few steps under HIP-event timers; with DDP that must not enqueue collectives the other ranks
-        # never join, hence no_sync() (local gradients only) and no optimizer step
-        with L.KernelTimer() as timer, (module.no_sync() if module is not None else contextlib.nullcontext()):
-            for _ in range(min(args.steps, 10)):
-                scene.step(module=module, optimizer_step=(world == 1))
-        prior, shape = scene.last["prior"], scene.last["shape"]
-        dims = dict(B=args.batch, V=int(prior.v_pos.shape[1]), F=int(prior.t_pos_idx.shape[1]), H=args.resolution, W=args.resolution,
-                    Nv=int(scene.netShape.verts.shape[0]), Ne=int(scene.netShape.topology.edges32.shape[0]),
-                    Nt=int(scene.netShape.topology.tets32.shape[0]), K=int(scene.bones.shape[2]),
-                    P=int((scene.last["rast"][..., 3] > 0).sum()) if "rast" in scene.last else 0)
-        total_ms = 0.0
-        for name, (count, mean_ms) in sorted(timer.summary().items()):
-            per_step = count / min(args.steps, 10)
-            ab = algorithmic_bytes(name, dims)
-            kernels[name] = dict(launches_per_step=round(per_step, 2), mean_us=round(mean_ms * 1e3, 2),
-                                 algorithmic_MB=None if ab is None else round(ab / 1e6, 3),
-                                 GBps=None if ab is None else round(ab / (mean_ms * 1e-3) / 1e9, 1))
-            total_ms += mean_ms * per_step
-        # dominant = most time per step among the C-ABI entry points (all have a byte model)
-        cand = {k: v for k, v in kernels.items() if v["GBps"] is not None}
-        dom = max(cand, key=lambda k: cand[k]["mean_us"] * cand[k]["launches_per_step"])
-        # bytes-weighted aggregate over the whole HIP path: sum(algorithmic bytes) / sum(time), per step
-        tot_b = sum(v["algorithmic_MB"] * v["launches_per_step"] for v in cand.values()) * 1e6
-        tot_t = sum(v["mean_us"] * v["launches_per_step"] for v in cand.values()) * 1e-6
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed)
-        if os.path.exists(pmc):
-            rec = json.load(open(pmc))["per_call"].get(dom.split("[")[0])
-            traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
-        hip_path = dict(ms_per_step=round(total_ms, 3), algorithmic_MB_per_step=round(tot_b / 1e6, 1),
-                        GBps=round(tot_b / tot_t / 1e9, 1), frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4))
-        flops = algorithmic_flops(dom, dims)
-        if flops is not None:  # the one compute-bound kernel of the path: fp32 MFMA GEMM (157.3 TFLOP/s dense fp32 MFMA peak, MI355X guide)
-            tf = flops / (cand[dom]["mean_us"] * 1e-6) / 1e12
-            roofline = dict(kernel=dom, bound="mfma", achieved=round(tf, 1), peak=MFMA_FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(tf / MFMA_FP32_PEAK_TFLOPS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
-                            algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6),
-                            hbm_GBps=cand[dom]["GBps"], hip_path=hip_path, mesh=dims)
-        else:
-            roofline = dict(kernel=dom, bound="hbm", achieved=cand[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(cand[dom]["GBps"] / HBM_PEAK_GBS, 4), traffic=traffic, launch_us=cand[dom]["mean_us"],
-                            algorithmic_bytes_per_launch=round(cand[dom]["algorithmic_MB"] * 1e6), hip_path=hip_path, mesh=dims)
-        # the streaming kernel with the most time per step, for the HBM side of the picture
-        mem = {k: v for k, v in cand.items() if algorithmic_flops(k, dims) is None}
-        if mem:
-            top = max(mem, key=lambda k: mem[k]["mean_us"] * mem[k]["launches_per_step"])
-            roofline["top_hbm_kernel"] = dict(kernel=top, achieved=mem[top]["GBps"], unit="GB/s", frac=round(mem[top]["GBps"] / HBM_PEAK_GBS, 4),
-                                              launch_us=mem[top]["mean_us"])
-
-    cpu_baseline = None
+    threads = min(os.cpu_count(), 32)  # torch-CPU stops scaling (and thrashes) far below the 256 logical cores of the GPU box
+    parity = cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import step_ref
+        parity, cpu_baseline = parity_and_cpu_baseline(scene, args, threads)
 
-        threads = min(os.cpu_count(), 32)  # torch-CPU stops scaling (and thrashes) far below the 256 logical cores of the GPU box
-        torch.set_num_threads(threads)
-        n = max(1, min(args.cpu_sample_images, args.batch))
-        st = step_ref.snapshot(scene, n)
-        res = step_ref.cpu_step(st, backward=True)
-        cpu_baseline = dict(value=round(n / res["seconds"], 4), unit="images/s", cores=threads, kind="port",
-                            sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {args.batch} images of this workload "
-                                   f"(Kuhn R={args.grid_res} DMTet, LBS, {args.resolution}x{args.resolution} raster+shade+antialias, losses), "
-                                   f"1 run, torch {threads} threads of {os.cpu_count()} logical cores, {res['seconds']:.1f} s")
+    # ---- the drop-in figure: the same step with model/networks evaluated the reference's own way (what a maintainer gets who
+    # overlays only model/geometry + model/render).  Single GPU only; a fresh scene, since Adam state is per formulation.
+    dropin = None
+    if rank == 0 and world == 1 and args.networks == "both":
+        hostnets.reference_formulation(True)
+        tunable_was = torch.cuda.tunable.is_enabled()
+        torch.cuda.tunable.enable(False)
+        ref_scene = make_scene()
+        ref_steps = max(3, min(args.steps, 10))
+        t = du.timed_steps(lambda: ref_scene.step(), ref_steps, 2, device=dev)
+        dropin = dict(networks="reference formulation: per-point feature concatenation (MLPs.py:84-90), frequency table uploaded in every forward "
+                               "(HarmonicEmbedding.py:41), one plain Linear per layer, no TunableOp table, no HIP field kernels; hot path unchanged",
+                      value=round(ref_scene.frames * ref_steps / t, 3), unit="images/s", ms_per_step=round(t / ref_steps * 1e3, 3), steps=ref_steps)
+        hostnets.reference_formulation(False)
+        torch.cuda.tunable.enable(tunable_was)
+        del ref_scene
 
     config1 = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "magicpony":
         # BASELINE config 1 (geometry only, no raster): CPU oracle beside the HIP path on the same inputs
         from oracle import geometry_ref
 
@@ -221,6 +327,12 @@ def main():
                        note="estimate_bones (host logic with read-backs, once per epoch in training) is inside both timings")
 
     if rank == 0:
+        what = {"magicpony": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+deformation+LBS(20 bones)+3x make_mesh+raster/interp/antialias "
+                             "+ SDF/texture/DINO/light/deform MLPs + photometric/mask/DINO losses + regularisers, fwd+bwd+Adam" % args.grid_res,
+                "fauna": "train_fauna per-rank synthetic step: conditioned SDF (CoordMLP_Mod, 128-d embedding) + DMTet(Kuhn R=%d) + bones re-estimated "
+                         "every iteration (bone_y_threshold 0.4) + LBS + main render + random-view mask render + losses, fwd+bwd+Adam" % args.grid_res,
+                "ponymation": "train_ponymation stage-2-like synthetic step with rendering: DMTet(Kuhn R=%d) + [B,F] LBS + B*F frames rendered with "
+                              "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % args.grid_res}[args.workload]
         line = {
             "metric": "train images/sec fwd+bwd @256x256 b16",
             "value": round(images / elapsed, 3),
@@ -234,12 +346,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+LBS(20 bones)+raster/interp/antialias "
-                                   "+ SDF/texture/DINO/light MLPs + photometric/mask/DINO losses, fwd+bwd+Adam" % args.grid_res,
-                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "resolution": [args.resolution, args.resolution],
-                       "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}", "tuned_mlp_gemms": bool(tuned),
+            "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
+                       "resolution": [args.resolution, args.resolution], "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}",
+                       "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
                        "per_rank_data": "same poses/cameras on every rank (equal work per GPU), per-rank image features and targets"},
             "roofline": roofline,
+            "parity": parity,
+            "dropin": dropin,
             "cpu_baseline": cpu_baseline,
             "config1_geometry": config1,
             "kernels": kernels,

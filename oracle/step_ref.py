@@ -20,60 +20,115 @@ def _cpu(t):
 
 
 def snapshot(scene, n_images=None):
-    """CPU copies of everything one step needs (network weights included), for the first ``n_images`` of the batch."""
-    n = scene.batch if n_images is None else min(n_images, scene.batch)
+    """CPU copies of everything one step needs (network weights included), for the first ``n_images`` of the batch (whole sequences
+    for the sequence workload).  Taken AFTER a HIP step: the jittered grid, the bones and the random-view cameras are that step's."""
+    F = getattr(scene, "num_frames", 1)
+    nb = scene.batch if n_images is None else max(1, min(n_images // F if F > 1 else n_images, scene.batch))
+    n = nb * F
     geo = scene.netShape
     scene.netLight.light_params = None
-    st = dict(n=n, resolution=scene.resolution, temperature=scene.temperature, tree=scene.kinematic_tree)
+    st = dict(n=n, nb=nb, num_frames=F, workload=getattr(scene, "workload", "magicpony"), resolution=scene.resolution, temperature=scene.temperature,
+              tree=scene.kinematic_tree)
     st["pos"], st["tets"] = _cpu(geo.current_pos if hasattr(geo, "current_pos") else geo.verts), geo.indices.cpu()
     st["sdf_mlp"] = copy.deepcopy(geo.mlp).cpu()
     st["sdf_gain"], st["leg_radius"], st["symmetrize"] = geo._mlp_gain, geo._leg_radius, geo.symmetrize
     st["tex"], st["dino"], st["lgt"] = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))
+    st["deform"] = copy.deepcopy(scene.netDeform).cpu() if getattr(scene, "deform", False) else None
+    st["class_emb"] = _cpu(scene.class_emb) if getattr(scene, "class_emb", None) is not None else None
     st["bones"] = _cpu(scene.bones)
-    for k in ("mvp", "w2c", "campos", "feat", "arti", "image_gt", "dino_gt", "mask_gt", "mask_dt", "mask_valid", "background"):
+    for k in ("mvp", "w2c", "campos", "feat", "image_gt", "dino_gt", "mask_gt", "mask_dt", "mask_valid", "background"):
         st[k] = _cpu(getattr(scene, k))[:n]
+    st["arti"] = _cpu(scene.arti)[:nb]
+    st["flow_gt"] = _cpu(scene.flow_gt)[:nb] if getattr(scene, "flow_gt", None) is not None else None
+    rv = scene.last.get("random_view") if st["workload"] == "fauna" else None
+    st["random_view"] = {k: _cpu(rv[k])[:n] for k in ("mvp", "w2c", "campos")} if rv is not None else None
     return st
 
 
+def _eroded(mask_pred, st):
+    both = ((mask_pred * st["mask_valid"] > 0.0).float() * st["mask_gt"]).detach()
+    return (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
+
+
 def cpu_step(st, backward=True):
-    """-> dict(loss, shaded, dino_pred, grads{sdf_mlp..., arti, mvp, feat}, seconds)."""
+    """-> dict(loss, losses, shaded, dino_pred[, flow, mask_random], grads{...}, faces, seconds).  Follows AnimalModel.forward around
+    the replaced modules (/root/reference/model/models/AnimalModel.py:356-515) for the workload the snapshot was taken from."""
     from importlib import import_module
 
-    quadruped = import_module("3danimals_amd.pipeline").synthetic_quadruped_device  # pure torch SDF prior (input generator)
+    pipeline = import_module("3danimals_amd.pipeline")
+    quadruped = pipeline.synthetic_quadruped_device  # pure torch SDF prior (input generator)
     t0 = time.perf_counter()
-    n = st["n"]
+    n, nb, F = st["n"], st.get("nb", st["n"]), st.get("num_frames", 1)
+    workload = st.get("workload", "magicpony")
+    H, W = st["resolution"]
     leaves = {k: st[k].clone().requires_grad_(backward) for k in ("mvp", "w2c", "campos", "feat", "arti")}
+    if st.get("class_emb") is not None:
+        leaves["class_emb"] = st["class_emb"].clone().requires_grad_(backward)
     pos = st["pos"]
     pts = torch.cat([pos[:, :1].abs(), pos[:, 1:]], -1) if st["symmetrize"] else pos
     with torch.set_grad_enabled(backward):
-        sdf = st["sdf_mlp"](pts)[:, 0] * st["sdf_gain"] + quadruped(pos, st["leg_radius"])
+        if "class_emb" in leaves:  # dmtet.py:231-236 with the weight-modulated field
+            raw = st["sdf_mlp"](pts, feat=leaves["class_emb"].unsqueeze(0).repeat(pts.shape[0], 1))
+        else:
+            raw = st["sdf_mlp"](pts)
+        sdf = raw[:, 0] * st["sdf_gain"] + quadruped(pos, st["leg_radius"])
         verts, faces, _, _ = dmtet_ref.marching_tets(pos, sdf, st["tets"])
-        posed, _ = skinning_ref.skinning(verts[None, None], st["bones"], st["tree"], leaves["arti"], st["temperature"])
-        posed = posed.view(n, -1, 3)
+        rest, deformation = verts[None, None], None
+        if st.get("deform") is not None:  # InstancePredictorBase.py:306-313
+            V = verts.shape[0]
+            deformation = st["deform"](verts[None].expand(n, -1, -1), leaves["feat"][:, None, :].expand(-1, V, -1)) * 0.1
+            rest = (verts[None] + deformation).view(nb, F, V, 3)
+        posed, _ = skinning_ref.skinning(rest, st["bones"], st["tree"], leaves["arti"], st["temperature"])
+        posed = posed.reshape(n, -1, 3)
         nrm = mesh_ref.vertex_normals(posed, faces)
-        shaded, dino_pred = render_ref.render_mesh(posed, faces, nrm, leaves["mvp"], leaves["w2c"], leaves["campos"], st["tex"], st["lgt"],
-                                                   st["resolution"], background=st["background"], feat=leaves["feat"],
-                                                   render_modes=("shaded", "dino_pred"), prior_v_pos=verts[None], dino_net=st["dino"])
+        modes = ("shaded", "dino_pred") + (("flow",) if (workload == "ponymation" and F > 1) else ())
+        rendered = render_ref.render_mesh(posed, faces, nrm, leaves["mvp"], leaves["w2c"], leaves["campos"], st["tex"], st["lgt"],
+                                          st["resolution"], background=st["background"], feat=leaves["feat"], render_modes=modes,
+                                          prior_v_pos=verts[None], dino_net=st["dino"], num_frames=F)
+        shaded, dino_pred = rendered[0], rendered[1]
         image_pred, mask_pred = shaded[:, :3], shaded[:, 3]
         parts = {}
         parts["mask"] = ((mask_pred * st["mask_valid"] - st["mask_gt"]) ** 2).flatten(1).mean(1)
         parts["mask_inv_dt"] = ((1 - mask_pred) * st["mask_dt"][:, 0]).flatten(1).mean(1)
-        both = ((mask_pred * st["mask_valid"] > 0.0).float() * st["mask_gt"]).detach()
-        both = (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
+        both = _eroded(mask_pred, st)
         parts["rgb"] = ((image_pred - st["image_gt"]).abs() * both.unsqueeze(1)).flatten(1).mean(1)
         parts["dino"] = (((dino_pred - st["dino_gt"]) ** 2) * both.unsqueeze(1)).flatten(1).mean(1)
         loss = sum(LOSS_WEIGHTS[k] * v.mean() for k, v in parts.items())
+        out = {}
+        if len(rendered) > 2:  # AnimalModel.py:285-298
+            flow = rendered[2]
+            out["flow"] = flow.detach()
+            pred = flow.view(nb, F, 2, H, W)[:, :-1]
+            fm = both.view(nb, F, H, W)[:, :-1].unsqueeze(2).expand_as(st["flow_gt"])
+            large = ((st["flow_gt"].abs() > 0.5).float() * fm).reshape(nb, F - 1, -1).sum(2) > 0
+            err = (pred - st["flow_gt"]) ** 2 * fm * (~large).float()[:, :, None, None, None]
+            parts["flow"] = err.reshape(nb, F - 1, -1).sum(2) / fm.reshape(nb, F - 1, -1).sum(2).clamp(min=1)
+            loss = loss + pipeline.REG_WEIGHTS["flow"] * parts["flow"].mean()
+        if deformation is not None:  # AnimalModel.py:313-316
+            parts["arti_reg"] = (leaves["arti"] ** 2).mean()
+            parts["deform_reg"] = (deformation ** 2).mean()
+            loss = loss + pipeline.REG_WEIGHTS["arti_reg"] * parts["arti_reg"] + pipeline.REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+        if st.get("random_view") is not None:  # Fauna.py:111-173
+            rv = st["random_view"]
+            (second,) = render_ref.render_mesh(posed, faces, nrm, rv["mvp"], rv["w2c"], rv["campos"], None, None, st["resolution"], background=None,
+                                               render_modes=("shaded",), prior_v_pos=verts[None], two_sided=False, num_frames=F)
+            mask_random = second[:, 3:].clamp(0, 1)
+            out["mask_random"] = mask_random.detach()
+            parts["mask_random"] = ((mask_random - 0.5) ** 2).flatten(1).mean(1)
+            loss = loss + pipeline.REG_WEIGHTS["mask_random"] * parts["mask_random"].mean()
     grads = {}
+    nets = [("sdf_mlp", st["sdf_mlp"]), ("tex", st["tex"]), ("dino", st["dino"]), ("lgt", st["lgt"])] + ([("deform", st["deform"])] if st.get("deform") is not None else [])
     if backward:
-        for m in (st["sdf_mlp"], st["tex"], st["dino"], st["lgt"]):
+        for _, m in nets:
             m.zero_grad(set_to_none=True)
         loss.backward()
         grads = {k: v.grad for k, v in leaves.items()}
-        for name, m in (("sdf_mlp", st["sdf_mlp"]), ("tex", st["tex"]), ("dino", st["dino"]), ("lgt", st["lgt"])):
+        for name, m in nets:
             for pn, p in m.named_parameters():
                 grads[f"{name}.{pn}"] = p.grad
-    return dict(loss=loss.detach(), losses={k: v.detach() for k, v in parts.items()}, shaded=shaded.detach(), dino_pred=dino_pred.detach(),
-                grads=grads, num_faces=int(faces.shape[0]), seconds=time.perf_counter() - t0)
+    out.update(loss=loss.detach(), losses={k: v.detach() for k, v in parts.items()}, shaded=shaded.detach(), dino_pred=dino_pred.detach(),
+               grads=grads, num_faces=int(faces.shape[0]), faces=faces, verts=verts.detach(), posed=posed.detach(), seconds=time.perf_counter() - t0)
+    return out
 
 
 def synthetic_state(grid_res=16, n=2, resolution=(64, 64), seed=0, net_width=32, net_layers=3, feat_dim=16, embedder_freq=4, spatial_scale=7.0,

@@ -330,3 +330,51 @@ def test_coordmlp_per_image_feature_path_equals_concatenation():
     assert torch.allclose(a, b, atol=1e-6)
     for u, v in zip(ga, gb):
         assert torch.allclose(u, v, atol=1e-5, rtol=1e-4)
+
+
+def test_oracle_step_handles_every_workload():
+    """oracle/step_ref.cpu_step on CPU for the three workloads of pipeline.SyntheticScene (BASELINE configs 3-5): the instance
+    deformation with its regularisers, the conditioned SDF + second random-view render of train_fauna, and T-frame sequences with
+    the flow loss.  (The GPU tests compare the HIP step with exactly this function.)"""
+    import math
+
+    from oracle import step_ref
+
+    a3d = importlib.import_module("3danimals_amd")
+    nets = importlib.import_module("3danimals_amd.hostnets")
+
+    def base(n=2):
+        return step_ref.synthetic_state(grid_res=8, n=n, resolution=(32, 32), net_width=16, net_layers=3, feat_dim=8, embedder_freq=3)
+
+    st = base()
+    st["deform"] = nets.CoordMLP(3, 3, 3, nf=16, n_harmonic_functions=3, embedder_scalar=1.0, extra_feat_dim=8, symmetrize=True)
+    r = step_ref.cpu_step(st)
+    assert {"arti_reg", "deform_reg"} <= set(r["losses"]) and any(k.startswith("deform.") and v is not None for k, v in r["grads"].items())
+
+    st = base()
+    st["workload"] = "fauna"
+    st["sdf_mlp"] = nets.CoordMLP_Mod(3, 1, 3, nf=16, n_harmonic_functions=3, embedder_scalar=2 * math.pi / 7 * 0.9)
+    st["class_emb"] = 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(0))
+    mvp, w2c, campos = a3d.synthetic.random_cameras(2, seed=9)
+    st["random_view"] = dict(mvp=mvp, w2c=w2c, campos=campos)
+    r = step_ref.cpu_step(st)
+    assert "mask_random" in r["losses"] and float(r["grads"]["class_emb"].abs().max()) > 0 and r["mask_random"].shape == (2, 1, 32, 32)
+
+    st = base(n=4)
+    st.update(workload="ponymation", nb=2, num_frames=2)
+    st["arti"] = st["arti"].view(2, 2, 20, 3)
+    st["flow_gt"] = 0.05 * torch.randn(2, 1, 2, 32, 32, generator=torch.Generator().manual_seed(1))
+    r = step_ref.cpu_step(st)
+    assert r["flow"].shape == (4, 2, 32, 32) and r["losses"]["flow"].shape == (2, 1) and bool(torch.isfinite(r["loss"]))
+
+
+def test_weight_modulated_field_matches_reference_state_dict_layout():
+    """hostnets.CoordMLP_Mod keeps the parameter names of the reference class (MLPs.py:104-247) so Fauna checkpoints load."""
+    nets = importlib.import_module("3danimals_amd.hostnets")
+    m = nets.CoordMLP_Mod(3, 1, 5, nf=32, n_harmonic_functions=4)
+    names = set(m.state_dict())
+    assert {"in_layer.weight", "in_layer.bias", "mlp.linear_0.weight", "mlp.linear_4.weight", "style_mlp.network.0.weight",
+            "style_mlp.network.2.weight"} <= names
+    x = torch.randn(7, 3)
+    f = torch.randn(128)
+    assert torch.allclose(m(x, feat=f[None]), m(x, feat=f[None].repeat(7, 1)), atol=1e-6)  # only the first style row is read
