@@ -251,6 +251,17 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
     }
 }
 
+// g_color = g_out (streamed, 16 bytes per lane) and g_clip = 0 in ONE launch (was a device-to-device memcpy + a memset)
+__global__ __launch_bounds__(256) void aa_copy_zero_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
+                                                           float* __restrict__ zero, long long nz) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = n >> 2;
+    for (long long i = t; i < n4; i += stride) reinterpret_cast<float4*>(dst)[i] = a3d_load_stream4(src + 4 * i);
+    for (long long i = (n4 << 2) + t; i < n; i += stride) dst[i] = src[i];
+    for (long long i = t; i < nz; i += stride) zero[i] = 0.f;
+}
+
 extern "C" int a3d_aa_shards(void) { return AA_SHARDS; }
 
 // records the work list must hold for a [B,H,W] frame: AA_SHARDS segments of 256 records per analysis work-group mapped to them
@@ -316,8 +327,13 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
     A3D_CHECK_ARG(g_out && color && work && count && clip && g_color && g_clip && C > 0 && B > 0 && V > 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     hipStream_t s = (hipStream_t)stream;
-    A3D_HIP(hipMemcpyAsync(g_color, g_out, sizeof(float) * (size_t)B * H * W * C, hipMemcpyDeviceToDevice, s));
-    A3D_HIP(hipMemsetAsync(g_clip, 0, sizeof(float) * 4 * (size_t)clip_batch * V, s));
+    {
+        const long long n = (long long)B * H * W * C, nz = 4ll * clip_batch * V;
+        int blocks = a3d_div_up(n >> 2, 256 * 4);
+        blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+        hipLaunchKernelGGL(aa_copy_zero_kernel, dim3(blocks), dim3(256), 0, s, g_out, g_color, n, g_clip, nz);
+        A3D_LAUNCH_CHECK();
+    }
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri);
     hipLaunchKernelGGL(aa_bwd_kernel, dim3(256), dim3(256), 0, s, g_out, color, C, (const AaRec*)work, count, capacity,

@@ -10,8 +10,10 @@ from . import util
 
 try:
     from model.networks import MLP  # type: ignore  (overlaid on the reference tree)
-except Exception:
+except ImportError:  # stand-alone
     from ...hostnets import MLP
+
+_STANDALONE_ONLY = ("EnvironmentLight",)  # placeholders for stand-alone use: never overlaid on the reference's real definitions
 
 
 class DirectionalLight(torch.nn.Module):

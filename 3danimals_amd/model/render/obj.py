@@ -7,6 +7,8 @@ import (`load_obj`) is outside the reconstruct-and-render path and not provided.
 """
 import os
 
+_STANDALONE_ONLY = ("load_obj",)  # placeholders for stand-alone use: never overlaid on the reference's real definitions
+
 
 def write_obj(folder, fname, mesh, idx, save_material=True, feat=None, resolution=[256, 256]):
     obj_file = os.path.join(folder, fname + ".obj")

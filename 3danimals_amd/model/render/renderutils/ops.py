@@ -1,3 +1,5 @@
+"""``use_python`` is accepted for signature parity (reference default False = its JIT CUDA plugin, which does not exist on this
+platform); both values take the torch path below -- the one every config of the reference selects (render.py:72,278)."""
 import torch
 import torch.nn.functional as F
 
@@ -8,7 +10,7 @@ def _dot(x, y):
     return torch.sum(x * y, -1, keepdim=True)
 
 
-def xfm_points(points, matrix, use_python=True):
+def xfm_points(points, matrix, use_python=False):
     """[B|1,V,3] x [B,4,4] -> homogeneous [B,V,4] = [p,1] . M^T (reference ops.py:524-525).
 
     One padded batched matmul (rocBLAS); autograd reaches both the points and the matrix (camera pose).
@@ -19,7 +21,7 @@ def xfm_points(points, matrix, use_python=True):
     return out
 
 
-def xfm_vectors(vectors, matrix, use_python=True):
+def xfm_vectors(vectors, matrix, use_python=False):
     """Direction transform (w = 0), reference ops.py:533-549."""
     out = torch.matmul(F.pad(vectors, pad=(0, 1), mode="constant", value=0.0), torch.transpose(matrix, 1, 2))[..., 0:3].contiguous()
     if torch.is_anomaly_enabled():
@@ -28,7 +30,7 @@ def xfm_vectors(vectors, matrix, use_python=True):
 
 
 def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True,
-                           use_python=True):
+                           use_python=False):
     """Final shading normal (reference ops.py:194-227 -> bsdf.py:46-51): optional tangent-space perturbation,
     two-sided flip by the geometric normal, bend toward the geometric normal at grazing view angles.
 
