@@ -45,8 +45,12 @@ SIGNATURES = {
     "a3d_harmonic_embed_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),
     "a3d_recon_losses_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_recon_losses_mask_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_recon_losses_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
-    "a3d_recon_losses_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_recon_losses_columns": (_c_int, []),
+    "a3d_recon_losses_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_recon_losses_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_flow_loss_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "a3d_flow_loss_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_flow_loss_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_rows_segsum": (_c_int, [_p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p]),
     "a3d_rows_add_relu_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p]),
     "a3d_rows_add_relu_bwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p, _p]),

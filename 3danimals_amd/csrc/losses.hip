@@ -1,7 +1,9 @@
 // Reconstruction losses on gfx950 -- the image-space consumers of the renderer's outputs, fused
-// (/root/reference/model/models/AnimalModel.py:260-307, compute_reconstruction_losses with F = 1, background_mode 'none'):
+// (/root/reference/model/models/AnimalModel.py:260-307, compute_reconstruction_losses, background_mode 'none'; images = B*F frames):
 //   mask        = mean((m*valid - mask_gt)^2)                    m = shaded alpha (antialiased coverage)
-//   mask_inv_dt = mean((1 - m) * dt0)                            dt0 = distance transform of the target mask
+//   mask_inv_dt = mean((1 - m) * dt0)                            dt0 / dt1 = distance transforms of the target mask / its complement
+//   mask_dt     = mean(m * dt1)
+//   flow        = sum((flow - flow_gt)^2 * both) / max(2 * sum(both), 1) per frame pair, 0 where |flow_gt| > 0.5 on the mask
 //   both        = erode3x3((m*valid > 0) * mask_gt)              avg_pool2d(3, stride 1, pad 1) > 0.99, zero padded
 //   rgb         = mean(|rgb - image_gt| * both)     over 3 channels
 //   dino        = mean((dino - dino_gt)^2 * both)   over D channels
@@ -14,6 +16,7 @@
 namespace {
 
 constexpr int LS_BLOCK = 256;
+constexpr int LS_NL = 5;  // loss columns: mask, mask_inv_dt, rgb, dino, mask_dt
 
 __device__ __forceinline__ float ls_q(const float* __restrict__ shaded, const float* __restrict__ valid, const float* __restrict__ mask_gt,
                                       long long img_px, int x, int y, int H, int W) {
@@ -35,13 +38,14 @@ __device__ __forceinline__ float ls_both(const float* __restrict__ shaded, const
 // partial[(b*nblk + blk)*4 + k]: per-block sums of the four summands
 __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D,
                                                           const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
-                                                          const float* __restrict__ mask_gt, const float* __restrict__ dt0, long long dt_stride,
+                                                          const float* __restrict__ mask_gt, const float* __restrict__ dt0,
+                                                          const float* __restrict__ dt1, long long dt_stride,
                                                           const float* __restrict__ valid, int H, int W, float* __restrict__ partial,
                                                           unsigned char* __restrict__ both_out) {
-    __shared__ float red[LS_BLOCK / 64][4];
+    __shared__ float red[LS_BLOCK / 64][LS_NL];
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[LS_NL] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float both = 0.f;  // of this thread's own pixel
     if (i < HW) {
         const long long img_px = (long long)b * HW, p = img_px + i;
@@ -50,6 +54,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
         const float m = s.w, t = m * valid[p] - mask_gt[p];
         v[0] = t * t;
         v[1] = (1.f - m) * dt0[(long long)b * dt_stride + i];
+        if (dt1) v[4] = m * dt1[(long long)b * dt_stride + i];
         both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
         both_out[p] = both > 0.f ? 1 : 0;  // saved for the backward: 1 byte instead of 27 neighbourhood loads per pixel
         const float* g = image_gt + (long long)b * 3 * HW + i;
@@ -88,14 +93,14 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = a3d_wave_sum(v[k]);
+    for (int k = 0; k < LS_NL; ++k) v[k] = a3d_wave_sum(v[k]);
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = v[k];
+        for (int k = 0; k < LS_NL; ++k) red[threadIdx.x >> 6][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < LS_NL) {
         float t = 0.f;
         for (int w = 0; w < LS_BLOCK / 64; ++w) t += red[w][threadIdx.x];
-        partial[((long long)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = t;
+        partial[((long long)b * gridDim.x + blockIdx.x) * LS_NL + threadIdx.x] = t;
     }
 }
 
@@ -103,19 +108,19 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(64) void ls_finish_kernel(const float* __restrict__ partial, int nblk, int HW, int D, float* __restrict__ loss) {
     const int b = blockIdx.x, k = blockIdx.y;
     float t = 0.f;
-    for (int j = threadIdx.x; j < nblk; j += 64) t += partial[((long long)b * nblk + j) * 4 + k];
+    for (int j = threadIdx.x; j < nblk; j += 64) t += partial[((long long)b * nblk + j) * LS_NL + k];
     t = a3d_wave_sum(t);
     if (threadIdx.x == 0) {
-        const float n = k < 2 ? (float)HW : (k == 2 ? 3.f * (float)HW : (float)D * (float)HW);
-        loss[b * 4 + k] = D == 0 && k == 3 ? 0.f : t / n;
+        const float n = (k < 2 || k == 4) ? (float)HW : (k == 2 ? 3.f * (float)HW : (float)D * (float)HW);
+        loss[b * LS_NL + k] = D == 0 && k == 3 ? 0.f : t / n;
     }
 }
 
 __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ shaded,
                                                           const float* __restrict__ dino, int D, const float* __restrict__ image_gt,
                                                           const float* __restrict__ dino_gt, const float* __restrict__ mask_gt,
-                                                          const float* __restrict__ dt0, long long dt_stride, const float* __restrict__ valid,
-                                                          int H, int W, const unsigned char* __restrict__ both_in,
+                                                          const float* __restrict__ dt0, const float* __restrict__ dt1, long long dt_stride,
+                                                          const float* __restrict__ valid, int H, int W, const unsigned char* __restrict__ both_in,
                                                           float* __restrict__ g_shaded, float* __restrict__ g_dino) {
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
     float both = 0.f;
     if (i < HW) {
         const long long p = img_px + i;
-        const float gm = g_loss[4 * b] / (float)HW, gd = g_loss[4 * b + 1] / (float)HW, gr = g_loss[4 * b + 2] / (3.f * (float)HW);
+        const float gm = g_loss[LS_NL * b] / (float)HW, gd = g_loss[LS_NL * b + 1] / (float)HW, gr = g_loss[LS_NL * b + 2] / (3.f * (float)HW);
+        const float g1 = dt1 ? g_loss[LS_NL * b + 4] / (float)HW : 0.f;
         const float4 s = reinterpret_cast<const float4*>(shaded)[p];
         both = both_in[p] ? 1.f : 0.f;
         const float* g = image_gt + (long long)b * 3 * HW + i;
@@ -134,10 +140,11 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
         o.z = gr * sgn(s.z - g[2ll * HW]) * both;
         const float va = valid[p];
         o.w = gm * 2.f * (s.w * va - mask_gt[p]) * va - gd * dt0[(long long)b * dt_stride + i];
+        if (dt1) o.w += g1 * dt1[(long long)b * dt_stride + i];
         reinterpret_cast<float4*>(g_shaded)[p] = o;
     }
     if (!dino) return;
-    const float gq0 = g_loss[4 * b + 3] / ((float)D * (float)HW) * 2.f;
+    const float gq0 = g_loss[LS_NL * b + 3] / ((float)D * (float)HW) * 2.f;
     if ((D & 3) == 0) {  // wave-cooperative, fully coalesced float4 loads and stores (see ls_fwd_kernel)
         const int D4 = D >> 2, lane = threadIdx.x & 63;
         const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);
@@ -167,11 +174,76 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
     }
 }
 
+// ---- flow loss between consecutive frames (AnimalModel.py:285-298).  pair = (sequence, frame f < F-1): the eroded common mask of
+// frame f (saved by ls_fwd_kernel) gates the squared error; a pair whose target flow exceeds 0.5 anywhere on the mask is dropped.
+// partial[(pair*nblk + blk)*3 + {0: sum err, 1: mask count, 2: large-flow hits}]
+__global__ __launch_bounds__(LS_BLOCK) void fl_fwd_kernel(const float* __restrict__ flow, int pix_stride, const float* __restrict__ flow_gt,
+                                                          const unsigned char* __restrict__ both, int F, int HW, float* __restrict__ partial) {
+    __shared__ float red[LS_BLOCK / 64][3];
+    const int pair = blockIdx.y, b = pair / (F - 1), f = pair - b * (F - 1);
+    const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (i < HW) {
+        const long long p = ((long long)b * F + f) * HW + i;  // pixel of frame (b, f) in the renderer's buffers
+        if (both[p]) {
+            const float* g = flow_gt + (long long)pair * 2 * HW + i;
+            const float e0 = flow[p * pix_stride] - g[0], e1 = flow[p * pix_stride + 1] - g[HW];
+            v[0] = e0 * e0 + e1 * e1;
+            v[1] = 1.f;
+            v[2] = (fabsf(g[0]) > 0.5f ? 1.f : 0.f) + (fabsf(g[HW]) > 0.5f ? 1.f : 0.f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = a3d_wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int w = 0; w < LS_BLOCK / 64; ++w) t += red[w][threadIdx.x];
+        partial[((long long)pair * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = t;
+    }
+}
+
+// loss[pair] and scale[pair] = (large ? 0 : 1 / max(2 * count, 1)) for the backward; one wave per pair
+__global__ __launch_bounds__(64) void fl_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ loss, float* __restrict__ scale) {
+    const int pair = blockIdx.x;
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < nblk; j += 64)
+        for (int k = 0; k < 3; ++k) t[k] += partial[((long long)pair * nblk + j) * 3 + k];
+    for (int k = 0; k < 3; ++k) t[k] = a3d_wave_sum(t[k]);
+    if (threadIdx.x == 0) {
+        const float sc = t[2] > 0.f ? 0.f : 1.f / fmaxf(2.f * t[1], 1.f);
+        scale[pair] = sc;
+        loss[pair] = t[0] * sc;
+    }
+}
+
+// g_flow over ALL B*F frames (the last frame of a sequence has no pair: zeros)
+__global__ __launch_bounds__(LS_BLOCK) void fl_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ scale,
+                                                          const float* __restrict__ flow, int pix_stride, const float* __restrict__ flow_gt,
+                                                          const unsigned char* __restrict__ both, int F, int HW, float* __restrict__ g_flow) {
+    const int n = blockIdx.y, b = n / F, f = n - b * F;
+    const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const long long p = (long long)n * HW + i;
+    float g0 = 0.f, g1 = 0.f;
+    if (f < F - 1 && both[p]) {
+        const int pair = b * (F - 1) + f;
+        const float k = 2.f * g_loss[pair] * scale[pair];
+        const float* g = flow_gt + (long long)pair * 2 * HW + i;
+        g0 = k * (flow[p * pix_stride] - g[0]);
+        g1 = k * (flow[p * pix_stride + 1] - g[HW]);
+    }
+    g_flow[2 * p] = g0;
+    g_flow[2 * p + 1] = g1;
+}
+
 }  // namespace
 
 extern "C" size_t a3d_recon_losses_scratch_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return sizeof(float) * 4 * (size_t)B * a3d_div_up((long long)H * W, LS_BLOCK);
+    return sizeof(float) * LS_NL * (size_t)B * a3d_div_up((long long)H * W, LS_BLOCK);
 }
 
 extern "C" size_t a3d_recon_losses_mask_bytes(int B, int H, int W) {
@@ -179,28 +251,57 @@ extern "C" size_t a3d_recon_losses_mask_bytes(int B, int H, int W) {
     return (size_t)B * H * W;
 }
 
+extern "C" int a3d_recon_losses_columns(void) { return LS_NL; }
+
 extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
-                                    const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W,
-                                    void* scratch, uint8_t* both, float* loss, a3d_stream_t stream) {
+                                    const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B,
+                                    int H, int W, void* scratch, uint8_t* both, float* loss, a3d_stream_t stream) {
     A3D_CHECK_ARG(shaded && image_gt && mask_gt && dt0 && valid && scratch && both && loss && B > 0 && H > 0 && W > 0 && D >= 0);
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt));
     hipStream_t s = (hipStream_t)stream;
     const int nblk = a3d_div_up((long long)H * W, LS_BLOCK);
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0,
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, dt1_or_null,
                        (long long)dt_stride, valid, H, W, (float*)scratch, both);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ls_finish_kernel, dim3(B, 4), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
+    hipLaunchKernelGGL(ls_finish_kernel, dim3(B, LS_NL), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt,
-                                    const float* dino_gt, const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B,
-                                    int H, int W, const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream) {
+                                    const float* dino_gt, const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride,
+                                    const float* valid, int B, int H, int W, const uint8_t* both, float* g_shaded, float* g_dino,
+                                    a3d_stream_t stream) {
     A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && both && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino));
     hipLaunchKernelGGL(ls_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
-                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
+                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, dt1_or_null, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" size_t a3d_flow_loss_scratch_bytes(int B, int F, int H, int W) {
+    if (B <= 0 || F < 2 || H <= 0 || W <= 0) return 16;
+    return sizeof(float) * 3 * (size_t)B * (F - 1) * a3d_div_up((long long)H * W, LS_BLOCK);
+}
+
+extern "C" int a3d_flow_loss_fwd(const float* flow, int pix_stride, const float* flow_gt, const uint8_t* both, int B, int F, int H, int W,
+                                 void* scratch, float* loss, float* scale, a3d_stream_t stream) {
+    A3D_CHECK_ARG(flow && flow_gt && both && scratch && loss && scale && B > 0 && F >= 2 && H > 0 && W > 0 && pix_stride >= 2);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = a3d_div_up((long long)H * W, LS_BLOCK), pairs = B * (F - 1);
+    hipLaunchKernelGGL(fl_fwd_kernel, dim3(nblk, pairs), dim3(LS_BLOCK), 0, s, flow, pix_stride, flow_gt, both, F, H * W, (float*)scratch);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fl_finish_kernel, dim3(pairs), dim3(64), 0, s, (const float*)scratch, nblk, loss, scale);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_flow_loss_bwd(const float* g_loss, const float* scale, const float* flow, int pix_stride, const float* flow_gt,
+                                 const uint8_t* both, int B, int F, int H, int W, float* g_flow, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_loss && scale && flow && flow_gt && both && g_flow && B > 0 && F >= 2 && H > 0 && W > 0 && pix_stride >= 2);
+    hipLaunchKernelGGL(fl_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B * F), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, scale, flow,
+                       pix_stride, flow_gt, both, F, H * W, g_flow);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

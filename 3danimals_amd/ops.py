@@ -600,47 +600,84 @@ def antialias(color, rast, clip, tri, analysis=None):
 # ---------------------------------------------------------------------------------------------- reconstruction losses
 class _ReconLosses(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid):
+    def forward(ctx, shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid):
         require_device(shaded, image_gt, mask_gt, dt0, valid, what="reconstruction_losses")
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
         assert shaded.shape == (B, H, W, 4) and shaded.is_contiguous() and image_gt.shape == (B, 3, H, W)
         assert dt0.shape == (B, H, W) and dt0.stride(2) == 1 and dt0.stride(1) == W
+        assert dt1 is None or (dt1.shape == dt0.shape and dt1.stride() == dt0.stride())
         image_gt, mask_gt, valid = f32c(image_gt), f32c(mask_gt), f32c(valid)
         if D:
             assert dino.is_contiguous() and dino_gt.shape == (B, D, H, W)
             dino_gt = f32c(dino_gt)
-        loss = torch.empty((B, 4), dtype=torch.float32, device=shaded.device)
+        loss = torch.empty((B, _lib.lib().a3d_recon_losses_columns()), dtype=torch.float32, device=shaded.device)
         scratch = torch.empty(_lib.lib().a3d_recon_losses_scratch_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
         both = torch.empty(_lib.lib().a3d_recon_losses_mask_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
-        call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0), ptr(valid), B, H, W,
-             ptr(scratch), ptr(both), ptr(loss), stream())
-        ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid, both)
-        return loss
+        call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1), dt0.stride(0), ptr(valid),
+             B, H, W, ptr(scratch), ptr(both), ptr(loss), stream())
+        ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid, both)
+        ctx.mark_non_differentiable(both)
+        return loss, both
 
     @staticmethod
-    def backward(ctx, g_loss):
-        shaded, dino, image_gt, dino_gt, mask_gt, dt0, valid, both = ctx.saved_tensors
+    def backward(ctx, g_loss, _g_both=None):
+        shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid, both = ctx.saved_tensors
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
         g_shaded = torch.empty_like(shaded)
         g_dino = torch.empty_like(dino) if D else None
-        call("a3d_recon_losses_bwd", ptr(f32c(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), dt0.stride(0),
-             ptr(valid), B, H, W, ptr(both), ptr(g_shaded), ptr(g_dino), stream())
-        return g_shaded, g_dino, None, None, None, None, None
+        call("a3d_recon_losses_bwd", ptr(f32c(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1),
+             dt0.stride(0), ptr(valid), B, H, W, ptr(both), ptr(g_shaded), ptr(g_dino), stream())
+        return g_shaded, g_dino, None, None, None, None, None, None
 
 
-def reconstruction_losses(shaded_nchw, dino_nchw, image_gt, dino_gt, mask_gt, mask_dt, mask_valid):
-    """Per-image [B,4] = (mask, mask_inv_dt, rgb, dino) losses of compute_reconstruction_losses (AnimalModel.py:260-307; F=1,
-    background_mode 'none') from render_mesh's outputs: ``shaded_nchw`` [B,4,H,W] and ``dino_nchw`` [B,D,H,W] (or None) are the NCHW
-    views render_mesh returns (NHWC in memory -- read in place, no copy); targets in the dataset's NCHW layout; mask_dt [B,2,H,W]."""
+def reconstruction_losses(shaded_nchw, dino_nchw, image_gt, dino_gt, mask_gt, mask_dt, mask_valid, return_mask=False):
+    """Per-frame [N,5] = (mask, mask_inv_dt, rgb, dino, mask_dt) losses of compute_reconstruction_losses (AnimalModel.py:260-307,
+    background_mode 'none'; N = images x frames) from render_mesh's outputs: ``shaded_nchw`` [N,4,H,W] and ``dino_nchw`` [N,D,H,W] (or
+    None) are the NCHW views render_mesh returns (NHWC in memory -- read in place, no copy); targets in the dataset's NCHW layout;
+    mask_dt [N,2,H,W].  ``return_mask=True`` also returns the eroded common mask (uint8 [N*H*W]) that :func:`flow_loss` needs."""
     shaded = shaded_nchw.permute(0, 2, 3, 1)
     shaded = shaded if shaded.is_contiguous() else shaded.contiguous()
     dino = None
     if dino_nchw is not None:
         dino = dino_nchw.permute(0, 2, 3, 1)
         dino = dino if dino.is_contiguous() else dino.contiguous()
-    return _ReconLosses.apply(shaded, dino, image_gt, dino_gt, mask_gt, mask_dt[:, 0], mask_valid)
+    loss, both = _ReconLosses.apply(shaded, dino, image_gt, dino_gt, mask_gt, mask_dt[:, 0], mask_dt[:, 1], mask_valid)
+    return (loss, both) if return_mask else loss
+
+
+class _FlowLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, flow_gt, both, B, F):
+        require_device(flow, flow_gt, both, what="flow_loss")
+        N, H, W = flow.shape[:3]
+        assert N == B * F and F >= 2 and flow.shape[3] == 2 and flow.stride(3) == 1 and flow.stride(1) == W * flow.stride(2) \
+            and flow.stride(0) == H * flow.stride(1), "flow must be the renderer's NHWC buffer (channel slice allowed)"
+        flow_gt = f32c(flow_gt)
+        assert flow_gt.shape == (B, F - 1, 2, H, W) and both.numel() == N * H * W
+        loss = torch.empty((B, F - 1), dtype=torch.float32, device=flow.device)
+        scale = torch.empty_like(loss)
+        scratch = torch.empty(_lib.lib().a3d_flow_loss_scratch_bytes(B, F, H, W), dtype=torch.uint8, device=flow.device)
+        call("a3d_flow_loss_fwd", ptr(flow), flow.stride(2), ptr(flow_gt), ptr(both), B, F, H, W, ptr(scratch), ptr(loss), ptr(scale), stream())
+        ctx.save_for_backward(flow, flow_gt, both, scale)
+        ctx.dims = (B, F, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        flow, flow_gt, both, scale = ctx.saved_tensors
+        B, F, H, W = ctx.dims
+        g_flow = torch.empty((B * F, H, W, 2), dtype=torch.float32, device=flow.device)
+        call("a3d_flow_loss_bwd", ptr(f32c(g_loss)), ptr(scale), ptr(flow), flow.stride(2), ptr(flow_gt), ptr(both), B, F, H, W, ptr(g_flow), stream())
+        return g_flow, None, None, None, None
+
+
+def flow_loss(flow_nchw, flow_gt, both, batch, num_frames):
+    """[B,F-1] flow loss between consecutive frames (AnimalModel.py:285-298) from render_mesh's 'flow' output [B*F,2,H,W] (the NCHW
+    view of the renderer's NHWC buffer, read in place), flow_gt [B,F-1,2,H,W] and the eroded common mask of
+    :func:`reconstruction_losses` (``return_mask=True``)."""
+    return _FlowLoss.apply(flow_nchw.permute(0, 2, 3, 1), flow_gt, both, int(batch), int(num_frames))
 
 
 # ---------------------------------------------------------------------------------------------- harmonic embedding

@@ -227,8 +227,10 @@ class SyntheticScene(torch.nn.Module):
         if FUSED_LOSSES and shaded.is_cuda:
             from . import ops
 
-            per_image = ops.reconstruction_losses(shaded, dino_pred, self.image_gt, self.dino_gt, self.mask_gt, self.mask_dt, self.mask_valid)
+            per_image, self._both = ops.reconstruction_losses(shaded, dino_pred, self.image_gt, self.dino_gt, self.mask_gt, self.mask_dt,
+                                                               self.mask_valid, return_mask=True)
             return {k: per_image[:, i] for i, k in enumerate(("mask", "mask_inv_dt", "rgb", "dino"))}
+        self._both = None
         return self.losses_torch(shaded, dino_pred)
 
     def losses_torch(self, shaded, dino_pred):
@@ -251,7 +253,11 @@ class SyntheticScene(torch.nn.Module):
         flow exceeds 0.5 anywhere on the mask dropped, normalised by the mask's pixel count.  flow_pred [B*F,2,H,W]."""
         B, F = self.batch, self.num_frames
         H, W = self.resolution
-        pred = flow_pred.view(B, F, 2, H, W)[:, :-1]
+        if FUSED_LOSSES and flow_pred.is_cuda and getattr(self, "_both", None) is not None:
+            from . import ops
+
+            return ops.flow_loss(flow_pred, self.flow_gt, self._both, B, F)  # one HIP kernel each way (csrc/losses.hip)
+        pred = flow_pred.reshape(B, F, 2, H, W)[:, :-1]
         both = self.eroded_mask(mask_pred).view(B, F, H, W)[:, :-1].unsqueeze(2).expand_as(self.flow_gt)
         large = ((self.flow_gt.abs() > 0.5).float() * both).reshape(B, F - 1, -1).sum(2) > 0
         err = (pred - self.flow_gt) ** 2 * both * (~large).float()[:, :, None, None, None]

@@ -229,19 +229,30 @@ int a3d_harmonic_embed_bwd(const float* g_out, const float* x, const float* freq
 
 /* ------------------------------------------------------------------------------------------------
  * Reconstruction losses -- the image-space consumers of render_mesh's outputs, fused:
- * /root/reference/model/models/AnimalModel.py:260-307 (compute_reconstruction_losses; F = 1, background_mode 'none').
+ * /root/reference/model/models/AnimalModel.py:260-307 (compute_reconstruction_losses, background_mode 'none'; B here = images x frames).
  * shaded[B,H,W,4] / dino[B,H,W,D] = the renderer's NHWC buffers (D = 0: no DINO term); image_gt[B,3,H,W], dino_gt[B,D,H,W],
- * mask_gt / valid [B,H,W], dt0 = mask_dt[:,0] with image stride dt_stride floats.  loss[B,4] = per-image mask, mask_inv_dt, rgb,
- * dino.  bwd: g_loss[B,4] -> g_shaded[B,H,W,4], g_dino[B,H,W,D] (every element written).
+ * mask_gt / valid [B,H,W], dt0 = mask_dt[:,0] and dt1 = mask_dt[:,1] (may be NULL) with image stride dt_stride floats.
+ * loss[B,a3d_recon_losses_columns()] = per-image mask, mask_inv_dt, rgb, dino, mask_dt.  bwd: g_loss -> g_shaded[B,H,W,4],
+ * g_dino[B,H,W,D] (every element written).  both[B*H*W] = the eroded common mask, written by fwd, read by bwd and by the flow loss.
+ *
+ * Flow loss between consecutive frames (AnimalModel.py:285-298): flow = the renderer's 'flow' buffer over B*F frames with pix_stride
+ * floats per pixel (3: two flow channels + alpha), flow_gt[B,F-1,2,H,W]; loss[B,F-1]; scale[B,F-1] is kept for the backward;
+ * g_flow[B*F,H,W,2] (every element written; the last frame of a sequence gets zeros).
  */
 size_t a3d_recon_losses_scratch_bytes(int B, int H, int W);
-size_t a3d_recon_losses_mask_bytes(int B, int H, int W); /* the eroded 'both' mask, written by fwd and read by bwd */
+size_t a3d_recon_losses_mask_bytes(int B, int H, int W);
+int a3d_recon_losses_columns(void);
 int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt, const float* mask_gt,
-                         const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch, uint8_t* both,
-                         float* loss, a3d_stream_t stream);
+                         const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch,
+                         uint8_t* both, float* loss, a3d_stream_t stream);
 int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
-                         const float* mask_gt, const float* dt0, int64_t dt_stride, const float* valid, int B, int H, int W,
-                         const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream);
+                         const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B, int H,
+                         int W, const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream);
+size_t a3d_flow_loss_scratch_bytes(int B, int F, int H, int W);
+int a3d_flow_loss_fwd(const float* flow, int pix_stride, const float* flow_gt, const uint8_t* both, int B, int F, int H, int W, void* scratch,
+                      float* loss, float* scale, a3d_stream_t stream);
+int a3d_flow_loss_bwd(const float* g_loss, const float* scale, const float* flow, int pix_stride, const float* flow_gt, const uint8_t* both,
+                      int B, int F, int H, int W, float* g_flow, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -287,6 +287,52 @@ def main():
     except Exception as e:
         g7["unknown_mode_error"] = np.array(type(e).__name__)
     save("render_mesh_e2e.npz", **g7, **sd)
+
+    # ------------------------------------------------------------------ G8: AnimalModel.render -- the sole training-time caller (a13)
+    # (AnimalModel.py:217-258, called unbound with a minimal stand-in for self: background image, lazily created context, spp from
+    # cfg_render, render_mesh(..., num_layers=1, msaa=True); the oracle operators stand in for nvdiffrast as in G7)
+    from types import SimpleNamespace
+
+    from model.models import AnimalModel as _am_mod
+
+    ref_am = _am_mod if hasattr(_am_mod, "AnimalModel") and not isinstance(_am_mod, type) else SimpleNamespace(AnimalModel=_am_mod)
+
+    dummy = SimpleNamespace(cfg_render=SimpleNamespace(background_mode="none", renderer_spp=1), glctx=None)
+    g8 = {}
+    with torch.no_grad():
+        for tag, bgmode in (("none", None), ("white", "white")):
+            outs = ref_am.AnimalModel.render(dummy, ["shaded", "dino_pred"], shape7, tex, mvp7, w2c7, campos7, (H, W), background=bgmode,
+                                             im_features=feat7, light=lgt, prior_shape=prior7, dino_net=dino)
+            g8[f"{tag}_shaded"], g8[f"{tag}_dino_pred"] = outs[0].contiguous().numpy(), outs[1].contiguous().numpy()
+    g8["context_created"] = np.array(dummy.glctx is not None)
+    save("animal_model_render.npz", **g8)
+
+    # ------------------------------------------------------------------ G9: AnimalModel.compute_reconstruction_losses (a14 / f3)
+    def recon_case(b, f, with_flow, seed):
+        gen = torch.Generator().manual_seed(seed)
+        r = lambda *shape: torch.rand(*shape, generator=gen)
+        h = w = 16
+        c = dict(image_pred=r(b, f, 3, h, w), image_gt=r(b, f, 3, h, w), mask_pred=r(b, f, h, w), mask_gt=(r(b, f, h, w) > 0.4).float(),
+                 mask_dt=r(b, f, 2, h, w), mask_valid=(r(b, f, h, w) > 0.1).float(), dino_gt=r(b, f, 16, h, w), dino_pred=r(b, f, 16, h, w))
+        # a rendered mask is mostly exactly 0 or 1: reproduce that so that the erosion / (mask > 0) logic is exercised
+        hard = (r(b, f, h, w) > 0.5).float()
+        soft = r(b, f, h, w) < 0.15
+        c["mask_pred"] = torch.where(soft, c["mask_pred"], hard)
+        for k in ("mask_pred", "mask_gt", "mask_valid"):  # a solid patch, so that the eroded common mask is not empty
+            c[k][..., 3:11, 2:12] = 1.0
+        c["flow_pred"] = (r(b, f - 1, 2, h, w) - 0.5) * 0.4 if with_flow else None
+        c["flow_gt"] = (r(b, f - 1, 2, h, w) - 0.5) * 0.8 if with_flow else None
+        if with_flow:  # one frame pair carries a target flow above 0.5 on the mask: the reference drops that pair (AnimalModel.py:290-294)
+            c["flow_gt"][0, 1, 1, 6, 6] = 0.9
+        out = ref_am.AnimalModel.compute_reconstruction_losses(SimpleNamespace(), c["image_pred"], c["image_gt"], c["mask_pred"], c["mask_gt"],
+                                                               c["mask_dt"], c["mask_valid"], c["flow_pred"], c["flow_gt"], c["dino_gt"],
+                                                               c["dino_pred"], background_mode="none", reduce=False)
+        return {**{f"in_{k}": v.numpy() for k, v in c.items() if v is not None}, **{f"out_{k}": v.numpy() for k, v in out.items()}}
+
+    g9 = {}
+    for tag, args in (("b3f1", (3, 1, False, 90)), ("b2f4_flow", (2, 4, True, 91))):
+        g9.update({f"{tag}_{k}": v for k, v in recon_case(*args).items()})
+    save("recon_losses.npz", **g9)
     print("golden vectors written to", HERE)
 
 

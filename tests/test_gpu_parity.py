@@ -990,7 +990,7 @@ def test_ddp_wrapper_over_rccl_gives_the_same_gradients(dev):
 
 @pytest.mark.parametrize("with_dino,hw", [(True, (64, 64)), (False, (40, 24)), (True, (17, 33))])
 def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev, ops):
-    """csrc/losses.hip against the four torch expressions of compute_reconstruction_losses (AnimalModel.py:260-307), values and
+    """csrc/losses.hip against the five torch expressions of compute_reconstruction_losses (AnimalModel.py:260-307), values and
     both image gradients; the eroded 'both' mask is integer logic and must agree exactly."""
     B, (H, W), D = 3, hw, 16
     g = torch.Generator().manual_seed(H * W + with_dino)
@@ -1002,7 +1002,7 @@ def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev,
     mask_gt = (torch.rand(B, H, W, generator=g) > 0.3).float()
     mask_gt[:, 4:13, 2:16] = 1.0
     mask_dt, valid = torch.rand(B, 2, H, W, generator=g), (torch.rand(B, H, W, generator=g) > 0.1).float()
-    w = torch.rand(B, 4, generator=g) + 0.5
+    w = torch.rand(B, 5, generator=g) + 0.5
 
     def torch_losses(shaded, dino):
         image_pred, mask_pred = shaded[:, :3], shaded[:, 3]
@@ -1011,6 +1011,7 @@ def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev,
         both = (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
         out.append(((image_pred - image_gt_d).abs() * both.unsqueeze(1)).flatten(1).mean(1))
         out.append((((dino - dino_gt_d) ** 2) * both.unsqueeze(1)).flatten(1).mean(1) if dino is not None else torch.zeros_like(out[0]))
+        out.append((mask_pred * mask_dt_d[:, 1]).flatten(1).mean(1))  # mask_dt_loss (AnimalModel.py:268)
         return torch.stack(out, 1), both
 
     image_gt_d, dino_gt_d, mask_gt_d, mask_dt_d, valid_d = (t.to(dev) for t in (image_gt, dino_gt, mask_gt, mask_dt, valid))
@@ -1031,6 +1032,64 @@ def test_fused_reconstruction_losses_match_torch_formulation(with_dino, hw, dev,
     assert torch.allclose(gsa, gsb, rtol=1e-5, atol=1e-9)
     if with_dino:
         assert torch.allclose(gda, gdb, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["b3f1", "b2f4_flow"])
+def test_fused_losses_match_reference_compute_reconstruction_losses_golden(tag, dev, ops):
+    """G9: csrc/losses.hip (all six terms: mask, mask_dt, mask_inv_dt, rgb, flow, dino; F = 1 and F = 4) against the outputs of the
+    REFERENCE's AnimalModel.compute_reconstruction_losses (imported in the build container, tests/golden/make_golden.py)."""
+    g = golden("recon_losses.npz")
+    t = lambda k: torch.from_numpy(g[f"{tag}_in_{k}"]).to(dev)
+    image_pred, mask_pred = t("image_pred"), t("mask_pred")
+    B, F, _, H, W = image_pred.shape
+    N = B * F
+    # the renderer's layout: NHWC buffers, handed over as NCHW views
+    shaded = torch.cat([image_pred.view(N, 3, H, W), mask_pred.view(N, 1, H, W)], 1).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    dino = t("dino_pred").view(N, 16, H, W).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    loss, both = ops.reconstruction_losses(shaded.permute(0, 3, 1, 2), dino.permute(0, 3, 1, 2), t("image_gt").view(N, 3, H, W),
+                                           t("dino_gt").view(N, 16, H, W), t("mask_gt").view(N, H, W), t("mask_dt").view(N, 2, H, W),
+                                           t("mask_valid").view(N, H, W), return_mask=True)
+    cols = dict(mask_loss=0, mask_inv_dt_loss=1, rgb_loss=2, dino_feat_im_loss=3, mask_dt_loss=4)
+    for name, c in cols.items():
+        np.testing.assert_allclose(loss[:, c].detach().cpu().view(B, F).numpy(), g[f"{tag}_out_{name}"], rtol=2e-5, atol=1e-7, err_msg=name)
+    if f"{tag}_in_flow_pred" in g.files:
+        flow3 = torch.cat([t("flow_pred"), torch.zeros(B, 1, 2, H, W, device=dev)], 1).view(N, 2, H, W)  # last frame: no pair
+        buf = torch.cat([flow3.permute(0, 2, 3, 1), torch.ones(N, H, W, 1, device=dev)], -1).contiguous().requires_grad_(True)  # [N,H,W,3] as rendered
+        fl = ops.flow_loss(buf[..., :2].permute(0, 3, 1, 2), t("flow_gt"), both, B, F)
+        ref = g[f"{tag}_out_flow_loss"]
+        assert (ref == 0).any() and (ref > 0).any()  # the fixture exercises the large-flow rule both ways
+        np.testing.assert_allclose(fl.detach().cpu().numpy(), ref, rtol=2e-5, atol=1e-8)
+        fl.sum().backward()
+        assert float(buf.grad[..., 2].abs().max()) == 0 and float(buf.grad.view(B, F, H, W, 3)[:, -1].abs().max()) == 0
+        assert float(buf.grad.abs().max()) > 0
+
+
+def test_animal_model_render_golden(dev, mods):
+    """G8: what the sole training-time caller, AnimalModel.render (AnimalModel.py:217-258), returns in the reference
+    -- background image by mode, render_mesh(spp=1, num_layers=1, msaa=True) -- against the product's render_mesh called the same way."""
+    import copy
+
+    from test_oracle_golden import _load_nets
+
+    g7, g8 = golden("render_mesh_e2e.npz"), golden("animal_model_render.npz")
+    assert bool(g8["context_created"])
+    tex, dino, lgt = (copy.deepcopy(m).to(dev) for m in _load_nets(None, g7))
+    t = lambda k: torch.from_numpy(g7[k]).to(dev)
+    M, faces = mods["mesh"], t("faces")
+    B = g7["v_pos"].shape[0]
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    shape = M.make_mesh(t("v_pos"), faces[None], uvs.expand(B, -1, -1), uvi, None)
+    prior = M.make_mesh(t("prior_v_pos")[None], faces[None], uvs, uvi, None)
+    for tag, bg in (("none", torch.zeros), ("white", torch.ones)):
+        bg_image = bg((B, 32, 32, 3), device=dev)  # AnimalModel.py:226-229
+        with torch.no_grad():
+            outs = mods["render"].render_mesh(None, shape, mtx_in=t("mvp"), w2c=t("w2c"), view_pos=t("campos"), material=tex, lgt=lgt,
+                                              resolution=(32, 32), spp=1, num_layers=1, msaa=True, background=bg_image, bsdf="diffuse",
+                                              feat=t("feat"), render_modes=["shaded", "dino_pred"], prior_mesh=prior, two_sided_shading=True,
+                                              dino_net=dino, num_frames=None, class_vector=None)
+        np.testing.assert_allclose(outs[0].cpu().numpy(), g8[f"{tag}_shaded"], atol=1e-4, err_msg=tag)
+        np.testing.assert_allclose(outs[1].cpu().numpy(), g8[f"{tag}_dino_pred"], atol=1e-4, err_msg=tag)
 
 
 @pytest.mark.parametrize("bone_y_threshold", [None, 0.4])

@@ -1,0 +1,264 @@
+"""Derived known-answer tests for rasterise / interpolate / antialias (forward AND gradient) that do not call oracle/raster_ref.
+
+nvdiffrast is absent and un-pinned ("parity unpinned"), so the oracle for these three operators is this project's
+own restatement of the published semantics.  The tests below pin the kernels against closed forms instead -- identities and analytic
+values that follow from the operator definitions -- so that an error shared by kernel and oracle cannot hide.
+Everything goes through the C ABI (3danimals_amd.ops).  Float64 torch expressions written out in the tests are the closed forms.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return importlib.import_module("3danimals_amd.ops")
+
+
+def _centres(H, W):
+    """NDC coordinates of the pixel centres: column j <-> x = (j + 0.5) * 2 / W - 1, row i <-> y = (i + 0.5) * 2 / H - 1."""
+    ys = (torch.arange(H, dtype=torch.float64) + 0.5) * 2 / H - 1
+    xs = (torch.arange(W, dtype=torch.float64) + 0.5) * 2 / W - 1
+    return torch.meshgrid(ys, xs, indexing="ij")
+
+
+# ------------------------------------------------------------------------------------------------ rasterise
+def test_rasterize_perspective_correct_barycentrics_unequal_w(dev, ops):
+    """(u, v, 1-u-v) are PERSPECTIVE-correct: sum_i b_i * (x_i - fx * w_i) = 0 and likewise for y at every covered pixel, and
+    z/w = sum b_i z_i / sum b_i w_i.  With w = (1, 3, 0.6) they differ from the screen-space (affine) weights by > 0.1."""
+    H = W = 64
+    pos = torch.tensor([[[-0.8, -0.7, 0.1, 1.0], [2.4, -0.3, 0.9, 3.0], [-0.06, 0.54, -0.12, 0.6]]])  # NDC (-.8,-.7) (.8,-.1) (-.1,.9)
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    rast = ops.rasterize(pos.to(dev), tri.to(dev), (H, W)).cpu().double()[0]
+    cov = rast[..., 3] > 0
+    assert 300 < int(cov.sum()) < 1500
+    fy, fx = _centres(H, W)
+    p = pos[0].double()
+    u, v = rast[..., 0], rast[..., 1]
+    b = torch.stack([u, v, 1 - u - v], -1)
+    rx = (b * (p[:, 0] - fx[..., None] * p[:, 3])).sum(-1)
+    ry = (b * (p[:, 1] - fy[..., None] * p[:, 3])).sum(-1)
+    assert float(rx[cov].abs().max()) < 2e-6 and float(ry[cov].abs().max()) < 2e-6
+    zw = (b * p[:, 2]).sum(-1) / (b * p[:, 3]).sum(-1)
+    assert float((zw - rast[..., 2])[cov].abs().max()) < 2e-6
+    assert float(b[cov].min()) >= 0 and float(b[cov].max()) <= 1
+    # the affine weights of the projected triangle are something else
+    s = p[:, :2] / p[:, 3:]
+    den = (s[1, 1] - s[2, 1]) * (s[0, 0] - s[2, 0]) + (s[2, 0] - s[1, 0]) * (s[0, 1] - s[2, 1])
+    lam0 = ((s[1, 1] - s[2, 1]) * (fx - s[2, 0]) + (s[2, 0] - s[1, 0]) * (fy - s[2, 1])) / den
+    assert float((lam0 - u)[cov].abs().max()) > 0.1
+    # coverage = the pixel centres inside the projected triangle (none of them within 1e-6 of an edge here)
+    lam1 = ((s[2, 1] - s[0, 1]) * (fx - s[2, 0]) + (s[0, 0] - s[2, 0]) * (fy - s[2, 1])) / den
+    inside = (lam0 > 0) & (lam1 > 0) & (1 - lam0 - lam1 > 0)
+    assert torch.equal(inside, cov)
+
+
+def test_rasterize_image_orientation_row0_is_ndc_y_minus_one(dev, ops):
+    """Row 0 is NDC y = -1 and column 0 is NDC x = -1 (the OpenGL convention nvdiffrast returns; the reference's projection flips y,
+    util.py:192, so that images come out upright)."""
+    H, W = 32, 48
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32)
+    low = torch.tensor([[[-1.0, -1.0, 0, 1], [1.0, -1.0, 0, 1], [1.0, -0.5, 0, 1], [-1.0, -0.5, 0, 1]]])  # the band y in [-1, -0.5]
+    r = ops.rasterize(low.to(dev), tri.to(dev), (H, W)).cpu()[0, ..., 3] > 0
+    assert bool(r[: H // 4].all()) and not bool(r[H // 4:].any())
+    left = torch.tensor([[[-1.0, -1.0, 0, 1], [-0.5, -1.0, 0, 1], [-0.5, 1.0, 0, 1], [-1.0, 1.0, 0, 1]]])  # the band x in [-1, -0.5]
+    r = ops.rasterize(left.to(dev), tri.to(dev), (H, W)).cpu()[0, ..., 3] > 0
+    assert bool(r[:, : W // 4].all()) and not bool(r[:, W // 4:].any())
+
+
+def test_rasterize_depth_test_and_depth_tie_goes_to_lower_id(dev, ops):
+    H = W = 16
+    quad = lambda z: [[-0.9, -0.9, z, 1.0], [0.9, -0.9, z, 1.0], [0.9, 0.9, z, 1.0], [-0.9, 0.9, z, 1.0]]
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], dtype=torch.int32)
+    for z_first, z_second, winners in ((0.5, -0.5, {3, 4}), (-0.5, 0.5, {1, 2}), (0.25, 0.25, {1, 2})):  # nearer wins; a tie -> lower id
+        pos = torch.tensor([quad(z_first) + quad(z_second)])
+        r = ops.rasterize(pos.to(dev), tri.to(dev), (H, W)).cpu()[0]
+        ids = set(r[..., 3][r[..., 3] > 0].int().tolist())
+        assert ids == winners, (z_first, z_second, ids)
+        assert torch.allclose(r[..., 2][r[..., 3] > 0], torch.tensor(min(z_first, z_second)))
+
+
+@pytest.mark.parametrize("axis", ["x", "y"])
+def test_rasterize_shared_edge_through_pixel_centres_is_owned_exactly_once(axis, dev, ops):
+    """Two quads share an edge that runs exactly through a line of pixel centres: every such pixel belongs to exactly one of the two
+    (no hole, no double hit) and the same side owns the whole line; swapping the triangle order does not change the owner."""
+    H = W = 32
+    k = 12
+    e = (k + 0.5) * 2 / W - 1  # exactly representable
+    if axis == "x":
+        a = [[-1.0, -1.0, 0, 1], [e, -1.0, 0, 1], [e, 1.0, 0, 1], [-1.0, 1.0, 0, 1]]
+        b = [[e, -1.0, 0, 1], [1.0, -1.0, 0, 1], [1.0, 1.0, 0, 1], [e, 1.0, 0, 1]]
+    else:
+        a = [[-1.0, -1.0, 0, 1], [1.0, -1.0, 0, 1], [1.0, e, 0, 1], [-1.0, e, 0, 1]]
+        b = [[-1.0, e, 0, 1], [1.0, e, 0, 1], [1.0, 1.0, 0, 1], [-1.0, 1.0, 0, 1]]
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], dtype=torch.int32)
+    owners = []
+    for order in ((a, b), (b, a)):
+        r = ops.rasterize(torch.tensor([order[0] + order[1]]).to(dev), tri.to(dev), (H, W)).cpu()[0, ..., 3]
+        assert bool((r > 0).all())  # watertight
+        line = r[:, k] if axis == "x" else r[k, :]
+        first_quad = line <= 2
+        assert bool(first_quad.all()) or bool((~first_quad).all())
+        owners.append(bool(first_quad.all()) == (order[0] is a))  # True: quad `a` owns the line
+    assert owners[0] == owners[1]
+
+
+def test_rasterize_backward_matches_float64_autograd_of_the_definition(dev, ops):
+    """d(u, v)/d(clip) against float64 autograd of the DEFINITION u = a0/(a0+a1+a2), a_i = q_j x q_k, q_i = p_i.xy - f * p_i.w
+    (Appendix A), evaluated on the pixels the kernel covered -- unequal w, so x, y AND w gradients are exercised."""
+    H = W = 48
+    pos = torch.tensor([[[-0.7, -0.8, 0.2, 1.0], [1.6, -0.4, 0.5, 2.0], [0.1, 0.63, 0.1, 0.7]]])
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    p_gpu = pos.clone().to(dev).requires_grad_(True)
+    rast = ops.rasterize(p_gpu, tri.to(dev), (H, W))
+    g = torch.rand(1, H, W, 4, generator=torch.Generator().manual_seed(3)) - 0.5
+    (rast[..., :2] * g[..., :2].to(dev)).sum().backward()
+    cov = rast.detach().cpu()[0, ..., 3] > 0
+    fy, fx = _centres(H, W)
+    p = pos[0].detach().double().clone().requires_grad_(True)
+    q = p[:, None, None, :2] - torch.stack([fx, fy], -1)[None] * p[:, None, None, 3:]
+    cross = lambda a, b: a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    a0, a1, a2 = cross(q[1], q[2]), cross(q[2], q[0]), cross(q[0], q[1])
+    s = a0 + a1 + a2
+    ((a0 / s * g[0, ..., 0].double() + a1 / s * g[0, ..., 1].double()) * cov).sum().backward()
+    got, want = p_gpu.grad.cpu()[0].double(), p.grad
+    assert float(want.abs().max()) > 1
+    np.testing.assert_allclose(got[:, [0, 1, 3]].numpy(), want[:, [0, 1, 3]].numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+    assert float(got[:, 2].abs().max()) == 0  # z does not enter the barycentrics
+
+
+# ------------------------------------------------------------------------------------------------ interpolate
+def test_interpolate_reproduces_an_affine_function_and_its_broadcast_gradient(dev, ops):
+    """Attribute = an affine function of NDC position -> the interpolated value at every covered pixel is that function of the pixel
+    centre (w = 1).  The attribute is [1,V,C], broadcast over B = 3 images with different coverage; its gradient for L = sum(out * g)
+    is sum over images and pixels of g * barycentric weight -- written out in float64 from the 2-D geometry."""
+    H = W = 40
+    B = 3
+    xy = torch.tensor([[-0.8, -0.6], [0.9, -0.2], [-0.3, 0.85], [0.7, 0.8]], dtype=torch.float64)
+    shift = torch.tensor([[0.0, 0.0], [0.05, -0.1], [-0.12, 0.07]], dtype=torch.float64)
+    pos = torch.zeros(B, 4, 4, dtype=torch.float64)
+    pos[..., :2] = xy[None] + shift[:, None]
+    pos[..., 3] = 1
+    tri = torch.tensor([[0, 1, 2], [1, 3, 2]], dtype=torch.int32)
+    A = torch.tensor([[2.0, -1.0, 0.5], [0.3, 0.7, -1.1]], dtype=torch.float64)  # attribute c = A[c] . (x, y, 1) of the UNSHIFTED vertex
+    attr = (torch.cat([xy, torch.ones(4, 1, dtype=torch.float64)], -1) @ A.T)[None].float()  # [1,4,2]
+    rast = ops.rasterize(pos.float().to(dev), tri.to(dev), (H, W))
+    a_gpu = attr.clone().to(dev).requires_grad_(True)
+    out = ops.interpolate(a_gpu, rast, tri.to(dev))
+    g = torch.rand(B, H, W, 2, generator=torch.Generator().manual_seed(5)) - 0.5
+    (out * g.to(dev)).sum().backward()
+    fy, fx = _centres(H, W)
+    ids = rast.detach().cpu()[..., 3].long()
+    want_grad = torch.zeros(4, 2, dtype=torch.float64)
+    for b in range(B):
+        cov = ids[b] > 0
+        # forward: the affine function at the pixel centre, in the vertex frame of image b (vertices moved by shift[b])
+        expect = torch.stack([A[c, 0] * (fx - shift[b, 0]) + A[c, 1] * (fy - shift[b, 1]) + A[c, 2] for c in range(2)], -1)
+        assert float((out.detach().cpu()[b].double() - expect)[cov].abs().max()) < 2e-5
+        assert float(out.detach().cpu()[b][~cov].abs().max()) == 0
+        for t in range(2):
+            m = ids[b] == t + 1
+            v = pos[b, tri[t].long(), :2]
+            den = (v[1, 1] - v[2, 1]) * (v[0, 0] - v[2, 0]) + (v[2, 0] - v[1, 0]) * (v[0, 1] - v[2, 1])
+            l0 = ((v[1, 1] - v[2, 1]) * (fx - v[2, 0]) + (v[2, 0] - v[1, 0]) * (fy - v[2, 1])) / den
+            l1 = ((v[2, 1] - v[0, 1]) * (fx - v[2, 0]) + (v[0, 0] - v[2, 0]) * (fy - v[2, 1])) / den
+            for lam, vi in ((l0, tri[t, 0]), (l1, tri[t, 1]), (1 - l0 - l1, tri[t, 2])):
+                want_grad[vi] += ((lam * m)[..., None] * g[b].double()).sum((0, 1))
+    np.testing.assert_allclose(a_gpu.grad.cpu()[0].double().numpy(), want_grad.numpy(), rtol=1e-4, atol=1e-4)
+    # barycentrics sum to one: the total gradient of a constant-1 upstream is the number of covered pixels
+    a2 = attr.clone().to(dev).requires_grad_(True)
+    ops.interpolate(a2, rast, tri.to(dev)).sum().backward()
+    total = 2 * int((ids > 0).sum())  # C = 2 channels
+    assert abs(float(a2.grad.double().sum()) - total) < 2e-4 * total
+
+
+# ------------------------------------------------------------------------------------------------ antialias
+def _edge_scene(axis, k, frac, H, W, fold=None):
+    """A surface covering everything on the low side of coordinate (k + frac) pixels along ``axis`` (two triangles, vertices far
+    outside the view).  ``fold`` adds a third triangle on the silhouette edge: 'back' = folded back under the surface (deeper),
+    'forward' = continuing the surface past the edge."""
+    e = (k + frac) / (W if axis == "x" else H) * 2 - 1
+    verts = [[-3.0, -3.0, 0.0, 1.0], [e, -3.0, 0.0, 1.0], [e, 3.0, 0.0, 1.0], [-3.0, 3.0, 0.0, 1.0]]
+    tris = [[0, 1, 2], [0, 2, 3]]
+    if fold == "back":
+        verts.append([-2.0, 0.0, 0.5, 1.0])  # behind the surface, same side of the edge
+        tris.append([1, 4, 2])
+    elif fold == "forward":
+        verts.append([3.0, 0.0, 0.0, 1.0])  # the surface goes on: the edge is interior
+        tris.append([1, 4, 2])
+    pos = torch.tensor([verts])
+    if axis == "y":
+        pos = pos[..., [1, 0, 2, 3]].contiguous()
+    return pos, torch.tensor(tris, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("axis,frac", [("x", 0.3), ("y", 0.3), ("x", 0.8), ("y", 0.65)])
+def test_antialias_straight_silhouette_known_answer(axis, frac, dev, ops):
+    """Silhouette at k + frac pixels.  frac < 0.5: pixel k (uncovered) takes ``frac`` of its covered neighbour k-1; frac > 0.5: pixel k
+    IS covered and gives 1 - frac of itself away to the background colour of pixel k+1 -- i.e. it keeps ``frac`` coverage."""
+    H = W = 16
+    k = 8
+    pos, tri = _edge_scene(axis, k, frac, H, W)
+    rast = ops.rasterize(pos.to(dev), tri.to(dev), (H, W))
+    cover = (rast[..., 3:] > 0).float()
+    out = ops.antialias(cover.contiguous(), rast, pos.to(dev), tri.to(dev)).cpu()[0, ..., 0]
+    line = (lambda j: out[2:-2, j]) if axis == "x" else (lambda j: out[j, 2:-2])
+    np.testing.assert_allclose(line(k).numpy(), frac, atol=1e-5)
+    np.testing.assert_allclose(line(k - 1).numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(line(k + 1).numpy(), 0.0, atol=1e-6)
+
+
+def test_antialias_fold_is_a_silhouette_and_an_interior_edge_is_not(dev, ops):
+    """The silhouette test of a NON-boundary edge: with a second triangle folded back under the surface the edge still antialiases
+    exactly like a boundary edge; with the second triangle continuing the surface it is interior and nothing is blended."""
+    H = W = 16
+    k = 8
+    pos, tri = _edge_scene("x", k, 0.3, H, W, fold="back")
+    rast = ops.rasterize(pos.to(dev), tri.to(dev), (H, W))
+    assert set(rast[0, :, :k, 3].int().unique().tolist()) <= {1, 2}  # the folded triangle is hidden behind the surface
+    cover = (rast[..., 3:] > 0).float()
+    out = ops.antialias(cover.contiguous(), rast, pos.to(dev), tri.to(dev)).cpu()[0, ..., 0]
+    np.testing.assert_allclose(out[2:-2, k].numpy(), 0.3, atol=1e-5)
+    pos, tri = _edge_scene("x", k, 0.3, H, W, fold="forward")
+    rast = ops.rasterize(pos.to(dev), tri.to(dev), (H, W))
+    colour = torch.where(rast[..., 3:] > 2.5, 0.25, 1.0) * (rast[..., 3:] > 0)  # the continuation has another colour
+    out = ops.antialias(colour.contiguous(), rast, pos.to(dev), tri.to(dev)).cpu()[0, ..., 0]
+    np.testing.assert_allclose(out[4:-4, k - 1].numpy(), 1.0, atol=1e-6)  # id discontinuity, but no silhouette: untouched
+    np.testing.assert_allclose(out[4:-4, k].numpy(), 0.25, atol=1e-6)
+
+
+def test_antialias_gradients_closed_form_vertical_edge(dev, ops):
+    """out[row, k] = frac * c_in + (1 - frac) * c_bg with frac = W/2 * (x_edge(row) + 1) - k, x_edge linear between the two edge
+    vertices.  Hence d sum_rows(out[:, k]) / d x_v = W/2 * (c_in - c_bg) * sum_rows t_v(row) (t_v = the vertex's interpolation weight
+    along the edge), d/d colour of the covered neighbour = frac, d/d colour of pixel k itself = 1 - frac."""
+    H = W = 16
+    k, frac = 8, 0.3
+    pos, tri = _edge_scene("x", k, frac, H, W)
+    p = pos.clone().to(dev).requires_grad_(True)
+    rast = ops.rasterize(p, tri.to(dev), (H, W)).detach()
+    c_in, c_bg = 0.9, 0.2
+    colour = (torch.where(rast[..., 3:] > 0, c_in, c_bg)).contiguous().clone().requires_grad_(True)
+    out = ops.antialias(colour, rast, p, tri.to(dev))
+    out[0, :, k, 0].sum().backward()
+    gc = colour.grad.cpu()[0, ..., 0]
+    np.testing.assert_allclose(gc[:, k - 1].numpy(), frac, atol=1e-5)
+    np.testing.assert_allclose(gc[:, k].numpy(), 1 - frac, atol=1e-5)
+    assert float(gc[:, :k - 1].abs().max()) == 0 and float(gc[:, k + 1:].abs().max()) == 0
+    ys = (torch.arange(H, dtype=torch.float64) + 0.5) * 2 / H - 1
+    t2 = (ys + 3) / 6  # weight of vertex 2 (y = +3) at each row; vertex 1 (y = -3) has 1 - t2
+    want1, want2 = W / 2 * (c_in - c_bg) * float((1 - t2).sum()), W / 2 * (c_in - c_bg) * float(t2.sum())
+    g = p.grad.cpu()[0]
+    np.testing.assert_allclose([float(g[1, 0]), float(g[2, 0])], [want1, want2], rtol=1e-4)
+    assert float(g[0].abs().max()) == 0 and float(g[3].abs().max()) == 0  # the far vertices do not move the silhouette
+    # moving a vertex ALONG the edge direction does not change a vertical edge's crossing
+    assert abs(float(g[1, 1])) < 1e-4 * want1 and abs(float(g[2, 1])) < 1e-4 * want2
