@@ -149,45 +149,45 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
             quadrants = [(xs - x0 > mx) & (zs - z0 > mz), (xs - x0 > mx) & (zs < z0), (xs - x0 < -mx) & (zs < z0),
                          (xs - x0 < -mx) & (zs - z0 > mz)]
 
-        def leg_joints_in(quadrant, body_bone_idx):
-            """Foot = lowest vertex of the quadrant (first one on ties, like indexing the masked subset), leg joints = linear blend
-            from the foot to the attachment joint of the body (skinning.py:177-199).  All (b, f) at once on the tensor's device: no
-            Python loop over instances and, once ``body_bone_idx`` is known (cached chain), no host synchronisation; the empty-
-            quadrant check is a device-side assert on the GPU."""
+        def foot_of(quadrant):
+            """Lowest vertex of the quadrant (first one on ties, like indexing the masked subset; skinning.py:177-186), all (b, f) at
+            once on the tensor's device; the empty-quadrant check is a device-side assert on the GPU."""
             populated = quadrant.any(dim=-1)
             if seq_shape.is_cuda:
                 torch._assert_async(populated.all(), "estimate_bones: no vertex in a leg quadrant (skinning.py:183)")
             elif not bool(populated.all()):
                 raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
             y_in = torch.where(quadrant, ys, torch.full_like(ys, float("inf")))
-            foot = torch.gather(seq_shape, 2, y_in.argmin(dim=-1)[..., None, None].expand(-1, -1, 1, 3))  # [B,F,1,3]
-            if body_bone_idx is None:  # fixed by the first instance and shared by all, as in the reference (:187-189)
-                body_bone_idx = int(torch.argmin((bones_pred[0, 0, :, 1, 2] - foot[0, 0, 0, 2]).abs()))
-            ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[None, None, :, None]
-            out = foot * (1 - ramp) + bones_pred[:, :, body_bone_idx, 1][:, :, None, :] * ramp
-            return out, body_bone_idx
+            return torch.gather(seq_shape, 2, y_in.argmin(dim=-1)[..., None, None].expand(-1, -1, 1, 3))  # [B,F,1,3]
 
+        feet = [foot_of(q) for q in quadrants]
+        ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[None, None, :, None]
         if legs_to_body_joint_indices is None:
             legs_to_body_joint_indices = [None, None, None, None]
+        if compute_kinematic_chain:
+            # attachment joint = the body joint nearest in z to the foot, fixed by the first instance and shared by all (:187-192); legs
+            # 2 / 3 reuse the joints of legs 1 / 0 (:213-216).  Whatever is not prescribed is found on the device and read back in ONE
+            # transfer -- the kinematic chain is a Python structure that depends on it, so this read-back is inherent when the chain is
+            # rebuilt (once per epoch; Fauna: every iteration); with a cached chain (compute_kinematic_chain=False) nothing is read back.
+            need = [i for i in (0, 1) if legs_to_body_joint_indices[i] is None]
+            if need:
+                nearest = torch.stack([torch.argmin((bones_pred[0, 0, :, 1, 2] - feet[i][0, 0, 0, 2]).abs()) for i in need]).tolist()
+                for i, j in zip(need, nearest):
+                    legs_to_body_joint_indices[i] = int(j)
         start = n_body_bones
         leg_bones_all = []
         leg_auxs = [] if compute_kinematic_chain else aux["legs"]
-        for i, quadrant in enumerate(quadrants):
+        for i in range(4):
             if compute_kinematic_chain:
-                body_bone_idx = legs_to_body_joint_indices[i]
-                if i == 2:
-                    body_bone_idx = legs_to_body_joint_indices[1]
-                elif i == 3:
-                    body_bone_idx = legs_to_body_joint_indices[0]
-                leg_joints, body_bone_idx = leg_joints_in(quadrant, body_bone_idx)
+                body_bone_idx = legs_to_body_joint_indices[1] if i == 2 else (legs_to_body_joint_indices[0] if i == 3 else legs_to_body_joint_indices[i])
                 legs_to_body_joint_indices[i] = body_bone_idx  # written back into the caller's list, as the reference does (:220)
                 leg_b2j, leg_chain, leg_ids = build_kinematic_chain(n_leg_bones, start_bone_idx=start)
                 kinematic_chain = update_body_kinematic_chain(kinematic_chain, leg_chain, body_bone_idx, leg_ids, attach_legs_to_body)
                 leg_auxs.append({"body_bone_idx": body_bone_idx, "leg_bones_to_joints": leg_b2j})
                 start += n_leg_bones
             else:
-                leg_joints, _ = leg_joints_in(quadrant, leg_auxs[i]["body_bone_idx"])
-                leg_b2j = leg_auxs[i]["leg_bones_to_joints"]
+                body_bone_idx, leg_b2j = leg_auxs[i]["body_bone_idx"], leg_auxs[i]["leg_bones_to_joints"]
+            leg_joints = feet[i] * (1 - ramp) + bones_pred[:, :, body_bone_idx, 1][:, :, None, :] * ramp
             leg_bones_all.append(_joints_to_bones(leg_joints, leg_b2j))
         all_bones = torch.cat([bones_pred] + leg_bones_all, dim=2)
     else:

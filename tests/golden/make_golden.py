@@ -333,6 +333,25 @@ def main():
     for tag, args in (("b3f1", (3, 1, False, 90)), ("b2f4_flow", (2, 4, True, 91))):
         g9.update({f"{tag}_{k}": v for k, v in recon_case(*args).items()})
     save("recon_losses.npz", **g9)
+
+    # ------------------------------------------------------------------ G10: the reference's OBJ writer (obj.py:128-177), f4 output side
+    import contextlib
+    import io
+    import tempfile
+
+    from model.render import obj as ref_obj
+
+    vq = qv[:40].clone()
+    mesh10 = SimpleNamespace(v_pos=torch.stack([vq, vq * 1.5 + 0.125]), v_nrm=torch.nn.functional.normalize(torch.stack([vq, -vq]) + 0.3, dim=-1),
+                             v_tex=synthetic.seeded((2, 24, 2), 77, 0, 1), t_pos_idx=qf[(qf < 40).all(1)][None],
+                             t_nrm_idx=qf[(qf < 40).all(1)][None], t_tex_idx=(qf[(qf < 40).all(1)] % 24)[None], material=None)
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        ref_obj.write_obj(tmp, "animal", mesh10, 1, save_material=True)
+        text_mat = open(os.path.join(tmp, "animal.obj")).read()
+        ref_obj.write_obj(tmp, "animal2", mesh10, 0, save_material=False)
+        text_nomat = open(os.path.join(tmp, "animal2.obj")).read()
+    save("write_obj.npz", v_pos=mesh10.v_pos.numpy(), v_nrm=mesh10.v_nrm.numpy(), v_tex=mesh10.v_tex.numpy(), t_pos_idx=mesh10.t_pos_idx.numpy(),
+         t_tex_idx=mesh10.t_tex_idx.numpy(), obj_idx1_material=np.array(text_mat), obj_idx0_nomaterial=np.array(text_nomat))
     print("golden vectors written to", HERE)
 
 

@@ -1111,6 +1111,93 @@ def test_estimate_bones_on_device_matches_golden_without_host_sync(bone_y_thresh
     assert torch.allclose(bones_dev.cpu(), bones_cpu, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag,kw", [("default", dict(attach_legs_to_body=True)), ("fauna", dict(attach_legs_to_body=True, bone_y_threshold=0.4)),
+                                    ("fixed", dict(attach_legs_to_body=True, legs_to_body_joint_indices=[2, 7, 7, 2]))])
+def test_estimate_bones_on_device_against_reference_golden(tag, kw, dev, mods):
+    """estimate_bones run ON THE GPU with the kinematic chain rebuilt (what Fauna does every iteration) against the reference's own
+    outputs (bones_quadruped_r16.npz): bones, chain, attachment joints.  Rebuilding the chain costs exactly one read-back (the two
+    attachment joints in one transfer; none when they are prescribed) -- counted through torch's sync-debug warnings."""
+    import warnings
+
+    sk = mods["skinning"]
+    g = golden("bones_quadruped_r16.npz")
+    shape = torch.from_numpy(g["verts"])[None, None].to(dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            bones, chain, aux = sk.estimate_bones(shape.clone(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+",
+                                                  compute_kinematic_chain=True, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    syncs = [w for w in caught if "synchroniz" in str(w.message).lower() and "prototype feature" not in str(w.message)]
+    assert len(syncs) <= (0 if "legs_to_body_joint_indices" in kw else 1), [str(w.message)[:120] for w in syncs]
+    np.testing.assert_allclose(bones.cpu().numpy(), g[f"{tag}_bones"], atol=1e-6)
+    assert repr(chain) == str(g[f"{tag}_chain"])
+    assert [l["body_bone_idx"] for l in aux["legs"]] == list(g[f"{tag}_leg_body_idx"])
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_present():
+    """The first N > 1 RCCL execution should not be the driver's scaling run: bench.py --gpus 2 under torch.distributed.run, exactly as the
+    driver launches it.  Skips on the single-GPU development boxes."""
+    import json
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid-res", "32", "--resolution", "128", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["global_batch"] == 32
+
+
+def test_render_uv_bake_and_material_export(tmp_path, dev, mods):
+    """f4 output side: render_uv (render.py:342-360) -- rasterise the uv atlas, interpolate the positions, sample the texture field --
+    against the oracle operators on the same mesh, then write_obj + save_mtl with the MLP material (the test_* configs' export)."""
+    from PIL import Image
+
+    from oracle import raster_ref
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    scene = pipeline.SyntheticScene(grid_res=8, batch=2, resolution=(32, 32), device=dev, seed=2, net_width=32, net_layers=3, feat_dim=16,
+                                    embedder_freq=4)
+    with torch.no_grad():
+        scene.step(backward=False)
+        shape = scene.last["shape"]
+        res = (64, 64)
+        mask, kd, ks, nrm = mods["render"].render_uv(None, shape, res, scene.netTexture, feat=scene.feat)
+    assert mask.shape == (2, 64, 64, 1) and kd.shape == (2, 64, 64, 3) and ks.shape == kd.shape and nrm.shape == kd.shape
+    # oracle: the same three steps with the CPU operators and the same field
+    import copy
+
+    tex = copy.deepcopy(scene.netTexture).cpu()
+    uv = shape.v_tex.cpu() * 2 - 1
+    uv4 = torch.cat((uv, torch.zeros_like(uv[..., :1]), torch.ones_like(uv[..., :1])), -1)
+    rast = raster_ref.rasterize(uv4.contiguous(), shape.t_tex_idx[0].cpu().int(), res)
+    gb_pos = raster_ref.interpolate(shape.v_pos.cpu(), rast, shape.t_pos_idx[0].cpu().int())
+    with torch.no_grad():
+        all_tex = tex.sample(gb_pos, feat=scene.feat.detach().cpu())
+    assert torch.equal(mask.cpu()[..., 0] > 0, rast[..., 3] > 0) and 0.0 < float(mask.mean()) < 1.0
+    cov = (rast[..., 3] > 0)[..., None]
+    np.testing.assert_allclose((kd.cpu() * cov).numpy(), (all_tex[..., :3] * cov).numpy(), atol=1e-4)
+    np.testing.assert_allclose((ks.cpu() * cov).numpy(), (all_tex[..., 3:6] * cov).numpy(), atol=1e-4)
+    # export: OBJ + MTL + the three baked maps
+    shape.material = {"bsdf": "diffuse", "kd_ks_normal": scene.netTexture}
+    mods["render"]  # (render module imported)
+    obj = importlib.import_module("3danimals_amd.model.render.obj")
+    obj.write_obj(str(tmp_path), "horse_mesh", shape, 1, save_material=True, feat=scene.feat[1:2], resolution=[32, 32])
+    mtl = open(tmp_path / "horse_mesh.mtl").read()
+    assert "newmtl defaultMat" in mtl and "bsdf   diffuse" in mtl and "map_Kd horse_texture_kd.png" in mtl and "bump horse_texture_n.png" in mtl
+    img = np.asarray(Image.open(tmp_path / "horse_texture_kd.png"))
+    assert img.shape == (32, 32, 3) and img.dtype == np.uint8 and img.max() > 0
+
+
 def test_graphed_sdf_gradient_equals_eager(dev):
     """DMTetGeometry._graphed_sdf_gradient (forward + double backward replayed from HIP graphs) against the eager autograd path on
     the same points: same kernels in the same order, so the values and the parameter gradients are bit-identical."""

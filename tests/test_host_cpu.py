@@ -311,6 +311,28 @@ def test_write_obj_format(tmp_path):
     assert text[-1] == "f  1/1/1 2/2/2 3/3/3" and "usemtl defaultMat" in text
 
 
+def test_write_obj_matches_the_reference_writer_golden(tmp_path):
+    """G10: byte-for-byte the text the REFERENCE's write_obj produced for the same mesh (obj.py:128-177; generated by importing the
+    reference in the build container), with and without texture coordinates, second and first batch entry."""
+    from types import SimpleNamespace
+
+    obj = importlib.import_module("3danimals_amd.model.render.obj")
+    g = golden("write_obj.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    mesh = SimpleNamespace(v_pos=t("v_pos"), v_nrm=t("v_nrm"), v_tex=t("v_tex"), t_pos_idx=t("t_pos_idx"), t_nrm_idx=t("t_pos_idx"),
+                           t_tex_idx=t("t_tex_idx"), material=None)
+    obj.write_obj(str(tmp_path), "animal", mesh, 1, save_material=True)
+    assert open(tmp_path / "animal.obj").read() == str(g["obj_idx1_material"])
+    obj.write_obj(str(tmp_path), "animal2", mesh, 0, save_material=False)
+    assert open(tmp_path / "animal2.obj").read() == str(g["obj_idx0_nomaterial"])
+
+
+def test_save_mtl_without_material(tmp_path):
+    obj = importlib.import_module("3danimals_amd.model.render.obj")
+    obj.save_mtl(str(tmp_path / "a_b.mtl"), None)
+    assert open(tmp_path / "a_b.mtl").read().split() == "newmtl defaultMat Kd 1 1 1 Ks 0 0 0 Ka 0 0 0 Tf 1 1 1 Ni 1 Ns 0".split()
+
+
 def test_coordmlp_per_image_feature_path_equals_concatenation():
     """CoordMLP.sample(x, feat=[B,C], feat_index=[P]) == the reference formulation with the per-point feature concatenated
     (networks/MLPs.py:84-90), values and gradients (same sum, other association -> fp32 rounding)."""
