@@ -56,8 +56,9 @@ __device__ __forceinline__ void aa_project(const float4 p, float fx, float fy, f
 // instead of 12 times per pixel pair.  (p.x / p.w * xh) - fx is evaluated unfused (this TU is built with -ffp-contract=off), so
 // subtracting fx from the stored product gives the same bits as aa_project.
 __global__ __launch_bounds__(256) void aa_screen_kernel(const float4* __restrict__ clip, long long n, float xh, float yh,
-                                                        float2* __restrict__ screen) {
+                                                        float2* __restrict__ screen, int* __restrict__ count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < AA_SHARDS) count[i] = 0;  // the analysis launch that follows appends from zero (one launch less than a memset)
     if (i >= n) return;
     const float4 p = clip[i];
     screen[i] = make_float2(p.x / p.w * xh, p.y / p.w * yh);
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
     }
 }
 
+// 32 lanes per crossing record: lane l takes channels l, l + 32, ... (colour gradients of both pixels, two atomics per channel) and
+// the lanes' partial d(loss)/d(alpha) meet in lane 0, which pushes it onto the two vertices of the crossing edge.  (One thread per
+// record walked the channels serially: 21 us for the 17-channel buffer.)
 __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ color, int C,
                                                      const AaRec* __restrict__ work, const int* __restrict__ count, int capacity,
                                                      const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
@@ -204,14 +208,15 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
     __shared__ int s_off[AA_SHARDS + 1];
     const int n = aa_segment_offsets(count, capacity, s_off);
     const float xh = 0.5f * W, yh = 0.5f * H;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 31, groups = (gridDim.x * blockDim.x) >> 5;
+    for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; r < n; r += groups) {
         const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
         const int d = rec.flags & 1, di = (rec.flags >> 1) & 3;
         const bool use1 = rec.flags & 8, clamped = rec.flags & 16;
         const long long p0 = rec.pix0, p1 = p0 + (d ? W : 1);
         const long long dst = rec.alpha > 0.f ? p0 : p1;
         float dd = 0.f;
-        for (int c = 0; c < C; ++c) {
+        for (int c = sub; c < C; c += 32) {
             const float gd = g_out[dst * C + c];
             if (gd != 0.f) {
                 atomicAdd(g_color + p1 * C + c, rec.alpha * gd);
@@ -219,7 +224,9 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
                 dd += gd * (color[p1 * C + c] - color[p0 * C + c]);
             }
         }
-        if (clamped || dd == 0.f) continue;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);  // stays inside the 32-lane half
+        if (sub != 0 || clamped || dd == 0.f) continue;
         // alpha = ds*0.5 - xint,  xint = (Xa*Yb - Ya*Xb)/(Yb - Ya) in the (pair-direction, other) frame
         const int b = (int)(p0 / ((long long)H * W));
         const int rem = (int)(p0 - (long long)b * H * W);
@@ -297,13 +304,15 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
     hipStream_t s = (hipStream_t)stream;
     A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W));
-    A3D_HIP(hipMemsetAsync(count, 0, sizeof(int) * AA_SHARDS, s));
-    if (F == 0) return A3D_OK;
+    if (F == 0) {
+        A3D_HIP(hipMemsetAsync(count, 0, sizeof(int) * AA_SHARDS, s));
+        return A3D_OK;
+    }
     A3D_CHECK_ARG(tri && opp);
     const long long nvert = (long long)clip_batch * V;
     A3D_CHECK_ARG(B <= 65535);
-    hipLaunchKernelGGL(aa_screen_kernel, dim3(a3d_div_up(nvert, 256)), dim3(256), 0, s, (const float4*)clip, nvert, 0.5f * W, 0.5f * H,
-                       (float2*)screen);
+    hipLaunchKernelGGL(aa_screen_kernel, dim3(a3d_div_up(nvert > AA_SHARDS ? nvert : AA_SHARDS, 256)), dim3(256), 0, s, (const float4*)clip, nvert,
+                       0.5f * W, 0.5f * H, (float2*)screen, count);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, (const float4*)rast, (const float2*)screen,
                        clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count);
@@ -336,7 +345,7 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
     }
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri);
-    hipLaunchKernelGGL(aa_bwd_kernel, dim3(256), dim3(256), 0, s, g_out, color, C, (const AaRec*)work, count, capacity,
+    hipLaunchKernelGGL(aa_bwd_kernel, dim3(1024), dim3(256), 0, s, g_out, color, C, (const AaRec*)work, count, capacity,
                        (const float4*)clip, clip_batch, tri, V, H, W, g_color, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;

@@ -4,7 +4,8 @@
 // nvdiffrast, third party, goes through OpenGL).  The meshes on this path are marching-tets surfaces: tens of
 // thousands of triangles per 256x256 image whose pixel boxes hold ~10 candidates and ~2 covered pixels each.
 //
-//   clear   : keys[B,H,W] (u64) <- ~0                                              (hipMemsetAsync, 8 B/pixel)
+//   clear   : keys[B,H,W] (u64) <- ~0       (hipMemsetAsync, 8 B/pixel; skipped when the caller hands back the buffer of the
+//             previous call on the same stream: the resolve re-arms every key it consumes)
 //   tri     : 4 lanes per (image, triangle): 12 B of indices + 3 x 16 B vertex gathers (L2 resident), the
 //             conservative pixel box, then the box's pixels are shared out over the 4 lanes; every covered pixel
 //             does atomicMin(keys[pixel], order(z/w) << 32 | id).  min over (depth, id) is order independent, so
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
 
 // grid (ceil(H*W / 256), B): the image comes from blockIdx.y and the row/column from one 32-bit division
 __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
-                                                         int H, int W, const unsigned long long* __restrict__ keys,
+                                                         int H, int W, unsigned long long* __restrict__ keys,
                                                          float4* __restrict__ rast) {
     const unsigned hw = (unsigned)H * (unsigned)W;
     const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
     const unsigned long long key = keys[i];
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (key != RS_EMPTY) {
+        keys[i] = RS_EMPTY;  // leave the key buffer armed for the next call (saves its 8 B/pixel clear launch: scratch_is_clean)
         const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
         const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
         const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
 extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
 
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                            void* scratch, a3d_stream_t stream) {
+                            void* scratch, int scratch_is_clean, a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
@@ -215,7 +217,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
         return A3D_OK;
     }
     unsigned long long* keys = (unsigned long long*)scratch;
-    A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
+    if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     hipLaunchKernelGGL(rs_tri_kernel, dim3(a3d_div_up(F, 64), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W, keys);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(rs_resolve_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, H, W,

@@ -313,6 +313,9 @@ def covered_pixels(rast, tile=8):
 
 
 # ---------------------------------------------------------------------------------------------- rasterise
+_rast_keys = {}
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clip, tri32, B, H, W):
@@ -320,8 +323,16 @@ class _Rasterize(torch.autograd.Function):
         clip = f32c(clip)
         V, F = clip.shape[1], tri32.shape[0]
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=clip.device)
-        scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), stream())
+        # the (depth, id) key buffer is kept per (device, stream, size): the resolve leaves it armed, so only its first use pays the clear
+        key = (clip.device, stream(), B, H, W)
+        scratch = _rast_keys.pop(key, None)
+        clean = scratch is not None
+        if scratch is None:
+            scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), stream())
+        if len(_rast_keys) >= 4:
+            _rast_keys.clear()
+        _rast_keys[key] = scratch  # only after a successful call (a failed one leaves the buffer out of the cache)
         ctx.save_for_backward(clip, tri32, rast)
         return rast
 

@@ -22,7 +22,8 @@ ENTRY = {
     "a3d_skin_bwd": (["sk_bwd_kernel"], "sk_bwd_kernel"),
     "a3d_bone_transforms_fwd": (["bn_fwd_kernel"], "bn_fwd_kernel"),
     "a3d_bone_transforms_bwd": (["bn_bwd_kernel"], "bn_bwd_kernel"),
-    "a3d_normals_adjacency": (["nr_adj_count_kernel", "nr_adj_scan_kernel", "nr_adj_fill_kernel", "nr_adj_sort_kernel"], "nr_adj_scan_kernel"),
+    "a3d_mesh_topology": (["tp_init_kernel", "tp_count_insert_kernel", "nr_adj_scan_kernel", "tp_fill_lookup_kernel", "nr_adj_sort_kernel"],
+                          "nr_adj_scan_kernel"),
     "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
     "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel"], "nr_bwd_kernel"),
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
@@ -40,10 +41,11 @@ ENTRY = {
     "a3d_harmonic_embed_bwd": (["he_bwd_kernel"], "he_bwd_kernel"),
     "a3d_recon_losses_fwd": (["ls_fwd_kernel", "ls_finish_kernel"], "ls_fwd_kernel"),
     "a3d_recon_losses_bwd": (["ls_bwd_kernel"], "ls_bwd_kernel"),
-    "a3d_aa_topology": (["aa_hash_insert_kernel", "aa_hash_lookup_kernel"], "aa_hash_insert_kernel"),
-    "a3d_aa_analyze": (["aa_analyze_kernel"], "aa_analyze_kernel"),
+    "a3d_aa_analyze": (["aa_screen_kernel", "aa_analyze_kernel"], "aa_analyze_kernel"),
     "a3d_aa_fwd": (["aa_fwd_kernel"], "aa_fwd_kernel"),
-    "a3d_aa_bwd": (["aa_bwd_kernel"], "aa_bwd_kernel"),
+    "a3d_aa_bwd": (["aa_copy_zero_kernel", "aa_bwd_kernel"], "aa_bwd_kernel"),
+    "a3d_flow_loss_fwd": (["fl_fwd_kernel", "fl_finish_kernel"], "fl_fwd_kernel"),
+    "a3d_flow_loss_bwd": (["fl_bwd_kernel"], "fl_bwd_kernel"),
 }
 
 
