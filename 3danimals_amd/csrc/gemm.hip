@@ -251,14 +251,19 @@ extern "C" int a3d_gemm_nn_relumask(const float* A, const float* B, const float*
     static const int variant = getenv("A3D_GEMM_VARIANT") ? atoi(getenv("A3D_GEMM_VARIANT")) : 3;  // experiment knob; 3 = persistent
     const dim3 block256(256);
     if (variant == 3 && K == 256) {  // persistent, weight half resident in LDS
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            A3D_HIP(hipGetDevice(&dev));
-            A3D_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        // per device ordinal (a process may drive more than one GPU); idempotent values, so a race between threads is harmless
+        static int n_cu_of[64] = {0};
+        int dev = 0;
+        A3D_HIP(hipGetDevice(&dev));
+        A3D_CHECK_ARG(dev >= 0 && dev < 64);
+        if (!n_cu_of[dev]) {
+            int n = 0;
+            A3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
             A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 * G3_BN * 4 + 16 * 64 * 8)));
             A3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gm_nn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 * G3_BN * 4 + 16 * 64 * 8)));
+            n_cu_of[dev] = n;
         }
+        const int n_cu = n_cu_of[dev];
         const dim3 grid(n_cu & ~1), block(64 * G3_WAVES);
         if (X) hipLaunchKernelGGL(gm_nn3_kernel<true>, grid, block, (256 * G3_BN * 4 + 16 * 64 * 8), s, A, B, X, (int)M, C);
         else hipLaunchKernelGGL(gm_nn3_kernel<false>, grid, block, (256 * G3_BN * 4 + 16 * 64 * 8), s, A, B, X, (int)M, C);

@@ -162,7 +162,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     n_pts = pix.shape[0]
     n_pad = (-n_pts) % POINT_BUCKET if POINT_BUCKET else 0
     if n_pad:
-        img_p = torch.cat((img, img.new_zeros(n_pad)))
+        img_p = torch.cat((img, img.new_full((n_pad,), b - 1)))  # padding rows ride with the last image: the index stays non-decreasing
         tex_in = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))
         per_img_p = lambda t: None if t is None else (_rows_per_point(t, img_p, b) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
     else:

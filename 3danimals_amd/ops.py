@@ -503,9 +503,20 @@ class _RowsPerPoint(torch.autograd.Function):
         return out, None
 
 
+CHECK_SORTED_INDEX = False  # debugging aid: device-side assert (no host sync) that a point -> image index is non-decreasing
+
+
+def _assert_sorted(img):
+    """The per-image segment sums (csrc/segsum.hip) treat a 128-row block whose first and last rows belong to the same image as
+    single-image: the index must be non-decreasing (the render path's is: pixel lists are image-major, padding rows repeat an image)."""
+    if CHECK_SORTED_INDEX and img.numel() > 1:
+        torch._assert_async((img[1:] >= img[:-1]).all(), "point -> image index must be non-decreasing")
+
+
 def rows_per_point(t, img):
-    """t [B,...] -> [P,...] rows gathered by img [P] (int64, contiguous)."""
+    """t [B,...] -> [P,...] rows gathered by img [P] (int64, contiguous, NON-DECREASING: see _assert_sorted)."""
     require_device(t, img, what="rows_per_point")
+    _assert_sorted(img)
     return _RowsPerPoint.apply(t, img) if (t.requires_grad and torch.is_grad_enabled()) else t.index_select(0, img)
 
 
@@ -541,7 +552,8 @@ def rows_add_relu_raw_(y, rows, img):
 
 
 def rows_segsum_raw(g, img, b):
-    """[B,C] per-image sums of g [P,C] (no autograd)."""
+    """[B,C] per-image sums of g [P,C] (no autograd); img non-decreasing."""
+    _assert_sorted(img)
     g = f32c(g)
     out = torch.empty((b, g.shape[1]), dtype=torch.float32, device=g.device)
     call("a3d_rows_segsum", ptr(g), ptr(img), g.shape[0], g.shape[1], b, ptr(out), stream(), tag=f"[C{g.shape[1]}]")
@@ -549,7 +561,8 @@ def rows_segsum_raw(g, img, b):
 
 
 def rows_add_relu_(y, rows, img):
-    """In place: y[p] = relu(y[p] + rows[img[p]]);  y [P,C] fresh GEMM output, rows [B,C], img int64 [P]."""
+    """In place: y[p] = relu(y[p] + rows[img[p]]);  y [P,C] fresh GEMM output, rows [B,C], img int64 [P], non-decreasing."""
+    _assert_sorted(img)
     return _RowsAddReLU.apply(y, rows, img)
 
 

@@ -613,6 +613,51 @@ def test_fused_gbuffer_matches_generic_path_and_gradients(res, H, W, dev, mods, 
     np.testing.assert_allclose(gv.cpu().numpy(), a[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a[1].abs().max()))
 
 
+def test_fused_gbuffer_backward_table_overflow_falls_back_to_global_atomics(dev, mods, ops):
+    """One tiny triangle per pixel, no shared vertices: 256 consecutive list entries reference 768 distinct vertices, more than the 512
+    slots of the work-group's LDS table, so part of every block takes the global-atomic fallback of gb_bwd_kernel.  Gradients must still
+    equal the modular rasterise/interpolate path."""
+    H = W = 32
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    cx, cy = ((xs + 0.5) * 2 / W - 1).reshape(-1), ((ys + 0.5) * 2 / H - 1).reshape(-1)
+    r = 0.6 / W  # the triangle holds its own pixel centre only
+    offs = torch.tensor([[-1.0, -0.7], [1.0, -0.7], [0.0, 1.1]]) * r
+    xy = torch.stack([cx, cy], -1)[:, None, :] + offs[None]  # [HW,3,2]
+    V = H * W * 3
+    depth = seeded((H * W, 3, 1), 3, 0.1, 0.6)
+    verts = torch.cat([xy, depth], -1).reshape(1, V, 3)
+    tri = torch.arange(V, dtype=torch.int64).reshape(-1, 3)
+    mvp = torch.eye(4)[None]
+    R = mods["render"]
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+
+    def run(fused):
+        v = verts.clone().to(dev).requires_grad_(True)
+        pv = (verts * 0.5 + 0.1).to(dev).requires_grad_(True)
+        nrm = torch.nn.functional.normalize(seeded((1, V, 3), 8, -1, 1), dim=-1).to(dev).requires_grad_(True)
+        clip = ru.xfm_points(v, mvp.to(dev))
+        rast = ops.rasterize(clip, tri.to(dev), (H, W))
+        assert int((rast[..., 3] > 0).sum()) == H * W  # every pixel owned by its own triangle
+        pix = ops.covered_pixels(rast)
+        t = tri.to(dev)
+        if fused:
+            gb = ops.gbuffer(clip, v, nrm, pv, rast, t, pix)
+        else:
+            fn = R.util.safe_normalize(torch.cross(v[:, t[:, 1]] - v[:, t[:, 0]], v[:, t[:, 2]] - v[:, t[:, 0]], dim=-1))
+            parts = [ops.interpolate(v, rast, t), ops.interpolate(fn, rast, R._face_index_buffer(t)), ops.interpolate(nrm, rast, t),
+                     ops.interpolate(pv, rast, t)]
+            gb = torch.cat([p.reshape(-1, 3).index_select(0, pix) for p in parts], -1)
+        wgt = seeded((pix.shape[0], 12), 41, -1, 1).to(dev)
+        return (gb.detach(),) + torch.autograd.grad((gb * wgt).sum(), [v, nrm, pv])
+
+    a, b = run(True), run(False)
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=2e-6)
+    for x, y, name in zip(a[1:], b[1:], ("v_pos", "v_nrm", "prior")):
+        scale = float(y.abs().max())
+        assert scale > 0, name
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
+
+
 def test_mesh_topology_fused_entry_point_equals_the_two_separate_ones(dev, ops):
     """a3d_mesh_topology against a3d_normals_adjacency + a3d_aa_topology, bit for bit (incl. an empty list and isolated vertices)."""
     verts, faces = quadruped_mesh(16, 0.3)

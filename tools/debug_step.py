@@ -1,7 +1,7 @@
 """Locate the pixel where the HIP step and the oracle step disagree (run on the GPU box)."""
 import importlib, os, sys, copy
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import mesh_ref, render_ref, raster_ref
 pipeline = importlib.import_module("3danimals_amd.pipeline")
