@@ -4,7 +4,7 @@ Same signatures, same return contract (a list of NCHW tensors in ``render_modes`
 inside shade like the reference, render.py:127-128), same arithmetic; underneath, the nvdiffrast calls become HIP kernels:
 
 * one triangle-parallel rasterisation pass (csrc/raster.hip: 64-bit atomicMin on depth|id, then a resolve) instead of the OpenGL
-  depth peeler;
+  depth peeler (layers > 0 peel behind the previous layer's (depth, id): render_mesh(num_layers > 1) takes the general dense path);
 * on the training path (spp 1, no tangent/depth mode) ONE fused kernel builds the G-buffer of the covered pixels only
   (csrc/cover.hip + csrc/gbuffer.hip: world position, face normal, smooth normal, canonical position; its backward also carries
   the rasteriser's gradient), ONE kernel does the shading arithmetic (csrc/shade.hip), and the texture / DINO fields see the
@@ -34,10 +34,10 @@ FUSED_SHADING = True  # shading normal + camera normal + directional light of th
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
-    """dr.interpolate wrapper of the reference (render.py:23-24); returns (values, None)."""
-    if rast_db is not None:
-        raise NotImplementedError("pixel-differential attributes (rast_db) are not used on this path (spp=1)")
-    return ops.interpolate(attr.contiguous(), rast, attr_idx), None
+    """dr.interpolate wrapper of the reference (render.py:23-24): (values, None) -- or (values, pixel differentials of every attribute)
+    when ``rast_db`` is given, which no caller on this path does."""
+    out = ops.interpolate(attr.contiguous(), rast, attr_idx)
+    return out, (None if rast_db is None else ops.interpolate_da(attr.contiguous(), rast, attr_idx, rast_db, "all"))
 
 
 def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, view_pos, lgt, material, bsdf, feat=None, render_modes=None,
@@ -296,8 +296,6 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     """
     assert mesh.t_pos_idx.shape[1] > 0, "Got empty training triangle mesh (unrecoverable discontinuity)"
     assert background is None or (background.shape[1] == resolution[0] and background.shape[2] == resolution[1])
-    if num_layers != 1:
-        raise NotImplementedError("depth peeling beyond the first layer is never used (num_layers=1, AnimalModel.py:247)")
     render_modes = render_modes if render_modes is not None else ["shaded"]
     dev = mesh.v_pos.device
     full_res = [resolution[0] * spp, resolution[1] * spp]
@@ -316,6 +314,9 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
 
     tri = mesh.t_pos_idx[0]
     clip_f = v_pos_clip.float()
+    if num_layers != 1:  # depth peeling: never used by a config (AnimalModel.py:247); the general, dense path
+        return _render_mesh_layers(mesh, clip_f, tri, w2c, view_pos, material, lgt, resolution, spp, num_layers, msaa, background, bsdf, feat,
+                                   render_modes, prior_mesh, two_sided_shading, dino_net, class_vector, delta_xy)
     rast = ops.rasterize(clip_f, tri, full_res)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
@@ -369,6 +370,59 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         elif key == "dino_pred":
             out = out[..., :-1]
         out_buffers.append(out.permute(0, 3, 1, 2))
+    return out_buffers
+
+
+def _slice_mode(key, out):
+    """Channel selection per render mode (reference render.py:320-331)."""
+    if key in ("kd", "ks", "normal", "geo_normal", "tangent"):
+        return out[..., :3]
+    if key in ("shading", "depth"):
+        return out[..., :1]
+    if key == "flow":
+        return out[..., :2]
+    if key == "dino_pred":
+        return out[..., :-1]
+    return out
+
+
+def _render_mesh_layers(mesh, clip_f, tri, w2c, view_pos, material, lgt, resolution, spp, num_layers, msaa, background, bsdf, feat, render_modes,
+                        prior_mesh, two_sided_shading, dino_net, class_vector, delta_xy):
+    """render_mesh with ``num_layers`` depth layers (reference render.py:258-268, 290-337): every layer is rasterised behind the previous
+    one (DepthPeeler), shaded, and the layers are composited back to front, antialiasing after each layer with that layer's geometry."""
+    dev = clip_f.device
+    full_res = [resolution[0] * spp, resolution[1] * spp]
+    layers, prev = [], None
+    for _ in range(num_layers):
+        rast = ops.rasterize(clip_f, tri, full_res, prev=prev)
+        prev = rast.detach()
+        rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
+                                prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
+                                class_vector=class_vector, clip=None, sparse=False)
+        layers.append((rendered, rast, ops.AAAnalysis(rast, clip_f, ops.aa_topology(ops.tri_int32(tri), clip_f.shape[1]))))
+    LAST_RAST[0] = layers[0][1].detach()
+    if background is not None:
+        if spp > 1:
+            background = util.scale_img_nhwc(background, full_res, mag="nearest", min="nearest")
+        background = torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
+    else:
+        background = torch.zeros(1, full_res[0], full_res[1], 4, dtype=torch.float32, device=dev)
+    out_buffers = []
+    for key in render_modes:
+        if key not in layers[0][0]:
+            out_buffers.append(None)
+            continue
+        accum = background if key in ("shaded", "geo_normal", "shading") else torch.zeros_like(layers[0][0][key])
+        if key == "shading" and accum.shape[-1] == 4:
+            accum = accum[..., 2:]
+        for buffers, rast, analysis in reversed(layers):
+            buf = buffers[key]
+            alpha = (rast[..., -1:] > 0).float() * buf[..., -1:]
+            accum = torch.lerp(accum, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)
+            if key in ANTIALIASED_MODES:
+                accum = ops.antialias(accum.contiguous().float(), rast, clip_f, tri, analysis=analysis)
+        out = util.avg_pool_nhwc(accum, spp) if spp > 1 else accum
+        out_buffers.append(_slice_mode(key, out).permute(0, 3, 1, 2))
     return out_buffers
 
 

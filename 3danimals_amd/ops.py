@@ -318,7 +318,7 @@ _rast_keys = {}
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, clip, tri32, B, H, W):
+    def forward(ctx, clip, tri32, B, H, W, prev):
         require_device(clip, tri32, what="rasterize")
         clip = f32c(clip)
         V, F = clip.shape[1], tri32.shape[0]
@@ -329,7 +329,10 @@ class _Rasterize(torch.autograd.Function):
         clean = scratch is not None
         if scratch is None:
             scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), stream())
+        if prev is not None:
+            prev = f32c(prev.detach())
+            assert prev.shape == (B, H, W, 4)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), stream())
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
         _rast_keys[key] = scratch  # only after a successful call (a failed one leaves the buffer out of the cache)
@@ -343,15 +346,42 @@ class _Rasterize(torch.autograd.Function):
         g_clip = torch.empty_like(clip)
         call("a3d_rast_bwd", ptr(f32c(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
              ptr(g_clip), stream())
-        return g_clip, None, None, None, None
+        return g_clip, None, None, None, None, None
 
 
-def rasterize(clip, tri, resolution, batch=None):
-    """clip [B|1,V,4] -> rast [B,H,W,4] = (u, v, z/w, triangle_id+1); differentiable through (u,v)."""
+def rasterize(clip, tri, resolution, batch=None, prev=None):
+    """clip [B|1,V,4] -> rast [B,H,W,4] = (u, v, z/w, triangle_id+1); differentiable through (u,v).  ``prev`` = the previous
+    depth layer (DepthPeeler.rasterize_next_layer for layer n > 0): the nearest surface strictly behind it is returned."""
     if clip.dim() == 2:
         clip = clip[None]
     B = clip.shape[0] if batch is None else batch
-    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]))
+    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]), prev)
+
+
+def rasterize_db(clip, tri, rast):
+    """rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) per pixel: the image-space derivatives of the perspective-correct
+    barycentrics of the stored triangle, from the definition u = a0/s, a_i = q_j x q_k, q_i = p_i.xy - f p_i.w (torch ops, so they are
+    differentiable w.r.t. clip like nvdiffrast's; nothing on the training path consumes them: render.py:24 passes rast_db=None)."""
+    B, H, W, _ = rast.shape
+    ids = rast[..., 3].long() - 1
+    hit = ids >= 0
+    t = tri.long()[ids.clamp(min=0)]
+    P = clip.expand(B, -1, -1)[torch.arange(B, device=rast.device)[:, None, None, None].expand_as(t), t]  # [B,H,W,3,4]
+    fx = ((torch.arange(W, dtype=torch.float32, device=rast.device) + 0.5) * (2.0 / W) - 1.0)[None, None, :, None]
+    fy = ((torch.arange(H, dtype=torch.float32, device=rast.device) + 0.5) * (2.0 / H) - 1.0)[None, :, None, None]
+    x, y, w = P[..., 0], P[..., 1], P[..., 3]
+    qx, qy = x - fx * w, y - fy * w
+    a = [qx[..., 1] * qy[..., 2] - qy[..., 1] * qx[..., 2], qx[..., 2] * qy[..., 0] - qy[..., 2] * qx[..., 0],
+         qx[..., 0] * qy[..., 1] - qy[..., 0] * qx[..., 1]]
+    # d a_i / d fx = -w_j qy_k + qy_j w_k ;  d a_i / d fy = -qx_j w_k + w_j qx_k   (j, k) = (i+1, i+2)
+    dax = [-w[..., (i + 1) % 3] * qy[..., (i + 2) % 3] + qy[..., (i + 1) % 3] * w[..., (i + 2) % 3] for i in range(3)]
+    day = [-qx[..., (i + 1) % 3] * w[..., (i + 2) % 3] + w[..., (i + 1) % 3] * qx[..., (i + 2) % 3] for i in range(3)]
+    s_ = a[0] + a[1] + a[2]
+    s_ = torch.where(hit, s_, torch.ones_like(s_))
+    sx, sy = dax[0] + dax[1] + dax[2], day[0] + day[1] + day[2]
+    d = lambda ai, dai, ds, scale: (dai * s_ - ai * ds) / (s_ * s_) * scale
+    db = torch.stack([d(a[0], dax[0], sx, 2.0 / W), d(a[0], day[0], sy, 2.0 / H), d(a[1], dax[1], sx, 2.0 / W), d(a[1], day[1], sy, 2.0 / H)], -1)
+    return torch.where(hit[..., None], db, torch.zeros_like(db))
 
 
 # ---------------------------------------------------------------------------------------------- interpolate
@@ -385,6 +415,23 @@ def interpolate(attr, rast, tri):
     if attr.dim() == 2:
         attr = attr[None]
     return _Interpolate.apply(attr, rast, tri_int32(tri))
+
+
+def interpolate_da(attr, rast, tri, rast_db, diff_attrs="all"):
+    """out_da [B,H,W,2*S] = (dA/dX, dA/dY) per selected attribute (dr.interpolate's second output with ``rast_db`` / ``diff_attrs``):
+    dA/dX = du/dX (A0 - A2) + dv/dX (A1 - A2).  torch ops (differentiable); nothing on the training path consumes it (render.py:24)."""
+    a = attr if attr.dim() == 3 else attr[None]
+    sel = list(range(a.shape[-1])) if isinstance(diff_attrs, str) and diff_attrs == "all" else list(diff_attrs)
+    B = rast.shape[0]
+    ids = rast[..., 3].long() - 1
+    hit = (ids >= 0)[..., None]
+    t = tri.long()[ids.clamp(min=0)]
+    A = a.expand(B, -1, -1)[torch.arange(B, device=rast.device)[:, None, None, None].expand_as(t), t][..., sel]  # [B,H,W,3,S]
+    d0, d1 = A[..., 0, :] - A[..., 2, :], A[..., 1, :] - A[..., 2, :]
+    dx = rast_db[..., 0:1] * d0 + rast_db[..., 2:3] * d1
+    dy = rast_db[..., 1:2] * d0 + rast_db[..., 3:4] * d1
+    da = torch.stack([dx, dy], -1).reshape(*dx.shape[:-1], -1)
+    return torch.where(hit, da, torch.zeros_like(da))
 
 
 # ---------------------------------------------------------------------------------------------- fused G-buffer

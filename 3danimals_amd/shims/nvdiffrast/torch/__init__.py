@@ -48,13 +48,13 @@ def _check(pos, tri, resolution):
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
-    """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db).  rast_db is returned as zeros: image-space
-    derivatives are only consumed with spp>1 texture filtering, which this path never uses (render.py:24)."""
+    """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)).  The image-space
+    derivatives are analytic (ops.rasterize_db, torch ops); no caller on the training path consumes them (render.py:24)."""
     if ranges is not None:
         raise NotImplementedError("range mode")
     _check(pos, tri, resolution)
     rast = _ops.rasterize(pos, tri, resolution)
-    return rast, torch.zeros_like(rast)
+    return rast, (_ops.rasterize_db(pos, tri, rast) if grad_db else _ops.rasterize_db(pos.detach(), tri, rast.detach()))
 
 
 class DepthPeeler:
@@ -62,8 +62,8 @@ class DepthPeeler:
         if ranges is not None:
             raise NotImplementedError("range mode")
         _check(pos, tri, resolution)
-        self.pos, self.tri, self.resolution = pos, tri, resolution
-        self.layer = 0
+        self.pos, self.tri, self.resolution, self.grad_db = pos, tri, resolution, grad_db
+        self.layer, self._prev = 0, None
 
     def __enter__(self):
         return self
@@ -72,17 +72,21 @@ class DepthPeeler:
         return False
 
     def rasterize_next_layer(self):
-        if self.layer > 0:
-            raise NotImplementedError("only the first depth layer is implemented (the reference always uses num_layers=1)")
+        """Layer 0 = rasterize(); layer n = the nearest surface strictly behind layer n-1 (depth peeling)."""
+        rast = _ops.rasterize(self.pos, self.tri, self.resolution, prev=self._prev)
         self.layer += 1
-        return rasterize(None, self.pos, self.tri, self.resolution)
+        self._prev = rast.detach()
+        pos = self.pos if self.grad_db else self.pos.detach()
+        return rast, _ops.rasterize_db(pos, self.tri, rast if self.grad_db else rast.detach())
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
-    """-> (out [B,H,W,C], out_da).  Pixel-differential outputs (rast_db/diff_attrs) are not implemented."""
-    if rast_db is not None or diff_attrs is not None:
-        raise NotImplementedError("attribute pixel differentials (rast_db / diff_attrs)")
-    return _ops.interpolate(attr, rast, tri), torch.empty(0, device=rast.device)
+    """-> (out [B,H,W,C], out_da).  With ``rast_db`` and ``diff_attrs`` ('all' or a list of attribute indices) out_da
+    [B,H,W,2*len(diff_attrs)] holds (dA/dX, dA/dY) per selected attribute: dA/dX = du/dX (A0 - A2) + dv/dX (A1 - A2) (torch ops)."""
+    out = _ops.interpolate(attr, rast, tri)
+    if rast_db is None or diff_attrs is None:
+        return out, torch.empty(0, device=rast.device)
+    return out, _ops.interpolate_da(attr, rast, tri, rast_db, diff_attrs)
 
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):

@@ -131,10 +131,12 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * (z/w and the id carry none); g_clip[clip_batch,V,4] zeroed by callee.
  * scratch_is_clean != 0: the caller hands back the scratch buffer of a previous a3d_rast_fwd call of the same size that completed
  * on the same stream (every key is all-ones again: the resolve re-arms what it consumed) -- the 8 B/pixel clear launch is skipped.
+ * prev_rast != NULL: depth peeling, DepthPeeler.rasterize_next_layer() for layer n > 0 -- prev_rast[B,H,W,4] is the previous layer;
+ * per pixel the nearest fragment strictly behind the previous layer's (depth, id) is returned, empty pixels stay empty.
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                 void* scratch, int scratch_is_clean, a3d_stream_t stream);
+                 void* scratch, int scratch_is_clean, const float* prev_rast_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 

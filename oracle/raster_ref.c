@@ -64,9 +64,11 @@ static frag_t frag(const float* p0, const float* p1, const float* p2, float fx, 
     return r;
 }
 
-/* pos [B,V,4] (or [1,V,4] with pos_batch==1), tri [F,3], out rast [B,H,W,4] */
-int a3d_ref_rasterize(const float* pos, int pos_batch, const int32_t* tri, int B, int V, int F, int H, int W,
-                      float* rast) {
+/* pos [B,V,4] (or [1,V,4] with pos_batch==1), tri [F,3], out rast [B,H,W,4].
+ * prev (NULL or [B,H,W,4]) = the previous depth layer (DepthPeeler.rasterize_next_layer, layer n > 0): a fragment is eligible only
+ * where the previous layer is non-empty and only if it lies strictly behind it in (z/w, triangle id) order. */
+int a3d_ref_rasterize_peel(const float* pos, int pos_batch, const int32_t* tri, int B, int V, int F, int H, int W,
+                           const float* prev, float* rast) {
     const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
     const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
     size_t npix = (size_t)H * W;
@@ -104,6 +106,11 @@ int a3d_ref_rasterize(const float* pos, int pos_batch, const int32_t* tri, int B
                     frag_t f = frag(p0, p1, p2, fx, fy);
                     if (!f.hit) continue;
                     size_t pi = (size_t)py * W + px;
+                    if (prev) {
+                        const float* pr = prev + ((size_t)b * npix + pi) * 4;
+                        if (!(pr[3] > 0.f)) continue;
+                        if (f.zw < pr[2] || (f.zw == pr[2] && t <= (int)pr[3] - 1)) continue;
+                    }
                     if (best_t[pi] < 0 || f.zw < best_z[pi]) { best_z[pi] = f.zw; best_t[pi] = t; }
                 }
             }
@@ -126,4 +133,8 @@ int a3d_ref_rasterize(const float* pos, int pos_batch, const int32_t* tri, int B
     free(best_z);
     free(best_t);
     return 0;
+}
+
+int a3d_ref_rasterize(const float* pos, int pos_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast) {
+    return a3d_ref_rasterize_peel(pos, pos_batch, tri, B, V, F, H, W, 0, rast);
 }

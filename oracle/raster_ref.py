@@ -35,17 +35,25 @@ def _lib():
         _LIB = ctypes.CDLL(build())
         _LIB.a3d_ref_rasterize.restype = ctypes.c_int
         _LIB.a3d_ref_rasterize.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        _LIB.a3d_ref_rasterize_peel.restype = ctypes.c_int
+        _LIB.a3d_ref_rasterize_peel.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
     return _LIB
 
 
-def rasterize(pos: torch.Tensor, tri: torch.Tensor, resolution) -> torch.Tensor:
-    """dr.rasterize / DepthPeeler layer 0 -> rast [B,H,W,4] = (u, v, z/w, tri_id+1)."""
+def rasterize(pos: torch.Tensor, tri: torch.Tensor, resolution, prev: torch.Tensor = None) -> torch.Tensor:
+    """dr.rasterize / DepthPeeler layer 0 -> rast [B,H,W,4] = (u, v, z/w, tri_id+1); with ``prev`` (the previous layer) the next
+    depth layer: per pixel the nearest fragment strictly behind the previous one in (z/w, id) order."""
     H, W = int(resolution[0]), int(resolution[1])
     p = pos.detach().to(torch.float32).contiguous()
     t = tri.to(torch.int32).contiguous()
     B, V = p.shape[0], p.shape[1]
     out = torch.empty(B, H, W, 4, dtype=torch.float32)
-    rc = _lib().a3d_ref_rasterize(p.data_ptr(), B, t.data_ptr(), B, V, t.shape[0], H, W, out.data_ptr())
+    if prev is None:
+        rc = _lib().a3d_ref_rasterize(p.data_ptr(), B, t.data_ptr(), B, V, t.shape[0], H, W, out.data_ptr())
+    else:
+        pv = prev.detach().to(torch.float32).contiguous()
+        assert tuple(pv.shape) == (B, H, W, 4)
+        rc = _lib().a3d_ref_rasterize_peel(p.data_ptr(), B, t.data_ptr(), B, V, t.shape[0], H, W, pv.data_ptr(), out.data_ptr())
     assert rc == 0
     return out
 

@@ -59,7 +59,7 @@ def _inject_oracle_nvdiffrast():
 
     class DepthPeeler:
         def __init__(self, ctx, pos, tri, resolution):
-            self.pos, self.tri, self.res = pos, tri, resolution
+            self.pos, self.tri, self.res, self.prev = pos, tri, resolution, None
 
         def __enter__(self):
             return self
@@ -68,7 +68,8 @@ def _inject_oracle_nvdiffrast():
             return False
 
         def rasterize_next_layer(self):
-            rast = raster_ref.rasterize(self.pos, self.tri, self.res)
+            rast = raster_ref.rasterize(self.pos, self.tri, self.res, prev=self.prev)  # layer n > 0: peeled behind layer n-1
+            self.prev = rast
             uv = raster_ref.barycentrics(self.pos, self.tri, rast)  # keep the gradient path like the real op
             return torch.cat([uv.clamp(0, 1), rast[..., 2:]], -1), torch.zeros_like(rast)
 
@@ -271,11 +272,12 @@ def main():
         "b": dict(modes=["geo_normal", "kd", "shading", "normal"], nets=True, kw={}),
         "c": dict(modes=["shaded", "flow"], nets=False, kw=dict(num_frames=2)),
         "d": dict(modes=["shaded"], nets=False, kw=dict(two_sided_shading=False)),
+        "e": dict(modes=["shaded", "kd"], nets=True, kw=dict(num_layers=2)),  # two depth layers composited back to front (render.py:258-296)
     }
     with torch.no_grad():
         for tag, c in cases7.items():
             outs = rrender.render_mesh(ctx, shape7, mvp7, w2c7, campos7, tex if c["nets"] else None, lgt if c["nets"] else None, (H, W), spp=1,
-                                       num_layers=1, msaa=True, background=bg7, bsdf="diffuse", feat=feat7 if c["nets"] else None,
+                                       num_layers=c["kw"].pop("num_layers", 1), msaa=True, background=bg7, bsdf="diffuse", feat=feat7 if c["nets"] else None,
                                        render_modes=c["modes"], prior_mesh=prior7, dino_net=dino if c["nets"] else None, **c["kw"])
             for m, o in zip(c["modes"], outs):
                 if o is not None:

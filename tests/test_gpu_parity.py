@@ -221,6 +221,24 @@ def test_rasterize_bit_exact_vs_oracle(B, H, W, dev, ops):
     assert float((out[..., 3] > 0).float().mean()) > 0.05
 
 
+def test_depth_peeling_bit_exact_vs_oracle(dev, ops):
+    """DepthPeeler layers 1 and 2 of a closed mesh (front surface, then what lies behind it) against oracle/raster_ref, ids and values."""
+    from oracle import raster_ref
+
+    B, H, W = 2, 96, 80
+    _, faces, clip, _ = _scene(B, seed=4)
+    tri = faces.int()
+    prev_o = prev_h = None
+    for layer in range(3):
+        prev_o = raster_ref.rasterize(clip, tri, (H, W), prev=prev_o)
+        prev_h = ops.rasterize(clip.to(dev), tri.to(dev), (H, W), prev=prev_h)
+        assert torch.equal(prev_h.cpu()[..., 3], prev_o[..., 3]), layer
+        np.testing.assert_allclose(prev_h.cpu().numpy(), prev_o.numpy(), atol=1e-6)
+        if layer:
+            assert 0 < int((prev_o[..., 3] > 0).sum()) <= cover
+        cover = int((prev_o[..., 3] > 0).sum())
+
+
 def test_rasterize_edge_cases(dev, ops):
     from oracle import raster_ref
 
@@ -851,7 +869,8 @@ def test_max_size_grid_and_raster_properties(dev, mods, ops):
     assert int(((cover == 0) & (nb == 4)).sum()) == 0
 
 
-@pytest.mark.parametrize("tag,nets,kw", [("a", True, {}), ("b", True, {}), ("c", False, dict(num_frames=2)), ("d", False, dict(two_sided_shading=False))])
+@pytest.mark.parametrize("tag,nets,kw", [("a", True, {}), ("b", True, {}), ("c", False, dict(num_frames=2)), ("d", False, dict(two_sided_shading=False)),
+                                         ("e", True, dict(num_layers=2))])
 def test_render_mesh_matches_reference_render_mesh_golden(tag, nets, kw, dev, mods):
     """G7: product render_mesh against buffers produced by the REFERENCE's render_mesh (oracle operators as nvdiffrast)."""
     import copy
@@ -870,9 +889,10 @@ def test_render_mesh_matches_reference_render_mesh_golden(tag, nets, kw, dev, mo
     prior = M.make_mesh(t("prior_v_pos")[None], faces[None], uvs, uvi, None)
     modes = str(g[f"{tag}_modes"]).split(",")
     with torch.no_grad():
+        kw = dict(kw)
         outs = mods["render"].render_mesh(None, shape, t("mvp"), t("w2c"), t("campos"), tex if nets else None, lgt if nets else None, (32, 32), spp=1,
-                                          num_layers=1, msaa=True, background=t("background"), bsdf="diffuse", feat=t("feat") if nets else None,
-                                          render_modes=modes, prior_mesh=prior, dino_net=dino if nets else None, **kw)
+                                          num_layers=kw.pop("num_layers", 1), msaa=True, background=t("background"), bsdf="diffuse",
+                                          feat=t("feat") if nets else None, render_modes=modes, prior_mesh=prior, dino_net=dino if nets else None, **kw)
     for m, o in zip(modes, outs):
         assert tuple(o.shape) == tuple(g[f"{tag}_{m}"].shape), m
         np.testing.assert_allclose(o.cpu().numpy(), g[f"{tag}_{m}"], atol=1e-4, err_msg=m)

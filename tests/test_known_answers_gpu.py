@@ -262,3 +262,67 @@ def test_antialias_gradients_closed_form_vertical_edge(dev, ops):
     assert float(g[0].abs().max()) == 0 and float(g[3].abs().max()) == 0  # the far vertices do not move the silhouette
     # moving a vertex ALONG the edge direction does not change a vertical edge's crossing
     assert abs(float(g[1, 1])) < 1e-4 * want1 and abs(float(g[2, 1])) < 1e-4 * want2
+
+
+# ------------------------------------------------------------------------------------------------ depth peeling, pixel differentials
+def test_depth_peeling_layers_known_answer(dev, ops):
+    """Three stacked quads: layer 0 sees the nearest, layer 1 the middle one, layer 2 the farthest, layer 3 nothing; pixels the
+    previous layer left empty stay empty; coincident duplicates come out one per layer in id order."""
+    H = W = 16
+    quad = lambda z, r=0.9: [[-r, -r, z, 1.0], [r, -r, z, 1.0], [r, r, z, 1.0], [-r, r, z, 1.0]]
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], dtype=torch.int32).to(dev)
+    pos = torch.tensor([quad(0.2) + quad(-0.6, 0.5) + quad(0.7)]).to(dev)  # the nearest quad (ids 3, 4) is the small one
+    layers, prev = [], None
+    for _ in range(4):
+        prev = ops.rasterize(pos, tri, (H, W), prev=prev)
+        layers.append(prev.cpu()[0])
+    ids = [set(l[..., 3].int().unique().tolist()) for l in layers]
+    assert ids[0] == {0, 1, 2, 3, 4} and ids[3] == {0}  # (0: the border pixels outside the 0.9 quads)
+    inner = layers[0][..., 3] >= 3  # where the small near quad is
+    ring = (layers[0][..., 3] >= 1) & ~inner
+    empty = layers[0][..., 3] == 0
+    assert set(layers[1][..., 3][inner].int().tolist()) == {1, 2} and set(layers[2][..., 3][inner].int().tolist()) == {5, 6}
+    assert set(layers[1][..., 3][ring].int().tolist()) == {5, 6} and float(layers[2][..., 3][ring].abs().max()) == 0
+    assert all(float(l[empty].abs().max()) == 0 for l in layers)  # what layer 0 left empty stays empty
+    assert torch.allclose(layers[1][..., 2][inner], torch.tensor(0.2)) and torch.allclose(layers[2][..., 2][inner], torch.tensor(0.7))
+    dup = torch.tensor([quad(0.3) + quad(0.3) + quad(0.3)]).to(dev)  # three coincident surfaces
+    prev, seen = None, []
+    for _ in range(3):
+        prev = ops.rasterize(dup, tri, (H, W), prev=prev)
+        seen.append(set(prev[..., 3].int().unique().tolist()))
+    assert [x - {0} for x in seen] == [{1, 2}, {3, 4}, {5, 6}]
+
+
+def test_rast_db_equals_finite_differences_for_an_affine_triangle(dev, ops):
+    """w = 1: the barycentrics are affine in the pixel coordinates, so rast_db (du/dX, du/dY, dv/dX, dv/dY) must equal the difference
+    of (u, v) between neighbouring pixels of the same triangle; with unequal w it must match float64 autograd of the definition."""
+    H = W = 32
+    pos = torch.tensor([[[-0.8, -0.7, 0.1, 1.0], [0.9, -0.4, 0.3, 1.0], [-0.1, 0.85, 0.2, 1.0]]]).to(dev)
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32).to(dev)
+    rast = ops.rasterize(pos, tri, (H, W))
+    db = ops.rasterize_db(pos, tri, rast).cpu()[0]
+    r = rast.cpu()[0]
+    cov = r[..., 3] > 0
+    both_x = cov[:, :-1] & cov[:, 1:]
+    both_y = cov[:-1, :] & cov[1:, :]
+    np.testing.assert_allclose(db[:, :-1, 0][both_x].numpy(), (r[:, 1:, 0] - r[:, :-1, 0])[both_x].numpy(), atol=2e-6)
+    np.testing.assert_allclose(db[:, :-1, 2][both_x].numpy(), (r[:, 1:, 1] - r[:, :-1, 1])[both_x].numpy(), atol=2e-6)
+    np.testing.assert_allclose(db[:-1, :, 1][both_y].numpy(), (r[1:, :, 0] - r[:-1, :, 0])[both_y].numpy(), atol=2e-6)
+    np.testing.assert_allclose(db[:-1, :, 3][both_y].numpy(), (r[1:, :, 1] - r[:-1, :, 1])[both_y].numpy(), atol=2e-6)
+    assert float(db[~cov].abs().max()) == 0
+    # perspective case: autograd of u(fx, fy) in float64
+    posp = torch.tensor([[[-0.7, -0.8, 0.2, 1.0], [1.6, -0.4, 0.5, 2.0], [0.1, 0.63, 0.1, 0.7]]])
+    rast = ops.rasterize(posp.to(dev), tri, (H, W))
+    db = ops.rasterize_db(posp.to(dev), tri, rast).cpu()[0].double()
+    cov = rast.cpu()[0, ..., 3] > 0
+    fy, fx = _centres(H, W)
+    fx, fy = fx.clone().requires_grad_(True), fy.clone().requires_grad_(True)
+    p = posp[0].double()
+    q = p[:, None, None, :2] - torch.stack([fx, fy], -1)[None] * p[:, None, None, 3:]
+    cross = lambda a, b: a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    a0, a1, a2 = cross(q[1], q[2]), cross(q[2], q[0]), cross(q[0], q[1])
+    s = a0 + a1 + a2
+    for comp, (num, cx, cy) in enumerate(((a0, 0, 1), (a1, 2, 3))):
+        gx, gy = torch.autograd.grad((num / s).sum(), [fx, fy], retain_graph=True)
+        np.testing.assert_allclose(db[..., cx][cov].numpy(), (gx * 2 / W)[cov].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(db[..., cy][cov].numpy(), (gy * 2 / H)[cov].numpy(), rtol=1e-4, atol=1e-6)
