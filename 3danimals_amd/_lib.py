@@ -25,7 +25,7 @@ SIGNATURES = {
     "a3d_bone_transforms_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_normals_bwd": (_c_int, [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_mesh_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
-    "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p,
+    "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int,
                                  _p]),
     "a3d_gemm_nn_relumask": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p]),
     "a3d_harmonic_embed_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),

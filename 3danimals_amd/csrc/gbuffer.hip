@@ -164,45 +164,54 @@ __device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0
     }
 }
 
-#define GB_SLOTS 512  // vertices per work-group table (256 pixels reference ~150-200 distinct ones)
+#define GB_SLOTS 512    // vertex table of one work-group (256 pixels reference ~150-200 distinct vertices)
 #define GB_PROBES 16
+#define GB_ENTRIES 640  // staged (pixel, corner) contributions of one work-group (768 possible, ~512 after the pair merge); overflow goes direct
+#define GB_ROW 16       // floats per gradient row = one 64-byte line: [0..2] v_pos, [3..5] v_nrm, [6..8] canonical, [12] [13] [15] clip x y w
 
-__device__ __forceinline__ int gb_slot(int* s_key, int key) {
+// find-or-claim the table slot of a vertex row; `first` is set for the one thread that claimed it
+__device__ __forceinline__ int gb_slot(int* s_key, int key, bool& first) {
     unsigned h = ((unsigned)key * 2654435761u) >> 23;  // top 9 bits
+    first = false;
 #pragma unroll 1
     for (int t = 0; t < GB_PROBES; ++t) {
         const int old = atomicCAS(&s_key[h], -1, key);
-        if (old == -1 || old == key) return (int)h;
+        if (old == -1) { first = true; return (int)h; }
+        if (old == key) return (int)h;
         h = (h + 1) & (GB_SLOTS - 1);
     }
     return -1;  // table crowded: the caller falls back to global atomics
 }
 
-struct GbTargets {
-    float* vpos; float* vnrm; float* prior; float* clip;
-};
+__device__ __forceinline__ int gb_col(int k) { return k < 9 ? k : (k == 11 ? 15 : k + 3); }  // component 0..11 -> column of the gradient row
 
-__device__ __forceinline__ void gb_flush_row(const GbTargets& t, long long row, const float c[12]) {
-    float* a = t.vpos + 3ll * row;
-    float* n = t.vnrm + 3ll * row;
-    atomicAdd(a, c[0]); atomicAdd(a + 1, c[1]); atomicAdd(a + 2, c[2]);
-    atomicAdd(n, c[3]); atomicAdd(n + 1, c[4]); atomicAdd(n + 2, c[5]);
-    if (t.prior) { float* q = t.prior + 3ll * row; atomicAdd(q, c[6]); atomicAdd(q + 1, c[7]); atomicAdd(q + 2, c[8]); }
-    if (t.clip) { float* q = t.clip + 4ll * row; atomicAdd(q, c[9]); atomicAdd(q + 1, c[10]); atomicAdd(q + 3, c[11]); }
+__device__ __forceinline__ void gb_row_direct(float* g_rows, long long row, const float c[12], bool want_prior, bool want_clip) {
+    float* r = g_rows + GB_ROW * row;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        if ((k < 6 || k >= 9 || want_prior) && (k < 9 || want_clip)) atomicAdd(r + gb_col(k), c[k]);
 }
+
+// lane ^ 1 through the DPP quad permute (no LDS traffic)
+__device__ __forceinline__ float gb_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int gb_xor1(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
 
 __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g_out, const float4* __restrict__ rast, const int* __restrict__ tri,
                                                      const long long* __restrict__ pix, long long P, const float* __restrict__ v_pos,
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
-                                                     const float4* __restrict__ clip, int V, int F, int H, int W, GbTargets tg) {
-    __shared__ int s_key[GB_SLOTS];
-    __shared__ float s_acc[GB_SLOTS][13];  // 13: odd stride
-    for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) {
-        s_key[i] = -1;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) s_acc[i][k] = 0.f;
-    }
+                                                     const float4* __restrict__ clip, int V, int F, int H, int W, float* __restrict__ g_rows,
+                                                     int want_prior) {
+    __shared__ int s_key[GB_SLOTS];    // vertex row (b*V + v) of a slot, -1 = free
+    __shared__ int s_head[GB_SLOTS];   // last staged entry of the slot's list
+    __shared__ int s_used[GB_SLOTS];   // claimed slots, in claim order
+    __shared__ float s_stage[GB_ENTRIES * 13];  // 12 floats + the previous entry of the same slot; 13: odd stride
+    __shared__ int s_n[2];             // staged entries, used slots
+    for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) { s_key[i] = -1; s_head[i] = -1; }
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
+    const bool want_clip = clip != nullptr;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long i = p < P ? pix[p] : 0;
     const float4 r = p < P ? rast[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -214,55 +223,71 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 #pragma unroll
         for (int k = 0; k < 12; ++k) acc[c][k] = 0.f;
     int i0 = 0, i1 = 0, i2 = 0;
-    long long b = 0;
+    int b = 0;
     if (live) {
         const unsigned hw = (unsigned)H * (unsigned)W;
-        b = (long long)((unsigned)i / hw);
+        b = (int)((unsigned)i / hw);
         const unsigned rem = (unsigned)i - (unsigned)b * hw;
         const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
         i0 = tri[3 * f]; i1 = tri[3 * f + 1]; i2 = tri[3 * f + 2];
-        const long long vb3 = b * V * 3, pb3 = prior_batch == 1 ? 0ll : vb3;
+        const long long vb3 = (long long)b * V * 3, pb3 = prior_batch == 1 ? 0ll : vb3;
         GbTri t;
         gb_load_tri(t, v_pos, v_nrm, prior, vb3, pb3, i0, i1, i2);
         float4 p0 = make_float4(0.f, 0.f, 0.f, 1.f), p1 = p0, p2 = p0;
-        if (tg.clip) { const float4* cb = clip + b * V; p0 = cb[i0]; p1 = cb[i1]; p2 = cb[i2]; }
+        if (want_clip) { const float4* cb = clip + (long long)b * V; p0 = cb[i0]; p1 = cb[i1]; p2 = cb[i2]; }
         const float4* gp = reinterpret_cast<const float4*>(g_out + p * 12);
         const float4 ga = gp[0], gb4 = gp[1], gc = gp[2];
         const float g[12] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z, gc.w};
-        gb_pixel_adjoint(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, tg.clip != nullptr, acc);
+        gb_pixel_adjoint(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, want_clip, acc);
     }
-    // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums (DPP), so a third
-    // fewer table updates (measured 70 -> 61 us)
-    const long long tkey = live ? b * F + f : -1 - (long long)threadIdx.x;
-    const bool same = live && __shfl_xor(tkey, 1, 64) == tkey;
+    // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums, a third fewer entries
+    const int tkey = live ? b * F + f : -1 - (int)threadIdx.x;  // (B*F < 2^31 is checked by the entry point)
+    const bool same = live && gb_xor1(tkey) == tkey;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const float o = __shfl_xor(acc[c][k], 1, 64);
+            const float o = gb_xor1(acc[c][k]);
             if (same) acc[c][k] += o;
         }
+    // stage: each (pixel, corner) row goes to LDS with plain stores and is linked into the list of its vertex (one integer exchange)
     if (live && !(same && (threadIdx.x & 1))) {
-        const int rowb = (int)(b * V);
+        const int rowb = b * V;
         const int idx[3] = {i0, i1, i2};
+        const int base = atomicAdd(&s_n[0], 3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int slot = gb_slot(s_key, rowb + idx[c]);
+            const int key = rowb + idx[c];
+            bool first = false;
+            const int e = base + c;
+            const int slot = e < GB_ENTRIES ? gb_slot(s_key, key, first) : -1;
             if (slot >= 0) {
-                float* dst = s_acc[slot];
+                if (first) s_used[atomicAdd(&s_n[1], 1)] = slot;
+                float* dst = s_stage + e * 13;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) atomicAdd(dst + k, acc[c][k]);
+                for (int k = 0; k < 12; ++k) dst[k] = acc[c][k];
+                dst[12] = __int_as_float(atomicExch(&s_head[slot], e));
             } else {
-                gb_flush_row(tg, rowb + idx[c], acc[c]);
+                gb_row_direct(g_rows, key, acc[c], want_prior != 0, want_clip);
             }
         }
     }
     __syncthreads();
-    // flush: one set of global atomics per distinct vertex touched by this block
-    for (int sidx = threadIdx.x; sidx < GB_SLOTS; sidx += blockDim.x) {
-        const int row = s_key[sidx];
-        if (row < 0) continue;
-        gb_flush_row(tg, row, s_acc[sidx]);
+    // reduce + flush: 16 lanes per vertex, lane = component, so the twelve atomics of a vertex are ONE 64-byte line request
+    // (line-coalesced device atomics are ~10x cheaper than the same number of scattered ones, see the header)
+    const int n_used = s_n[1];
+    const int k = threadIdx.x & 15;
+    const bool lane_on = k < 12 && (k < 6 || k >= 9 || want_prior) && (k < 9 || want_clip);
+    for (int j = threadIdx.x >> 4; j < n_used; j += 16) {
+        const int slot = s_used[j];
+        int e = s_head[slot];
+        float sum = 0.f;
+        while (e >= 0) {
+            const float* src = s_stage + e * 13;
+            if (k < 12) sum += src[k];
+            e = __float_as_int(src[12]);
+        }
+        if (lane_on) atomicAdd(g_rows + (long long)GB_ROW * s_key[slot] + gb_col(k), sum);
     }
 }
 
@@ -279,34 +304,18 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
 }
 
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
-                               const float* v_nrm, const float* prior, int prior_batch, const float* clip, int B, int V, int F, int H, int W,
-                               float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream) {
+                               const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
+                               float* g_rows, int want_prior, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
+    A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
-    A3D_CHECK_ARG(g_vpos && g_vnrm);
+    A3D_CHECK_ARG(g_rows && ((uintptr_t)g_rows & 63) == 0);
     hipStream_t s = (hipStream_t)stream;
-    const size_t n3 = 3 * (size_t)B * V;
-    // the four gradient buffers are zeroed here; when the caller carved them out of one allocation (vpos | vnrm | prior | clip,
-    // what ops.py does) that is ONE memset launch instead of four
-    float* nxt = g_vpos + n3;
-    bool one = g_vnrm == nxt;
-    nxt = g_vnrm + n3;
-    if (g_prior_or_null) { one = one && g_prior_or_null == nxt; nxt = g_prior_or_null + n3; }
-    if (g_clip_or_null) { one = one && g_clip_or_null == nxt; nxt = g_clip_or_null + 4 * (size_t)B * V; }
-    if (one) {
-        A3D_HIP(hipMemsetAsync(g_vpos, 0, sizeof(float) * (size_t)(nxt - g_vpos), s));
-    } else {
-        A3D_HIP(hipMemsetAsync(g_vpos, 0, sizeof(float) * n3, s));
-        A3D_HIP(hipMemsetAsync(g_vnrm, 0, sizeof(float) * n3, s));
-        if (g_prior_or_null) A3D_HIP(hipMemsetAsync(g_prior_or_null, 0, sizeof(float) * n3, s));
-        if (g_clip_or_null) A3D_HIP(hipMemsetAsync(g_clip_or_null, 0, sizeof(float) * 4 * (size_t)B * V, s));
-    }
+    A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;
-    A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior && (!g_clip_or_null || clip));
-    GbTargets tg;
-    tg.vpos = g_vpos; tg.vnrm = g_vnrm; tg.prior = g_prior_or_null; tg.clip = g_clip_or_null;
+    A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior);
     hipLaunchKernelGGL(gb_bwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P,
-                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, tg);
+                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows, want_prior);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

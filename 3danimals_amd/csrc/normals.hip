@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v
 }
 
 // d(normalize(acc))/d(acc) applied to g_nrm; zero where the default normal was substituted
-__global__ __launch_bounds__(256) void nr_vert_bwd_kernel(const float* __restrict__ g_nrm, const float* __restrict__ acc, long long n,
-                                                          float* __restrict__ g_acc) {
+__global__ __launch_bounds__(256) void nr_vert_bwd_kernel(const float* __restrict__ g_nrm, int g_stride, const float* __restrict__ acc,
+                                                          long long n, float* __restrict__ g_acc) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = acc[3 * i], y = acc[3 * i + 1], z = acc[3 * i + 2];
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void nr_vert_bwd_kernel(const float* __restric
     if (d > 1e-20f) {
         const float inv = 1.f / sqrtf(d);
         const float nx = x * inv, ny = y * inv, nz = z * inv;
-        const float gx = g_nrm[3 * i], gy = g_nrm[3 * i + 1], gz = g_nrm[3 * i + 2];
+        const float* gr = g_nrm + (long long)g_stride * i;
+        const float gx = gr[0], gy = gr[1], gz = gr[2];
         const float dot = nx * gx + ny * gy + nz * gz;
         ox = (gx - nx * dot) * inv; oy = (gy - ny * dot) * inv; oz = (gz - nz * dot) * inv;
     }
@@ -145,13 +146,13 @@ extern "C" int a3d_normals_fwd(const float* v, const int32_t* tri, const int32_t
     return A3D_OK;
 }
 
-extern "C" int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const int32_t* tri, const int32_t* off,
+extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float* acc, const float* v, const int32_t* tri, const int32_t* off,
                                const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_nrm && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0);
+    A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * V;
-    hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, acc, n, g_acc_scratch);
+    hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, n, g_acc_scratch);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(nr_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v);
     A3D_LAUNCH_CHECK();

@@ -282,7 +282,9 @@ class _Normals(torch.autograd.Function):
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         scratch = torch.empty_like(v)
         g_v = torch.empty_like(v)
-        call("a3d_normals_bwd", ptr(f32c(g_nrm)), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
+        if g_nrm.dtype != torch.float32 or g_nrm.stride(2) != 1 or g_nrm.stride(0) != V * g_nrm.stride(1):  # rows must be evenly strided
+            g_nrm = f32c(g_nrm)
+        call("a3d_normals_bwd", ptr(g_nrm), g_nrm.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
              ptr(scratch), ptr(g_v), stream(), tag=f"[B{B}]")
         return g_v, None, None
 
@@ -435,6 +437,9 @@ def interpolate_da(attr, rast, tri, rast_db, diff_attrs="all"):
 
 
 # ---------------------------------------------------------------------------------------------- fused G-buffer
+GBUFFER_GRAD_COLS = 16  # A3D_GBUFFER_GRAD_COLS of include/a3d.h
+
+
 class _GBuffer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix):
@@ -456,20 +461,18 @@ class _GBuffer(torch.autograd.Function):
         B, H, W = rast.shape[:3]
         V, P = v_pos.shape[1], pix.shape[0]
         want_prior, want_clip = ctx.needs_input_grad[3], ctx.needs_input_grad[0]
-        # the four gradient buffers carved out of ONE allocation (vpos | vnrm | prior | clip): the C side zeroes them with one memset
-        n3 = B * V * 3
-        flat = torch.empty(n3 * (2 + int(want_prior)) + (B * V * 4 if want_clip else 0), dtype=torch.float32, device=rast.device)
-        g_vpos, g_vnrm = flat[:n3].view(B, V, 3), flat[n3:2 * n3].view(B, V, 3)
-        off = 2 * n3
-        g_prior = g_clip = None
+        # one 64-byte gradient row per (image, vertex): the kernel's twelve atomics of a vertex are then one line request; the four
+        # gradients are strided views of the rows (a3d.h: v_pos 0..2 | v_nrm 3..5 | canonical 6..8 | clip 12..15)
+        rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
+        call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
+             ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(want_prior), stream())
+        g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
+        g_clip = rows[..., 12:16] if want_clip else None
+        g_prior = None
         if want_prior:
-            g_prior, off = flat[off:off + n3].view(B, V, 3), off + n3
-        if want_clip:
-            g_clip = flat[off:].view(B, V, 4)
-        call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], ptr(clip),
-             B, V, tri32.shape[0], H, W, ptr(g_vpos), ptr(g_vnrm), ptr(g_prior), ptr(g_clip), stream())
-        if g_prior is not None and prior.shape[0] == 1:
-            g_prior = g_prior.sum(0, keepdim=True)
+            g_prior = rows[..., 6:9]
+            if prior.shape[0] == 1:
+                g_prior = g_prior.sum(0, keepdim=True)
         return g_clip, g_vpos, g_vnrm, g_prior, None, None, None
 
 

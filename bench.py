@@ -279,6 +279,23 @@ def main():
         kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of)
         roofline = roofline_of(kernels, dims)
 
+    # ---- blocking host <-> device synchronisations inside one steady-state step (torch's sync-debug hook; sizes that shapes depend on)
+    host_syncs = None
+    if rank == 0 and world == 1:
+        import warnings
+
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                scene.step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        sites = [str(w.message).split("(Triggered")[0].strip()[:80] + f" @ {os.path.basename(w.filename)}:{w.lineno}" for w in caught
+                 if "synchroniz" in str(w.message).lower() and "prototype feature" not in str(w.message)]
+        host_syncs = dict(per_step=len(sites), sites=sorted(set(sites)))
+
     threads = min(os.cpu_count(), 32)  # torch-CPU stops scaling (and thrashes) far below the 256 logical cores of the GPU box
     parity = cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -351,6 +368,7 @@ def main():
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
                        "per_rank_data": "same poses/cameras on every rank (equal work per GPU), per-rank image features and targets"},
             "roofline": roofline,
+            "host_syncs": host_syncs,
             "parity": parity,
             "dropin": dropin,
             "cpu_baseline": cpu_baseline,

@@ -91,12 +91,14 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
  *   list sorted, i.e. in the order the reference's three scatter_add_ passes visit them, mesh.py:291-293); cursor[V] = scratch.
  * fwd: acc[B,V,3] receives the un-normalised sums (saved for backward), nrm[B,V,3] the result (zero sums -> (0,0,1), then
  *   safe_normalize, mesh.py:296-299).  No float atomics: results are bit-reproducible.
+ * bwd: g_nrm is read with a row stride (3 = contiguous [B,V,3]; 16 = the v_nrm columns of a3d_gbuffer_bwd's gradient rows).
  */
 int a3d_normals_adjacency(const int32_t* tri /*[F,3]*/, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream);
 int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, const int32_t* off, const int32_t* adj, int B, int V, int F,
                     float* acc, float* nrm, a3d_stream_t stream);
-int a3d_normals_bwd(const float* g_nrm, const float* acc, const float* v, const int32_t* tri, const int32_t* off, const int32_t* adj, int B,
-                    int V, int F, float* g_acc_scratch /*[B,V,3]*/, float* g_v /*[B,V,3]*/, a3d_stream_t stream);
+int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apart*/, int g_nrm_stride, const float* acc, const float* v,
+                    const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3]*/,
+                    float* g_v /*[B,V,3]*/, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-point shading arithmetic -- replaces the elementwise part of shade(), /root/reference/model/render/render.py:71-93:
@@ -166,15 +168,17 @@ int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* a
  * render_layer, /root/reference/model/render/render.py:182-209, and in backward also dr.rasterize's gradient.
  * pix[P] = flat indices (b*H + y)*W + x of the covered pixels (int64); out[P,12] =
  * [world position | normalised face normal | interpolated vertex normal | interpolated canonical position].
- * Backward (all zeroed by callee -- one memset when the four buffers are consecutive in one allocation, vpos | vnrm | prior | clip):
- * g_vpos[B,V,3], g_vnrm[B,V,3], g_prior[B,V,3] (per image even when the canonical mesh is shared: the caller sums over B; may be
- * null), g_clip[B,V,4] (x, y, w gradients through the barycentrics; may be null).  clip is [B,V,4].
+ * Backward: g_rows[B*V, A3D_GBUFFER_GRAD_COLS] (64-byte aligned, zeroed by callee), one 64-byte row per (image, vertex) so that the
+ * twelve atomics of a vertex are one line request: columns 0..2 d/d v_pos, 3..5 d/d v_nrm, 6..8 d/d canonical position (per image even
+ * when the canonical mesh is shared: the caller sums over B; left zero unless want_prior), 12..15 d/d clip (x, y, 0, w -- through the
+ * barycentrics; left zero when clip is null), 9..11 zero.  Callers take strided views of the rows.  clip is [B,V,4].
  */
+#define A3D_GBUFFER_GRAD_COLS 16
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                     const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream);
 int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
-                    const float* v_nrm, const float* prior, int prior_batch, const float* clip, int B, int V, int F, int H, int W,
-                    float* g_vpos, float* g_vnrm, float* g_prior_or_null, float* g_clip_or_null, a3d_stream_t stream);
+                    const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
+                    float* g_rows, int want_prior, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of

@@ -53,11 +53,9 @@ def main():
     ptr, stream = L.ptr, L.stream
     if what == "gbuffer_bwd":
         g = torch.rand(P, 12, device=dev)
-        flat = torch.empty(B * V * 13, device=dev)
-        n3 = B * V * 3
-        gv, gn, gp, gc = flat[:n3], flat[n3:2 * n3], flat[2 * n3:3 * n3], flat[3 * n3:]
+        rows = torch.empty(B * V, 16, device=dev)
         fn = lambda: L.call("a3d_gbuffer_bwd", ptr(g), ptr(rast), ptr(tri32), ptr(pix), P, ptr(vpos), ptr(nrm), ptr(pv), 1, ptr(clip), B, V, F, H, W,
-                            ptr(gv), ptr(gn), ptr(gp), ptr(gc), stream())
+                            ptr(rows), 1, stream())
     elif what == "rast_fwd":
         out = torch.empty(B, H, W, 4, device=dev)
         scratch = torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
