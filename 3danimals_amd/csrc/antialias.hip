@@ -198,6 +198,40 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
     }
 }
 
+// d(loss)/d(alpha) of one crossing record pushed onto the two vertices of the crossing edge (clip x, y, w)
+__device__ __forceinline__ void aa_edge_adjoint(const AaRec& rec, unsigned p0, int d, int di, bool use1, float dd, const float4* __restrict__ clip,
+                                                int clip_batch, const int* __restrict__ tri, int V, int H, int W, float xh, float yh,
+                                                float* __restrict__ g_clip) {
+    // alpha = ds*0.5 - xint,  xint = (Xa*Yb - Ya*Xb)/(Yb - Ya) in the (pair-direction, other) frame
+    const int b = (int)(p0 / ((unsigned)H * (unsigned)W));
+    const int rem = (int)(p0 - (unsigned)b * ((unsigned)H * (unsigned)W));
+    const int y = rem / W, x = rem - y * W;
+    const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
+    const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
+    const long long vb = clip_batch == 1 ? 0ll : (long long)b * V;
+    const int ia = tri[3 * rec.tri + (di + 1) % 3], ib = tri[3 * rec.tri + (di + 2) % 3];
+    const float4 pa = clip[vb + ia], pbv = clip[vb + ib];
+    float sxa, sya, sxb, syb;
+    aa_project(pa, fx, fy, xh, yh, sxa, sya);
+    aa_project(pbv, fx, fy, xh, yh, sxb, syb);
+    const float Xa = d ? sya : sxa, Ya = d ? sxa : sya, Xb = d ? syb : sxb, Yb = d ? sxb : syb;
+    const float D = Yb - Ya, iD = 1.f / D, iD2 = iD * iD;
+    const float gx = -dd;  // dL/dxint
+    const float gXa = gx * Yb * iD, gXb = -gx * Ya * iD;
+    const float gYa = gx * Yb * (Xa - Xb) * iD2, gYb = gx * Ya * (Xb - Xa) * iD2;
+    // back to screen x / y
+    const float gsxa = d ? gYa : gXa, gsya = d ? gXa : gYa, gsxb = d ? gYb : gXb, gsyb = d ? gXb : gYb;
+    float* oa = g_clip + (vb + ia) * 4;
+    float* ob = g_clip + (vb + ib) * 4;
+    const float iwa = 1.f / pa.w, iwb = 1.f / pbv.w;
+    atomicAdd(oa, gsxa * xh * iwa);
+    atomicAdd(oa + 1, gsya * yh * iwa);
+    atomicAdd(oa + 3, -(gsxa * pa.x * xh + gsya * pa.y * yh) * iwa * iwa);
+    atomicAdd(ob, gsxb * xh * iwb);
+    atomicAdd(ob + 1, gsyb * yh * iwb);
+    atomicAdd(ob + 3, -(gsxb * pbv.x * xh + gsyb * pbv.y * yh) * iwb * iwb);
+}
+
 // 32 lanes per crossing record: lane l takes channels l, l + 32, ... (colour gradients of both pixels, two atomics per channel) and
 // the lanes' partial d(loss)/d(alpha) meet in lane 0, which pushes it onto the two vertices of the crossing edge.  (One thread per
 // record walked the channels serially: 21 us for the 17-channel buffer.)
@@ -227,34 +261,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ g
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);  // stays inside the 32-lane half
         if (sub != 0 || clamped || dd == 0.f) continue;
-        // alpha = ds*0.5 - xint,  xint = (Xa*Yb - Ya*Xb)/(Yb - Ya) in the (pair-direction, other) frame
-        const int b = (int)(p0 / ((long long)H * W));
-        const int rem = (int)(p0 - (long long)b * H * W);
-        const int y = rem / W, x = rem - y * W;
-        const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
-        const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
-        const long long vb = clip_batch == 1 ? 0ll : (long long)b * V;
-        const int ia = tri[3 * rec.tri + (di + 1) % 3], ib = tri[3 * rec.tri + (di + 2) % 3];
-        const float4 pa = clip[vb + ia], pbv = clip[vb + ib];
-        float sxa, sya, sxb, syb;
-        aa_project(pa, fx, fy, xh, yh, sxa, sya);
-        aa_project(pbv, fx, fy, xh, yh, sxb, syb);
-        const float Xa = d ? sya : sxa, Ya = d ? sxa : sya, Xb = d ? syb : sxb, Yb = d ? sxb : syb;
-        const float D = Yb - Ya, iD = 1.f / D, iD2 = iD * iD;
-        const float gx = -dd;  // dL/dxint
-        const float gXa = gx * Yb * iD, gXb = -gx * Ya * iD;
-        const float gYa = gx * Yb * (Xa - Xb) * iD2, gYb = gx * Ya * (Xb - Xa) * iD2;
-        // back to screen x / y
-        const float gsxa = d ? gYa : gXa, gsya = d ? gXa : gYa, gsxb = d ? gYb : gXb, gsyb = d ? gXb : gYb;
-        float* oa = g_clip + (vb + ia) * 4;
-        float* ob = g_clip + (vb + ib) * 4;
-        const float iwa = 1.f / pa.w, iwb = 1.f / pbv.w;
-        atomicAdd(oa, gsxa * xh * iwa);
-        atomicAdd(oa + 1, gsya * yh * iwa);
-        atomicAdd(oa + 3, -(gsxa * pa.x * xh + gsya * pa.y * yh) * iwa * iwa);
-        atomicAdd(ob, gsxb * xh * iwb);
-        atomicAdd(ob + 1, gsyb * yh * iwb);
-        atomicAdd(ob + 3, -(gsxb * pbv.x * xh + gsyb * pbv.y * yh) * iwb * iwb);
+        aa_edge_adjoint(rec, (unsigned)p0, d, di, use1, dd, clip, clip_batch, tri, V, H, W, xh, yh, g_clip);
     }
 }
 
@@ -276,6 +283,152 @@ extern "C" int a3d_aa_capacity(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return AA_SHARDS;
     const long long groups = 2ll * B * a3d_div_up((long long)H * W, 256);
     return (int)(a3d_div_up(groups, AA_SHARDS) * 256 * AA_SHARDS);
+}
+
+// ---- compositing fused with the antialiasing -------------------------------------------------------------------------------------------
+// render_mesh composites the shaded points over the background (coverage is 0 or 1, so lerp(bg, [rgb, 1], alpha), render.py:261-262, is
+// a select) and antialiases the result (render.py:311-312).  As separate steps that is a background fill, a scatter of the points, the
+// antialiasing's copy of the whole image and its blends -- and in backward the same passes again.  Here the image is written ONCE from
+// its sources (point rows through the pixel -> point map `inv`, background elsewhere), the blends read the same sources (dr.antialias
+// blends input colours, never already blended ones), and the backward never materialises a dense colour gradient: the incoming
+// gradient is gathered at the covered pixels and the blend adjoints are added to the point rows directly.
+struct CaSrc {
+    const float* vals;  // [P, C]
+    const int* inv;     // [B*H*W] point of a pixel, -1 = uncovered
+    const float* bg;    // [bg_batch, H, W, C+1] or null (zeros)
+    int bg_shared;      // bg_batch == 1
+    int C;
+    unsigned hw;
+};
+
+__device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
+    const int q = s.inv[p];
+    if (q >= 0) return c < s.C ? s.vals[(long long)q * s.C + c] : 1.f;
+    if (!s.bg) return 0.f;
+    const unsigned r = s.bg_shared ? p % s.hw : p;
+    return s.bg[(long long)r * (s.C + 1) + c];
+}
+
+// 256 pixels per work-group: the pixel -> source map goes through LDS once, then the work-group writes the pixels' C+1 floats as one
+// contiguous run.  (j / C1 for j < 256*C1 as a float multiply: exact in that range, and an integer division per element -- ~40
+// instructions, 150 in 64 bits -- made this pass instruction bound: 39 us for the 17-channel image.)
+__global__ __launch_bounds__(256) void ca_compose_kernel(CaSrc s, unsigned n_pix, float* __restrict__ out) {
+    __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
+    const unsigned base = blockIdx.x * 256u, p = base + threadIdx.x;
+    const int C1 = s.C + 1;
+    if (p < n_pix) {
+        const int q = s.inv[p];
+        s_src[threadIdx.x] = q >= 0 ? q : (s.bg ? -2 - (int)(s.bg_shared ? p % s.hw : p) : -1);
+    }
+    __syncthreads();
+    const int nloc = (int)min(256u, n_pix - base) * C1;
+    const float rc = 1.f / (float)C1;
+    float* o = out + (long long)base * C1;
+    // 16 bytes per lane (the run starts on a 16-byte boundary: 256 * C1 floats per work-group); a ragged tail goes float by float
+    const int n4 = (((uintptr_t)out & 15) == 0) ? (nloc & ~3) : 0;
+    for (int j0 = 4 * threadIdx.x; j0 < n4; j0 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
+            const int src = s_src[pl];
+            v[k] = 0.f;
+            if (src >= 0) v[k] = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
+            else if (src <= -2) v[k] = s.bg[(long long)(-2 - src) * C1 + c];
+        }
+        *reinterpret_cast<float4*>(o + j0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int j = n4 + threadIdx.x; j < nloc; j += 256) {
+        const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
+        const int src = s_src[pl];
+        float v = 0.f;
+        if (src >= 0) v = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
+        else if (src <= -2) v = s.bg[(long long)(-2 - src) * C1 + c];
+        o[j] = v;
+    }
+}
+
+// C + 1 == 4: one 16-byte texel per thread
+__global__ __launch_bounds__(256) void ca_compose4_kernel(CaSrc s, unsigned n_pix, float4* __restrict__ out) {
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    const int q = s.inv[p];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= 0) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
+    else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
+    out[p] = v;
+}
+
+__global__ __launch_bounds__(256) void ca_blend_kernel(CaSrc s, const AaRec* __restrict__ work, const int* __restrict__ count, int capacity, int W,
+                                                       float* __restrict__ out) {
+    __shared__ int s_off[AA_SHARDS + 1];
+    const int n = aa_segment_offsets(count, capacity, s_off);
+    const unsigned C1 = (unsigned)s.C + 1u;
+    const unsigned total = (unsigned)n * C1;  // (n <= capacity records, C1 <= 4096)
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned ru = idx / C1;
+        const int r = (int)ru, c = (int)(idx - ru * C1);
+        const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
+        const unsigned p0 = (unsigned)rec.pix0, p1 = p0 + ((rec.flags & 1) ? (unsigned)W : 1u);
+        const unsigned dst = rec.alpha > 0.f ? p0 : p1;
+        const float d = ca_pre(s, p1, c) - ca_pre(s, p0, c);
+        if (d != 0.f) atomicAdd(out + (long long)dst * C1 + c, rec.alpha * d);
+    }
+}
+
+// g_vals[p, :C] = g_out[pix[p], :C] (the select's adjoint), 256 points per work-group (same index arithmetic as the compositor); the
+// first work-groups also zero g_clip
+__global__ __launch_bounds__(256) void ca_gather_kernel(const float* __restrict__ g_out, const long long* __restrict__ pix, long long P, int C,
+                                                        float* __restrict__ g_vals, float* __restrict__ zero, long long nz) {
+    __shared__ unsigned s_pix[256];
+    const long long base = (long long)blockIdx.x * 256, p = base + threadIdx.x;
+    if (p < P) s_pix[threadIdx.x] = (unsigned)pix[p];
+    for (long long i = p; i < nz; i += (long long)gridDim.x * 256) zero[i] = 0.f;
+    __syncthreads();
+    if (base >= P) return;
+    const int nloc = (int)min(256ll, P - base) * C, C1 = C + 1;
+    const float rc = 1.f / (float)C;
+    float* o = g_vals + base * C;
+    for (int j = threadIdx.x; j < nloc; j += 256) {
+        const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C;
+        o[j] = g_out[(long long)s_pix[pl] * C1 + c];
+    }
+}
+
+// aa_bwd_kernel on the composited image: colours come from the sources, colour adjoints go to the point rows
+__global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ g_out, CaSrc s, const AaRec* __restrict__ work,
+                                                     const int* __restrict__ count, int capacity, const float4* __restrict__ clip, int clip_batch,
+                                                     const int* __restrict__ tri, int V, int H, int W, float* __restrict__ g_vals,
+                                                     float* __restrict__ g_clip) {
+    __shared__ int s_off[AA_SHARDS + 1];
+    const int n = aa_segment_offsets(count, capacity, s_off);
+    const float xh = 0.5f * W, yh = 0.5f * H;
+    const int C = s.C, C1 = s.C + 1;
+    const int sub = threadIdx.x & 31, groups = (gridDim.x * blockDim.x) >> 5;
+    for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; r < n; r += groups) {
+        const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
+        const int d = rec.flags & 1, di = (rec.flags >> 1) & 3;
+        const bool use1 = rec.flags & 8, clamped = rec.flags & 16;
+        const unsigned p0 = (unsigned)rec.pix0, p1 = p0 + (d ? (unsigned)W : 1u);
+        const unsigned dst = rec.alpha > 0.f ? p0 : p1;
+        const int q0 = s.inv[p0], q1 = s.inv[p1];
+        float dd = 0.f;
+        for (int c = sub; c < C1; c += 32) {
+            const float gd = g_out[(long long)dst * C1 + c];
+            if (gd != 0.f) {
+                if (c < C) {
+                    if (q1 >= 0) atomicAdd(g_vals + (long long)q1 * C + c, rec.alpha * gd);
+                    if (q0 >= 0) atomicAdd(g_vals + (long long)q0 * C + c, -rec.alpha * gd);
+                }
+                dd += gd * (ca_pre(s, p1, c) - ca_pre(s, p0, c));
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 64);  // stays inside the 32-lane half
+        if (sub != 0 || clamped || dd == 0.f) continue;
+        aa_edge_adjoint(rec, p0, d, di, use1, dd, clip, clip_batch, tri, V, H, W, xh, yh, g_clip);
+    }
 }
 
 extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * 16; }
@@ -347,6 +500,52 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
     A3D_CHECK_ARG(tri);
     hipLaunchKernelGGL(aa_bwd_kernel, dim3(1024), dim3(256), 0, s, g_out, color, C, (const AaRec*)work, count, capacity,
                        (const float4*)clip, clip_batch, tri, V, H, W, g_color, g_clip);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const int32_t* inv, const float* bg_or_null, int bg_batch, const void* work,
+                                    const int32_t* count, int capacity, int B, int H, int W, float* out, a3d_stream_t stream) {
+    A3D_CHECK_ARG(inv && work && count && out && C > 0 && B > 0 && H > 0 && W > 0 && capacity > 0);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
+    hipStream_t s = (hipStream_t)stream;
+    CaSrc src;
+    src.vals = vals; src.inv = inv; src.bg = bg_or_null; src.bg_shared = bg_batch == 1; src.C = C; src.hw = (unsigned)H * (unsigned)W;
+    const unsigned n_pix = (unsigned)B * src.hw;
+    if (C == 3 && (((uintptr_t)out | (uintptr_t)bg_or_null) & 15) == 0) {
+        hipLaunchKernelGGL(ca_compose4_kernel, dim3(a3d_div_up(n_pix, 256)), dim3(256), 0, s, src, n_pix, (float4*)out);
+    } else {
+        A3D_CHECK_ARG(C + 1 <= 4096);  // the float-multiply division of the kernel
+        hipLaunchKernelGGL(ca_compose_kernel, dim3(a3d_div_up(n_pix, 256)), dim3(256), 0, s, src, n_pix, out);
+    }
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_blend_kernel, dim3(512), dim3(256), 0, s, src, (const AaRec*)work, count, capacity, W, out);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const int64_t* pix, int64_t P, const int32_t* inv,
+                                    const float* bg_or_null, int bg_batch, const void* work, const int32_t* count, int capacity, const float* clip,
+                                    int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_vals, float* g_clip,
+                                    a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && inv && work && count && clip && g_clip && C > 0 && B > 0 && V > 0 && H > 0 && W > 0 && P >= 0 && capacity > 0);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
+    A3D_CHECK_ARG(P == 0 || (vals && pix && g_vals));
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const long long nz = 4ll * clip_batch * V;
+        long long blocks = a3d_div_up((long long)P, 256);
+        if (blocks < 64) blocks = 64;  // enough work-groups to zero g_clip when the point list is short
+        A3D_CHECK_ARG(C <= 4096);
+        hipLaunchKernelGGL(ca_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_out, (const long long*)pix, (long long)P, C, g_vals, g_clip, nz);
+        A3D_LAUNCH_CHECK();
+    }
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri);
+    CaSrc src;
+    src.vals = vals; src.inv = inv; src.bg = bg_or_null; src.bg_shared = bg_batch == 1; src.C = C; src.hw = (unsigned)H * (unsigned)W;
+    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024), dim3(256), 0, s, g_out, src, (const AaRec*)work, count, capacity, (const float4*)clip, clip_batch,
+                       tri, V, H, W, g_vals, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

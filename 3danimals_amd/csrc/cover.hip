@@ -65,7 +65,8 @@ __global__ __launch_bounds__(CV_SCAN_THREADS) void cv_scan_kernel(int* __restric
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
-                                                           const int* __restrict__ block_off, long long* __restrict__ pix) {
+                                                           const int* __restrict__ block_off, long long* __restrict__ pix,
+                                                           int* __restrict__ inv) {
     __shared__ int wave_n[CV_BLOCK / 64];
     const long long k = (long long)blockIdx.x * CV_BLOCK + threadIdx.x;
     const long long flat = k < n ? cv_flat(k, H, W, tile) : 0;
@@ -74,10 +75,14 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restr
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) wave_n[wave] = __popcll(m);
     __syncthreads();
-    if (!on) return;
+    if (!on) {
+        if (inv && k < n) inv[flat] = -1;
+        return;
+    }
     int o = block_off[blockIdx.x] + a3d_wave_prefix(m);
     for (int w = 0; w < wave; ++w) o += wave_n[w];
     pix[o] = flat;
+    if (inv) inv[flat] = o;  // pixel -> entry of the list: what the fused compositor reads
 }
 
 }  // namespace
@@ -106,12 +111,13 @@ extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile,
     return A3D_OK;
 }
 
-extern "C" int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix, a3d_stream_t stream) {
+extern "C" int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix, int32_t* inv_or_null,
+                              a3d_stream_t stream) {
     if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
-    A3D_CHECK_ARG(pix);
+    A3D_CHECK_ARG(pix || inv_or_null);  // an empty list (total = 0) has no pix storage; the inverse map is still written
     const long long n = (long long)B * H * W;
     hipLaunchKernelGGL(cv_emit_kernel, dim3(a3d_div_up(n, CV_BLOCK)), dim3(CV_BLOCK), 0, (hipStream_t)stream, (const float4*)rast, n, H, W,
-                       tile, (const int*)scratch, (long long*)pix);
+                       tile, (const int*)scratch, (long long*)pix, inv_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

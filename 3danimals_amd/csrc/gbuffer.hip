@@ -169,15 +169,13 @@ __device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0
 #define GB_ENTRIES 640  // staged (pixel, corner) contributions of one work-group (768 possible, ~512 after the pair merge); overflow goes direct
 #define GB_ROW 16       // floats per gradient row = one 64-byte line: [0..2] v_pos, [3..5] v_nrm, [6..8] canonical, [12] [13] [15] clip x y w
 
-// find-or-claim the table slot of a vertex row; `first` is set for the one thread that claimed it
-__device__ __forceinline__ int gb_slot(int* s_key, int key, bool& first) {
+// find-or-claim the table slot of a vertex row
+__device__ __forceinline__ int gb_slot(int* s_key, int key) {
     unsigned h = ((unsigned)key * 2654435761u) >> 23;  // top 9 bits
-    first = false;
 #pragma unroll 1
     for (int t = 0; t < GB_PROBES; ++t) {
         const int old = atomicCAS(&s_key[h], -1, key);
-        if (old == -1) { first = true; return (int)h; }
-        if (old == key) return (int)h;
+        if (old == -1 || old == key) return (int)h;
         h = (h + 1) & (GB_SLOTS - 1);
     }
     return -1;  // table crowded: the caller falls back to global atomics
@@ -250,19 +248,23 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
             const float o = gb_xor1(acc[c][k]);
             if (same) acc[c][k] += o;
         }
-    // stage: each (pixel, corner) row goes to LDS with plain stores and is linked into the list of its vertex (one integer exchange)
-    if (live && !(same && (threadIdx.x & 1))) {
+    // stage: each (pixel, corner) row goes to LDS with plain stores and is linked into the list of its vertex (one integer exchange);
+    // entries are handed out per wave (one counter update per wave, not per lane)
+    const bool active = live && !(same && (threadIdx.x & 1));
+    const unsigned long long amask = __ballot(active);
+    int wbase = 0;
+    if (a3d_lane_id() == 0 && amask) wbase = atomicAdd(&s_n[0], 3 * __popcll(amask));
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    if (active) {
         const int rowb = b * V;
         const int idx[3] = {i0, i1, i2};
-        const int base = atomicAdd(&s_n[0], 3);
+        const int base = wbase + 3 * a3d_wave_prefix(amask);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int key = rowb + idx[c];
-            bool first = false;
             const int e = base + c;
-            const int slot = e < GB_ENTRIES ? gb_slot(s_key, key, first) : -1;
+            const int slot = e < GB_ENTRIES ? gb_slot(s_key, key) : -1;
             if (slot >= 0) {
-                if (first) s_used[atomicAdd(&s_n[1], 1)] = slot;
                 float* dst = s_stage + e * 13;
 #pragma unroll
                 for (int k = 0; k < 12; ++k) dst[k] = acc[c][k];
@@ -273,21 +275,34 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         }
     }
     __syncthreads();
+    // the claimed slots, compacted (ballot + one counter update per wave)
+    for (int sidx = threadIdx.x; sidx < GB_SLOTS; sidx += blockDim.x) {
+        const bool used = s_key[sidx] >= 0;
+        const unsigned long long um = __ballot(used);
+        int ub = 0;
+        if (a3d_lane_id() == 0 && um) ub = atomicAdd(&s_n[1], __popcll(um));
+        ub = __builtin_amdgcn_readfirstlane(ub);
+        if (used) s_used[ub + a3d_wave_prefix(um)] = sidx;
+    }
+    __syncthreads();
     // reduce + flush: 16 lanes per vertex, lane = component, so the twelve atomics of a vertex are ONE 64-byte line request
-    // (line-coalesced device atomics are ~10x cheaper than the same number of scattered ones, see the header)
+    // (line-coalesced device atomics are ~10x cheaper than the same number of scattered ones, see the header); two vertices in
+    // flight per group so that the list walks (one LDS round trip per entry) overlap
     const int n_used = s_n[1];
-    const int k = threadIdx.x & 15;
+    const int k = threadIdx.x & 15, kk = k < 12 ? k : 12;
     const bool lane_on = k < 12 && (k < 6 || k >= 9 || want_prior) && (k < 9 || want_clip);
-    for (int j = threadIdx.x >> 4; j < n_used; j += 16) {
-        const int slot = s_used[j];
-        int e = s_head[slot];
-        float sum = 0.f;
-        while (e >= 0) {
-            const float* src = s_stage + e * 13;
-            if (k < 12) sum += src[k];
-            e = __float_as_int(src[12]);
+    for (int j = threadIdx.x >> 4; j < n_used; j += 32) {
+        const int slot_a = s_used[j], slot_b = j + 16 < n_used ? s_used[j + 16] : -1;
+        int ea = s_head[slot_a], eb = slot_b >= 0 ? s_head[slot_b] : -1;
+        float sum_a = 0.f, sum_b = 0.f;
+        while (ea >= 0 || eb >= 0) {
+            if (ea >= 0) { const float* src = s_stage + ea * 13; const float v = src[kk]; ea = __float_as_int(src[12]); if (k < 12) sum_a += v; }
+            if (eb >= 0) { const float* src = s_stage + eb * 13; const float v = src[kk]; eb = __float_as_int(src[12]); if (k < 12) sum_b += v; }
         }
-        if (lane_on) atomicAdd(g_rows + (long long)GB_ROW * s_key[slot] + gb_col(k), sum);
+        if (lane_on) {
+            atomicAdd(g_rows + (long long)GB_ROW * s_key[slot_a] + gb_col(k), sum_a);
+            if (slot_b >= 0) atomicAdd(g_rows + (long long)GB_ROW * s_key[slot_b] + gb_col(k), sum_b);
+        }
     }
 }
 

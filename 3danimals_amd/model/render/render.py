@@ -26,6 +26,7 @@ from . import light, util
 from . import renderutils as ru
 
 ANTIALIASED_MODES = ("shaded", "flow", "dino_pred", "depth", "shading")  # reference render.py:311
+FUSED_COMPOSITE = True  # sparse buffers: composite + antialias as one op (ops.composite_antialias); False = torch composite + ops.antialias
 SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixels only (output-identical; see shade())
 POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple of this (0 = off)
 LAST_RAST = [None]
@@ -136,9 +137,9 @@ def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_po
 class SparseBuffers(dict):
     """mode -> [P,C] values at the covered pixels ``pix`` (flat indices into [B,H,W]); what the fused path hands to the compositor."""
 
-    def __init__(self, pix, bhw):
+    def __init__(self, pix, bhw, inv=None):
         super().__init__()
-        self.pix, self.bhw = pix, bhw
+        self.pix, self.bhw, self.inv = pix, bhw, inv  # inv: pixel -> row (int32 [B*H*W], -1 = uncovered) when the list came with it
 
     def dense(self, mode):
         """[B,H,W,C+1] with alpha 1 on covered pixels, zeros elsewhere (the layout render_layer returns in the reference)."""
@@ -149,7 +150,7 @@ class SparseBuffers(dict):
 
 
 def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lgt, material, bsdf, feat, render_modes, two_sided_shading,
-                  dino_net, class_vector, sparse=False, gb=None):
+                  dino_net, class_vector, sparse=False, gb=None, inv=None):
     """The arithmetic of shade() (reference render.py:30-132) on compact [P,.] arrays; scatters into dense [B,H,W,C+1]
     buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points."""
     b, h, w = bhw
@@ -208,7 +209,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
 
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
-    out = SparseBuffers(pix, (b, h, w))
+    out = SparseBuffers(pix, (b, h, w), inv)
     for mode in modes:
         out[mode] = buffers[mode]  # KeyError for an unknown / unavailable mode, like the reference (render.py:127-128)
     return out if sparse else {mode: out.dense(mode) for mode in out}
@@ -250,13 +251,13 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
              and clip.shape[0] == mesh.v_pos.shape[0] and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr())
     if fused:
         b, h, w = rast.shape[:3]
-        pix = _covered_pixels(rast)  # one host sync for the number of covered pixels
+        pix, inv = ops.covered_pixels(rast, tile=PIXEL_TILE, return_inverse=True)  # one host sync for the number of covered pixels
         gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
         flow = None
         if "flow" in render_modes:  # the one extra attribute of the sequence models: modular interpolate (its gradient reaches clip
             flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)  # through the rasteriser's own backward)
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
-                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb)
+                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb, inv=inv)
 
     rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
     gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)
@@ -337,7 +338,18 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         if key not in rendered:
             out_buffers.append(None)
             continue
-        if isinstance(rendered, SparseBuffers):
+        fused_aa = (isinstance(rendered, SparseBuffers) and rendered.inv is not None and key in ANTIALIASED_MODES and FUSED_COMPOSITE
+                    and not background.requires_grad)
+        if fused_aa:
+            # composite + antialias in one pass over the image (csrc/antialias.hip): same values as the two steps below
+            if analysis is None:
+                tri32 = ops.tri_int32(tri)
+                analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))
+            bgk = None
+            if key in ("shaded", "geo_normal", "shading"):
+                bgk = background[..., 2:] if (key == "shading" and background.shape[-1] == 4) else background
+            accum = ops.composite_antialias(rendered[key], rendered.pix, rendered.inv, bgk, clip_f, analysis)
+        elif isinstance(rendered, SparseBuffers):
             # coverage is 0 or 1, for which lerp(bg, [rgb,1], alpha) (render.py:261-262) returns exactly bg or exactly [rgb,1]:
             # start from the background and overwrite the covered pixels -- same bits, a third of the passes over the image
             vals = rendered[key]
@@ -355,7 +367,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
                 bg = bg[..., 2:]
             alpha = coverage * buf[..., -1:]
             accum = torch.lerp(bg, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)  # render.py:261-262
-        if key in ANTIALIASED_MODES:
+        if key in ANTIALIASED_MODES and not fused_aa:
             if analysis is None:
                 tri32 = ops.tri_int32(tri)
                 analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))

@@ -296,9 +296,10 @@ def vertex_normals(v, tri):
 
 
 # ---------------------------------------------------------------------------------------------- covered pixels
-def covered_pixels(rast, tile=8):
+def covered_pixels(rast, tile=8, return_inverse=False):
     """int64 [P] flat indices of the pixels with rast[...,3] > 0, image-major, 8x8-tile order inside an image (``tile=8``; falls back
-    to row-major when H or W is not a multiple of 8).  One 8-byte read-back (P) between the count and the emit launches."""
+    to row-major when H or W is not a multiple of 8).  One 8-byte read-back (P) between the count and the emit launches.
+    ``return_inverse``: also int32 [B*H*W], the list entry of every pixel (-1 = uncovered), written by the same launch."""
     require_device(rast, what="covered_pixels")
     rast = f32c(rast.detach())
     B, H, W = rast.shape[:3]
@@ -309,9 +310,10 @@ def covered_pixels(rast, tile=8):
     total = torch.empty(1, dtype=torch.int64, device=dev)
     call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), ptr(total), stream())
     pix = torch.empty(int(total.item()), dtype=torch.int64, device=dev)
-    if pix.shape[0]:
-        call("a3d_cover_emit", ptr(rast), B, H, W, tile, ptr(scratch), ptr(pix), stream())
-    return pix
+    inv = torch.empty(B * H * W, dtype=torch.int32, device=dev) if return_inverse else None
+    if pix.shape[0] or return_inverse:
+        call("a3d_cover_emit", ptr(rast), B, H, W, tile, ptr(scratch), ptr(pix), ptr(inv), stream())
+    return (pix, inv) if return_inverse else pix
 
 
 # ---------------------------------------------------------------------------------------------- rasterise
@@ -659,6 +661,47 @@ class _Antialias(torch.autograd.Function):
         call("a3d_aa_bwd", ptr(f32c(g_out)), ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri),
              B, a.clip.shape[1], a.topo.tri.shape[0], H, W, ptr(g_color), ptr(g_clip), stream(), tag=f"[C{C}]")
         return g_color, g_clip, None
+
+
+class _CompositeAntialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vals, clip, pix, inv, bg, analysis):
+        require_device(vals, pix, inv, what="composite_antialias")
+        vals = f32c(vals)
+        a = analysis
+        P, C = vals.shape
+        assert pix.shape == (P,) and pix.dtype == torch.int64 and inv.shape == (a.B * a.H * a.W,) and inv.dtype == torch.int32
+        if bg is not None:
+            bg = f32c(bg)
+            assert bg.shape[1:] == (a.H, a.W, C + 1) and bg.shape[0] in (1, a.B)
+        out = torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=vals.device)
+        call("a3d_composite_aa_fwd", ptr(vals), C, ptr(inv), ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
+             a.B, a.H, a.W, ptr(out), stream(), tag=f"[C{C + 1}]")
+        ctx.save_for_backward(vals, pix, inv, bg)
+        ctx.analysis = a
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        vals, pix, inv, bg = ctx.saved_tensors
+        a = ctx.analysis
+        P, C = vals.shape
+        g_vals = torch.empty_like(vals)
+        g_clip = torch.empty_like(a.clip)
+        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), ptr(vals), C, ptr(pix), P, ptr(inv), ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work),
+             ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W,
+             ptr(g_vals), ptr(g_clip), stream(), tag=f"[C{C + 1}]")
+        return g_vals, g_clip, None, None, None, None
+
+
+def composite_antialias(vals, pix, inv, background, clip, analysis):
+    """antialias(lerp(background, [vals, 1], coverage)) for a buffer given as rows ``vals`` [P,C] at the covered pixels ``pix`` (``inv`` =
+    the pixel -> row map of covered_pixels(return_inverse=True)): [B,H,W,C+1].  ``background`` [1|B,H,W,C+1] or None (zeros); it gets no
+    gradient (callers with a differentiable background composite with torch and call antialias)."""
+    assert background is None or not background.requires_grad
+    if clip.dim() == 2:
+        clip = clip[None]
+    return _CompositeAntialias.apply(vals, clip, pix, inv, background, analysis)
 
 
 def antialias(color, rast, clip, tri, analysis=None):

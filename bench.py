@@ -42,7 +42,7 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # roc
 # what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
 # (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
 IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
-            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_")
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_")
 F3 = ("a3d_recon_losses_",)
 
 
@@ -83,7 +83,11 @@ def algorithmic_bytes(name, d):
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
         "a3d_recon_losses_bwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1 + 16 + 64),
         "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
-        "a3d_cover_emit": 4 * B * HW + 8 * P,
+        "a3d_cover_emit": 4 * B * HW + 8 * P + 4 * B * HW,  # id channel in; list + pixel -> entry map out
+        # C = channels of the composited image (values + alpha): point rows in, image out (+ the crossing pixels); backward: image
+        # gradient read at the covered pixels, point-row gradient out, vertex gradient out
+        "a3d_composite_aa_fwd": 4 * B * HW + 4 * P * max(C - 1, 0) + 4 * C * B * HW,
+        "a3d_composite_aa_bwd": 8 * P + 8 * P * max(C - 1, 0) + 16 * B * V,
         "a3d_shade_fwd": P * (48 + 68 + 12 + 12 + 4 + 12),
         "a3d_shade_bwd": P * (48 + 68 + 12 + 28 + 48 + 68 + 12),
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,

@@ -119,11 +119,13 @@ int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_sha
  * image-major and inside an image 8x8-tile by tile (tile = 8; H, W multiples of 8) or row-major (tile = 0).  The list the fused
  * G-buffer / shading path runs over instead of the reference's dense [B,H,W] frame (/root/reference/model/render/render.py:
  * 139-221 shades every pixel; uncovered ones are composited with alpha 0, :261-262).
- * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device); the caller reads total back to size pix; emit writes pix.
+ * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device); the caller reads total back to size pix; emit writes pix and,
+ * when given, the inverse map inv[B*H*W] (entry of the list per pixel, -1 = uncovered) that a3d_composite_aa_* reads.
  */
 size_t a3d_cover_scratch_bytes(int B, int H, int W);
 int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, int64_t* total, a3d_stream_t stream);
-int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix /*[total]*/, a3d_stream_t stream);
+int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix /*[total]*/, int32_t* inv_or_null,
+                   a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rasterise -- replaces dr.DepthPeeler(...).rasterize_next_layer() layer 0 / dr.rasterize,
@@ -216,6 +218,18 @@ int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count
 int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,
                const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_color,
                float* g_clip, a3d_stream_t stream);
+/* Compositing fused with the antialiasing -- the lerp(bg, [value, 1], coverage) of /root/reference/model/render/render.py:261-262 followed
+ * by dr.antialias (render.py:311-315) for a buffer that exists as rows vals[P,C] at the covered pixels (pix / inv of a3d_cover_emit):
+ *   out[B,H,W,C+1] = [vals row, 1] at covered pixels, bg[bg_batch,H,W,C+1] (null = zeros) elsewhere, then the blends of a3d_aa_fwd
+ *   computed from the same sources.  One pass over the image instead of fill + scatter + copy + blend.
+ * bwd: g_vals[P,C] (fully written: g_out at the covered pixels + the blend adjoints; no dense colour gradient exists) and
+ *   g_clip[clip_batch,V,4] (zeroed by callee).  The background receives no gradient. */
+int a3d_composite_aa_fwd(const float* vals, int C, const int32_t* inv, const float* bg_or_null, int bg_batch, const void* work,
+                         const int32_t* count, int capacity, int B, int H, int W, float* out, a3d_stream_t stream);
+int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const int64_t* pix, int64_t P, const int32_t* inv,
+                         const float* bg_or_null, int bg_batch, const void* work, const int32_t* count, int capacity, const float* clip,
+                         int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_vals, float* g_clip,
+                         a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM with the ReLU adjoint in the epilogue: C[M,N] = (A[M,K] . B[K,N]) * (X[M,N] > 0), row-major, N = 256,

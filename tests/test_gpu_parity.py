@@ -941,6 +941,43 @@ def test_covered_pixels_compaction_is_exact(shape, tile, dev, ops):
         else:
             want = torch.nonzero(cover.reshape(-1)).squeeze(1)
         assert pix.dtype == torch.int64 and torch.equal(pix, want), (shape, tile, density)
+        pix2, inv = ops.covered_pixels(rast, tile=tile, return_inverse=True)  # the pixel -> entry map written by the same launch
+        want_inv = torch.full((b * h * w,), -1, dtype=torch.int32, device=dev)
+        want_inv[want] = torch.arange(want.shape[0], dtype=torch.int32, device=dev)
+        assert torch.equal(pix2, want) and inv.dtype == torch.int32 and torch.equal(inv, want_inv), (shape, tile, density)
+
+
+@pytest.mark.parametrize("C,bg_mode,hw", [(3, "per_image", (64, 64)), (3, "shared", (48, 40)), (16, None, (64, 64)), (2, None, (50, 70)), (1, "per_image", (32, 32))])
+def test_composite_antialias_equals_composite_then_antialias(C, bg_mode, hw, dev, ops):
+    """The fused compositor (one pass over the image, gradient straight to the point rows) against the two steps it replaces:
+    background fill + scatter of the rows (render.py:261-262 with coverage 0/1) and ops.antialias (itself checked against the oracle)."""
+    B, (H, W) = 3, hw
+    _, faces, clip, _ = _scene(B, seed=7)
+    clip, tri = clip.to(dev).requires_grad_(True), faces.to(dev)
+    rast = ops.rasterize(clip.detach(), tri, (H, W))
+    pix, inv = ops.covered_pixels(rast, return_inverse=True)
+    P = pix.shape[0]
+    assert P > 100
+    g = torch.Generator().manual_seed(C * 100 + H)
+    vals = torch.rand(P, C, generator=g).to(dev).requires_grad_(True)
+    bg = None
+    if bg_mode is not None:
+        bg = torch.rand(B if bg_mode == "per_image" else 1, H, W, C + 1, generator=g).to(dev)
+    g_out = torch.randn(B, H, W, C + 1, generator=g).to(dev)
+    analysis = ops.AAAnalysis(rast, clip.detach(), ops.aa_topology(ops.tri_int32(tri), clip.shape[1]))
+
+    fused = ops.composite_antialias(vals, pix, inv, bg, clip, analysis)
+    gv_f, gc_f = torch.autograd.grad(fused, (vals, clip), g_out)
+
+    base = bg.expand(B, -1, -1, -1).clone() if bg is not None else torch.zeros(B, H, W, C + 1, device=dev)
+    base = base.view(-1, C + 1).index_copy(0, pix, torch.cat((vals, torch.ones_like(vals[:, :1])), -1)).view(B, H, W, C + 1)
+    two_step = ops.antialias(base, rast, clip, tri, analysis=analysis)
+    gv_t, gc_t = torch.autograd.grad(two_step, (vals, clip), g_out)
+
+    assert float((fused.detach() - base.detach()).abs().max()) > 1e-3  # the silhouette was really blended
+    torch.testing.assert_close(fused, two_step, atol=2e-6, rtol=0)  # same blends; pixels with two crossings add in any order
+    torch.testing.assert_close(gv_f, gv_t, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(gc_f, gc_t, atol=1e-4 * float(gc_t.abs().max()), rtol=1e-4)
 
 
 @pytest.mark.parametrize("light,two_sided", [(True, True), (True, False), (False, True)])
