@@ -189,14 +189,16 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     cols = [w2c[:, :3, :3].reshape(-1, 9).expand(b, 9), view.expand(b, 3)]
     if lgt is not None:
         cols.append(lgt(feat))  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
-    per_point = _rows_per_point(torch.cat(cols, dim=-1), img, b)
+    per_image = torch.cat(cols, dim=-1)  # [B, 12 | 17]
     shading = None
-    if gb is not None and FUSED_SHADING:  # one HIP kernel each way for the ~30 (+~70 backward) elementwise launches below
+    if gb is not None and FUSED_SHADING:  # one HIP kernel each way for the ~30 (+~70 backward) elementwise launches below; the kernels
+        # read the image's row through the point -> image index (no [P,17] copy) and reduce its gradient per image themselves
         if lgt is None:
-            nrm, shaded_col = ops.shade_points(gb, per_point, None, two_sided_shading), kd
+            nrm, shaded_col = ops.shade_points(gb, per_image, None, two_sided_shading, img=img), kd
         else:
-            nrm, shading, shaded_col = ops.shade_points(gb, per_point, kd, two_sided_shading)
+            nrm, shading, shaded_col = ops.shade_points(gb, per_image, kd, two_sided_shading, img=img)
     else:
+        per_point = _rows_per_point(per_image, img, b)
         rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
         nrm = ru.prepare_shading_normal(pos, view_p, None, nrm, tng, geo, two_sided_shading=two_sided_shading, opengl=True, use_python=True)
         cam_normal = util.safe_normalize((rot * nrm[:, None, :]).sum(-1))  # per-point 3x3 . 3 as elementwise work, not P tiny GEMMs

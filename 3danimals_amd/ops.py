@@ -489,14 +489,16 @@ def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix):
 
 # ---------------------------------------------------------------------------------------------- per-point shading
 class _ShadePoints(torch.autograd.Function):
-    """(shading normal [P,3], shading [P,1], shaded [P,3]) from the G-buffer rows, the per-point camera/light rows and kd."""
+    """(shading normal [P,3], shading [P,1], shaded [P,3]) from the G-buffer rows, the camera/light rows and kd."""
 
     @staticmethod
-    def forward(ctx, gb, par, kd, two_sided):
-        require_device(gb, par, what="shade_points")
+    def forward(ctx, gb, par, kd, two_sided, img):
+        require_device(gb, par, img, what="shade_points")
         gb, par = f32c(gb), f32c(par)
         P, ncol = gb.shape[0], par.shape[1]
-        assert gb.shape == (P, 12) and par.shape[0] == P and ncol in (12, 17) and (kd is not None) == (ncol == 17)
+        assert gb.shape == (P, 12) and ncol in (12, 17) and (kd is not None) == (ncol == 17)
+        assert par.shape[0] == P if img is None else (img.shape == (P,) and img.dtype == torch.int64 and img.is_contiguous())
+        _assert_sorted(img)
         nrm = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
         shading = shaded = None
         kd_stride = 0
@@ -507,8 +509,8 @@ class _ShadePoints(torch.autograd.Function):
             kd_stride = kd.stride(0)
             shading = torch.empty((P, 1), dtype=torch.float32, device=gb.device)
             shaded = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
-        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded), stream())
-        ctx.save_for_backward(gb, par, kd)
+        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded), stream())
+        ctx.save_for_backward(gb, par, kd, img)
         ctx.two_sided, ctx.kd_stride = int(two_sided), kd_stride
         if kd is None:
             return nrm
@@ -516,22 +518,24 @@ class _ShadePoints(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_nrm, g_shading=None, g_shaded=None):
-        gb, par, kd = ctx.saved_tensors
+        gb, par, kd, img = ctx.saved_tensors
         P, ncol = gb.shape[0], par.shape[1]
         g_gb, g_par = torch.empty_like(gb), torch.empty_like(par)
         g_kd = torch.empty((P, 3), dtype=torch.float32, device=gb.device) if kd is not None else None
         opt = lambda t: None if t is None else f32c(t)
-        call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(kd), ctx.kd_stride, P,
-             ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), stream())
-        return g_gb, g_par, g_kd, None
+        call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(img), par.shape[0], ptr(kd),
+             ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), stream())
+        return g_gb, g_par, g_kd, None, None
 
 
-def shade_points(gb, par, kd=None, two_sided=True):
+def shade_points(gb, par, kd=None, two_sided=True, img=None):
     """Shading normal, Lambert shading and shaded colour at the covered pixels (csrc/shade.hip).
 
-    gb [P,12] from :func:`gbuffer`; par [P,12|17] per-point rows (w2c rotation 9, view position 3[, light direction 3, ambient,
-    diffuse]); kd [P,3] (any row stride).  Returns nrm, or (nrm, shading [P,1], shaded [P,3]) when a light is given."""
-    return _ShadePoints.apply(gb, par, kd, two_sided)
+    gb [P,12] from :func:`gbuffer`; par rows (w2c rotation 9, view position 3[, light direction 3, ambient, diffuse]): one per point
+    [P,12|17], or -- with ``img`` [P] (point -> image, int64, non-decreasing) -- one per image [B,12|17], in which case their gradient is
+    reduced per image inside the backward kernel; kd [P,3] (any row stride).  Returns nrm, or (nrm, shading [P,1], shaded [P,3]) when a
+    light is given."""
+    return _ShadePoints.apply(gb, par, kd, two_sided, img)
 
 
 # ---------------------------------------------------------------------------------------------- per-image rows <-> points
@@ -561,7 +565,7 @@ CHECK_SORTED_INDEX = False  # debugging aid: device-side assert (no host sync) t
 def _assert_sorted(img):
     """The per-image segment sums (csrc/segsum.hip) treat a 128-row block whose first and last rows belong to the same image as
     single-image: the index must be non-decreasing (the render path's is: pixel lists are image-major, padding rows repeat an image)."""
-    if CHECK_SORTED_INDEX and img.numel() > 1:
+    if CHECK_SORTED_INDEX and img is not None and img.numel() > 1:
         torch._assert_async((img[1:] >= img[:-1]).all(), "point -> image index must be non-decreasing")
 
 

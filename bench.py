@@ -88,8 +88,8 @@ def algorithmic_bytes(name, d):
         # gradient read at the covered pixels, point-row gradient out, vertex gradient out
         "a3d_composite_aa_fwd": 4 * B * HW + 4 * P * max(C - 1, 0) + 4 * C * B * HW,
         "a3d_composite_aa_bwd": 8 * P + 8 * P * max(C - 1, 0) + 16 * B * V,
-        "a3d_shade_fwd": P * (48 + 68 + 12 + 12 + 4 + 12),
-        "a3d_shade_bwd": P * (48 + 68 + 12 + 28 + 48 + 68 + 12),
+        "a3d_shade_fwd": P * (48 + 8 + 12 + 12 + 4 + 12),  # G-buffer row, image index, kd in; normal, shading, shaded out (camera/light rows: 1 KB table)
+        "a3d_shade_bwd": P * (48 + 8 + 12 + 28 + 48 + 12),  # + the three incoming gradients; G-buffer and kd gradients out
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,
         "a3d_bone_transforms_bwd": B * K * (12 + 48 + 12) + 24 * K,
         "a3d_aa_topology": 12 * F + 12 * F,

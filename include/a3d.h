@@ -104,15 +104,18 @@ int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apar
  * Per-point shading arithmetic -- replaces the elementwise part of shade(), /root/reference/model/render/render.py:71-93:
  * prepare_shading_normal with perturbed_nrm=None (renderutils/ops.py:194-227 -> bsdf.py:28-51), camera-space normal
  * (render.py:73-74) and DirectionalLight.shade (light.py:186-190), on the covered-pixel list.
- * gb[P,12] as written by a3d_gbuffer_fwd; par[P,ncol] = per-point rows of w2c rotation (9) | view position (3) | light
- * direction, ambient, diffuse (5) -- ncol 12 without a light, 17 with; kd[P,3] with row stride kd_stride floats.
+ * gb[P,12] as written by a3d_gbuffer_fwd; par rows of w2c rotation (9) | view position (3) | light direction, ambient, diffuse (5) --
+ * ncol 12 without a light, 17 with.  With img (point -> image, int64 [P], non-decreasing) par is [B,ncol], one row per image, and
+ * the backward reduces g_par[B,ncol] itself (zeroed by callee); with img null par and g_par hold one row per point [P,ncol].
+ * kd[P,3] with row stride kd_stride floats.
  * fwd: nrm[P,3]; with a light also shading[P] and shaded[P,3] = shading*kd.   bwd: g_nrm / g_shading / g_shaded may be NULL
- * (= zero); writes g_gb[P,12] (canonical-position columns zero), g_par[P,ncol], g_kd[P,3] (contiguous).
+ * (= zero); writes g_gb[P,12] (canonical-position columns zero), g_par, g_kd[P,3] (contiguous).
  */
-int a3d_shade_fwd(const float* gb, const float* par, int ncol, const float* kd, int kd_stride, int64_t P, int two_sided, float* nrm,
-                  float* shading, float* shaded, a3d_stream_t stream);
+int a3d_shade_fwd(const float* gb, const float* par, int ncol, const int64_t* img_or_null, const float* kd, int kd_stride, int64_t P,
+                  int two_sided, float* nrm, float* shading, float* shaded, a3d_stream_t stream);
 int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
-                  const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par, float* g_kd, a3d_stream_t stream);
+                  const int64_t* img_or_null, int B, const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par,
+                  float* g_kd, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Covered-pixel list: flat indices (b*H + y)*W + x of the pixels with rast.w > 0 (triangle_id + 1, as dr.rasterize returns it),

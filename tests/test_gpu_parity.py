@@ -1026,6 +1026,41 @@ def test_shade_points_kernel_matches_oracle(light, two_sided, dev, ops):
         assert float(((a - b_).abs() / scale).max()) < 2e-4, (name, float(((a - b_).abs() / scale).max()))
 
 
+@pytest.mark.parametrize("light,P,B", [(True, 5000, 7), (False, 3000, 4), (True, 700, 16), (True, 257, 1)])
+def test_shade_points_per_image_rows_equal_per_point_rows(light, P, B, dev, ops):
+    """The indexed form (camera / light rows per image + point -> image index, gradient reduced per image inside the kernel) against the
+    per-point form fed with the gathered rows (itself checked against the oracle above): same values, row gradient = per-image sums.
+    Work-groups inside one image, straddling two, and images without points are all present."""
+    g = torch.Generator().manual_seed(P + B)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    ncol = 17 if light else 12
+    gb = torch.cat((r(P, 3), torch.nn.functional.normalize(r(P, 3), dim=-1), r(P, 3), r(P, 3)), -1).requires_grad_(True)
+    rows = torch.cat((r(B, 9), r(B, 3) * 3, torch.nn.functional.normalize(r(B, 3), dim=-1), torch.rand(B, 2, generator=g).to(dev)), -1)[:, :ncol]
+    img = torch.sort(torch.randint(0, B, (P,), generator=g))[0].to(dev)
+    if B > 2:
+        img[img == 1] = 2  # an image without points
+    tex = torch.rand(P, 9, generator=g).to(dev).requires_grad_(True)
+    kd = tex[:, :3] if light else None
+    w = [r(P, 3), r(P, 1), r(P, 3)]
+
+    def run(indexed):
+        rows_ = rows.clone().requires_grad_(True)
+        out = ops.shade_points(gb, rows_, kd, True, img=img) if indexed else ops.shade_points(gb, rows_.index_select(0, img), kd, True)
+        outs = out if light else (out,)
+        loss = sum((o * wi).sum() for o, wi in zip(outs, w))
+        grads = torch.autograd.grad(loss, (gb, rows_) + ((tex,) if light else ()))
+        return [o.detach() for o in outs], grads
+
+    (v_i, g_i), (v_p, g_p) = run(True), run(False)
+    for a, b_ in zip(v_i, v_p):
+        assert torch.equal(a, b_)
+    assert torch.equal(g_i[0], g_p[0]) and (not light or torch.equal(g_i[2], g_p[2]))
+    scale = float(g_p[1].abs().max())
+    torch.testing.assert_close(g_i[1], g_p[1], atol=2e-5 * scale, rtol=1e-4)  # summation order differs
+    if B > 2:
+        assert float(g_i[1][1].abs().max()) == 0.0
+
+
 def test_rows_add_relu_and_indexed_feature_field(dev, ops):
     """a3d_rows_add_relu_fwd/bwd against torch, and CoordMLP's per-image feature path (HIP add+ReLU, split-K weight gradient)
     against the reference formulation (feature concatenated per point) on the GPU."""
