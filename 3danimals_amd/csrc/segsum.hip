@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
     for (int cbase = 0; cbase < CV; cbase += CP) {  // uniform trip count (barriers inside)
         const int cc = cbase + c;
         const bool active = cc < CV;
-        if (first == last) {  // the whole block belongs to one image (the list is sorted): branch-free accumulation
+        // one pass per image present in the block: a single one, except in the <= B-1 blocks that straddle an image boundary of the sorted
+        // list, which repeat the pass with the other images' rows skipped.  (Those blocks used to add row by row with atomics: up to
+        // rows_per_block adds onto each of the C addresses, and same-address device atomics serialise at ~30 ns each.)
+        for (long long bi = min(first, last); bi <= max(first, last); ++bi) {  // uniform bounds (min/max: a padded tail may wrap to image 0)
+            const bool uniform = first == last;
             constexpr int NS = 4;  // independent row streams per thread (loads in flight)
             float acc[NS][VEC];
 #pragma unroll
@@ -61,32 +65,27 @@ __global__ __launch_bounds__(256) void ss_kernel(const float* __restrict__ g, co
                 for (int k = 0; k < VEC; ++k) acc[q][k] = 0.f;
             if (active) {
                 long long r = r0 + rl;
-                for (; r + (long long)(NS - 1) * RL < r1; r += (long long)NS * RL) {
+                if (uniform) {  // branch-free accumulation
+                    for (; r + (long long)(NS - 1) * RL < r1; r += (long long)NS * RL) {
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) add_group((r + (long long)q * RL) * C + (long long)cc * VEC, acc[q]);
+                        for (int q = 0; q < NS; ++q) add_group((r + (long long)q * RL) * C + (long long)cc * VEC, acc[q]);
+                    }
                 }
-                for (; r < r1; r += RL) add_group(r * C + (long long)cc * VEC, acc[0]);
+                for (; r < r1; r += RL)
+                    if (uniform || img[r] == bi) add_group(r * C + (long long)cc * VEC, acc[0]);
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) s_part[threadIdx.x * VEC + k] = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
             __syncthreads();
-            if (rl == 0 && active && (unsigned long long)first < (unsigned long long)B) {
+            if (rl == 0 && active && (unsigned long long)bi < (unsigned long long)B) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float t = 0.f;
                     for (int q = 0; q < RL; ++q) t += s_part[(q * CP + c) * VEC + k];
-                    atomicAdd(out + first * C + (long long)cc * VEC + k, t);
+                    if (uniform || t != 0.f) atomicAdd(out + bi * C + (long long)cc * VEC + k, t);
                 }
             }
             __syncthreads();
-        } else if (active) {  // block straddles an image boundary (at most B-1 blocks do): plain per-row atomics
-            for (long long r = r0 + rl; r < r1; r += RL) {
-                const long long b = img[r];
-                for (int k = 0; k < VEC; ++k) {
-                    const float v = val(r * C + (long long)cc * VEC + k);
-                    if ((unsigned long long)b < (unsigned long long)B) atomicAdd(out + b * C + (long long)cc * VEC + k, v);
-                }
-            }
         }
     }
 }

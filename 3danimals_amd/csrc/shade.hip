@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
     }
     // the images this work-group's points belong to: img[first] .. img[last] (one, except at the ~B image boundaries of the list)
     const long long first = (long long)blockIdx.x * blockDim.x, last = min(first + (long long)blockDim.x, P) - 1;
-    const long long b_lo = img[first], b_hi = img[last];
+    const long long b_first = img[first], b_last = img[last], b_lo = min(b_first, b_last), b_hi = max(b_first, b_last);
     const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 4;
     for (long long bi = b_lo; bi <= b_hi; ++bi) {  // uniform bounds
         const bool mine = live && row == bi;
