@@ -15,13 +15,17 @@ from ... import ops
 from . import util
 
 
+LAZY_NORMALS = True  # auto_normals defers the kernel to the first read of Mesh.v_nrm (same values; False = at make_mesh time)
+
+
 class Mesh:
     """Batched vertices sharing one topology: v_pos [B,V,3], t_pos_idx [1,F,3] int64 (reference mesh.py:21-175)."""
 
     def __init__(self, v_pos=None, t_pos_idx=None, v_nrm=None, t_nrm_idx=None, v_tex=None, t_tex_idx=None, v_tng=None, t_tng_idx=None,
                  material=None, base=None):
         self.v_pos = v_pos
-        self.v_nrm = v_nrm
+        self._v_nrm = v_nrm
+        self._lazy_nrm = None  # grad mode at make_mesh time while the normals are still to be computed (LAZY_NORMALS)
         self.v_tex = v_tex
         self._v_tng = v_tng
         self._lazy_tng = False
@@ -32,6 +36,22 @@ class Mesh:
         self.material = material
         if base is not None:
             self.copy_none(base)
+
+    # normals on demand: make_mesh is called for the canonical, the deformed and the posed mesh of every step (reference
+    # BasePredictorBase.py / InstancePredictorBase.py) and only the rendered one is ever asked for its normals -------------------
+    @property
+    def v_nrm(self):
+        if self._v_nrm is None and self._lazy_nrm is not None:
+            with torch.set_grad_enabled(self._lazy_nrm):
+                self._v_nrm = ops.vertex_normals(self.v_pos, self.t_pos_idx)
+            self._lazy_nrm = None
+            if torch.is_anomaly_enabled():
+                assert torch.all(torch.isfinite(self._v_nrm))
+        return self._v_nrm
+
+    @v_nrm.setter
+    def v_nrm(self, value):
+        self._v_nrm, self._lazy_nrm = value, None
 
     # tangents on demand ----------------------------------------------------------------------------
     @property
@@ -58,9 +78,14 @@ class Mesh:
         return len(self.v_pos)
 
     def copy_none(self, other):
-        for name in ("v_pos", "t_pos_idx", "v_nrm", "t_nrm_idx", "v_tex", "t_tex_idx", "material"):
+        for name in ("v_pos", "t_pos_idx", "t_nrm_idx", "v_tex", "t_tex_idx", "material"):
             if getattr(self, name) is None:
                 setattr(self, name, getattr(other, name))
+        if self._v_nrm is None and self._lazy_nrm is None:
+            if other._lazy_nrm is not None and self.v_pos is not other.v_pos:
+                self._v_nrm = other.v_nrm  # the normals belong to the other mesh's vertices: compute them there
+            else:
+                self._v_nrm, self._lazy_nrm = other._v_nrm, other._lazy_nrm
         if self._v_tng is None:
             self._v_tng, self._lazy_tng = other._v_tng, other._lazy_tng
         if self._t_tng_idx is None:
@@ -157,6 +182,10 @@ def center_by_reference(base_mesh, ref_aabb, scale):
 
 def auto_normals(imesh):
     """Smooth vertex normals (reference :276-304) -- one HIP scatter pass + one normalise pass, see csrc/normals.hip."""
+    if LAZY_NORMALS:
+        out = Mesh(t_nrm_idx=imesh.t_pos_idx, base=imesh)
+        out._v_nrm, out._lazy_nrm = None, torch.is_grad_enabled()
+        return out
     v_nrm = ops.vertex_normals(imesh.v_pos, imesh.t_pos_idx)
     if torch.is_anomaly_enabled():
         assert torch.all(torch.isfinite(v_nrm))
