@@ -24,7 +24,7 @@ def category(name):
     name = name.replace("(anonymous namespace)::", "")
     if name.startswith("Cijk_") or "rocblas" in name:
         return "torch GEMM (MLPs)"
-    for tag in ("rs_", "ip_", "aa_", "dm_", "sk_", "nr_", "gb_", "tp_", "bn_", "cv_", "sh_", "ss_", "ls_", "fl_", "he_", "gm_"):
+    for tag in ("rs_", "ip_", "aa_", "ca_", "dm_", "sk_", "nr_", "gb_", "tp_", "bn_", "cv_", "sh_", "ss_", "ls_", "fl_", "he_", "gm_"):
         if name.startswith(tag) or name.startswith("void " + tag):
             return "a3d HIP kernels"
     if "rocclr" in name or "fillBuffer" in name.lower():
