@@ -5,11 +5,14 @@
 // grid's unique edge list is static and already lexicographically sorted (dmtet.py:283-288), that rank is
 // an exclusive prefix sum of the "sign crossing" flag over the static list.  So:
 //   count : wave-ballot popcounts of the crossing flag per 1024-edge block and of the 1-/2-triangle case
-//           per 1024-tet block, then one work-group scan per block-sum array  (-> V, n1, n2)
-//   emit  : edges re-evaluate the flag, ballot/mbcnt gives the in-wave rank, LDS the cross-wave offset;
-//           tets look their 3-4 surface vertices up through tet2edge -> edge2vert and write int64 faces.
-// Integer/byte work, HBM-bound: 8 B/edge + 16 B/tet (count) and 8 B/edge + 40 B/tet (emit) of streaming
-// reads plus L2-resident sdf gathers.  This TU is compiled with -ffp-contract=off: the vertex placement
+//           per 1024-tet block, the ballots themselves kept as bit planes (1 bit/edge, 4 bits/tet), then one
+//           work-group scan per block-sum array (-> V, n1, n2)
+//   emit  : ONE launch over the bit planes: a crossing edge's vertex id is block prefix + word prefix + popcount below its bit;
+//           crossing edges place their vertex, surface tets read their tet2edge row and write int64 faces.
+//           (Until round 2 the emit re-gathered every SDF value and re-read both index arrays in two launches
+//           chained through an edge -> vertex table: 23 us of kernel time against 8 now.)
+// Integer/byte work: 8 B/edge + 16 B/tet of streaming reads plus ~1e7 L2-resident 4-byte SDF gathers in the count
+// pass (TA line rate bound), ~1 MB of bit planes in the emit pass.  This TU is compiled with -ffp-contract=off: the vertex placement
 // must round exactly like the reference's separate torch kernels (mul, mul, add).
 #include "a3d_common.h"
 
@@ -37,11 +40,16 @@ __device__ __forceinline__ bool dm_edge_cross(const float* __restrict__ sdf, int
 }
 
 // ------------------------------------------------------------------------------------------------ count
+// Besides the block sums the pass leaves what it found as bit planes, so that the emit pass never gathers an SDF value or reads an
+// index row for a tet or edge that is not on the surface (~1 % are): edge_bits[word] = crossing flags of 64 consecutive edges,
+// tet_bits[word*4 + j] = bit j of the marching-tets case of 64 consecutive tets.
 __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __restrict__ sdf, const int2* __restrict__ edges,
                                                                 const int4* __restrict__ tets, int Ne, int Nt, int nbe,
                                                                 int* __restrict__ blk_e, int* __restrict__ blk_t1,
-                                                                int* __restrict__ blk_t2) {
+                                                                int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
+                                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal) {
     __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
+    __shared__ int s_pc[DM_BLOCK_ITEMS / 64];  // crossings per 64-edge word of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
     if ((int)blockIdx.x < nbe) {
@@ -50,15 +58,22 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
         for (int k = 0; k < DM_SLABS; ++k) {
             long long i = base + k * DM_THREADS + tid;
             bool f = i < Ne && dm_edge_cross(sdf, edges[i]);
-            c0 += __popcll(__ballot(f));  // wave-uniform
+            const unsigned long long m = __ballot(f);
+            if (lane == 0) {
+                edge_bits[(base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave] = m;
+                s_pc[k * (DM_THREADS / A3D_WAVE) + wave] = __popcll(m);
+            }
+            c0 += __popcll(m);  // wave-uniform
         }
     } else {
         const long long base = (long long)(blockIdx.x - nbe) * DM_BLOCK_ITEMS;
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             long long i = base + k * DM_THREADS + tid;
-            unsigned n = 0;
-            if (i < Nt) n = DM_NTRI(dm_tet_case(sdf, tets[i]));
+            const int cs = i < Nt ? dm_tet_case(sdf, tets[i]) : 0;
+            const unsigned long long w0 = __ballot(cs & 1), w1 = __ballot(cs & 2), w2 = __ballot(cs & 4), w3 = __ballot(cs & 8);
+            if (lane < 4) tet_bits[((base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave) * 4 + lane] = lane == 0 ? w0 : (lane == 1 ? w1 : (lane == 2 ? w2 : w3));
+            const unsigned n = DM_NTRI(cs);
             c0 += __popcll(__ballot(n == 1u));
             c1 += __popcll(__ballot(n == 2u));
         }
@@ -71,9 +86,16 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
         if ((int)blockIdx.x < nbe) blk_e[blockIdx.x] = a;
         else { blk_t1[blockIdx.x - nbe] = a; blk_t2[blockIdx.x - nbe] = b; }
     }
+    if ((int)blockIdx.x < nbe && tid < DM_BLOCK_ITEMS / 64) {  // crossings of this block before word tid
+        int before = 0;
+        for (int j = 0; j < tid; ++j) before += s_pc[j];
+        wlocal[(long long)blockIdx.x * (DM_BLOCK_ITEMS / 64) + tid] = before;
+    }
 }
 
-// three work-groups, one per block-sum array: in-place exclusive scan, totals to counts[0..2]
+// three work-groups, one per block-sum array: in-place exclusive scan, totals to counts[0..2].  With the count pass's wlocal (crossings
+// of the same block before a 64-edge word) a surface vertex id is blk_e[e >> 10] + wlocal[e >> 6] + popcount(edge_bits[e >> 6] below
+// bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts) {
     __shared__ int s_wave[16];
@@ -110,113 +132,98 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
 }
 
 // ------------------------------------------------------------------------------------------------ emit
-__global__ __launch_bounds__(DM_THREADS) void dm_emit_edges_kernel(const float* __restrict__ pos, const float* __restrict__ sdf,
-                                                                     const int2* __restrict__ edges, int Ne,
-                                                                     const int* __restrict__ blk_e, int* __restrict__ edge2vert,
-                                                                     float* __restrict__ verts, int* __restrict__ vert_edge) {
-    __shared__ int s_cnt[DM_THREADS / A3D_WAVE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int running = blk_e[blockIdx.x];
-    const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
-    for (int k = 0; k < DM_SLABS; ++k) {
-        long long i = base + k * DM_THREADS + tid;
-        int2 e = make_int2(0, 0);
-        float sa = 0.f, sb = 0.f;
-        bool f = false;
-        if (i < Ne) {
-            e = edges[i];
-            sa = sdf[e.x];
-            sb = sdf[e.y];
-            f = (sa > 0.f) != (sb > 0.f);
-        }
-        unsigned long long m = __ballot(f);
-        if (lane == 0) s_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int woff = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) {
-            int c = s_cnt[w];
-            if (w < wave) woff += c;
-            total += c;
-        }
-        if (i < Ne) {
-            int vid = -1;
-            if (f) {
-                vid = running + woff + a3d_wave_prefix(m);
-                // reference dmtet.py:124-131: w = flip([s_a, -s_b]) / (s_a + (-s_b)); v = p_a*w_a + p_b*w_b
-                float nsb = -sb;
-                float den = sa + nsb;
-                float wa = nsb / den, wb = sa / den;
-                const float* pa = pos + 3ll * e.x;
-                const float* pb = pos + 3ll * e.y;
-                float* o = verts + 3ll * vid;
-                o[0] = pa[0] * wa + pb[0] * wb;
-                o[1] = pa[1] * wa + pb[1] * wb;
-                o[2] = pa[2] * wa + pb[2] * wb;
-                vert_edge[vid] = (int)i;
-            }
-            edge2vert[i] = vid;
-        }
-        running += total;
-        __syncthreads();
-    }
+// One launch: edge work-groups place the surface vertices, tet work-groups write the faces.  Both read the bit planes of the count
+// pass (8 B per 64 edges, 32 B per 64 tets); only crossing edges read their index pair / SDF / positions and only surface tets read
+// their tet2edge row.  A vertex id is wprefix + a popcount, so the tets do not wait for the edges (no edge -> vertex table).
+__device__ __forceinline__ int dm_vertex_of_edge(int eid, const unsigned long long* __restrict__ edge_bits, const int* __restrict__ wlocal,
+                                                 const int* __restrict__ blk_e) {
+    const unsigned long long word = edge_bits[eid >> 6];
+    return blk_e[eid / DM_BLOCK_ITEMS] + wlocal[eid >> 6] + __popcll(word & ((1ull << (eid & 63)) - 1ull));
 }
 
-__global__ __launch_bounds__(DM_THREADS) void dm_emit_tets_kernel(const float* __restrict__ sdf, const int4* __restrict__ tets,
-                                                                    const int* __restrict__ tet2edge, int Nt,
-                                                                    const int* __restrict__ blk_t1, const int* __restrict__ blk_t2,
-                                                                    const int* __restrict__ edge2vert, int n1,
-                                                                    long long* __restrict__ faces, long long* __restrict__ uv_idx) {
-    __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
+__global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __restrict__ pos, const float* __restrict__ sdf,
+                                                             const int2* __restrict__ edges, const int* __restrict__ tet2edge, int Ne, int Nt,
+                                                             int nbe, const int* __restrict__ blk_e, const int* __restrict__ blk_t1,
+                                                             const int* __restrict__ blk_t2, const unsigned long long* __restrict__ edge_bits,
+                                                             const unsigned long long* __restrict__ tet_bits, const int* __restrict__ wlocal,
+                                                             int n1, float* __restrict__ verts, int* __restrict__ vert_edge,
+                                                             long long* __restrict__ faces, long long* __restrict__ uv_idx) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int run1 = blk_t1[blockIdx.x], run2 = blk_t2[blockIdx.x];
-    const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+    constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
+    if ((int)blockIdx.x < nbe) {
+        const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) {
+            const long long wi = (base >> 6) + k * WPS + wave;
+            const unsigned long long word = edge_bits[wi];
+            if (!((word >> lane) & 1ull)) continue;
+            const long long i = base + k * DM_THREADS + tid;
+            const int vid = blk_e[blockIdx.x] + wlocal[wi] + a3d_wave_prefix(word);
+            const int2 e = edges[i];
+            const float sa = sdf[e.x], sb = sdf[e.y];
+            // reference dmtet.py:124-131: w = flip([s_a, -s_b]) / (s_a + (-s_b)); v = p_a*w_a + p_b*w_b
+            const float nsb = -sb;
+            const float den = sa + nsb;
+            const float wa = nsb / den, wb = sa / den;
+            const float* pa = pos + 3ll * e.x;
+            const float* pb = pos + 3ll * e.y;
+            float* o = verts + 3ll * vid;
+            o[0] = pa[0] * wa + pb[0] * wb;
+            o[1] = pa[1] * wa + pb[1] * wb;
+            o[2] = pa[2] * wa + pb[2] * wb;
+            vert_edge[vid] = (int)i;
+        }
+        return;
+    }
+    const int bt = blockIdx.x - nbe;
+    const long long base = (long long)bt * DM_BLOCK_ITEMS;
+    // per-chunk counts of the 16 chunks of this block (lane j < 16 holds chunk j's): n == 1 <=> odd number of inside corners
+    int c1 = 0, c2 = 0;
+    if (lane < DM_BLOCK_ITEMS / 64) {
+        const unsigned long long* w = tet_bits + ((base >> 6) + lane) * 4;
+        const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
+        c1 = __popcll(odd);
+        c2 = __popcll(~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3));
+    }
+    const int blk1 = blk_t1[bt], blk2 = blk_t2[bt];
+#pragma unroll
     for (int k = 0; k < DM_SLABS; ++k) {
-        long long t = base + k * DM_THREADS + tid;
-        int cs = 0;
-        unsigned n = 0;
-        if (t < Nt) {
-            cs = dm_tet_case(sdf, tets[t]);
-            n = DM_NTRI(cs);
-        }
-        unsigned long long m1 = __ballot(n == 1u), m2 = __ballot(n == 2u);
-        if (lane == 0) { s_cnt[0][wave] = __popcll(m1); s_cnt[1][wave] = __popcll(m2); }
-        __syncthreads();
-        int w1 = 0, w2 = 0, t1 = 0, t2 = 0;
+        const int chunk = k * WPS + wave;
+        const unsigned long long* w = tet_bits + ((base >> 6) + chunk) * 4;
+        const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
+        const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
+        if (!(m1 | m2)) continue;  // wave-uniform: no surface tet among these 64
+        int run1 = blk1, run2 = blk2;
+        for (int j = 0; j < chunk; ++j) { run1 += __shfl(c1, j, 64); run2 += __shfl(c2, j, 64); }
+        const int cs = (int)((w0 >> lane) & 1ull) | ((int)((w1 >> lane) & 1ull) << 1) | ((int)((w2 >> lane) & 1ull) << 2) |
+                       ((int)((w3 >> lane) & 1ull) << 3);
+        const unsigned n = DM_NTRI(cs);
+        if (n == 0u) continue;
+        const long long t = base + k * DM_THREADS + tid;
+        const int* te = tet2edge + 6ll * t;
+        int ev[6];
 #pragma unroll
-        for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) {
-            int a = s_cnt[0][w], b = s_cnt[1][w];
-            if (w < wave) { w1 += a; w2 += b; }
-            t1 += a; t2 += b;
-        }
-        if (n != 0u) {
-            const int* te = tet2edge + 6ll * t;
-            int ev[6];
+        for (int j = 0; j < 6; ++j) ev[j] = te[j];
+        const long long slot = (n == 1u) ? (long long)(run1 + a3d_wave_prefix(m1)) : (long long)n1 + 2ll * (run2 + a3d_wave_prefix(m2));
+        const signed char* row = c_tri_table[cs];
+        for (unsigned q = 0; q < n; ++q) {
+            long long* fo = faces + 3 * (slot + q);
+            long long* uo = uv_idx + 3 * (slot + q);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ev[j] = te[j];
-            long long slot = (n == 1u) ? (long long)(run1 + w1 + a3d_wave_prefix(m1))
-                                       : (long long)n1 + 2ll * (run2 + w2 + a3d_wave_prefix(m2));
-            const signed char* row = c_tri_table[cs];
-            for (unsigned q = 0; q < n; ++q) {
-                long long* fo = faces + 3 * (slot + q);
-                long long* uo = uv_idx + 3 * (slot + q);
+            for (int j = 0; j < 3; ++j) {
+                int slot_e = row[3 * q + j];
+                int eid = ev[0];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    int slot_e = row[3 * q + j];
-                    int eid = ev[0];
-#pragma unroll
-                    for (int s = 1; s < 6; ++s) eid = (slot_e == s) ? ev[s] : eid;  // register select, no scratch
-                    fo[j] = (long long)edge2vert[eid];
-                }
-                // reference dmtet.py:91-96 with face_gidx = 2t + q
-                uo[0] = 4ll * t;
-                uo[1] = 4ll * t + q + 1;
-                uo[2] = 4ll * t + q + 2;
+                for (int s = 1; s < 6; ++s) eid = (slot_e == s) ? ev[s] : eid;  // register select, no scratch
+                fo[j] = (long long)dm_vertex_of_edge(eid, edge_bits, wlocal, blk_e);
             }
+            // reference dmtet.py:91-96 with face_gidx = 2t + q
+            uo[0] = 4ll * t;
+            uo[1] = 4ll * t + q + 1;
+            uo[2] = 4ll * t + q + 2;
         }
-        run1 += t1;
-        run2 += t2;
-        __syncthreads();
     }
 }
 
@@ -246,51 +253,61 @@ __global__ __launch_bounds__(256) void dm_bwd_kernel(const float* __restrict__ g
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+struct DmScratch {
+    int *be, *b1, *b2, *wlocal;
+    unsigned long long *edge_bits, *tet_bits;
+    int nbe, nbt;
+};
+
+static size_t dm_split_scratch(void* scratch, int Ne, int Nt, DmScratch* d) {
+    d->nbe = a3d_div_up(Ne, DM_BLOCK_ITEMS);
+    d->nbt = a3d_div_up(Nt, DM_BLOCK_ITEMS);
+    const size_t nwe = (size_t)d->nbe * (DM_BLOCK_ITEMS / 64), nwt = (size_t)d->nbt * (DM_BLOCK_ITEMS / 64);
+    unsigned long long* q = (unsigned long long*)scratch;  // the 8-byte arrays first
+    d->edge_bits = q;
+    d->tet_bits = q + nwe;
+    int* p = (int*)(q + nwe + 4 * nwt);
+    d->wlocal = p;
+    d->be = p + nwe;
+    d->b1 = d->be + d->nbe;
+    d->b2 = d->b1 + d->nbt;
+    return sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + 4);
+}
+
 extern "C" size_t a3d_dmtet_scratch_bytes(int Ne, int Nt) {
-    return sizeof(int) * ((size_t)a3d_div_up(Ne, DM_BLOCK_ITEMS) + 2 * (size_t)a3d_div_up(Nt, DM_BLOCK_ITEMS) + 4);
+    DmScratch d;
+    return dm_split_scratch(nullptr, Ne < 1 ? 1 : Ne, Nt < 1 ? 1 : Nt, &d);
 }
 
-static void dm_split_scratch(void* scratch, int Ne, int Nt, int** e, int** t1, int** t2, int* nbe, int* nbt) {
-    *nbe = a3d_div_up(Ne, DM_BLOCK_ITEMS);
-    *nbt = a3d_div_up(Nt, DM_BLOCK_ITEMS);
-    *e = (int*)scratch;
-    *t1 = *e + *nbe;
-    *t2 = *t1 + *nbt;
-}
-
-extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* block_scan,
+extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                                int32_t* counts, a3d_stream_t stream) {
-    A3D_CHECK_ARG(sdf && edges && tets && block_scan && counts);
+    A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0);
-    int *be, *b1, *b2, nbe, nbt;
-    dm_split_scratch(block_scan, Ne, Nt, &be, &b1, &b2, &nbe, &nbt);
+    DmScratch d;
+    dm_split_scratch(scratch, Ne, Nt, &d);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dm_count_kernel, dim3(nbe + nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
-                       nbe, be, b1, b2);
+    hipLaunchKernelGGL(dm_count_kernel, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
+                       d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dm_scan_kernel, dim3(3), dim3(1024), 0, s, be, b1, b2, nbe, nbt, counts);
+    hipLaunchKernelGGL(dm_scan_kernel, dim3(3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
-extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tets, const int32_t* tet2edge,
-                              int Ne, int Nt, const void* block_scan, int V, int n1, int n2, int32_t* edge2vert, float* verts,
-                              int32_t* vert_edge, int64_t* faces, int64_t* uv_idx, a3d_stream_t stream) {
-    A3D_CHECK_ARG(pos && sdf && edges && tets && tet2edge && block_scan && edge2vert);
+extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
+                              const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
+                              a3d_stream_t stream) {
+    A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
-    int *be, *b1, *b2, nbe, nbt;
-    dm_split_scratch((void*)block_scan, Ne, Nt, &be, &b1, &b2, &nbe, &nbt);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dm_emit_edges_kernel, dim3(nbe), dim3(DM_THREADS), 0, s, pos, sdf, (const int2*)edges, Ne, be, edge2vert,
-                       verts, vert_edge);
+    if (V == 0) return A3D_OK;  // no crossing edge, hence no surface tet
+    DmScratch d;
+    dm_split_scratch((void*)scratch, Ne, Nt, &d);
+    hipLaunchKernelGGL(dm_emit_kernel, dim3(d.nbe + ((n1 + n2) > 0 ? d.nbt : 0)), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf,
+                       (const int2*)edges, tet2edge, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge,
+                       (long long*)faces, (long long*)uv_idx);
     A3D_LAUNCH_CHECK();
-    if (n1 + n2 > 0) {
-        hipLaunchKernelGGL(dm_emit_tets_kernel, dim3(nbt), dim3(DM_THREADS), 0, s, sdf, (const int4*)tets, tet2edge, Nt, b1, b2,
-                           edge2vert, n1, (long long*)faces, (long long*)uv_idx);
-        A3D_LAUNCH_CHECK();
-    }
     return A3D_OK;
 }
 

@@ -121,11 +121,10 @@ def dmtet_extract(pos, sdf, grid):
     F = n1 + 2 * n2
     verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
     vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
-    edge2vert = torch.empty((Ne,), dtype=torch.int32, device=dev)
     faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
-    call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch),
-         V, n1, n2, ptr(edge2vert), ptr(verts), ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
+    call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
+         ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
     return verts, faces, uv_idx, vert_edge
 
 

@@ -42,19 +42,20 @@ const char* a3d_last_error(void);
  * Two phases with one 16-byte read-back in between (output sizes are data dependent; the reference
  * synchronises at the same place, dmtet.py:110):
  *   a3d_dmtet_count : counts[0]=V crossing edges, counts[1]=n1 one-triangle tets, counts[2]=n2 two-triangle
- *                     tets (F = n1 + 2 n2); block_scan = scratch of a3d_dmtet_scratch_bytes(Ne,Nt) bytes.
+ *                     tets (F = n1 + 2 n2); scratch = a3d_dmtet_scratch_bytes(Ne,Nt) bytes, 8-byte aligned; it carries the
+ *                     block scans and the crossing / case bit planes from count to emit.
  *   a3d_dmtet_emit  : verts[V,3] (vertex v = v-th crossing edge in `edges` order, placed at the SDF zero
  *                     crossing with the reference's operation order), vert_edge[V] (edge row, for backward),
- *                     edge2vert[Ne] (-1 if not crossing), faces[F,3] int64 (1-triangle tets first, then
- *                     2-triangle tets, dmtet.py:140-143), uv_idx[F,3] int64 (dmtet.py:91-96).
+ *                     faces[F,3] int64 (1-triangle tets first, then 2-triangle tets, dmtet.py:140-143),
+ *                     uv_idx[F,3] int64 (dmtet.py:91-96).
  *   a3d_dmtet_bwd   : g_sdf[Nv] (zeroed by callee) and optionally g_pos[Nv,3] (zeroed by callee) from g_verts.
  */
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
-int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* block_scan,
-                    int32_t* counts /*[4] device*/, a3d_stream_t stream);
-int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tets, const int32_t* tet2edge,
-                   int Ne, int Nt, const void* block_scan, int V, int n1, int n2, int32_t* edge2vert, float* verts,
-                   int32_t* vert_edge, int64_t* faces, int64_t* uv_idx, a3d_stream_t stream);
+int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
+                    int32_t* counts /*[4]*/, a3d_stream_t stream);
+int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
+                   const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
+                   a3d_stream_t stream);
 int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
                   int V, int Nv, float* g_pos_or_null, float* g_sdf, a3d_stream_t stream);
 
