@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
 // ------------------------------------------------------------------------------------------------ emit
 // One launch: edge work-groups place the surface vertices, tet work-groups write the faces.  Both read the bit planes of the count
 // pass (8 B per 64 edges, 32 B per 64 tets); only crossing edges read their index pair / SDF / positions and only surface tets read
-// their tet2edge row.  A vertex id is wprefix + a popcount, so the tets do not wait for the edges (no edge -> vertex table).
+// their tet2edge row.  A vertex id is block prefix + word prefix + a popcount, so the tets do not wait for the edges (no edge -> vertex table).
 __device__ __forceinline__ int dm_vertex_of_edge(int eid, const unsigned long long* __restrict__ edge_bits, const int* __restrict__ wlocal,
                                                  const int* __restrict__ blk_e) {
     const unsigned long long word = edge_bits[eid >> 6];

@@ -59,8 +59,10 @@ def algorithmic_bytes(name, d):
     P = int(d.get("P", 0))
     Pp = -(-P // 8192) * 8192  # render.POINT_BUCKET
     table = {
-        "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt,
-        "a3d_dmtet_emit": 16 * Nv + 8 * Ne + 4 * Ne + 16 * Nt + 24 * Nt + 16 * V + 48 * F,
+        "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt + (Ne // 8 + Nt // 2 + Ne // 16),  # sdf, both index arrays in; bit planes + word prefixes out
+        # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
+        # 48 bytes of int64 indices out
+        "a3d_dmtet_emit": (Ne // 8 + Nt // 2 + Ne // 16) + 56 * V + 72 * F,
         "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
