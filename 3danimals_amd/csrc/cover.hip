@@ -39,29 +39,23 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __rest
 // exclusive scan of block_count[nb] in place; total[0] = number of covered pixels
 __global__ __launch_bounds__(CV_SCAN_THREADS) void cv_scan_kernel(int* __restrict__ block_count, int nb, long long* __restrict__ total) {
     __shared__ int wave_tot[CV_SCAN_THREADS / 64];
-    __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += CV_SCAN_THREADS) {
-        const int i = base + threadIdx.x;
-        const int c = i < nb ? block_count[i] : 0;
-        int incl = c;
+    // contiguous run per thread, one barrier (see a3d_run_sum)
+    const int per = (nb + CV_SCAN_THREADS - 1) / CV_SCAN_THREADS;
+    const int lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+    const int mine = a3d_run_sum(block_count, lo, hi);
+    int incl = mine;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        if (i < nb) block_count[i] = before + incl - c;
-        __syncthreads();
-        if (threadIdx.x == CV_SCAN_THREADS - 1) carry_s = before + incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
     }
-    if (threadIdx.x == 0) total[0] = carry_s;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    run = a3d_run_scan<false>(block_count, block_count, lo, hi, run);
+    if (threadIdx.x == CV_SCAN_THREADS - 1) total[0] = run;
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,

@@ -164,14 +164,18 @@ __device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0
     }
 }
 
-#define GB_SLOTS 512    // vertex table of one work-group (256 pixels reference ~150-200 distinct vertices)
+// Two sizes of the work-group tables, chosen by the entry point from the pixels-per-triangle ratio of the call:
+//   <512, 640>  triangles of a few pixels (256 pixels reference ~150-200 distinct vertices, ~512 entries after the pair merge): 39 KB
+//   <1024, 768> sub-pixel triangles (every pixel its own three vertices: up to 768 entries and as many vertices): 52 KB
+// Whatever still does not fit goes to the gradient rows directly (twelve single-lane atomics: slow, so it has to stay rare -- with
+// the small tables the R = 128 grid, 0.3 pixels per triangle, ran at 74 us).
 #define GB_PROBES 16
-#define GB_ENTRIES 640  // staged (pixel, corner) contributions of one work-group (768 possible, ~512 after the pair merge); overflow goes direct
 #define GB_ROW 16       // floats per gradient row = one 64-byte line: [0..2] v_pos, [3..5] v_nrm, [6..8] canonical, [12] [13] [15] clip x y w
 
 // find-or-claim the table slot of a vertex row
+template <int GB_SLOTS>
 __device__ __forceinline__ int gb_slot(int* s_key, int key) {
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;  // top 9 bits
+    unsigned h = ((unsigned)key * 2654435761u) >> (GB_SLOTS == 512 ? 23 : 22);  // top 9 / 10 bits
 #pragma unroll 1
     for (int t = 0; t < GB_PROBES; ++t) {
         const int old = atomicCAS(&s_key[h], -1, key);
@@ -196,6 +200,7 @@ __device__ __forceinline__ float gb_xor1(float x) {
 }
 __device__ __forceinline__ int gb_xor1(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
 
+template <int GB_SLOTS, int GB_ENTRIES>
 __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g_out, const float4* __restrict__ rast, const int* __restrict__ tri,
                                                      const long long* __restrict__ pix, long long P, const float* __restrict__ v_pos,
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         for (int c = 0; c < 3; ++c) {
             const int key = rowb + idx[c];
             const int e = base + c;
-            const int slot = e < GB_ENTRIES ? gb_slot(s_key, key) : -1;
+            const int slot = e < GB_ENTRIES ? gb_slot<GB_SLOTS>(s_key, key) : -1;
             if (slot >= 0) {
                 float* dst = s_stage + e * 13;
 #pragma unroll
@@ -329,8 +334,16 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior);
-    hipLaunchKernelGGL(gb_bwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P,
-                       v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows, want_prior);
+    // covered pixels per triangle of the call (all triangles, visible or not): below ~0.6 most pixels own their three vertices
+    if ((double)P >= 0.6 * (double)B * (double)F) {
+        hipLaunchKernelGGL((gb_bwd_kernel<512, 640>), dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri,
+                           (const long long*)pix, (long long)P, v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows,
+                           want_prior);
+    } else {
+        hipLaunchKernelGGL((gb_bwd_kernel<1024, 768>), dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri,
+                           (const long long*)pix, (long long)P, v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows,
+                           want_prior);
+    }
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

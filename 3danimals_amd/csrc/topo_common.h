@@ -78,8 +78,7 @@ __global__ __launch_bounds__(NR_SCAN_THREADS) void nr_adj_scan_kernel(int* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = (V + NR_SCAN_THREADS - 1) / NR_SCAN_THREADS;
     const int lo = min((int)threadIdx.x * per, V), hi = min(lo + per, V);
-    int mine = 0;
-    for (int i = lo; i < hi; ++i) mine += cnt[i];
+    const int mine = a3d_run_sum(cnt, lo, hi);
     int incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -90,12 +89,7 @@ __global__ __launch_bounds__(NR_SCAN_THREADS) void nr_adj_scan_kernel(int* __res
     __syncthreads();
     int run = incl - mine;
     for (int w = 0; w < wave; ++w) run += wave_tot[w];
-    for (int i = lo; i < hi; ++i) {
-        const int c = cnt[i];
-        off[i] = run;
-        cnt[i] = 0;
-        run += c;
-    }
+    run = a3d_run_scan<true>(cnt, off, lo, hi, run);
     if (threadIdx.x == NR_SCAN_THREADS - 1) off[V] = run;
 }
 
