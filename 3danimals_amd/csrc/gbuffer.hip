@@ -31,7 +31,8 @@ __device__ __forceinline__ void gb_load3(const float* __restrict__ p, float& x, 
 __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ rast, const int* __restrict__ tri, const long long* __restrict__ pix,
                                                      long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                      const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const float* __restrict__ extra, int E,
+                                                     float* __restrict__ extra_out) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const long long i = pix[p];
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     if (f < 0 || f >= F) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) o[c] = 0.f;
+        if (extra)
+            for (int c = 0; c < E; ++c) extra_out[p * E + c] = 0.f;
         return;
     }
     const long long b = i / hw;
@@ -73,6 +76,10 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     o[9] = u * ax + v * bx + w * cx;
     o[10] = u * ay + v * by + w * cy;
     o[11] = u * az + v * bz + w * cz;
+    if (extra) {  // one more per-vertex attribute (the sequence models' 2-D motion, render.py:281-288), E <= 3 channels
+        const float* eb = extra + b * V * E;
+        for (int c = 0; c < E; ++c) extra_out[p * E + c] = u * eb[(long long)i0 * E + c] + v * eb[(long long)i1 * E + c] + w * eb[(long long)i2 * E + c];
+    }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------
@@ -105,10 +112,20 @@ __device__ __forceinline__ void gb_load_tri(GbTri& t, const float* __restrict__ 
 // Adjoint of one covered pixel onto the three corners of its triangle, ADDED to acc[corner][0..11]: [0..2] d/d v_pos, [3..5]
 // d/d v_nrm, [6..8] d/d canonical position, [9..11] d/d clip x, y, w.  (u, v) = barycentrics of the texel, g = the 12 incoming
 // gradients of the G-buffer row, p0..p2 = clip-space vertices.
+template <int NC>
 __device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0, const float4 p1, const float4 p2, float u, float v,
-                                                 const float g[12], int px, int py, int H, int W, bool want_clip, float acc[3][12]) {
+                                                 const float g[12], int px, int py, int H, int W, bool want_clip, float acc[3][NC],
+                                                 const float ex[3][3], const float ge[3]) {
     const float w = 1.f - u - v;
     float gu = 0.f, gv = 0.f;
+    if (NC > 12) {  // the extra attribute: acc[.][12..14] d/d extra, and its share of d/du, d/dv
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gu += ge[c] * (ex[0][c] - ex[2][c]);
+            gv += ge[c] * (ex[1][c] - ex[2][c]);
+            acc[0][12 + c] += u * ge[c]; acc[1][12 + c] += v * ge[c]; acc[2][12 + c] += w * ge[c];
+        }
+    }
     // world position
     const float gx = g[0], gy = g[1], gz = g[2];
     gu += gx * (t.pos[0][0] - t.pos[2][0]) + gy * (t.pos[0][1] - t.pos[2][1]) + gz * (t.pos[0][2] - t.pos[2][2]);
@@ -170,7 +187,7 @@ __device__ __forceinline__ void gb_pixel_adjoint(const GbTri& t, const float4 p0
 // Whatever still does not fit goes to the gradient rows directly (twelve single-lane atomics: slow, so it has to stay rare -- with
 // the small tables the R = 128 grid, 0.3 pixels per triangle, ran at 74 us).
 #define GB_PROBES 16
-#define GB_ROW 16       // floats per gradient row = one 64-byte line: [0..2] v_pos, [3..5] v_nrm, [6..8] canonical, [12] [13] [15] clip x y w
+#define GB_ROW 16       // floats per gradient row = one 64-byte line: [0..2] v_pos, [3..5] v_nrm, [6..8] canonical, [9..11] extra, [12] [13] [15] clip x y w
 
 // find-or-claim the table slot of a vertex row
 template <int GB_SLOTS>
@@ -185,13 +202,18 @@ __device__ __forceinline__ int gb_slot(int* s_key, int key) {
     return -1;  // table crowded: the caller falls back to global atomics
 }
 
-__device__ __forceinline__ int gb_col(int k) { return k < 9 ? k : (k == 11 ? 15 : k + 3); }  // component 0..11 -> column of the gradient row
+// component -> column of the gradient row: 0..8 in place, 9..11 (clip x, y, w) -> 12, 13, 15, 12..14 (extra attribute) -> 9..11
+__device__ __forceinline__ int gb_col(int k) { return k < 9 ? k : (k < 12 ? (k == 11 ? 15 : k + 3) : k - 3); }
+__device__ __forceinline__ bool gb_comp_on(int k, int NC, bool want_prior, bool want_clip) {
+    return k < NC && (k < 6 || k >= 9 || want_prior) && (k < 9 || k >= 12 || want_clip);
+}
 
-__device__ __forceinline__ void gb_row_direct(float* g_rows, long long row, const float c[12], bool want_prior, bool want_clip) {
+template <int NC>
+__device__ __forceinline__ void gb_row_direct(float* g_rows, long long row, const float c[NC], bool want_prior, bool want_clip) {
     float* r = g_rows + GB_ROW * row;
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-        if ((k < 6 || k >= 9 || want_prior) && (k < 9 || want_clip)) atomicAdd(r + gb_col(k), c[k]);
+    for (int k = 0; k < NC; ++k)
+        if (gb_comp_on(k, NC, want_prior, want_clip)) atomicAdd(r + gb_col(k), c[k]);
 }
 
 // lane ^ 1 through the DPP quad permute (no LDS traffic)
@@ -200,16 +222,18 @@ __device__ __forceinline__ float gb_xor1(float x) {
 }
 __device__ __forceinline__ int gb_xor1(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
 
-template <int GB_SLOTS, int GB_ENTRIES>
+template <int GB_SLOTS, int GB_ENTRIES, int NC>  // NC = components per (pixel, corner): 12, or 15 with the extra attribute
 __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g_out, const float4* __restrict__ rast, const int* __restrict__ tri,
                                                      const long long* __restrict__ pix, long long P, const float* __restrict__ v_pos,
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
                                                      const float4* __restrict__ clip, int V, int F, int H, int W, float* __restrict__ g_rows,
-                                                     int want_prior) {
+                                                     int want_prior, const float* __restrict__ extra, int E,
+                                                     const float* __restrict__ g_extra) {
+    constexpr int ST = NC == 12 ? 13 : 17;  // floats per staged entry: NC sums + the previous entry of the same slot, odd stride
     __shared__ int s_key[GB_SLOTS];    // vertex row (b*V + v) of a slot, -1 = free
     __shared__ int s_head[GB_SLOTS];   // last staged entry of the slot's list
     __shared__ int s_used[GB_SLOTS];   // claimed slots, in claim order
-    __shared__ float s_stage[GB_ENTRIES * 13];  // 12 floats + the previous entry of the same slot; 13: odd stride
+    __shared__ float s_stage[GB_ENTRIES * ST];
     __shared__ int s_n[2];             // staged entries, used slots
     for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) { s_key[i] = -1; s_head[i] = -1; }
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
@@ -220,11 +244,11 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     const float4 r = p < P ? rast[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int f = (int)r.w - 1;
     const bool live = p < P && f >= 0 && f < F;
-    float acc[3][12];
+    float acc[3][NC];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) acc[c][k] = 0.f;
+        for (int k = 0; k < NC; ++k) acc[c][k] = 0.f;
     int i0 = 0, i1 = 0, i2 = 0;
     int b = 0;
     if (live) {
@@ -241,7 +265,15 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         const float4* gp = reinterpret_cast<const float4*>(g_out + p * 12);
         const float4 ga = gp[0], gb4 = gp[1], gc = gp[2];
         const float g[12] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z, gc.w};
-        gb_pixel_adjoint(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, want_clip, acc);
+        float ex[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, ge[3] = {0.f, 0.f, 0.f};
+        if (NC > 12) {
+            const float* eb = extra + (long long)b * V * E;
+            for (int c = 0; c < E; ++c) {
+                ex[0][c] = eb[(long long)i0 * E + c]; ex[1][c] = eb[(long long)i1 * E + c]; ex[2][c] = eb[(long long)i2 * E + c];
+                ge[c] = g_extra[p * E + c];
+            }
+        }
+        gb_pixel_adjoint<NC>(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, want_clip, acc, ex, ge);
     }
     // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums, a third fewer entries
     const int tkey = live ? b * F + f : -1 - (int)threadIdx.x;  // (B*F < 2^31 is checked by the entry point)
@@ -249,7 +281,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < NC; ++k) {
             const float o = gb_xor1(acc[c][k]);
             if (same) acc[c][k] += o;
         }
@@ -270,12 +302,12 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
             const int e = base + c;
             const int slot = e < GB_ENTRIES ? gb_slot<GB_SLOTS>(s_key, key) : -1;
             if (slot >= 0) {
-                float* dst = s_stage + e * 13;
+                float* dst = s_stage + e * ST;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) dst[k] = acc[c][k];
-                dst[12] = __int_as_float(atomicExch(&s_head[slot], e));
+                for (int k = 0; k < NC; ++k) dst[k] = acc[c][k];
+                dst[ST - 1] = __int_as_float(atomicExch(&s_head[slot], e));
             } else {
-                gb_row_direct(g_rows, key, acc[c], want_prior != 0, want_clip);
+                gb_row_direct<NC>(g_rows, key, acc[c], want_prior != 0, want_clip);
             }
         }
     }
@@ -294,15 +326,15 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     // (line-coalesced device atomics are ~10x cheaper than the same number of scattered ones, see the header); two vertices in
     // flight per group so that the list walks (one LDS round trip per entry) overlap
     const int n_used = s_n[1];
-    const int k = threadIdx.x & 15, kk = k < 12 ? k : 12;
-    const bool lane_on = k < 12 && (k < 6 || k >= 9 || want_prior) && (k < 9 || want_clip);
+    const int k = threadIdx.x & 15, kk = k < NC ? k : ST - 1;
+    const bool lane_on = gb_comp_on(k, NC, want_prior != 0, want_clip);
     for (int j = threadIdx.x >> 4; j < n_used; j += 32) {
         const int slot_a = s_used[j], slot_b = j + 16 < n_used ? s_used[j + 16] : -1;
         int ea = s_head[slot_a], eb = slot_b >= 0 ? s_head[slot_b] : -1;
         float sum_a = 0.f, sum_b = 0.f;
         while (ea >= 0 || eb >= 0) {
-            if (ea >= 0) { const float* src = s_stage + ea * 13; const float v = src[kk]; ea = __float_as_int(src[12]); if (k < 12) sum_a += v; }
-            if (eb >= 0) { const float* src = s_stage + eb * 13; const float v = src[kk]; eb = __float_as_int(src[12]); if (k < 12) sum_b += v; }
+            if (ea >= 0) { const float* src = s_stage + ea * ST; const float v = src[kk]; ea = __float_as_int(src[ST - 1]); if (k < NC) sum_a += v; }
+            if (eb >= 0) { const float* src = s_stage + eb * ST; const float v = src[kk]; eb = __float_as_int(src[ST - 1]); if (k < NC) sum_b += v; }
         }
         if (lane_on) {
             atomicAdd(g_rows + (long long)GB_ROW * s_key[slot_a] + gb_col(k), sum_a);
@@ -312,38 +344,53 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 }
 
 extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
-                               const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream) {
+                               const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null,
+                               int E, float* extra_out_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && extra_out_or_null));
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
-                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out);
+                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
+template <int NC>
+static void gb_launch_bwd(bool big, hipStream_t s, const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P,
+                          const float* v_pos, const float* v_nrm, const float* prior, int prior_batch, const float* clip, int V, int F, int H, int W,
+                          float* g_rows, int want_prior, const float* extra, int E, const float* g_extra) {
+    const dim3 grid(a3d_div_up(P, 256)), block(256);
+    if (!big)
+        hipLaunchKernelGGL((gb_bwd_kernel<512, 640, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
+    else
+        hipLaunchKernelGGL((gb_bwd_kernel<1024, 768, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
+}
+
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                                const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
-                               float* g_rows, int want_prior, a3d_stream_t stream) {
+                               float* g_rows, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null,
+                               a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(g_rows && ((uintptr_t)g_rows & 63) == 0);
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && g_extra_out_or_null));
     hipStream_t s = (hipStream_t)stream;
     A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior);
     // covered pixels per triangle of the call (all triangles, visible or not): below ~0.6 most pixels own their three vertices
-    if ((double)P >= 0.6 * (double)B * (double)F) {
-        hipLaunchKernelGGL((gb_bwd_kernel<512, 640>), dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri,
-                           (const long long*)pix, (long long)P, v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows,
-                           want_prior);
-    } else {
-        hipLaunchKernelGGL((gb_bwd_kernel<1024, 768>), dim3(a3d_div_up(P, 256)), dim3(256), 0, s, g_out, (const float4*)rast, tri,
-                           (const long long*)pix, (long long)P, v_pos, v_nrm, prior, prior_batch, (const float4*)clip_or_null, V, F, H, W, g_rows,
-                           want_prior);
-    }
+    const bool big = (double)P < 0.6 * (double)B * (double)F;
+    if (extra_or_null)
+        gb_launch_bwd<15>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior,
+                          extra_or_null, E, g_extra_out_or_null);
+    else
+        gb_launch_bwd<12>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior, nullptr, 0,
+                          nullptr);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

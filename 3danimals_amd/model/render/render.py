@@ -254,10 +254,13 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
     if fused:
         b, h, w = rast.shape[:3]
         pix, inv = ops.covered_pixels(rast, tile=PIXEL_TILE, return_inverse=True)  # one host sync for the number of covered pixels
-        gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
         flow = None
-        if "flow" in render_modes:  # the one extra attribute of the sequence models: modular interpolate (its gradient reaches clip
-            flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)  # through the rasteriser's own backward)
+        if "flow" in render_modes and delta_xy.shape[-1] <= 3:  # the one extra attribute of the sequence models rides in the same kernels
+            gb, flow = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix, extra=delta_xy)  # [P,12], [P,2]
+        else:
+            gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
+            if "flow" in render_modes:
+                flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
                              render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb, inv=inv)
 

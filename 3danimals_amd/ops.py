@@ -443,30 +443,42 @@ GBUFFER_GRAD_COLS = 16  # A3D_GBUFFER_GRAD_COLS of include/a3d.h
 
 class _GBuffer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix):
-        require_device(clip, v_pos, v_nrm, prior, rast, tri32, pix, what="gbuffer")
+    def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix, extra):
+        require_device(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra, what="gbuffer")
         clip, v_pos, v_nrm, prior, rast = f32c(clip), f32c(v_pos), f32c(v_nrm), f32c(prior), f32c(rast)
         B, H, W = rast.shape[:3]
         V, P = v_pos.shape[1], pix.shape[0]
         assert clip.shape[:2] == (B, V) and v_pos.shape[0] == B and v_nrm.shape == v_pos.shape and prior.shape[0] in (1, B)
         assert pix.dtype == torch.int64 and pix.is_contiguous()
         out = torch.empty((P, 12), dtype=torch.float32, device=rast.device)
+        E, extra_out = 0, None
+        if extra is not None:
+            extra = f32c(extra)
+            E = extra.shape[2]
+            assert extra.shape[:2] == (B, V) and 1 <= E <= 3
+            extra_out = torch.empty((P, E), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-             ptr(out), stream())
-        ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix)
-        return out
+             ptr(out), ptr(extra), E, ptr(extra_out), stream())
+        ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
+        if extra is None:
+            return out
+        return out, extra_out
 
     @staticmethod
-    def backward(ctx, g_out):
-        clip, v_pos, v_nrm, prior, rast, tri32, pix = ctx.saved_tensors
+    def backward(ctx, g_out, g_extra_out=None):
+        clip, v_pos, v_nrm, prior, rast, tri32, pix, extra = ctx.saved_tensors
         B, H, W = rast.shape[:3]
         V, P = v_pos.shape[1], pix.shape[0]
         want_prior, want_clip = ctx.needs_input_grad[3], ctx.needs_input_grad[0]
-        # one 64-byte gradient row per (image, vertex): the kernel's twelve atomics of a vertex are then one line request; the four
-        # gradients are strided views of the rows (a3d.h: v_pos 0..2 | v_nrm 3..5 | canonical 6..8 | clip 12..15)
+        E = 0 if extra is None else extra.shape[2]
+        if extra is not None and g_extra_out is None:
+            g_extra_out = torch.zeros((P, E), dtype=torch.float32, device=rast.device)
+        # one 64-byte gradient row per (image, vertex): the kernel's atomics of a vertex are then one line request; the gradients are
+        # strided views of the rows (a3d.h: v_pos 0..2 | v_nrm 3..5 | canonical 6..8 | extra 9..11 | clip 12..15)
         rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
-             ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(want_prior), stream())
+             ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(want_prior), ptr(extra), E,
+             None if extra is None else ptr(f32c(g_extra_out)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None
@@ -474,16 +486,18 @@ class _GBuffer(torch.autograd.Function):
             g_prior = rows[..., 6:9]
             if prior.shape[0] == 1:
                 g_prior = g_prior.sum(0, keepdim=True)
-        return g_clip, g_vpos, g_vnrm, g_prior, None, None, None
+        g_extra = rows[..., 9:9 + E] if (extra is not None and ctx.needs_input_grad[7]) else None
+        return g_clip, g_vpos, g_vnrm, g_prior, None, None, None, g_extra
 
 
-def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix):
-    """[P,12] = world position | face normal | smooth normal | canonical position at the covered pixels ``pix``.
+def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix, extra=None):
+    """[P,12] = world position | face normal | smooth normal | canonical position at the covered pixels ``pix``; with ``extra`` [B,V,E<=3]
+    also that attribute interpolated to [P,E] (returns a pair).
 
-    Differentiable w.r.t. v_pos, v_nrm, prior_v_pos and -- through the barycentrics -- clip (x, y, w); pass ``rast.detach()``
+    Differentiable w.r.t. v_pos, v_nrm, prior_v_pos, extra and -- through the barycentrics -- clip (x, y, w); pass ``rast.detach()``
     semantics are implied: the gradient to ``clip`` is produced here, not through ``rast``.
     """
-    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix)
+    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix, extra)
 
 
 # ---------------------------------------------------------------------------------------------- per-point shading

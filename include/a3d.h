@@ -174,17 +174,21 @@ int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* a
  * render_layer, /root/reference/model/render/render.py:182-209, and in backward also dr.rasterize's gradient.
  * pix[P] = flat indices (b*H + y)*W + x of the covered pixels (int64); out[P,12] =
  * [world position | normalised face normal | interpolated vertex normal | interpolated canonical position].
+ * extra (optional, [B,V,E], E <= 3): one more per-vertex attribute interpolated the same way into extra_out[P,E] (the sequence models'
+ * 2-D vertex motion, render.py:281-288 / :206-207), so that its backward rides the same scatter instead of dr.interpolate's.
  * Backward: g_rows[B*V, A3D_GBUFFER_GRAD_COLS] (64-byte aligned, zeroed by callee), one 64-byte row per (image, vertex) so that the
- * twelve atomics of a vertex are one line request: columns 0..2 d/d v_pos, 3..5 d/d v_nrm, 6..8 d/d canonical position (per image even
- * when the canonical mesh is shared: the caller sums over B; left zero unless want_prior), 12..15 d/d clip (x, y, 0, w -- through the
- * barycentrics; left zero when clip is null), 9..11 zero.  Callers take strided views of the rows.  clip is [B,V,4].
+ * atomics of a vertex are one line request: columns 0..2 d/d v_pos, 3..5 d/d v_nrm, 6..8 d/d canonical position (per image even
+ * when the canonical mesh is shared: the caller sums over B; left zero unless want_prior), 9..11 d/d extra (first E; zero without),
+ * 12..15 d/d clip (x, y, 0, w -- through the barycentrics; left zero when clip is null).  Callers take strided views of the rows.
+ * clip is [B,V,4].
  */
 #define A3D_GBUFFER_GRAD_COLS 16
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
-                    const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, a3d_stream_t stream);
+                    const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null, int E,
+                    float* extra_out_or_null, a3d_stream_t stream);
 int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                     const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
-                    float* g_rows, int want_prior, a3d_stream_t stream);
+                    float* g_rows, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of

@@ -947,6 +947,46 @@ def test_covered_pixels_compaction_is_exact(shape, tile, dev, ops):
         assert torch.equal(pix2, want) and inv.dtype == torch.int32 and torch.equal(inv, want_inv), (shape, tile, density)
 
 
+@pytest.mark.parametrize("E,res,hw", [(2, 16, (64, 64)), (3, 16, (96, 80)), (1, 40, (64, 64))])
+def test_gbuffer_extra_attribute_equals_modular_interpolate(E, res, hw, dev, ops, mods):
+    """The optional per-vertex attribute of the fused G-buffer (the sequence models' 2-D motion) against dr.interpolate + the
+    rasteriser's backward on the same pixels: values and the gradients to the attribute and -- through the barycentrics -- to the camera.
+    res = 40 gives sub-pixel triangles (the large work-group tables of the backward)."""
+    H, W = hw
+    B = 3
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, res=res, seed=9)
+    posed = (verts[None] + 0.03 * seeded((B, *verts.shape), 33, -1, 1)).to(dev)
+    tri = faces.to(dev)
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+    attr0 = seeded((B, verts.shape[0], E), 35, -1, 1).to(dev)
+
+    def run(fused):
+        v = posed.clone().requires_grad_(True)
+        a = attr0.clone().requires_grad_(True)
+        m = mvp.to(dev).clone().requires_grad_(True)
+        nrm = ops.vertex_normals(v, tri)
+        clip = ru.xfm_points(v, m)
+        rast = ops.rasterize(clip, tri, (H, W))
+        pix = ops.covered_pixels(rast)
+        if fused:
+            gb, out = ops.gbuffer(clip, v, nrm, verts[None].to(dev), rast, tri, pix, extra=a)
+        else:
+            gb = ops.gbuffer(clip, v, nrm, verts[None].to(dev), rast, tri, pix)
+            out = ops.interpolate(a, rast, tri).reshape(-1, E).index_select(0, pix)
+        wgt, wgb = seeded(out.shape, 43, -1, 1).to(dev), seeded(gb.shape, 45, -1, 1).to(dev)
+        ga, gv, gm = torch.autograd.grad((out * wgt).sum() + 0.1 * (gb * wgb).sum(), [a, v, m])
+        return out.detach(), gb.detach(), ga, gv, gm
+
+    f, u = run(True), run(False)
+    assert f[0].shape[0] > 500
+    np.testing.assert_allclose(f[0].cpu().numpy(), u[0].cpu().numpy(), atol=2e-6)
+    assert torch.equal(f[1], u[1])
+    for x, y, name in zip(f[2:], u[2:], ("attr", "v_pos", "mvp")):
+        scale = float(y.abs().max())
+        assert scale > 0, name
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
+
+
 @pytest.mark.parametrize("C,bg_mode,hw", [(3, "per_image", (64, 64)), (3, "shared", (48, 40)), (16, None, (64, 64)), (2, None, (50, 70)), (1, "per_image", (32, 32))])
 def test_composite_antialias_equals_composite_then_antialias(C, bg_mode, hw, dev, ops):
     """The fused compositor (one pass over the image, gradient straight to the point rows) against the two steps it replaces:
