@@ -29,10 +29,10 @@ SIGNATURES = {
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),

@@ -92,14 +92,18 @@ static int cv_check(const float* rast, int B, int H, int W, int tile, const void
     return A3D_OK;
 }
 
-extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile, void* scratch, int64_t* total, a3d_stream_t stream) {
+extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile, void* scratch, int counted, int64_t* total,
+                               a3d_stream_t stream) {
     if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
     A3D_CHECK_ARG(total);
+    A3D_CHECK_ARG(!counted || (tile == 8 && ((long long)H * W) % CV_BLOCK == 0));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * H * W;
     const int nb = a3d_div_up(n, CV_BLOCK);
-    hipLaunchKernelGGL(cv_count_kernel, dim3(nb), dim3(CV_BLOCK), 0, s, (const float4*)rast, n, H, W, tile, (int*)scratch);
-    A3D_LAUNCH_CHECK();
+    if (!counted) {  // (counted: a3d_rast_fwd left the block counts in scratch)
+        hipLaunchKernelGGL(cv_count_kernel, dim3(nb), dim3(CV_BLOCK), 0, s, (const float4*)rast, n, H, W, tile, (int*)scratch);
+        A3D_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(cv_scan_kernel, dim3(1), dim3(CV_SCAN_THREADS), 0, s, (int*)scratch, nb, (long long*)total);
     A3D_LAUNCH_CHECK();
     return A3D_OK;

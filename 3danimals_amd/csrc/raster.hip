@@ -147,20 +147,36 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     }
 }
 
-// grid (ceil(H*W / 256), B): the image comes from blockIdx.y and the row/column from one 32-bit division
+// grid (ceil(H*W / 256), B): the image comes from blockIdx.y and the row/column from one 32-bit division.
+// TILE: the work-group walks its 256 pixels as four 8x8 tiles in the covered-pixel list's order (cover.hip) and leaves that list's
+// per-256-entry block count behind, so a3d_cover_count can skip its own pass over the frame.
+template <bool TILE>
 __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
                                                          int H, int W, unsigned long long* __restrict__ keys,
-                                                         float4* __restrict__ rast) {
+                                                         float4* __restrict__ rast, int* __restrict__ cover_block_count) {
+    __shared__ int s_wave[4];
     const unsigned hw = (unsigned)H * (unsigned)W;
-    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rem >= hw) return;
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_frame = k < hw;
+    unsigned rem = k;
+    int px, py;
+    if (TILE) {  // (H, W multiples of 8 and H*W a multiple of 256: checked by the entry point)
+        const unsigned in_tile = k & 63u, t = k >> 6, tw = (unsigned)W >> 3;
+        const unsigned ty = t / tw, tx = t - ty * tw;
+        py = (int)(ty * 8u + (in_tile >> 3));
+        px = (int)(tx * 8u + (in_tile & 7u));
+        rem = (unsigned)py * (unsigned)W + (unsigned)px;
+    } else {
+        if (!in_frame) return;
+        py = (int)(rem / (unsigned)W);
+        px = (int)(rem - (unsigned)py * (unsigned)W);
+    }
     const int b = blockIdx.y;
     const long long i = (long long)b * hw + rem;
     const unsigned long long key = keys[i];
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (key != RS_EMPTY) {
         keys[i] = RS_EMPTY;  // leave the key buffer armed for the next call (saves its 8 B/pixel clear launch: scratch_is_clean)
-        const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
         const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
         const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
         const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
@@ -170,6 +186,12 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
         o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
     }
     rast[i] = o;
+    if (TILE) {
+        const unsigned long long m = __ballot(key != RS_EMPTY);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) cover_block_count[(long long)b * gridDim.x + blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
 }
 
 // backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; one thread per pixel
@@ -215,23 +237,31 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
 extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
 
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                            void* scratch, int scratch_is_clean, const float* prev_rast_or_null, a3d_stream_t stream) {
+                            void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
+                            a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)H * W < 0x7fffffffll && B <= 65535);
     hipStream_t s = (hipStream_t)stream;
     const long long npix = (long long)B * H * W;
+    // the covered-pixel block counts ride along when the list's tile order applies and its blocks do not cross images
+    A3D_CHECK_ARG(!cover_scratch_or_null || (H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0));
     if (F == 0) {
         A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)npix, s));
+        if (cover_scratch_or_null) A3D_HIP(hipMemsetAsync(cover_scratch_or_null, 0, sizeof(int) * (size_t)(npix / 256), s));
         return A3D_OK;
     }
     unsigned long long* keys = (unsigned long long*)scratch;
     if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     hipLaunchKernelGGL(rs_tri_kernel, dim3(a3d_div_up(F, 64), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W, keys, (const float4*)prev_rast_or_null);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rs_resolve_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, H, W,
-                       keys, (float4*)rast);
+    if (cover_scratch_or_null)
+        hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
+                           V, H, W, keys, (float4*)rast, (int*)cover_scratch_or_null);
+    else
+        hipLaunchKernelGGL(rs_resolve_kernel<false>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
+                           V, H, W, keys, (float4*)rast, (int*)nullptr);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -295,6 +295,9 @@ def vertex_normals(v, tri):
 
 
 # ---------------------------------------------------------------------------------------------- covered pixels
+_cover_counts = _IdentityCache(maxsize=2)  # raster buffer -> block counts of its covered-pixel list
+
+
 def covered_pixels(rast, tile=8, return_inverse=False):
     """int64 [P] flat indices of the pixels with rast[...,3] > 0, image-major, 8x8-tile order inside an image (``tile=8``; falls back
     to row-major when H or W is not a multiple of 8).  One 8-byte read-back (P) between the count and the emit launches.
@@ -305,9 +308,12 @@ def covered_pixels(rast, tile=8, return_inverse=False):
     if tile != 8 or H % 8 or W % 8:
         tile = 0
     dev = rast.device
-    scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    scratch = _cover_counts.peek(rast) if tile == 8 else None  # block counts left by the rasteriser's resolve (same launch)
+    counted = scratch is not None
+    if not counted:
+        scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     total = torch.empty(1, dtype=torch.int64, device=dev)
-    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), ptr(total), stream())
+    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), int(counted), ptr(total), stream())
     pix = torch.empty(int(total.item()), dtype=torch.int64, device=dev)
     inv = torch.empty(B * H * W, dtype=torch.int32, device=dev) if return_inverse else None
     if pix.shape[0] or return_inverse:
@@ -335,7 +341,13 @@ class _Rasterize(torch.autograd.Function):
         if prev is not None:
             prev = f32c(prev.detach())
             assert prev.shape == (B, H, W, 4)
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), stream())
+        # the covered-pixel list's block counts ride along with the resolve when the list's tile order applies (covered_pixels picks them up)
+        cover = None
+        if H % 8 == 0 and W % 8 == 0 and (H * W) % 256 == 0 and F > 0:
+            cover = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover), stream())
+        if cover is not None:
+            _cover_counts.put(rast, cover)
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
         _rast_keys[key] = scratch  # only after a successful call (a failed one leaves the buffer out of the cache)

@@ -123,11 +123,14 @@ int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_sha
  * image-major and inside an image 8x8-tile by tile (tile = 8; H, W multiples of 8) or row-major (tile = 0).  The list the fused
  * G-buffer / shading path runs over instead of the reference's dense [B,H,W] frame (/root/reference/model/render/render.py:
  * 139-221 shades every pixel; uncovered ones are composited with alpha 0, :261-262).
- * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device); the caller reads total back to size pix; emit writes pix and,
+ * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device) -- with counted != 0 the block counts are already in scratch
+ * (left there by a3d_rast_fwd's resolve, tile = 8 and H*W a multiple of 256) and only the scan runs; the caller reads total back to
+ * size pix; emit writes pix and,
  * when given, the inverse map inv[B*H*W] (entry of the list per pixel, -1 = uncovered) that a3d_composite_aa_* reads.
  */
 size_t a3d_cover_scratch_bytes(int B, int H, int W);
-int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, int64_t* total, a3d_stream_t stream);
+int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, int counted, int64_t* total,
+                    a3d_stream_t stream);
 int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix /*[total]*/, int32_t* inv_or_null,
                    a3d_stream_t stream);
 
@@ -141,10 +144,13 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * on the same stream (every key is all-ones again: the resolve re-arms what it consumed) -- the 8 B/pixel clear launch is skipped.
  * prev_rast != NULL: depth peeling, DepthPeeler.rasterize_next_layer() for layer n > 0 -- prev_rast[B,H,W,4] is the previous layer;
  * per pixel the nearest fragment strictly behind the previous layer's (depth, id) is returned, empty pixels stay empty.
+ * cover_scratch != NULL (H, W multiples of 8, H*W a multiple of 256): the resolve also leaves the covered-pixel list's block counts
+ * (a3d_cover_scratch_bytes) there, for a3d_cover_count(counted = 1).
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                 void* scratch, int scratch_is_clean, const float* prev_rast_or_null, a3d_stream_t stream);
+                 void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
+                a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 
