@@ -66,6 +66,7 @@ SIGNATURES = {
                                       _c_int, _c_int, _p, _p, _p]),
 }
 
+ABI_VERSION = 200  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 
@@ -86,6 +87,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here == ABI drift
             fn.restype, fn.argtypes = res, args
+        if handle.a3d_version() != ABI_VERSION:  # same symbols, other argument lists: a stale build must not be called
+            raise A3DError(f"{LIB_PATH} has ABI version {handle.a3d_version()}, this package binds version {ABI_VERSION}: rebuild it "
+                           "with `python 3danimals_amd/csrc/build.py`")
         _lib = handle
     return _lib
 

@@ -14,7 +14,7 @@ void a3d_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* a3d_last_error(void) { return g_err; }
-extern "C" int a3d_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int a3d_version(void) { return 200; /* 0.2.0: round-2 ABI (gradient rows, per-image shading rows, fused compositor, bit-plane DMTet) */ }
 
 int a3d_exp(void) {
     const char* e = getenv("A3D_EXP");

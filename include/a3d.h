@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void);
+int a3d_version(void); /* 200 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
