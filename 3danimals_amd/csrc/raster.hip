@@ -194,19 +194,24 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
     }
 }
 
-// backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; one thread per pixel
+// backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; FOUR lanes per pixel, lane = component of the 16-byte gradient
+// row of a vertex (x, y, -, w): every lane repeats the pixel's small algebra and adds its own component, so the three adds of a
+// (pixel, vertex) pair are one request to the L2's atomic unit instead of three (line-coalesced atomics)
 __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ g_rast, const float4* __restrict__ rast,
                                                      const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
                                                      int V, int F, int H, int W, long long npix, float* __restrict__ g_clip) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
+    const long long t4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = t4 >> 2;
+    const int sub = (int)(t4 & 3);
+    if (i >= npix || sub == 2) return;
     const float4 r = rast[i];
     const int f = (int)r.w - 1;
     if (f < 0 || f >= F) return;
     const float4 g = g_rast[i];
     if (g.x == 0.f && g.y == 0.f) return;
-    const int b = (int)(i / ((long long)H * W));
-    const int rem = (int)(i - (long long)b * H * W);
+    const unsigned hw = (unsigned)H * (unsigned)W;
+    const int b = (int)((unsigned)i / hw);
+    const int rem = (int)((unsigned)i - (unsigned)b * hw);
     const int py = rem / W, px = rem - py * W;
     const long long vb = clip_batch == 1 ? 0ll : (long long)b * V;
     const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
@@ -226,12 +231,10 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
     const float g0x = -ga1 * q2y + ga2 * q1y, g0y = ga1 * q2x - ga2 * q1x;
     const float g1x = ga0 * q2y - ga2 * q0y, g1y = -ga0 * q2x + ga2 * q0x;
     const float g2x = -ga0 * q1y + ga1 * q0y, g2y = ga0 * q1x - ga1 * q0x;
-    float* o0 = g_clip + (vb + i0) * 4;
-    float* o1 = g_clip + (vb + i1) * 4;
-    float* o2 = g_clip + (vb + i2) * 4;
-    atomicAdd(o0, g0x); atomicAdd(o0 + 1, g0y); atomicAdd(o0 + 3, -fx * g0x - fy * g0y);
-    atomicAdd(o1, g1x); atomicAdd(o1 + 1, g1y); atomicAdd(o1 + 3, -fx * g1x - fy * g1y);
-    atomicAdd(o2, g2x); atomicAdd(o2 + 1, g2y); atomicAdd(o2 + 3, -fx * g2x - fy * g2y);
+    auto comp = [&](float gx, float gy) { return sub == 0 ? gx : (sub == 1 ? gy : -fx * gx - fy * gy); };
+    atomicAdd(g_clip + (vb + i0) * 4 + sub, comp(g0x, g0y));
+    atomicAdd(g_clip + (vb + i1) * 4 + sub, comp(g1x, g1y));
+    atomicAdd(g_clip + (vb + i2) * 4 + sub, comp(g2x, g2y));
 }
 
 extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
@@ -274,7 +277,8 @@ extern "C" int a3d_rast_bwd(const float* g_rast, const float* rast, const float*
     A3D_HIP(hipMemsetAsync(g_clip, 0, sizeof(float) * 4 * (size_t)clip_batch * V, s));
     if (F == 0) return A3D_OK;
     const long long npix = (long long)B * H * W;
-    hipLaunchKernelGGL(rs_bwd_kernel, dim3(a3d_div_up(npix, 256)), dim3(256), 0, s, (const float4*)g_rast, (const float4*)rast,
+    A3D_CHECK_ARG(npix < 0x7fffffffll);
+    hipLaunchKernelGGL(rs_bwd_kernel, dim3(a3d_div_up(4 * npix, 256)), dim3(256), 0, s, (const float4*)g_rast, (const float4*)rast,
                        (const float4*)clip, clip_batch, tri, V, F, H, W, npix, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
