@@ -348,7 +348,7 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
                                int E, float* extra_out_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
-    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && extra_out_or_null));
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || P == 0)));  // (an empty list has no output storage)
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
@@ -378,7 +378,7 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(g_rows && ((uintptr_t)g_rows & 63) == 0);
-    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && g_extra_out_or_null));
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (g_extra_out_or_null || P == 0)));
     hipStream_t s = (hipStream_t)stream;
     A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;

@@ -456,6 +456,26 @@ def test_render_mesh_flow_and_empty_mesh_assert(dev, mods):
         mods["render"].render_mesh(None, empty, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), render_modes=["shaded"])
 
 
+def test_render_mesh_with_nothing_on_screen(dev, mods):
+    """A mesh pushed entirely out of the frustum: no covered pixel (P = 0) through the fused path -- rasterise, covered-pixel list,
+    G-buffer, shading, fused compositor -- forward returns the background with alpha 0 and the backward runs to zero gradients."""
+    B, H, W = 2, 32, 32
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=5)
+    M = mods["mesh"]
+    posed = (verts[None].expand(B, -1, -1) + torch.tensor([50.0, 0.0, 0.0])).to(dev).requires_grad_(True)
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    shape = M.make_mesh(posed, faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+    bg = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = mods["render"].render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), bsdf="diffuse",
+                                     background=bg, render_modes=["shaded", "flow"], num_frames=2)
+    shaded, flow = out
+    assert shaded.shape == (B, 4, H, W) and torch.equal(shaded[:, :3], bg.permute(0, 3, 1, 2)) and float(shaded[:, 3].detach().abs().max()) == 0.0
+    assert float(flow.abs().max()) == 0.0
+    (g,) = torch.autograd.grad(shaded.sum() + flow.sum(), posed, allow_unused=True)
+    assert g is None or float(g.abs().max()) == 0.0
+
+
 def test_full_step_against_oracle_and_grads_finite(dev):
     """One fwd+bwd step of the synthetic training scene; every stage re-done by the oracle from the same numbers."""
     from oracle import check
