@@ -967,6 +967,32 @@ def test_covered_pixels_compaction_is_exact(shape, tile, dev, ops):
         assert torch.equal(pix2, want) and inv.dtype == torch.int32 and torch.equal(inv, want_inv), (shape, tile, density)
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (32, 96), (48, 40), (256, 256)])
+def test_covered_pixels_of_a_rasterised_buffer_use_the_resolve_counts(hw, dev, ops):
+    """For buffers that come out of ops.rasterize the list's block counts are written by the rasteriser's resolve (tile order, H*W a
+    multiple of 256) instead of a3d_cover_count's own pass: the list must equal the plain torch expression either way."""
+    H, W = hw
+    B = 3
+    _, faces, clip, _ = _scene(B, seed=11)
+    rast = ops.rasterize(clip.to(dev), faces.to(dev), (H, W))
+    counted = ops._cover_counts.peek(rast) is not None
+    assert counted == ((H * W) % 256 == 0)
+    pix, inv = ops.covered_pixels(rast, return_inverse=True)
+    cover = rast[..., 3] > 0
+    flat = torch.arange(B * H * W, device=dev).view(B, H // 8, 8, W // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)
+    want = flat[cover.view(B, H // 8, 8, W // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)]
+    assert want.shape[0] > 50 and torch.equal(pix, want)
+    want_inv = torch.full((B * H * W,), -1, dtype=torch.int32, device=dev)
+    want_inv[want] = torch.arange(want.shape[0], dtype=torch.int32, device=dev)
+    assert torch.equal(inv, want_inv)
+    # an in-place edit of the buffer invalidates the cached counts (the version counter is part of the cache key)
+    rast[0, : H // 2] = 0.0
+    assert ops._cover_counts.peek(rast) is None
+    cover = rast[..., 3] > 0
+    want = flat[cover.view(B, H // 8, 8, W // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)]
+    assert torch.equal(ops.covered_pixels(rast), want)
+
+
 @pytest.mark.parametrize("E,res,hw", [(2, 16, (64, 64)), (3, 16, (96, 80)), (1, 40, (64, 64))])
 def test_gbuffer_extra_attribute_equals_modular_interpolate(E, res, hw, dev, ops, mods):
     """The optional per-vertex attribute of the fused G-buffer (the sequence models' 2-D motion) against dr.interpolate + the
