@@ -148,9 +148,17 @@ def ptr(t):
 
 
 def require_device(*tensors, what: str = "op"):
+    """Every tensor on the GPU, and on torch's CURRENT device: the kernels are enqueued on the current device's current stream."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise A3DError(f"{what}: tensor on {t.device}; the HIP hot path only runs on a ROCm device (no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise A3DError(f"{what}: tensor on {t.device} while the current device is cuda:{cur}; wrap the call in torch.cuda.device(...)")
 
 
 def f32c(t):

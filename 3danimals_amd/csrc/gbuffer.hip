@@ -10,18 +10,18 @@
 //   bwd : one thread per covered pixel: the adjoint of the pixel onto the three corners of its triangle -- the four attribute
 //         adjoints (bary weighted), the face-normal adjoint (normalise + cross product) and, folded in, the rasteriser's
 //         backward: d/du, d/dv of all attributes pushed straight through u = a0/(a0+a1+a2), v = a1/(...) onto clip-space x, y, w.
-//         The 36 scatter-adds per pixel are aggregated per work-group in an LDS hash table keyed by vertex and every distinct
-//         vertex is flushed once (12 device-scope atomics).  No [B,H,W,4] gradient image is ever materialised.
-//         What bounds it (bisected on the bench workload, B=16, 2e5 covered pixels): the LDS float atomics -- a wave's 64 pixels
-//         reference ~25 distinct vertices, so every ds_add_f32 instruction serialises on shared addresses.  Neighbouring list
-//         entries that hit the same triangle are therefore merged through DPP first (70 -> 61 us); replicating the table rows to
-//         spread the collisions cost more in table set-up and flush than it saved (2 replicas 70 us, 4 replicas 85 us).
-//         Designs measured and dropped (rocprofv3, same workload; the single hash table took 72 us): per-triangle pixel slots
-//         filled by the forward with one returning atomic per pixel + a gather per (vertex, face) 38 (fwd) + 55 + 59 us; an
-//         atomic-free face pass over each triangle's pixel box + vertex gather 83 + 9 us (176 VGPRs, serial load chains);
-//         screen-aligned 16x16 regions with an LDS table written out to per-vertex slots + vertex pass 131 + 6 us (same LDS
-//         atomics, 4096 work-groups of 57 KB).  Device-scope atomics are fabric transactions on gfx950 (~30/ns fire-and-forget,
-//         ~7/ns returning); LDS atomics ~7 cycles per lane when lanes collide.
+//         No [B,H,W,4] gradient image is ever materialised.  The 36 scatter-adds per pixel go through the work-group's LDS:
+//         neighbouring list entries on one triangle are merged through DPP, every (pixel, corner) row is STAGED with plain stores
+//         and linked into the list of its vertex (hash claim + one integer exchange), then 16-lane groups walk the lists with
+//         lane = component and add each vertex's sums to ONE 64-byte gradient row [B*V, 16] -- a single line request.
+//         What the measurements behind this say (bench workload, B=16, 2e5 covered pixels; DESIGN.md has the full table):
+//         LDS atomics cost ~3.5 clocks per active lane whatever the kind (36 ds_add_f32 per pixel: 42 us); device float atomics
+//         are priced per 64-byte line request, not per lane (140k rows x 12 adds: 86 us as single-lane instructions, 8 us as one
+//         16-lane instruction per row); same-address device atomics serialise at ~30 ns.  Earlier designs, all slower: LDS hash
+//         table with float atomics + per-vertex flush of 12 single-lane atomics 62-72 us; per-triangle pixel slots filled by the
+//         forward + gather per (vertex, face) 38 (fwd) + 55 + 59; atomic-free face pass over each triangle's pixel box + vertex
+//         gather 83 + 9; screen-aligned 16x16 regions + vertex pass 131 + 6; table replicas 70 / 85; no LDS aggregation at all
+//         (every staged entry straight to its row: 410k contended row atomics) 60.  Shipped: 32 us.
 // The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller.
 // HBM traffic per covered pixel: fwd 8 (index) + 16 (texel) + 48 (out) B; bwd 8 + 16 + 48 B in; vertex data lives in L2.
 #include "a3d_common.h"

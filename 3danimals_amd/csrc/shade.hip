@@ -6,8 +6,9 @@
 // ~70 backward over dense [B,H,W,3] frames for this; here it is one launch each way over the covered-pixel list, and the backward
 // recomputes the forward instead of saving intermediates.
 //   in : gb[P,12] (world position | face normal | smooth normal | canonical position, from a3d_gbuffer_fwd),
-//        par[P,ncol] per-point rows of the per-image quantities: w2c rotation (9, row-major) | view position (3) | light (5:
-//        direction 3, ambient, diffuse) -- ncol 12 (no light) or 17,  kd[P,3] (row stride kd_stride floats)
+//        par[B,ncol] rows of the per-image quantities, read through the point -> image index img[P] (or, without img, one row per
+//        point [P,ncol]): w2c rotation (9, row-major) | view position (3) | light (5: direction 3, ambient, diffuse) -- ncol 12
+//        (no light) or 17,  kd[P,3] (row stride kd_stride floats)
 //   out: nrm[P,3] shading normal, shading[P] = amb + diff*max(L.n_cam, 0), shaded[P,3] = shading*kd   (last two only with a light)
 #include "a3d_common.h"
 
