@@ -337,7 +337,11 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaSrc s, unsigned n_pix
             if (src >= 0) v[k] = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
             else if (src <= -2) v[k] = s.bg[(long long)(-2 - src) * C1 + c];
         }
-        *reinterpret_cast<float4*>(o + j0) = make_float4(v[0], v[1], v[2], v[3]);
+        {  // streamed (non-temporal): the image is far larger than the L2s; 20.3 -> 17.2 us for the 17-channel image
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+            __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(o + j0));
+        }
     }
     for (int j = n4 + threadIdx.x; j < nloc; j += 256) {
         const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
@@ -357,7 +361,9 @@ __global__ __launch_bounds__(256) void ca_compose4_kernel(CaSrc s, unsigned n_pi
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q >= 0) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
     else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
-    out[p] = v;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
+    __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out + p));  // streamed: the image is far larger than the L2s
 }
 
 __global__ __launch_bounds__(256) void ca_blend_kernel(CaSrc s, const AaRec* __restrict__ work, const int* __restrict__ count, int capacity, int W,
