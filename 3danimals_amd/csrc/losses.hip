@@ -18,23 +18,6 @@ namespace {
 constexpr int LS_BLOCK = 256;
 constexpr int LS_NL = 5;  // loss columns: mask, mask_inv_dt, rgb, dino, mask_dt
 
-__device__ __forceinline__ float ls_q(const float* __restrict__ shaded, const float* __restrict__ valid, const float* __restrict__ mask_gt,
-                                      long long img_px, int x, int y, int H, int W) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;  // zero padding of avg_pool2d
-    const long long p = img_px + (long long)y * W + x;
-    return (shaded[4 * p + 3] * valid[p] > 0.f ? 1.f : 0.f) * mask_gt[p];
-}
-
-__device__ __forceinline__ float ls_both(const float* __restrict__ shaded, const float* __restrict__ valid, const float* __restrict__ mask_gt,
-                                         long long img_px, int x, int y, int H, int W) {
-    float s = 0.f;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) s += ls_q(shaded, valid, mask_gt, img_px, x + dx, y + dy, H, W);
-    return s / 9.f > 0.99f ? 1.f : 0.f;
-}
-
 // partial[(b*nblk + blk)*4 + k]: per-block sums of the four summands
 __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D,
                                                           const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
@@ -43,8 +26,26 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
                                                           const float* __restrict__ valid, int H, int W, float* __restrict__ partial,
                                                           unsigned char* __restrict__ both_out) {
     __shared__ float red[LS_BLOCK / 64][LS_NL];
+    // q = (rendered mask * valid > 0) * mask_gt of the rows above / of / below this work-group's 256 pixels (+ one pixel either side):
+    // the 3x3 erosion then reads LDS instead of 27 global loads per pixel (the kernel was bound by those, not by its 177 MB)
+    __shared__ float s_q[3][LS_BLOCK + 2];
     const int b = blockIdx.y, HW = H * W;
     const int i = blockIdx.x * LS_BLOCK + threadIdx.x;
+    {
+        const long long img0 = (long long)b * HW;
+        const int i0 = blockIdx.x * LS_BLOCK;
+        for (int k = threadIdx.x; k < 3 * (LS_BLOCK + 2); k += LS_BLOCK) {
+            const int r = k / (LS_BLOCK + 2), c = k - r * (LS_BLOCK + 2);
+            const int j = i0 + (r - 1) * W - 1 + c;
+            float q = 0.f;
+            if (j >= 0 && j < HW) {
+                const long long p = img0 + j;
+                q = (shaded[4 * p + 3] * valid[p] > 0.f ? 1.f : 0.f) * mask_gt[p];
+            }
+            s_q[r][c] = q;
+        }
+        __syncthreads();
+    }
     float v[LS_NL] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float both = 0.f;  // of this thread's own pixel
     if (i < HW) {
@@ -55,7 +56,17 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
         v[0] = t * t;
         v[1] = (1.f - m) * dt0[(long long)b * dt_stride + i];
         if (dt1) v[4] = m * dt1[(long long)b * dt_stride + i];
-        both = ls_both(shaded, valid, mask_gt, img_px, x, y, H, W);
+        {
+            float sum = 0.f;  // 3x3 box sum, dy outer, dx inner (the order of the first version's 27-load form: bit-identical); zero padding of avg_pool2d outside the frame
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const bool in = x + dx >= 0 && x + dx < W && y + dy >= 0 && y + dy < H;
+                    sum += in ? s_q[dy + 1][threadIdx.x + 1 + dx] : 0.f;
+                }
+            both = sum / 9.f > 0.99f ? 1.f : 0.f;
+        }
         both_out[p] = both > 0.f ? 1 : 0;  // saved for the backward: 1 byte instead of 27 neighbourhood loads per pixel
         const float* g = image_gt + (long long)b * 3 * HW + i;
         v[2] = (fabsf(s.x - g[0]) + fabsf(s.y - g[HW]) + fabsf(s.z - g[2ll * HW])) * both;
@@ -161,7 +172,11 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
                 o4.y = gq * (q.y - dg[HW]);
                 o4.z = gq * (q.z - dg[2ll * HW]);
                 o4.w = gq * (q.w - dg[3ll * HW]);
-                gchunk[f] = o4;
+                {  // streamed: 67 MB that only the compositor's gather reads back, sparsely
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f nt; nt.x = o4.x; nt.y = o4.y; nt.z = o4.z; nt.w = o4.w;
+                    __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(gchunk + f));
+                }
             }
         }
     } else if (i < HW) {
