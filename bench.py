@@ -148,6 +148,8 @@ def roofline_of(kernels, dims):
                 with_f3_losses=_aggregate(kernels, IN_SCOPE + F3), mesh=dims)
     # the best-fed streaming kernel of the path, for the other end of the picture
     top = max(scope, key=lambda k: scope[k]["GBps"])
+    roof["in_scope_note"] = ("us_per_step is the figure comparable across rounds (round 1: 645.0): fused entry points (compositor, per-image shading rows, "
+                             "bit-plane DMTet emit) are credited only the bytes they still move, so algorithmic_MB_per_step fell with the time")
     roof["fastest_in_scope"] = dict(kernel=top, achieved=scope[top]["GBps"], unit="GB/s", frac=round(scope[top]["GBps"] / HBM_PEAK_GBS, 4),
                                     launch_us=scope[top]["mean_us"])
     # model/networks side (out of scope): the field kernels, incl. the one compute-bound kernel of the library
