@@ -47,7 +47,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
                                                                 const int4* __restrict__ tets, int Ne, int Nt, int nbe,
                                                                 int* __restrict__ blk_e, int* __restrict__ blk_t1,
                                                                 int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
-                                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal) {
+                                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
+                                                                unsigned* __restrict__ vbits) {
     __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];  // crossings per 64-edge word of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,7 +58,12 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             long long i = base + k * DM_THREADS + tid;
-            bool f = i < Ne && dm_edge_cross(sdf, edges[i]);
+            const int2 e = i < Ne ? edges[i] : make_int2(0, 0);
+            const bool f = i < Ne && dm_edge_cross(sdf, e);
+            if (f && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
+                atomicOr(vbits + (e.x >> 5), 1u << (e.x & 31));
+                atomicOr(vbits + (e.y >> 5), 1u << (e.y & 31));
+            }
             const unsigned long long m = __ballot(f);
             if (lane == 0) {
                 edge_bits[(base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave] = m;
@@ -97,10 +103,36 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
 // of the same block before a 64-edge word) a surface vertex id is blk_e[e >> 10] + wlocal[e >> 6] + popcount(edge_bits[e >> 6] below
 // bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
-                                                       int nbe, int nbt, int* __restrict__ counts) {
+                                                       int nbe, int nbt, int* __restrict__ counts, const unsigned* __restrict__ vbits,
+                                                       int* __restrict__ vchunk, int nvc) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int which = blockIdx.x;
+    if (which == 3) {  // surface-adjacent grid vertices: bits per 1024-vertex chunk (32 words), exclusive prefix over the chunks -> counts[3]
+        const int per = (nvc + 1023) / 1024;
+        const int lo = min(tid * per, nvc), hi = min(lo + per, nvc);
+        for (int c = lo; c < hi; ++c) {
+            const uint4* w = reinterpret_cast<const uint4*>(vbits + 32ll * c);
+            int n = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const uint4 x = w[q]; n += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w); }
+            vchunk[c] = n;
+        }
+        const int mine = a3d_run_sum(vchunk, lo, hi);  // (this thread's own stores)
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        run = a3d_run_scan<false>(vchunk, vchunk, lo, hi, run);
+        if (tid == 1023) counts[3] = run;
+        return;
+    }
     int* arr = which == 0 ? blk_e : (which == 1 ? blk_t1 : blk_t2);
     const int n = which == 0 ? nbe : nbt;
     // every thread owns a contiguous run of ceil(n / 1024) block sums: one pass, one barrier (a loop over 1024-element slabs with
@@ -121,7 +153,27 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
     run = a3d_run_scan<false>(arr, arr, lo, hi, run);
     if (tid == 1023) {
         counts[which] = run;
-        if (which == 0) counts[3] = 0;
+        if (which == 0 && !vbits) counts[3] = 0;
+    }
+}
+
+// sorted list of the flagged grid vertices: chunk c = vertices [1024 c, 1024 c + 1024); entry = chunk prefix + bits below
+__global__ __launch_bounds__(256) void dm_surface_vertices_kernel(const unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
+                                                                  long long* __restrict__ idx) {
+    __shared__ int s_pre[32];  // set bits before each of the chunk's 32 words
+    const int c = blockIdx.x;
+    if (threadIdx.x < 32) {
+        int before = 0;
+        for (int j = 0; j < (int)threadIdx.x; ++j) before += __popc(vbits[32ll * c + j]);
+        s_pre[threadIdx.x] = before;
+    }
+    __syncthreads();
+    const int base = vchunk[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int local = k * 256 + threadIdx.x, v = c * 1024 + local;
+        const unsigned word = vbits[32ll * c + (local >> 5)];
+        if (v < Nv && ((word >> (local & 31)) & 1u)) idx[base + s_pre[local >> 5] + __popc(word & ((1u << (local & 31)) - 1u))] = v;
     }
 }
 
@@ -273,17 +325,40 @@ extern "C" size_t a3d_dmtet_scratch_bytes(int Ne, int Nt) {
     return dm_split_scratch(nullptr, Ne < 1 ? 1 : Ne, Nt < 1 ? 1 : Nt, &d);
 }
 
+// surface-adjacent vertex list (optional): 1 bit per grid vertex in 1024-vertex chunks + one int per chunk
+extern "C" size_t a3d_dmtet_vertex_scratch_bytes(int Nv) {
+    const size_t nvc = (size_t)a3d_div_up(Nv < 1 ? 1 : Nv, 1024);
+    return nvc * 128 + nvc * sizeof(int);
+}
+
 extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                               int32_t* counts, a3d_stream_t stream) {
+                               int32_t* counts, void* vertex_scratch_or_null, int Nv, a3d_stream_t stream) {
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0);
+    A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && ((uintptr_t)vertex_scratch_or_null & 15) == 0));
     DmScratch d;
     dm_split_scratch(scratch, Ne, Nt, &d);
     hipStream_t s = (hipStream_t)stream;
+    unsigned* vbits = (unsigned*)vertex_scratch_or_null;
+    const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
+    int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
+    if (vbits) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
     hipLaunchKernelGGL(dm_count_kernel, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
-                       d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal);
+                       d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dm_scan_kernel, dim3(3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts);
+    hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_dmtet_surface_vertices(const void* vertex_scratch, int Nv, int n, int64_t* idx, a3d_stream_t stream) {
+    A3D_CHECK_ARG(vertex_scratch && Nv > 0 && n >= 0);
+    if (n == 0) return A3D_OK;
+    A3D_CHECK_ARG(idx);
+    const unsigned* vbits = (const unsigned*)vertex_scratch;
+    const int nvc = a3d_div_up(Nv, 1024);
+    hipLaunchKernelGGL(dm_surface_vertices_kernel, dim3(nvc), dim3(256), 0, (hipStream_t)stream, vbits, (const int*)(vbits + 32ll * nvc), Nv,
+                       (long long*)idx);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

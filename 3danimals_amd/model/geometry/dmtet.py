@@ -302,10 +302,9 @@ class DMTetGeometry(torch.nn.Module):
         """
         with torch.no_grad():
             sdf0 = self.get_sdf(pos, total_iter=total_iter, feats=feats)
-        verts0, faces, uv_idx, vert_edge = ops.dmtet_extract(pos, sdf0, self.topology)
-        mask = torch.zeros(pos.shape[0], dtype=torch.bool, device=pos.device)
-        mask.index_fill_(0, self.topology.edges32[vert_edge.long()].reshape(-1).long(), True)  # (mask[idx] = True uploads the scalar: a sync)
-        idx = torch.nonzero(mask).squeeze(1)  # sorted, unique
+        # idx = the grid vertices at the ends of crossing edges, sorted and unique; their count arrives with the DMTet counts (the
+        # mask + torch.nonzero this replaces was a second host synchronisation per step)
+        verts0, faces, uv_idx, vert_edge, idx = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True)
         pts = pos[idx]
         n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0
         if n_pad:  # pad (zeros, sliced off again) so the MLP's GEMM shapes repeat from step to step

@@ -107,17 +107,20 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
 
 
 # ---------------------------------------------------------------------------------------------- DMTet
-def dmtet_extract(pos, sdf, grid):
-    """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V])."""
+def dmtet_extract(pos, sdf, grid, surface_vertices=False):
+    """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V]).
+    ``surface_vertices``: also the sorted int64 list of the grid vertices at the ends of sign-crossing edges (their count rides in the
+    same read-back as V, n1, n2: no torch.nonzero, no second host synchronisation)."""
     require_device(pos, sdf, grid.edges32, what="dmtet")
     pos_c, sdf_c = f32c(pos.detach()), f32c(sdf.detach()).reshape(-1)
     Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
     assert sdf_c.shape[0] == Nv, "sdf must have one value per grid vertex"
     dev = pos_c.device
     scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
+    vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev) if surface_vertices else None
     counts = torch.empty(4, dtype=torch.int32, device=dev)
-    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), stream())
-    V, n1, n2 = counts.tolist()[:3]  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
+    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), Nv, stream())
+    V, n1, n2, n_surf = counts.tolist()  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
     F = n1 + 2 * n2
     verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
     vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
@@ -125,7 +128,11 @@ def dmtet_extract(pos, sdf, grid):
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
     call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
          ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
-    return verts, faces, uv_idx, vert_edge
+    if not surface_vertices:
+        return verts, faces, uv_idx, vert_edge
+    idx = torch.empty((n_surf,), dtype=torch.int64, device=dev)
+    call("a3d_dmtet_surface_vertices", ptr(vscratch), Nv, n_surf, ptr(idx), stream())
+    return verts, faces, uv_idx, vert_edge, idx
 
 
 class _DMTetVerts(torch.autograd.Function):

@@ -89,6 +89,28 @@ def test_dmtet_matches_oracle_larger(res, kind, dev, mods):
     np.testing.assert_allclose(gp.cpu().numpy(), gp_ref.numpy(), rtol=2e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("res,kind", [(12, "random"), (32, "quadruped"), (64, "quadruped"), (16, "empty")])
+def test_dmtet_surface_adjacent_vertices_ride_in_the_count(res, kind, dev, mods, ops):
+    """The sorted list of grid vertices at the ends of crossing edges (what DMTetGeometry re-evaluates the SDF network on) against its
+    plain definition, and the other outputs unchanged by asking for it."""
+    pos, tets = kuhn(res)
+    g = torch.Generator().manual_seed(res + 1)
+    if kind == "random":
+        sdf = torch.randn(pos.shape[0], generator=g)
+    elif kind == "empty":
+        sdf = torch.ones(pos.shape[0])
+    else:
+        sdf = mods["synthetic"].quadruped_sdf(pos, 0.2, noise=0.01, seed=res)
+    topo = mods["dmtet"].TetGridTopology(tets.to(dev))
+    pos_d, sdf_d = pos.to(dev), sdf.to(dev)
+    v0, f0, u0, e0 = ops.dmtet_extract(pos_d, sdf_d, topo)
+    v1, f1, u1, e1, idx = ops.dmtet_extract(pos_d, sdf_d, topo, surface_vertices=True)
+    assert torch.equal(v0, v1) and torch.equal(f0, f1) and torch.equal(u0, u1) and torch.equal(e0, e1)
+    want = torch.unique(topo.edges32[e0.long()].reshape(-1).long())  # sorted
+    assert idx.dtype == torch.int64 and torch.equal(idx, want)
+    assert (kind == "empty") == (idx.numel() == 0)
+
+
 def test_dmtet_full_size_properties(dev, mods):
     """BASELINE-size grid (Kuhn R=64): size-independent invariants + run-to-run determinism."""
     pos, tets = kuhn(64)
