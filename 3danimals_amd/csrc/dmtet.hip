@@ -157,15 +157,22 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
     }
 }
 
-// sorted list of the flagged grid vertices: chunk c = vertices [1024 c, 1024 c + 1024); entry = chunk prefix + bits below
-__global__ __launch_bounds__(256) void dm_surface_vertices_kernel(const unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
-                                                                  long long* __restrict__ idx) {
-    __shared__ int s_pre[32];  // set bits before each of the chunk's 32 words
-    const int c = blockIdx.x;
-    if (threadIdx.x < 32) {
-        int before = 0;
-        for (int j = 0; j < (int)threadIdx.x; ++j) before += __popc(vbits[32ll * c + j]);
-        s_pre[threadIdx.x] = before;
+// sorted list of the flagged grid vertices: chunk c = vertices [1024 c, 1024 c + 1024); entry = chunk prefix + bits below.  Runs as
+// extra work-groups of the emit launch; every work-group clears the 32 words it consumed, which leaves the bit plane armed for the
+// next count (vertex_scratch_is_clean: no memset).
+__device__ __forceinline__ void dm_surface_vertices_chunk(int c, unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
+                                                          long long* __restrict__ idx, int* s_pre) {
+    unsigned mine = 0;
+    if (threadIdx.x < 64) {  // (first wave) exclusive prefix of the 32 word popcounts through shuffles
+        mine = threadIdx.x < 32 ? vbits[32ll * c + threadIdx.x] : 0u;
+        const int n = __popc(mine);
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        if (threadIdx.x < 32) s_pre[threadIdx.x] = incl - n;
     }
     __syncthreads();
     const int base = vchunk[c];
@@ -175,6 +182,8 @@ __global__ __launch_bounds__(256) void dm_surface_vertices_kernel(const unsigned
         const unsigned word = vbits[32ll * c + (local >> 5)];
         if (v < Nv && ((word >> (local & 31)) & 1u)) idx[base + s_pre[local >> 5] + __popc(word & ((1u << (local & 31)) - 1u))] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < 32 && mine) vbits[32ll * c + threadIdx.x] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ emit
@@ -193,8 +202,15 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              const int* __restrict__ blk_t2, const unsigned long long* __restrict__ edge_bits,
                                                              const unsigned long long* __restrict__ tet_bits, const int* __restrict__ wlocal,
                                                              int n1, float* __restrict__ verts, int* __restrict__ vert_edge,
-                                                             long long* __restrict__ faces, long long* __restrict__ uv_idx) {
+                                                             long long* __restrict__ faces, long long* __restrict__ uv_idx, int nbt,
+                                                             unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
+                                                             long long* __restrict__ surf_idx) {
+    __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= nbe + nbt) {
+        dm_surface_vertices_chunk((int)blockIdx.x - nbe - nbt, vbits, vchunk, Nv, surf_idx, s_pre);
+        return;
+    }
     constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
     if ((int)blockIdx.x < nbe) {
         const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
@@ -332,7 +348,7 @@ extern "C" size_t a3d_dmtet_vertex_scratch_bytes(int Nv) {
 }
 
 extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                               int32_t* counts, void* vertex_scratch_or_null, int Nv, a3d_stream_t stream) {
+                               int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream) {
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0);
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && ((uintptr_t)vertex_scratch_or_null & 15) == 0));
@@ -342,7 +358,7 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     unsigned* vbits = (unsigned*)vertex_scratch_or_null;
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
-    if (vbits) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
+    if (vbits && !vertex_scratch_is_clean) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
     hipLaunchKernelGGL(dm_count_kernel, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
                        d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
     A3D_LAUNCH_CHECK();
@@ -351,31 +367,23 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     return A3D_OK;
 }
 
-extern "C" int a3d_dmtet_surface_vertices(const void* vertex_scratch, int Nv, int n, int64_t* idx, a3d_stream_t stream) {
-    A3D_CHECK_ARG(vertex_scratch && Nv > 0 && n >= 0);
-    if (n == 0) return A3D_OK;
-    A3D_CHECK_ARG(idx);
-    const unsigned* vbits = (const unsigned*)vertex_scratch;
-    const int nvc = a3d_div_up(Nv, 1024);
-    hipLaunchKernelGGL(dm_surface_vertices_kernel, dim3(nvc), dim3(256), 0, (hipStream_t)stream, vbits, (const int*)(vbits + 32ll * nvc), Nv,
-                       (long long*)idx);
-    A3D_LAUNCH_CHECK();
-    return A3D_OK;
-}
-
 extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                              a3d_stream_t stream) {
+                              void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
-    if (V == 0) return A3D_OK;  // no crossing edge, hence no surface tet
+    A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && n_surf >= 0 && (n_surf == 0 || surf_idx_or_null)));
+    if (V == 0) return A3D_OK;  // no crossing edge, hence no surface tet and no flagged vertex
     DmScratch d;
     dm_split_scratch((void*)scratch, Ne, Nt, &d);
-    hipLaunchKernelGGL(dm_emit_kernel, dim3(d.nbe + ((n1 + n2) > 0 ? d.nbt : 0)), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf,
-                       (const int2*)edges, tet2edge, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge,
-                       (long long*)faces, (long long*)uv_idx);
+    unsigned* vbits = (unsigned*)vertex_scratch_or_null;
+    const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
+    const int nbt = (n1 + n2) > 0 ? d.nbt : 0;
+    hipLaunchKernelGGL(dm_emit_kernel, dim3(d.nbe + nbt + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
+                       Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
+                       (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -107,6 +107,9 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
 
 
 # ---------------------------------------------------------------------------------------------- DMTet
+_dm_vertex_scratch = {}
+
+
 def dmtet_extract(pos, sdf, grid, surface_vertices=False):
     """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V]).
     ``surface_vertices``: also the sorted int64 list of the grid vertices at the ends of sign-crossing edges (their count rides in the
@@ -117,21 +120,30 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False):
     assert sdf_c.shape[0] == Nv, "sdf must have one value per grid vertex"
     dev = pos_c.device
     scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
-    vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev) if surface_vertices else None
+    # the vertex bit plane is kept per (device, stream, grid size): the emit leaves it cleared, so only its first use pays the memset
+    vscratch, vkey, vclean = None, (dev, stream(), Nv), False
+    if surface_vertices:
+        vscratch = _dm_vertex_scratch.pop(vkey, None)
+        vclean = vscratch is not None
+        if vscratch is None:
+            vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
     counts = torch.empty(4, dtype=torch.int32, device=dev)
-    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), Nv, stream())
+    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
+         stream())
     V, n1, n2, n_surf = counts.tolist()  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
     F = n1 + 2 * n2
     verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
     vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
     faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
+    idx = torch.empty((n_surf,), dtype=torch.int64, device=dev) if surface_vertices else None
     call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
-         ptr(vert_edge), ptr(faces), ptr(uv_idx), stream())
+         ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), stream())
     if not surface_vertices:
         return verts, faces, uv_idx, vert_edge
-    idx = torch.empty((n_surf,), dtype=torch.int64, device=dev)
-    call("a3d_dmtet_surface_vertices", ptr(vscratch), Nv, n_surf, ptr(idx), stream())
+    if len(_dm_vertex_scratch) >= 4:
+        _dm_vertex_scratch.clear()
+    _dm_vertex_scratch[vkey] = vscratch  # only after a completed count + emit pair (a failed call leaves the buffer out of the cache)
     return verts, faces, uv_idx, vert_edge, idx
 
 

@@ -63,7 +63,6 @@ def algorithmic_bytes(name, d):
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
         "a3d_dmtet_emit": (Ne // 8 + Nt // 2 + Ne // 16) + 56 * V + 72 * F,
-        "a3d_dmtet_surface_vertices": Nv // 8 + 16 * V,  # vertex bit plane in; the list out (at most the 2V end points of the crossing edges)
         "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,

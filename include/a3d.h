@@ -52,17 +52,17 @@ const char* a3d_last_error(void);
  */
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                    int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int Nv, a3d_stream_t stream);
+                    int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream);
+int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
+                   const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
+                   void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, a3d_stream_t stream);
 /* Optional, for callers that evaluate the SDF network with a graph only where the surface's gradient can reach (DMTetGeometry.
  * _get_mesh_surface_backward): with vertex_scratch (a3d_dmtet_vertex_scratch_bytes(Nv) bytes, 16-byte aligned) a3d_dmtet_count also
  * flags the grid vertices at the ends of crossing edges and returns their number in counts[3] -- the same read-back as V, n1, n2 --
- * and a3d_dmtet_surface_vertices writes them as a sorted int64 list idx[counts[3]].  Replaces a mask + torch.nonzero and its own
- * host synchronisation. */
+ * and a3d_dmtet_emit writes them as a sorted int64 list surf_idx[n_surf] (extra work-groups of the same launch) and clears the flags
+ * again: a caller that hands the same vertex_scratch to the next count on the same stream passes vertex_scratch_is_clean = 1 and
+ * saves its memset.  Replaces a mask + torch.nonzero and its own host synchronisation. */
 size_t a3d_dmtet_vertex_scratch_bytes(int Nv);
-int a3d_dmtet_surface_vertices(const void* vertex_scratch, int Nv, int n, int64_t* idx, a3d_stream_t stream);
-int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
-                   const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                   a3d_stream_t stream);
 int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
                   int V, int Nv, float* g_pos_or_null, float* g_sdf, a3d_stream_t stream);
 

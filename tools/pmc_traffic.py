@@ -17,7 +17,6 @@ from collections import defaultdict
 ENTRY = {
     "a3d_dmtet_count": (["dm_count_kernel", "dm_scan_kernel"], "dm_count_kernel"),
     "a3d_dmtet_emit": (["dm_emit_kernel"], "dm_emit_kernel"),
-    "a3d_dmtet_surface_vertices": (["dm_surface_vertices_kernel"], "dm_surface_vertices_kernel"),
     "a3d_dmtet_bwd": (["dm_bwd_kernel"], "dm_bwd_kernel"),
     "a3d_skin_fwd": (["sk_fwd_kernel"], "sk_fwd_kernel"),
     "a3d_skin_bwd": (["sk_bwd_kernel"], "sk_bwd_kernel"),
