@@ -11,7 +11,7 @@
 //         adjoints (bary weighted), the face-normal adjoint (normalise + cross product) and, folded in, the rasteriser's
 //         backward: d/du, d/dv of all attributes pushed straight through u = a0/(a0+a1+a2), v = a1/(...) onto clip-space x, y, w.
 //         No [B,H,W,4] gradient image is ever materialised.  The 36 scatter-adds per pixel go through the work-group's LDS:
-//         neighbouring list entries on one triangle are merged through DPP, every (pixel, corner) row is STAGED with plain stores
+//         list entries on one triangle 1 and 8 lanes apart are merged through DPP, every (pixel, corner) row is STAGED with plain stores
 //         and linked into the list of its vertex (hash claim + one integer exchange), then 16-lane groups walk the lists with
 //         lane = component and add each vertex's sums to ONE 64-byte gradient row [B*V, 16] -- a single line request.
 //         What the measurements behind this say (bench workload, B=16, 2e5 covered pixels; DESIGN.md has the full table):
@@ -21,7 +21,8 @@
 //         table with float atomics + per-vertex flush of 12 single-lane atomics 62-72 us; per-triangle pixel slots filled by the
 //         forward + gather per (vertex, face) 38 (fwd) + 55 + 59; atomic-free face pass over each triangle's pixel box + vertex
 //         gather 83 + 9; screen-aligned 16x16 regions + vertex pass 131 + 6; table replicas 70 / 85; no LDS aggregation at all
-//         (every staged entry straight to its row: 410k contended row atomics) 60.  Shipped: 32 us.
+//         (every staged entry straight to its row: 410k contended row atomics) 60.  Shipped: 32 us with the 1-lane merge, 21 us with the
+//         8-lane merge on top.
 // The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller.
 // HBM traffic per covered pixel: fwd 8 (index) + 16 (texel) + 48 (out) B; bwd 8 + 16 + 48 B in; vertex data lives in L2.
 #include "a3d_common.h"
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     }
     // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums, a third fewer entries
     const int tkey = live ? b * F + f : -1 - (int)threadIdx.x;  // (B*F < 2^31 is checked by the entry point)
-    const bool same = live && gb_xor1(tkey) == tkey;
+    const int tkey1 = gb_xor1(tkey);
+    const bool same = live && tkey1 == tkey;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -285,9 +287,26 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
             const float o = gb_xor1(acc[c][k]);
             if (same) acc[c][k] += o;
         }
+    bool active = live && !(same && (threadIdx.x & 1));
+    // a second round of the same merge with the lane 8 away (DPP row_ror:8) -- the pixel below in a full 8x8 tile, and triangles
+    // of a few pixels are usually two rows tall: 34 -> 21 us, every entry saved is an LDS claim, an exchange and a list hop less.
+    // (Any two live entries on one triangle may merge, adjacency only makes it likely.  Further rounds -- 2 away, mirrored lanes,
+    // 16 / 32 away -- cost more exchanges than they save: 21.1 - 23.1 us.)
+    {
+        const int mykey = active ? tkey : -1 - (int)threadIdx.x;
+        const int other = __builtin_amdgcn_mov_dpp(mykey, 0x128, 0xF, 0xF, true);  // (outside the &&: every lane must take part)
+        const bool same_r = active && other == mykey;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const float o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[c][k]), 0x128, 0xF, 0xF, true));
+                if (same_r) acc[c][k] += o;
+            }
+        active = active && !(same_r && (threadIdx.x & 8));
+    }
     // stage: each (pixel, corner) row goes to LDS with plain stores and is linked into the list of its vertex (one integer exchange);
     // entries are handed out per wave (one counter update per wave, not per lane)
-    const bool active = live && !(same && (threadIdx.x & 1));
     const unsigned long long amask = __ballot(active);
     int wbase = 0;
     if (a3d_lane_id() == 0 && amask) wbase = atomicAdd(&s_n[0], 3 * __popcll(amask));
