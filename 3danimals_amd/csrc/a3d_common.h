@@ -59,7 +59,17 @@ __device__ __forceinline__ int a3d_run_sum(const int* __restrict__ a, int lo, in
         const int v0 = a[i], v1 = a[i + 1], v2 = a[i + 2], v3 = a[i + 3], v4 = a[i + 4], v5 = a[i + 5], v6 = a[i + 6], v7 = a[i + 7];
         s += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
     }
-    for (; i < hi; ++i) s += a[i];
+    if (i + 4 <= hi) {
+        const int v0 = a[i], v1 = a[i + 1], v2 = a[i + 2], v3 = a[i + 3];
+        s += (v0 + v1) + (v2 + v3);
+        i += 4;
+    }
+    if (i + 2 <= hi) {
+        const int v0 = a[i], v1 = a[i + 1];
+        s += v0 + v1;
+        i += 2;
+    }
+    if (i < hi) s += a[i];
     return s;
 }
 
@@ -79,7 +89,26 @@ __device__ __forceinline__ int a3d_run_scan(int* a, int* dst, int lo, int hi, in
             run += v[k];
         }
     }
-    for (; i < hi; ++i) {
+    if (i + 4 <= hi) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = a[i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[i + k] = run;
+            if (RESET) a[i + k] = fill;
+            run += v[k];
+        }
+        i += 4;
+    }
+    if (i + 2 <= hi) {
+        const int v0 = a[i], v1 = a[i + 1];
+        dst[i] = run; dst[i + 1] = run + v0;
+        if (RESET) { a[i] = fill; a[i + 1] = fill; }
+        run += v0 + v1;
+        i += 2;
+    }
+    if (i < hi) {
         const int c = a[i];
         dst[i] = run;
         if (RESET) a[i] = fill;

@@ -95,9 +95,7 @@ __global__ __launch_bounds__(NR_SCAN_THREADS) void nr_adj_scan_kernel(int* __res
 
 // per-vertex lists into ascending key order, which makes the summation order independent of the fill atomics.  Lists are short
 // (valence ~6): up to 8 entries are sorted in registers with a 19-comparator network, longer ones by insertion in place.
-__global__ __launch_bounds__(256) void nr_adj_sort_kernel(const int* __restrict__ off, int V, int* __restrict__ adj) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+__device__ __forceinline__ void nr_adj_sort_vertex(const int* __restrict__ off, int v, int* __restrict__ adj) {
     const int lo = off[v], hi = off[v + 1], n = hi - lo;
     if (n <= 1) return;
     if (n <= 8) {
@@ -124,6 +122,11 @@ __global__ __launch_bounds__(256) void nr_adj_sort_kernel(const int* __restrict_
         while (j >= lo && adj[j] > key) { adj[j + 1] = adj[j]; --j; }
         adj[j + 1] = key;
     }
+}
+
+__global__ __launch_bounds__(256) void nr_adj_sort_kernel(const int* __restrict__ off, int V, int* __restrict__ adj) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) nr_adj_sort_vertex(off, v, adj);
 }
 
 }  // namespace

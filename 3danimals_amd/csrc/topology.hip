@@ -5,8 +5,9 @@
 //   count + insert  : thread = corner 3f+i: atomicAdd(cursor[tri]) and hash insert of the edge opposite to it
 //   scan            : single work-group exclusive scan -> off[V+1]
 //   fill + lookup   : thread = corner: adj[off[v] + cursor[v]++] = c*F + f and opp[3f+i] from the finished hash
-//   sort            : per-vertex lists into corner-major order (the reference's scatter_add_ order, mesh.py:291-293)
-// 5 launches instead of 9 (5 + 4) on a latency-bound stretch: ~24 KB of indices in, 12F + 4V + 12F bytes out.
+//   sort            : per-vertex lists into corner-major order (the reference's scatter_add_ order, mesh.py:291-293); the same launch
+//                     re-arms cursor and hash, so a caller that keeps the scratch skips the init launch of the next call
+// 4-5 launches instead of 9 (5 + 4) on a latency-bound stretch: ~24 KB of indices in, 12F + 4V + 12F bytes out.
 // Replaces what /root/reference/model/render/mesh.py:276-304 (index.repeat / scatter_add_) and nvdiffrast's antialias topology
 // hash (constructed lazily inside dr.antialias, render.py:264-267) do per call.
 #include "a3d_common.h"
@@ -45,10 +46,26 @@ __global__ __launch_bounds__(256) void tp_fill_lookup_kernel(const int* __restri
     opp[idx] = aa_lookup_edge(tri, idx, mask, keys, vals);
 }
 
+// the sort, and afterwards the scratch left the way the next call wants to find it: fill cursors zero, hash slots empty (neither is
+// read by this launch), which saves the next call its init launch (scratch_is_clean)
+__global__ __launch_bounds__(256) void tp_sort_rearm_kernel(const int* __restrict__ off, int V, int* __restrict__ adj, int* __restrict__ cursor,
+                                                            unsigned long long* __restrict__ keys, int* __restrict__ vals, unsigned n) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (t < (unsigned)V) {
+        nr_adj_sort_vertex(off, (int)t, adj);
+        cursor[t] = 0;
+    }
+    for (unsigned i = t; i < n; i += stride) {
+        keys[i] = AA_EMPTY_KEY;
+        vals[2 * i] = AA_NONE;
+        vals[2 * i + 1] = AA_NONE;
+    }
+}
+
 }  // namespace
 
 extern "C" int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
-                                 a3d_stream_t stream) {
+                                 int scratch_is_clean, a3d_stream_t stream) {
     A3D_CHECK_ARG(off && cursor && V > 0 && F >= 0 && (long long)3 * F < 0x7fffffffll);
     A3D_CHECK_ARG(F == 0 || (tri && adj && hash && opp));
     hipStream_t s = (hipStream_t)stream;
@@ -58,8 +75,10 @@ extern "C" int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off,
     const long long work = (long long)n > V ? (long long)n : V;
     int blocks = a3d_div_up(work, 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(tp_init_kernel, dim3(blocks), dim3(256), 0, s, cursor, V, keys, vals, n);
-    A3D_LAUNCH_CHECK();
+    if (!scratch_is_clean) {  // (clean: cursor[V] and the hash of a3d_aa_hash_bytes(F) bytes as a previous call of the same F left them)
+        hipLaunchKernelGGL(tp_init_kernel, dim3(blocks), dim3(256), 0, s, cursor, V, keys, vals, n);
+        A3D_LAUNCH_CHECK();
+    }
     if (F > 0) {
         hipLaunchKernelGGL(tp_count_insert_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, V, cursor, n - 1, keys, vals);
         A3D_LAUNCH_CHECK();
@@ -69,7 +88,9 @@ extern "C" int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off,
     if (F > 0) {
         hipLaunchKernelGGL(tp_fill_lookup_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, V, off, cursor, adj, n - 1, keys, vals, opp);
         A3D_LAUNCH_CHECK();
-        hipLaunchKernelGGL(nr_adj_sort_kernel, dim3(a3d_div_up(V, 256)), dim3(256), 0, s, off, V, adj);
+        // (enough work-groups that clearing the n hash slots is one or two rounds of stores, not ten)
+        hipLaunchKernelGGL(tp_sort_rearm_kernel, dim3(a3d_div_up((long long)V > (long long)n / 2 ? (long long)V : (long long)n / 2, 256)), dim3(256), 0, s, off, V,
+                           adj, cursor, keys, vals, n);
         A3D_LAUNCH_CHECK();
     }
     return A3D_OK;

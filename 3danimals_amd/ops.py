@@ -91,6 +91,9 @@ def aa_topology(tri32: torch.Tensor, num_vertices: int) -> AATopology:
     return hit if hit is not None else mesh_topology(tri32, num_vertices)[1]
 
 
+_topology_scratch = {}
+
+
 def mesh_topology(tri32: torch.Tensor, num_vertices: int):
     """(VertexFaceAdjacency, AATopology) of one triangle list, built together by a3d_mesh_topology (5 launches instead of 9) and
     entered into both caches: the normals, the G-buffer backward and the antialiasing of every mesh that shares the list hit them."""
@@ -98,9 +101,20 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
     F, V = tri32.shape[0], int(num_vertices)
     adj = VertexFaceAdjacency(tri32, V, build=False)
     topo = AATopology(tri32, V, build=False)
-    cursor = torch.empty(V, dtype=torch.int32, device=tri32.device)
-    scratch = torch.empty(_lib.lib().a3d_aa_hash_bytes(max(F, 1)), dtype=torch.uint8, device=tri32.device)
-    call("a3d_mesh_topology", ptr(tri32), V, F, ptr(adj.off), ptr(adj.adj), ptr(cursor), ptr(scratch), ptr(topo.opp), stream())
+    # cursor + hash are kept per (device, stream, hash size): the last launch of a call re-arms them, so only the first use pays the init
+    nbytes = _lib.lib().a3d_aa_hash_bytes(max(F, 1))
+    key = (tri32.device, stream(), nbytes)
+    kept = _topology_scratch.pop(key, None)
+    clean = kept is not None and kept[0].shape[0] >= V
+    if clean:
+        cursor, scratch = kept
+    else:
+        cursor = torch.zeros(max(V, nbytes // 16), dtype=torch.int32, device=tri32.device)  # zero beyond V too: later calls of this F class may have more vertices (V <= 3F < slots)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=tri32.device)
+    call("a3d_mesh_topology", ptr(tri32), V, F, ptr(adj.off), ptr(adj.adj), ptr(cursor), ptr(scratch), ptr(topo.opp), int(clean), stream())
+    if len(_topology_scratch) >= 4:
+        _topology_scratch.clear()
+    _topology_scratch[key] = (cursor, scratch)  # only after a completed call
     _adj_cache.put(tri32, adj)
     _topo_cache.put(tri32, topo)
     return adj, topo

@@ -175,12 +175,14 @@ int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C,
 /* ------------------------------------------------------------------------------------------------
  * Both topology tables of one triangle list in one entry point (5 launches instead of 9): the vertex -> (corner, face) CSR of
  * a3d_normals_adjacency (off[V+1], adj[3F], cursor[V] scratch) and the opposite-vertex table opp[F,3] of a3d_aa_topology
- * (hash = a3d_aa_hash_bytes(F) bytes of scratch).  Same outputs, bit for bit, as the two separate calls.  Once per DMTet call:
+ * (hash = a3d_aa_hash_bytes(F) bytes of scratch).  Same outputs, bit for bit, as the two separate calls.  The last launch leaves
+ * cursor and hash re-armed: a caller that hands the same cursor / hash (same hash size, cursor at least V long) to the next call on
+ * the same stream passes scratch_is_clean = 1 and saves the init launch.  Once per DMTet call:
  * replaces the per-call index.repeat / scatter_add_ bookkeeping of /root/reference/model/render/mesh.py:276-304 and the
  * topology hash nvdiffrast builds inside dr.antialias (render.py:264-267).
  */
 int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
-                      a3d_stream_t stream);
+                      int scratch_is_clean, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused G-buffer over the covered-pixel list -- replaces the five dr.interpolate calls + face-normal torch ops of
