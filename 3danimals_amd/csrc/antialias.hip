@@ -309,12 +309,37 @@ __device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
     return s.bg[(long long)r * (s.C + 1) + c];
 }
 
+// One or two buffers per launch (blockIdx.y picks the job): the render path composites and antialiases the colour image and the
+// feature image of a step against the same pixel list and the same crossing records, and four launches each way instead of eight is
+// the larger part of what these latency-bound kernels cost.
+struct CaJob {
+    CaSrc s;
+    float* out;          // forward: [B,H,W,C+1]
+    const float* g_out;  // backward: [B,H,W,C+1]
+    float* g_vals;       // backward: [P,C]
+};
+
 // 256 pixels per work-group: the pixel -> source map goes through LDS once, then the work-group writes the pixels' C+1 floats as one
 // contiguous run.  (j / C1 for j < 256*C1 as a float multiply: exact in that range, and an integer division per element -- ~40
-// instructions, 150 in 64 bits -- made this pass instruction bound: 39 us for the 17-channel image.)
-__global__ __launch_bounds__(256) void ca_compose_kernel(CaSrc s, unsigned n_pix, float* __restrict__ out) {
+// instructions, 150 in 64 bits -- made this pass instruction bound: 39 us for the 17-channel image.)  C + 1 == 4: one 16-byte texel
+// per thread.  Stores are non-temporal: the image is far larger than the L2s (17-channel image: 20.3 -> 17.2 us).
+__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix) {
     __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
+    const CaJob& job = blockIdx.y ? jb : ja;
+    const CaSrc& s = job.s;
+    float* __restrict__ out = job.out;
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned base = blockIdx.x * 256u, p = base + threadIdx.x;
+    if (s.C == 3 && (((uintptr_t)out | (uintptr_t)s.bg) & 15) == 0) {
+        if (p >= n_pix) return;
+        const int q = s.inv[p];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q >= 0) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
+        else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
+        v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
+        __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out) + p);
+        return;
+    }
     const int C1 = s.C + 1;
     if (p < n_pix) {
         const int q = s.inv[p];
@@ -337,11 +362,8 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaSrc s, unsigned n_pix
             if (src >= 0) v[k] = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
             else if (src <= -2) v[k] = s.bg[(long long)(-2 - src) * C1 + c];
         }
-        {  // streamed (non-temporal): the image is far larger than the L2s; 20.3 -> 17.2 us for the 17-channel image
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            v4f q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
-            __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(o + j0));
-        }
+        v4f q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(o + j0));
     }
     for (int j = n4 + threadIdx.x; j < nloc; j += 256) {
         const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
@@ -353,22 +375,12 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaSrc s, unsigned n_pix
     }
 }
 
-// C + 1 == 4: one 16-byte texel per thread
-__global__ __launch_bounds__(256) void ca_compose4_kernel(CaSrc s, unsigned n_pix, float4* __restrict__ out) {
-    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pix) return;
-    const int q = s.inv[p];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q >= 0) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
-    else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
-    __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out + p));  // streamed: the image is far larger than the L2s
-}
-
-__global__ __launch_bounds__(256) void ca_blend_kernel(CaSrc s, const AaRec* __restrict__ work, const int* __restrict__ count, int capacity, int W,
-                                                       float* __restrict__ out) {
+__global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const AaRec* __restrict__ work, const int* __restrict__ count,
+                                                       int capacity, int W) {
     __shared__ int s_off[AA_SHARDS + 1];
+    const CaJob& job = blockIdx.y ? jb : ja;
+    const CaSrc& s = job.s;
+    float* __restrict__ out = job.out;
     const int n = aa_segment_offsets(count, capacity, s_off);
     const unsigned C1 = (unsigned)s.C + 1u;
     const unsigned total = (unsigned)n * C1;  // (n <= capacity records, C1 <= 4096)
@@ -384,18 +396,22 @@ __global__ __launch_bounds__(256) void ca_blend_kernel(CaSrc s, const AaRec* __r
 }
 
 // g_vals[p, :C] = g_out[pix[p], :C] (the select's adjoint), 256 points per work-group (same index arithmetic as the compositor); the
-// first work-groups also zero g_clip
-__global__ __launch_bounds__(256) void ca_gather_kernel(const float* __restrict__ g_out, const long long* __restrict__ pix, long long P, int C,
-                                                        float* __restrict__ g_vals, float* __restrict__ zero, long long nz) {
+// first job's work-groups also zero g_clip
+__global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, const long long* __restrict__ pix, long long P,
+                                                        float* __restrict__ zero, long long nz) {
     __shared__ unsigned s_pix[256];
+    const CaJob& job = blockIdx.y ? jb : ja;
+    const int C = job.s.C;
+    const float* __restrict__ g_out = job.g_out;
     const long long base = (long long)blockIdx.x * 256, p = base + threadIdx.x;
     if (p < P) s_pix[threadIdx.x] = (unsigned)pix[p];
-    for (long long i = p; i < nz; i += (long long)gridDim.x * 256) zero[i] = 0.f;
+    if (blockIdx.y == 0)
+        for (long long i = p; i < nz; i += (long long)gridDim.x * 256) zero[i] = 0.f;
     __syncthreads();
     if (base >= P) return;
     const int nloc = (int)min(256ll, P - base) * C, C1 = C + 1;
     const float rc = 1.f / (float)C;
-    float* o = g_vals + base * C;
+    float* o = job.g_vals + base * C;
     for (int j = threadIdx.x; j < nloc; j += 256) {
         const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C;
         o[j] = g_out[(long long)s_pix[pl] * C1 + c];
@@ -403,11 +419,14 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(const float* __restrict_
 }
 
 // aa_bwd_kernel on the composited image: colours come from the sources, colour adjoints go to the point rows
-__global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ g_out, CaSrc s, const AaRec* __restrict__ work,
-                                                     const int* __restrict__ count, int capacity, const float4* __restrict__ clip, int clip_batch,
-                                                     const int* __restrict__ tri, int V, int H, int W, float* __restrict__ g_vals,
-                                                     float* __restrict__ g_clip) {
+__global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const AaRec* __restrict__ work, const int* __restrict__ count,
+                                                     int capacity, const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
+                                                     int V, int H, int W, float* __restrict__ g_clip) {
     __shared__ int s_off[AA_SHARDS + 1];
+    const CaJob& job = blockIdx.y ? jb : ja;
+    const CaSrc& s = job.s;
+    const float* __restrict__ g_out = job.g_out;
+    float* __restrict__ g_vals = job.g_vals;
     const int n = aa_segment_offsets(count, capacity, s_off);
     const float xh = 0.5f * W, yh = 0.5f * H;
     const int C = s.C, C1 = s.C + 1;
@@ -510,48 +529,56 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
     return A3D_OK;
 }
 
-extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const int32_t* inv, const float* bg_or_null, int bg_batch, const void* work,
-                                    const int32_t* count, int capacity, int B, int H, int W, float* out, a3d_stream_t stream) {
-    A3D_CHECK_ARG(inv && work && count && out && C > 0 && B > 0 && H > 0 && W > 0 && capacity > 0);
+static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* bg, int bg_batch, int H, int W, float* out, const float* g_out,
+                    float* g_vals) {
+    CaJob j;
+    j.s.vals = vals; j.s.inv = inv; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
+    j.out = out; j.g_out = g_out; j.g_vals = g_vals;
+    return j;
+}
+
+extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null,
+                                    int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, const void* work,
+                                    const int32_t* count, int capacity, int B, int H, int W, a3d_stream_t stream) {
+    A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
+    const bool two = out2_or_null != nullptr;
+    A3D_CHECK_ARG(!two || (C2 > 0 && C2 + 1 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B)));
     hipStream_t s = (hipStream_t)stream;
-    CaSrc src;
-    src.vals = vals; src.inv = inv; src.bg = bg_or_null; src.bg_shared = bg_batch == 1; src.C = C; src.hw = (unsigned)H * (unsigned)W;
-    const unsigned n_pix = (unsigned)B * src.hw;
-    if (C == 3 && (((uintptr_t)out | (uintptr_t)bg_or_null) & 15) == 0) {
-        hipLaunchKernelGGL(ca_compose4_kernel, dim3(a3d_div_up(n_pix, 256)), dim3(256), 0, s, src, n_pix, (float4*)out);
-    } else {
-        A3D_CHECK_ARG(C + 1 <= 4096);  // the float-multiply division of the kernel
-        hipLaunchKernelGGL(ca_compose_kernel, dim3(a3d_div_up(n_pix, 256)), dim3(256), 0, s, src, n_pix, out);
-    }
+    const CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
+    const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr) : ja;
+    const unsigned n_pix = (unsigned)B * ja.s.hw;
+    hipLaunchKernelGGL(ca_compose_kernel, dim3(a3d_div_up(n_pix, 256), two ? 2 : 1), dim3(256), 0, s, ja, jb, n_pix);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ca_blend_kernel, dim3(512), dim3(256), 0, s, src, (const AaRec*)work, count, capacity, W, out);
+    hipLaunchKernelGGL(ca_blend_kernel, dim3(512, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, W);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
-extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const int64_t* pix, int64_t P, const int32_t* inv,
-                                    const float* bg_or_null, int bg_batch, const void* work, const int32_t* count, int capacity, const float* clip,
-                                    int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_vals, float* g_clip,
-                                    a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_out && inv && work && count && clip && g_clip && C > 0 && B > 0 && V > 0 && H > 0 && W > 0 && P >= 0 && capacity > 0);
+extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
+                                    const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch,
+                                    float* g_vals2, const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count,
+                                    int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W,
+                                    float* g_clip, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && inv && work && count && clip && g_clip && C > 0 && C <= 4096 && B > 0 && V > 0 && H > 0 && W > 0 && P >= 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
     A3D_CHECK_ARG(P == 0 || (vals && pix && g_vals));
+    const bool two = g_out2_or_null != nullptr;
+    A3D_CHECK_ARG(!two || (C2 > 0 && C2 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B) && (P == 0 || (vals2 && g_vals2))));
     hipStream_t s = (hipStream_t)stream;
+    const CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, nullptr, g_out, g_vals);
+    const CaJob jb = two ? ca_job(vals2, C2, inv, bg2_or_null, bg2_batch, H, W, nullptr, g_out2_or_null, g_vals2) : ja;
     {
         const long long nz = 4ll * clip_batch * V;
         long long blocks = a3d_div_up((long long)P, 256);
         if (blocks < 64) blocks = 64;  // enough work-groups to zero g_clip when the point list is short
-        A3D_CHECK_ARG(C <= 4096);
-        hipLaunchKernelGGL(ca_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_out, (const long long*)pix, (long long)P, C, g_vals, g_clip, nz);
+        hipLaunchKernelGGL(ca_gather_kernel, dim3((unsigned)blocks, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const long long*)pix, (long long)P, g_clip, nz);
         A3D_LAUNCH_CHECK();
     }
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri);
-    CaSrc src;
-    src.vals = vals; src.inv = inv; src.bg = bg_or_null; src.bg_shared = bg_batch == 1; src.C = C; src.hw = (unsigned)H * (unsigned)W;
-    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024), dim3(256), 0, s, g_out, src, (const AaRec*)work, count, capacity, (const float4*)clip, clip_batch,
-                       tri, V, H, W, g_vals, g_clip);
+    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, (const float4*)clip,
+                       clip_batch, tri, V, H, W, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -338,22 +338,35 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
 
     analysis = None
     coverage = (rast[..., -1:] > 0).float()
+    # composite + antialias fused (csrc/antialias.hip): one pass over the image per buffer, same values as the two steps further down;
+    # the buffers go through the op two at a time (the colour and the feature image of a training step share its launches)
+    fused = {}
+    can_fuse = isinstance(rendered, SparseBuffers) and rendered.inv is not None and FUSED_COMPOSITE and not background.requires_grad
+    fuse_keys = [k for k in dict.fromkeys(render_modes) if can_fuse and k in rendered and k in ANTIALIASED_MODES]
+    if fuse_keys:
+        tri32 = ops.tri_int32(tri)
+        analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))
+
+        def bg_of(k):
+            if k not in ("shaded", "geo_normal", "shading"):
+                return None
+            return background[..., 2:] if (k == "shading" and background.shape[-1] == 4) else background
+
+        for i in range(0, len(fuse_keys), 2):
+            ka, kb = fuse_keys[i], (fuse_keys[i + 1] if i + 1 < len(fuse_keys) else None)
+            if kb is None:
+                fused[ka] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis)
+            else:
+                fused[ka], fused[kb] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
+                                                               vals2=rendered[kb], background2=bg_of(kb))
     out_buffers = []
     for key in render_modes:
         if key not in rendered:
             out_buffers.append(None)
             continue
-        fused_aa = (isinstance(rendered, SparseBuffers) and rendered.inv is not None and key in ANTIALIASED_MODES and FUSED_COMPOSITE
-                    and not background.requires_grad)
+        fused_aa = key in fused
         if fused_aa:
-            # composite + antialias in one pass over the image (csrc/antialias.hip): same values as the two steps below
-            if analysis is None:
-                tri32 = ops.tri_int32(tri)
-                analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))
-            bgk = None
-            if key in ("shaded", "geo_normal", "shading"):
-                bgk = background[..., 2:] if (key == "shading" and background.shape[-1] == 4) else background
-            accum = ops.composite_antialias(rendered[key], rendered.pix, rendered.inv, bgk, clip_f, analysis)
+            accum = fused[key]
         elif isinstance(rendered, SparseBuffers):
             # coverage is 0 or 1, for which lerp(bg, [rgb,1], alpha) (render.py:261-262) returns exactly bg or exactly [rgb,1]:
             # start from the background and overwrite the covered pixels -- same bits, a third of the passes over the image

@@ -726,44 +726,68 @@ class _Antialias(torch.autograd.Function):
 
 
 class _CompositeAntialias(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, vals, clip, pix, inv, bg, analysis):
-        require_device(vals, pix, inv, what="composite_antialias")
-        vals = f32c(vals)
-        a = analysis
-        P, C = vals.shape
-        assert pix.shape == (P,) and pix.dtype == torch.int64 and inv.shape == (a.B * a.H * a.W,) and inv.dtype == torch.int32
-        if bg is not None:
-            bg = f32c(bg)
-            assert bg.shape[1:] == (a.H, a.W, C + 1) and bg.shape[0] in (1, a.B)
-        out = torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=vals.device)
-        call("a3d_composite_aa_fwd", ptr(vals), C, ptr(inv), ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
-             a.B, a.H, a.W, ptr(out), stream(), tag=f"[C{C + 1}]")
-        ctx.save_for_backward(vals, pix, inv, bg)
-        ctx.analysis = a
-        return out
+    """One or two buffers (vals2 None = one) against the same pixel list and crossing records, in the same launches."""
 
     @staticmethod
-    def backward(ctx, g_out):
-        vals, pix, inv, bg = ctx.saved_tensors
+    def forward(ctx, vals, vals2, clip, pix, inv, bg, bg2, analysis):
+        require_device(vals, vals2, pix, inv, what="composite_antialias")
+        a = analysis
+        P = vals.shape[0]
+        assert pix.shape == (P,) and pix.dtype == torch.int64 and inv.shape == (a.B * a.H * a.W,) and inv.dtype == torch.int32
+
+        def prep(v, g):
+            if v is None:
+                return None, None, 0, None
+            v = f32c(v)
+            assert v.shape[0] == P
+            C = v.shape[1]
+            if g is not None:
+                g = f32c(g)
+                assert g.shape[1:] == (a.H, a.W, C + 1) and g.shape[0] in (1, a.B)
+            return v, g, C, torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=v.device)
+
+        vals, bg, C, out = prep(vals, bg)
+        vals2, bg2, C2, out2 = prep(vals2, bg2)
+        tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
+        call("a3d_composite_aa_fwd", ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
+             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W, stream(), tag=tag)
+        ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
+        ctx.analysis, ctx.tag = a, tag
+        if vals2 is None:
+            return out
+        return out, out2
+
+    @staticmethod
+    def backward(ctx, g_out, g_out2=None):
+        vals, vals2, pix, inv, bg, bg2 = ctx.saved_tensors
         a = ctx.analysis
         P, C = vals.shape
+        two = vals2 is not None
+        C2 = vals2.shape[1] if two else 0
+        if g_out is None:  # (an output nobody differentiated: zero gradient)
+            g_out = torch.zeros((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=vals.device)
+        if two and g_out2 is None:
+            g_out2 = torch.zeros((a.B, a.H, a.W, C2 + 1), dtype=torch.float32, device=vals.device)
         g_vals = torch.empty_like(vals)
+        g_vals2 = torch.empty_like(vals2) if two else None
         g_clip = torch.empty_like(a.clip)
-        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), ptr(vals), C, ptr(pix), P, ptr(inv), ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work),
-             ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W,
-             ptr(g_vals), ptr(g_clip), stream(), tag=f"[C{C + 1}]")
-        return g_vals, g_clip, None, None, None, None
+        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(g_vals),
+             ptr(f32c(g_out2)) if two else None, ptr(vals2), C2, ptr(bg2), 0 if bg2 is None else bg2.shape[0], ptr(g_vals2), ptr(pix), P, ptr(inv),
+             ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H,
+             a.W, ptr(g_clip), stream(), tag=ctx.tag)
+        return g_vals, g_vals2, g_clip, None, None, None, None, None
 
 
-def composite_antialias(vals, pix, inv, background, clip, analysis):
+def composite_antialias(vals, pix, inv, background, clip, analysis, vals2=None, background2=None):
     """antialias(lerp(background, [vals, 1], coverage)) for a buffer given as rows ``vals`` [P,C] at the covered pixels ``pix`` (``inv`` =
     the pixel -> row map of covered_pixels(return_inverse=True)): [B,H,W,C+1].  ``background`` [1|B,H,W,C+1] or None (zeros); it gets no
-    gradient (callers with a differentiable background composite with torch and call antialias)."""
+    gradient (callers with a differentiable background composite with torch and call antialias).  With ``vals2`` (and ``background2``) a
+    second buffer over the same pixels is composited and antialiased by the same launches: returns the pair of images."""
     assert background is None or not background.requires_grad
+    assert background2 is None or not background2.requires_grad
     if clip.dim() == 2:
         clip = clip[None]
-    return _CompositeAntialias.apply(vals, clip, pix, inv, background, analysis)
+    return _CompositeAntialias.apply(vals, vals2, clip, pix, inv, background, background2, analysis)
 
 
 def antialias(color, rast, clip, tri, analysis=None):

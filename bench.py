@@ -53,6 +53,9 @@ def algorithmic_bytes(name, d):
     rendered per step (images x frames), V / F = surface vertices / faces, P = covered pixels, K = bones.
     """
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
+    if "+C" in name:  # two buffers in one call of the compositor: [C17+C4] = the sum of the single-buffer figures
+        base, tags = name.split("[")[0], name.split("[")[1].rstrip("]").split("+")
+        return sum(algorithmic_bytes(f"{base}[{t}]", d) for t in tags)
     C = int(name.split("[C")[1].split("]")[0]) if "[C" in name else 0
     Bn = int(name.split("[B")[1].split("]")[0]) if "[B" in name else B  # batch tag of the normals calls (prior mesh: 1)
     base = name.split("[")[0]

@@ -245,13 +245,17 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
  * by dr.antialias (render.py:311-315) for a buffer that exists as rows vals[P,C] at the covered pixels (pix / inv of a3d_cover_emit):
  *   out[B,H,W,C+1] = [vals row, 1] at covered pixels, bg[bg_batch,H,W,C+1] (null = zeros) elsewhere, then the blends of a3d_aa_fwd
  *   computed from the same sources.  One pass over the image instead of fill + scatter + copy + blend.
- * bwd: g_vals[P,C] (fully written: g_out at the covered pixels + the blend adjoints; no dense colour gradient exists) and
- *   g_clip[clip_batch,V,4] (zeroed by callee).  The background receives no gradient. */
-int a3d_composite_aa_fwd(const float* vals, int C, const int32_t* inv, const float* bg_or_null, int bg_batch, const void* work,
-                         const int32_t* count, int capacity, int B, int H, int W, float* out, a3d_stream_t stream);
-int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const int64_t* pix, int64_t P, const int32_t* inv,
-                         const float* bg_or_null, int bg_batch, const void* work, const int32_t* count, int capacity, const float* clip,
-                         int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_vals, float* g_clip,
+ * A second buffer (vals2 / C2 / bg2 / out2; null = none) against the same pixel list and crossing records rides in the same launches
+ * (render_mesh antialiases the colour and the feature image of a step).
+ * bwd: g_vals[P,C] (fully written: g_out at the covered pixels + the blend adjoints; no dense colour gradient exists) -- likewise
+ *   g_vals2 -- and g_clip[clip_batch,V,4] (zeroed by callee; both buffers add to it).  The backgrounds receive no gradient. */
+int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null, int C2,
+                         const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, const void* work,
+                         const int32_t* count, int capacity, int B, int H, int W, a3d_stream_t stream);
+int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
+                         const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch, float* g_vals2,
+                         const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count, int capacity,
+                         const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_clip,
                          a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1169,6 +1169,42 @@ def test_shade_points_per_image_rows_equal_per_point_rows(light, P, B, dev, ops)
         assert float(g_i[1][1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("Ca,Cb,hw", [(3, 16, (64, 64)), (16, 3, (48, 40)), (2, 1, (50, 70))])
+def test_composite_antialias_two_buffers_in_one_call(Ca, Cb, hw, dev, ops):
+    """Two buffers over the same pixel list through the same launches against two single-buffer calls: values, both row gradients
+    and the summed vertex gradient; one output left undifferentiated must behave as a zero gradient."""
+    B, (H, W) = 3, hw
+    _, faces, clip, _ = _scene(B, seed=7)
+    clip, tri = clip.to(dev).requires_grad_(True), faces.to(dev)
+    rast = ops.rasterize(clip.detach(), tri, (H, W))
+    pix, inv = ops.covered_pixels(rast, return_inverse=True)
+    P = pix.shape[0]
+    g = torch.Generator().manual_seed(Ca * 10 + Cb)
+    va = torch.rand(P, Ca, generator=g).to(dev).requires_grad_(True)
+    vb = torch.rand(P, Cb, generator=g).to(dev).requires_grad_(True)
+    bga = torch.rand(B, H, W, Ca + 1, generator=g).to(dev)
+    ga, gb = torch.randn(B, H, W, Ca + 1, generator=g).to(dev), torch.randn(B, H, W, Cb + 1, generator=g).to(dev)
+    analysis = ops.AAAnalysis(rast, clip.detach(), ops.aa_topology(ops.tri_int32(tri), clip.shape[1]))
+
+    oa, ob = ops.composite_antialias(va, pix, inv, bga, clip, analysis, vals2=vb, background2=None)
+    sa = ops.composite_antialias(va, pix, inv, bga, clip, analysis)
+    sb = ops.composite_antialias(vb, pix, inv, None, clip, analysis)
+    torch.testing.assert_close(oa, sa, atol=2e-6, rtol=0)
+    torch.testing.assert_close(ob, sb, atol=2e-6, rtol=0)
+    g2 = torch.autograd.grad((oa * ga).sum() + (ob * gb).sum(), (va, vb, clip))
+    g1 = torch.autograd.grad((sa * ga).sum() + (sb * gb).sum(), (va, vb, clip))
+    torch.testing.assert_close(g2[0], g1[0], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(g2[1], g1[1], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(g2[2], g1[2], atol=1e-4 * float(g1[2].abs().max()), rtol=1e-4)
+    # only the second output used
+    oa, ob = ops.composite_antialias(va, pix, inv, bga, clip, analysis, vals2=vb)
+    h2 = torch.autograd.grad((ob * gb).sum(), (va, vb, clip), allow_unused=True)
+    h1 = torch.autograd.grad((ops.composite_antialias(vb, pix, inv, None, clip, analysis) * gb).sum(), (vb, clip))
+    assert h2[0] is None or float(h2[0].abs().max()) == 0.0
+    torch.testing.assert_close(h2[1], h1[0], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(h2[2], h1[1], atol=1e-4 * float(h1[1].abs().max()), rtol=1e-4)
+
+
 def test_rows_add_relu_and_indexed_feature_field(dev, ops):
     """a3d_rows_add_relu_fwd/bwd against torch, and CoordMLP's per-image feature path (HIP add+ReLU, split-K weight gradient)
     against the reference formulation (feature concatenated per point) on the GPU."""

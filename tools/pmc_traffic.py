@@ -44,8 +44,8 @@ ENTRY = {
     "a3d_aa_analyze": (["aa_screen_kernel", "aa_analyze_kernel"], "aa_analyze_kernel"),
     "a3d_aa_fwd": (["aa_fwd_kernel"], "aa_fwd_kernel"),
     "a3d_aa_bwd": (["aa_copy_zero_kernel", "aa_bwd_kernel"], "aa_bwd_kernel"),
-    # (the 17- and 4-channel calls of a step are averaged here: the blend / gather / adjoint kernels are shared)
-    "a3d_composite_aa_fwd": (["ca_compose_kernel", "ca_compose4_kernel", "ca_blend_kernel"], "ca_blend_kernel"),
+    # (one call per step handles the 4- and the 17-channel buffer together)
+    "a3d_composite_aa_fwd": (["ca_compose_kernel", "ca_blend_kernel"], "ca_blend_kernel"),
     "a3d_composite_aa_bwd": (["ca_gather_kernel", "ca_bwd_kernel"], "ca_bwd_kernel"),
     "a3d_flow_loss_fwd": (["fl_fwd_kernel", "fl_finish_kernel"], "fl_fwd_kernel"),
     "a3d_flow_loss_bwd": (["fl_bwd_kernel"], "fl_bwd_kernel"),
