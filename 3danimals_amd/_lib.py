@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liba3d_hip.so")
 
 _c_int, _c_float, _c_size_t, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
-# name -> (restype, argtypes); must list every symbol declared in include/a3d.h (tests/test_host_cpu.py::test_abi_table_matches_header checks)
+# name -> (restype, argtypes); must list every symbol declared in include/a3d.h (tests/test_host_cpu.py::test_library_exports_every_declared_symbol checks)
 SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),

@@ -78,7 +78,7 @@ class _LinearSplitK(torch.autograd.Function):
     Forward and the input gradient are the GEMMs autograd would issue.  The weight gradient g^T x is a [N,M] x [M,K] product with
     a tiny output and a huge reduction: as ONE GEMM rocBLAS/hipBLASLt reach 65 TFLOP/s on gfx950 (409 us tuned, 606 us untuned at
     M=204800, N=K=256); cut into SPLITK_PARTS row blocks and issued as a batched GEMM + a sum of the partial products it takes
-    222 us (tools/scratch/wgrad_split.py).  Same sum, different association: equal to fp32 rounding (7e-6 relative).
+    222 us (a throw-away micro-benchmark, not kept).  Same sum, different association: equal to fp32 rounding (7e-6 relative).
     The backward is written with differentiable torch ops, so double backward (create_graph=True) still works.
     """
 
