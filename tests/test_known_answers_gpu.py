@@ -264,6 +264,54 @@ def test_antialias_gradients_closed_form_vertical_edge(dev, ops):
     assert abs(float(g[1, 1])) < 1e-4 * want1 and abs(float(g[2, 1])) < 1e-4 * want2
 
 
+@pytest.mark.parametrize("axis,frac", [("x", 0.3), ("y", 0.65)])
+def test_composite_antialias_known_answer_and_closed_form_gradients(axis, frac, dev, ops):
+    """The fused compositor on the straight-silhouette scene, from the definition alone.  Rows [c_in] at the covered pixels over a
+    background [c_bg, 0]: the crossing pixel k ends up with coverage ``frac`` in the alpha channel and frac*c_in + (1-frac)*c_bg in the
+    colour channel (whichever side of the pixel centre the edge lies on); d out[.., k] / d (row of the covered neighbour) = frac for
+    frac < 0.5 -- where pixel k is background -- and d out[.., k] / d (its own row) = frac for frac > 0.5; the colour channel's vertex
+    gradient is W/2 (or H/2) * (c_in - c_bg) * the vertex's interpolation weight summed over the rows (columns)."""
+    H = W = 16
+    k = 8
+    c_in, c_bg = 0.9, 0.2
+    pos, tri = _edge_scene(axis, k, frac, H, W)
+    p = pos.clone().to(dev).requires_grad_(True)
+    rast = ops.rasterize(p.detach(), tri.to(dev), (H, W))
+    pix, inv = ops.covered_pixels(rast, return_inverse=True)
+    vals = torch.full((pix.shape[0], 1), c_in, device=dev).requires_grad_(True)
+    bg = torch.zeros(1, H, W, 2, device=dev)
+    bg[..., 0] = c_bg
+    analysis = ops.AAAnalysis(rast, p.detach(), ops.aa_topology(ops.tri_int32(tri.to(dev)), p.shape[1]))
+    out = ops.composite_antialias(vals, pix, inv, bg, p, analysis)  # [1,H,W,2]
+    o = out.detach().cpu()[0]
+    line = (lambda t, j: t[2:-2, j]) if axis == "x" else (lambda t, j: t[j, 2:-2])
+    np.testing.assert_allclose(line(o[..., 1], k).numpy(), frac, atol=1e-5)  # coverage
+    np.testing.assert_allclose(line(o[..., 0], k).numpy(), frac * c_in + (1 - frac) * c_bg, atol=1e-5)
+    np.testing.assert_allclose(line(o[..., 1], k - 1).numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(line(o[..., 0], k + 1).numpy(), c_bg, atol=1e-6)
+    # gradients of the colour channel summed along the crossing line
+    sel = out[0, :, k, 0] if axis == "x" else out[0, k, :, 0]
+    gv, gp = torch.autograd.grad(sel.sum(), (vals, p))
+    dense = torch.zeros(H * W, device=dev).index_copy(0, pix, gv[:, 0]).view(H, W).cpu()
+    src = k - 1 if frac < 0.5 else k  # the covered pixel whose row feeds pixel k's colour
+    np.testing.assert_allclose(line(dense, src).numpy(), frac, atol=1e-5)
+    zeroed = dense.clone()
+    if axis == "x":
+        zeroed[:, src] = 0
+    else:
+        zeroed[src, :] = 0
+    assert float(zeroed.abs().max()) == 0
+    n = H if axis == "x" else W
+    ys = (torch.arange(n, dtype=torch.float64) + 0.5) * 2 / n - 1
+    t2 = (ys + 3) / 6  # weight of edge vertex 2 (at +3 along the edge) at each row / column; vertex 1 (at -3) has 1 - t2
+    half = (W if axis == "x" else H) / 2
+    want1, want2 = half * (c_in - c_bg) * float((1 - t2).sum()), half * (c_in - c_bg) * float(t2.sum())
+    g = gp.cpu()[0]
+    comp = 0 if axis == "x" else 1
+    np.testing.assert_allclose(sorted([abs(float(g[1, comp])), abs(float(g[2, comp]))]), sorted([want1, want2]), rtol=1e-4)
+    assert float(g[0].abs().max()) == 0 and float(g[3].abs().max()) == 0  # the far vertices do not move the silhouette
+
+
 # ------------------------------------------------------------------------------------------------ depth peeling, pixel differentials
 def test_depth_peeling_layers_known_answer(dev, ops):
     """Three stacked quads: layer 0 sees the nearest, layer 1 the middle one, layer 2 the farthest, layer 3 nothing; pixels the
