@@ -4,7 +4,9 @@
     python tools/microbench.py [--batch 16] [--grid-res 64] [--iters 50]
 
 Builds the SyntheticScene, runs one step to obtain realistic inputs (mesh, clip positions, rast ...), then times
-each op in isolation with HIP events (median over --iters), printing microseconds and algorithmic GB/s.
+each op in isolation with HIP events (median over --iters), printing microseconds and algorithmic GB/s.  The backward rows go through
+torch.autograd.grad, whose host-side dispatch (~100 us) is longer than the kernels: run it under `rocprofv3 --kernel-trace --stats` for
+kernel times (e.g. rs_bwd_kernel 39 us, ip_bwd_kernel 52 us, gb_bwd_kernel 21 us), or see bench.py's per-entry-point events.
 """
 import argparse
 import importlib
