@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     const long long i = pix[p];
     const float4 r = rast[i];
     const int f = (int)r.w - 1;
-    float* o = out + p * 12;
+    float4* o4 = reinterpret_cast<float4*>(out + p * 12);  // rows are 48 bytes: three aligned 16-byte stores
+    float o[12];
     if (f < 0 || f >= F) {
-#pragma unroll
-        for (int c = 0; c < 12; ++c) o[c] = 0.f;
+        o4[0] = o4[1] = o4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (extra)
             for (int c = 0; c < E; ++c) extra_out[p * E + c] = 0.f;
         return;
@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     o[9] = u * ax + v * bx + w * cx;
     o[10] = u * ay + v * by + w * cy;
     o[11] = u * az + v * bz + w * cz;
+    o4[0] = make_float4(o[0], o[1], o[2], o[3]);
+    o4[1] = make_float4(o[4], o[5], o[6], o[7]);
+    o4[2] = make_float4(o[8], o[9], o[10], o[11]);
     if (extra) {  // one more per-vertex attribute (the sequence models' 2-D motion, render.py:281-288), E <= 3 channels
         const float* eb = extra + b * V * E;
         for (int c = 0; c < E; ++c) extra_out[p * E + c] = u * eb[(long long)i0 * E + c] + v * eb[(long long)i1 * E + c] + w * eb[(long long)i2 * E + c];

@@ -44,7 +44,10 @@ struct ShFwd {
 
 __device__ __forceinline__ ShFwd sh_forward(const float* __restrict__ gbp, const float* __restrict__ pr, int ncol, int two_sided) {
     ShFwd f;
-    const V3 pos = ld3(gbp), geo = ld3(gbp + 3), a = ld3(gbp + 6), view = ld3(pr + 9);
+    // (the 48-byte G-buffer row as three aligned 16-byte loads; the canonical-position columns 9..11 are not needed here)
+    const float4 g0 = reinterpret_cast<const float4*>(gbp)[0], g1 = reinterpret_cast<const float4*>(gbp)[1],
+                 g2 = reinterpret_cast<const float4*>(gbp)[2];
+    const V3 pos = {g0.x, g0.y, g0.z}, geo = {g0.w, g1.x, g1.y}, a = {g1.z, g1.w, g2.x}, view = ld3(pr + 9);
     f.n1 = normalize_f(a, &f.len1);
     f.n2 = normalize_f(f.n1, &f.len2);
     f.v = normalize_f(view - pos, &f.lenv);
@@ -147,11 +150,11 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
         const V3 g_n1 = normalize_b(g_n2, f.n2, f.len2);
         const V3 g_a = normalize_b(g_n1, f.n1, f.len1);
         const V3 g_d = normalize_b(g_v, f.v, f.lenv);  // d = view - pos
-        float* go = g_gb + 12 * p;
-        st3(go, g_d * -1.f);
-        st3(go + 3, g_g * f.sigma);
-        st3(go + 6, g_a);
-        st3(go + 9, V3{0.f, 0.f, 0.f});
+        float4* go = reinterpret_cast<float4*>(g_gb + 12 * p);
+        const V3 gg = g_g * f.sigma;
+        go[0] = make_float4(-g_d.x, -g_d.y, -g_d.z, gg.x);
+        go[1] = make_float4(gg.y, gg.z, g_a.x, g_a.y);
+        go[2] = make_float4(g_a.z, 0.f, 0.f, 0.f);
         gp[9] = g_d.x; gp[10] = g_d.y; gp[11] = g_d.z;
     }
     if (!img) {
