@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
                                                      long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                      const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
                                                      float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                     float* __restrict__ extra_out) {
+                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the backward's gradient rows cleared here, while this launch is waiting for its gathers anyway (saves the backward its memset)
+    for (long long z = p; z < n_zero4; z += (long long)gridDim.x * blockDim.x) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p >= P) return;
     const long long i = pix[p];
     const float4 r = rast[i];
@@ -367,14 +369,20 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 
 extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                                const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null,
-                               int E, float* extra_out_or_null, a3d_stream_t stream) {
+                               int E, float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || P == 0)));  // (an empty list has no output storage)
-    if (P == 0) return A3D_OK;
+    A3D_CHECK_ARG(!g_rows_to_clear_or_null || ((uintptr_t)g_rows_to_clear_or_null & 63) == 0);
+    const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * (GB_ROW / 4) : 0;
+    if (P == 0) {
+        if (n_zero4) A3D_HIP(hipMemsetAsync(g_rows_to_clear_or_null, 0, sizeof(float4) * (size_t)n_zero4, (hipStream_t)stream));
+        return A3D_OK;
+    }
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
-                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null);
+                       (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null,
+                       (float4*)g_rows_to_clear_or_null, n_zero4);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -394,15 +402,15 @@ static void gb_launch_bwd(bool big, hipStream_t s, const float* g_out, const flo
 
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                                const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
-                               float* g_rows, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null,
-                               a3d_stream_t stream) {
+                               float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E,
+                               const float* g_extra_out_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(g_rows && ((uintptr_t)g_rows & 63) == 0);
     A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (g_extra_out_or_null || P == 0)));
     hipStream_t s = (hipStream_t)stream;
-    A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
+    if (!g_rows_are_clear) A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior);
     // covered pixels per triangle of the call (all triangles, visible or not): below ~0.6 most pixels own their three vertices

@@ -502,9 +502,14 @@ class _GBuffer(torch.autograd.Function):
             E = extra.shape[2]
             assert extra.shape[:2] == (B, V) and 1 <= E <= 3
             extra_out = torch.empty((P, E), dtype=torch.float32, device=rast.device)
+        # when a backward will follow, its gradient rows (one 64-byte row per (image, vertex), see backward) are allocated now and
+        # cleared by the forward launch: one memset less on the backward path
+        needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
+        rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device) if needs_grad else None
         call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-             ptr(out), ptr(extra), E, ptr(extra_out), stream())
+             ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
         ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
+        ctx.rows = rows
         if extra is None:
             return out
         return out, extra_out
@@ -520,9 +525,12 @@ class _GBuffer(torch.autograd.Function):
             g_extra_out = torch.zeros((P, E), dtype=torch.float32, device=rast.device)
         # one 64-byte gradient row per (image, vertex): the kernel's atomics of a vertex are then one line request; the gradients are
         # strided views of the rows (a3d.h: v_pos 0..2 | v_nrm 3..5 | canonical 6..8 | extra 9..11 | clip 12..15)
-        rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
+        rows, ctx.rows = ctx.rows, None  # the rows the forward cleared serve ONE backward (their views are handed out as gradients)
+        clear = rows is not None
+        if rows is None:
+            rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
-             ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(want_prior), ptr(extra), E,
+             ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(clear), int(want_prior), ptr(extra), E,
              None if extra is None else ptr(f32c(g_extra_out)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None

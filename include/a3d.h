@@ -200,10 +200,13 @@ int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* a
 #define A3D_GBUFFER_GRAD_COLS 16
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                     const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null, int E,
-                    float* extra_out_or_null, a3d_stream_t stream);
+                    float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream);
+/* g_rows_to_clear (forward, optional): the backward's g_rows buffer, cleared by the forward launch; the backward is then called with
+ * g_rows_are_clear = 1 and skips its memset (a caller that runs the backward twice clears the second time itself: flag 0). */
 int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                     const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
-                    float* g_rows, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null, a3d_stream_t stream);
+                    float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null,
+                    a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of
