@@ -79,8 +79,9 @@ __device__ __forceinline__ ShFwd sh_forward(const float* __restrict__ gbp, const
 __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ gb, const float* __restrict__ par, int ncol,
                                                      const long long* __restrict__ img, const float* __restrict__ kd, int kd_stride,
                                                      long long P, int two_sided, float* __restrict__ nrm, float* __restrict__ shading,
-                                                     float* __restrict__ shaded) {
+                                                     float* __restrict__ shaded, float* __restrict__ clear, int n_clear) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_clear) clear[p] = 0.f;  // the backward's per-image row gradient (accumulated there with atomics): one memset less
     if (p >= P) return;
     const ShFwd f = sh_forward(gb + 12 * p, par + (long long)ncol * (img ? img[p] : p), ncol, two_sided);
     st3(nrm + 3 * p, f.N);
@@ -191,23 +192,27 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
 }  // namespace
 
 extern "C" int a3d_shade_fwd(const float* gb, const float* par, int ncol, const int64_t* img_or_null, const float* kd, int kd_stride, int64_t P,
-                             int two_sided, float* nrm, float* shading, float* shaded, a3d_stream_t stream) {
-    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17));
-    if (P == 0) return A3D_OK;
+                             int two_sided, float* nrm, float* shading, float* shaded, float* g_par_to_clear_or_null, int B,
+                             a3d_stream_t stream) {
+    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17) && (!g_par_to_clear_or_null || (B > 0 && (long long)B * ncol <= P + 256)));
+    if (P == 0) {
+        if (g_par_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_par_to_clear_or_null, 0, sizeof(float) * (size_t)B * ncol, (hipStream_t)stream));
+        return A3D_OK;
+    }
     A3D_CHECK_ARG(gb && par && nrm);
     A3D_CHECK_ARG(ncol == 12 || (kd && kd_stride >= 3 && shading && shaded));
     hipLaunchKernelGGL(sh_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, gb, par, ncol, (const long long*)img_or_null, kd,
-                       kd_stride, (long long)P, two_sided, nrm, shading, shaded);
+                       kd_stride, (long long)P, two_sided, nrm, shading, shaded, g_par_to_clear_or_null, g_par_to_clear_or_null ? B * ncol : 0);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
                              const int64_t* img_or_null, int B, const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par,
-                             float* g_kd, a3d_stream_t stream) {
+                             float* g_kd, int g_par_is_clear, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17) && g_par && (!img_or_null || B > 0));
     hipStream_t s = (hipStream_t)stream;
-    if (img_or_null) A3D_HIP(hipMemsetAsync(g_par, 0, sizeof(float) * (size_t)B * ncol, s));
+    if (img_or_null && !g_par_is_clear) A3D_HIP(hipMemsetAsync(g_par, 0, sizeof(float) * (size_t)B * ncol, s));
     if (P == 0) return A3D_OK;
     A3D_CHECK_ARG(gb && par && g_gb);
     A3D_CHECK_ARG(ncol == 12 || (kd && kd_stride >= 3 && g_kd));

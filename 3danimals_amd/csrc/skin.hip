@@ -43,10 +43,13 @@ __device__ __forceinline__ float sk_logit(const SkBone& b, float px, float py, f
 template <int KMAX>
 __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restrict__ v, int v_batch, const float* __restrict__ bones,
                                                             int bones_batch, const float* __restrict__ T, int V, int K,
-                                                            float neg_inv_temp, float* __restrict__ out, float* __restrict__ weights) {
+                                                            float neg_inv_temp, float* __restrict__ out, float* __restrict__ weights,
+                                                            float* __restrict__ clear, int n_clear) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     const int b = blockIdx.y;
+    // the backward's per-image transform gradient (accumulated there with atomics) cleared here: one memset less on the backward path
+    for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; z < n_clear; z += gridDim.x * gridDim.y * blockDim.x) clear[z] = 0.f;
     sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,28 +200,29 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
 }
 
 extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B, int V, int K,
-                            float temperature, float* out, float* weights_or_null, a3d_stream_t stream) {
+                            float temperature, float* out, float* weights_or_null, float* g_T_to_clear_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(v && bones && T && out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     const dim3 grid(a3d_div_up(V, SK_THREADS), B), block(SK_THREADS);
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
-    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
-    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
-    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null);
+    const int ncl = g_T_to_clear_or_null ? B * K * 12 : 0;
+    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
+    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
+    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B,
-                            int V, int K, float temperature, float* g_v_or_null, float* g_T, a3d_stream_t stream) {
+                            int V, int K, float temperature, float* g_v_or_null, float* g_T, int g_T_is_clear, a3d_stream_t stream) {
     A3D_CHECK_ARG(g_out && v && bones && T && g_T);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
-    A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
+    if (!g_T_is_clear) A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
     // one 256-vertex chunk per block while that already gives >= 1024 blocks; more chunks per block for very large meshes
     const int chunks = a3d_div_up(V, SK_THREADS);
     int cpb = a3d_div_up((long long)chunks * B, 4096);

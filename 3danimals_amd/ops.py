@@ -232,8 +232,11 @@ class _Skin(torch.autograd.Function):
         V = v.shape[1]
         assert v.shape[0] in (1, B) and bones.shape[0] in (1, B) and bones.shape[1] == K and T.shape[2] == 12
         out = torch.empty((B, V, 3), dtype=torch.float32, device=v.device)
-        call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, float(temperature), ptr(out), None, stream())
+        # the backward accumulates g_T with atomics: allocated now and cleared by the forward launch when a backward can follow
+        g_T = torch.empty_like(T) if ctx.needs_input_grad[2] else None
+        call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, float(temperature), ptr(out), None, ptr(g_T), stream())
         ctx.save_for_backward(v, bones, T)
+        ctx.g_T = g_T
         ctx.temperature = float(temperature)
         return out
 
@@ -242,9 +245,12 @@ class _Skin(torch.autograd.Function):
         v, bones, T = ctx.saved_tensors
         B, K, V = T.shape[0], T.shape[1], v.shape[1]
         g_v = torch.empty((B, V, 3), dtype=torch.float32, device=v.device) if ctx.needs_input_grad[0] else None
-        g_T = torch.empty_like(T)
+        g_T, ctx.g_T = ctx.g_T, None  # the cleared buffer serves ONE backward (it is handed out as the gradient)
+        clear = g_T is not None
+        if g_T is None:
+            g_T = torch.empty_like(T)
         call("a3d_skin_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, ctx.temperature, ptr(g_v),
-             ptr(g_T), stream())
+             ptr(g_T), int(clear), stream())
         if g_v is not None and v.shape[0] == 1 and B > 1:
             g_v = g_v.sum(0, keepdim=True)  # shared canonical mesh: per-image partials, reduced here (no 16-way atomic contention)
         return g_v, None, g_T, None
@@ -264,7 +270,7 @@ def skin_weights(v, bones, B, temperature):
     T = torch.zeros((Bw, K, 12), dtype=torch.float32, device=v.device)
     out = torch.empty((Bw, V, 3), dtype=torch.float32, device=v.device)
     w = torch.empty((K, Bw, V), dtype=torch.float32, device=v.device)
-    call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), Bw, V, K, float(temperature), ptr(out), ptr(w), stream())
+    call("a3d_skin_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), Bw, V, K, float(temperature), ptr(out), ptr(w), None, stream())
     return w
 
 
@@ -575,8 +581,12 @@ class _ShadePoints(torch.autograd.Function):
             kd_stride = kd.stride(0)
             shading = torch.empty((P, 1), dtype=torch.float32, device=gb.device)
             shaded = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
-        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded), stream())
+        # per-image rows: their gradient is accumulated by the backward with atomics -- allocated now, cleared by the forward launch
+        g_par = torch.empty_like(par) if (img is not None and ctx.needs_input_grad[1]) else None
+        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded),
+             ptr(g_par), par.shape[0], stream())
         ctx.save_for_backward(gb, par, kd, img)
+        ctx.g_par = g_par
         ctx.two_sided, ctx.kd_stride = int(two_sided), kd_stride
         if kd is None:
             return nrm
@@ -586,11 +596,15 @@ class _ShadePoints(torch.autograd.Function):
     def backward(ctx, g_nrm, g_shading=None, g_shaded=None):
         gb, par, kd, img = ctx.saved_tensors
         P, ncol = gb.shape[0], par.shape[1]
-        g_gb, g_par = torch.empty_like(gb), torch.empty_like(par)
+        g_gb = torch.empty_like(gb)
+        g_par, ctx.g_par = ctx.g_par, None  # (cleared by the forward launch; serves one backward)
+        clear = g_par is not None
+        if g_par is None:
+            g_par = torch.empty_like(par)
         g_kd = torch.empty((P, 3), dtype=torch.float32, device=gb.device) if kd is not None else None
         opt = lambda t: None if t is None else f32c(t)
         call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(img), par.shape[0], ptr(kd),
-             ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), stream())
+             ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), int(clear), stream())
         return g_gb, g_par, g_kd, None, None
 
 

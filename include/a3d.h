@@ -76,9 +76,12 @@ int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, cons
  * through the affine maps only (weights are detached, skinning.py:377) and g_T[B,K,12] (zeroed by callee).
  */
 int a3d_skin_fwd(const float* v, int v_batch, const float* bones /*[Bb,K,2,3]*/, int bones_batch, const float* T, int B, int V,
-                 int K, float temperature, float* out /*[B,V,3]*/, float* weights_or_null, a3d_stream_t stream);
+                 int K, float temperature, float* out /*[B,V,3]*/, float* weights_or_null, float* g_T_to_clear_or_null,
+                 a3d_stream_t stream);
 int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B,
-                 int V, int K, float temperature, float* g_v_or_null, float* g_T, a3d_stream_t stream);
+                 int V, int K, float temperature, float* g_v_or_null, float* g_T, int g_T_is_clear, a3d_stream_t stream);
+/* (g_T_to_clear: the backward's g_T buffer, cleared by the forward launch; the backward then takes g_T_is_clear = 1 and skips its memset.
+ * The same pair exists for a3d_shade_fwd / _bwd (g_par) and a3d_gbuffer_fwd / _bwd (g_rows).) */
 
 /* ------------------------------------------------------------------------------------------------
  * Per-bone world transforms from the kinematic chain -- replaces the chain-composition loops of skinning(),
@@ -120,10 +123,10 @@ int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apar
  * (= zero); writes g_gb[P,12] (canonical-position columns zero), g_par, g_kd[P,3] (contiguous).
  */
 int a3d_shade_fwd(const float* gb, const float* par, int ncol, const int64_t* img_or_null, const float* kd, int kd_stride, int64_t P,
-                  int two_sided, float* nrm, float* shading, float* shaded, a3d_stream_t stream);
+                  int two_sided, float* nrm, float* shading, float* shaded, float* g_par_to_clear_or_null, int B, a3d_stream_t stream);
 int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
                   const int64_t* img_or_null, int B, const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par,
-                  float* g_kd, a3d_stream_t stream);
+                  float* g_kd, int g_par_is_clear, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Covered-pixel list: flat indices (b*H + y)*W + x of the pixels with rast.w > 0 (triangle_id + 1, as dr.rasterize returns it),
