@@ -204,9 +204,11 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              int n1, float* __restrict__ verts, int* __restrict__ vert_edge,
                                                              long long* __restrict__ faces, long long* __restrict__ uv_idx, int nbt,
                                                              unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
-                                                             long long* __restrict__ surf_idx) {
+                                                             long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
+    for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
     if ((int)blockIdx.x >= nbe + nbt) {
         dm_surface_vertices_chunk((int)blockIdx.x - nbe - nbt, vbits, vchunk, Nv, surf_idx, s_pre);
         return;
@@ -369,13 +371,18 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
 
 extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                              void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, a3d_stream_t stream) {
+                              void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
+                              a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && n_surf >= 0 && (n_surf == 0 || surf_idx_or_null)));
-    if (V == 0) return A3D_OK;  // no crossing edge, hence no surface tet and no flagged vertex
+    A3D_CHECK_ARG(!g_sdf_to_clear_or_null || Nv > 0);
+    if (V == 0) {  // no crossing edge, hence no surface tet and no flagged vertex
+        if (g_sdf_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_sdf_to_clear_or_null, 0, sizeof(float) * (size_t)Nv, (hipStream_t)stream));
+        return A3D_OK;
+    }
     DmScratch d;
     dm_split_scratch((void*)scratch, Ne, Nt, &d);
     unsigned* vbits = (unsigned*)vertex_scratch_or_null;
@@ -383,16 +390,17 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     const int nbt = (n1 + n2) > 0 ? d.nbt : 0;
     hipLaunchKernelGGL(dm_emit_kernel, dim3(d.nbe + nbt + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
-                       (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null);
+                       (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
+                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
-                             int V, int Nv, float* g_pos_or_null, float* g_sdf, a3d_stream_t stream) {
+                             int V, int Nv, float* g_pos_or_null, float* g_sdf, int g_sdf_is_clear, a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && g_sdf && Nv > 0 && V >= 0);
     hipStream_t s = (hipStream_t)stream;
-    A3D_HIP(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)Nv, s));
+    if (!g_sdf_is_clear) A3D_HIP(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)Nv, s));
     if (g_pos_or_null) A3D_HIP(hipMemsetAsync(g_pos_or_null, 0, sizeof(float) * 3 * (size_t)Nv, s));
     if (V > 0) {
         A3D_CHECK_ARG(g_verts && vert_edge);

@@ -304,7 +304,7 @@ class DMTetGeometry(torch.nn.Module):
             sdf0 = self.get_sdf(pos, total_iter=total_iter, feats=feats)
         # idx = the grid vertices at the ends of crossing edges, sorted and unique; their count arrives with the DMTet counts (the
         # mask + torch.nonzero this replaces was a second host synchronisation per step)
-        verts0, faces, uv_idx, vert_edge, idx = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True)
+        verts0, faces, uv_idx, vert_edge, idx = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True, for_backward=True)
         pts = pos[idx]
         n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0
         if n_pad:  # pad (zeros, sliced off again) so the MLP's GEMM shapes repeat from step to step

@@ -57,6 +57,11 @@ class _IdentityCache:
         self.data.move_to_end(k)
         return hit[1]
 
+    def take(self, t):
+        """peek + remove (None when absent)."""
+        hit = self.data.pop(self.key(t), None)
+        return None if hit is None else hit[1]
+
 
 _tri32_cache = _IdentityCache()
 _topo_cache = _IdentityCache()
@@ -122,12 +127,15 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
 
 # ---------------------------------------------------------------------------------------------- DMTet
 _dm_vertex_scratch = {}
+_dm_grad_buffers = _IdentityCache(maxsize=2)  # vert_edge of an extraction -> its cleared SDF gradient buffer
 
 
-def dmtet_extract(pos, sdf, grid, surface_vertices=False):
+def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V]).
     ``surface_vertices``: also the sorted int64 list of the grid vertices at the ends of sign-crossing edges (their count rides in the
-    same read-back as V, n1, n2: no torch.nonzero, no second host synchronisation)."""
+    same read-back as V, n1, n2: no torch.nonzero, no second host synchronisation).
+    ``for_backward``: a dmtet_verts(...) on this extraction will be differentiated -- its dense SDF gradient buffer is allocated now and
+    cleared by the emit launch (picked up by dmtet_verts through the returned vert_edge tensor)."""
     require_device(pos, sdf, grid.edges32, what="dmtet")
     pos_c, sdf_c = f32c(pos.detach()), f32c(sdf.detach()).reshape(-1)
     Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
@@ -151,8 +159,11 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False):
     faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
     idx = torch.empty((n_surf,), dtype=torch.int64, device=dev) if surface_vertices else None
+    g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
     call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
-         ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), stream())
+         ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), stream())
+    if g_sdf is not None:
+        _dm_grad_buffers.put(vert_edge, g_sdf)
     if not surface_vertices:
         return verts, faces, uv_idx, vert_edge
     if len(_dm_vertex_scratch) >= 4:
@@ -169,16 +180,20 @@ class _DMTetVerts(torch.autograd.Function):
         pos_c, sdf_c = f32c(pos), f32c(sdf).reshape(-1)
         ctx.save_for_backward(pos_c, sdf_c, vert_edge)
         ctx.grid, ctx.sdf_shape = grid, sdf.shape
+        ctx.g_sdf = _dm_grad_buffers.take(vert_edge)  # cleared by the emit launch of dmtet_extract(for_backward=True), or None
         return verts0.clone()
 
     @staticmethod
     def backward(ctx, g_verts):
         pos_c, sdf_c, vert_edge = ctx.saved_tensors
         Nv, V = pos_c.shape[0], vert_edge.shape[0]
-        g_sdf = torch.empty_like(sdf_c)
+        g_sdf, ctx.g_sdf = ctx.g_sdf, None  # serves ONE backward
+        clear = g_sdf is not None and g_sdf.shape[0] == Nv
+        if not clear:
+            g_sdf = torch.empty_like(sdf_c)
         g_pos = torch.empty_like(pos_c) if ctx.needs_input_grad[0] else None
         g = f32c(g_verts) if V > 0 else None
-        call("a3d_dmtet_bwd", ptr(g), ptr(pos_c), ptr(sdf_c), ptr(ctx.grid.edges32), ptr(vert_edge), V, Nv, ptr(g_pos), ptr(g_sdf), stream())
+        call("a3d_dmtet_bwd", ptr(g), ptr(pos_c), ptr(sdf_c), ptr(ctx.grid.edges32), ptr(vert_edge), V, Nv, ptr(g_pos), ptr(g_sdf), int(clear), stream())
         return g_pos, g_sdf.reshape(ctx.sdf_shape), None, None, None
 
 

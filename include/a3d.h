@@ -55,7 +55,8 @@ int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets,
                     int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream);
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                   void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, a3d_stream_t stream);
+                   void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
+                   a3d_stream_t stream);
 /* Optional, for callers that evaluate the SDF network with a graph only where the surface's gradient can reach (DMTetGeometry.
  * _get_mesh_surface_backward): with vertex_scratch (a3d_dmtet_vertex_scratch_bytes(Nv) bytes, 16-byte aligned) a3d_dmtet_count also
  * flags the grid vertices at the ends of crossing edges and returns their number in counts[3] -- the same read-back as V, n1, n2 --
@@ -64,7 +65,8 @@ int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, con
  * saves its memset.  Replaces a mask + torch.nonzero and its own host synchronisation. */
 size_t a3d_dmtet_vertex_scratch_bytes(int Nv);
 int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
-                  int V, int Nv, float* g_pos_or_null, float* g_sdf, a3d_stream_t stream);
+                  int V, int Nv, float* g_pos_or_null, float* g_sdf, int g_sdf_is_clear,
+                  a3d_stream_t stream); /* (g_sdf_to_clear of a3d_dmtet_emit + g_sdf_is_clear = 1: the emit launch cleared the buffer) */
 
 /* ------------------------------------------------------------------------------------------------
  * Linear-blend skinning -- replaces the per-vertex part of skinning(),
