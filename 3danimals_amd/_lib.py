@@ -33,7 +33,7 @@ SIGNATURES = {
     "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
@@ -59,7 +59,7 @@ SIGNATURES = {
     "a3d_aa_shards": (_c_int, []),
     "a3d_aa_capacity": (_c_int, [_c_int, _c_int, _c_int]),
     "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
-    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
+    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p]),

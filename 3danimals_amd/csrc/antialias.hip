@@ -476,7 +476,7 @@ extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int
 }
 
 extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
-                              int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, a3d_stream_t stream) {
+                              int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared, a3d_stream_t stream) {
     A3D_CHECK_ARG(rast && clip && screen && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
@@ -489,9 +489,11 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     A3D_CHECK_ARG(tri && opp);
     const long long nvert = (long long)clip_batch * V;
     A3D_CHECK_ARG(B <= 65535);
-    hipLaunchKernelGGL(aa_screen_kernel, dim3(a3d_div_up(nvert > AA_SHARDS ? nvert : AA_SHARDS, 256)), dim3(256), 0, s, (const float4*)clip, nvert,
-                       0.5f * W, 0.5f * H, (float2*)screen, count);
-    A3D_LAUNCH_CHECK();
+    if (!prepared) {  // (prepared: a3d_rast_fwd of the same clip filled `screen` and zeroed `count` in its own launch)
+        hipLaunchKernelGGL(aa_screen_kernel, dim3(a3d_div_up(nvert > AA_SHARDS ? nvert : AA_SHARDS, 256)), dim3(256), 0, s, (const float4*)clip, nvert,
+                           0.5f * W, 0.5f * H, (float2*)screen, count);
+        A3D_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, (const float4*)rast, (const float2*)screen,
                        clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count);
     A3D_LAUNCH_CHECK();

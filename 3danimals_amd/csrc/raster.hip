@@ -104,8 +104,20 @@ __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, 
 
 // 4 lanes per (image, triangle); blockDim = 256 = 64 triangles
 __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
-                                                     int H, int W, unsigned long long* __restrict__ keys, const float4* __restrict__ prev) {
+                                                     int H, int W, unsigned long long* __restrict__ keys, const float4* __restrict__ prev,
+                                                     int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards) {
     const int b = blockIdx.y;
+    if ((int)blockIdx.x >= nb_tri) {
+        // extra work-groups: what the silhouette analysis of this frame needs first -- pixel-space vertex positions, once per (image,
+        // vertex), with the operations of antialias.hip's aa_screen_kernel (p.x / p.w * W/2, unfused), and its append counters at zero
+        if (b == 0 && (int)blockIdx.x == nb_tri && (int)threadIdx.x < aa_shards) aa_count[threadIdx.x] = 0;
+        if (clip_batch == 1 && b > 0) return;
+        const int i = ((int)blockIdx.x - nb_tri) * 256 + threadIdx.x;
+        if (i >= V) return;
+        const float4 p = clip[(clip_batch == 1 ? 0ll : (long long)b * V) + i];
+        aa_screen[(long long)b * V + i] = make_float2(p.x / p.w * (0.5f * W), p.y / p.w * (0.5f * H));
+        return;
+    }
     const int f = blockIdx.x * 64 + (threadIdx.x >> 2);
     const int sub = threadIdx.x & 3, lane = threadIdx.x & 63;
     const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
@@ -241,7 +253,7 @@ extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(un
 
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                             void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                            a3d_stream_t stream) {
+                            float* aa_screen_or_null, int32_t* aa_count_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
@@ -257,7 +269,11 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     }
     unsigned long long* keys = (unsigned long long*)scratch;
     if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
-    hipLaunchKernelGGL(rs_tri_kernel, dim3(a3d_div_up(F, 64), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W, keys, (const float4*)prev_rast_or_null);
+    A3D_CHECK_ARG((aa_screen_or_null == nullptr) == (aa_count_or_null == nullptr) && a3d_aa_shards() <= 256);
+    const int nb_tri = a3d_div_up(F, 64);
+    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + (aa_screen_or_null ? a3d_div_up(V, 256) : 0), B), dim3(256), 0, s, (const float4*)clip, clip_batch,
+                       tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null,
+                       a3d_aa_shards());
     A3D_LAUNCH_CHECK();
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,

@@ -350,6 +350,7 @@ def vertex_normals(v, tri):
 
 # ---------------------------------------------------------------------------------------------- covered pixels
 _cover_counts = _IdentityCache(maxsize=2)  # raster buffer -> block counts of its covered-pixel list
+_aa_prepared = _IdentityCache(maxsize=2)  # raster buffer -> (key of its clip tensor, screen positions, zeroed counters)
 
 
 def covered_pixels(rast, tile=8, return_inverse=False):
@@ -399,9 +400,18 @@ class _Rasterize(torch.autograd.Function):
         cover = None
         if H % 8 == 0 and W % 8 == 0 and (H * W) % 256 == 0 and F > 0:
             cover = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover), stream())
+        # ... and so does what the silhouette analysis of this frame needs first (pixel-space vertex positions, zeroed append counters):
+        # AAAnalysis picks them up when it is built for this raster buffer and this clip tensor
+        aa_screen = aa_count = None
+        if F > 0 and prev is None:
+            aa_screen = torch.empty((clip.shape[0], V, 2), dtype=torch.float32, device=clip.device)
+            aa_count = torch.empty((_lib.lib().a3d_aa_shards(),), dtype=torch.int32, device=clip.device)
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
+             ptr(aa_screen), ptr(aa_count), stream())
         if cover is not None:
             _cover_counts.put(rast, cover)
+        if aa_screen is not None:
+            _aa_prepared.put(rast, (_IdentityCache.key(clip), aa_screen, aa_count))
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
         _rast_keys[key] = scratch  # only after a successful call (a failed one leaves the buffer out of the cache)
@@ -730,10 +740,15 @@ class AAAnalysis:
         self.capacity = _lib.lib().a3d_aa_capacity(B, H, W)
         dev = rast.device
         self.work = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
-        self.count = torch.empty((shards,), dtype=torch.int32, device=dev)
-        screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
+        prep = _aa_prepared.take(self.rast)  # (one analysis per prepared pair: the counters are consumed)
+        prepared = prep is not None and prep[0] == _IdentityCache.key(self.clip)
+        if prepared:
+            screen, self.count = prep[1], prep[2]
+        else:
+            self.count = torch.empty((shards,), dtype=torch.int32, device=dev)
+            screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
         call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), B, self.clip.shape[1],
-             topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), stream())
+             topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), int(prepared), stream())
 
 
 class _Antialias(torch.autograd.Function):

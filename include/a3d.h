@@ -158,11 +158,13 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * per pixel the nearest fragment strictly behind the previous layer's (depth, id) is returned, empty pixels stay empty.
  * cover_scratch != NULL (H, W multiples of 8, H*W a multiple of 256): the resolve also leaves the covered-pixel list's block counts
  * (a3d_cover_scratch_bytes) there, for a3d_cover_count(counted = 1).
+ * aa_screen / aa_count != NULL: extra work-groups of the triangle launch fill a3d_aa_analyze's `screen` [clip_batch,V,2] and zero its
+ * `count` [a3d_aa_shards()], for a3d_aa_analyze(prepared = 1) on the same clip.
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                a3d_stream_t stream);
+                 float* aa_screen_or_null, int32_t* aa_count_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 
@@ -243,7 +245,8 @@ int a3d_aa_shards(void);
 int a3d_aa_capacity(int B, int H, int W);
 int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
 int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
-                   int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, a3d_stream_t stream);
+                   int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared,
+                   a3d_stream_t stream);
 int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
                a3d_stream_t stream);
 int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,

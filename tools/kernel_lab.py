@@ -59,7 +59,7 @@ def main():
     elif what == "rast_fwd":
         out = torch.empty(B, H, W, 4, device=dev)
         scratch = torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
-        fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), 0, None, None, stream())
+        fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), 0, None, None, None, None, stream())
     elif what == "aa_analyze":
         topo = ops.aa_topology(tri32, V)
         cap = L.lib().a3d_aa_capacity(B, H, W)
@@ -67,7 +67,7 @@ def main():
         count = torch.empty(L.lib().a3d_aa_shards(), dtype=torch.int32, device=dev)
         screen = torch.empty(B, V, 2, device=dev)
         fn = lambda: L.call("a3d_aa_analyze", ptr(rast), ptr(clip), B, ptr(tri32), ptr(topo.opp), B, V, F, H, W, ptr(screen), ptr(work),
-                            cap, ptr(count), stream())
+                            cap, ptr(count), 0, stream())
     else:
         raise SystemExit("unknown entry point")
     for k in knobs:
