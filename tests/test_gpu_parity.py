@@ -498,6 +498,36 @@ def test_render_mesh_with_nothing_on_screen(dev, mods):
     assert g is None or float(g.abs().max()) == 0.0
 
 
+def test_backward_twice_with_retain_graph_gives_the_same_gradients(dev, mods, ops):
+    """The G-buffer, skinning, shading and DMTet-vertex backwards accumulate into buffers that their forward launch cleared; those
+    serve one backward.  A second backward through the same graph (retain_graph) takes the memset path: same gradients."""
+    B, H, W = 2, 48, 48
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=13)
+    tri = faces.to(dev)
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+    v = (verts[None] + 0.02 * seeded((B, *verts.shape), 51, -1, 1)).to(dev).requires_grad_(True)
+    K = 4
+    bones = seeded((1, K, 2, 3), 52, -0.4, 0.4).to(dev)
+    T = (torch.eye(3, 4).reshape(1, 1, 12).repeat(B, K, 1) + 0.01 * seeded((B, K, 12), 53, -1, 1)).to(dev).requires_grad_(True)
+    posed = ops.skin(v, bones, T, 0.05)
+    nrm = ops.vertex_normals(posed, tri)
+    clip = ru.xfm_points(posed, mvp.to(dev))
+    rast = ops.rasterize(clip, tri, (H, W))
+    pix = ops.covered_pixels(rast)
+    gb = ops.gbuffer(clip, posed, nrm, verts[None].to(dev), rast, tri, pix)
+    img = torch.div(pix, H * W, rounding_mode="floor")
+    par = torch.cat((w2c.to(dev)[:, :3, :3].reshape(B, 9), campos.to(dev).reshape(B, 3), seeded((B, 5), 54, 0.1, 1.0).to(dev)), -1).requires_grad_(True)
+    kd = seeded((pix.shape[0], 3), 55, 0, 1).to(dev)
+    n_s, shading, shaded = ops.shade_points(gb, par, kd, True, img=img)
+    loss = (shaded * seeded(tuple(shaded.shape), 56, -1, 1).to(dev)).sum() + (n_s * seeded(tuple(n_s.shape), 57, -1, 1).to(dev)).sum()
+    g1 = torch.autograd.grad(loss, (v, T, par), retain_graph=True)
+    g2 = torch.autograd.grad(loss, (v, T, par))
+    for a, b_, name in zip(g1, g2, ("v", "T", "par")):
+        scale = float(a.abs().max())
+        assert scale > 0, name
+        torch.testing.assert_close(a, b_, atol=2e-5 * scale, rtol=1e-4, msg=name)  # float atomics: order only
+
+
 def test_full_step_against_oracle_and_grads_finite(dev):
     """One fwd+bwd step of the synthetic training scene; every stage re-done by the oracle from the same numbers."""
     from oracle import check
