@@ -17,7 +17,7 @@
 #include "a3d_common.h"
 #include "topo_common.h"
 
-#define AA_SHARDS 64  // segments of the crossing work list (wave size: one wave scans their fill counts)
+#define AA_SHARDS 256  // segments of the crossing work list (the consumers' work-group size: one thread per segment scans the fill counts)
 
 struct AaRec {
     int pix0;     // flat index (b*H + y)*W + x of the pair's first pixel
@@ -159,15 +159,21 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
 // consumers: exclusive prefix of the segment fills into LDS (call with all threads of the block), then record r -> its slot
 __device__ __forceinline__ int aa_segment_offsets(const int* __restrict__ count, int capacity, int* s_off) {
     const int seg_cap = capacity / AA_SHARDS;
-    if (threadIdx.x < AA_SHARDS) {
-        const int c = min(count[threadIdx.x], seg_cap);
+    __shared__ int s_wsum[AA_SHARDS / 64];
+    {   // (blockDim.x == 256 == AA_SHARDS in every consumer)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int c = (int)threadIdx.x < AA_SHARDS ? min(count[threadIdx.x], seg_cap) : 0;
         int incl = c;
 #pragma unroll
-        for (int d = 1; d < AA_SHARDS; d <<= 1) {
+        for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(incl, d, 64);
-            if ((int)threadIdx.x >= d) incl += o;
+            if (lane >= d) incl += o;
         }
-        s_off[threadIdx.x + 1] = incl;
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        if ((int)threadIdx.x < AA_SHARDS) s_off[threadIdx.x + 1] = before + incl;
         if (threadIdx.x == 0) s_off[0] = 0;
     }
     __syncthreads();
@@ -177,7 +183,7 @@ __device__ __forceinline__ int aa_segment_offsets(const int* __restrict__ count,
 __device__ __forceinline__ long long aa_record_slot(int r, const int* s_off, int capacity) {
     int lo = 0, hi = AA_SHARDS;  // largest seg with s_off[seg] <= r
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 8; ++it) {
         const int mid = (lo + hi) >> 1;
         if (s_off[mid] <= r) lo = mid; else hi = mid;
     }
