@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ g
                                                      long long P, int two_sided, float* __restrict__ nrm, float* __restrict__ shading,
                                                      float* __restrict__ shaded, float* __restrict__ clear, int n_clear) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n_clear) clear[p] = 0.f;  // the backward's per-image row gradient (accumulated there with atomics): one memset less
+    // the backward's per-image row gradient (accumulated there with atomics): one memset less.  Grid-stride: B*ncol may exceed the
+    // launch's thread count when only a few pixels are covered
+    for (long long i = p; i < n_clear; i += (long long)gridDim.x * blockDim.x) clear[i] = 0.f;
     if (p >= P) return;
     const ShFwd f = sh_forward(gb + 12 * p, par + (long long)ncol * (img ? img[p] : p), ncol, two_sided);
     st3(nrm + 3 * p, f.N);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
 extern "C" int a3d_shade_fwd(const float* gb, const float* par, int ncol, const int64_t* img_or_null, const float* kd, int kd_stride, int64_t P,
                              int two_sided, float* nrm, float* shading, float* shaded, float* g_par_to_clear_or_null, int B,
                              a3d_stream_t stream) {
-    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17) && (!g_par_to_clear_or_null || (B > 0 && (long long)B * ncol <= P + 256)));
+    A3D_CHECK_ARG(P >= 0 && (ncol == 12 || ncol == 17) && (!g_par_to_clear_or_null || B > 0));
     if (P == 0) {
         if (g_par_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_par_to_clear_or_null, 0, sizeof(float) * (size_t)B * ncol, (hipStream_t)stream));
         return A3D_OK;

@@ -30,6 +30,7 @@ FUSED_COMPOSITE = True  # sparse buffers: composite + antialias as one op (ops.c
 SHADE_COVERED_ONLY = True  # evaluate the texture / DINO MLPs on rasterised pixels only (output-identical; see shade())
 POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple of this (0 = off)
 LAST_RAST = [None]
+LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path handed from stage to stage in the last render_mesh call
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
@@ -209,6 +210,10 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
             shading = params[:, 3:4] + params[:, 4:5] * torch.clamp(util.dot(params[:, :3], cam_normal), min=0.0)
             shaded_col = shading * kd
 
+    if gb is not None:  # references only (no copies): the stage-wise checkers re-do every stage from the previous stage's HIP output
+        LAST_POINTS[0] = dict(pix=pix, gb=gb.detach(), all_tex=all_tex.detach() if material is not None else None,
+                              dino=None if dino_pred is None else dino_pred.detach(), per_image=per_image.detach(),
+                              flow=None if flow is None else flow.detach())
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
     out = SparseBuffers(pix, (b, h, w), inv)
@@ -325,6 +330,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
                                    render_modes, prior_mesh, two_sided_shading, dino_net, class_vector, delta_xy)
     rast = ops.rasterize(clip_f, tri, full_res)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
+    LAST_POINTS[0] = None
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
                             prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
                             class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
@@ -359,6 +365,8 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
             else:
                 fused[ka], fused[kb] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
                                                                vals2=rendered[kb], background2=bg_of(kb))
+    if LAST_POINTS[0] is not None:
+        LAST_POINTS[0]["clip"] = clip_f.detach()
     out_buffers = []
     for key in render_modes:
         if key not in rendered:

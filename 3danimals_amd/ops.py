@@ -119,7 +119,8 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
     call("a3d_mesh_topology", ptr(tri32), V, F, ptr(adj.off), ptr(adj.adj), ptr(cursor), ptr(scratch), ptr(topo.opp), int(clean), stream())
     if len(_topology_scratch) >= 4:
         _topology_scratch.clear()
-    _topology_scratch[key] = (cursor, scratch)  # only after a completed call
+    if F > 0 or clean:  # only after a completed call whose last launch re-armed it (F == 0 launches nothing that touches the hash: a fresh,
+        _topology_scratch[key] = (cursor, scratch)  # never initialised buffer must not be handed to the next call as clean)
     _adj_cache.put(tri32, adj)
     _topo_cache.put(tri32, topo)
     return adj, topo
@@ -363,12 +364,14 @@ def covered_pixels(rast, tile=8, return_inverse=False):
     if tile != 8 or H % 8 or W % 8:
         tile = 0
     dev = rast.device
-    scratch = _cover_counts.peek(rast) if tile == 8 else None  # block counts left by the rasteriser's resolve (same launch)
+    # block counts left by the rasteriser's resolve (same launch).  CONSUMED: the scan below turns them into offsets in place, so a second
+    # list of the same buffer counts again
+    scratch = _cover_counts.take(rast) if tile == 8 else None
     counted = scratch is not None
     if not counted:
         scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     total = torch.empty(1, dtype=torch.int64, device=dev)
-    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), int(counted), ptr(total), stream())
+    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), int(counted), ptr(total), stream(), tag="[scan]" if counted else "")
     pix = torch.empty(int(total.item()), dtype=torch.int64, device=dev)
     inv = torch.empty(B * H * W, dtype=torch.int32, device=dev) if return_inverse else None
     if pix.shape[0] or return_inverse:
@@ -409,12 +412,14 @@ class _Rasterize(torch.autograd.Function):
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
              ptr(aa_screen), ptr(aa_count), stream())
         if cover is not None:
-            _cover_counts.put(rast, cover)
+            _cover_counts.put(rast.detach(), cover)  # keyed on a detached alias: the entry must not pin this iteration's autograd graph
         if aa_screen is not None:
-            _aa_prepared.put(rast, (_IdentityCache.key(clip), aa_screen, aa_count))
+            # (the clip tensor rides in the entry so that its address cannot be recycled while the entry can still match)
+            _aa_prepared.put(rast.detach(), (_IdentityCache.key(clip), aa_screen, aa_count, clip.detach()))
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
-        _rast_keys[key] = scratch  # only after a successful call (a failed one leaves the buffer out of the cache)
+        if F > 0 or clean:  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching them: a fresh
+            _rast_keys[key] = scratch  # torch.empty buffer must not come back as "clean"; a failed call leaves the buffer out too)
         ctx.save_for_backward(clip, tri32, rast)
         return rast
 

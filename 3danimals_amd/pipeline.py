@@ -101,9 +101,10 @@ class SyntheticScene(torch.nn.Module):
 
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
                  embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None,
-                 workload="magicpony", num_frames=1, deform=False):
+                 workload="magicpony", num_frames=1, deform=False, pose_seed=0):
         """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
-        data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter."""
+        data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter.
+        ``pose_seed`` != 0 draws other cameras / articulations with the SAME networks (per-rank poses: unequal covered-pixel counts)."""
         super().__init__()
         assert workload in WORKLOADS, workload
         assert num_frames == 1 or workload == "ponymation"
@@ -141,12 +142,12 @@ class SyntheticScene(torch.nn.Module):
         B, F, (H, W) = batch, self.num_frames, self.resolution
         N = B * F  # rendered frames per iteration
         self.frames = N
-        mvp, w2c, campos = synthetic.random_cameras(N, seed=seed + 1)
+        mvp, w2c, campos = synthetic.random_cameras(N, seed=seed + 1 + 7919 * pose_seed)
         self.mvp = mvp.to(dev).requires_grad_(True)
         self.w2c = w2c.to(dev).requires_grad_(True)
         self.campos = campos.to(dev).requires_grad_(True)
         self.feat = torch.randn(N, feat_dim, generator=torch.Generator().manual_seed(data_seed + 2)).to(dev).requires_grad_(True)
-        self.arti = synthetic.seeded((B, F, 20, 3), seed + 3, -0.25, 0.25).to(dev).requires_grad_(True)
+        self.arti = synthetic.seeded((B, F, 20, 3), seed + 3 + 7919 * pose_seed, -0.25, 0.25).to(dev).requires_grad_(True)
         self.class_emb = None
         if workload == "fauna":  # the memory bank's batch embedding (BasePredictorBank.py:98-102)
             self.class_emb = (0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 6))).to(dev).requires_grad_(True)
@@ -162,7 +163,7 @@ class SyntheticScene(torch.nn.Module):
         self.flow_gt = (0.05 * torch.randn(B, max(F - 1, 1), 2, H, W, generator=g)).to(dev) if F > 1 else None
         self.background = torch.zeros(N, H, W, 3, device=dev)
         with torch.no_grad():  # mask of the same animal under a perturbed articulation, + its distance transforms
-            arti0 = synthetic.seeded((B, F, 20, 3), seed + 5, -0.25, 0.25).to(dev)
+            arti0 = synthetic.seeded((B, F, 20, 3), seed + 5 + 7919 * pose_seed, -0.25, 0.25).to(dev)
             mask = self.forward_render(arti0, prior=prior, modes=["shaded"], with_nets=False)[0][:, 3]
             self.mask_gt = (mask > 0.5).float()
             self.mask_dt = _distance_transforms(self.mask_gt).to(dev)
@@ -201,7 +202,7 @@ class SyntheticScene(torch.nn.Module):
                                       self.netLight if with_nets else None, self.resolution, background=self.background, bsdf="diffuse",
                                       feat=self.feat if with_nets else None, render_modes=list(modes), prior_mesh=prior,
                                       dino_net=self.netDINO if with_nets else None, num_frames=F)
-        self.last["rast"] = render_mod.LAST_RAST[0]
+        self.last["rast"], self.last["points"] = render_mod.LAST_RAST[0], render_mod.LAST_POINTS[0]
         return out
 
     def random_view_mask(self, shape, prior):
@@ -220,6 +221,7 @@ class SyntheticScene(torch.nn.Module):
         self.last["random_view"] = dict(mvp=mvp, w2c=w2c, campos=campos, deg=deg)
         out = render_mod.render_mesh(None, shape, mvp, w2c, campos, None, None, self.resolution, background=None, bsdf="diffuse", feat=None,
                                       render_modes=["shaded"], prior_mesh=prior, dino_net=None, two_sided_shading=False, num_frames=self.num_frames)
+        self.last["random_view"].update(rast=render_mod.LAST_RAST[0], points=render_mod.LAST_POINTS[0])
         return out[0][:, 3:].clamp(0, 1)
 
     def losses(self, shaded, dino_pred):
@@ -280,6 +282,12 @@ class SyntheticScene(torch.nn.Module):
             parts["arti_reg"] = (self.arti ** 2).mean()
             parts["deform_reg"] = (self.last["deformation"] ** 2).mean()
             total = total + REG_WEIGHTS["arti_reg"] * parts["arti_reg"] + REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+        # prior surface-normal regulariser (AnimalModel.py:317-328): computed on EVERY iteration by the unchanged caller, weight 0 by
+        # default (AnimalModel.py:58) and then left out of the total (AnimalModel.py:493-494).  It reads prior_shape.v_nrm, i.e. it is
+        # what makes the prior mesh's normals pass run although nothing else on the training path looks at them.
+        parts["prior_normal_reg"] = prior_normal_regulariser(self.last["prior"])
+        if REG_WEIGHTS["prior_normal_reg"] > 0:
+            total = total + REG_WEIGHTS["prior_normal_reg"] * parts["prior_normal_reg"]
         if self.workload == "fauna":
             mask_random = self.random_view_mask(self.last["shape"], self.last["prior"])
             out["mask_random"] = mask_random
@@ -305,6 +313,15 @@ class SyntheticScene(torch.nn.Module):
             if optimizer_step:
                 self.optimizer.step()
         return out
+
+
+def prior_normal_regulariser(prior):
+    """R_normal of compute_regularizers (AnimalModel.py:317-328): 1 - <n_a, n_b> over the vertex pairs (0,1) and (1,2) of every face,
+    uniformly weighted (the reference overwrites its radial weights with ones, :326)."""
+    idx = prior.t_nrm_idx[0]
+    pairs = torch.cat([idx[:, 0:2], idx[:, 1:3]], dim=0)  # [2F,2]
+    nrm = prior.v_nrm[0][pairs]  # [2F,2,3]
+    return (1 - (nrm[:, 0] * nrm[:, 1]).sum(-1)).mean()
 
 
 def _distance_transforms(mask: torch.Tensor) -> torch.Tensor:

@@ -36,6 +36,42 @@ class RasterizeCudaContext(_Context):
         super().__init__(output_db=True, device=device)
 
 
+class _LazyRastDb:
+    """rast_db computed on first use.  The reference's render.py receives it from every rasterize call and discards it (render.py:24
+    passes rast_db=None), so the ~30 torch launches over [B,H,W,3,4] gathers are only paid by a caller that actually looks at it:
+    any torch function applied to the object, an attribute (.shape, .dtype ...) or an index materialises the tensor."""
+
+    def __init__(self, make):
+        self._make, self._value = make, None
+
+    def materialize(self):
+        if self._value is None:
+            self._value, self._make = self._make(), None
+        return self._value
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, index):
+        return self.materialize()[index]
+
+    def __len__(self):
+        return len(self.materialize())
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        unwrap = lambda a: a.materialize() if isinstance(a, _LazyRastDb) else a
+        args = tuple(type(a)(unwrap(x) for x in a) if isinstance(a, (list, tuple)) else unwrap(a) for a in args)
+        kwargs = {k: unwrap(v) for k, v in (kwargs or {}).items()}
+        return func(*args, **kwargs)
+
+
+def _rast_db(pos, tri, rast, grad_db):
+    if grad_db:
+        return _LazyRastDb(lambda: _ops.rasterize_db(pos, tri, rast))
+    return _LazyRastDb(lambda: _ops.rasterize_db(pos.detach(), tri, rast.detach()))
+
+
 def _check(pos, tri, resolution):
     if not (torch.is_tensor(pos) and torch.is_tensor(tri)):
         raise RuntimeError("pos and tri must be tensors")
@@ -49,12 +85,13 @@ def _check(pos, tri, resolution):
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)).  The image-space
-    derivatives are analytic (ops.rasterize_db, torch ops); no caller on the training path consumes them (render.py:24)."""
+    derivatives are analytic (ops.rasterize_db, torch ops) and computed on first use: no caller on the training path consumes them
+    (render.py:24)."""
     if ranges is not None:
         raise NotImplementedError("range mode")
     _check(pos, tri, resolution)
     rast = _ops.rasterize(pos, tri, resolution)
-    return rast, (_ops.rasterize_db(pos, tri, rast) if grad_db else _ops.rasterize_db(pos.detach(), tri, rast.detach()))
+    return rast, _rast_db(pos, tri, rast, grad_db)
 
 
 class DepthPeeler:
@@ -76,8 +113,7 @@ class DepthPeeler:
         rast = _ops.rasterize(self.pos, self.tri, self.resolution, prev=self._prev)
         self.layer += 1
         self._prev = rast.detach()
-        pos = self.pos if self.grad_db else self.pos.detach()
-        return rast, _ops.rasterize_db(pos, self.tri, rast if self.grad_db else rast.detach())
+        return rast, _rast_db(self.pos, self.tri, rast, self.grad_db)
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
@@ -86,6 +122,8 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     out = _ops.interpolate(attr, rast, tri)
     if rast_db is None or diff_attrs is None:
         return out, torch.empty(0, device=rast.device)
+    if isinstance(rast_db, _LazyRastDb):
+        rast_db = rast_db.materialize()
     return out, _ops.interpolate_da(attr, rast, tri, rast_db, diff_attrs)
 
 

@@ -37,7 +37,37 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+
+
+def kernel_source_sha16():
+    """sha256 over the HIP sources the library is built from (3danimals_amd/csrc/*.hip, *.h, in name order): what a PMC traffic file is
+    stamped with (tools/pmc_traffic.py), so that a file taken from other kernels is recognised as stale instead of being quoted."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "3danimals_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """(per-call traffic table or None, note, stale flag): the newest committed PMC file whose stamp equals the current kernel sources."""
+    import glob
+
+    files = sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True)
+    if not files:
+        return None, "no PMC traffic file under profiles/", False
+    sha = kernel_source_sha16()
+    for f in files:
+        rec = json.load(open(f))
+        if rec.get("kernel_source_sha16") == sha:
+            return rec["per_call"], ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as " + os.path.relpath(f, ROOT) +
+                                     f" (kernel sources {sha})"), False
+    return None, (f"stale: no PMC traffic file under profiles/ carries the stamp of the current kernel sources ({sha}); newest is "
+                  + os.path.relpath(files[0], ROOT) + " -- re-run tools/pmc_traffic.sh"), True
 
 # SURVEY.md section 8(a): what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
 # (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
@@ -87,7 +117,9 @@ def algorithmic_bytes(name, d):
         "a3d_harmonic_embed_bwd": Pp * (4 * 64 + 12 + 12),
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
         "a3d_recon_losses_bwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1 + 16 + 64),
-        "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer
+        # the id channel of the raster buffer -- or, for a buffer whose block counts the rasteriser's resolve left behind ([scan]), only
+        # those counts in and their offsets out
+        "a3d_cover_count": 8 * (B * HW // 256) if "[scan]" in name else 4 * B * HW,
         "a3d_cover_emit": 4 * B * HW + 8 * P + 4 * B * HW,  # id channel in; list + pixel -> entry map out
         # C = channels of the composited image (values + alpha): point rows in, image out (+ the crossing pixels); backward: image
         # gradient read at the covered pixels, point-row gradient out, vertex gradient out
@@ -121,12 +153,12 @@ def _aggregate(kernels, prefixes):
                 frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4), entry_point_calls_per_step=round(sum(v["launches_per_step"] for v in sel.values()), 1))
 
 
-def kernel_pass(scene, module, L, steps, world, dims_of):
+def kernel_pass(scene, module, L, steps, world, dims_of, train=True):
     """Per-entry-point timing of a few steps under HIP events (same workload, separate from the headline timing)."""
     # with DDP, rank 0 alone re-runs a few steps: that must not enqueue collectives the other ranks never join, hence no_sync()
     with L.KernelTimer() as timer, (module.no_sync() if module is not None else contextlib.nullcontext()):
         for _ in range(steps):
-            scene.step(module=module, optimizer_step=(world == 1))
+            scene.step(module=module, backward=train, optimizer_step=(train and world == 1))
     dims = dims_of(scene)
     kernels = {}
     for name, (count, mean_ms) in sorted(timer.summary().items()):
@@ -140,13 +172,11 @@ def kernel_pass(scene, module, L, steps, world, dims_of):
 def roofline_of(kernels, dims):
     scope = {k: v for k, v in kernels.items() if k.startswith(IN_SCOPE) and v["GBps"] is not None}
     dom = max(scope, key=lambda k: scope[k]["mean_us"] * scope[k]["launches_per_step"])  # most time per step among the in-scope entry points
-    traffic, traffic_note = None, "no PMC file for this round yet"
-    if os.path.exists(PMC_TRAFFIC_FILE):
-        rec = json.load(open(PMC_TRAFFIC_FILE))["per_call"].get(dom.split("[")[0])
-        traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
-        traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as " + os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+    table, traffic_note, stale = pmc_traffic()
+    rec = None if table is None else table.get(dom.split("[")[0])
+    traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
     roof = dict(kernel=dom, bound="hbm", achieved=scope[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(scope[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                traffic=traffic, traffic_source=traffic_note, launch_us=scope[dom]["mean_us"], launches_per_step=scope[dom]["launches_per_step"],
+                traffic=traffic, traffic_stale=stale, traffic_source=traffic_note, launch_us=scope[dom]["mean_us"], launches_per_step=scope[dom]["launches_per_step"],
                 algorithmic_bytes_per_launch=round(scope[dom]["algorithmic_MB"] * 1e6), in_scope=_aggregate(kernels, IN_SCOPE),
                 with_f3_losses=_aggregate(kernels, IN_SCOPE + F3), mesh=dims)
     # the best-fed streaming kernel of the path, for the other end of the picture
@@ -169,49 +199,106 @@ def roofline_of(kernels, dims):
 
 
 def parity_and_cpu_baseline(scene, args, threads):
-    """One HIP step (weights untouched) -> snapshot -> the CPU oracle on the first images of the SAME step: full-size parity figures,
-    and the oracle's wall clock as the CPU baseline (1 warm-up + median of ``--cpu-runs``)."""
-    from oracle import raster_ref, render_ref, step_ref
+    """One HIP step (weights untouched) -> (i) oracle/check.compare_step: STAGE-WISE parity at full size -- every stage re-done by the CPU
+    oracle from the HIP output of the stage before it, per output, with the pixel of the maximum -- plus the end-to-end figure through
+    the oracle's own chain; (ii) the CPU oracle's whole step on the first images of the SAME step, timed: the CPU baseline (1 warm-up +
+    median of ``--cpu-runs``), whose per-term losses are compared too."""
+    from oracle import check, step_ref
 
     torch.set_num_threads(threads)
-    out = scene.step(backward=True, optimizer_step=False)
+    out = scene.step(backward=not args.forward_only, optimizer_step=False)
     torch.cuda.synchronize()
     n = max(1, min(args.cpu_sample_images, scene.frames))
+    rep = check.compare_step(scene, out, n_images=n)
     st = step_ref.snapshot(scene, n)
     n = st["n"]
-    runs = [step_ref.cpu_step(st, backward=True) for _ in range(1 + args.cpu_runs)]
+    runs = [step_ref.cpu_step(st, backward=not args.forward_only) for _ in range(1 + args.cpu_runs)]
     res = runs[-1]
     secs = sorted(r["seconds"] for r in runs[1:])
     sec = secs[len(secs) // 2]
     cpu = lambda t: t.detach().float().cpu()
-    faces_equal = bool(torch.equal(res["faces"], scene.last["prior"].t_pos_idx[0].cpu()))
-    parity = dict(images=n, resolution=list(scene.resolution), faces_equal=faces_equal, num_faces=res["num_faces"])
-    if faces_equal:
-        # pixels whose owner differs between the two id buffers (the clip transform is a GPU matmul on one side, a CPU matmul on the
-        # other) and their antialiasing neighbours are excluded, and counted -- see oracle/check.py
-        clip = render_ref.xfm_points(res["posed"], st["mvp"]).contiguous()
-        rast_o = raster_ref.rasterize(clip, res["faces"].int(), scene.resolution)
-        flip = rast_o[..., 3] != cpu(scene.last["rast"])[:n, ..., 3]
-        keep = ~(torch.nn.functional.max_pool2d(flip.float()[:, None], 3, 1, 1)[:, 0] > 0)
-        err = 0.0
-        for name in ("shaded", "dino_pred", "flow"):
-            if name in res and name in out:
-                err = max(err, float(((cpu(out[name])[:n] - res[name]).abs() * keep[:, None]).max()))
-        parity.update(max_abs_image_err=err, frac_pixels_owner_flip=round(float(flip.float().mean()), 7),
-                      max_abs_vertex_err=float((res["verts"] - cpu(scene.last["prior"].v_pos[0])).abs().max()),
-                      max_abs_posed_vertex_err=float((res["posed"] - cpu(scene.last["shape"].v_pos)[:n]).abs().max()))
+    parity = dict(frames=n, resolution=list(scene.resolution), faces_equal=rep["faces_equal"], num_faces=rep["num_faces"])
+    if rep["faces_equal"]:
+        stage_keys = [k for k in rep if k.endswith(("clip", "raster", "gbuffer", "gbuffer_flow"))]
+        parity.update(
+            raster_ids_equal=rep["raster_ids_equal"], max_abs_image_err=rep["max_abs_image_err"], images=rep["images"],
+            stages=dict(dmtet_vertices=rep["max_abs_vert_err"], prior_normals=rep["max_abs_prior_normal_err"], skinning=rep["max_abs_skin_err"],
+                        posed_normals=rep["max_abs_posed_normal_err"], **{k: rep[k] for k in stage_keys}),
+            networks_cpu_vs_gpu=rep.get("fields"),
+            end_to_end=dict(max_abs_image_err=rep["max_abs_image_err_end_to_end"], images=rep["end_to_end"],
+                            frac_pixels_owner_flip=round(rep["frac_pixels_owner_flip"], 7)),
+            note="stage-wise: each stage re-done by the CPU oracle from the HIP output of the previous stage (identical inputs, no pixel excluded; the "
+                 "networks' GPU outputs injected, their own CPU-vs-GPU difference under networks_cpu_vs_gpu); end_to_end: the oracle's own chain "
+                 "from the SDF values on (its own skinning, clip matmul and CPU networks), owner-flipped pixels excluded and counted")
         rel = {}
         for k, v in res["losses"].items():
             if k in out["losses"] and v.dim() >= 1 and v.shape[0] in (n, st["nb"]):
                 a, b = float(cpu(out["losses"][k])[: v.shape[0]].mean()), float(v.mean())
                 rel[k] = round(abs(a - b) / max(abs(b), 1e-12), 7)
         parity["loss_rel_err"] = rel
-        parity["pass"] = bool(err < 1e-4 and parity["frac_pixels_owner_flip"] < 2e-3)
+    parity["pass"] = check.passes(rep)
     cpu_baseline = dict(value=round(n / sec, 4), unit="images/s", cores=threads, kind="port",
                         sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {scene.frames} frames of this workload ({scene.workload}: Kuhn R={args.grid_res} "
                                f"DMTet, LBS, {args.resolution}x{args.resolution} raster+shade+antialias, losses), 1 warm-up + median of {args.cpu_runs} runs, "
                                f"torch {threads} threads of {os.cpu_count()} logical cores, {sec:.1f} s per run")
     return parity, cpu_baseline
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run, one rank per GPU of this node
+    (what `accelerate launch --multi_gpu run.py` does for the reference, /root/reference/README.md:49-52).  Everything the ranks write to
+    stdout is passed on to stderr, except rank 0's JSON line, which is printed last -- the ONE line on stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for raw in proc.stdout:
+        text = raw.rstrip("\n")
+        cand = None
+        if text.startswith("{") and text.endswith("}"):
+            try:
+                cand = json.loads(text)
+            except ValueError:
+                cand = None
+        if isinstance(cand, dict) and "metric" in cand:
+            line = cand
+        else:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        line["launcher"] = "bench.py self-launch (torch.distributed.run, 127.0.0.1:%d)" % port
+        print(json.dumps(line), flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
+def dry_launch(args, rank, world):
+    """The launch / rendezvous / collect plumbing without any GPU work (tests: 2 gloo ranks on CPU)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    total = float(rank + 1)
+    if world > 1:
+        dist.init_process_group(args.backend)
+        t = torch.tensor([total], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.barrier()
+        dist.all_reduce(t)
+        total, ranks = float(t.item()), dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print("rank 0: stdout chatter before the line goes to stderr under self-launch", flush=True)
+        print(json.dumps({"metric": "train images/sec fwd+bwd @256x256 b16", "value": None, "unit": "images/s", "n_gpus": world, "dry_launch": True,
+                          "rccl_ranks": ranks, "backend": args.backend, "allreduce_sum": total, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    return 0
 
 
 def main():
@@ -232,15 +319,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (parity and cpu_baseline = null)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="do not load the shipped TunableOp results for the torch MLPs")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1] (test_magicpony_horse): forward passes under no_grad, no "
+                    "backward, no optimiser; combine with --batch 8")
     ap.add_argument("--cpu-sample-images", type=int, default=4)
     ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo "
+                    "only for the launch-plumbing tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (gloo only: exercises the N-rank path on a 1-GPU box)")
+    ap.add_argument("--dry-launch", action="store_true", help="launch plumbing only: rendezvous, barrier, one all-reduce, the JSON line; no GPU work")
+    ap.add_argument("--per-rank-poses", action="store_true", help="different poses / cameras per rank (unequal covered-pixel counts) instead of "
+                    "the equal-work default")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: spawn the ranks ourselves
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if args.dry_launch:
+        return dry_launch(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP hot path has no CPU fallback"
+    assert not args.share_gpu or args.backend == "gloo", "two RCCL ranks cannot share a device: --share-gpu needs --backend gloo"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pipeline = importlib.import_module("3danimals_amd.pipeline")
@@ -259,22 +362,29 @@ def main():
     def make_scene():
         return pipeline.SyntheticScene(grid_res=args.grid_res, batch=batch, resolution=(args.resolution, args.resolution), device=dev, seed=0,
                                        data_seed=1000 * rank, workload=args.workload, num_frames=frames,
-                                       deform=(args.workload == "magicpony" and not args.no_deform))
+                                       deform=(args.workload == "magicpony" and not args.no_deform),
+                                       pose_seed=(rank if args.per_rank_poses else 0))
 
     scene = make_scene()
     scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     # weak scaling = fixed work per GPU: every rank renders the same poses / cameras (hence the same number of covered pixels and
     # the same GEMM shapes) against its own image features and target images, so the all-reduced gradients differ per rank.
     module = None
     if world > 1:
         module = torch.nn.parallel.DistributedDataParallel(scene, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
+    train = not args.forward_only
+    if not train:
+        module = None  # forward only: nothing to all-reduce; the ranks are independent replicas
 
     # W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides, MAX over ranks
     du = importlib.import_module("3danimals_amd.dist_util")
-    elapsed = du.timed_steps(lambda: scene.step(module=module), args.steps, args.warmup, device=dev)
+    elapsed = du.timed_steps(lambda: scene.step(module=module, backward=train), args.steps, args.warmup, device=dev)
     images = world * scene.frames * args.steps
 
     def dims_of(sc):
@@ -287,7 +397,7 @@ def main():
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
     if rank == 0 and not args.no_kernel_timing:
-        kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of)
+        kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of, train)
         roofline = roofline_of(kernels, dims)
 
     # ---- blocking host <-> device synchronisations inside one steady-state step (torch's sync-debug hook; sizes that shapes depend on)
@@ -300,7 +410,7 @@ def main():
         try:
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
-                scene.step()
+                scene.step(backward=train)
         finally:
             torch.cuda.set_sync_debug_mode("default")
         sites = [str(w.message).split("(Triggered")[0].strip()[:80] + f" @ {os.path.basename(w.filename)}:{w.lineno}" for w in caught
@@ -321,7 +431,7 @@ def main():
         torch.cuda.tunable.enable(False)
         ref_scene = make_scene()
         ref_steps = max(3, min(args.steps, 10))
-        t = du.timed_steps(lambda: ref_scene.step(), ref_steps, 2, device=dev)
+        t = du.timed_steps(lambda: ref_scene.step(backward=train), ref_steps, 2, device=dev)
         dropin = dict(networks="reference formulation: per-point feature concatenation (MLPs.py:84-90), frequency table uploaded in every forward "
                                "(HarmonicEmbedding.py:41), one plain Linear per layer, no TunableOp table, no HIP field kernels; hot path unchanged",
                       value=round(ref_scene.frames * ref_steps / t, 3), unit="images/s", ms_per_step=round(t / ref_steps * 1e3, 3), steps=ref_steps)
@@ -354,6 +464,15 @@ def main():
                        cpu_threads=threads, hip_ms=round(hip_s * 1e3, 3), hip_images_per_s=round(16 / hip_s, 1),
                        note="estimate_bones (host logic with read-backs, once per epoch in training) is inside both timings")
 
+    # what every rank rendered (covered pixels decide the MLP work): gathered so the line shows the balance across ranks
+    covered = int((scene.last["rast"][..., 3] > 0).sum()) if "rast" in scene.last else 0
+    covered_per_rank, ranks = [covered], 1
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        t[rank] = covered
+        dist.all_reduce(t)
+        covered_per_rank, ranks = [int(v) for v in t.tolist()], dist.get_world_size()
+
     if rank == 0:
         what = {"magicpony": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+deformation+LBS(20 bones)+3x make_mesh+raster/interp/antialias "
                              "+ SDF/texture/DINO/light/deform MLPs + photometric/mask/DINO losses + regularisers, fwd+bwd+Adam" % args.grid_res,
@@ -362,7 +481,7 @@ def main():
                 "ponymation": "train_ponymation stage-2-like synthetic step with rendering: DMTet(Kuhn R=%d) + [B,F] LBS + B*F frames rendered with "
                               "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % args.grid_res}[args.workload]
         line = {
-            "metric": "train images/sec fwd+bwd @256x256 b16",
+            "metric": "train images/sec fwd+bwd @256x256 b16" if train else "test images/sec forward only @256x256 b8 (BASELINE configs[1])",
             "value": round(images / elapsed, 3),
             "unit": "images/s",
             "n_gpus": world,
@@ -371,13 +490,19 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
+            "rccl_ranks": ranks,
+            "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+            "covered_pixels_per_rank": covered_per_rank,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
                        "resolution": [args.resolution, args.resolution], "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}",
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
-                       "per_rank_data": "same poses/cameras on every rank (equal work per GPU), per-rank image features and targets"},
+                       "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)",
+                       "per_rank_data": ("per-rank poses/cameras, image features and targets (covered pixels differ per rank)" if args.per_rank_poses else
+                                         "same poses/cameras on every rank (equal work per GPU: covered-pixel imbalance across ranks is NOT in this "
+                                         "figure), per-rank image features and targets")},
             "roofline": roofline,
             "host_syncs": host_syncs,
             "parity": parity,

@@ -1,7 +1,23 @@
-"""Oracle-side checker for one SyntheticScene step (used by __graft_entry__.smoke() and tests).  TEST INFRASTRUCTURE ONLY.
+"""Oracle-side checker for one SyntheticScene step (used by __graft_entry__.smoke(), bench.py's parity leg and tests).
+TEST INFRASTRUCTURE ONLY.
 
-Recomputes, on CPU with the oracle, every stage of the step the HIP path just ran -- from the very same SDF values,
-bones, angles, cameras and network weights -- and reports the largest deviations.
+STAGE-WISE parity: every stage of the step the HIP path just ran is recomputed on CPU with the oracle **from the HIP output of the
+stage before it** -- the same SDF values, the same rest vertices, the same posed vertices, the same clip-space vertices, the same
+network outputs at the covered pixels -- so a figure names the stage responsible, and "identical inputs" (the wording of the 1e-4
+bar) holds literally: no pixel is excluded.  The networks (model/networks: SDF / texture / DINO / light MLPs) are NOT part of the
+path; their GPU outputs are injected into the oracle's renderer and their own CPU-vs-GPU fp32 difference is reported separately
+(``fields``), as is the END-TO-END figure (oracle chain from the SDF values on, its own clip transform and its own CPU networks),
+where a last-bit difference in a matmul can hand an edge pixel to another triangle -- those pixels are counted and excluded.
+
+Stages and what feeds them:
+  dmtet          HIP SDF values                      -> faces / uv_idx bit-equal, vertices
+  prior_normals  oracle vertices (== HIP, checked)   -> vertex normals of the prior mesh
+  skinning       HIP rest vertices (+ deformation), HIP bones, angles -> posed vertices
+  posed_normals  HIP posed vertices                  -> vertex normals
+  clip           HIP posed vertices                  -> clip-space vertices (a torch bmm on both sides)
+  raster         HIP clip-space vertices             -> triangle ids bit-equal, (u, v, z/w)
+  gbuffer        HIP clip, posed, normals, prior     -> position / face normal / smooth normal / canonical position (+ flow) rows
+  images         all of the above + HIP field values -> every output of render_mesh (shading, compositing, antialiasing)
 """
 import copy
 
@@ -11,57 +27,202 @@ import torch
 from . import dmtet_ref, mesh_ref, raster_ref, render_ref, skinning_ref
 
 
-def compare_step(scene, out):
+class _InjectedField:
+    """Stands in for a texture / DINO MLP: returns the values the GPU network produced at the covered pixels (dense, zeros elsewhere:
+    uncovered pixels are composited with alpha 0, render.py:261-262)."""
+
+    def __init__(self, dense):
+        self.dense = dense
+
+    def sample(self, x, feat=None):
+        assert x.shape[:-1] == self.dense.shape[:-1]
+        return self.dense
+
+
+class _InjectedLight:
+    """DirectionalLight.shade (light.py:186-193) with the [B,5] parameters the GPU MLP produced."""
+
+    def __init__(self, params):
+        self.params = params
+
+    def shade(self, feat, kd, normal):
+        p = self.params
+        d, amb, diff = p[:, None, None, :3], p[:, None, None, 3:4], p[:, None, None, 4:5]
+        shading = amb + diff * torch.clamp((d * normal).sum(-1, keepdim=True), min=0.0)
+        return shading * kd, shading
+
+
+def _cpu(t):
+    return t.detach().float().cpu()
+
+
+def _err(a, b):
+    """max |a - b| with its location and the fraction of entries above 1e-4."""
+    d = (a - b).abs()
+    if d.numel() == 0:
+        return {"max_abs_err": 0.0, "at": None, "frac_gt_1e-4": 0.0}
+    i = int(d.argmax())
+    return {"max_abs_err": float(d.reshape(-1)[i]), "at": [int(v) for v in np.unravel_index(i, tuple(d.shape))],
+            "frac_gt_1e-4": float((d > 1e-4).float().mean())}
+
+
+def _dense(points, key, n, H, W, cols=None):
+    """[n,H,W,C] from the [P,C] rows of the covered pixels (list is image-major: the first n images are a prefix)."""
+    pix = points["pix"].cpu()
+    m = pix < n * H * W
+    vals = _cpu(points[key])[: int(m.sum())]
+    if cols is not None:
+        vals = vals[:, cols]
+    out = torch.zeros(n * H * W, vals.shape[-1])
+    out[pix[m]] = vals
+    return out.view(n, H, W, -1), pix[m]
+
+
+def _render_stage(rep, tag, points, rast_hip, posed, nrm, prior_verts, faces, cams, nets_cpu, feat, background, resolution, modes, num_frames,
+                  two_sided, hip_out):
+    """One render_mesh call re-done stage by stage.  ``cams`` = (mvp, w2c, campos) CPU; ``nets_cpu`` = (tex, dino, lgt) CPU copies or
+    Nones; ``hip_out`` = {mode: HIP NCHW output}."""
+    n = posed.shape[0]
+    H, W = resolution
+    mvp, w2c, campos = cams
+    clip_hip = _cpu(points["clip"])[:n]
+    rep[f"{tag}clip"] = _err(render_ref.xfm_points(posed, mvp), clip_hip)
+    tex_cpu, dino_cpu, lgt_cpu = nets_cpu
+    material = dino_net = lgt = None
+    if tex_cpu is not None:
+        dense_tex, _ = _dense(points, "all_tex", n, H, W)
+        material = _InjectedField(dense_tex)
+    if dino_cpu is not None:
+        dense_dino, _ = _dense(points, "dino", n, H, W)
+        dino_net = _InjectedField(dense_dino)
+    if lgt_cpu is not None:
+        lgt = _InjectedLight(_cpu(points["per_image"])[:n, 12:17])
+    taps = {}
+    with torch.no_grad():
+        outs = render_ref.render_mesh(posed, faces, nrm, mvp, w2c, campos, material, lgt, resolution, background=background, feat=None,
+                                      render_modes=modes, prior_v_pos=prior_verts, two_sided=two_sided, dino_net=dino_net, num_frames=num_frames,
+                                      clip=clip_hip, taps=taps)
+    rast_h = _cpu(rast_hip)[:n]
+    ids_equal = bool(torch.equal(taps["rast"][..., 3], rast_h[..., 3]))
+    rep[f"{tag}raster"] = dict(ids_equal=ids_equal, frac_ids_differ=float((taps["rast"][..., 3] != rast_h[..., 3]).float().mean()),
+                               **_err(taps["rast"][..., :3], rast_h[..., :3]))
+    gb_hip, pix = _dense(points, "gb", n, H, W)
+    covered = torch.zeros(n * H * W, dtype=torch.bool)
+    covered[pix] = True
+    covered = covered.view(n, H, W, 1)
+    rep[f"{tag}gbuffer"] = _err(taps["gb"] * covered, gb_hip)
+    if points.get("flow") is not None and taps.get("flow") is not None:
+        flow_hip, _ = _dense(points, "flow", n, H, W)
+        rep[f"{tag}gbuffer_flow"] = _err(taps["flow"][..., : flow_hip.shape[-1]] * covered, flow_hip)
+    # the networks' own fp32 difference between the two machines (model/networks, out of scope: informational)
+    if tex_cpu is not None:
+        with torch.no_grad():
+            f = feat[:, None, None, :].expand(-1, H, W, -1) if feat is not None else None
+            cpu_tex = tex_cpu.sample(gb_hip[..., 9:12], feat=f)
+            rep.setdefault("fields", {})[f"{tag}texture"] = _err(cpu_tex * covered, material.dense)
+            if dino_cpu is not None:
+                rep["fields"][f"{tag}dino"] = _err(dino_cpu.sample(gb_hip[..., 9:12]) * covered, dino_net.dense)
+            if lgt_cpu is not None:
+                rep["fields"][f"{tag}light"] = _err(lgt_cpu(feat), lgt.params)
+    outs = dict(zip(modes, outs))
+    images = {mode: _err(o, _cpu(hip_out[mode])[:n]) for mode, o in outs.items() if mode in hip_out}
+    return images, taps, outs
+
+
+def compare_step(scene, out, n_images=None, end_to_end=True):
+    """-> report dict.  ``n_images``: check the first n frames only (whole sequences for the sequence workload); default all."""
     geo = scene.netShape
-    cpu = lambda t: t.detach().float().cpu()
-    pos, sdf, tets = cpu(geo.current_pos), cpu(geo.current_sdf).reshape(-1), geo.indices.cpu()
+    F = getattr(scene, "num_frames", 1)
+    nb = scene.batch if n_images is None else max(1, min(n_images // F if F > 1 else n_images, scene.batch))
+    n = nb * F
+    H, W = scene.resolution
+    workload = getattr(scene, "workload", "magicpony")
+    pos, sdf, tets = _cpu(geo.current_pos), _cpu(geo.current_sdf).reshape(-1), geo.indices.cpu()
     verts, faces, _, uv_idx = dmtet_ref.marching_tets(pos, sdf, tets)
     prior, shape = scene.last["prior"], scene.last["shape"]
-    rep = {}
+    rep = dict(workload=workload, frames=n, resolution=[H, W])
     rep["faces_equal"] = bool(np.array_equal(faces.numpy(), prior.t_pos_idx[0].cpu().numpy())
                               and np.array_equal(uv_idx.numpy(), prior.t_tex_idx[0].cpu().numpy()))
     rep["num_verts"], rep["num_faces"] = int(verts.shape[0]), int(faces.shape[0])
+    rep["loss"] = float(out["loss"])
     if not rep["faces_equal"]:
         rep["max_abs_image_err"] = float("inf")
-        rep["loss"] = float(out["loss"])
         return rep
-    rep["max_abs_vert_err"] = float((verts - cpu(prior.v_pos[0])).abs().max())
-    nrm = mesh_ref.vertex_normals(verts[None], faces)
-    rep["max_abs_prior_normal_err"] = float((nrm - cpu(prior.v_nrm)).abs().max())
-    bones, arti = cpu(scene.bones), cpu(scene.arti)
-    sk, _ = skinning_ref.skinning(verts[None, None], bones, scene.kinematic_tree, arti, scene.temperature)
-    sk = sk.view(scene.batch, -1, 3)
-    rep["max_abs_skin_err"] = float((sk - cpu(shape.v_pos)).abs().max())
-    snrm = mesh_ref.vertex_normals(sk, faces)
-    rep["max_abs_posed_normal_err"] = float((snrm - cpu(shape.v_nrm)).abs().max())
+    rep["max_abs_vert_err"] = float((verts - _cpu(prior.v_pos[0])).abs().max())
+    rep["max_abs_prior_normal_err"] = float((mesh_ref.vertex_normals(verts[None], faces) - _cpu(prior.v_nrm)).abs().max())
+
+    # ---- skinning from the HIP rest vertices (prior, or prior + the deformation network's offsets)
+    bones, arti = _cpu(scene.bones), _cpu(scene.arti)[:nb]
+    V = verts.shape[0]
+    if scene.last.get("deformation") is not None:
+        rest = _cpu(scene.last["deformed"].v_pos)[:n].view(nb, F, V, 3)
+        rep["max_abs_deform_add_err"] = float((rest.view(n, V, 3) - (_cpu(prior.v_pos) + _cpu(scene.last["deformation"])[:n])).abs().max())
+    else:
+        rest = _cpu(prior.v_pos)[None]
+    bones = bones[:nb] if bones.shape[0] == scene.batch and scene.batch > 1 else bones
+    sk, _ = skinning_ref.skinning(rest, bones, scene.kinematic_tree, arti, scene.temperature)
+    sk = sk.reshape(n, V, 3)
+    posed = _cpu(shape.v_pos)[:n]
+    rep["max_abs_skin_err"] = float((sk - posed).abs().max())
+    nrm_hip = _cpu(shape.v_nrm)[:n]
+    rep["max_abs_posed_normal_err"] = float((mesh_ref.vertex_normals(posed, faces) - nrm_hip).abs().max())
+
+    # ---- the main render, stage by stage
     scene.netLight.light_params = None  # non-leaf cache of the last forward; not deep-copyable
     tex, dino, lgt = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))
+    cams = tuple(_cpu(t)[:n] for t in (scene.mvp, scene.w2c, scene.campos))
+    feat, bg = _cpu(scene.feat)[:n], _cpu(scene.background)[:n]
+    modes = tuple(m for m in ("shaded", "dino_pred", "flow") if m in out)
+    prior_verts = _cpu(prior.v_pos)
+    images, taps, _ = _render_stage(rep, "", scene.last["points"], scene.last["rast"], posed, nrm_hip, prior_verts, faces, cams, (tex, dino, lgt), feat,
+                                 bg, scene.resolution, modes, F, True, out)
+    rep["coverage"] = float((taps["rast"][..., 3] > 0).float().mean())
+    if workload == "fauna" and scene.last.get("random_view") is not None and "mask_random" in out:  # Fauna.py:111-173
+        rv = scene.last["random_view"]
+        rcams = tuple(_cpu(rv[k])[:n] for k in ("mvp", "w2c", "campos"))
 
-    def render(posed):
-        with torch.no_grad():
-            return render_ref.render_mesh(posed, faces, mesh_ref.vertex_normals(posed, faces), cpu(scene.mvp), cpu(scene.w2c), cpu(scene.campos),
-                                          tex, lgt, scene.resolution, background=cpu(scene.background), feat=cpu(scene.feat),
-                                          render_modes=("shaded", "dino_pred"), prior_v_pos=verts[None], dino_net=dino)
+        im2, _, outs2 = _render_stage(rep, "random_view_", rv["points"], rv["rast"], posed, nrm_hip, prior_verts, faces, rcams, (None, None, None),
+                                      None, None, scene.resolution, ("shaded",), F, False, {})
+        images["mask_random"] = _err(outs2["shaded"][:, 3:].clamp(0, 1), _cpu(out["mask_random"])[:n])  # only the alpha channel leaves
+    rep["images"] = images
+    rep["max_abs_image_err"] = max(v["max_abs_err"] for v in images.values())
+    rep["frac_pixels_gt_1e-4"] = max(v["frac_gt_1e-4"] for v in images.values())
+    rep["raster_ids_equal"] = bool(all(v["ids_equal"] for k, v in rep.items() if k.endswith("raster")))
 
-    # stage-wise parity: the renderer is checked on the SAME posed vertices the HIP renderer saw (the skinning stage has its own
-    # figure above).  Even so the clip-space transform is a GPU matmul on one side and a CPU matmul on the other: a last-bit
-    # difference there can hand a pixel on a shared edge or on the silhouette to another triangle (or to the background), which
-    # says nothing about the kernels -- such pixels (from the two id buffers) and their antialiasing neighbours are excluded and
-    # their fraction is reported; the rasteriser's own tests compare ids bit for bit on identical clip-space inputs.
-    posed = cpu(shape.v_pos)
-    shaded, dino_pred = render(posed)
-    rast_o = raster_ref.rasterize(render_ref.xfm_points(posed, cpu(scene.mvp)).contiguous(), faces.int(), scene.resolution)
-    flip = rast_o[..., 3] != cpu(scene.last["rast"])[..., 3]
-    near = torch.nn.functional.max_pool2d(flip.float()[:, None], 3, 1, 1)[:, 0] > 0
-    rep["frac_pixels_owner_flip"] = float(flip.float().mean())
-    e1 = (shaded - cpu(out["shaded"])).abs() * (~near)[:, None]
-    e2 = (dino_pred - cpu(out["dino_pred"])).abs() * (~near)[:, None]
-    rep["max_abs_image_err"] = float(max(e1.max(), e2.max()))
-    rep["frac_pixels_gt_1e-4"] = float(((e1.amax(1) > 1e-4) | (e2.amax(1) > 1e-4)).float().mean())
-    rep["coverage"] = float((shaded[:, 3] > 0).float().mean())
-    # end to end from the oracle's own skinning: informational (silhouette pixels may flip, see above)
-    shaded_o, dino_o = render(sk)
-    rep["frac_pixels_gt_1e-4_end_to_end"] = float((((shaded_o - cpu(out["shaded"])).abs().amax(1) > 1e-4)
-                                                   | ((dino_o - cpu(out["dino_pred"])).abs().amax(1) > 1e-4)).float().mean())
-    rep["loss"] = float(out["loss"])
+    # ---- end to end from the SDF values: the oracle's own skinning, normals, clip transform and CPU networks.  Informational: pixels whose
+    # owner differs between the two id buffers (and their antialiasing neighbours) are counted and excluded.
+    rep["frac_pixels_owner_flip"] = 0.0
+    if end_to_end:
+        def render(p):
+            with torch.no_grad():
+                t = {}
+                o = render_ref.render_mesh(p, faces, mesh_ref.vertex_normals(p, faces), *cams, tex, lgt, scene.resolution, background=bg, feat=feat,
+                                           render_modes=modes, prior_v_pos=verts[None], dino_net=dino, num_frames=F, taps=t)
+            return o, t["rast"]
+
+        if scene.last.get("deformation") is not None:
+            with torch.no_grad():
+                dnet = copy.deepcopy(scene.netDeform).cpu()
+                deformation = dnet(verts[None].expand(n, -1, -1), feat[:, None, :].expand(-1, V, -1)) * 0.1
+            rest_o = (verts[None] + deformation).view(nb, F, V, 3)
+        else:
+            rest_o = verts[None, None]
+        sk_o, _ = skinning_ref.skinning(rest_o, bones, scene.kinematic_tree, arti, scene.temperature)
+        outs_o, rast_o = render(sk_o.reshape(n, V, 3))
+        flip = rast_o[..., 3] != _cpu(scene.last["rast"])[:n, ..., 3]
+        near = torch.nn.functional.max_pool2d(flip.float()[:, None], 3, 1, 1)[:, 0] > 0
+        rep["frac_pixels_owner_flip"] = float(flip.float().mean())
+        e2e = {}
+        for mode, o in zip(modes, outs_o):
+            h = _cpu(out[mode])[:n]
+            e2e[mode] = _err(o * (~near)[:, None], h * (~near)[:, None])
+        rep["end_to_end"] = e2e
+        rep["max_abs_image_err_end_to_end"] = max(v["max_abs_err"] for v in e2e.values())
+        rep["frac_pixels_gt_1e-4_end_to_end"] = max(v["frac_gt_1e-4"] for v in e2e.values())
     return rep
+
+
+def passes(rep, image_tol=1e-4):
+    """The north_star bar on a compare_step report: index buffers bit-exact, triangle ids bit-exact on identical clip-space input,
+    every rendered buffer within 1e-4 absolute of the oracle on identical stage inputs."""
+    return bool(rep.get("faces_equal") and rep.get("raster_ids_equal") and rep.get("max_abs_image_err", float("inf")) < image_tol)

@@ -81,15 +81,17 @@ def shade(gb_pos, gb_geo_nrm, gb_nrm, gb_tex_pos, w2c, view_pos, lgt, material, 
 
 def render_mesh(v_pos, faces, v_nrm, mtx, w2c, view_pos, material, lgt, resolution, background=None, feat=None,
                 render_modes=("shaded",), prior_v_pos=None, two_sided=True, dino_net=None, num_frames=None,
-                class_vector=None):
+                class_vector=None, clip=None, taps=None):
     """reference render.py:228-337 with spp=1, num_layers=1 (the only setting used, AnimalModel.py:245-248).
 
     v_pos [B,V,3], faces [F,3] int64, v_nrm [B,V,3]; returns the list of NCHW buffers in render_modes order.
+    Checker hooks (oracle/check.py): ``clip`` replaces the clip transform's result (stage-wise parity: the next stage starts from
+    the HIP stage's own output); ``taps`` (a dict) receives the intermediate buffers.
     """
     assert faces.shape[0] > 0, "Got empty training triangle mesh (unrecoverable discontinuity)"
     H, W = resolution
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
-    clip = xfm_points(v_pos, mtx)  # :278
+    clip = xfm_points(v_pos, mtx) if clip is None else clip  # :278
     flow_attr = None
     if "flow" in render_modes:  # :281-288
         ndc = clip[..., :2] / clip[..., -1:]
@@ -99,8 +101,10 @@ def render_mesh(v_pos, faces, v_nrm, mtx, w2c, view_pos, material, lgt, resoluti
         flow_attr = dxy.view(-1, *dxy.shape[2:])
     tri = faces.int()
     rast = raster_ref.rasterize(clip, tri, (H, W))  # :292-294
-    # carry gradients through the barycentrics
+    # values: the rasteriser's own stored (u, v) -- what dr.interpolate reads; gradients: d(u, v)/d(clip) of the same triangle ids
+    # (the recomputed pair differs from the stored one by rounding only, but on sliver triangles that reaches 1e-4 in the normals)
     uv = raster_ref.barycentrics(clip, tri, rast)
+    uv = rast[..., :2] + (uv - uv.detach())
     rast_d = torch.cat([uv.clamp(0, 1), rast[..., 2:]], -1)
     gb_pos = raster_ref.interpolate(v_pos, rast_d, tri)  # :182
     fn = mesh_ref.face_normals(v_pos, faces)  # :185-188
@@ -110,6 +114,8 @@ def render_mesh(v_pos, faces, v_nrm, mtx, w2c, view_pos, material, lgt, resoluti
     gb_flow = raster_ref.interpolate(flow_attr, rast_d, tri) if flow_attr is not None else None  # :199-200
     prior = v_pos if prior_v_pos is None else prior_v_pos
     gb_tex = raster_ref.interpolate(prior, rast_d, tri)  # :209
+    if taps is not None:
+        taps.update(clip=clip, rast=rast, gb=torch.cat([gb_pos, gb_geo, gb_nrm, gb_tex], -1), flow=gb_flow)
     buffers = shade(gb_pos, gb_geo, gb_nrm, gb_tex, w2c, view_pos, lgt, material, feat, render_modes, two_sided, gb_flow,
                     dino_net, class_vector)
     if background is not None:  # :299-304

@@ -50,9 +50,27 @@ def _eroded(mask_pred, st):
     return (torch.nn.functional.avg_pool2d(both.unsqueeze(1), 3, stride=1, padding=1).squeeze(1) > 0.99).float()
 
 
-def cpu_step(st, backward=True):
+def cpu_step(st, backward=True, dtype=torch.float32):
     """-> dict(loss, losses, shaded, dino_pred[, flow, mask_random], grads{...}, faces, seconds).  Follows AnimalModel.forward around
-    the replaced modules (/root/reference/model/models/AnimalModel.py:356-515) for the workload the snapshot was taken from."""
+    the replaced modules (/root/reference/model/models/AnimalModel.py:356-515) for the workload the snapshot was taken from.
+    ``dtype=torch.float64``: the same step in double precision (networks included; the triangle ids still come from the float32 C
+    rasteriser) -- the reference the gradient tests use, so that their tolerance measures the HIP path and not the CPU's own rounding."""
+    if dtype != torch.float32:
+        if hasattr(st.get("lgt"), "light_params"):
+            st["lgt"].light_params = None  # non-leaf cache of the last forward; not deep-copyable
+        st = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else
+                  copy.deepcopy(v).to(dtype) if isinstance(v, torch.nn.Module) else
+                  {kk: vv.to(dtype) for kk, vv in v.items()} if (isinstance(v, dict) and k == "random_view") else v) for k, v in st.items()}
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            return _cpu_step(st, backward)
+        finally:
+            torch.set_default_dtype(prev)
+    return _cpu_step(st, backward)
+
+
+def _cpu_step(st, backward):
     from importlib import import_module
 
     pipeline = import_module("3danimals_amd.pipeline")
@@ -108,6 +126,9 @@ def cpu_step(st, backward=True):
             parts["arti_reg"] = (leaves["arti"] ** 2).mean()
             parts["deform_reg"] = (deformation ** 2).mean()
             loss = loss + pipeline.REG_WEIGHTS["arti_reg"] * parts["arti_reg"] + pipeline.REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+        # AnimalModel.py:317-328 (computed every iteration, weight 0: not in the total)
+        pn = mesh_ref.vertex_normals(verts[None], faces)[0][torch.cat([faces[:, 0:2], faces[:, 1:3]], 0)]
+        parts["prior_normal_reg"] = (1 - (pn[:, 0] * pn[:, 1]).sum(-1)).mean()
         if st.get("random_view") is not None:  # Fauna.py:111-173
             rv = st["random_view"]
             (second,) = render_ref.render_mesh(posed, faces, nrm, rv["mvp"], rv["w2c"], rv["campos"], None, None, st["resolution"], background=None,

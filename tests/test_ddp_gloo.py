@@ -90,3 +90,34 @@ def test_shard_range_covers_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_plain_command_spawns_its_own_ranks_dry_launch():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): bench.py re-runs itself under torch.distributed.run, the
+    ranks rendezvous on 127.0.0.1, all-reduce, and rank 0's JSON line is the ONLY thing on stdout (other output is passed to stderr).
+    --dry-launch skips the GPU work, so the launch / collect plumbing of the 8-GPU driver run is exercised here on CPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-launch", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["allreduce_sum"] == 3.0 and line["steps"] == 3
+    assert "self-launch" in line["launcher"] and "stdout chatter" in p.stderr
+    # and under an external launcher (the driver's documented command shape) the same line comes straight from rank 0
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["rccl_ranks"] == 2 and "launcher" not in line
+    # a wrong --gpus under a launcher is refused before any collective
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-launch"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd="/tmp")
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr

@@ -379,6 +379,44 @@ def test_antialias_fwd_bwd_vs_oracle(C, dev, ops):
     np.testing.assert_allclose(gp.cpu().numpy(), gp_ref.numpy(), rtol=1e-3, atol=2e-4 * scale)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_antialias_run_to_run_difference_is_bounded_by_the_blend_order(fused, dev, ops):
+    """The silhouette crossings are appended to 256 work-list segments with atomics, so the order in which a pixel's (at most four:
+    left / right / up / down pair) blend terms are added changes from run to run -- the only non-determinism of the antialiasing ops.
+    Stated bound: every output value within 2 ulp of 1.0 (2.4e-7) of any other run, only silhouette pixels differ at all, and the two
+    gradients agree to float-atomic order."""
+    B, H, W, C = 4, 128, 128, 4
+    _, faces, clip, _ = _scene(B, seed=9)
+    tri = faces.to(dev)
+    clip_d = clip.to(dev)
+    rast = ops.rasterize(clip_d, tri, (H, W))
+    wgt = seeded((B, H, W, C), 8, -1, 1).to(dev)
+
+    def run():
+        p = clip_d.clone().requires_grad_(True)
+        if fused:
+            pix, inv = ops.covered_pixels(rast, return_inverse=True)
+            vals = seeded((pix.shape[0], C - 1), 3, 0.3, 1.0).to(dev).requires_grad_(True)
+            analysis = ops.AAAnalysis(rast, p, ops.aa_topology(ops.tri_int32(tri), clip.shape[1]))
+            out = ops.composite_antialias(vals, pix, inv, None, p, analysis)
+            leaf = vals
+        else:
+            cover = (rast[..., 3:] > 0).float()
+            leaf = torch.lerp(seeded((B, H, W, C), 1, 0, 0.2).to(dev), seeded((B, H, W, C), 2, 0.5, 1.0).to(dev), cover).requires_grad_(True)
+            out = ops.antialias(leaf, rast, p, tri)
+        gl, gp = torch.autograd.grad((out * wgt).sum(), [leaf, p])
+        return out.detach(), gl, gp
+
+    runs = [run() for _ in range(4)]
+    o0, gl0, gp0 = runs[0]
+    for o, gl, gp in runs[1:]:
+        d = (o - o0).abs()
+        assert float(d.max()) <= 2.4e-7, float(d.max())
+        assert int((d > 0).any(-1).sum()) <= 0.05 * B * H * W  # silhouette pixels only
+        assert float((gl - gl0).abs().max()) <= 5e-7 * float(gl0.abs().max())
+        assert float((gp - gp0).abs().max()) <= 2e-5 * float(gp0.abs().max())
+
+
 def test_antialias_known_answer_vertical_edge(dev, ops):
     """A surface covering x < k+0.3: pixel k (centre k+0.5, uncovered) takes 0.3 of its covered left neighbour."""
     H = W = 16
@@ -556,6 +594,27 @@ def test_ops_refuse_cpu_tensors(ops):
         ops.vertex_normals(torch.rand(1, 4, 3), torch.zeros(1, 3, dtype=torch.int64))
 
 
+GRAD_RTOL, GRAD_ATOL_RMS = 1e-3, 1e-3
+
+
+def _gradients_close(pairs, rtol=GRAD_RTOL, atol_rms=GRAD_ATOL_RMS):
+    """Every (name, hip, oracle64) pair: |hip - oracle| <= rtol*|oracle| + atol_rms*RMS(oracle) PER ENTRY, against the float64 oracle
+    (its own rounding is then out of the picture).  All offenders are reported together."""
+    bad = []
+    for name, a, b in pairs:
+        assert a is not None, name
+        a, b = a.detach().cpu().double(), b.double()
+        rms = float(b.pow(2).mean().sqrt())
+        if rms == 0:  # e.g. the camera position at 32x32: it only enters through the shading normal's bend, which may not trigger
+            if float(a.abs().max()) >= 1e-6:
+                bad.append((name, "oracle is zero", float(a.abs().max())))
+            continue
+        worst = float(((a - b).abs() / (rtol * b.abs() + atol_rms * rms)).max())
+        if not worst <= 1.0:
+            bad.append((name, round(worst, 2), f"max|d|={float((a - b).abs().max()):.3e} rms={rms:.3e}"))
+    assert not bad, bad
+
+
 def test_full_step_loss_and_gradients_vs_oracle_step(dev):
     """fwd+bwd of the whole path (HIP) against torch-CPU autograd through the oracle, from identical weights and inputs."""
     from oracle import step_ref
@@ -564,22 +623,14 @@ def test_full_step_loss_and_gradients_vs_oracle_step(dev):
     scene = pipeline.SyntheticScene(grid_res=16, batch=2, resolution=(64, 64), device=dev, seed=3, net_width=32, net_layers=3, feat_dim=16,
                                     embedder_freq=4)
     out = scene.step(backward=True, optimizer_step=False, sdf_reg=False)
-    ref = step_ref.cpu_step(step_ref.snapshot(scene), backward=True)
+    ref = step_ref.cpu_step(step_ref.snapshot(scene), backward=True, dtype=torch.float64)
     assert ref["num_faces"] == scene.last["prior"].t_pos_idx.shape[1]
-    np.testing.assert_allclose(float(out["loss"]), float(ref["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(out["loss"]), float(ref["loss"]), rtol=2e-5)
     np.testing.assert_allclose(out["shaded"].detach().cpu().numpy(), ref["shaded"].numpy(), atol=1e-4)
-
-    def close(a, b, name, tol=5e-3):
-        a, b = a.detach().cpu().double(), b.double()
-        scale = float(b.abs().max())
-        assert scale > 0, name
-        assert float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
-
-    for k in ("arti", "feat", "mvp", "campos", "w2c"):
-        close(getattr(scene, k).grad, ref["grads"][k], k)
+    pairs = [(k, getattr(scene, k).grad, ref["grads"][k]) for k in ("arti", "feat", "mvp", "campos", "w2c")]
     for name, mod in (("sdf_mlp", scene.netShape.mlp), ("tex", scene.netTexture), ("dino", scene.netDINO), ("lgt", scene.netLight)):
-        for pn, p in mod.named_parameters():
-            close(p.grad, ref["grads"][f"{name}.{pn}"], f"{name}.{pn}")
+        pairs += [(f"{name}.{pn}", p.grad, ref["grads"][f"{name}.{pn}"]) for pn, p in mod.named_parameters()]
+    _gradients_close(pairs)
 
 
 def _owner_flip_mask(scene, ref):
@@ -610,44 +661,55 @@ def test_workload_steps_vs_oracle_step(workload, kw, dev):
     scene = pipeline.SyntheticScene(grid_res=16, batch=batch, resolution=resolution, device=dev, seed=5, net_width=32, net_layers=3, feat_dim=16,
                                     embedder_freq=4, workload=workload, **kw)
     out = scene.step(backward=True, optimizer_step=False, sdf_reg=False)
-    ref = step_ref.cpu_step(step_ref.snapshot(scene), backward=True)
+    ref = step_ref.cpu_step(step_ref.snapshot(scene), backward=True, dtype=torch.float64)
     assert torch.equal(ref["faces"], scene.last["prior"].t_pos_idx[0].cpu())  # index buffers bit-exact
     keep = ~_owner_flip_mask(scene, ref)
     for name in ("shaded", "dino_pred", "flow"):
         if name in ref:
-            # END-TO-END figure (oracle skinning -> oracle normals -> oracle render against the HIP chain): the ~1e-6 skinning
-            # difference reaches the shading through the vertex normals of sliver triangles (measured up to 1.6e-4 on one pixel);
-            # the renderer's own 1e-4 bar is checked on identical posed vertices in test_full_step_against_oracle_and_grads_finite
+            # END-TO-END figure against the float64 chain (oracle skinning -> normals -> render); the renderer's own 1e-4 bar on
+            # identical stage inputs is test_full_step_against_oracle_and_grads_finite / test_full_size_workloads_stagewise_parity
             err = ((out[name].detach().cpu() - ref[name]).abs() * keep[:, None]).max()
-            assert float(err) < 5e-4, (name, float(err))
+            assert float(err) < 2e-4, (name, float(err))
     if workload == "ponymation":
         assert "flow" in ref and out["flow"].shape[1] == 2 and scene.frames == batch * kw["num_frames"]
     if workload == "fauna":  # the second render has its own cameras; its mask is 0/1 + antialiased edges
         d = (out["mask_random"].detach().cpu() - ref["mask_random"]).abs()
         assert float((d > 1e-4).float().mean()) < 2e-3
         assert scene.bone_aux is not None and scene.class_emb.grad is not None and float(scene.class_emb.grad.abs().max()) > 0
-    np.testing.assert_allclose(float(out["loss"]), float(ref["loss"]), rtol=2e-4)
+    np.testing.assert_allclose(float(out["loss"]), float(ref["loss"]), rtol=5e-5)
     for k, v in ref["losses"].items():
-        np.testing.assert_allclose(out["losses"][k].detach().cpu().numpy(), v.numpy(), rtol=2e-3, atol=1e-6, err_msg=k)
-
-    def close(a, b, name, tol=1e-2):
-        a, b = a.detach().cpu().double(), b.double()
-        scale = float(b.abs().max())
-        if scale == 0:  # e.g. the camera position at 32x32: it only enters through the shading normal's bend, which may not trigger
-            assert float(a.abs().max()) < 1e-6, name
-            return
-        assert float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
-
-    for k in ("arti", "feat", "mvp", "campos", "w2c"):
-        close(getattr(scene, k).grad, ref["grads"][k], k)
+        np.testing.assert_allclose(out["losses"][k].detach().cpu().numpy(), v.numpy(), rtol=5e-4, atol=1e-6, err_msg=k)
+    pairs = [(k, getattr(scene, k).grad, ref["grads"][k]) for k in ("arti", "feat", "mvp", "campos", "w2c")]
     if workload == "fauna":
-        close(scene.class_emb.grad, ref["grads"]["class_emb"], "class_emb")
+        pairs.append(("class_emb", scene.class_emb.grad, ref["grads"]["class_emb"]))
     nets = [("sdf_mlp", scene.netShape.mlp), ("tex", scene.netTexture), ("dino", scene.netDINO), ("lgt", scene.netLight)]
     if scene.deform:
         nets.append(("deform", scene.netDeform))
     for name, mod in nets:
-        for pn, p in mod.named_parameters():
-            close(p.grad, ref["grads"][f"{name}.{pn}"], f"{name}.{pn}")
+        pairs += [(f"{name}.{pn}", p.grad, ref["grads"][f"{name}.{pn}"]) for pn, p in mod.named_parameters()]
+    _gradients_close(pairs)
+
+
+@pytest.mark.parametrize("workload,kw,n", [("magicpony", dict(deform=True), 16), ("fauna", {}, 16), ("ponymation", dict(num_frames=8, batch=8), 16)])
+def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
+    """BASELINE configs 3 / 4 / 5 at FULL size (batch 16 resp. 8 sequences x 8 frames, 256x256, Kuhn R=64 grid, the networks at the
+    reference's sizes), fixed weights (no optimiser step before the check): every stage of the step re-done by the CPU oracle from the
+    HIP output of the stage before it (oracle/check.py) -- index buffers bit-exact, triangle ids bit-exact on the same clip-space
+    vertices, every rendered buffer ('shaded', 'dino_pred', 'flow', the random-view mask) within 1e-4 absolute with NO pixel excluded."""
+    from oracle import check
+
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    kw = dict(kw)
+    scene = pipeline.SyntheticScene(grid_res=64, batch=kw.pop("batch", 16), resolution=(256, 256), device=dev, seed=0, workload=workload, **kw)
+    out = scene.step(backward=True, optimizer_step=False)
+    rep = check.compare_step(scene, out, n_images=n, end_to_end=False)
+    assert rep["faces_equal"] and rep["num_faces"] > 8000, rep
+    assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 5e-6 and rep["max_abs_posed_normal_err"] < 2e-5, rep
+    assert rep["raster_ids_equal"] and rep["raster"]["max_abs_err"] <= 2e-6, rep["raster"]
+    assert rep["gbuffer"]["max_abs_err"] < 1e-5, rep["gbuffer"]
+    assert set(rep["images"]) >= {"shaded", "dino_pred"} | ({"flow"} if workload == "ponymation" else set()) | ({"mask_random"} if workload == "fauna" else set())
+    assert rep["max_abs_image_err"] < 1e-4 and check.passes(rep), rep["images"]
+    assert rep["max_abs_image_err"] < 2e-5, rep["images"]  # measured: <= 1e-5; a regression shows long before the 1e-4 bar
 
 
 @pytest.mark.parametrize("res,H,W", [(16, 64, 64), (8, 160, 128), (16, 256, 256)])
@@ -823,14 +885,20 @@ def test_nvdiffrast_shim_end_to_end(dev):
     sys.path.insert(0, shim)
     try:
         dr = importlib.import_module("nvdiffrast.torch")
+        ops_mod = importlib.import_module("3danimals_amd.ops")
         B, H, W = 2, 48, 48
         verts, faces, clip, _ = _scene(B)
         ctx = dr.RasterizeGLContext()
         pos, tri = clip.to(dev).requires_grad_(True), faces.to(dev).int()
         with dr.DepthPeeler(ctx, pos.float(), tri, [H, W]) as peeler:
             rast, db = peeler.rasterize_next_layer()
-        rast2, _ = dr.rasterize(ctx, pos, tri, [H, W])
+        rast2, db2 = dr.rasterize(ctx, pos, tri, [H, W])
+        assert db._value is None  # rast_db is computed on first use only (the reference discards it: render.py:24)
         assert torch.equal(rast, rast2) and db.shape == rast.shape
+        dense = ops_mod.rasterize_db(pos, tri, rast)
+        assert torch.equal(db.materialize(), dense) and torch.equal(torch.nn.functional.avg_pool2d(db2.permute(0, 3, 1, 2), 1).permute(0, 2, 3, 1), dense)
+        _, da = dr.interpolate(verts[None].to(dev).contiguous(), rast, tri, rast_db=db2, diff_attrs="all")
+        assert da.shape == (B, H, W, 6) and bool(torch.isfinite(da).all()) and float(da.abs().max()) > 0
         assert np.array_equal(rast.detach().cpu().numpy(), raster_ref.rasterize(clip, faces.int(), (H, W)).numpy())
         attr = verts[None].to(dev)
         out, _ = dr.interpolate(attr.contiguous(), rast, tri, rast_db=None, diff_attrs=None)
@@ -1037,12 +1105,39 @@ def test_covered_pixels_of_a_rasterised_buffer_use_the_resolve_counts(hw, dev, o
     want_inv = torch.full((B * H * W,), -1, dtype=torch.int32, device=dev)
     want_inv[want] = torch.arange(want.shape[0], dtype=torch.int32, device=dev)
     assert torch.equal(inv, want_inv)
+    # a SECOND list of the same, unmodified buffer: the resolve's block counts were consumed (scanned in place) by the first call
+    assert ops._cover_counts.peek(rast) is None
+    pix2, inv2 = ops.covered_pixels(rast, return_inverse=True)
+    assert torch.equal(pix2, want) and torch.equal(inv2, want_inv)
     # an in-place edit of the buffer invalidates the cached counts (the version counter is part of the cache key)
     rast[0, : H // 2] = 0.0
     assert ops._cover_counts.peek(rast) is None
     cover = rast[..., 3] > 0
     want = flat[cover.view(B, H // 8, 8, W // 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)]
     assert torch.equal(ops.covered_pixels(rast), want)
+
+
+def test_empty_triangle_list_does_not_poison_the_kept_scratch_buffers(dev, ops):
+    """F == 0 launches nothing that touches the rasteriser's key buffer / the topology hash; the fresh (uninitialised) scratch of such a
+    call must not be kept as 'clean' for the next call of the same size (DMTet can legitimately emit an empty mesh)."""
+    from oracle import raster_ref
+
+    B, H, W = 2, 40, 56  # a size no other test uses: the first call of this size allocates fresh scratch
+    _, faces, clip, _ = _scene(B, seed=21)
+    ops._rast_keys.clear()
+    ops._topology_scratch.clear()
+    poison = torch.full((1 << 22,), 0x3C, dtype=torch.uint8, device=dev)  # make it likely that recycled allocations hold non-0xFF garbage
+    del poison
+    empty = faces[:0].to(dev).int().contiguous()
+    r0 = ops.rasterize(clip.to(dev), empty, (H, W))
+    assert float(r0.abs().max()) == 0.0
+    r1 = ops.rasterize(clip.to(dev), faces.to(dev), (H, W))
+    assert np.array_equal(r1.cpu().numpy(), raster_ref.rasterize(clip, faces.int(), (H, W)).numpy())
+    V = int(faces.max()) + 1
+    few = faces[:7].to(dev).int().contiguous()  # same hash-size class as F == 0
+    ops.mesh_topology(empty, V)
+    a, t = ops.mesh_topology(few, V)
+    assert np.array_equal(t.opp.cpu().numpy(), raster_ref.edge_opposites(few.cpu().numpy()))
 
 
 @pytest.mark.parametrize("E,res,hw", [(2, 16, (64, 64)), (3, 16, (96, 80)), (1, 40, (64, 64))])
@@ -1164,7 +1259,8 @@ def test_shade_points_kernel_matches_oracle(light, two_sided, dev, ops):
         assert float(((a - b_).abs() / scale).max()) < 2e-4, (name, float(((a - b_).abs() / scale).max()))
 
 
-@pytest.mark.parametrize("light,P,B", [(True, 5000, 7), (False, 3000, 4), (True, 700, 16), (True, 257, 1)])
+@pytest.mark.parametrize("light,P,B", [(True, 5000, 7), (False, 3000, 4), (True, 700, 16), (True, 257, 1), (True, 20, 16), (True, 900, 64),
+                                       (False, 3, 40)])  # the last three: B*ncol far above the forward launch's thread count
 def test_shade_points_per_image_rows_equal_per_point_rows(light, P, B, dev, ops):
     """The indexed form (camera / light rows per image + point -> image index, gradient reduced per image inside the kernel) against the
     per-point form fed with the gathered rows (itself checked against the oracle above): same values, row gradient = per-image sums.
@@ -1466,6 +1562,32 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_present():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["global_batch"] == 32
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_two_ranks_on_one_gpu_through_both_command_shapes(launcher):
+    """`python bench.py --gpus 2 ...` (bench.py spawns its own ranks, the way `accelerate launch --multi_gpu run.py` does for the reference,
+    README.md:49-52) and the same under torch.distributed.run: two ranks, both on cuda:0, DDP over gloo (two RCCL ranks cannot share a
+    device) -- the whole N > 1 path of bench.py (scene -> graph capture -> process group -> DDP -> barrier-bracketed timing -> max over
+    ranks -> gathered per-rank covered pixels -> ONE json line, last on stdout) on the single-GPU box."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1", "--grid-res", "16",
+            "--resolution", "64", "--batch", "2", "--no-cpu-baseline", "--no-tuned-gemms"]
+    cmd = [sys.executable] + tail if launcher == "plain" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                              "--master-addr", "127.0.0.1", "--master-port", "29541"] + tail
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = p.stdout.strip().splitlines()
+    line = json.loads(lines[-1])
+    if launcher == "plain":
+        assert len(lines) == 1 and "self-launch" in line["launcher"]  # everything else the ranks print goes to stderr
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 4 and len(line["covered_pixels_per_rank"]) == 2 and min(line["covered_pixels_per_rank"]) > 0
+    assert line["roofline"] is not None and line["roofline"]["in_scope"]["us_per_step"] > 0
 
 
 def test_render_uv_bake_and_material_export(tmp_path, dev, mods):

@@ -30,6 +30,52 @@ def test_library_exports_every_declared_symbol():
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
 
 
+def _header_prototypes():
+    """name -> (return kind, [parameter kinds]) parsed from include/a3d.h; kinds: ptr, int, int64, float, size_t, char_p."""
+    header = open(os.path.join(ROOT, "include", "a3d.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header = re.sub(r"//[^\n]*", "", header)
+    header = re.sub(r"^\s*#[^\n]*", "", header, flags=re.M)
+
+    def kind(decl):
+        decl = decl.strip()
+        if "*" in decl or re.search(r"\ba3d_stream_t\b", decl):
+            return "char_p" if re.match(r"const\s+char\s*\*$", decl) else "ptr"
+        base = re.sub(r"\b(const|unsigned)\b", "", decl).split()
+        base = base[0] if base else ""
+        return {"int": "int", "int32_t": "int", "int64_t": "int64", "float": "float", "size_t": "size_t"}.get(base, "?" + decl)
+
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_\s\*]*?)\b(a3d_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        ret = re.sub(r"\b(A3D_API|extern|\"C\")\b", "", ret).strip()
+        plist = [] if params in ("", "void") else [kind(re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*$", "", p.strip()) if not p.strip().endswith("*") else p) for p in params.split(",")]
+        protos[name] = (kind(ret), plist)
+    return protos
+
+
+def test_header_prototypes_match_the_ctypes_signatures_in_arity_and_kind():
+    """include/a3d.h against _lib.SIGNATURES parameter by parameter: count, and pointer / int / int64 / float / size_t kind.  With ctypes an
+    argument inserted on one side only is silent stack garbage; this makes it a CPU-suite failure."""
+    L = importlib.import_module("3danimals_amd._lib")
+    protos = _header_prototypes()
+    assert set(protos) == set(L.SIGNATURES), set(protos) ^ set(L.SIGNATURES)
+    ck = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_int64: "int64", ctypes.c_float: "float", ctypes.c_size_t: "size_t",
+          ctypes.c_char_p: "char_p"}
+    bad = []
+    for name, (res, args) in L.SIGNATURES.items():
+        want = (ck[res], [ck[a] for a in args])
+        if protos[name] != want:
+            bad.append((name, "header", protos[name], "ctypes", want))
+    assert not bad, bad
+    assert not any(k.startswith("?") for r, ps in protos.values() for k in [r] + ps), "unparsed parameter kind"
+    # the check bites: an extra int in one place only, or an int where the header has a pointer, is reported
+    res, args = L.SIGNATURES["a3d_rast_fwd"]
+    assert protos["a3d_rast_fwd"] != (ck[res], [ck[a] for a in args] + ["int"])
+    assert protos["a3d_rast_fwd"][1][0] == "ptr" and protos["a3d_rast_fwd"][1][1] == "int"
+    assert sum(len(ps) for _, ps in protos.values()) > 400
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     L = importlib.import_module("3danimals_amd._lib")
     monkeypatch.setattr(L, "_lib", None)

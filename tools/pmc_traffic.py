@@ -82,7 +82,12 @@ def main():
             continue
         fe, wr = fe or 0.0, wr or 0.0
         per_call[entry] = dict(fetch_MB_raw=round(fe / 1e6, 2), write_MB=round(wr / 1e6, 2), traffic_MB=round((2 * fe + wr) / 1e6, 2))
-    out = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    out = dict(kernel_source_sha16=bench.kernel_source_sha16(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
                     "MB per C-ABI call; traffic = 2*FETCH (gfx950 correction for wide reads, upper bound for gathers) + WRITE; "
                     "the copy/memset helpers of an entry point (hipMemcpyAsync / hipMemsetAsync) are not included", per_call=per_call)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
