@@ -640,7 +640,7 @@ def _owner_flip_mask(scene, ref):
     from oracle import raster_ref, render_ref
 
     n = ref["posed"].shape[0]
-    clip = render_ref.xfm_points(ref["posed"], scene.mvp.detach().cpu()[:n]).contiguous()
+    clip = render_ref.xfm_points(ref["posed"].float(), scene.mvp.detach().cpu()[:n]).contiguous()
     rast_o = raster_ref.rasterize(clip, ref["faces"].int(), scene.resolution)
     flip = rast_o[..., 3] != scene.last["rast"].cpu()[:n, ..., 3]
     assert float(flip.float().mean()) < 2e-3
@@ -690,7 +690,7 @@ def test_workload_steps_vs_oracle_step(workload, kw, dev):
     _gradients_close(pairs)
 
 
-@pytest.mark.parametrize("workload,kw,n", [("magicpony", dict(deform=True), 16), ("fauna", {}, 16), ("ponymation", dict(num_frames=8, batch=8), 16)])
+@pytest.mark.parametrize("workload,kw,n", [("magicpony", dict(deform=True), 16), ("fauna", {}, 16), ("ponymation", dict(num_frames=8, batch=8), 64)])
 def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     """BASELINE configs 3 / 4 / 5 at FULL size (batch 16 resp. 8 sequences x 8 frames, 256x256, Kuhn R=64 grid, the networks at the
     reference's sizes), fixed weights (no optimiser step before the check): every stage of the step re-done by the CPU oracle from the
