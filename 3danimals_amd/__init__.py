@@ -16,4 +16,4 @@ HIP device.
 from . import synthetic, tetgrid  # noqa: F401  (pure numpy/torch helpers; no native code needed)
 
 __all__ = ["synthetic", "tetgrid"]
-__version__ = "0.2.0"
+__version__ = "0.3.0"

@@ -18,26 +18,35 @@ SIGNATURES = {
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
     "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p]),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
-    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p]),
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _c_int, _p]),
     "a3d_bone_transforms_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_bone_transforms_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_skin_pose_max_bones": (_c_int, []),
+    "a3d_skin_pose_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p, _p, _p]),
+    "a3d_skin_pose_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _c_int, _p, _p,
+                                   _p]),
     "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
-    "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
+    "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _c_int, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p]),
+    "a3d_cover_blocks": (_c_int, [_c_int, _c_int, _c_int]),
+    "a3d_cover_groups": (_c_int, [_c_int, _c_int, _c_int]),
+    "a3d_cover_group_stride": (_c_int, []),
+    "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_mesh_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
+    "a3d_mesh_topology_finalize_max_vertices": (_c_int, []),
+    "a3d_mesh_topology_finalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p]),
     "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int,
                                  _c_int, _p, _c_int, _p, _p]),
@@ -59,7 +68,8 @@ SIGNATURES = {
     "a3d_aa_shards": (_c_int, []),
     "a3d_aa_capacity": (_c_int, [_c_int, _c_int, _c_int]),
     "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
-    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p]),
+    "a3d_aa_topology_from_lists": (_c_int, [_p, _c_int, _p, _p, _p, _p]),
+    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p]),
@@ -67,7 +77,7 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 200  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 300  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

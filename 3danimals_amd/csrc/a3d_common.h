@@ -7,6 +7,11 @@
 #include "../../include/a3d.h"
 
 #define A3D_WAVE 64
+// covered-pixel list (cover.hip; the rasteriser's resolve writes the same scratch): per-256-pixel block counts [nb] followed by the sums
+// of groups of 64 consecutive blocks, one sum per 64-byte line [ceil(nb / 64) * 16 ints] (the sums are accumulated with device atomics:
+// neighbours in one line serialise against each other in the L2's atomic unit)
+#define A3D_COVER_GROUP 64
+#define A3D_COVER_GROUP_STRIDE 16
 
 void a3d_set_error(const char* fmt, ...);
 

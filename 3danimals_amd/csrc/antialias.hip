@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void aa_screen_kernel(const float4* __restrict
 // one thread per (pixel, direction): blockIdx.y = d (0: right neighbour, 1: lower neighbour)
 __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restrict__ rast, const float2* __restrict__ screen, int clip_batch,
                                                          const int* __restrict__ tri, const int* __restrict__ opp, int V, int F, int H,
-                                                         int W, AaRec* __restrict__ work, int capacity, int* __restrict__ count) {
+                                                         int W, AaRec* __restrict__ work, int capacity, int* __restrict__ count,
+                                                         const int* __restrict__ off, const int* __restrict__ adj) {
     const unsigned hw = (unsigned)H * (unsigned)W;
     const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
     const int d = blockIdx.y, b = blockIdx.z;
@@ -90,41 +91,41 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
                     const int px = x + (use1 ? 1 - d : 0), py = y + (use1 ? d : 0);
                     const float ds = use1 ? -1.f : 1.f;
                     const int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
-                    int o0 = opp[3 * t], o1 = opp[3 * t + 1], o2 = opp[3 * t + 2];
-                    o0 = o0 >= 0 ? o0 : v0; o1 = o1 >= 0 ? o1 : v1; o2 = o2 >= 0 ? o2 : v2;
                     const float fx = (float)px + 0.5f - xh, fy = (float)py + 0.5f - yh;
-                    const float2 a0 = sb[v0], a1 = sb[v1], a2 = sb[v2], b0 = sb[o0], b1 = sb[o1], b2 = sb[o2];
+                    const float2 a0 = sb[v0], a1 = sb[v1], a2 = sb[v2];
                     float x0 = a0.x - fx, y0 = a0.y - fy, x1 = a1.x - fx, y1 = a1.y - fy, x2 = a2.x - fx, y2 = a2.y - fy;
-                    const float ox0 = b0.x - fx, oy0 = b0.y - fy, ox1 = b1.x - fx, oy1 = b1.y - fy, ox2 = b2.x - fx, oy2 = b2.y - fy;
                     const float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-                    const float w0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
-                    const float w1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
-                    const float w2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
-                    const bool s0 = aa_same_sign(w0, bb), s1 = aa_same_sign(w1, bb), s2 = aa_same_sign(w2, bb);
-                    if (s0 || s1 || s2) {
-                        if (d == 1) {  // pair direction becomes the first coordinate
-                            float tmp;
-                            tmp = x0; x0 = y0; y0 = tmp;
-                            tmp = x1; x1 = y1; y1 = tmp;
-                            tmp = x2; x2 = y2; y2 = tmp;
-                        }
-                        // edge k joins vertices (k+1, k+2)
-                        const float exa[3] = {x1, x2, x0}, eya[3] = {y1, y2, y0}, exb[3] = {x2, x0, x1}, eyb[3] = {y2, y0, y1};
-                        const bool sil[3] = {s0, s1, s2};
-                        float best = -INFINITY, bdx = 0.f, bdy = 1.f;
-                        int di = 0;
-                        bool bstr = false;
+                    // the geometric tests first (which edge the pair's line leaves the triangle through, its slope, the crossing distance);
+                    // the silhouette test -- the only part that needs the neighbouring triangle -- only for the pairs that pass them, and
+                    // only for that ONE edge.  Same operations on the same operands as testing all three edges up front: same records.
+                    float px0 = x0, py0 = y0, px1 = x1, py1 = y1, px2 = x2, py2 = y2;
+                    if (d == 1) {  // pair direction becomes the first coordinate
+                        px0 = y0; py0 = x0; px1 = y1; py1 = x1; px2 = y2; py2 = x2;
+                    }
+                    // edge k joins vertices (k+1, k+2)
+                    const float exa[3] = {px1, px2, px0}, eya[3] = {py1, py2, py0}, exb[3] = {px2, px0, px1}, eyb[3] = {py2, py0, py1};
+                    float best = -INFINITY, bdx = 0.f, bdy = 1.f;
+                    int di = 0;
+                    bool bstr = false;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const float dxe = exb[k] - exa[k], dye = eyb[k] - eya[k];
-                            const bool str = !aa_same_sign(eya[k], eyb[k]);
-                            const float ratio = str ? (ds * (exa[k] * dye - eya[k] * dxe)) / dye : -INFINITY;
-                            const bool better = (k == 0) ? true : (ratio > best);
-                            if (better) { best = ratio; di = k; bdx = dxe; bdy = dye; bstr = str; }
-                        }
-                        const float dc = best;
-                        const bool ok = sil[di] && bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f);
-                        if (ok) {
+                    for (int k = 0; k < 3; ++k) {
+                        const float dxe = exb[k] - exa[k], dye = eyb[k] - eya[k];
+                        const bool str = !aa_same_sign(eya[k], eyb[k]);
+                        const float ratio = str ? (ds * (exa[k] * dye - eya[k] * dxe)) / dye : -INFINITY;
+                        const bool better = (k == 0) ? true : (ratio > best);
+                        if (better) { best = ratio; di = k; bdx = dxe; bdy = dye; bstr = str; }
+                    }
+                    const float dc = best;
+                    if (bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f)) {
+                        // silhouette: the vertex opposite to edge di in the adjacent triangle lies on the same side as the own third vertex
+                        // (no neighbour: the own vertex, i.e. always a silhouette)
+                        int o = opp ? opp[3 * t + di] : aa_opposite_from_lists(tri, off, adj, F, t, di);
+                        o = o >= 0 ? o : (di == 0 ? v0 : (di == 1 ? v1 : v2));
+                        const float2 bo = sb[o];
+                        const float ox = bo.x - fx, oy = bo.y - fy;
+                        const float w = di == 0 ? (x1 - ox) * (y2 - oy) - (x2 - ox) * (y1 - oy)
+                                      : (di == 1 ? (x2 - ox) * (y0 - oy) - (x0 - ox) * (y2 - oy) : (x0 - ox) * (y1 - oy) - (x1 - ox) * (y0 - oy));
+                        if (aa_same_sign(w, bb)) {
                             const float dcc = fminf(fmaxf(dc, 0.f), 1.f);
                             rec.pix0 = (int)i;
                             rec.tri = t;
@@ -481,8 +482,27 @@ extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int
     return A3D_OK;
 }
 
-extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
-                              int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared, a3d_stream_t stream) {
+// the whole table from the lists (every corner looked up the way a3d_aa_analyze does it for the pairs it needs): same table, bit for bit,
+// as a3d_aa_topology's hash -- checks the list walk against the hash and the oracle, and serves callers that have the lists anyway
+__global__ __launch_bounds__(256) void aa_opp_from_lists_kernel(const int* __restrict__ tri, int F, const int* __restrict__ off,
+                                                                const int* __restrict__ adj, int* __restrict__ opp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 3 * F) opp[idx] = aa_opposite_from_lists(tri, off, adj, F, idx / 3, idx - 3 * (idx / 3));
+}
+
+extern "C" int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp, a3d_stream_t stream) {
+    A3D_CHECK_ARG(F >= 0 && (long long)3 * F < 0x7fffffffll);
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri && off && adj && opp);
+    hipLaunchKernelGGL(aa_opp_from_lists_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, (hipStream_t)stream, tri, F, off, adj, opp);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp_or_null, int B, int V,
+                              int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared,
+                              const int32_t* off_or_null, const int32_t* adj_or_null, a3d_stream_t stream) {
+    const int32_t* opp = opp_or_null;
     A3D_CHECK_ARG(rast && clip && screen && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
@@ -492,7 +512,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
         A3D_HIP(hipMemsetAsync(count, 0, sizeof(int) * AA_SHARDS, s));
         return A3D_OK;
     }
-    A3D_CHECK_ARG(tri && opp);
+    A3D_CHECK_ARG(tri && (opp || (off_or_null && adj_or_null)));  // the opposite-vertex table, or the vertex -> face lists to find them in
     const long long nvert = (long long)clip_batch * V;
     A3D_CHECK_ARG(B <= 65535);
     if (!prepared) {  // (prepared: a3d_rast_fwd of the same clip filled `screen` and zeroed `count` in its own launch)
@@ -501,7 +521,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
         A3D_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, (const float4*)rast, (const float2*)screen,
-                       clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count);
+                       clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count, off_or_null, adj_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -14,7 +14,7 @@ void a3d_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* a3d_last_error(void) { return g_err; }
-extern "C" int a3d_version(void) { return 200; /* 0.2.0: round-2 ABI (gradient rows, per-image shading rows, fused compositor, bit-plane DMTet) */ }
+extern "C" int a3d_version(void) { return 300; /* 0.3.0: round-3 ABI (skin_pose, scan-free covered-pixel list and DMTet, topology inside the DMTet emit) */ }
 
 int a3d_exp(void) {
     const char* e = getenv("A3D_EXP");

@@ -3,7 +3,11 @@
 // (The reference shades every pixel of the frame, render.py:30-132; evaluating only the covered ones is output-identical
 //  because uncovered pixels are composited with alpha 0, render.py:261-262.)
 //
-// Same three-step shape as the DMTet extraction: per-work-group ballot counts -> one-work-group scan -> ordered emit.
+// Two steps: per-work-group ballot counts (a pass of its own, or left behind by the rasteriser's resolve) + fire-and-forget adds of
+// every count into the sum of its group of 64 blocks; then the ordered emit, in which every work-group sums the group sums before
+// its group and the block counts before it inside the group itself (<= nb/64 + 64 four-byte loads from L2, eight in flight).  The
+// host reads the group sums back (ceil(nb/64) ints) and adds them up: the list's length.  No scan launch: the single-work-group scan
+// of the first version cost a launch (~9 us of event time for 16 KB of data) between the rasteriser and everything that follows.
 // One wave covers one 8x8 tile, so a work-group of 256 threads covers 4 tiles; entry k of the tile-ordered pixel space is
 //   k = ((b*H/8 + ty)*W/8 + tx)*64 + iy*8 + ix        (tile = 8)      or      k = flat index      (tile = 0, row-major).
 #include "a3d_common.h"
@@ -11,7 +15,6 @@
 namespace {
 
 constexpr int CV_BLOCK = 256;
-constexpr int CV_SCAN_THREADS = 1024;
 
 // (all 32-bit: B*H*W < 2^31 is checked by the entry points, and a 64-bit division costs ~150 instructions per thread)
 __device__ __forceinline__ long long cv_flat(long long k64, int H, int W, int tile) {
@@ -26,54 +29,56 @@ __device__ __forceinline__ long long cv_flat(long long k64, int H, int W, int ti
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
-                                                            int* __restrict__ block_count) {
+                                                            int* __restrict__ block_count, int* __restrict__ group_sum) {
     __shared__ int wave_n[CV_BLOCK / 64];
     const long long k = (long long)blockIdx.x * CV_BLOCK + threadIdx.x;
     const bool on = k < n && rast[cv_flat(k, H, W, tile)].w > 0.f;
     const unsigned long long m = __ballot(on);
     if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) block_count[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    if (threadIdx.x == 0) {
+        const int c = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+        block_count[blockIdx.x] = c;
+        if (c) atomicAdd(group_sum + (long long)(blockIdx.x / A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, c);
+    }
 }
 
-// exclusive scan of block_count[nb] in place; total[0] = number of covered pixels
-__global__ __launch_bounds__(CV_SCAN_THREADS) void cv_scan_kernel(int* __restrict__ block_count, int nb, long long* __restrict__ total) {
-    __shared__ int wave_tot[CV_SCAN_THREADS / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // contiguous run per thread, one barrier (see a3d_run_sum)
-    const int per = (nb + CV_SCAN_THREADS - 1) / CV_SCAN_THREADS;
-    const int lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
-    const int mine = a3d_run_sum(block_count, lo, hi);
-    int incl = mine;
+// entries of the list before work-group ``blk``: whole groups from the group sums, the rest of its own group from the block counts.
+// Computed by the FIRST WAVE only (<= nb/64 + 63 loads, a few per lane, all in flight at once) while the other waves are busy with
+// their pixels; the result reaches them through LDS at the barrier the kernel has anyway.
+__device__ __forceinline__ int cv_block_offset_wave0(const int* __restrict__ block_count, const int* __restrict__ group_sum, int blk) {
+    const int g = blk / A3D_COVER_GROUP, r = blk - g * A3D_COVER_GROUP;
+    const int lane = threadIdx.x & 63;
+    int mine = lane < r ? block_count[g * A3D_COVER_GROUP + lane] : 0;
+    for (int j = lane; j < g; j += 64) mine += group_sum[(long long)j * A3D_COVER_GROUP_STRIDE];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int run = incl - mine;
-    for (int w = 0; w < wave; ++w) run += wave_tot[w];
-    run = a3d_run_scan<false>(block_count, block_count, lo, hi, run);
-    if (threadIdx.x == CV_SCAN_THREADS - 1) total[0] = run;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    return mine;
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
-                                                           const int* __restrict__ block_off, long long* __restrict__ pix,
-                                                           int* __restrict__ inv) {
+                                                           const int* __restrict__ block_count, const int* __restrict__ group_sum,
+                                                           long long* __restrict__ pix, int* __restrict__ inv) {
     __shared__ int wave_n[CV_BLOCK / 64];
+    __shared__ int s_off;
     const long long k = (long long)blockIdx.x * CV_BLOCK + threadIdx.x;
     const long long flat = k < n ? cv_flat(k, H, W, tile) : 0;
-    const bool on = k < n && rast[flat].w > 0.f;
-    const unsigned long long m = __ballot(on);
+    const float idw = k < n ? rast[flat].w : 0.f;  // (issued before the offset's loads: the two latencies overlap)
     const int wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const int off = cv_block_offset_wave0(block_count, group_sum, (int)blockIdx.x);
+        if (threadIdx.x == 0) s_off = off;
+    }
+    const bool on = idw > 0.f;
+    const unsigned long long m = __ballot(on);
     if ((threadIdx.x & 63) == 0) wave_n[wave] = __popcll(m);
     __syncthreads();
+    const int block_off = s_off;
     if (!on) {
         if (inv && k < n) inv[flat] = -1;
         return;
     }
-    int o = block_off[blockIdx.x] + a3d_wave_prefix(m);
+    int o = block_off + a3d_wave_prefix(m);
     for (int w = 0; w < wave; ++w) o += wave_n[w];
     pix[o] = flat;
     if (inv) inv[flat] = o;  // pixel -> entry of the list: what the fused compositor reads
@@ -83,8 +88,13 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restr
 
 extern "C" size_t a3d_cover_scratch_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return sizeof(int) * (size_t)a3d_div_up((long long)B * H * W, CV_BLOCK);
+    const size_t nb = (size_t)a3d_div_up((long long)B * H * W, CV_BLOCK);
+    return sizeof(int) * (nb + (size_t)a3d_div_up((long long)nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE);
 }
+
+extern "C" int a3d_cover_blocks(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : a3d_div_up((long long)B * H * W, CV_BLOCK); }
+extern "C" int a3d_cover_groups(int B, int H, int W) { return a3d_div_up(a3d_cover_blocks(B, H, W), A3D_COVER_GROUP); }
+extern "C" int a3d_cover_group_stride(void) { return A3D_COVER_GROUP_STRIDE; }
 
 static int cv_check(const float* rast, int B, int H, int W, int tile, const void* scratch) {
     A3D_CHECK_ARG(rast && scratch && B > 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
@@ -92,19 +102,14 @@ static int cv_check(const float* rast, int B, int H, int W, int tile, const void
     return A3D_OK;
 }
 
-extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile, void* scratch, int counted, int64_t* total,
-                               a3d_stream_t stream) {
+extern "C" int a3d_cover_count(const float* rast, int B, int H, int W, int tile, void* scratch, a3d_stream_t stream) {
     if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
-    A3D_CHECK_ARG(total);
-    A3D_CHECK_ARG(!counted || (tile == 8 && ((long long)H * W) % CV_BLOCK == 0));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * H * W;
     const int nb = a3d_div_up(n, CV_BLOCK);
-    if (!counted) {  // (counted: a3d_rast_fwd left the block counts in scratch)
-        hipLaunchKernelGGL(cv_count_kernel, dim3(nb), dim3(CV_BLOCK), 0, s, (const float4*)rast, n, H, W, tile, (int*)scratch);
-        A3D_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(cv_scan_kernel, dim3(1), dim3(CV_SCAN_THREADS), 0, s, (int*)scratch, nb, (long long*)total);
+    int* group_sum = (int*)scratch + nb;
+    A3D_HIP(hipMemsetAsync(group_sum, 0, sizeof(int) * (size_t)a3d_div_up(nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, s));
+    hipLaunchKernelGGL(cv_count_kernel, dim3(nb), dim3(CV_BLOCK), 0, s, (const float4*)rast, n, H, W, tile, (int*)scratch, group_sum);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -114,8 +119,9 @@ extern "C" int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, 
     if (int rc = cv_check(rast, B, H, W, tile, scratch)) return rc;
     A3D_CHECK_ARG(pix || inv_or_null);  // an empty list (total = 0) has no pix storage; the inverse map is still written
     const long long n = (long long)B * H * W;
-    hipLaunchKernelGGL(cv_emit_kernel, dim3(a3d_div_up(n, CV_BLOCK)), dim3(CV_BLOCK), 0, (hipStream_t)stream, (const float4*)rast, n, H, W,
-                       tile, (const int*)scratch, (long long*)pix, inv_or_null);
+    const int nb = a3d_div_up(n, CV_BLOCK);
+    hipLaunchKernelGGL(cv_emit_kernel, dim3(nb), dim3(CV_BLOCK), 0, (hipStream_t)stream, (const float4*)rast, n, H, W, tile, (const int*)scratch,
+                       (const int*)scratch + nb, (long long*)pix, inv_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              int n1, float* __restrict__ verts, int* __restrict__ vert_edge,
                                                              long long* __restrict__ faces, long long* __restrict__ uv_idx, int nbt,
                                                              unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
-                                                             long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear) {
+                                                             long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear,
+                                                             int* __restrict__ tri32, int* __restrict__ topo_cnt) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
@@ -275,13 +276,23 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
         for (unsigned q = 0; q < n; ++q) {
             long long* fo = faces + 3 * (slot + q);
             long long* uo = uv_idx + 3 * (slot + q);
+            int ids[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 int slot_e = row[3 * q + j];
                 int eid = ev[0];
 #pragma unroll
                 for (int s = 1; s < 6; ++s) eid = (slot_e == s) ? ev[s] : eid;  // register select, no scratch
-                fo[j] = (long long)dm_vertex_of_edge(eid, edge_bits, wlocal, blk_e);
+                ids[j] = dm_vertex_of_edge(eid, edge_bits, wlocal, blk_e);
+                fo[j] = (long long)ids[j];
+            }
+            if (tri32) {
+                // the first half of the mesh topology (topology.hip: a3d_mesh_topology_finalize does the rest in ONE launch): the int32
+                // triangle list the render kernels read and the valence counts of the vertex -> face lists, from the three ids this
+                // thread holds anyway (fire-and-forget adds; this used to be a launch of its own over the finished list)
+                const int fi = (int)(slot + q);
+                tri32[3 * fi] = ids[0]; tri32[3 * fi + 1] = ids[1]; tri32[3 * fi + 2] = ids[2];
+                atomicAdd(topo_cnt + ids[0], 1); atomicAdd(topo_cnt + ids[1], 1); atomicAdd(topo_cnt + ids[2], 1);
             }
             // reference dmtet.py:91-96 with face_gidx = 2t + q
             uo[0] = 4ll * t;
@@ -372,13 +383,14 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
 extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                               void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                              a3d_stream_t stream) {
+                              int32_t* tri32_or_null, int32_t* topo_count_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && n_surf >= 0 && (n_surf == 0 || surf_idx_or_null)));
     A3D_CHECK_ARG(!g_sdf_to_clear_or_null || Nv > 0);
+    A3D_CHECK_ARG((tri32_or_null == nullptr) == (topo_count_or_null == nullptr));
     if (V == 0) {  // no crossing edge, hence no surface tet and no flagged vertex
         if (g_sdf_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_sdf_to_clear_or_null, 0, sizeof(float) * (size_t)Nv, (hipStream_t)stream));
         return A3D_OK;
@@ -391,7 +403,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     hipLaunchKernelGGL(dm_emit_kernel, dim3(d.nbe + nbt + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
-                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0);
+                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

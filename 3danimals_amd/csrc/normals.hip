@@ -2,8 +2,9 @@
 //
 // Gather formulation, no float atomics, bit-reproducible:
 //   adjacency (once per triangle list, shared by the rest and the posed mesh and by every image of the batch):
-//       CSR vertex -> incident (corner, face) entries, each list sorted by corner-major key c*F+f, i.e. the order in which the
-//       reference's three scatter_add_ passes (mesh.py:291-293) visit them.
+//       CSR vertex -> incident (corner, face) entries with corner-major keys c*F+f; the kernels below visit a list in ascending key
+//       order -- the order in which the reference's three scatter_add_ passes (mesh.py:291-293) visit them -- whether it is stored
+//       sorted (a3d_normals_adjacency, a3d_mesh_topology) or not (the lists the DMTet emit + a3d_mesh_topology_finalize build).
 //   fwd : one thread per (image, vertex) walks its list, recomputes the face's cross product (un-normalised == area weighted,
 //         mesh.py:285) and sums in list order; zero sums -> (0,0,1) (mesh.py:296-298), safe_normalize (render/util.py:28-32).
 //   bwd : per vertex the normalisation Jacobian (prepass), then one thread per (image, vertex) gathers the cross-product
@@ -38,6 +39,46 @@ __device__ __forceinline__ NrFace nr_decode(int key, int F, const int* __restric
     return r;
 }
 
+// The walk over a vertex's list is a chain of dependent gathers (list entry -> index row -> three positions): done entry by entry it
+// costs three round trips per incident face and the kernel is pure latency (9 us for 1e5 vertices, the same for 6e3).  Lists are short
+// (valence ~6), so a thread takes up to NR_SLOTS entries at once: all keys in flight, then all index rows, then all positions -- three
+// round trips per VERTEX -- and sorts the keys in registers in between (19 compare-exchanges), so the sums run in ascending key order
+// (the reference's scatter_add_ order, mesh.py:291-293) whatever order the list is stored in.  Longer lists take the entry-by-entry
+// loop for the rest (keys picked in ascending order from memory).
+#define NR_SLOTS 8
+
+__device__ __forceinline__ void nr_sort8(int a[8]) {
+#define NR_CX(i, j) { const int x = min(a[i], a[j]), y = max(a[i], a[j]); a[i] = x; a[j] = y; }
+    NR_CX(0, 1) NR_CX(2, 3) NR_CX(4, 5) NR_CX(6, 7)
+    NR_CX(0, 2) NR_CX(1, 3) NR_CX(4, 6) NR_CX(5, 7)
+    NR_CX(1, 2) NR_CX(5, 6) NR_CX(0, 4) NR_CX(3, 7)
+    NR_CX(1, 5) NR_CX(2, 6)
+    NR_CX(1, 4) NR_CX(3, 6)
+    NR_CX(2, 4) NR_CX(3, 5)
+    NR_CX(3, 4)
+#undef NR_CX
+}
+
+// the NR_SLOTS smallest keys of the list, ascending (0x7fffffff = none); for lists of up to NR_SLOTS entries: the whole list
+__device__ __forceinline__ void nr_first_keys(const int* __restrict__ adj, int lo, int n, int keys[NR_SLOTS]) {
+    nr_load_keys(adj, lo, n, keys);  // eight unconditional loads in flight
+    if (n > NR_SLOTS) {  // rare: keep the eight smallest of the whole list
+        for (int e = NR_SLOTS; e < n; ++e) {
+            const int k = adj[lo + e];
+            int imax = 0, vmax = keys[0];
+#pragma unroll
+            for (int q = 1; q < NR_SLOTS; ++q)
+                if (keys[q] > vmax) { vmax = keys[q]; imax = q; }
+            if (k < vmax) {
+#pragma unroll
+                for (int q = 0; q < NR_SLOTS; ++q)
+                    if (q == imax) keys[q] = k;
+            }
+        }
+    }
+    nr_sort8(keys);
+}
+
 __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v, const int* __restrict__ tri, const int* __restrict__ off,
                                                      const int* __restrict__ adj, int V, int F, float* __restrict__ acc,
                                                      float* __restrict__ nrm) {
@@ -46,15 +87,42 @@ __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v
     const long long vb = (long long)blockIdx.y * V;
     const float* vp = v + vb * 3;
     float x = 0.f, y = 0.f, z = 0.f;
-    const int hi = off[vi + 1];
-    for (int e = off[vi]; e < hi; ++e) {
-        const NrFace t = nr_decode(adj[e], F, tri);
-        const float* p0 = vp + 3ll * t.i0;
-        const float* p1 = vp + 3ll * t.i1;
-        const float* p2 = vp + 3ll * t.i2;
+    const int lo = off[vi], cnt = off[vi + 1] - lo;
+    if (cnt > 0) {  // (an isolated vertex -- or F == 0 -- touches neither adj nor tri)
+    int keys[NR_SLOTS];
+    nr_first_keys(adj, lo, cnt, keys);
+    NrFace t[NR_SLOTS];
+#pragma unroll
+    for (int k = 0; k < NR_SLOTS; ++k) t[k] = nr_decode(k < cnt ? keys[k] : keys[0], F, tri);  // (the first face again for unused slots: no branch)
+    float p[NR_SLOTS][9];
+#pragma unroll
+    for (int k = 0; k < NR_SLOTS; ++k) {
+        const float* p0 = vp + 3ll * t[k].i0;
+        const float* p1 = vp + 3ll * t[k].i1;
+        const float* p2 = vp + 3ll * t[k].i2;
+        p[k][0] = p0[0]; p[k][1] = p0[1]; p[k][2] = p0[2];
+        p[k][3] = p1[0]; p[k][4] = p1[1]; p[k][5] = p1[2];
+        p[k][6] = p2[0]; p[k][7] = p2[1]; p[k][8] = p2[2];
+    }
+#pragma unroll
+    for (int k = 0; k < NR_SLOTS; ++k) {
+        if (k < cnt) {
+            const float ax = p[k][3] - p[k][0], ay = p[k][4] - p[k][1], az = p[k][5] - p[k][2];
+            const float bx = p[k][6] - p[k][0], by = p[k][7] - p[k][1], bz = p[k][8] - p[k][2];
+            x += ay * bz - az * by; y += az * bx - ax * bz; z += ax * by - ay * bx;
+        }
+    }
+    int last = keys[NR_SLOTS - 1];
+    for (int e = NR_SLOTS; e < cnt; ++e) {  // valence above NR_SLOTS: the remaining entries one by one, in ascending key order
+        last = nr_next_key_mem(adj, lo, cnt, last);
+        const NrFace tt = nr_decode(last, F, tri);
+        const float* p0 = vp + 3ll * tt.i0;
+        const float* p1 = vp + 3ll * tt.i1;
+        const float* p2 = vp + 3ll * tt.i2;
         const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
         const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
         x += ay * bz - az * by; y += az * bx - ax * bz; z += ax * by - ay * bx;
+    }
     }
     const long long o = (vb + vi) * 3;
     acc[o] = x; acc[o + 1] = y; acc[o + 2] = z;
@@ -83,6 +151,19 @@ __global__ __launch_bounds__(256) void nr_vert_bwd_kernel(const float* __restric
     g_acc[3 * i] = ox; g_acc[3 * i + 1] = oy; g_acc[3 * i + 2] = oz;
 }
 
+__device__ __forceinline__ void nr_bwd_entry(int c, const float g0[3], const float g1[3], const float g2[3], const float p0[3], const float p1[3],
+                                             const float p2[3], float& ox, float& oy, float& oz) {
+    const float gx = g0[0] + g1[0] + g2[0], gy = g0[1] + g1[1] + g2[1], gz = g0[2] + g1[2] + g2[2];
+    const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+    const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+    // n = a x b :  g_a = b x g_n  (-> corner 1),  g_b = g_n x a  (-> corner 2),  corner 0 gets -(g_a + g_b)
+    const float gax = by * gz - bz * gy, gay = bz * gx - bx * gz, gaz = bx * gy - by * gx;
+    const float gbx = gy * az - gz * ay, gby = gz * ax - gx * az, gbz = gx * ay - gy * ax;
+    if (c == 1) { ox += gax; oy += gay; oz += gaz; }
+    else if (c == 2) { ox += gbx; oy += gby; oz += gbz; }
+    else { ox -= gax + gbx; oy -= gay + gby; oz -= gaz + gbz; }
+}
+
 __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g_acc, const float* __restrict__ v, const int* __restrict__ tri,
                                                      const int* __restrict__ off, const int* __restrict__ adj, int V, int F,
                                                      float* __restrict__ g_v) {
@@ -92,24 +173,42 @@ __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g
     const float* vp = v + vb * 3;
     const float* gp = g_acc + vb * 3;
     float ox = 0.f, oy = 0.f, oz = 0.f;
-    const int hi = off[vi + 1];
-    for (int e = off[vi]; e < hi; ++e) {
-        const NrFace t = nr_decode(adj[e], F, tri);
-        const float* g0 = gp + 3ll * t.i0;
-        const float* g1 = gp + 3ll * t.i1;
-        const float* g2 = gp + 3ll * t.i2;
-        const float gx = g0[0] + g1[0] + g2[0], gy = g0[1] + g1[1] + g2[1], gz = g0[2] + g1[2] + g2[2];
-        const float* p0 = vp + 3ll * t.i0;
-        const float* p1 = vp + 3ll * t.i1;
-        const float* p2 = vp + 3ll * t.i2;
-        const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
-        const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
-        // n = a x b :  g_a = b x g_n  (-> corner 1),  g_b = g_n x a  (-> corner 2),  corner 0 gets -(g_a + g_b)
-        const float gax = by * gz - bz * gy, gay = bz * gx - bx * gz, gaz = bx * gy - by * gx;
-        const float gbx = gy * az - gz * ay, gby = gz * ax - gx * az, gbz = gx * ay - gy * ax;
-        if (t.c == 1) { ox += gax; oy += gay; oz += gaz; }
-        else if (t.c == 2) { ox += gbx; oy += gby; oz += gbz; }
-        else { ox -= gax + gbx; oy -= gay + gby; oz -= gaz + gbz; }
+    const int lo = off[vi], cnt = off[vi + 1] - lo;
+    if (cnt > 0) {
+    int keys[NR_SLOTS];
+    nr_first_keys(adj, lo, cnt, keys);
+    NrFace t[NR_SLOTS];
+#pragma unroll
+    for (int k = 0; k < NR_SLOTS; ++k) t[k] = nr_decode(k < cnt ? keys[k] : keys[0], F, tri);
+    // two half-batches of four entries: 18 gathered floats per entry (positions + adjoints of the three corners) in flight at once
+#pragma unroll
+    for (int h = 0; h < NR_SLOTS; h += 4) {
+        float p[4][9], g[4][9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i0 = t[h + k].i0, i1 = t[h + k].i1, i2 = t[h + k].i2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                p[k][q] = vp[3ll * i0 + q]; p[k][3 + q] = vp[3ll * i1 + q]; p[k][6 + q] = vp[3ll * i2 + q];
+                g[k][q] = gp[3ll * i0 + q]; g[k][3 + q] = gp[3ll * i1 + q]; g[k][6 + q] = gp[3ll * i2 + q];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (h + k < cnt) nr_bwd_entry(t[h + k].c, g[k], g[k] + 3, g[k] + 6, p[k], p[k] + 3, p[k] + 6, ox, oy, oz);
+    }
+    int last = keys[NR_SLOTS - 1];
+    for (int e = NR_SLOTS; e < cnt; ++e) {
+        last = nr_next_key_mem(adj, lo, cnt, last);
+        const NrFace tt = nr_decode(last, F, tri);
+        float p[9], g[9];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            p[q] = vp[3ll * tt.i0 + q]; p[3 + q] = vp[3ll * tt.i1 + q]; p[6 + q] = vp[3ll * tt.i2 + q];
+            g[q] = gp[3ll * tt.i0 + q]; g[3 + q] = gp[3ll * tt.i1 + q]; g[6 + q] = gp[3ll * tt.i2 + q];
+        }
+        nr_bwd_entry(tt.c, g, g + 3, g + 6, p, p + 3, p + 6, ox, oy, oz);
+    }
     }
     const long long o = (vb + vi) * 3;
     g_v[o] = ox; g_v[o + 1] = oy; g_v[o + 2] = oz;
@@ -138,22 +237,25 @@ extern "C" int a3d_normals_adjacency(const int32_t* tri, int V, int F, int32_t* 
 }
 
 extern "C" int a3d_normals_fwd(const float* v, const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* acc,
-                               float* nrm, a3d_stream_t stream) {
+                               float* nrm, int lists_sorted, a3d_stream_t stream) {
     A3D_CHECK_ARG(v && off && acc && nrm && B > 0 && V > 0 && F >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
+    (void)lists_sorted;  // (kept in the ABI: the kernels order the keys themselves, a sorted list is simply an easy input)
     hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, (hipStream_t)stream, v, tri, off, adj, V, F, acc, nrm);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float* acc, const float* v, const int32_t* tri, const int32_t* off,
-                               const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, a3d_stream_t stream) {
+                               const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, int lists_sorted,
+                               a3d_stream_t stream) {
     A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * V;
     hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, n, g_acc_scratch);
     A3D_LAUNCH_CHECK();
+    (void)lists_sorted;
     hipLaunchKernelGGL(nr_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v);
     A3D_LAUNCH_CHECK();
     return A3D_OK;

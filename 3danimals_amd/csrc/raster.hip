@@ -24,6 +24,7 @@
 // and the triangle ids match the oracle bit for bit.
 #include "a3d_common.h"
 #include "raster_common.h"
+#include "topo_common.h"
 
 #define RS_COOP_AREA 64  // boxes above this many pixels are rasterised by all 64 lanes of the wave
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -105,8 +106,23 @@ __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, 
 // 4 lanes per (image, triangle); blockDim = 256 = 64 triangles
 __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
                                                      int H, int W, unsigned long long* __restrict__ keys, const float4* __restrict__ prev,
-                                                     int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards) {
+                                                     int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards,
+                                                     int* __restrict__ cover_group_sum, int cover_groups, int nb_screen,
+                                                     const int* __restrict__ topo_off, const int* __restrict__ topo_adj,
+                                                     int* __restrict__ topo_opp) {
     const int b = blockIdx.y;
+    if ((int)blockIdx.x >= nb_tri + nb_screen) {
+        // more extra work-groups (image 0 only): the opposite-vertex table of the silhouette analysis, looked up in the vertex -> face
+        // lists the DMTet extraction left (no edge hash on that path).  Each lookup is a chain of five dependent gathers -- inside the
+        // analysis it doubled that kernel's time (13 -> 24 us); here it runs beside the triangle work of the same launch for free.
+        if (b != 0) return;
+        const int idx = ((int)blockIdx.x - nb_tri - nb_screen) * 256 + threadIdx.x;
+        if (idx < 3 * F) topo_opp[idx] = aa_opposite_from_lists(tri, topo_off, topo_adj, F, idx / 3, idx - 3 * (idx / 3));
+        return;
+    }
+    // the covered-pixel list's group sums, accumulated by the resolve launch that follows: zeroed here (no memset launch)
+    if (cover_group_sum && blockIdx.x == 0 && b == 0)
+        for (int i = threadIdx.x; i < cover_groups; i += blockDim.x) cover_group_sum[i] = 0;
     if ((int)blockIdx.x >= nb_tri) {
         // extra work-groups: what the silhouette analysis of this frame needs first -- pixel-space vertex positions, once per (image,
         // vertex), with the operations of antialias.hip's aa_screen_kernel (p.x / p.w * W/2, unfused), and its append counters at zero
@@ -202,7 +218,12 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
         const unsigned long long m = __ballot(key != RS_EMPTY);
         if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
         __syncthreads();
-        if (threadIdx.x == 0) cover_block_count[(long long)b * gridDim.x + blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (threadIdx.x == 0) {
+            const int blk = b * (int)gridDim.x + (int)blockIdx.x, c = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            cover_block_count[blk] = c;
+            // the sum of this block's group of 64 (cover.hip): <= 64 fire-and-forget adds per address
+            if (c) atomicAdd(cover_block_count + (long long)gridDim.x * gridDim.y + (long long)(blk / A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, c);
+        }
     }
 }
 
@@ -253,7 +274,8 @@ extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(un
 
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                             void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                            float* aa_screen_or_null, int32_t* aa_count_or_null, a3d_stream_t stream) {
+                            float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null,
+                            const int32_t* topo_adj_or_null, int32_t* topo_opp_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
@@ -262,18 +284,22 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     const long long npix = (long long)B * H * W;
     // the covered-pixel block counts ride along when the list's tile order applies and its blocks do not cross images
     A3D_CHECK_ARG(!cover_scratch_or_null || (H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0));
+    const int cover_nb = (int)(npix / 256), cover_ng = a3d_div_up(cover_nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE;  // (words of the group-sum area)
     if (F == 0) {
         A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)npix, s));
-        if (cover_scratch_or_null) A3D_HIP(hipMemsetAsync(cover_scratch_or_null, 0, sizeof(int) * (size_t)(npix / 256), s));
+        if (cover_scratch_or_null) A3D_HIP(hipMemsetAsync(cover_scratch_or_null, 0, sizeof(int) * ((size_t)cover_nb + cover_ng), s));
         return A3D_OK;
     }
     unsigned long long* keys = (unsigned long long*)scratch;
     if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     A3D_CHECK_ARG((aa_screen_or_null == nullptr) == (aa_count_or_null == nullptr) && a3d_aa_shards() <= 256);
-    const int nb_tri = a3d_div_up(F, 64);
-    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + (aa_screen_or_null ? a3d_div_up(V, 256) : 0), B), dim3(256), 0, s, (const float4*)clip, clip_batch,
+    A3D_CHECK_ARG((topo_opp_or_null == nullptr) == (topo_off_or_null == nullptr) && (topo_opp_or_null == nullptr) == (topo_adj_or_null == nullptr));
+    const int nb_tri = a3d_div_up(F, 64), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
+    const int nb_opp = topo_opp_or_null ? a3d_div_up(3ll * F, 256) : 0;
+    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + nb_screen + nb_opp, B), dim3(256), 0, s, (const float4*)clip, clip_batch,
                        tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null,
-                       a3d_aa_shards());
+                       a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen,
+                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null);
     A3D_LAUNCH_CHECK();
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,

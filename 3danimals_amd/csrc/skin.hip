@@ -7,6 +7,7 @@
 // and the softmax runs in registers over the K cached logits.  Weights are recomputed in backward instead of stored.
 // HBM traffic: 12 B/vertex in (shared prior: once per image from L2), 12 B/vertex out.
 #include "a3d_common.h"
+#include "bones_common.h"
 
 #define SK_THREADS 256
 #define SK_MAXK 64
@@ -15,8 +16,7 @@ struct SkBone {
     float ax, ay, az, dx, dy, dz, inv_len2;
 };
 
-__device__ __forceinline__ void sk_stage(const float* __restrict__ bones, const float* __restrict__ T, int K, SkBone* s_bone,
-                                         float* s_T) {
+__device__ __forceinline__ void sk_stage_bones(const float* __restrict__ bones, int K, SkBone* s_bone) {
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const float* b = bones + 6 * k;
         SkBone sb;
@@ -26,6 +26,11 @@ __device__ __forceinline__ void sk_stage(const float* __restrict__ bones, const 
         sb.inv_len2 = 1.f / fmaxf(l2, 1e-6f);  // geometry/util.py:41
         s_bone[k] = sb;
     }
+}
+
+__device__ __forceinline__ void sk_stage(const float* __restrict__ bones, const float* __restrict__ T, int K, SkBone* s_bone,
+                                         float* s_T) {
+    sk_stage_bones(bones, K, s_bone);
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) s_T[i] = T[i];
 }
 
@@ -40,17 +45,45 @@ __device__ __forceinline__ float sk_logit(const SkBone& b, float px, float py, f
 
 // KMAX = compile-time bound on K: the K logits of a vertex (a sqrt each) are computed ONCE and stay in registers for the
 // max / sum / blend passes (the first version recomputed them per pass: 3 sqrt chains per bone per vertex).
-template <int KMAX>
+// POSE (a3d_skin_pose_fwd): ``T`` is an OUTPUT -- every work-group composes the K chain transforms of its image itself (links built
+// once into LDS, every bone multiplies the <= 8 links of its chain: the work of bones.hip's bn_fwd_kernel, ~1 us per work-group, all
+// work-groups at once) instead of reading the result of a separate launch; the first work-group of an image also writes them out for
+// the backward and for posed_bones.  ``angles`` [B,K,3], ``chain`` [K,D]; ``clear`` then also covers the backward's tickets.
+template <int KMAX, bool POSE>
 __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restrict__ v, int v_batch, const float* __restrict__ bones,
-                                                            int bones_batch, const float* __restrict__ T, int V, int K,
+                                                            int bones_batch, float* T, int V, int K,
                                                             float neg_inv_temp, float* __restrict__ out, float* __restrict__ weights,
-                                                            float* __restrict__ clear, int n_clear) {
+                                                            float* __restrict__ clear, int n_clear, const float* __restrict__ angles,
+                                                            const int* __restrict__ chain, int D, float* __restrict__ PS) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     const int b = blockIdx.y;
     // the backward's per-image transform gradient (accumulated there with atomics) cleared here: one memset less on the backward path
     for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; z < n_clear; z += gridDim.x * gridDim.y * blockDim.x) clear[z] = 0.f;
-    sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
+    if (POSE) {
+        __shared__ float s_L[POSE ? SK_MAXK : 1][13];
+        __shared__ int s_chain[POSE ? SK_MAXK * BN_MAXD : 1];
+        const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6);
+        const float* aa = angles + (long long)b * K * 3;
+        for (int w = threadIdx.x; w < K * D; w += blockDim.x) s_chain[w] = chain[w];
+        for (int i = threadIdx.x; i < K; i += blockDim.x) bn_store(s_L[i], bn_link(bb + 6 * i, aa + 3 * i));
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            A34 acc = bn_identity();
+            for (int j = 0; j < D; ++j) {
+                const int i = s_chain[k * D + j];
+                if (i >= 0) acc = bn_mul(acc, bn_load(s_L[i]));
+            }
+            bn_store(s_T + 12 * k, acc);
+            if (blockIdx.x == 0) bn_store(T + ((long long)b * K + k) * 12, acc);
+        }
+        // one work-group per image (not the one that writes T) leaves the prefix / suffix products of every chain position for the
+        // backward's tail (bn_chain_adjoint_ps): off the critical path here, ~7 us off it there
+        if (PS && blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * K * D * 24);
+        sk_stage_bones(bb, K, s_bone);
+    } else {
+        sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
+    }
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
@@ -95,11 +128,18 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
 // phase 2 (wave = bone group): g_T[b,k] = sum_v w_k(v) * g(v) (x) [v,1] -- a [K x V].[V x 12] product per image.  Wave w owns the bones
 //          [w*KG, (w+1)*KG); every lane keeps KG x 12 partial sums in registers while it strides over the chunk's vertices in LDS, and
 //          the cross-lane reduction happens once per block (KG*12 butterfly sums), not once per vertex.
-template <int KG>
+// POSE (a3d_skin_pose_bwd): the work-group that finishes an image LAST (a ticket per image, taken after a device-scope fence behind the
+// work-group's g_T atomics) goes on to run the adjoint of the chain composition for that image (bones_common.h: bn_chain_adjoint, the
+// work of bones.hip's bn_bwd_kernel) on the now complete g_T[b] -- one launch and one launch gap less on a latency-bound stretch.  Per
+// image ~24 work-groups meet at one ticket, at different times: the contention that rules such tickets out for 4096-work-group launches
+//  does not arise.
+template <int KG, bool POSE>
 __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
                                                             const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
                                                             int V, int K, float neg_inv_temp, int chunks_per_block, float* __restrict__ g_v,
-                                                            float* __restrict__ g_T) {
+                                                            float* g_T, const float* __restrict__ angles, const int* __restrict__ chain, int D,
+                                                            int* __restrict__ ticket, const float* __restrict__ g_T_extra,
+                                                            float* __restrict__ g_angles, const float* __restrict__ PS) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     __shared__ float s_w[4 * KG][SK_THREADS];
@@ -195,7 +235,31 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
     for (int t = threadIdx.x; t < (SK_THREADS / 64) * KG * 12; t += SK_THREADS) {
         const int w = t / (KG * 12), j = t - w * (KG * 12);
         const int k = w * KG + j / 12;
-        if (k < K) atomicAdd(g_T + ((long long)b * K + k) * 12 + (j % 12), s_red[0][w][j] + s_red[1][w][j] + s_red[2][w][j] + s_red[3][w][j]);
+        if (k < K) {
+            float* dst = g_T + ((long long)b * K + k) * 12 + (j % 12);
+            const float val = s_red[0][w][j] + s_red[1][w][j] + s_red[2][w][j] + s_red[3][w][j];
+            if (POSE) {
+                // RETURNING form, and the returned value is consumed: the wave then waits until the device-scope atomic has been performed
+                // at the memory side, which is what orders it before the ticket below.  (A __threadfence() here is a write-back +
+                // invalidate of the whole L2 of the XCD on gfx950 -- buffer_wbl2 / buffer_inv -- and took this kernel from 14 to 46 us.)
+                const float old = __hip_atomic_fetch_add(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(old));
+            } else {
+                atomicAdd(dst, val);
+            }
+        }
+    }
+    if (POSE) {
+        __shared__ float s_adj[POSE ? 4 * 20 * BN_MAXD + 20 * 20 : 1];
+        __shared__ int s_last;
+        __syncthreads();  // every thread's atomics have returned
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (!s_last) return;
+        // (bn_chain_adjoint_ps reads g_T with agent-scope loads, which do not hit in this XCD's L2)
+        bn_chain_adjoint_ps(g_T + (long long)b * K * 12, g_T_extra ? g_T_extra + (long long)b * K * 12 : nullptr,
+                            PS + (long long)b * K * D * 24, bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6),
+                            angles + (long long)b * K * 3, chain, K, D, g_angles + (long long)b * K * 3, s_adj);
     }
 }
 
@@ -208,9 +272,13 @@ extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
     const int ncl = g_T_to_clear_or_null ? B * K * 12 : 0;
-    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
-    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
-    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK>), grid, block, 0, s, v, v_batch, bones, bones_batch, T, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl);
+    float* Tm = const_cast<float*>(T);  // (read only without POSE)
+    const float* no_angles = nullptr;
+    const int* no_chain = nullptr;
+    float* no_ps = nullptr;
+    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
+    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
+    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -228,9 +296,56 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
     int cpb = a3d_div_up((long long)chunks * B, 4096);
     if (cpb < 1) cpb = 1;
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
-    if (K <= 20) hipLaunchKernelGGL((sk_bwd_kernel<5>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
-    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_kernel<8>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
-    else hipLaunchKernelGGL((sk_bwd_kernel<16>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T);
+    const float* nf = nullptr;
+    const int* ni = nullptr;
+    int* nt = nullptr;
+    float* ng = nullptr;
+    if (K <= 20) hipLaunchKernelGGL((sk_bwd_kernel<5, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
+    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_kernel<8, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
+    else hipLaunchKernelGGL((sk_bwd_kernel<16, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+// ---- kinematic chain + skinning in ONE launch each way (K <= 20 bones, chains of D <= 8 links: every configuration of the reference)
+extern "C" int a3d_skin_pose_max_bones(void) { return 20; }
+
+extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain,
+                                 int B, int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null,
+                                 float* g_T_to_clear_or_null, int32_t* ticket_to_clear_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(v && bones && angles && chain && out && T_out);
+    A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= 20 && D > 0 && D <= BN_MAXD && temperature > 0.f);
+    A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
+    // g_T[B,K,12] and the B tickets are cleared as ONE run of 4-byte words: the caller allocates them back to back
+    A3D_CHECK_ARG((g_T_to_clear_or_null == nullptr) == (ticket_to_clear_or_null == nullptr));
+    A3D_CHECK_ARG(!g_T_to_clear_or_null || (void*)ticket_to_clear_or_null == (void*)(g_T_to_clear_or_null + (size_t)B * K * 12));
+    const dim3 grid(a3d_div_up(V, SK_THREADS), B), block(SK_THREADS);
+    const int ncl = g_T_to_clear_or_null ? B * K * 12 + B : 0;
+    float* no_w = nullptr;
+    hipLaunchKernelGGL((sk_fwd_kernel<20, true>), grid, block, 0, (hipStream_t)stream, v, v_batch, bones, bones_batch, T_out, V, K,
+                       -1.f / temperature, out, no_w, g_T_to_clear_or_null, ncl, angles, chain, D, chain_products_or_null);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T,
+                                 const float* chain_products, const float* angles, const int32_t* chain, int B, int V, int K, int D,
+                                 float temperature, float* g_v_or_null, float* g_T, int32_t* ticket, int scratch_is_clear,
+                                 const float* g_T_extra_or_null, float* g_angles, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && v && bones && T && chain_products && angles && chain && g_T && ticket && g_angles);
+    A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= 20 && D > 0 && D <= BN_MAXD && temperature > 0.f);
+    A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
+    hipStream_t s = (hipStream_t)stream;
+    if (!scratch_is_clear) {
+        A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
+        A3D_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t) * (size_t)B, s));
+    }
+    const int chunks = a3d_div_up(V, SK_THREADS);
+    int cpb = a3d_div_up((long long)chunks * B, 4096);
+    if (cpb < 1) cpb = 1;
+    const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
+    hipLaunchKernelGGL((sk_bwd_kernel<5, true>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, -1.f / temperature, cpb,
+                       g_v_or_null, g_T, angles, chain, D, ticket, g_T_extra_or_null, g_angles, chain_products);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -19,12 +19,10 @@ __device__ __forceinline__ unsigned aa_hash(unsigned long long k) {
     return (unsigned)k;
 }
 
-// corner idx = 3f + i owns the edge opposite to it, (tri[f][(i+1)%3], tri[f][(i+2)%3]); the table keeps, per undirected edge and
+// corner i of face f owns the edge opposite to it, (a, b) = (tri[f][(i+1)%3], tri[f][(i+2)%3]); the table keeps, per undirected edge and
 // per traversal direction, the smallest code f*4+i that claimed it (atomicMin => deterministic)
-__device__ __forceinline__ void aa_insert_edge(const int* __restrict__ tri, int idx, unsigned mask, unsigned long long* __restrict__ keys,
-                                               int* __restrict__ vals) {
-    const int f = idx / 3, i = idx - 3 * f;
-    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
+__device__ __forceinline__ void aa_insert_edge_ab(int a, int b, int code, unsigned mask, unsigned long long* __restrict__ keys,
+                                                  int* __restrict__ vals) {
     if (a == b) return;
     const int d = a < b ? 0 : 1;
     const unsigned long long key = a < b ? (((unsigned long long)(unsigned)a << 32) | (unsigned)b)
@@ -33,11 +31,17 @@ __device__ __forceinline__ void aa_insert_edge(const int* __restrict__ tri, int 
     for (unsigned probe = 0; probe <= mask; ++probe) {
         const unsigned long long old = atomicCAS(&keys[h], AA_EMPTY_KEY, key);
         if (old == AA_EMPTY_KEY || old == key) {
-            atomicMin(&vals[2 * h + d], f * 4 + i);
+            atomicMin(&vals[2 * h + d], code);
             return;
         }
         h = (h + 1) & mask;
     }
+}
+
+__device__ __forceinline__ void aa_insert_edge(const int* __restrict__ tri, int idx, unsigned mask, unsigned long long* __restrict__ keys,
+                                               int* __restrict__ vals) {
+    const int f = idx / 3, i = idx - 3 * f;
+    aa_insert_edge_ab(tri[3 * f + (i + 1) % 3], tri[3 * f + (i + 2) % 3], f * 4 + i, mask, keys, vals);
 }
 
 // vertex opposite to corner idx's edge in the adjacent triangle (-1: boundary edge)
@@ -64,6 +68,82 @@ __device__ __forceinline__ int aa_lookup_edge(const int* __restrict__ tri, int i
         h = (h + 1) & mask;
     }
     return -1;
+}
+
+// The same answer WITHOUT a hash, from the vertex -> (corner, face) lists (any storage order): every face that holds both end points of
+// the edge is found in a's list; per traversal direction the lowest code f'*4+i' is kept, exactly what the hash's atomicMin leaves.
+// ~valence x (1 + 3) L2-resident loads: for callers that need a few thousand lookups (the silhouette analysis asks only for pixel
+// pairs that passed every geometric test), not a table for all 3F corners.
+__device__ __forceinline__ void aa_consider_face(int key, int u0, int u1, int u2, int F, int a, int b, int slot[2]) {
+    const int c = key >= 2 * F ? 2 : (key >= F ? 1 : 0);  // a sits at corner c of face g
+    const int g = key - c * F;
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+        const int ub = cb == 0 ? u0 : (cb == 1 ? u1 : u2);
+        if (cb == c || ub != b) continue;
+        const int io = 3 - c - cb;  // the corner opposite to the edge in g; g traverses the edge from corner io+1 to corner io+2
+        const int ea = (io + 1) % 3 == c ? a : b, eb = (io + 1) % 3 == c ? b : a;
+        const int dd = ea < eb ? 0 : 1;
+        const int code = g * 4 + io;
+        slot[dd] = code < slot[dd] ? code : slot[dd];
+    }
+}
+
+__device__ __forceinline__ int aa_opposite_from_lists(const int* __restrict__ tri, const int* __restrict__ off, const int* __restrict__ adj,
+                                                      int F, int f, int i) {
+    const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
+    if (a == b) return -1;
+    const int d = a < b ? 0 : 1;
+    int slot[2] = {AA_NONE, AA_NONE};
+    const int lo = off[a], n = off[a + 1] - lo;
+    // up to eight entries at once: all keys in flight, then all index rows in flight (two round trips instead of two per entry)
+    int keys[8], rows[8][3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) keys[k] = adj[lo + (k < n ? k : 0)];  // (n >= 1: the face f itself is in a's list)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = keys[k] >= 2 * F ? 2 : (keys[k] >= F ? 1 : 0);
+        const int g = keys[k] - c * F;
+        rows[k][0] = tri[3 * g]; rows[k][1] = tri[3 * g + 1]; rows[k][2] = tri[3 * g + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < n) aa_consider_face(keys[k], rows[k][0], rows[k][1], rows[k][2], F, a, b, slot);
+    for (int e = 8; e < n; ++e) {  // valence above eight: the rest one by one
+        const int key = adj[lo + e];
+        const int c = key >= 2 * F ? 2 : (key >= F ? 1 : 0);
+        const int g = key - c * F;
+        aa_consider_face(key, tri[3 * g], tri[3 * g + 1], tri[3 * g + 2], F, a, b, slot);
+    }
+    int other = slot[1 - d];
+    if (other == AA_NONE) {
+        const int same = slot[d];
+        if (same != AA_NONE && same != f * 4 + i) other = same;
+    }
+    return other != AA_NONE ? tri[3 * (other >> 2) + (other & 3)] : -1;
+}
+
+// Vertex -> (corner, face) lists may be stored in any order (the fused DMTet path fills them with atomics and does not sort); the
+// consumers visit a list in ascending key order all the same -- corner-major, the order of the reference's three scatter_add_ passes
+// (mesh.py:291-293) -- so their float sums do not depend on the fill order: the smallest key above ``last``.  Lists are short
+// (valence ~6): up to 8 keys are held in registers (``regs``, loaded once by nr_load_keys), longer lists are re-read from memory.
+__device__ __forceinline__ void nr_load_keys(const int* __restrict__ adj, int lo, int n, int regs[8]) {
+    // eight UNCONDITIONAL loads (clamped index) in flight, then the selects: a load under `k < n ? .. : ..` becomes a branch with its
+    // own wait, i.e. eight dependent round trips (measured: the normals kernels went from 9 to 13-15 us)
+    int raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = adj[lo + (k < n ? k : 0)];  // (callers guarantee n >= 1)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) regs[k] = k < n ? raw[k] : 0x7fffffff;
+}
+// smallest key above ``last`` in a list read from memory (lists longer than the register slots)
+__device__ __forceinline__ int nr_next_key_mem(const int* __restrict__ adj, int lo, int n, int last) {
+    int best = 0x7fffffff;
+    for (int k = 0; k < n; ++k) {
+        const int a = adj[lo + k];
+        best = (a > last && a < best) ? a : best;
+    }
+    return best;
 }
 
 namespace {

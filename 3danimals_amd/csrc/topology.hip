@@ -62,7 +62,81 @@ __global__ __launch_bounds__(256) void tp_sort_rearm_kernel(const int* __restric
     }
 }
 
+// ---- second half of the fused DMTet path: the emit launch (dmtet.hip) already wrote the int32 triangle list and counted the valences.
+// ONE launch (the stand-alone entry point above needs four, plus an init on first use) finishes the vertex -> (corner, face) lists:
+//   every work-group scans the V valence counts into LDS itself (V+1 ints; the first one also writes off[] out) -- no scan launch;
+//   thread = corner: slot in its vertex's list from an atomicAdd on the HIGH half of the count word (the low half stays readable for
+//   work-groups that scan later), entry written;
+//   the lists stay UNSORTED: the normals kernels take a vertex's whole list into registers and order the keys there (normals.hip) --
+//   no sort launch;
+//   the count array of the NEXT extraction (the two alternate) is zeroed by grid-stride stores -- no init launch.
+// There is no edge hash and no opposite-vertex table on this path: the silhouette analysis looks the few opposite vertices it needs up
+// in these lists (topo_common.h: aa_opposite_from_lists, two batched round trips per lookup).
+// (Measured on the way: hash inserts inside the emit launch -- three serial CAS chains per face thread: emit 17 -> 38 us; hash insert
+//  in this launch + a sort/lookup launch: 12 + 9 us of kernel time, as much as the four launches they replace.)
+__global__ __launch_bounds__(256) void tp_finalize_kernel(const int* __restrict__ tri, int F, int V, int* cnt, int* __restrict__ off,
+                                                          int* __restrict__ adj, int* __restrict__ cnt_next, int v_next) {
+    extern __shared__ int s_off[];  // [V + 1]
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * blockDim.x + tid;
+    const int my_v = idx < 3 * F ? tri[idx] : -1;  // (issued first: overlaps with the scan)
+    {   // exclusive scan of (cnt & 0xFFFF) over the vertices: a contiguous run per thread, eight unconditional loads in flight
+        const int per = (V + 255) / 256;
+        const int lo = min(tid * per, V), hi = min(lo + per, V);
+        int mine = 0;
+        for (int i = lo; i < hi; i += 8) {
+            int c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = cnt[min(i + k, V - 1)] & 0xFFFF;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (i + k < hi) {
+                    s_off[i + k] = mine;  // run-local exclusive prefix; the run's base is added below
+                    mine += c[k];
+                }
+            }
+        }
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int base = incl - mine;
+        for (int w = 0; w < wave; ++w) base += s_wave[w];
+        for (int i = lo; i < hi; ++i) s_off[i] += base;
+        if (tid == 255) s_off[V] = base + mine;
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int i = tid; i <= V; i += 256) off[i] = s_off[i];
+    }
+    if ((unsigned)my_v < (unsigned)V) {
+        const int f = idx / 3, c = idx - 3 * f;
+        const int slot = atomicAdd(cnt + my_v, 0x10000) >> 16;
+        adj[s_off[my_v] + slot] = c * F + f;
+    }
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + tid; i < (unsigned)v_next; i += stride) cnt_next[i] = 0;
+}
+
 }  // namespace
+
+extern "C" int a3d_mesh_topology_finalize_max_vertices(void) { return 36 * 1024 - 1; }  // (V + 1) ints of LDS per work-group <= 144 KB
+
+extern "C" int a3d_mesh_topology_finalize(const int32_t* tri, int V, int F, int32_t* count, int32_t* off, int32_t* adj, int32_t* count_next,
+                                          int v_next, a3d_stream_t stream) {
+    A3D_CHECK_ARG(tri && count && off && adj && count_next && V > 0 && F > 0 && v_next >= 0);
+    A3D_CHECK_ARG(V <= a3d_mesh_topology_finalize_max_vertices() && (long long)3 * F < 0x7fffffffll);
+    const size_t lds = sizeof(int) * ((size_t)V + 1);
+    if (lds > 48 * 1024) A3D_HIP(hipFuncSetAttribute((const void*)tp_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tp_finalize_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), lds, (hipStream_t)stream, tri, F, V, count, off, adj,
+                       count_next, v_next);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
 
 extern "C" int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
                                  int scratch_is_clean, a3d_stream_t stream) {

@@ -359,6 +359,9 @@ class _LazyAux(dict):
             return default
 
 
+FUSED_POSE = True  # chain composition inside the skinning launches (a3d_skin_pose_*); False = a3d_bone_transforms_* + a3d_skin_*
+
+
 def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bones=False, temperature=1):
     """Linear-blend skinning (reference :369-439).
 
@@ -368,11 +371,7 @@ def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bone
     """
     B, Fr = deform_params.shape[:2]
     K, V = bones_pred.shape[2], v_pos.shape[-2]
-    # per-bone world transforms from the kinematic chain: one HIP launch (csrc/bones.hip), gradients reach deform_params
     chain32 = _chain_index32(kinematic_tree, deform_params.device)
-    bones_nk = bones_pred.detach().reshape(-1, K, 2, 3) if (bones_pred.shape[0] == 1 and bones_pred.shape[1] == 1) else \
-        bones_pred.detach().expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
-    T = ops.bone_transforms(bones_nk, deform_params.reshape(B * Fr, K, 3), chain32)  # [B*F,K,12]
 
     def flat(x, tail):
         if x.shape[0] == 1 and x.shape[1] == 1:
@@ -381,7 +380,14 @@ def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bone
 
     v_flat = flat(v_pos, (V, 3))
     bones_flat = flat(bones_pred.detach(), (K, 2, 3))
-    out = ops.skin(v_flat, bones_flat, T, temperature).view(B, Fr, V, 3)
+    if FUSED_POSE and ops.skin_pose_supported(K, chain32.shape[1]):
+        # kinematic chain + blend in ONE launch each way (csrc/skin.hip): every work-group composes its image's transforms itself
+        out, T = ops.skin_pose(v_flat, bones_flat, deform_params.reshape(B * Fr, K, 3), chain32, temperature)
+        out = out.view(B, Fr, V, 3)
+    else:
+        # per-bone world transforms from the kinematic chain: one HIP launch (csrc/bones.hip), gradients reach deform_params
+        T = ops.bone_transforms(bones_flat, deform_params.reshape(B * Fr, K, 3), chain32)  # [B*F,K,12]
+        out = ops.skin(v_flat, bones_flat, T, temperature).view(B, Fr, V, 3)
 
     def weights():
         w = ops.skin_weights(v_flat.detach(), bones_flat, B * Fr, temperature)  # [K,Bw,V]

@@ -80,15 +80,25 @@ def tri_int32(tri: torch.Tensor) -> torch.Tensor:
 class AATopology:
     """opp[F,3] for one triangle list (nvdiffrast's topology hash), built by a3d_aa_topology."""
 
-    def __init__(self, tri32: torch.Tensor, num_vertices: int, build: bool = True):
+    def __init__(self, tri32: torch.Tensor, num_vertices: int, build: bool = True, lists=None):
+        """``lists`` (a VertexFaceAdjacency of the same triangle list) instead of the table: a3d_aa_analyze then looks the opposite
+        vertices it needs up in the vertex -> face lists (the DMTet extraction's topology builds no hash and no table)."""
         require_device(tri32, what="aa_topology")
         F = tri32.shape[0]
-        self.tri = tri32
-        self.opp = torch.empty((F, 3), dtype=torch.int32, device=tri32.device)
+        self.tri, self.lists = tri32, lists
+        self.opp = torch.empty((F, 3), dtype=torch.int32, device=tri32.device) if lists is None else None
         if F > 0 and build:
             nbytes = _lib.lib().a3d_aa_hash_bytes(F)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=tri32.device)
             call("a3d_aa_topology", ptr(tri32), F, int(num_vertices), ptr(scratch), ptr(self.opp), stream())
+
+
+def opposite_vertices_from_lists(adjacency) -> torch.Tensor:
+    """opp[F,3] from the vertex -> face lists (a3d_aa_topology_from_lists): the table a3d_aa_topology builds with its hash."""
+    tri32 = adjacency.tri
+    opp = torch.empty((tri32.shape[0], 3), dtype=torch.int32, device=tri32.device)
+    call("a3d_aa_topology_from_lists", ptr(tri32), tri32.shape[0], ptr(adjacency.off), ptr(adjacency.adj), ptr(opp), stream())
+    return opp
 
 
 def aa_topology(tri32: torch.Tensor, num_vertices: int) -> AATopology:
@@ -127,6 +137,23 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
 
 
 # ---------------------------------------------------------------------------------------------- DMTet
+DMTET_TOPOLOGY = True  # build the mesh topology inside the extraction (emit + one finalize launch) instead of a3d_mesh_topology on first use
+_topo_sets = {}
+
+
+def _topology_sets(dev, F, V):
+    """Two alternating valence-count arrays (int32 [vcap], zero) per (device, stream, size class): an extraction's emit launch counts into
+    one and its finalize launch zeroes the other, so only the first use of a size class pays an initialisation."""
+    vcap = 1 << max(10, int(V - 1).bit_length())
+    key = (dev, stream(), vcap)
+    st = _topo_sets.get(key)
+    if st is None:
+        if len(_topo_sets) >= 4:
+            _topo_sets.clear()
+        st = _topo_sets[key] = dict(sets=[torch.zeros(vcap, dtype=torch.int32, device=dev) for _ in range(2)], cur=0, vcap=vcap, key=key)
+    return st
+
+
 _dm_vertex_scratch = {}
 _dm_grad_buffers = _IdentityCache(maxsize=2)  # vert_edge of an extraction -> its cleared SDF gradient buffer
 
@@ -161,8 +188,31 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
     idx = torch.empty((n_surf,), dtype=torch.int64, device=dev) if surface_vertices else None
     g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
-    call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
-         ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), stream())
+    # mesh topology inside the extraction (DMTET_TOPOLOGY): the emit launch writes the int32 triangle list and counts the valences; ONE
+    # more launch (a3d_mesh_topology_finalize) leaves the vertex -> face lists in the caches the normals / antialiasing look them up in
+    # (the silhouette analysis finds its opposite vertices in the same lists: no hash, no table) -- instead of the conversion kernel +
+    # the four launches of a3d_mesh_topology on first use
+    topo = _topology_sets(dev, F, V) if (DMTET_TOPOLOGY and F > 0 and 0 < V <= _lib.lib().a3d_mesh_topology_finalize_max_vertices()) else None
+    tri32 = cur = nxt = None
+    if topo is not None:
+        cur, nxt = topo["sets"][topo["cur"]], topo["sets"][1 - topo["cur"]]
+        tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
+    try:
+        call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
+             ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
+             ptr(cur), stream())
+        if topo is not None:
+            adj = VertexFaceAdjacency(tri32, V, build=False)
+            adj.sorted = False
+            call("a3d_mesh_topology_finalize", ptr(tri32), V, F, ptr(cur), ptr(adj.off), ptr(adj.adj), ptr(nxt), topo["vcap"], stream())
+            topo["cur"] ^= 1
+            _adj_cache.put(tri32, adj)
+            _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
+            _tri32_cache.put(faces, tri32)
+    except Exception:
+        if topo is not None:  # a half-used scratch pair must not be taken for clean
+            _topo_sets.pop(topo["key"], None)
+        raise
     if g_sdf is not None:
         _dm_grad_buffers.put(vert_edge, g_sdf)
     if not surface_vertices:
@@ -277,6 +327,61 @@ def skin(v, bones, T, temperature):
     return _Skin.apply(v, bones, T, temperature)
 
 
+class _SkinPose(torch.autograd.Function):
+    """skinning() as one launch each way (csrc/skin.hip, POSE kernels): (posed vertices [B,V,3], transforms T [B,K,12])."""
+
+    @staticmethod
+    def forward(ctx, v, bones, angles, chain, temperature):
+        require_device(v, bones, angles, chain, what="skin_pose")
+        v, bones, angles = f32c(v), f32c(bones), f32c(angles)
+        B, K, V, D = angles.shape[0], angles.shape[1], v.shape[1], chain.shape[1]
+        assert v.shape[0] in (1, B) and bones.shape[0] in (1, B) and bones.shape[1] == K and chain.shape[0] == K and chain.dtype == torch.int32
+        out = torch.empty((B, V, 3), dtype=torch.float32, device=v.device)
+        T = torch.empty((B, K, 12), dtype=torch.float32, device=v.device)
+        # g_T and the per-image tickets of the backward: one buffer, cleared by the forward launch when a backward can follow
+        scratch = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            scratch = torch.empty((B * K * 12 + B,), dtype=torch.float32, device=v.device)
+        g_T = None if scratch is None else scratch[: B * K * 12]
+        ticket = None if scratch is None else scratch[B * K * 12:]
+        products = None if scratch is None else torch.empty((B, K, D, 2, 12), dtype=torch.float32, device=v.device)
+        call("a3d_skin_pose_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(angles), ptr(chain), B, V, K, D, float(temperature),
+             ptr(out), ptr(T), ptr(products), ptr(g_T), ptr(ticket), stream())
+        ctx.save_for_backward(v, bones, angles, chain, T, products)
+        ctx.scratch = scratch
+        ctx.temperature = float(temperature)
+        ctx.set_materialize_grads(False)
+        return out, T
+
+    @staticmethod
+    def backward(ctx, g_out, g_T_ext):
+        v, bones, angles, chain, T, products = ctx.saved_tensors
+        B, K, V, D = angles.shape[0], angles.shape[1], v.shape[1], chain.shape[1]
+        if g_out is None:  # only the transforms were used downstream
+            g_out = torch.zeros((B, V, 3), dtype=torch.float32, device=v.device)
+        g_v = torch.empty((B, V, 3), dtype=torch.float32, device=v.device) if ctx.needs_input_grad[0] else None
+        scratch, ctx.scratch = ctx.scratch, None  # the cleared buffer serves ONE backward
+        clear = scratch is not None
+        if scratch is None:
+            scratch = torch.empty((B * K * 12 + B,), dtype=torch.float32, device=v.device)
+        g_angles = torch.empty_like(angles)
+        call("a3d_skin_pose_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), ptr(products), ptr(angles), ptr(chain), B, V, K, D,
+             ctx.temperature, ptr(g_v), ptr(scratch[: B * K * 12]), ptr(scratch[B * K * 12:]), int(clear),
+             ptr(None if g_T_ext is None else f32c(g_T_ext)), ptr(g_angles), stream())
+        if g_v is not None and v.shape[0] == 1 and B > 1:
+            g_v = g_v.sum(0, keepdim=True)
+        return g_v, None, g_angles, None, None
+
+
+def skin_pose_supported(K, D):
+    return K <= _lib.lib().a3d_skin_pose_max_bones() and D <= 8
+
+
+def skin_pose(v, bones, angles, chain, temperature):
+    """v [1|B,V,3], bones [1|B,K,2,3] (detached), angles [B,K,3], chain int32 [K,D] -> (posed [B,V,3], T [B,K,12])."""
+    return _SkinPose.apply(v, bones, angles, chain, temperature)
+
+
 def skin_weights(v, bones, B, temperature):
     """aux['vertices_to_bones'] on demand: [K, Bw, V]."""
     require_device(v, bones, what="skin_weights")
@@ -298,6 +403,7 @@ class VertexFaceAdjacency:
         require_device(tri32, what="normals_adjacency")
         F, V = tri32.shape[0], int(num_vertices)
         self.tri, self.num_vertices = tri32, V
+        self.sorted = True  # lists stored in ascending key order (False for the lists a3d_mesh_topology_finalize leaves)
         self.off = torch.empty(V + 1, dtype=torch.int32, device=tri32.device)
         self.adj = torch.empty(max(3 * F, 1), dtype=torch.int32, device=tri32.device)
         if build:
@@ -325,7 +431,8 @@ class _Normals(torch.autograd.Function):
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         acc = torch.empty_like(v)
         nrm = torch.empty_like(v)
-        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), stream(), tag=f"[B{B}]")
+        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), int(adjacency.sorted),
+             stream(), tag=f"[B{B}]")
         ctx.save_for_backward(v, acc, tri32)
         ctx.adjacency = adjacency
         return nrm
@@ -339,7 +446,7 @@ class _Normals(torch.autograd.Function):
         if g_nrm.dtype != torch.float32 or g_nrm.stride(2) != 1 or g_nrm.stride(0) != V * g_nrm.stride(1):  # rows must be evenly strided
             g_nrm = f32c(g_nrm)
         call("a3d_normals_bwd", ptr(g_nrm), g_nrm.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-             ptr(scratch), ptr(g_v), stream(), tag=f"[B{B}]")
+             ptr(scratch), ptr(g_v), int(ctx.adjacency.sorted), stream(), tag=f"[B{B}]")
         return g_v, None, None
 
 
@@ -364,15 +471,14 @@ def covered_pixels(rast, tile=8, return_inverse=False):
     if tile != 8 or H % 8 or W % 8:
         tile = 0
     dev = rast.device
-    # block counts left by the rasteriser's resolve (same launch).  CONSUMED: the scan below turns them into offsets in place, so a second
-    # list of the same buffer counts again
-    scratch = _cover_counts.take(rast) if tile == 8 else None
-    counted = scratch is not None
-    if not counted:
-        scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
-    total = torch.empty(1, dtype=torch.int64, device=dev)
-    call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), int(counted), ptr(total), stream(), tag="[scan]" if counted else "")
-    pix = torch.empty(int(total.item()), dtype=torch.int64, device=dev)
+    # block counts + group sums left by the rasteriser's resolve (same launch); otherwise a counting pass of our own
+    scratch = _cover_counts.peek(rast) if tile == 8 else None
+    if scratch is None:
+        scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=dev)
+        call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
+    nb = _lib.lib().a3d_cover_blocks(B, H, W)
+    total = int(scratch[nb:].cpu().sum())  # the ONE read-back: the group sums (a few KB; unused words are zero), added up on the host
+    pix = torch.empty(total, dtype=torch.int64, device=dev)
     inv = torch.empty(B * H * W, dtype=torch.int32, device=dev) if return_inverse else None
     if pix.shape[0] or return_inverse:
         call("a3d_cover_emit", ptr(rast), B, H, W, tile, ptr(scratch), ptr(pix), ptr(inv), stream())
@@ -402,15 +508,22 @@ class _Rasterize(torch.autograd.Function):
         # the covered-pixel list's block counts ride along with the resolve when the list's tile order applies (covered_pixels picks them up)
         cover = None
         if H % 8 == 0 and W % 8 == 0 and (H * W) % 256 == 0 and F > 0:
-            cover = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
+            cover = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=clip.device)
         # ... and so does what the silhouette analysis of this frame needs first (pixel-space vertex positions, zeroed append counters):
         # AAAnalysis picks them up when it is built for this raster buffer and this clip tensor
         aa_screen = aa_count = None
         if F > 0 and prev is None:
             aa_screen = torch.empty((clip.shape[0], V, 2), dtype=torch.float32, device=clip.device)
             aa_count = torch.empty((_lib.lib().a3d_aa_shards(),), dtype=torch.int32, device=clip.device)
+        # ... and the opposite-vertex table, when this triangle list came with vertex -> face lists only (DMTet extraction): filled by
+        # further extra work-groups of the same launch, picked up by the silhouette analysis through the topology cache
+        topo = _topo_cache.peek(tri32) if F > 0 else None
+        lists = getattr(topo, "lists", None) if (topo is not None and topo.opp is None) else None
+        opp = torch.empty((F, 3), dtype=torch.int32, device=clip.device) if lists is not None else None
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
-             ptr(aa_screen), ptr(aa_count), stream())
+             ptr(aa_screen), ptr(aa_count), ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), ptr(opp), stream())
+        if opp is not None:
+            topo.opp = opp
         if cover is not None:
             _cover_counts.put(rast.detach(), cover)  # keyed on a detached alias: the entry must not pin this iteration's autograd graph
         if aa_screen is not None:
@@ -752,8 +865,10 @@ class AAAnalysis:
         else:
             self.count = torch.empty((shards,), dtype=torch.int32, device=dev)
             screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
+        lists = getattr(topo, "lists", None)
         call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), B, self.clip.shape[1],
-             topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), int(prepared), stream())
+             topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), int(prepared),
+             ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), stream())
 
 
 class _Antialias(torch.autograd.Function):

@@ -71,6 +71,68 @@ def kuhn_grid(res: int):
     return vertices, indices
 
 
+def bcc_grid(res: int, seed=None):
+    """Body-centred-cubic tetrahedral grid of the cube [-0.5,0.5]^3 -- the lattice family Quartet (the generator of the reference's
+    ``{res}_tets.npz`` files, data/tets/generate_tets.py:14-25) builds its meshes from: vertices = the (res+1)^3 cell corners + the
+    res^3 cell centres; every interior cell face contributes four tets (the two centres on either side + one edge of the face).
+    With ``seed`` the vertex numbering is a random permutation, the tet rows are shuffled and the four indices of every row are
+    permuted -- the arbitrary numbering a file produced by an external mesher has.  -> (vertices float32 [Nv,3], indices int64 [Nt,4])."""
+    n = res + 1
+    ax = np.arange(n, dtype=np.float64) / res - 0.5
+    corners = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    cx = (np.arange(res, dtype=np.float64) + 0.5) / res - 0.5
+    centres = np.stack(np.meshgrid(cx, cx, cx, indexing="ij"), -1).reshape(-1, 3)
+    vertices = np.concatenate([corners, centres]).astype(np.float32)
+    corner = lambda i, j, k: (i * n + j) * n + k
+    centre = lambda i, j, k: n ** 3 + (i * res + j) * res + k
+    tets = []
+    for axis in range(3):
+        u, v = [a for a in range(3) if a != axis]
+        for i in range(res - 1):  # the face between cell i and cell i + 1 along ``axis``
+            for j in range(res):
+                for k in range(res):
+                    lo, hi = [0, 0, 0], [0, 0, 0]
+                    lo[axis], lo[u], lo[v] = i, j, k
+                    hi[axis], hi[u], hi[v] = i + 1, j, k
+                    c0, c1 = centre(*lo), centre(*hi)
+                    ring = []
+                    for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):  # the face's four corners in cyclic order
+                        q = [0, 0, 0]
+                        q[axis], q[u], q[v] = i + 1, j + du, k + dv
+                        ring.append(corner(*q))
+                    for e in range(4):
+                        tets.append((c0, c1, ring[e], ring[(e + 1) % 4]))
+    indices = np.asarray(tets, dtype=np.int64)
+    if seed is not None:
+        vertices, indices = scramble(vertices, indices, seed)
+    return vertices, indices
+
+
+def delaunay_grid(num_points: int, seed: int = 0):
+    """Delaunay tetrahedralisation of ``num_points`` random points in [-0.5,0.5]^3 (scipy / Qhull), scrambled like an external
+    mesher's output: an irregular grid with varying vertex valence, the opposite extreme of the Kuhn grid's one repeated cell."""
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-0.5, 0.5, size=(num_points, 3))
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    vol = np.abs(np.einsum("ij,ij->i", np.cross(pts[tets[:, 1]] - pts[tets[:, 0]], pts[tets[:, 2]] - pts[tets[:, 0]]), pts[tets[:, 3]] - pts[tets[:, 0]]))
+    tets = tets[vol > 1e-12]  # Qhull may emit flat slivers on the hull
+    return scramble(pts.astype(np.float32), tets, seed + 1)
+
+
+def scramble(vertices: np.ndarray, indices: np.ndarray, seed: int):
+    """Renumber the vertices by a random permutation, shuffle the tet rows and permute the four indices inside every row."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(vertices.shape[0])  # new id of old vertex v = perm[v]
+    out_v = np.empty_like(vertices)
+    out_v[perm] = vertices
+    idx = perm[indices]
+    idx = idx[rng.permutation(idx.shape[0])]
+    order = np.argsort(rng.random(idx.shape), axis=1)
+    return out_v, np.take_along_axis(idx, order, axis=1).astype(np.int64)
+
+
 def save_tets_npz(path: str, vertices: np.ndarray, indices: np.ndarray) -> None:
     """Write a grid in the reference's ``{res}_tets.npz`` format."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

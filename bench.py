@@ -95,12 +95,16 @@ def algorithmic_bytes(name, d):
         "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt + (Ne // 8 + Nt // 2 + Ne // 16),  # sdf, both index arrays in; bit planes + word prefixes out
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
-        "a3d_dmtet_emit": (Ne // 8 + Nt // 2 + Ne // 16) + 56 * V + 72 * F,
+        "a3d_dmtet_emit": (Ne // 8 + Nt // 2 + Ne // 16) + 56 * V + 72 * F + 12 * F,  # (+ the int32 triangle list of the render kernels)
         "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
+        # chain + skinning in one launch: skin_fwd's bytes + the bones / angles in and the transforms (+ chain products) out
+        "a3d_skin_pose_fwd": 12 * V + 12 * B * V + B * K * (12 + 48 + 24) + B * K * 8 * 96,
+        "a3d_skin_pose_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K + B * K * (12 + 48 + 12 + 24) + B * K * 8 * 96,
         "a3d_normals_adjacency": 24 * F + 4 * V,  # triangle list in, CSR out
         "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
+        "a3d_mesh_topology_finalize": 12 * F + 4 * V + (4 * V + 12 * F),  # int32 triangle list + valence counts in; offsets + lists out
         "a3d_normals_fwd": 4 * V + 24 * F + Bn * (36 * F + 24 * V),  # CSR + indices once; per image position gathers, acc + nrm out
         "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 36 * F + 60 * V),
         "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
@@ -117,9 +121,7 @@ def algorithmic_bytes(name, d):
         "a3d_harmonic_embed_bwd": Pp * (4 * 64 + 12 + 12),
         "a3d_recon_losses_fwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1),  # shaded, dino(16), image_gt, dino_gt, three masks; 'both' out
         "a3d_recon_losses_bwd": B * HW * (16 + 64 + 12 + 64 + 12 + 1 + 16 + 64),
-        # the id channel of the raster buffer -- or, for a buffer whose block counts the rasteriser's resolve left behind ([scan]), only
-        # those counts in and their offsets out
-        "a3d_cover_count": 8 * (B * HW // 256) if "[scan]" in name else 4 * B * HW,
+        "a3d_cover_count": 4 * B * HW,  # the id channel of the raster buffer (only for buffers that did not come out of a3d_rast_fwd)
         "a3d_cover_emit": 4 * B * HW + 8 * P + 4 * B * HW,  # id channel in; list + pixel -> entry map out
         # C = channels of the composited image (values + alpha): point rows in, image out (+ the crossing pixels); backward: image
         # gradient read at the covered pixels, point-row gradient out, vertex gradient out

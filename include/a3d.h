@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 200 = this header */
+int a3d_version(void); /* 300 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -56,7 +56,10 @@ int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets,
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                   a3d_stream_t stream);
+                   int32_t* tri32_or_null, int32_t* topo_count_or_null, a3d_stream_t stream);
+/* tri32 / topo_count (both or none): the emit launch also writes the int32 copy of faces that the render kernels read and counts the
+ * valences of the surface vertices (topo_count[>= V], zero on entry) -- the first step of the mesh topology, which
+ * a3d_mesh_topology_finalize completes in one launch (the stand-alone a3d_mesh_topology needs four). */
 /* Optional, for callers that evaluate the SDF network with a graph only where the surface's gradient can reach (DMTetGeometry.
  * _get_mesh_surface_backward): with vertex_scratch (a3d_dmtet_vertex_scratch_bytes(Nv) bytes, 16-byte aligned) a3d_dmtet_count also
  * flags the grid vertices at the ends of crossing edges and returns their number in counts[3] -- the same read-back as V, n1, n2 --
@@ -99,6 +102,26 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
                             int D, float* g_angles, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Kinematic chain + skinning in ONE launch each way -- the whole of skinning(), /root/reference/model/geometry/skinning.py:369-439
+ * (chain composition :389-417 + the per-vertex blend :377, :419-431), for K <= a3d_skin_pose_max_bones() bones and chains of D <= 8
+ * links (every configuration of the reference: 20 bones, depth <= 8).  Forward: every work-group of the skinning launch composes the K
+ * transforms of its image in LDS; T_out[B,K,12] receives them (backward, posed_bones), chain_products (when a backward will follow) the
+ * prefix / suffix products of every chain position, which the backward's tail needs.  Backward: g_v as a3d_skin_bwd; the work-group that
+ * finishes an image last (ticket[b], after a device-scope fence) runs the chain adjoint on the complete g_T[b] (+ g_T_extra[b]: a gradient
+ * that reached the transforms directly, e.g. through posed_bones; may be null) -> g_angles[B,K,3], fully written.
+ * g_T[B,K,12] floats and ticket[B] ints must be allocated back to back (one buffer of B*K*12 + B words); the forward clears both when
+ * handed them (then scratch_is_clear = 1), otherwise the backward memsets them.
+ */
+int a3d_skin_pose_max_bones(void);
+int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int B,
+                      int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null /*[B,K,D,2,12]*/,
+                      float* g_T_to_clear_or_null, int32_t* ticket_to_clear_or_null, a3d_stream_t stream);
+int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T,
+                      const float* chain_products, const float* angles, const int32_t* chain, int B, int V, int K, int D, float temperature,
+                      float* g_v_or_null, float* g_T, int32_t* ticket, int scratch_is_clear, const float* g_T_extra_or_null, float* g_angles,
+                      a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Area-weighted vertex normals -- replaces auto_normals, /root/reference/model/render/mesh.py:276-304.
  * a3d_normals_adjacency: once per triangle list, CSR vertex -> incident corners: off[V+1], adj[3F] (entry = corner*F + face, each
  *   list sorted, i.e. in the order the reference's three scatter_add_ passes visit them, mesh.py:291-293); cursor[V] = scratch.
@@ -108,10 +131,13 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
  */
 int a3d_normals_adjacency(const int32_t* tri /*[F,3]*/, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream);
 int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, const int32_t* off, const int32_t* adj, int B, int V, int F,
-                    float* acc, float* nrm, a3d_stream_t stream);
+                    float* acc, float* nrm, int lists_sorted, a3d_stream_t stream);
 int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apart*/, int g_nrm_stride, const float* acc, const float* v,
                     const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3]*/,
-                    float* g_v /*[B,V,3]*/, a3d_stream_t stream);
+                    float* g_v /*[B,V,3]*/, int lists_sorted, a3d_stream_t stream);
+/* lists_sorted: informational (1 = every list of adj is stored in ascending key order: a3d_normals_adjacency, a3d_mesh_topology; 0 = any
+ * order: a3d_mesh_topology_finalize).  The kernels take a vertex's list into registers, order the keys there and issue all gathers at
+ * once, so the sums run in ascending key order -- the same bits -- either way. */
 
 /* ------------------------------------------------------------------------------------------------
  * Per-point shading arithmetic -- replaces the elementwise part of shade(), /root/reference/model/render/render.py:71-93:
@@ -135,14 +161,17 @@ int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_sha
  * image-major and inside an image 8x8-tile by tile (tile = 8; H, W multiples of 8) or row-major (tile = 0).  The list the fused
  * G-buffer / shading path runs over instead of the reference's dense [B,H,W] frame (/root/reference/model/render/render.py:
  * 139-221 shades every pixel; uncovered ones are composited with alpha 0, :261-262).
- * count: fills scratch (a3d_cover_scratch_bytes) and total[0] (device) -- with counted != 0 the block counts are already in scratch
- * (left there by a3d_rast_fwd's resolve, tile = 8 and H*W a multiple of 256) and only the scan runs; the caller reads total back to
- * size pix; emit writes pix and,
- * when given, the inverse map inv[B*H*W] (entry of the list per pixel, -1 = uncovered) that a3d_composite_aa_* reads.
+ * scratch (a3d_cover_scratch_bytes) = int block_count[a3d_cover_blocks] (covered pixels per 256 list positions) followed by
+ * int group_sum[a3d_cover_groups * a3d_cover_group_stride] (sums of 64 consecutive blocks, every stride-th word; the rest zero).  a3d_cover_count fills both -- or a3d_rast_fwd's resolve already did
+ * (cover_scratch, tile = 8 and H*W a multiple of 256).  The caller reads the group sums back and adds them up: the length of the list.
+ * emit writes pix (every work-group derives its own offset from the group sums and block counts before it: no scan launch) and, when
+ * given, the inverse map inv[B*H*W] (entry of the list per pixel, -1 = uncovered) that a3d_composite_aa_* reads.
  */
 size_t a3d_cover_scratch_bytes(int B, int H, int W);
-int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, int counted, int64_t* total,
-                    a3d_stream_t stream);
+int a3d_cover_blocks(int B, int H, int W);
+int a3d_cover_groups(int B, int H, int W);
+int a3d_cover_group_stride(void); /* ints between two group sums (each sits in its own 64-byte line) */
+int a3d_cover_count(const float* rast /*[B,H,W,4]*/, int B, int H, int W, int tile, void* scratch, a3d_stream_t stream);
 int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void* scratch, int64_t* pix /*[total]*/, int32_t* inv_or_null,
                    a3d_stream_t stream);
 
@@ -156,15 +185,19 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * on the same stream (every key is all-ones again: the resolve re-arms what it consumed) -- the 8 B/pixel clear launch is skipped.
  * prev_rast != NULL: depth peeling, DepthPeeler.rasterize_next_layer() for layer n > 0 -- prev_rast[B,H,W,4] is the previous layer;
  * per pixel the nearest fragment strictly behind the previous layer's (depth, id) is returned, empty pixels stay empty.
- * cover_scratch != NULL (H, W multiples of 8, H*W a multiple of 256): the resolve also leaves the covered-pixel list's block counts
- * (a3d_cover_scratch_bytes) there, for a3d_cover_count(counted = 1).
+ * cover_scratch != NULL (H, W multiples of 8, H*W a multiple of 256): the resolve also leaves the covered-pixel list's block counts and
+ * group sums (a3d_cover_scratch_bytes) there: a3d_cover_emit can follow without a3d_cover_count.
  * aa_screen / aa_count != NULL: extra work-groups of the triangle launch fill a3d_aa_analyze's `screen` [clip_batch,V,2] and zero its
  * `count` [a3d_aa_shards()], for a3d_aa_analyze(prepared = 1) on the same clip.
+ * topo_off / topo_adj / topo_opp (all or none): more extra work-groups fill the opposite-vertex table opp[F,3] of this triangle list from
+ * its vertex -> face lists (a3d_aa_topology_from_lists' work, beside the triangle work instead of in a launch of its own) -- for lists
+ * that came from a3d_mesh_topology_finalize, which builds no table.
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                 float* aa_screen_or_null, int32_t* aa_count_or_null, a3d_stream_t stream);
+                 float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null, const int32_t* topo_adj_or_null,
+                 int32_t* topo_opp_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 
@@ -190,6 +223,14 @@ int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C,
  */
 int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
                       int scratch_is_clean, a3d_stream_t stream);
+/* Second half of the topology for a triangle list that came out of a3d_dmtet_emit with tri32 / topo_count (see there): ONE launch turns
+ * the valence counts into off[V+1] (every work-group scans them in LDS; V <= a3d_mesh_topology_finalize_max_vertices()) and fills
+ * adj[3F].  The lists of adj are NOT sorted (lists_sorted = 0 for a3d_normals_*: same bits as with a3d_mesh_topology's sorted lists).
+ * No opposite-vertex table is built: a3d_aa_analyze finds the few opposite vertices it needs in these lists (opp = NULL, off / adj
+ * given).  count_next[v_next] = the count array of the NEXT extraction, zeroed by this launch: callers alternate two arrays. */
+int a3d_mesh_topology_finalize_max_vertices(void);
+int a3d_mesh_topology_finalize(const int32_t* tri, int V, int F, int32_t* count, int32_t* off, int32_t* adj, int32_t* count_next, int v_next,
+                               a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused G-buffer over the covered-pixel list -- replaces the five dr.interpolate calls + face-normal torch ops of
@@ -235,7 +276,9 @@ int a3d_rows_add_relu_bwd(const float* g, const float* y, const int64_t* img, in
  *   a3d_aa_analyze  : once per (rast, clip): finds every silhouette crossing between adjacent pixels; work =
  *                     scratch of capacity*16 bytes with capacity >= a3d_aa_capacity(B, H, W) (the list is kept in
  *                     a3d_aa_shards() segments, each with its own append counter), count[a3d_aa_shards()] zeroed by callee,
- *                     screen = scratch of clip_batch*V*2 floats (pixel-space vertex positions).
+ *                     screen = scratch of clip_batch*V*2 floats (pixel-space vertex positions).  Per pair the geometric tests
+ *                     (exit edge, slope, crossing distance) run first; the silhouette test needs the neighbouring triangle and runs
+ *                     only for the pairs that pass them, for the one exit edge.
  *   a3d_aa_fwd      : out = color, then blends across each recorded crossing; any number of colour buffers can
  *                     share one analysis (the reference re-analyses per buffer, render.py:311-315).
  *   a3d_aa_bwd      : g_color[B,H,W,C] and g_clip[clip_batch,V,4] (both fully written / zeroed by callee).
@@ -244,9 +287,13 @@ size_t a3d_aa_hash_bytes(int F);
 int a3d_aa_shards(void);
 int a3d_aa_capacity(int B, int H, int W);
 int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
-int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp, int B, int V,
+int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp,
+                               a3d_stream_t stream); /* the same table from the vertex -> face lists (no hash) */
+int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp_or_null, int B, int V,
                    int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared,
-                   a3d_stream_t stream);
+                   const int32_t* off_or_null, const int32_t* adj_or_null, a3d_stream_t stream);
+/* (opp_or_null = NULL with off / adj = the vertex -> face lists of a3d_normals_adjacency / a3d_mesh_topology[_finalize]: the opposite
+ * vertex is looked up in the lists, only for the pixel pairs that passed every geometric test -- same records as with the table) */
 int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
                a3d_stream_t stream);
 int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, const int32_t* count, int capacity,

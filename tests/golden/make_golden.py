@@ -122,6 +122,11 @@ def main():
     sys.path.insert(0, ROOT)
     import importlib
 
+    global HERE
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":  # regenerate into another directory (reproducibility check against the committed files)
+        HERE = sys.argv[2]
+        os.makedirs(HERE, exist_ok=True)
+
     a3d = importlib.import_module("3danimals_amd")
     tetgrid, synthetic = a3d.tetgrid, a3d.synthetic
     R = import_reference()
@@ -161,6 +166,24 @@ def main():
     run_dmtet("dmtet_ellipsoid_r32.npz", 32, synthetic.ellipsoid_sdf(pos32, scale, 0.01, seed=0))  # BASELINE config 1
     pos16, _ = grid(16)
     qv, qf = run_dmtet("dmtet_quadruped_r16.npz", 16, synthetic.quadruped_sdf(pos16, leg_radius=0.3))
+
+    # ------------------------------------------------------------------ G1b: DMTet on IRREGULAR grids (the reference trains on Quartet
+    # grids, dmtet.py:214-226: arbitrary vertex numbering, tet rows in no order, no fixed orientation).  The grid travels in the fixture.
+    def run_dmtet_grid(name, verts_np, tets_np, sdf):
+        pos, tets = torch.from_numpy(verts_np) * scale, torch.from_numpy(tets_np)
+        sdf = sdf.clone().float().requires_grad_(True)
+        verts, faces, uvs, uv_idx = dm(pos, sdf[:, None], tets)
+        wgt = synthetic.seeded(verts.shape, 123, -1, 1)
+        (g,) = torch.autograd.grad((verts * wgt).sum(), sdf, allow_unused=True)
+        save(name, pos=pos.numpy(), tets=tets_np.astype(np.int32), sdf=sdf.detach().numpy(), verts=verts.detach().numpy(), faces=faces.numpy(),
+             uv_idx=uv_idx.numpy(), uvs_shape=np.array(uvs.shape), grad_wgt_seed=123, grad_sdf=g.numpy())
+        print(name, "Nv", pos.shape[0], "Nt", tets.shape[0], "V", verts.shape[0], "F", faces.shape[0])
+
+    gi = torch.Generator().manual_seed(11)
+    for tag, (gv, gt) in (("bcc10", tetgrid.bcc_grid(10, seed=3)), ("delaunay3k", tetgrid.delaunay_grid(3000, seed=5))):
+        p = torch.from_numpy(gv) * scale
+        run_dmtet_grid(f"dmtet_{tag}_sphere.npz", gv, gt, 2.2 - p.norm(dim=-1) + 0.15 * torch.randn(p.shape[0], generator=gi))
+        run_dmtet_grid(f"dmtet_{tag}_random.npz", gv, gt, torch.randn(p.shape[0], generator=gi))
 
     # ------------------------------------------------------------------ G2: make_mesh (normals, tangents)
     pos, tets = grid(8)

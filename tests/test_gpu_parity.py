@@ -16,7 +16,7 @@ from conftest import GOLDEN, golden, kuhn, seeded
 
 pytestmark = pytest.mark.gpu
 
-DMTET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dmtet_*.npz")))
+DMTET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dmtet_*_r[0-9]*.npz")))  # Kuhn grids (regenerated from res); the irregular-grid fixtures have their own tests
 
 
 @pytest.fixture(scope="module")
@@ -64,6 +64,31 @@ def test_dmtet_matches_reference_golden(name, dev, mods):
         wgt = seeded(verts.shape, int(g["grad_wgt_seed"]), -1, 1).to(dev)
         (gs,) = torch.autograd.grad((verts * wgt).sum(), sdf)
         np.testing.assert_allclose(gs.cpu().numpy(), g["grad_sdf"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["dmtet_bcc10_sphere.npz", "dmtet_bcc10_random.npz", "dmtet_delaunay3k_sphere.npz", "dmtet_delaunay3k_random.npz"])
+def test_dmtet_on_irregular_grids_matches_reference_golden(name, tmp_path, dev, mods):
+    """The grid class the reference really trains on (Quartet files, dmtet.py:214-226): arbitrary vertex numbering, unordered rows,
+    mixed orientation.  DMTet.__call__ on the HIP path against the reference's own outputs, bit for bit, plus d/dsdf; and the same grid
+    written as a ``{res}_tets.npz`` file and loaded through DMTetGeometry.load_tets gives the same extraction."""
+    g = golden(name)
+    pos, tets = torch.from_numpy(g["pos"]).to(dev), torch.from_numpy(g["tets"]).long().to(dev)
+    sdf = torch.from_numpy(g["sdf"]).to(dev).requires_grad_(True)
+    dm = mods["dmtet"].DMTet()
+    verts, faces, uvs, uv_idx = dm(pos, sdf[:, None], tets)
+    assert np.array_equal(faces.cpu().numpy(), g["faces"]) and np.array_equal(uv_idx.cpu().numpy(), g["uv_idx"])
+    assert np.array_equal(verts.detach().cpu().numpy(), g["verts"]) and tuple(uvs.shape) == tuple(g["uvs_shape"])
+    (gs,) = torch.autograd.grad((verts * seeded(verts.shape, int(g["grad_wgt_seed"]), -1, 1).to(dev)).sum(), sdf)
+    np.testing.assert_allclose(gs.cpu().numpy(), g["grad_sdf"], rtol=1e-4, atol=1e-5)
+    # through the file format and the geometry class
+    a3d_pkg = importlib.import_module("3danimals_amd")
+    a3d_pkg.tetgrid.save_tets_npz(str(tmp_path / "77_tets.npz"), g["pos"] / 7.0, g["tets"].astype(np.int64))
+    geo = mods["dmtet"].DMTetGeometry(77, 7.0, num_layers=2, hidden_size=16, embedder_freq=2, device=dev, tets_dir=str(tmp_path)).to(dev)
+    assert torch.equal(geo.indices, tets) and torch.allclose(geo.verts, pos, atol=1e-6)
+    v2, f2, _, u2 = geo.marching_tets(geo.verts, sdf.detach()[:, None], geo.indices, topology=geo.topology)
+    if torch.equal(geo.verts, pos):  # (x / 7) * 7 is not always x in float32: vertices only compare when the round trip is exact
+        assert torch.equal(v2, verts.detach())
+    assert torch.equal(f2, faces) and torch.equal(u2, uv_idx)
 
 
 @pytest.mark.parametrize("res,kind", [(24, "random"), (32, "quadruped"), (64, "quadruped")])
@@ -219,6 +244,47 @@ def test_skinning_identity_and_oracle_larger(dev, mods):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize("B,F,shared", [(16, 1, True), (3, 4, False), (1, 1, True)])
+def test_fused_pose_skinning_equals_the_two_launch_path(B, F, shared, dev, mods):
+    """a3d_skin_pose_* (chain composition inside the skinning launches; the chain adjoint as the tail of the work-group that finishes an
+    image last) against a3d_bone_transforms_* + a3d_skin_*: same posed vertices and transforms, same gradients to the rest vertices and
+    the angles -- with the loss on the vertices, on the posed bones only (the transforms' direct gradient), on both, and for a second
+    backward through the same graph (the cleared g_T / ticket buffer serves one backward; the next one takes the memset path)."""
+    sk = mods["skinning"]
+    verts, _ = quadruped_mesh(24, 0.25)
+    bones, tree, _ = sk.estimate_bones(verts[None, None], n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")
+    V = verts.shape[0]
+    rest = verts[None, None] if shared else verts[None, None] + 0.02 * seeded((B, F, V, 3), 3, -1, 1)
+    ang0 = seeded((B, F, 20, 3), 9, -0.6, 0.6)
+    wv, wb = seeded((B, F, V, 3), 5, -1, 1).to(dev), seeded((B, F, 20, 2, 3), 6, -1, 1).to(dev)
+
+    def run(fused, which):
+        sk.FUSED_POSE = fused
+        try:
+            v, a = rest.to(dev).requires_grad_(True), ang0.to(dev).requires_grad_(True)
+            out, aux = sk.skinning(v, bones.to(dev), tree, a, output_posed_bones=True, temperature=0.05)
+            loss = ((out * wv).sum() if which != "bones" else 0) + ((aux["posed_bones"] * wb).sum() if which != "verts" else 0)
+            g1 = torch.autograd.grad(loss, [v, a], retain_graph=True, allow_unused=True)
+            g2 = torch.autograd.grad(loss, [v, a], allow_unused=True)
+            return out.detach(), aux["posed_bones"].detach(), g1, g2
+        finally:
+            sk.FUSED_POSE = True
+
+    for which in ("verts", "bones", "both"):
+        o_f, b_f, g1_f, g2_f = run(True, which)
+        o_s, b_s, g1_s, _ = run(False, which)
+        np.testing.assert_allclose(o_f.cpu().numpy(), o_s.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(b_f.cpu().numpy(), b_s.cpu().numpy(), atol=2e-6)
+        for gf, gs, g2, name in zip(g1_f, g1_s, g2_f, ("rest", "angles")):
+            if gs is None:
+                assert gf is None or float(gf.abs().max()) == 0.0, (which, name)
+                continue
+            scale = float(gs.abs().max())
+            assert scale > 0, (which, name)
+            np.testing.assert_allclose(gf.cpu().numpy(), gs.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=f"{which}/{name}")
+            np.testing.assert_allclose(g2.cpu().numpy(), gf.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale, err_msg=f"{which}/{name} second backward")
+
+
 # ------------------------------------------------------------------------------------------------ rasterise
 def _scene(B, res=16, seed=1):
     from oracle import render_ref
@@ -353,6 +419,40 @@ def test_aa_topology_matches_oracle(dev, ops):
     cut = torch.cat([faces[: len(faces) // 2], torch.tensor([[0, 0, 1], [0, 1, 2], [1, 0, 3], [0, 1, 4]])])
     topo = ops.AATopology(cut.to(dev).int().contiguous(), int(cut.max()) + 1)
     assert np.array_equal(topo.opp.cpu().numpy(), raster_ref.edge_opposites(cut.numpy()))
+    # the same table from the vertex -> face lists (what the silhouette analysis walks when it is given lists instead of a table):
+    # degenerate faces, boundary edges and the non-manifold fan included
+    for tri in (faces, cut):
+        tri32 = tri.to(dev).int().contiguous()
+        lists = ops.VertexFaceAdjacency(tri32, int(tri.max()) + 1)
+        assert np.array_equal(ops.opposite_vertices_from_lists(lists).cpu().numpy(), raster_ref.edge_opposites(tri.numpy()))
+
+
+def test_antialias_analysis_from_lists_equals_the_table_based_one(dev, ops):
+    """a3d_aa_analyze with opp = NULL + the vertex -> face lists against the table-based analysis: the same silhouette records (as a
+    set: the append order is not defined), hence the same antialiased image up to the blend order."""
+    B, H, W, C = 3, 96, 96, 4
+    _, faces, clip, _ = _scene(B, seed=5)
+    tri32 = faces.to(dev).int().contiguous()
+    V = clip.shape[1]
+    clip_d = clip.to(dev)
+    rast = ops.rasterize(clip_d, tri32, (H, W))
+    lists, table = ops.mesh_topology(tri32, V)
+    a_table = ops.AAAnalysis(rast, clip_d, table)
+    a_lists = ops.AAAnalysis(rast, clip_d, ops.AATopology(tri32, V, build=False, lists=lists))
+
+    def records(a):
+        shards = a.count.shape[0]
+        seg = a.capacity // shards
+        rows = [a.work[s * seg: s * seg + int(n)] for s, n in enumerate(a.count.cpu().tolist())]
+        r = torch.cat(rows).cpu().numpy()
+        return r[np.lexsort(r.T[::-1])]
+
+    ra, rb = records(a_table), records(a_lists)
+    assert ra.shape[0] > 500 and np.array_equal(ra, rb)
+    col = torch.lerp(seeded((B, H, W, C), 1, 0, 0.2).to(dev), seeded((B, H, W, C), 2, 0.5, 1.0).to(dev), (rast[..., 3:] > 0).float())
+    o1 = ops.antialias(col, rast, clip_d, tri32, analysis=a_table)
+    o2 = ops.antialias(col, rast, clip_d, tri32, analysis=a_lists)
+    assert float((o1 - o2).abs().max()) <= 2.4e-7
 
 
 @pytest.mark.parametrize("C", [4, 17])
@@ -810,6 +910,61 @@ def test_fused_gbuffer_backward_table_overflow_falls_back_to_global_atomics(dev,
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
 
 
+@pytest.mark.parametrize("grid", ["kuhn24", "kuhn64", "delaunay3k"])
+def test_topology_built_inside_the_dmtet_extraction_equals_the_stand_alone_one(grid, dev, ops, mods):
+    """ops.dmtet_extract leaves the mesh topology in the caches (emit launch: int32 list + valence counts; ONE finalize launch: offsets +
+    unsorted lists) -- against a3d_mesh_topology on the same list: offsets bit for bit, every vertex's list the same SET, the
+    opposite-vertex table a walk over the lists gives == the hash's, and vertex normals / their gradient the same BITS through either
+    and through lists stored in reverse (the kernels order the keys in registers).  Several extractions in a row with different SDFs:
+    the two count arrays alternate and zero each other."""
+    from oracle import dmtet_ref
+
+    a3d_pkg = importlib.import_module("3danimals_amd")
+    if grid.startswith("kuhn"):
+        pos, tets = kuhn(int(grid[4:]))
+    else:
+        v, t = a3d_pkg.tetgrid.delaunay_grid(3000, seed=5)
+        pos, tets = torch.from_numpy(v) * 7.0, torch.from_numpy(t)
+    topo = mods["dmtet"].TetGridTopology(tets.to(dev))
+    pos_d = pos.to(dev)
+    ops._topo_sets.clear()
+    for trial, radius in enumerate((2.2, 1.4, 2.9, 2.25)):
+        sdf = (radius - pos.norm(dim=-1) + 0.1 * seeded((pos.shape[0],), 40 + trial, -1, 1)).to(dev)
+        verts, faces, _, _ = ops.dmtet_extract(pos_d, sdf, topo)
+        V, F = verts.shape[0], faces.shape[0]
+        assert F > 100
+        tri32 = ops.tri_int32(faces)
+        assert tri32.dtype == torch.int32 and torch.equal(tri32.long(), faces)  # written by the emit launch, found through the cache
+        adj, aat = ops._adj_cache.peek(tri32), ops._topo_cache.peek(tri32)
+        if V > importlib.import_module("3danimals_amd._lib").lib().a3d_mesh_topology_finalize_max_vertices():
+            assert adj is None and aat is None  # too many vertices for the LDS scan: the stand-alone path builds it on first use
+            continue
+        assert adj is not None and aat is not None and not adj.sorted and aat.opp is None and aat.lists is adj
+        ref_adj, ref_aat = ops.mesh_topology(tri32.clone(), V)
+        assert torch.equal(adj.off, ref_adj.off)
+        # no hash and no opposite-vertex table on this path: the silhouette analysis walks the lists -- the walk gives the hash's table
+        assert torch.equal(ops.opposite_vertices_from_lists(adj), ref_aat.opp) and torch.equal(ops.opposite_vertices_from_lists(ref_adj), ref_aat.opp)
+        off = adj.off.cpu().numpy()
+        a, b = adj.adj[: 3 * F].cpu().numpy(), ref_adj.adj[: 3 * F].cpu().numpy()
+        seg = np.repeat(np.arange(V), np.diff(off))
+        assert np.array_equal(b, np.sort(b)[np.argsort(np.argsort(b))]) and np.array_equal(a[np.lexsort((a, seg))], b[np.lexsort((b, seg))])
+        vv = (verts[None] + 0.03 * seeded((3, V, 3), 7, -1, 1).to(dev)).requires_grad_(True)
+        n1 = ops._Normals.apply(vv, tri32, adj)
+        n2 = ops._Normals.apply(vv, tri32, ref_adj)
+        shuffled = ops.VertexFaceAdjacency(tri32, V, build=False)  # the sorted lists, every list reversed in storage
+        shuffled.off, shuffled.sorted = ref_adj.off, False
+        start = torch.repeat_interleave(ref_adj.off[:-1].long(), torch.diff(ref_adj.off.long()))
+        end = torch.repeat_interleave(ref_adj.off[1:].long(), torch.diff(ref_adj.off.long()))
+        shuffled.adj = ref_adj.adj[: 3 * F][(start + end - 1 - torch.arange(3 * F, device=dev)).long()].contiguous()
+        assert torch.equal(n1, n2) and torch.equal(n1, ops._Normals.apply(vv, tri32, shuffled))
+        w = seeded((3, V, 3), 8, -1, 1).to(dev)
+        assert torch.equal(torch.autograd.grad((n1 * w).sum(), vv)[0], torch.autograd.grad((n2 * w).sum(), vv)[0])
+        if grid == "kuhn24" and trial == 0:  # and against the reference's own index buffers through the oracle
+            _, f_ref, _, _ = dmtet_ref.marching_tets(pos, sdf.cpu(), tets)
+            assert torch.equal(f_ref, faces.cpu())
+    assert len(ops._topo_sets) >= 1
+
+
 def test_mesh_topology_fused_entry_point_equals_the_two_separate_ones(dev, ops):
     """a3d_mesh_topology against a3d_normals_adjacency + a3d_aa_topology, bit for bit (incl. an empty list and isolated vertices)."""
     verts, faces = quadruped_mesh(16, 0.3)
@@ -1105,8 +1260,8 @@ def test_covered_pixels_of_a_rasterised_buffer_use_the_resolve_counts(hw, dev, o
     want_inv = torch.full((B * H * W,), -1, dtype=torch.int32, device=dev)
     want_inv[want] = torch.arange(want.shape[0], dtype=torch.int32, device=dev)
     assert torch.equal(inv, want_inv)
-    # a SECOND list of the same, unmodified buffer: the resolve's block counts were consumed (scanned in place) by the first call
-    assert ops._cover_counts.peek(rast) is None
+    # a SECOND list of the same, unmodified buffer: the resolve's block counts are only read by the emit, so they serve again
+    assert (ops._cover_counts.peek(rast) is not None) == counted
     pix2, inv2 = ops.covered_pixels(rast, return_inverse=True)
     assert torch.equal(pix2, want) and torch.equal(inv2, want_inv)
     # an in-place edit of the buffer invalidates the cached counts (the version counter is part of the cache key)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 200
+    assert lib.a3d_version() == L.ABI_VERSION == 300
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -139,6 +139,34 @@ def test_grid_topology_torch_equals_numpy(a3d):
     assert np.array_equal(topo.edges32.numpy(), edges) and np.array_equal(topo.tet2edge32.numpy(), t2e)
     uvs_ref, _ = dmtet_ref.uv_atlas(t.shape[0])
     assert torch.equal(topo.uvs(), uvs_ref)
+
+
+IRREGULAR_DMTET = ["dmtet_bcc10_sphere.npz", "dmtet_bcc10_random.npz", "dmtet_delaunay3k_sphere.npz", "dmtet_delaunay3k_random.npz"]
+
+
+@pytest.mark.parametrize("name", IRREGULAR_DMTET)
+def test_dmtet_oracle_matches_reference_on_irregular_grids(name, a3d):
+    """The reference's DMTet run on grids with arbitrary numbering (a scrambled BCC lattice -- Quartet's family -- and a scrambled
+    Delaunay tetrahedralisation): the oracle and the product's static edge topology must reproduce faces / uv_idx / vertices bit for
+    bit; the grid generators must reproduce the grid the fixture holds."""
+    g = golden(name)
+    pos, tets = torch.from_numpy(g["pos"]), torch.from_numpy(g["tets"]).long()
+    gen = a3d.tetgrid.bcc_grid(10, seed=3) if "bcc10" in name else a3d.tetgrid.delaunay_grid(3000, seed=5)
+    assert np.array_equal(gen[1], g["tets"]) and np.array_equal((torch.from_numpy(gen[0]) * 7.0).numpy(), g["pos"])
+    assert not np.array_equal(np.sort(g["tets"], 1), g["tets"]) and not np.array_equal(g["tets"][np.lexsort(g["tets"].T[::-1])], g["tets"])
+    sdf = torch.from_numpy(g["sdf"]).requires_grad_(True)
+    verts, faces, _, uv_idx = dmtet_ref.marching_tets(pos, sdf, tets)
+    assert np.array_equal(faces.numpy(), g["faces"]) and np.array_equal(uv_idx.numpy(), g["uv_idx"])
+    assert np.array_equal(verts.detach().numpy(), g["verts"])
+    (gs,) = torch.autograd.grad((verts * seeded(verts.shape, int(g["grad_wgt_seed"]), -1, 1)).sum(), sdf)
+    np.testing.assert_allclose(gs.numpy(), g["grad_sdf"], rtol=1e-5, atol=1e-6)
+    # the static topology the kernels stream: sorted unique (min, max) edges == the reference's generate_edges (dmtet.py:283-288)
+    dm = importlib.import_module("3danimals_amd.model.geometry.dmtet")
+    topo = dm.TetGridTopology(tets)
+    e, t2e = a3d.tetgrid.build_topology(g["tets"])
+    assert np.array_equal(topo.edges32.numpy(), e) and np.array_equal(topo.tet2edge32.numpy(), t2e)
+    pairs = np.sort(g["tets"].astype(np.int64)[:, a3d.tetgrid.TET_EDGE_SLOTS], -1).reshape(-1, 2)
+    assert np.array_equal(np.unique(pairs, axis=0), e)
 
 
 # ------------------------------------------------------------------------------------------------ oracle known answers

@@ -9,7 +9,7 @@ import torch
 from conftest import GOLDEN, golden, kuhn, seeded
 from oracle import dmtet_ref, mesh_ref, render_ref, skinning_ref
 
-DMTET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dmtet_*.npz")))
+DMTET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dmtet_*_r[0-9]*.npz")))  # Kuhn grids (regenerated from res); the irregular-grid fixtures have their own tests
 
 
 @pytest.mark.parametrize("name", DMTET_CASES)

@@ -1,6 +1,4 @@
-mkdir -p gpurun_out/diag
-for w in magicpony fauna ponymation; do
-  n=4; [ $w = ponymation ] && n=8
-  timeout 900 python tools/parity_diag.py --workload $w --steps 0 35 --n $n --tuned > gpurun_out/diag/$w.jsonl 2> gpurun_out/diag/$w.err
-  echo $w $?; tail -3 gpurun_out/diag/$w.err
-done
+python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log
+bash tools/prof_bench.sh r03c 20 5 > /dev/null 2>&1
+grep -E "rs_|cv_|sk_|tp_|dm_|nr_|gb_fwd|aa_an" gpurun_out/r03c_kernel_summary.txt | head -30
+python bench.py --no-cpu-baseline --networks fast > gpurun_out/r03c_bench.json 2> gpurun_out/r03c_bench.err
