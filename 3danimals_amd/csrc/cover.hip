@@ -11,22 +11,11 @@
 // One wave covers one 8x8 tile, so a work-group of 256 threads covers 4 tiles; entry k of the tile-ordered pixel space is
 //   k = ((b*H/8 + ty)*W/8 + tx)*64 + iy*8 + ix        (tile = 8)      or      k = flat index      (tile = 0, row-major).
 #include "a3d_common.h"
+#include "cover_common.h"
 
 namespace {
 
 constexpr int CV_BLOCK = 256;
-
-// (all 32-bit: B*H*W < 2^31 is checked by the entry points, and a 64-bit division costs ~150 instructions per thread)
-__device__ __forceinline__ long long cv_flat(long long k64, int H, int W, int tile) {
-    if (tile == 0) return k64;
-    const unsigned k = (unsigned)k64;
-    const unsigned in_tile = k & 63u;
-    unsigned t = k >> 6;
-    const unsigned tw = (unsigned)W >> 3, th = (unsigned)H >> 3;
-    const unsigned tx = t % tw; t /= tw;
-    const unsigned ty = t % th; t /= th;  // t = image
-    return (long long)((t * (unsigned)H + (ty * 8u + (in_tile >> 3))) * (unsigned)W + tx * 8u + (in_tile & 7u));
-}
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,
                                                             int* __restrict__ block_count, int* __restrict__ group_sum) {
@@ -41,19 +30,6 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_count_kernel(const float4* __rest
         block_count[blockIdx.x] = c;
         if (c) atomicAdd(group_sum + (long long)(blockIdx.x / A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, c);
     }
-}
-
-// entries of the list before work-group ``blk``: whole groups from the group sums, the rest of its own group from the block counts.
-// Computed by the FIRST WAVE only (<= nb/64 + 63 loads, a few per lane, all in flight at once) while the other waves are busy with
-// their pixels; the result reaches them through LDS at the barrier the kernel has anyway.
-__device__ __forceinline__ int cv_block_offset_wave0(const int* __restrict__ block_count, const int* __restrict__ group_sum, int blk) {
-    const int g = blk / A3D_COVER_GROUP, r = blk - g * A3D_COVER_GROUP;
-    const int lane = threadIdx.x & 63;
-    int mine = lane < r ? block_count[g * A3D_COVER_GROUP + lane] : 0;
-    for (int j = lane; j < g; j += 64) mine += group_sum[(long long)j * A3D_COVER_GROUP_STRIDE];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-    return mine;
 }
 
 __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restrict__ rast, long long n, int H, int W, int tile,

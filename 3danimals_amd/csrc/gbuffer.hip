@@ -26,20 +26,19 @@
 // The shared canonical mesh accumulates per image ([B,V,3]) and is reduced by the caller.
 // HBM traffic per covered pixel: fwd 8 (index) + 16 (texel) + 48 (out) B; bwd 8 + 16 + 48 B in; vertex data lives in L2.
 #include "a3d_common.h"
+#include "cover_common.h"
 
 __device__ __forceinline__ void gb_load3(const float* __restrict__ p, float& x, float& y, float& z) { x = p[0]; y = p[1]; z = p[2]; }
 
-__global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ rast, const int* __restrict__ tri, const long long* __restrict__ pix,
-                                                     long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
-                                                     const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
-                                                     float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    // the backward's gradient rows cleared here, while this launch is waiting for its gathers anyway (saves the backward its memset)
-    for (long long z = p; z < n_zero4; z += (long long)gridDim.x * blockDim.x) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p >= P) return;
-    const long long i = pix[p];
-    const float4 r = rast[i];
+// u*a + v*b + w*c with the fused multiply-adds written out: the two kernels that inline gb_row must round identically, whatever
+// contraction the compiler would pick in either context
+__device__ __forceinline__ float gb_mix(float u, float a, float v, float b, float w, float c) { return __builtin_fmaf(u, a, __builtin_fmaf(v, b, w * c)); }
+
+// the G-buffer row of one covered pixel: texel r of flat pixel i -> out row p (+ the optional extra attribute)
+__device__ __forceinline__ void gb_row(const float4 r, long long i, long long p, const int* __restrict__ tri, const float* __restrict__ v_pos,
+                                       const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch, int V, int F,
+                                       long long hw, float* __restrict__ out, const float* __restrict__ extra, int E,
+                                       float* __restrict__ extra_out) {
     const int f = (int)r.w - 1;
     float4* o4 = reinterpret_cast<float4*>(out + p * 12);  // rows are 48 bytes: three aligned 16-byte stores
     float o[12];
@@ -57,35 +56,85 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
     gb_load3(vp + 3ll * i0, ax, ay, az);
     gb_load3(vp + 3ll * i1, bx, by, bz);
     gb_load3(vp + 3ll * i2, cx, cy, cz);
-    o[0] = u * ax + v * bx + w * cx;
-    o[1] = u * ay + v * by + w * cy;
-    o[2] = u * az + v * bz + w * cz;
+    o[0] = gb_mix(u, ax, v, bx, w, cx);
+    o[1] = gb_mix(u, ay, v, by, w, cy);
+    o[2] = gb_mix(u, az, v, bz, w, cz);
     // geometric normal: safe_normalize(cross(p1 - p0, p2 - p0))   (render.py:185-188, util.py:28-32)
     const float e1x = bx - ax, e1y = by - ay, e1z = bz - az, e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
-    const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-    const float inv = 1.f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
+    const float nx = __builtin_fmaf(e1y, e2z, -(e1z * e2y)), ny = __builtin_fmaf(e1z, e2x, -(e1x * e2z)), nz = __builtin_fmaf(e1x, e2y, -(e1y * e2x));
+    const float inv = 1.f / sqrtf(fmaxf(__builtin_fmaf(nx, nx, __builtin_fmaf(ny, ny, nz * nz)), 1e-20f));
     o[3] = nx * inv; o[4] = ny * inv; o[5] = nz * inv;
     const float* vn = v_nrm + b * V * 3;
     gb_load3(vn + 3ll * i0, ax, ay, az);
     gb_load3(vn + 3ll * i1, bx, by, bz);
     gb_load3(vn + 3ll * i2, cx, cy, cz);
-    o[6] = u * ax + v * bx + w * cx;
-    o[7] = u * ay + v * by + w * cy;
-    o[8] = u * az + v * bz + w * cz;
+    o[6] = gb_mix(u, ax, v, bx, w, cx);
+    o[7] = gb_mix(u, ay, v, by, w, cy);
+    o[8] = gb_mix(u, az, v, bz, w, cz);
     const float* pr = prior + (prior_batch == 1 ? 0ll : b * V * 3);
     gb_load3(pr + 3ll * i0, ax, ay, az);
     gb_load3(pr + 3ll * i1, bx, by, bz);
     gb_load3(pr + 3ll * i2, cx, cy, cz);
-    o[9] = u * ax + v * bx + w * cx;
-    o[10] = u * ay + v * by + w * cy;
-    o[11] = u * az + v * bz + w * cz;
+    o[9] = gb_mix(u, ax, v, bx, w, cx);
+    o[10] = gb_mix(u, ay, v, by, w, cy);
+    o[11] = gb_mix(u, az, v, bz, w, cz);
     o4[0] = make_float4(o[0], o[1], o[2], o[3]);
     o4[1] = make_float4(o[4], o[5], o[6], o[7]);
     o4[2] = make_float4(o[8], o[9], o[10], o[11]);
     if (extra) {  // one more per-vertex attribute (the sequence models' 2-D motion, render.py:281-288), E <= 3 channels
         const float* eb = extra + b * V * E;
-        for (int c = 0; c < E; ++c) extra_out[p * E + c] = u * eb[(long long)i0 * E + c] + v * eb[(long long)i1 * E + c] + w * eb[(long long)i2 * E + c];
+        for (int c = 0; c < E; ++c) extra_out[p * E + c] = gb_mix(u, eb[(long long)i0 * E + c], v, eb[(long long)i1 * E + c], w, eb[(long long)i2 * E + c]);
     }
+}
+
+__global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ rast, const int* __restrict__ tri, const long long* __restrict__ pix,
+                                                     long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
+                                                     const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
+                                                     float* __restrict__ out, const float* __restrict__ extra, int E,
+                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the backward's gradient rows cleared here, while this launch is waiting for its gathers anyway (saves the backward its memset)
+    for (long long z = p; z < n_zero4; z += (long long)gridDim.x * blockDim.x) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p >= P) return;
+    const long long i = pix[p];
+    gb_row(rast[i], i, p, tri, v_pos, v_nrm, prior, prior_batch, V, F, hw, out, extra, E, extra_out);
+}
+
+// The covered-pixel list AND its G-buffer rows in one launch (a3d_cover_emit + a3d_gbuffer_fwd): thread = position k of the tile-ordered
+// pixel space; the texel is read ONCE (its id decides coverage, its barycentrics feed the row), the list position comes from the block
+// counts / group sums the rasteriser's resolve left (cover_common.h), covered pixels write their list entry, the pixel -> entry map and
+// their row.  One launch and one pass over the id channel less; the rows' gathers hide behind the 80 % of threads that only write -1.
+__global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restrict__ rast, long long n, int H, int W,
+                                                           const int* __restrict__ block_count, const int* __restrict__ group_sum,
+                                                           long long* __restrict__ pix, int* __restrict__ inv, const int* __restrict__ tri,
+                                                           const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
+                                                           const float* __restrict__ prior, int prior_batch, int V, int F,
+                                                           float* __restrict__ out, const float* __restrict__ extra, int E,
+                                                           float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
+    __shared__ int wave_n[4];
+    __shared__ int s_off;
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long z = k; z < n_zero4; z += (long long)gridDim.x * 256) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long flat = k < n ? cv_flat(k, H, W, 8) : 0;
+    const float4 r = k < n ? rast[flat] : make_float4(0.f, 0.f, 0.f, 0.f);  // (issued before the offset's loads: the latencies overlap)
+    const int wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const int off = cv_block_offset_wave0(block_count, group_sum, (int)blockIdx.x);
+        if (threadIdx.x == 0) s_off = off;
+    }
+    const bool on = r.w > 0.f;
+    const unsigned long long m = __ballot(on);
+    if ((threadIdx.x & 63) == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    if (!on) {
+        if (inv && k < n) inv[flat] = -1;
+        return;
+    }
+    int o = s_off + a3d_wave_prefix(m);
+    for (int w = 0; w < wave; ++w) o += wave_n[w];
+    pix[o] = flat;
+    if (inv) inv[flat] = o;
+    gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out);
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------
@@ -383,6 +432,27 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
                        (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null,
                        (float4*)g_rows_to_clear_or_null, n_zero4);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int B, int V, int F, int H, int W, const void* cover_scratch,
+                                     int64_t P, int64_t* pix, int32_t* inv_or_null, const float* v_pos, const float* v_nrm, const float* prior,
+                                     int prior_batch, float* out, const float* extra_or_null, int E, float* extra_out_or_null,
+                                     float* g_rows_to_clear_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(rast && cover_scratch && P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
+    A3D_CHECK_ARG(H % 8 == 0 && W % 8 == 0);  // the tile-ordered list (a3d_cover_count / a3d_rast_fwd's resolve with tile = 8)
+    A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || P == 0)));
+    A3D_CHECK_ARG(!g_rows_to_clear_or_null || ((uintptr_t)g_rows_to_clear_or_null & 63) == 0);
+    A3D_CHECK_ARG(P == 0 || (tri && pix && v_pos && v_nrm && prior && out));
+    A3D_CHECK_ARG(P > 0 || inv_or_null || g_rows_to_clear_or_null);  // (something to do)
+    const long long n = (long long)B * H * W;
+    const int nb = a3d_div_up(n, 256);
+    const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * (GB_ROW / 4) : 0;
+    hipLaunchKernelGGL(gb_cover_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, n, H, W, (const int*)cover_scratch,
+                       (const int*)cover_scratch + nb, (long long*)pix, inv_or_null, tri, v_pos, v_nrm, prior, prior_batch, V, F, out,
+                       extra_or_null, E, extra_out_or_null, (float4*)g_rows_to_clear_or_null, n_zero4);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -32,6 +32,7 @@ POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple
 LAST_RAST = [None]
 LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path handed from stage to stage in the last render_mesh call
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
+FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
@@ -258,14 +259,20 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
              and clip.shape[0] == mesh.v_pos.shape[0] and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr())
     if fused:
         b, h, w = rast.shape[:3]
-        pix, inv = ops.covered_pixels(rast, tile=PIXEL_TILE, return_inverse=True)  # one host sync for the number of covered pixels
         flow = None
-        if "flow" in render_modes and delta_xy.shape[-1] <= 3:  # the one extra attribute of the sequence models rides in the same kernels
-            gb, flow = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix, extra=delta_xy)  # [P,12], [P,2]
+        flow_fused = "flow" in render_modes and delta_xy.shape[-1] <= 3  # the one extra attribute of the sequence models rides in the same kernels
+        if FUSED_COVER_GBUFFER and PIXEL_TILE == 8 and h % 8 == 0 and w % 8 == 0:
+            # the covered-pixel list and its G-buffer rows from ONE launch (one host sync before it: the number of covered pixels)
+            res = ops.covered_gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, extra=delta_xy if flow_fused else None)
+            (gb, flow, pix, inv) = res if flow_fused else (res[0], None, res[1], res[2])
         else:
-            gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
-            if "flow" in render_modes:
-                flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)
+            pix, inv = ops.covered_pixels(rast, tile=PIXEL_TILE, return_inverse=True)  # one host sync for the number of covered pixels
+            if flow_fused:
+                gb, flow = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix, extra=delta_xy)  # [P,12], [P,2]
+            else:
+                gb = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix)  # [P,12]
+        if "flow" in render_modes and not flow_fused:
+            flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
                              render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb, inv=inv)
 

@@ -461,6 +461,18 @@ _cover_counts = _IdentityCache(maxsize=2)  # raster buffer -> block counts of it
 _aa_prepared = _IdentityCache(maxsize=2)  # raster buffer -> (key of its clip tensor, screen positions, zeroed counters)
 
 
+def _cover_counted(rast, tile):
+    """(scratch, length of the list): block counts + group sums left by the rasteriser's resolve (same launch), otherwise a counting pass
+    of our own; the ONE read-back: the group sums (a few KB; unused words are zero), added up on the host."""
+    B, H, W = rast.shape[:3]
+    scratch = _cover_counts.peek(rast) if tile == 8 else None
+    if scratch is None:
+        scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=rast.device)
+        call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
+    nb = _lib.lib().a3d_cover_blocks(B, H, W)
+    return scratch, int(scratch[nb:].cpu().sum())
+
+
 def covered_pixels(rast, tile=8, return_inverse=False):
     """int64 [P] flat indices of the pixels with rast[...,3] > 0, image-major, 8x8-tile order inside an image (``tile=8``; falls back
     to row-major when H or W is not a multiple of 8).  One 8-byte read-back (P) between the count and the emit launches.
@@ -471,13 +483,7 @@ def covered_pixels(rast, tile=8, return_inverse=False):
     if tile != 8 or H % 8 or W % 8:
         tile = 0
     dev = rast.device
-    # block counts + group sums left by the rasteriser's resolve (same launch); otherwise a counting pass of our own
-    scratch = _cover_counts.peek(rast) if tile == 8 else None
-    if scratch is None:
-        scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=dev)
-        call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
-    nb = _lib.lib().a3d_cover_blocks(B, H, W)
-    total = int(scratch[nb:].cpu().sum())  # the ONE read-back: the group sums (a few KB; unused words are zero), added up on the host
+    scratch, total = _cover_counted(rast, tile)
     pix = torch.empty(total, dtype=torch.int64, device=dev)
     inv = torch.empty(B * H * W, dtype=torch.int32, device=dev) if return_inverse else None
     if pix.shape[0] or return_inverse:
@@ -641,8 +647,15 @@ class _GBuffer(torch.autograd.Function):
         require_device(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra, what="gbuffer")
         clip, v_pos, v_nrm, prior, rast = f32c(clip), f32c(v_pos), f32c(v_nrm), f32c(prior), f32c(rast)
         B, H, W = rast.shape[:3]
-        V, P = v_pos.shape[1], pix.shape[0]
+        V = v_pos.shape[1]
         assert clip.shape[:2] == (B, V) and v_pos.shape[0] == B and v_nrm.shape == v_pos.shape and prior.shape[0] in (1, B)
+        listed = pix is None  # no list given: build it in the same launch (a3d_cover_gbuffer_fwd) and return it with the rows
+        inv = cover_scratch = None
+        if listed:
+            cover_scratch, P = _cover_counted(rast, 8)
+            pix = torch.empty(P, dtype=torch.int64, device=rast.device)
+            inv = torch.empty(B * H * W, dtype=torch.int32, device=rast.device)
+        P = pix.shape[0]
         assert pix.dtype == torch.int64 and pix.is_contiguous()
         out = torch.empty((P, 12), dtype=torch.float32, device=rast.device)
         E, extra_out = 0, None
@@ -655,17 +668,26 @@ class _GBuffer(torch.autograd.Function):
         # cleared by the forward launch: one memset less on the backward path
         needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
         rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device) if needs_grad else None
-        call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-             ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+        if listed:
+            call("a3d_cover_gbuffer_fwd", ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(cover_scratch), P, ptr(pix), ptr(inv), ptr(v_pos),
+                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+        else:
+            call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
+                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
         ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
         ctx.rows = rows
+        ctx.listed = listed
+        if listed:  # (out[, extra_out], pix, inv): the list rides along as non-differentiable outputs
+            ctx.mark_non_differentiable(pix, inv)
+            return (out, pix, inv) if extra is None else (out, extra_out, pix, inv)
         if extra is None:
             return out
         return out, extra_out
 
     @staticmethod
-    def backward(ctx, g_out, g_extra_out=None):
+    def backward(ctx, g_out, *more):
         clip, v_pos, v_nrm, prior, rast, tri32, pix, extra = ctx.saved_tensors
+        g_extra_out = more[0] if (extra is not None and more) else None
         B, H, W = rast.shape[:3]
         V, P = v_pos.shape[1], pix.shape[0]
         want_prior, want_clip = ctx.needs_input_grad[3], ctx.needs_input_grad[0]
@@ -690,6 +712,13 @@ class _GBuffer(torch.autograd.Function):
                 g_prior = g_prior.sum(0, keepdim=True)
         g_extra = rows[..., 9:9 + E] if (extra is not None and ctx.needs_input_grad[7]) else None
         return g_clip, g_vpos, g_vnrm, g_prior, None, None, None, g_extra
+
+
+def covered_gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, extra=None):
+    """covered_pixels(rast, return_inverse=True) + gbuffer(...) as ONE launch: (gb [P,12][, extra [P,E]], pix [P], inv [B*H*W]).
+    H and W must be multiples of 8 (the tile-ordered list)."""
+    assert rast.shape[1] % 8 == 0 and rast.shape[2] % 8 == 0
+    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, f32c(rast.detach()), tri_int32(tri), None, extra)
 
 
 def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix, extra=None):

@@ -112,6 +112,8 @@ def algorithmic_bytes(name, d):
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
         "a3d_gbuffer_fwd": P * (8 + 16 + 48),
+        # list + map + rows in one launch: every texel in (16 B/pixel), list + pixel -> entry map + rows out
+        "a3d_cover_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2

@@ -865,6 +865,48 @@ def test_fused_gbuffer_matches_generic_path_and_gradients(res, H, W, dev, mods, 
     np.testing.assert_allclose(gv.cpu().numpy(), a[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a[1].abs().max()))
 
 
+@pytest.mark.parametrize("E,hw,from_rasteriser", [(0, (64, 64), True), (2, (96, 80), True), (0, (48, 40), True), (3, (64, 64), False)])
+def test_cover_list_and_gbuffer_in_one_launch_equal_the_two_launches(E, hw, from_rasteriser, dev, ops, mods):
+    """a3d_cover_gbuffer_fwd (list + pixel -> entry map + G-buffer rows [+ extra attribute] from one launch) against a3d_cover_emit followed
+    by a3d_gbuffer_fwd: identical list, map and rows (bit for bit), identical gradients -- for buffers whose block counts came from the
+    rasteriser's resolve (H*W a multiple of 256), from a3d_cover_count (48x40), and for a buffer that did not come from the rasteriser."""
+    B, (H, W) = 3, hw
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, res=16, seed=7)
+    ru = importlib.import_module("3danimals_amd.model.render.renderutils")
+    tri = faces.to(dev)
+    posed = (verts[None] + 0.05 * seeded((B, *verts.shape), 31, -1, 1)).to(dev)
+    extra0 = seeded((B, verts.shape[0], E), 12, -1, 1).to(dev) if E else None
+
+    def run(fused):
+        v = posed.clone().requires_grad_(True)
+        pv = verts[None].to(dev).clone().requires_grad_(True)
+        m = mvp.to(dev).clone().requires_grad_(True)
+        ex = extra0.clone().requires_grad_(True) if E else None
+        nrm = ops.vertex_normals(v, tri)
+        clip = ru.xfm_points(v, m)
+        rast = ops.rasterize(clip, tri, (H, W))
+        if not from_rasteriser:
+            rast = rast.detach().clone()  # a buffer the rasteriser's caches do not know
+        if fused:
+            res = ops.covered_gbuffer(clip, v, nrm, pv, rast, tri, extra=ex)
+            gb, fl, pix, inv = res if E else (res[0], None, res[1], res[2])
+        else:
+            pix, inv = ops.covered_pixels(rast, return_inverse=True)
+            res = ops.gbuffer(clip, v, nrm, pv, rast, tri, pix, extra=ex)
+            gb, fl = res if E else (res, None)
+        loss = (gb * seeded(tuple(gb.shape), 41, -1, 1).to(dev)).sum() + ((fl * seeded(tuple(fl.shape), 42, -1, 1).to(dev)).sum() if E else 0)
+        grads = torch.autograd.grad(loss, [v, pv, m] + ([ex] if E else []))
+        return gb.detach(), None if fl is None else fl.detach(), pix, inv, grads
+
+    a, b = run(True), run(False)
+    assert a[2].shape[0] > 100 and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert torch.equal(a[0], b[0]) and (not E or torch.equal(a[1], b[1]))
+    for x, y in zip(a[4], b[4]):
+        scale = float(y.abs().max())
+        assert scale > 0
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)  # same kernels: atomic order only
+
+
 def test_fused_gbuffer_backward_table_overflow_falls_back_to_global_atomics(dev, mods, ops):
     """One tiny triangle per pixel, no shared vertices: 256 consecutive list entries reference 768 distinct vertices, more than the 512
     slots of the work-group's LDS table, so part of every block takes the global-atomic fallback of gb_bwd_kernel.  Gradients must still

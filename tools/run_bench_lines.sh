@@ -1,0 +1,11 @@
+#!/bin/bash
+# every committed bench line of a round (run on the GPU box from the repo root):  bash tools/run_bench_lines.sh <tag>
+TAG=${1:-r03}
+mkdir -p gpurun_out
+run() { name=$1; shift; python bench.py "$@" > gpurun_out/${TAG}_bench_${name}.json 2> gpurun_out/${TAG}_bench_${name}.err || (echo "$name FAILED"; tail -5 gpurun_out/${TAG}_bench_${name}.err); tail -c 300 gpurun_out/${TAG}_bench_${name}.json | head -c 0; echo "$name done"; }
+run default
+run fwd_b8_grid64 --forward-only --batch 8 --networks fast
+run fwd_b8_grid128 --forward-only --batch 8 --networks fast --grid-res 128 --cpu-sample-images 2 --cpu-runs 1
+run grid128 --grid-res 128 --networks fast --cpu-sample-images 2 --cpu-runs 1
+run fauna --workload fauna --networks fast
+run ponymation --workload ponymation --networks fast --cpu-sample-images 8 --cpu-runs 1
