@@ -60,14 +60,21 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     const int b = blockIdx.y;
     // the backward's per-image transform gradient (accumulated there with atomics) cleared here: one memset less on the backward path
     for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; z < n_clear; z += gridDim.x * gridDim.y * blockDim.x) clear[z] = 0.f;
+    __shared__ float s_L[POSE ? SK_MAXK : 1][13];
+    __shared__ int s_chain[POSE ? SK_MAXK * BN_MAXD : 1];
+    const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6);
     if (POSE) {
-        __shared__ float s_L[POSE ? SK_MAXK : 1][13];
-        __shared__ int s_chain[POSE ? SK_MAXK * BN_MAXD : 1];
-        const float* bb = bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6);
         const float* aa = angles + (long long)b * K * 3;
         for (int w = threadIdx.x; w < K * D; w += blockDim.x) s_chain[w] = chain[w];
         for (int i = threadIdx.x; i < K; i += blockDim.x) bn_store(s_L[i], bn_link(bb + 6 * i, aa + 3 * i));
-        __syncthreads();
+        sk_stage_bones(bb, K, s_bone);
+    } else {
+        sk_stage(bb, T + (long long)b * K * 12, K, s_bone, s_T);
+    }
+    __syncthreads();
+    if (POSE) {
+        // the K chain products (K threads, ~8 dependent LDS round trips) run WHILE the rest of the work-group computes its vertices'
+        // K logits, which only need the bones; the blend below waits for both at one barrier
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
             A34 acc = bn_identity();
             for (int j = 0; j < D; ++j) {
@@ -80,28 +87,33 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
         // one work-group per image (not the one that writes T) leaves the prefix / suffix products of every chain position for the
         // backward's tail (bn_chain_adjoint_ps): off the critical path here, ~7 us off it there
         if (PS && blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * K * D * 24);
-        sk_stage_bones(bb, K, s_bone);
-    } else {
-        sk_stage(bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6), T + (long long)b * K * 12, K, s_bone, s_T);
     }
-    __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + i) * 3;
+    // FOUR lanes per vertex (a quad), each with a quarter of the bones: the K logits are a sqrt + an exp each and a thread that does all
+    // twenty is ~2000 dependent instructions with 1.5 waves per SIMD to hide them behind (the kernel took 9 us for 1 MB); four times
+    // the waves with a quarter of the chain each, and the quad meets through DPP (max, then the four sums)
+    const int i = blockIdx.x * (SK_THREADS / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool valid = i < V;
+    const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + (valid ? i : 0)) * 3;
     const float px = p[0], py = p[1], pz = p[2];
-    float lg[KMAX];
+    constexpr int KQ = (KMAX + 3) / 4;
+    float lg[KQ];
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        lg[k] = k < K ? sk_logit(s_bone[k], px, py, pz, neg_inv_temp) : -INFINITY;
-        m = fmaxf(m, lg[k]);
+    for (int q = 0; q < KQ; ++q) {
+        const int k = 4 * q + sub;
+        lg[q] = k < K ? sk_logit(s_bone[k < K ? k : 0], px, py, pz, neg_inv_temp) : -INFINITY;
+        m = fmaxf(m, lg[q]);
     }
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+    if (POSE) __syncthreads();  // s_T complete
     float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int q = 0; q < KQ; ++q) {
+        const int k = 4 * q + sub;
         if (k < K) {
-            const float e = __expf(lg[k] - m);
-            lg[k] = e;
+            const float e = __expf(lg[q] - m);
+            lg[q] = e;
             const float* t = s_T + 12 * k;
             s += e;
             ox += e * (t[0] * px + t[1] * py + t[2] * pz + t[3]);
@@ -109,15 +121,23 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
             oz += e * (t[8] * px + t[9] * py + t[10] * pz + t[11]);
         }
     }
+    auto quad_sum = [](float r) {
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0xB1, 0xF, 0xF, true));
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x4E, 0xF, 0xF, true));
+        return r;
+    };
+    s = quad_sum(s); ox = quad_sum(ox); oy = quad_sum(oy); oz = quad_sum(oz);
+    if (!valid) return;
     const float inv = 1.f / s;
-    float* o = out + ((long long)b * V + i) * 3;
-    o[0] = ox * inv; o[1] = oy * inv; o[2] = oz * inv;
+    if (sub < 3) out[((long long)b * V + i) * 3 + sub] = (sub == 0 ? ox : (sub == 1 ? oy : oz)) * inv;
     if (weights) {  // [K, Bw, V]; only images that own distinct weights write
         const int Bw = (v_batch == 1 && bones_batch == 1) ? 1 : (int)gridDim.y;
         if (b < Bw) {
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K) weights[((long long)k * Bw + b) * V + i] = lg[k] * inv;
+            for (int q = 0; q < KQ; ++q) {
+                const int k = 4 * q + sub;
+                if (k < K) weights[((long long)k * Bw + b) * V + i] = lg[q] * inv;
+            }
         }
     }
 }
@@ -268,7 +288,7 @@ extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int
     A3D_CHECK_ARG(v && bones && T && out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
-    const dim3 grid(a3d_div_up(V, SK_THREADS), B), block(SK_THREADS);
+    const dim3 grid(a3d_div_up(V, SK_THREADS / 4), B), block(SK_THREADS);  // four lanes per vertex
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
     const int ncl = g_T_to_clear_or_null ? B * K * 12 : 0;
@@ -319,7 +339,7 @@ extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones
     // g_T[B,K,12] and the B tickets are cleared as ONE run of 4-byte words: the caller allocates them back to back
     A3D_CHECK_ARG((g_T_to_clear_or_null == nullptr) == (ticket_to_clear_or_null == nullptr));
     A3D_CHECK_ARG(!g_T_to_clear_or_null || (void*)ticket_to_clear_or_null == (void*)(g_T_to_clear_or_null + (size_t)B * K * 12));
-    const dim3 grid(a3d_div_up(V, SK_THREADS), B), block(SK_THREADS);
+    const dim3 grid(a3d_div_up(V, SK_THREADS / 4), B), block(SK_THREADS);  // four lanes per vertex
     const int ncl = g_T_to_clear_or_null ? B * K * 12 + B : 0;
     float* no_w = nullptr;
     hipLaunchKernelGGL((sk_fwd_kernel<20, true>), grid, block, 0, (hipStream_t)stream, v, v_batch, bones, bones_batch, T_out, V, K,
