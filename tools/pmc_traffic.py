@@ -18,8 +18,12 @@ ENTRY = {
     "a3d_dmtet_count": (["dm_count_kernel", "dm_scan_kernel"], "dm_count_kernel"),
     "a3d_dmtet_emit": (["dm_emit_kernel"], "dm_emit_kernel"),
     "a3d_dmtet_bwd": (["dm_bwd_kernel"], "dm_bwd_kernel"),
-    "a3d_skin_fwd": (["sk_fwd_kernel"], "sk_fwd_kernel"),
-    "a3d_skin_bwd": (["sk_bwd_kernel"], "sk_bwd_kernel"),
+    "a3d_skin_fwd": (["sk_fwd_kernel<20, false>", "sk_fwd_kernel<32, false>", "sk_fwd_kernel<64, false>"], None),
+    "a3d_skin_bwd": (["sk_bwd_kernel<5, false>", "sk_bwd_kernel<8, false>", "sk_bwd_kernel<16, false>"], None),
+    "a3d_skin_pose_fwd": (["sk_fwd_kernel<20, true>"], None),
+    "a3d_skin_pose_bwd": (["sk_bwd_kernel<5, true>"], None),
+    "a3d_mesh_topology_finalize": (["tp_finalize_kernel"], "tp_finalize_kernel"),
+    "a3d_cover_gbuffer_fwd": (["gb_cover_fwd_kernel"], "gb_cover_fwd_kernel"),
     "a3d_bone_transforms_fwd": (["bn_fwd_kernel"], "bn_fwd_kernel"),
     "a3d_bone_transforms_bwd": (["bn_bwd_kernel"], "bn_bwd_kernel"),
     "a3d_mesh_topology": (["tp_init_kernel", "tp_count_insert_kernel", "nr_adj_scan_kernel", "tp_fill_lookup_kernel", "nr_adj_sort_kernel"],
@@ -27,7 +31,7 @@ ENTRY = {
     "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
     "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel"], "nr_bwd_kernel"),
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
-    "a3d_cover_count": (["cv_count_kernel", "cv_scan_kernel"], "cv_count_kernel"),
+    "a3d_cover_count": (["cv_count_kernel"], "cv_count_kernel"),
     "a3d_cover_emit": (["cv_emit_kernel"], "cv_emit_kernel"),
     "a3d_gbuffer_fwd": (["gb_fwd_kernel"], "gb_fwd_kernel"),
     "a3d_gbuffer_bwd": (["gb_bwd_kernel"], "gb_bwd_kernel"),
@@ -72,6 +76,8 @@ def main():
     for entry, (kernels, main_k) in ENTRY.items():
         def pick(tot, cnt):
             ks = [k for k in tot if any(k.startswith(s) or k == s for s in kernels)]
+            if entry in ("a3d_gbuffer_fwd",):  # (prefix of gb_fwd_kernel only, not gb_cover_fwd_kernel)
+                ks = [k for k in ks if not k.startswith("gb_cover")]
             if not ks:
                 return None
             calls = cnt.get(main_k, 0) if main_k else sum(cnt[k] for k in ks)
