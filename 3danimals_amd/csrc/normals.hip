@@ -79,12 +79,19 @@ __device__ __forceinline__ void nr_first_keys(const int* __restrict__ adj, int l
     nr_sort8(keys);
 }
 
+// (v2 / acc2 / nrm2: a SECOND vertex array over the same triangle list -- images B1, B1+1, ... of the launch -- so that e.g. the one
+// canonical mesh does not cost a launch of its own beside the B posed ones: a3d_normals_fwd_pair)
 __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v, const int* __restrict__ tri, const int* __restrict__ off,
                                                      const int* __restrict__ adj, int V, int F, float* __restrict__ acc,
-                                                     float* __restrict__ nrm) {
+                                                     float* __restrict__ nrm, int B1, const float* __restrict__ v2,
+                                                     float* __restrict__ acc2, float* __restrict__ nrm2) {
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
-    const long long vb = (long long)blockIdx.y * V;
+    long long vb = (long long)blockIdx.y * V;
+    if ((int)blockIdx.y >= B1) {
+        v = v2; acc = acc2; nrm = nrm2;
+        vb = (long long)((int)blockIdx.y - B1) * V;
+    }
     const float* vp = v + vb * 3;
     float x = 0.f, y = 0.f, z = 0.f;
     const int lo = off[vi], cnt = off[vi + 1] - lo;
@@ -241,7 +248,19 @@ extern "C" int a3d_normals_fwd(const float* v, const int32_t* tri, const int32_t
     A3D_CHECK_ARG(v && off && acc && nrm && B > 0 && V > 0 && F >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     (void)lists_sorted;  // (kept in the ABI: the kernels order the keys themselves, a sorted list is simply an easy input)
-    hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, (hipStream_t)stream, v, tri, off, adj, V, F, acc, nrm);
+    hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, (hipStream_t)stream, v, tri, off, adj, V, F, acc, nrm, B,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_normals_fwd_pair(const float* v_a, int B_a, const float* v_b, int B_b, const int32_t* tri, const int32_t* off,
+                                    const int32_t* adj, int V, int F, float* acc_a, float* nrm_a, float* acc_b, float* nrm_b,
+                                    a3d_stream_t stream) {
+    A3D_CHECK_ARG(v_a && v_b && off && acc_a && nrm_a && acc_b && nrm_b && B_a > 0 && B_b > 0 && B_a + B_b <= 65535 && V > 0 && F >= 0);
+    A3D_CHECK_ARG(F == 0 || (tri && adj));
+    hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B_a + B_b), dim3(256), 0, (hipStream_t)stream, v_a, tri, off, adj, V, F, acc_a,
+                       nrm_a, B_a, v_b, acc_b, nrm_b);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -9,6 +9,8 @@ Differences that do not change results on the hot path:
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from ... import ops
@@ -16,6 +18,20 @@ from . import util
 
 
 LAZY_NORMALS = True  # auto_normals defers the kernel to the first read of Mesh.v_nrm (same values; False = at make_mesh time)
+PAIR_NORMALS = True  # ... and a pending small mesh (<= PAIR_MAX_BATCH images: the canonical one) over the SAME triangle list rides in that launch
+PAIR_MAX_BATCH = 2
+_pending_normals = {}  # (storage pointer, shape, version) of t_pos_idx -> [weakref to meshes whose normals are still pending]
+
+
+def _tri_key(t):
+    return (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+
+
+def _register_pending(m):
+    if PAIR_NORMALS and m._lazy_nrm is not None and m._v_nrm is None and m.t_pos_idx is not None:
+        if len(_pending_normals) > 32:
+            _pending_normals.clear()
+        _pending_normals.setdefault(_tri_key(m.t_pos_idx), []).append(weakref.ref(m))
 
 
 class Mesh:
@@ -42,8 +58,13 @@ class Mesh:
     @property
     def v_nrm(self):
         if self._v_nrm is None and self._lazy_nrm is not None:
+            partner = self._normals_partner()
             with torch.set_grad_enabled(self._lazy_nrm):
-                self._v_nrm = ops.vertex_normals(self.v_pos, self.t_pos_idx)
+                if partner is None:
+                    self._v_nrm = ops.vertex_normals(self.v_pos, self.t_pos_idx)
+                else:  # the canonical mesh's normals (read by the regulariser every iteration, AnimalModel.py:317-328) from the same launch
+                    self._v_nrm, partner._v_nrm = ops.vertex_normals_pair(self.v_pos, partner.v_pos, self.t_pos_idx)
+                    partner._lazy_nrm = None
             self._lazy_nrm = None
             if torch.is_anomaly_enabled():
                 assert torch.all(torch.isfinite(self._v_nrm))
@@ -52,6 +73,28 @@ class Mesh:
     @v_nrm.setter
     def v_nrm(self, value):
         self._v_nrm, self._lazy_nrm = value, None
+
+    def _normals_partner(self):
+        """Another live mesh over the same triangle list whose normals are pending too and which is small (the one canonical mesh beside
+        the B posed ones): its normals are computed in this mesh's launch instead of a launch of their own later (one image = pure
+        launch latency).  Speculative for at most PAIR_MAX_BATCH images; the deformed meshes (B images, never read) are not picked up."""
+        if not PAIR_NORMALS or self.t_pos_idx is None or not self.v_pos.is_cuda:
+            return None
+        entries = _pending_normals.get(_tri_key(self.t_pos_idx))
+        if not entries:
+            return None
+        found = None
+        alive = []
+        for ref in entries:
+            m = ref()
+            if m is None or m._lazy_nrm is None or m._v_nrm is not None:
+                continue
+            alive.append(ref)
+            if (found is None and m is not self and m._lazy_nrm == self._lazy_nrm and m.v_pos.shape[0] <= PAIR_MAX_BATCH
+                    and m.v_pos.shape[1] == self.v_pos.shape[1] and m.v_pos.device == self.v_pos.device and m.t_nrm_idx is m.t_pos_idx):
+                found = m
+        _pending_normals[_tri_key(self.t_pos_idx)] = alive
+        return found
 
     # tangents on demand ----------------------------------------------------------------------------
     @property
@@ -86,6 +129,7 @@ class Mesh:
                 self._v_nrm = other.v_nrm  # the normals belong to the other mesh's vertices: compute them there
             else:
                 self._v_nrm, self._lazy_nrm = other._v_nrm, other._lazy_nrm
+                _register_pending(self)  # (the mesh make_mesh returns is a copy of the one auto_normals marked)
         if self._v_tng is None:
             self._v_tng, self._lazy_tng = other._v_tng, other._lazy_tng
         if self._t_tng_idx is None:
@@ -185,6 +229,7 @@ def auto_normals(imesh):
     if LAZY_NORMALS:
         out = Mesh(t_nrm_idx=imesh.t_pos_idx, base=imesh)
         out._v_nrm, out._lazy_nrm = None, torch.is_grad_enabled()
+        _register_pending(out)
         return out
     v_nrm = ops.vertex_normals(imesh.v_pos, imesh.t_pos_idx)
     if torch.is_anomaly_enabled():

@@ -450,6 +450,48 @@ class _Normals(torch.autograd.Function):
         return g_v, None, None
 
 
+class _NormalsPair(torch.autograd.Function):
+    """Vertex normals of two vertex arrays over one triangle list from ONE launch: (nrm_a [Ba,V,3], nrm_b [Bb,V,3])."""
+
+    @staticmethod
+    def forward(ctx, v_a, v_b, tri32, adjacency):
+        require_device(v_a, v_b, tri32, what="vertex_normals_pair")
+        v_a, v_b = f32c(v_a), f32c(v_b)
+        V, F = v_a.shape[1], tri32.shape[0]
+        assert v_b.shape[1] == V
+        acc_a, nrm_a, acc_b, nrm_b = torch.empty_like(v_a), torch.empty_like(v_a), torch.empty_like(v_b), torch.empty_like(v_b)
+        call("a3d_normals_fwd_pair", ptr(v_a), v_a.shape[0], ptr(v_b), v_b.shape[0], ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), V, F,
+             ptr(acc_a), ptr(nrm_a), ptr(acc_b), ptr(nrm_b), stream(), tag=f"[B{v_a.shape[0]}+B{v_b.shape[0]}]")
+        ctx.save_for_backward(v_a, acc_a, v_b, acc_b, tri32)
+        ctx.adjacency = adjacency
+        ctx.set_materialize_grads(False)
+        return nrm_a, nrm_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        v_a, acc_a, v_b, acc_b, tri32 = ctx.saved_tensors
+        F = tri32.shape[0]
+        out = []
+        for v, acc, g in ((v_a, acc_a, g_a), (v_b, acc_b, g_b)):
+            if g is None:
+                out.append(None)
+                continue
+            B, V = v.shape[0], v.shape[1]
+            if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(0) != V * g.stride(1):
+                g = f32c(g)
+            scratch, g_v = torch.empty_like(v), torch.empty_like(v)
+            call("a3d_normals_bwd", ptr(g), g.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
+                 ptr(scratch), ptr(g_v), int(ctx.adjacency.sorted), stream(), tag=f"[B{B}]")
+            out.append(g_v)
+        return out[0], out[1], None, None
+
+
+def vertex_normals_pair(v_a, v_b, tri):
+    """(normals of v_a, normals of v_b): two meshes that share ``tri``, one launch."""
+    tri32 = tri_int32(tri)
+    return _NormalsPair.apply(v_a, v_b, tri32, vertex_face_adjacency(tri32, v_a.shape[1]))
+
+
 def vertex_normals(v, tri):
     """Area-weighted, normalised vertex normals [B,V,3] (auto_normals); the adjacency is built once per triangle list."""
     tri32 = tri_int32(tri)

@@ -135,6 +135,11 @@ int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, co
 int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apart*/, int g_nrm_stride, const float* acc, const float* v,
                     const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3]*/,
                     float* g_v /*[B,V,3]*/, int lists_sorted, a3d_stream_t stream);
+/* Two vertex arrays over ONE triangle list in one launch (e.g. the canonical mesh beside the B posed meshes of an iteration: a launch
+ * of its own for one image is pure latency); results identical to two a3d_normals_fwd calls. */
+int a3d_normals_fwd_pair(const float* v_a /*[B_a,V,3]*/, int B_a, const float* v_b /*[B_b,V,3]*/, int B_b, const int32_t* tri,
+                         const int32_t* off, const int32_t* adj, int V, int F, float* acc_a, float* nrm_a, float* acc_b, float* nrm_b,
+                         a3d_stream_t stream);
 /* lists_sorted: informational (1 = every list of adj is stored in ascending key order: a3d_normals_adjacency, a3d_mesh_topology; 0 = any
  * order: a3d_mesh_topology_finalize).  The kernels take a vertex's list into registers, order the keys there and issue all gathers at
  * once, so the sums run in ascending key order -- the same bits -- either way. */

@@ -199,6 +199,46 @@ def test_normals_adjacency_and_bit_reproducibility(dev, ops):
     print(f"normals bit-identical to the reference CPU golden on {exact:.4%} of elements")
 
 
+def test_canonical_mesh_normals_ride_in_the_posed_meshes_launch(dev, ops, mods):
+    """make_mesh for the canonical mesh (B = 1) and for B posed meshes over the same triangle list: the first read of the posed meshes'
+    normals computes the canonical mesh's too (one launch, a3d_normals_fwd_pair) -- same bits as separate launches, gradients reach both
+    vertex arrays, a larger pending mesh (the deformed ones, never read) is not picked up, and nothing is shared across triangle lists."""
+    M = mods["mesh"]
+    L = importlib.import_module("3danimals_amd._lib")
+    verts, faces = quadruped_mesh(16, 0.3)
+    tri = faces.to(dev)[None]
+    uv, uvi = torch.zeros(1, 4, 2, device=dev), torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    B = 5
+    v1 = verts[None].to(dev).requires_grad_(True)
+    vB = (verts[None] + 0.03 * seeded((B, *verts.shape), 3, -1, 1)).to(dev).requires_grad_(True)
+    vD = (verts[None] + 0.01 * seeded((B, *verts.shape), 4, -1, 1)).to(dev)
+    prior = M.make_mesh(v1, tri, uv, uvi, None)
+    deformed = M.make_mesh(vD, tri, uv.expand(B, -1, -1), uvi, None)
+    posed = M.make_mesh(vB, tri, uv.expand(B, -1, -1), uvi, None)
+    with L.KernelTimer() as timer:
+        nB = posed.v_nrm
+        n1 = prior.v_nrm  # already there
+    names = [n for n in timer.summary() if n.startswith("a3d_normals")]  # (+ a3d_mesh_topology: this list did not come from the DMTet emit)
+    assert names == [f"a3d_normals_fwd_pair[B{B}+B1]"], names
+    assert deformed._v_nrm is None and deformed._lazy_nrm is not None  # not touched
+    ref1, refB = ops.vertex_normals(v1.detach(), tri), ops.vertex_normals(vB.detach(), tri)
+    assert torch.equal(n1, ref1) and torch.equal(nB, refB)
+    w1, wB = seeded(tuple(n1.shape), 5, -1, 1).to(dev), seeded(tuple(nB.shape), 6, -1, 1).to(dev)
+    g1, gB = torch.autograd.grad((n1 * w1).sum() + (nB * wB).sum(), [v1, vB])
+    v1r, vBr = v1.detach().clone().requires_grad_(True), vB.detach().clone().requires_grad_(True)
+    r1, rB = torch.autograd.grad((ops.vertex_normals(v1r, tri) * w1).sum() + (ops.vertex_normals(vBr, tri) * wB).sum(), [v1r, vBr])
+    assert torch.equal(g1, r1) and torch.equal(gB, rB)
+    # only one of the pair used downstream: the other's gradient is simply absent
+    prior2, posed2 = M.make_mesh(v1, tri, uv, uvi, None), M.make_mesh(vB, tri, uv.expand(B, -1, -1), uvi, None)
+    (gB2,) = torch.autograd.grad((posed2.v_nrm * wB).sum(), [vB])
+    assert torch.equal(gB2, rB) and prior2._v_nrm is not None
+    # another triangle list: no pairing
+    other = M.make_mesh(v1, tri.clone(), uv, uvi, None)
+    posed3 = M.make_mesh(vB, tri, uv.expand(B, -1, -1), uvi, None)
+    _ = posed3.v_nrm
+    assert other._v_nrm is None
+
+
 def test_normals_isolated_vertex_and_empty(dev, ops):
     g = golden("mesh_isolated.npz")
     nrm = ops.vertex_normals(torch.from_numpy(g["v_pos"]).to(dev), torch.from_numpy(g["faces"]).to(dev))
