@@ -53,9 +53,20 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """(per-call traffic table or None, note, stale flag): the newest committed PMC file whose stamp equals the current kernel sources."""
+PMC_WORKLOAD = "magicpony grid64 batch16 256x256 train"  # what tools/pmc_traffic.sh profiles (bench.py's default command)
+
+
+def workload_signature(args, batch):
+    return f"{args.workload} grid{args.grid_res} batch{batch} {args.resolution}x{args.resolution} {'forward' if args.forward_only else 'train'}"
+
+
+def pmc_traffic(signature=PMC_WORKLOAD):
+    """(per-call traffic table or None, note, stale flag): the newest committed PMC file whose stamp equals the current kernel sources --
+    for the workload it was taken on only (bytes per call depend on the mesh and the batch)."""
     import glob
+
+    if signature != PMC_WORKLOAD:
+        return None, f"the committed PMC passes profile the default workload ({PMC_WORKLOAD}), not this one ({signature})", False
 
     files = sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True)
     if not files:
@@ -176,10 +187,10 @@ def kernel_pass(scene, module, L, steps, world, dims_of, train=True):
     return kernels, dims
 
 
-def roofline_of(kernels, dims):
+def roofline_of(kernels, dims, signature=PMC_WORKLOAD):
     scope = {k: v for k, v in kernels.items() if k.startswith(IN_SCOPE) and v["GBps"] is not None}
     dom = max(scope, key=lambda k: scope[k]["mean_us"] * scope[k]["launches_per_step"])  # most time per step among the in-scope entry points
-    table, traffic_note, stale = pmc_traffic()
+    table, traffic_note, stale = pmc_traffic(signature)
     rec = None if table is None else table.get(dom.split("[")[0])
     traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
     roof = dict(kernel=dom, bound="hbm", achieved=scope[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(scope[dom]["GBps"] / HBM_PEAK_GBS, 4),
@@ -405,7 +416,7 @@ def main():
     roofline, kernels = None, {}
     if rank == 0 and not args.no_kernel_timing:
         kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of, train)
-        roofline = roofline_of(kernels, dims)
+        roofline = roofline_of(kernels, dims, workload_signature(args, batch))
 
     # ---- blocking host <-> device synchronisations inside one steady-state step (torch's sync-debug hook; sizes that shapes depend on)
     host_syncs = None

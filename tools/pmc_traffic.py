@@ -93,7 +93,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
 
-    out = dict(kernel_source_sha16=bench.kernel_source_sha16(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
+    out = dict(kernel_source_sha16=bench.kernel_source_sha16(), workload=bench.PMC_WORKLOAD, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
                     "MB per C-ABI call; traffic = 2*FETCH (gfx950 correction for wide reads, upper bound for gathers) + WRITE; "
                     "the copy/memset helpers of an entry point (hipMemcpyAsync / hipMemsetAsync) are not included", per_call=per_call)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
