@@ -3,8 +3,9 @@
 Put ``3danimals_amd/shims`` on ``sys.path`` and the reference's unchanged callers --
 ``dr.RasterizeGLContext()`` (AnimalModel.py:235-236), ``dr.DepthPeeler`` / ``dr.interpolate`` / ``dr.antialias``
 (render.py:24,264-267,292-294), ``dr.rasterize`` (render.py:351, visualize_results.py:225-229) -- run on MI355X
-without OpenGL or CUDA.  ``dr.texture`` has no call site on the reconstruct-and-render path (only EnvironmentLight,
-Texture2D mips and image_grad use it, all dead code in every config) and raises.
+without OpenGL or CUDA.  Instanced and range mode, ``grad_db``, ``diff_attrs`` and ``pos_gradient_boost`` are covered; ``dr.texture`` has
+no call site on the reconstruct-and-render path (only EnvironmentLight, Texture2D mips and image_grad use it, all dead code in every
+config) and raises.
 """
 import importlib
 
@@ -72,34 +73,54 @@ def _rast_db(pos, tri, rast, grad_db):
     return _LazyRastDb(lambda: _ops.rasterize_db(pos.detach(), tri, rast.detach()))
 
 
-def _check(pos, tri, resolution):
+def _check(pos, tri, resolution, ranges=None):
     if not (torch.is_tensor(pos) and torch.is_tensor(tri)):
         raise RuntimeError("pos and tri must be tensors")
-    if pos.dim() != 3 or pos.shape[-1] != 4:
-        raise RuntimeError("pos must have shape [minibatch, num_vertices, 4] (range mode is not supported)")
+    if ranges is None:
+        if pos.dim() != 3 or pos.shape[-1] != 4:
+            raise RuntimeError("instanced mode: pos must have shape [minibatch, num_vertices, 4]")
+    else:  # range mode: one shared vertex array, image b renders the triangles ranges[b] = (first, count)
+        if pos.dim() != 2 or pos.shape[-1] != 4:
+            raise RuntimeError("range mode: pos must have shape [num_vertices, 4]")
+        if not torch.is_tensor(ranges) or ranges.dim() != 2 or ranges.shape[-1] != 2 or ranges.dtype != torch.int32 or ranges.is_cuda:
+            raise RuntimeError("range mode: ranges must be a CPU int32 tensor of shape [minibatch, 2]")
     if tri.dim() != 2 or tri.shape[-1] != 3:
         raise RuntimeError("tri must have shape [num_triangles, 3]")
     if len(resolution) != 2:
         raise RuntimeError("resolution must be [height, width]")
 
 
+def _rasterize_ranges(pos, tri, resolution, ranges, prev=None):
+    """Range mode (nvdiffrast: pos [V,4], ranges [B,2] = (first triangle, count) per image): one rasterisation per image over its slice
+    of the triangle list, ids re-based to the full list.  No config of the reference uses it (render.py:292-294 is instanced); it
+    exists so that the stand-in covers the operator's whole signature.  Gradients reach the shared ``pos`` from every image."""
+    layers = []
+    for b, (first, count) in enumerate(ranges.tolist()):
+        if count <= 0:
+            layers.append(torch.zeros((1, int(resolution[0]), int(resolution[1]), 4), dtype=torch.float32, device=pos.device))
+            continue
+        r = _ops.rasterize(pos[None], tri[first:first + count].contiguous(), resolution, prev=None if prev is None else prev[b:b + 1])
+        ids = r[..., 3:]
+        layers.append(torch.cat((r[..., :3], torch.where(ids > 0, ids + float(first), ids)), dim=-1))
+    return torch.cat(layers, dim=0)
+
+
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     """-> (rast [B,H,W,4] = (u, v, z/w, triangle_id+1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)).  The image-space
     derivatives are analytic (ops.rasterize_db, torch ops) and computed on first use: no caller on the training path consumes them
     (render.py:24)."""
+    _check(pos, tri, resolution, ranges)
     if ranges is not None:
-        raise NotImplementedError("range mode")
-    _check(pos, tri, resolution)
+        rast = _rasterize_ranges(pos, tri, resolution, ranges)
+        return rast, _rast_db(pos[None], tri, rast, grad_db)
     rast = _ops.rasterize(pos, tri, resolution)
     return rast, _rast_db(pos, tri, rast, grad_db)
 
 
 class DepthPeeler:
     def __init__(self, glctx, pos, tri, resolution, ranges=None, grad_db=True):
-        if ranges is not None:
-            raise NotImplementedError("range mode")
-        _check(pos, tri, resolution)
-        self.pos, self.tri, self.resolution, self.grad_db = pos, tri, resolution, grad_db
+        _check(pos, tri, resolution, ranges)
+        self.pos, self.tri, self.resolution, self.grad_db, self.ranges = pos, tri, resolution, grad_db, ranges
         self.layer, self._prev = 0, None
 
     def __enter__(self):
@@ -110,15 +131,27 @@ class DepthPeeler:
 
     def rasterize_next_layer(self):
         """Layer 0 = rasterize(); layer n = the nearest surface strictly behind layer n-1 (depth peeling)."""
-        rast = _ops.rasterize(self.pos, self.tri, self.resolution, prev=self._prev)
+        if self.ranges is not None:
+            prev = self._prev
+            if prev is not None:  # the previous layer's ids are indices into the full list: back to each image's slice for the peel
+                first = self.ranges[:, 0].to(prev.device).float().view(-1, 1, 1, 1)
+                ids = prev[..., 3:]
+                prev = torch.cat((prev[..., :3], torch.where(ids > 0, ids - first, ids)), dim=-1)
+            rast = _rasterize_ranges(self.pos, self.tri, self.resolution, self.ranges, prev=prev)
+            pos_db = self.pos[None]
+        else:
+            rast = _ops.rasterize(self.pos, self.tri, self.resolution, prev=self._prev)
+            pos_db = self.pos
         self.layer += 1
         self._prev = rast.detach()
-        return rast, _rast_db(self.pos, self.tri, rast, self.grad_db)
+        return rast, _rast_db(pos_db, self.tri, rast, self.grad_db)
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     """-> (out [B,H,W,C], out_da).  With ``rast_db`` and ``diff_attrs`` ('all' or a list of attribute indices) out_da
     [B,H,W,2*len(diff_attrs)] holds (dA/dX, dA/dY) per selected attribute: dA/dX = du/dX (A0 - A2) + dv/dX (A1 - A2) (torch ops)."""
+    if attr.dim() == 2:  # range mode: one shared attribute array
+        attr = attr[None]
     out = _ops.interpolate(attr, rast, tri)
     if rast_db is None or diff_attrs is None:
         return out, torch.empty(0, device=rast.device)
@@ -127,11 +160,24 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     return out, _ops.interpolate_da(attr, rast, tri, rast_db, diff_attrs)
 
 
+class _ScaleGradient(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
-    out = _ops.antialias(color, rast, pos, tri)
+    """``pos_gradient_boost``: the gradient that reaches ``pos`` through the silhouette blends is multiplied by it (nvdiffrast's knob; 1.0
+    everywhere in the reference).  ``pos`` [B,V,4], or [V,4] (range mode).  ``topology_hash`` is accepted and ignored: the topology is
+    cached per triangle list."""
     if pos_gradient_boost != 1.0:
-        raise NotImplementedError("pos_gradient_boost")
-    return out
+        pos = _ScaleGradient.apply(pos, float(pos_gradient_boost))
+    return _ops.antialias(color, rast, pos if pos.dim() == 3 else pos[None], tri)
 
 
 def antialias_construct_topology_hash(tri):

@@ -1150,6 +1150,52 @@ def test_nvdiffrast_shim_end_to_end(dev):
         sys.path.remove(shim)
 
 
+def test_nvdiffrast_shim_range_mode_and_gradient_boost(dev):
+    """The rest of the operator signature: range mode (one shared vertex array, image b renders tri[first : first + count], ids index
+    the full list) for rasterize / DepthPeeler / interpolate / antialias against the oracle image by image, and pos_gradient_boost
+    (the gradient to pos through the silhouette blends multiplied, nothing else changed)."""
+    import sys
+
+    from oracle import raster_ref
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3danimals_amd", "shims")
+    sys.path.insert(0, shim)
+    try:
+        dr = importlib.import_module("nvdiffrast.torch")
+        H, W = 48, 56
+        verts, faces, clip, _ = _scene(1)
+        F = faces.shape[0]
+        ranges = torch.tensor([[0, F // 2], [F // 2, F - F // 2], [5, 0]], dtype=torch.int32)
+        pos = clip[0].to(dev).requires_grad_(True)  # [V,4]
+        tri = faces.to(dev).int()
+        ctx = dr.RasterizeGLContext()
+        rast, _ = dr.rasterize(ctx, pos, tri, [H, W], ranges=ranges)
+        assert rast.shape == (3, H, W, 4) and float(rast[2].abs().max()) == 0.0
+        for b, (first, count) in enumerate(ranges.tolist()[:2]):
+            ref = raster_ref.rasterize(clip, faces[first:first + count].int(), (H, W))[0]
+            ref[..., 3] = torch.where(ref[..., 3] > 0, ref[..., 3] + first, ref[..., 3])
+            assert np.array_equal(rast[b].detach().cpu().numpy(), ref.numpy()), b
+        with dr.DepthPeeler(ctx, pos, tri, [H, W], ranges=ranges) as peeler:
+            l0, _ = peeler.rasterize_next_layer()
+            l1, _ = peeler.rasterize_next_layer()
+        assert torch.equal(l0, rast)
+        both = (l0[..., 3] > 0) & (l1[..., 3] > 0)
+        assert int(both.sum()) > 50 and bool((l1[..., 2][both] >= l0[..., 2][both]).all()) and bool((l1[..., 3][both] != l0[..., 3][both]).all())
+        out, _ = dr.interpolate(verts.to(dev), rast, tri)  # attr [V,3]
+        assert out.shape == (3, H, W, 3) and float(out[2].abs().max()) == 0.0 and float(out[:2].abs().max()) > 0
+        col = torch.lerp(torch.zeros(3, H, W, 3, device=dev), torch.ones(3, H, W, 3, device=dev), (rast[..., 3:] > 0).float()).contiguous()
+        aa = dr.antialias(col, rast, pos, tri)
+        (g1,) = torch.autograd.grad(aa.sum(), pos)
+        aa3 = dr.antialias(col, rast, pos, tri, pos_gradient_boost=3.0)
+        (g3,) = torch.autograd.grad(aa3.sum(), pos)
+        assert torch.equal(aa, aa3) and float(g1.abs().max()) > 0
+        torch.testing.assert_close(g3, 3.0 * g1, rtol=1e-5, atol=1e-6 * float(g1.abs().max()))
+        with pytest.raises(RuntimeError, match="range mode"):
+            dr.rasterize(ctx, pos, tri, [H, W], ranges=ranges.to(dev))
+    finally:
+        sys.path.remove(shim)
+
+
 def test_render_mesh_spp2_runs_and_matches_generic_semantics(dev, mods):
     """spp > 1 takes the generic (dense, torch-resampled) path like the reference; output shapes and ranges are sane."""
     B, H, W = 2, 32, 32
