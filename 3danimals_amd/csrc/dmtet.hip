@@ -205,26 +205,28 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              long long* __restrict__ faces, long long* __restrict__ uv_idx, int nbt,
                                                              unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
                                                              long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear,
-                                                             int* __restrict__ tri32, int* __restrict__ topo_cnt) {
+                                                             int* __restrict__ tri32, int* __restrict__ topo_cnt, int wg_per_block) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
     for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
-    // one SLAB (256 items) per work-group: a slab is a chain of three dependent gathers (bit planes -> index row -> vertex ids), and four
-    // of them in series per work-group made the launch pure latency (16 us for ~1 MB); four times the work-groups overlap them instead
-    if ((int)blockIdx.x >= DM_SLABS * (nbe + nbt)) {
-        dm_surface_vertices_chunk((int)blockIdx.x - DM_SLABS * (nbe + nbt), vbits, vchunk, Nv, surf_idx, s_pre);
+    // wg_per_block = 4: one SLAB (256 items) per work-group -- a slab is a chain of three dependent gathers (bit planes -> index row ->
+    // vertex ids), and four of them in series per work-group made the launch pure latency at the bench size (16 us for ~1 MB; four
+    // times the work-groups overlap them: 12.8 us).  wg_per_block = 1: all four slabs in one work-group, for grids whose block count
+    // alone fills the machine many times over (R = 128: 27k blocks; 107k work-groups cost 62 us against 41 us)
+    if ((int)blockIdx.x >= wg_per_block * (nbe + nbt)) {
+        dm_surface_vertices_chunk((int)blockIdx.x - wg_per_block * (nbe + nbt), vbits, vchunk, Nv, surf_idx, s_pre);
         return;
     }
     constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
-    const int slab = blockIdx.x % DM_SLABS, blk = blockIdx.x / DM_SLABS;
+    const int blk = blockIdx.x / wg_per_block;
+    const int slab0 = (blockIdx.x % wg_per_block) * (DM_SLABS / wg_per_block), slab1 = slab0 + DM_SLABS / wg_per_block;
     if (blk < nbe) {
         const long long base = (long long)blk * DM_BLOCK_ITEMS;
-        {
-            const int k = slab;
+        for (int k = slab0; k < slab1; ++k) {
             const long long wi = (base >> 6) + k * WPS + wave;
             const unsigned long long word = edge_bits[wi];
-            if (!((word >> lane) & 1ull)) return;
+            if (!((word >> lane) & 1ull)) continue;
             const long long i = base + k * DM_THREADS + tid;
             const int vid = blk_e[blk] + wlocal[wi] + a3d_wave_prefix(word);
             const int2 e = edges[i];
@@ -255,20 +257,19 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
         c2 = __popcll(~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3));
     }
     const int blk1 = blk_t1[bt], blk2 = blk_t2[bt];
-    {
-        const int k = slab;
+    for (int k = slab0; k < slab1; ++k) {
         const int chunk = k * WPS + wave;
         const unsigned long long* w = tet_bits + ((base >> 6) + chunk) * 4;
         const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
         const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
-        if (!(m1 | m2)) return;  // wave-uniform: no surface tet among these 64
+        if (!(m1 | m2)) continue;  // wave-uniform: no surface tet among these 64
         int run1 = blk1, run2 = blk2;
         for (int j = 0; j < chunk; ++j) { run1 += __shfl(c1, j, 64); run2 += __shfl(c2, j, 64); }
         const int cs = (int)((w0 >> lane) & 1ull) | ((int)((w1 >> lane) & 1ull) << 1) | ((int)((w2 >> lane) & 1ull) << 2) |
                        ((int)((w3 >> lane) & 1ull) << 3);
         const unsigned n = DM_NTRI(cs);
-        if (n == 0u) return;
+        if (n == 0u) continue;
         const long long t = base + k * DM_THREADS + tid;
         const int* te = tet2edge + 6ll * t;
         int ev[6];
@@ -403,10 +404,11 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     unsigned* vbits = (unsigned*)vertex_scratch_or_null;
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     const int nbt = (n1 + n2) > 0 ? d.nbt : 0;
-    hipLaunchKernelGGL(dm_emit_kernel, dim3(DM_SLABS * (d.nbe + nbt) + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
+    const int wgpb = (d.nbe + nbt) <= 8192 ? DM_SLABS : 1;
+    hipLaunchKernelGGL(dm_emit_kernel, dim3(wgpb * (d.nbe + nbt) + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
-                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null);
+                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
                                                             int bones_batch, float* T, int V, int K,
                                                             float neg_inv_temp, float* __restrict__ out, float* __restrict__ weights,
                                                             float* __restrict__ clear, int n_clear, const float* __restrict__ angles,
-                                                            const int* __restrict__ chain, int D, float* __restrict__ PS) {
+                                                            const int* __restrict__ chain, int D, float* __restrict__ PS, int groups) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     const int b = blockIdx.y;
@@ -91,7 +91,13 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     // FOUR lanes per vertex (a quad), each with a quarter of the bones: the K logits are a sqrt + an exp each and a thread that does all
     // twenty is ~2000 dependent instructions with 1.5 waves per SIMD to hide them behind (the kernel took 9 us for 1 MB); four times
     // the waves with a quarter of the chain each, and the quad meets through DPP (max, then the four sums)
-    const int i = blockIdx.x * (SK_THREADS / 4) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const int sub = threadIdx.x & 3;
+    if (POSE) __syncthreads();  // s_T complete (the groups below only read it)
+    // ``groups`` consecutive 64-vertex groups per work-group: 1 at the bench size; more for large meshes, where a work-group per 64
+    // vertices would repeat the chain composition above thousands of times (R = 128 grid: 374 work-groups per image)
+    for (int gi = 0; gi < groups; ++gi) {
+    const int i = (blockIdx.x * groups + gi) * (SK_THREADS / 4) + (threadIdx.x >> 2);
+    if (i - (int)(threadIdx.x >> 2) >= V) break;  // (uniform: the whole group is past the end)
     const bool valid = i < V;
     const float* p = v + ((v_batch == 1 ? 0ll : (long long)b * V) + (valid ? i : 0)) * 3;
     const float px = p[0], py = p[1], pz = p[2];
@@ -106,7 +112,6 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     }
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
-    if (POSE) __syncthreads();  // s_T complete
     float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
         return r;
     };
     s = quad_sum(s); ox = quad_sum(ox); oy = quad_sum(oy); oz = quad_sum(oz);
-    if (!valid) return;
+    if (!valid) continue;
     const float inv = 1.f / s;
     if (sub < 3) out[((long long)b * V + i) * 3 + sub] = (sub == 0 ? ox : (sub == 1 ? oy : oz)) * inv;
     if (weights) {  // [K, Bw, V]; only images that own distinct weights write
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
                 if (k < K) weights[((long long)k * Bw + b) * V + i] = lg[q] * inv;
             }
         }
+    }
     }
 }
 
@@ -288,7 +294,8 @@ extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int
     A3D_CHECK_ARG(v && bones && T && out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= SK_MAXK && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
-    const dim3 grid(a3d_div_up(V, SK_THREADS / 4), B), block(SK_THREADS);  // four lanes per vertex
+    const int ngroups = a3d_div_up(V, SK_THREADS / 4), groups = a3d_div_up(ngroups, 128);  // four lanes per vertex; <= 128 work-groups per image
+    const dim3 grid(a3d_div_up(ngroups, groups), B), block(SK_THREADS);
     hipStream_t s = (hipStream_t)stream;
     const float nit = -1.f / temperature;
     const int ncl = g_T_to_clear_or_null ? B * K * 12 : 0;
@@ -296,9 +303,9 @@ extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int
     const float* no_angles = nullptr;
     const int* no_chain = nullptr;
     float* no_ps = nullptr;
-    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
-    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
-    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps);
+    if (K <= 20) hipLaunchKernelGGL((sk_fwd_kernel<20, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps, groups);
+    else if (K <= 32) hipLaunchKernelGGL((sk_fwd_kernel<32, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps, groups);
+    else hipLaunchKernelGGL((sk_fwd_kernel<SK_MAXK, false>), grid, block, 0, s, v, v_batch, bones, bones_batch, Tm, V, K, nit, out, weights_or_null, g_T_to_clear_or_null, ncl, no_angles, no_chain, 0, no_ps, groups);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -339,11 +346,12 @@ extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones
     // g_T[B,K,12] and the B tickets are cleared as ONE run of 4-byte words: the caller allocates them back to back
     A3D_CHECK_ARG((g_T_to_clear_or_null == nullptr) == (ticket_to_clear_or_null == nullptr));
     A3D_CHECK_ARG(!g_T_to_clear_or_null || (void*)ticket_to_clear_or_null == (void*)(g_T_to_clear_or_null + (size_t)B * K * 12));
-    const dim3 grid(a3d_div_up(V, SK_THREADS / 4), B), block(SK_THREADS);  // four lanes per vertex
+    const int ngroups = a3d_div_up(V, SK_THREADS / 4), groups = a3d_div_up(ngroups, 128);  // four lanes per vertex; <= 128 work-groups per image
+    const dim3 grid(a3d_div_up(ngroups, groups), B), block(SK_THREADS);
     const int ncl = g_T_to_clear_or_null ? B * K * 12 + B : 0;
     float* no_w = nullptr;
     hipLaunchKernelGGL((sk_fwd_kernel<20, true>), grid, block, 0, (hipStream_t)stream, v, v_batch, bones, bones_batch, T_out, V, K,
-                       -1.f / temperature, out, no_w, g_T_to_clear_or_null, ncl, angles, chain, D, chain_products_or_null);
+                       -1.f / temperature, out, no_w, g_T_to_clear_or_null, ncl, angles, chain, D, chain_products_or_null, groups);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

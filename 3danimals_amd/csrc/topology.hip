@@ -122,18 +122,41 @@ __global__ __launch_bounds__(256) void tp_finalize_kernel(const int* __restrict_
     for (unsigned i = blockIdx.x * blockDim.x + tid; i < (unsigned)v_next; i += stride) cnt_next[i] = 0;
 }
 
+// ---- the same for LARGE meshes (V above TP_LDS_SCAN_MAX): every work-group scanning all V counts is O(V * F / 256) loads (R = 128 grid,
+// V = 2.4e4, 558 work-groups: 49 us); there the counts are scanned once by the single-work-group scan (the counts it resets become the
+// fill cursor) and a plain fill launch follows -- two launches of ~8 us.
+__global__ __launch_bounds__(256) void tp_fill_kernel(const int* __restrict__ tri, int F, int V, const int* __restrict__ off, int* __restrict__ cursor,
+                                                      int* __restrict__ adj, int* __restrict__ cnt_next, int v_next) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 3 * F) {
+        const int f = idx / 3, c = idx - 3 * f, v = tri[idx];
+        if ((unsigned)v < (unsigned)V) adj[off[v] + atomicAdd(cursor + v, 1)] = c * F + f;
+    }
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)v_next; i += stride) cnt_next[i] = 0;
+}
+
 }  // namespace
 
-extern "C" int a3d_mesh_topology_finalize_max_vertices(void) { return 36 * 1024 - 1; }  // (V + 1) ints of LDS per work-group <= 144 KB
+#define TP_LDS_SCAN_MAX 12288
+
+extern "C" int a3d_mesh_topology_finalize_max_vertices(void) { return 0x3fffffff; }  // (no limit: large meshes take the two-launch form)
 
 extern "C" int a3d_mesh_topology_finalize(const int32_t* tri, int V, int F, int32_t* count, int32_t* off, int32_t* adj, int32_t* count_next,
                                           int v_next, a3d_stream_t stream) {
     A3D_CHECK_ARG(tri && count && off && adj && count_next && V > 0 && F > 0 && v_next >= 0);
-    A3D_CHECK_ARG(V <= a3d_mesh_topology_finalize_max_vertices() && (long long)3 * F < 0x7fffffffll);
+    A3D_CHECK_ARG((long long)3 * F < 0x7fffffffll);
+    hipStream_t s = (hipStream_t)stream;
+    if (V > TP_LDS_SCAN_MAX) {
+        hipLaunchKernelGGL(nr_adj_scan_kernel, dim3(1), dim3(NR_SCAN_THREADS), 0, s, count, V, off);  // (count -> 0: it is the fill cursor now)
+        A3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tp_fill_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, V, off, count, adj, count_next, v_next);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
     const size_t lds = sizeof(int) * ((size_t)V + 1);
     if (lds > 48 * 1024) A3D_HIP(hipFuncSetAttribute((const void*)tp_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tp_finalize_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), lds, (hipStream_t)stream, tri, F, V, count, off, adj,
-                       count_next, v_next);
+    hipLaunchKernelGGL(tp_finalize_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), lds, s, tri, F, V, count, off, adj, count_next, v_next);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -229,8 +229,8 @@ int a3d_interp_bwd(const float* g_out, const float* attr, int attr_batch, int C,
 int a3d_mesh_topology(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, void* hash, int32_t* opp,
                       int scratch_is_clean, a3d_stream_t stream);
 /* Second half of the topology for a triangle list that came out of a3d_dmtet_emit with tri32 / topo_count (see there): ONE launch turns
- * the valence counts into off[V+1] (every work-group scans them in LDS; V <= a3d_mesh_topology_finalize_max_vertices()) and fills
- * adj[3F].  The lists of adj are NOT sorted (lists_sorted = 0 for a3d_normals_*: same bits as with a3d_mesh_topology's sorted lists).
+ * the valence counts into off[V+1] (every work-group scans them in LDS) and fills adj[3F]; above 12k vertices, where that scan would be
+ * repeated by hundreds of work-groups, a single-work-group scan launch + a fill launch.  The lists of adj are NOT sorted (lists_sorted = 0 for a3d_normals_*: same bits as with a3d_mesh_topology's sorted lists).
  * No opposite-vertex table is built: a3d_aa_analyze finds the few opposite vertices it needs in these lists (opp = NULL, off / adj
  * given).  count_next[v_next] = the count array of the NEXT extraction, zeroed by this launch: callers alternate two arrays. */
 int a3d_mesh_topology_finalize_max_vertices(void);
