@@ -31,19 +31,38 @@ __constant__ signed char c_tri_table[16][6] = {
 
 static_assert(((0x16696994u >> 0) & 3) == 0 && ((0x16696994u >> 6) & 3) == 2 && ((0x16696994u >> 30) & 3) == 0, "ntri pack");
 
-__device__ __forceinline__ int dm_tet_case(const float* __restrict__ sdf, int4 t) {
-    return (sdf[t.x] > 0.f ? 1 : 0) | (sdf[t.y] > 0.f ? 2 : 0) | (sdf[t.z] > 0.f ? 4 : 0) | (sdf[t.w] > 0.f ? 8 : 0);
+// "inside" = sdf > 0 (dmtet.py:107; 0 counts as outside) -- read from the SDF itself, or (BITS) from a 1-bit-per-vertex plane a small
+// pre-pass left (dm_sign_kernel): on large grids the count pass is bound by its ~1e8 four-byte gathers (one cache line per 32 vertices);
+// from the bit plane the same wave touches a handful of lines (one per 1024 vertices)
+template <bool BITS>
+__device__ __forceinline__ bool dm_inside(const void* __restrict__ src, int v) {
+    if (BITS) return (reinterpret_cast<const unsigned*>(src)[v >> 5] >> (v & 31)) & 1u;
+    return reinterpret_cast<const float*>(src)[v] > 0.f;
 }
 
-__device__ __forceinline__ bool dm_edge_cross(const float* __restrict__ sdf, int2 e) {
-    return (sdf[e.x] > 0.f) != (sdf[e.y] > 0.f);  // exactly one endpoint inside (dmtet.py:118); 0 counts as outside
+template <bool BITS>
+__device__ __forceinline__ int dm_tet_case(const void* __restrict__ src, int4 t) {
+    return (dm_inside<BITS>(src, t.x) ? 1 : 0) | (dm_inside<BITS>(src, t.y) ? 2 : 0) | (dm_inside<BITS>(src, t.z) ? 4 : 0) |
+           (dm_inside<BITS>(src, t.w) ? 8 : 0);
+}
+
+template <bool BITS>
+__device__ __forceinline__ bool dm_edge_cross(const void* __restrict__ src, int2 e) {
+    return dm_inside<BITS>(src, e.x) != dm_inside<BITS>(src, e.y);  // exactly one endpoint inside (dmtet.py:118)
+}
+
+__global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(v < Nv && sdf[v] > 0.f);
+    if ((threadIdx.x & 63) == 0) bits[v >> 6] = m;
 }
 
 // ------------------------------------------------------------------------------------------------ count
 // Besides the block sums the pass leaves what it found as bit planes, so that the emit pass never gathers an SDF value or reads an
 // index row for a tet or edge that is not on the surface (~1 % are): edge_bits[word] = crossing flags of 64 consecutive edges,
 // tet_bits[word*4 + j] = bit j of the marching-tets case of 64 consecutive tets.
-__global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __restrict__ sdf, const int2* __restrict__ edges,
+template <bool BITS>
+__global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __restrict__ sdf, const int2* __restrict__ edges,
                                                                 const int4* __restrict__ tets, int Ne, int Nt, int nbe,
                                                                 int* __restrict__ blk_e, int* __restrict__ blk_t1,
                                                                 int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
@@ -53,18 +72,62 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];  // crossings per 64-edge word of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
+    if (!BITS) {
+        // SDF values gathered directly (grids below DM_SIGN_PLANE_MIN_NV vertices): row by row -- the pass is bound by the ~1e7 4-byte
+        // gathers (TA line rate), and more of them in flight per lane only made it slower (17.7 -> 22 us at R = 64)
+        if ((int)blockIdx.x < nbe) {
+            const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+#pragma unroll
+            for (int k = 0; k < DM_SLABS; ++k) {
+                long long i = base + k * DM_THREADS + tid;
+                const int2 e = i < Ne ? edges[i] : make_int2(0, 0);
+                const bool f = i < Ne && dm_edge_cross<false>(sdf, e);
+                if (f && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
+                    atomicOr(vbits + (e.x >> 5), 1u << (e.x & 31));
+                    atomicOr(vbits + (e.y >> 5), 1u << (e.y & 31));
+                }
+                const unsigned long long m = __ballot(f);
+                if (lane == 0) {
+                    edge_bits[(base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave] = m;
+                    s_pc[k * (DM_THREADS / A3D_WAVE) + wave] = __popcll(m);
+                }
+                c0 += __popcll(m);  // wave-uniform
+            }
+        } else {
+            const long long base = (long long)(blockIdx.x - nbe) * DM_BLOCK_ITEMS;
+#pragma unroll
+            for (int k = 0; k < DM_SLABS; ++k) {
+                long long i = base + k * DM_THREADS + tid;
+                const int cs = i < Nt ? dm_tet_case<false>(sdf, tets[i]) : 0;
+                const unsigned long long w0 = __ballot(cs & 1), w1 = __ballot(cs & 2), w2 = __ballot(cs & 4), w3 = __ballot(cs & 8);
+                if (lane < 4) tet_bits[((base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave) * 4 + lane] = lane == 0 ? w0 : (lane == 1 ? w1 : (lane == 2 ? w2 : w3));
+                const unsigned n = DM_NTRI(cs);
+                c0 += __popcll(__ballot(n == 1u));
+                c1 += __popcll(__ballot(n == 2u));
+            }
+        }
+    } else {
+    // Signs from the bit plane (large grids): the gathers hit a handful of cache lines per wave, what is left is streaming 8 B/edge +
+    // 16 B/tet -- and with one index row in flight per wave (load -> gathers -> ballot -> next row) that ran at 3 TB/s: too few bytes in
+    // flight for the HBM latency.  All DM_SLABS rows of a thread are loaded up front, then all their sign lookups (R = 128: 98 -> 86 us)
     if ((int)blockIdx.x < nbe) {
         const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+        int2 e[DM_SLABS];
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
-            long long i = base + k * DM_THREADS + tid;
-            const int2 e = i < Ne ? edges[i] : make_int2(0, 0);
-            const bool f = i < Ne && dm_edge_cross(sdf, e);
-            if (f && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
-                atomicOr(vbits + (e.x >> 5), 1u << (e.x & 31));
-                atomicOr(vbits + (e.y >> 5), 1u << (e.y & 31));
+            const long long i = base + k * DM_THREADS + tid;
+            e[k] = i < Ne ? edges[i] : make_int2(0, 0);
+        }
+        bool f[DM_SLABS];
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) f[k] = (base + k * DM_THREADS + tid) < Ne && dm_edge_cross<BITS>(sdf, e[k]);
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) {
+            if (f[k] && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
+                atomicOr(vbits + (e[k].x >> 5), 1u << (e[k].x & 31));
+                atomicOr(vbits + (e[k].y >> 5), 1u << (e[k].y & 31));
             }
-            const unsigned long long m = __ballot(f);
+            const unsigned long long m = __ballot(f[k]);
             if (lane == 0) {
                 edge_bits[(base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave] = m;
                 s_pc[k * (DM_THREADS / A3D_WAVE) + wave] = __popcll(m);
@@ -73,16 +136,24 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const float* __res
         }
     } else {
         const long long base = (long long)(blockIdx.x - nbe) * DM_BLOCK_ITEMS;
+        int4 t[DM_SLABS];
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
-            long long i = base + k * DM_THREADS + tid;
-            const int cs = i < Nt ? dm_tet_case(sdf, tets[i]) : 0;
-            const unsigned long long w0 = __ballot(cs & 1), w1 = __ballot(cs & 2), w2 = __ballot(cs & 4), w3 = __ballot(cs & 8);
+            const long long i = base + k * DM_THREADS + tid;
+            t[k] = i < Nt ? tets[i] : make_int4(0, 0, 0, 0);
+        }
+        int cs[DM_SLABS];
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) cs[k] = (base + k * DM_THREADS + tid) < Nt ? dm_tet_case<BITS>(sdf, t[k]) : 0;
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) {
+            const unsigned long long w0 = __ballot(cs[k] & 1), w1 = __ballot(cs[k] & 2), w2 = __ballot(cs[k] & 4), w3 = __ballot(cs[k] & 8);
             if (lane < 4) tet_bits[((base >> 6) + k * (DM_THREADS / A3D_WAVE) + wave) * 4 + lane] = lane == 0 ? w0 : (lane == 1 ? w1 : (lane == 2 ? w2 : w3));
-            const unsigned n = DM_NTRI(cs);
+            const unsigned n = DM_NTRI(cs[k]);
             c0 += __popcll(__ballot(n == 1u));
             c1 += __popcll(__ballot(n == 2u));
         }
+    }
     }
     if (lane == 0) { s_cnt[0][wave] = c0; s_cnt[1][wave] = c1; }
     __syncthreads();
@@ -336,7 +407,10 @@ struct DmScratch {
     int *be, *b1, *b2, *wlocal;
     unsigned long long *edge_bits, *tet_bits;
     int nbe, nbt;
+    size_t sign_off;
 };
+
+#define DM_SIGN_PLANE_MIN_NV (1 << 20)  // below this the pre-pass launch costs what the cheaper gathers save (R = 64: 2.7e5 vertices)
 
 static size_t dm_split_scratch(void* scratch, int Ne, int Nt, DmScratch* d) {
     d->nbe = a3d_div_up(Ne, DM_BLOCK_ITEMS);
@@ -350,7 +424,8 @@ static size_t dm_split_scratch(void* scratch, int Ne, int Nt, DmScratch* d) {
     d->be = p + nwe;
     d->b1 = d->be + d->nbe;
     d->b2 = d->b1 + d->nbt;
-    return sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + 4);
+    d->sign_off = (sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + 4) + 63) & ~(size_t)63;
+    return d->sign_off + ((size_t)Ne / 4 + 64);  // + a sign plane for up to 2 Ne grid vertices (large grids: DM_SIGN_PLANE_MIN_NV)
 }
 
 extern "C" size_t a3d_dmtet_scratch_bytes(int Ne, int Nt) {
@@ -369,6 +444,7 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0);
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && ((uintptr_t)vertex_scratch_or_null & 15) == 0));
+    A3D_CHECK_ARG(Nv >= 0);  // (Nv = 0: unknown -- the sign-plane path for large grids is then not taken)
     DmScratch d;
     dm_split_scratch(scratch, Ne, Nt, &d);
     hipStream_t s = (hipStream_t)stream;
@@ -376,8 +452,16 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
     if (vbits && !vertex_scratch_is_clean) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
-    hipLaunchKernelGGL(dm_count_kernel, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, sdf, (const int2*)edges, (const int4*)tets, Ne, Nt,
-                       d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
+    if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
+        unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
+        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256)), dim3(256), 0, s, sdf, Nv, sign);
+        A3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dm_count_kernel<true>, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, (const void*)sign, (const int2*)edges,
+                           (const int4*)tets, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
+    } else {
+        hipLaunchKernelGGL(dm_count_kernel<false>, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, (const void*)sdf, (const int2*)edges,
+                           (const int4*)tets, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
+    }
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc);
     A3D_LAUNCH_CHECK();

@@ -53,6 +53,9 @@ const char* a3d_last_error(void);
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                     int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream);
+/* (Nv = number of grid vertices, or 0 if unknown.  Grids of >= 2^20 vertices take a pre-pass that leaves one sign bit per vertex in
+ * scratch; the count pass then looks signs up there -- a handful of cache lines per wave instead of one per 32 vertices -- and streams
+ * its index rows with four rows per lane in flight.  Same bit planes and counts either way.) */
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
