@@ -294,9 +294,17 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     const int slab0 = (blockIdx.x % wg_per_block) * (DM_SLABS / wg_per_block), slab1 = slab0 + DM_SLABS / wg_per_block;
     if (blk < nbe) {
         const long long base = (long long)blk * DM_BLOCK_ITEMS;
-        for (int k = slab0; k < slab1; ++k) {
+        // this wave's (up to four) words at once: ~99 % of the blocks hold no crossing edge, and finding that out must not take a
+        // dependent load per slab
+        unsigned long long words[DM_SLABS];
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) words[k] = (k >= slab0 && k < slab1) ? edge_bits[(base >> 6) + k * WPS + wave] : 0ull;
+        if (!(words[0] | words[1] | words[2] | words[3])) return;
+#pragma unroll
+        for (int k = 0; k < DM_SLABS; ++k) {
+            if (k < slab0 || k >= slab1) continue;
             const long long wi = (base >> 6) + k * WPS + wave;
-            const unsigned long long word = edge_bits[wi];
+            const unsigned long long word = words[k];
             if (!((word >> lane) & 1ull)) continue;
             const long long i = base + k * DM_THREADS + tid;
             const int vid = blk_e[blk] + wlocal[wi] + a3d_wave_prefix(word);
@@ -320,18 +328,20 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     const long long base = (long long)bt * DM_BLOCK_ITEMS;
     // per-chunk counts of the 16 chunks of this block (lane j < 16 holds chunk j's): n == 1 <=> odd number of inside corners
     int c1 = 0, c2 = 0;
+    unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;  // lane j < 16: the four bit planes of chunk j
     if (lane < DM_BLOCK_ITEMS / 64) {
         const unsigned long long* w = tet_bits + ((base >> 6) + lane) * 4;
-        const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-        const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
+        pw0 = w[0]; pw1 = w[1]; pw2 = w[2]; pw3 = w[3];
+        const unsigned long long odd = pw0 ^ pw1 ^ pw2 ^ pw3;
         c1 = __popcll(odd);
-        c2 = __popcll(~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3));
+        c2 = __popcll(~odd & (pw0 | pw1 | pw2 | pw3) & ~(pw0 & pw1 & pw2 & pw3));
     }
+    if (!__ballot((c1 | c2) != 0)) return;  // no surface tet in the whole block (the usual case): one round trip, not one per slab
     const int blk1 = blk_t1[bt], blk2 = blk_t2[bt];
     for (int k = slab0; k < slab1; ++k) {
         const int chunk = k * WPS + wave;
-        const unsigned long long* w = tet_bits + ((base >> 6) + chunk) * 4;
-        const unsigned long long w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        // (the chunk's planes come from the lane that loaded them for the counts)
+        const unsigned long long w0 = __shfl(pw0, chunk, 64), w1 = __shfl(pw1, chunk, 64), w2 = __shfl(pw2, chunk, 64), w3 = __shfl(pw3, chunk, 64);
         const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
         const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
         if (!(m1 | m2)) continue;  // wave-uniform: no surface tet among these 64
