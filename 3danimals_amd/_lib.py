@@ -16,7 +16,10 @@ SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
-    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p]),
+    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_dmtet_word_group_slots": (_c_int, []),
+    "a3d_dmtet_word_group_bits": (_c_int, []),
+    "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
     "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
@@ -80,7 +83,7 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 300  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 301  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

@@ -51,32 +51,44 @@ __device__ __forceinline__ bool dm_edge_cross(const void* __restrict__ src, int2
     return dm_inside<BITS>(src, e.x) != dm_inside<BITS>(src, e.y);  // exactly one endpoint inside (dmtet.py:118)
 }
 
+// every wave leaves DM_SIGN_WORDS words: lane l reads the vertices base + 64 j + l, all loads in flight, one ballot per word
+#define DM_SIGN_WORDS 4
 __global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long m = __ballot(v < Nv && sdf[v] > 0.f);
-    if ((threadIdx.x & 63) == 0) bits[v >> 6] = m;
+    const int lane = threadIdx.x & 63;
+    const long long w0 = ((long long)blockIdx.x * (256 / 64) + (threadIdx.x >> 6)) * DM_SIGN_WORDS;  // first word of this wave
+    float x[DM_SIGN_WORDS];
+#pragma unroll
+    for (int j = 0; j < DM_SIGN_WORDS; ++j) {
+        const long long v = (w0 + j) * 64 + lane;
+        x[j] = sdf[v < Nv ? v : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < DM_SIGN_WORDS; ++j) {
+        const unsigned long long m = __ballot((w0 + j) * 64 + lane < Nv && x[j] > 0.f);
+        if (lane == 0 && (w0 + j) * 64 < Nv) bits[w0 + j] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ count
 // Besides the block sums the pass leaves what it found as bit planes, so that the emit pass never gathers an SDF value or reads an
 // index row for a tet or edge that is not on the surface (~1 % are): edge_bits[word] = crossing flags of 64 consecutive edges,
 // tet_bits[word*4 + j] = bit j of the marching-tets case of 64 consecutive tets.
+//
+// One 1024-item block (16 words; wave w owns the words k*4 + w).  ``skip`` (wave-uniform): bit k set = word k of this wave is known to
+// hold no crossing (dm_count_cull_kernel below) -- its index rows are not loaded, its bits are written as zeros.
 template <bool BITS>
-__global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __restrict__ sdf, const int2* __restrict__ edges,
-                                                                const int4* __restrict__ tets, int Ne, int Nt, int nbe,
-                                                                int* __restrict__ blk_e, int* __restrict__ blk_t1,
-                                                                int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
-                                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
-                                                                unsigned* __restrict__ vbits) {
-    __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
-    __shared__ int s_pc[DM_BLOCK_ITEMS / 64];  // crossings per 64-edge word of this block
+__device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, const int2* __restrict__ edges, const int4* __restrict__ tets,
+                                               int Ne, int Nt, bool is_edge, int blk, unsigned skip, int* __restrict__ blk_e,
+                                               int* __restrict__ blk_t1, int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
+                                               unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
+                                               unsigned* __restrict__ vbits, int (*s_cnt)[DM_THREADS / A3D_WAVE], int* s_pc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
+    const long long base = (long long)blk * DM_BLOCK_ITEMS;
     if (!BITS) {
         // SDF values gathered directly (grids below DM_SIGN_PLANE_MIN_NV vertices): row by row -- the pass is bound by the ~1e7 4-byte
         // gathers (TA line rate), and more of them in flight per lane only made it slower (17.7 -> 22 us at R = 64)
-        if ((int)blockIdx.x < nbe) {
-            const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+        if (is_edge) {
 #pragma unroll
             for (int k = 0; k < DM_SLABS; ++k) {
                 long long i = base + k * DM_THREADS + tid;
@@ -94,7 +106,6 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
                 c0 += __popcll(m);  // wave-uniform
             }
         } else {
-            const long long base = (long long)(blockIdx.x - nbe) * DM_BLOCK_ITEMS;
 #pragma unroll
             for (int k = 0; k < DM_SLABS; ++k) {
                 long long i = base + k * DM_THREADS + tid;
@@ -110,17 +121,18 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
     // Signs from the bit plane (large grids): the gathers hit a handful of cache lines per wave, what is left is streaming 8 B/edge +
     // 16 B/tet -- and with one index row in flight per wave (load -> gathers -> ballot -> next row) that ran at 3 TB/s: too few bytes in
     // flight for the HBM latency.  All DM_SLABS rows of a thread are loaded up front, then all their sign lookups (R = 128: 98 -> 86 us)
-    if ((int)blockIdx.x < nbe) {
-        const long long base = (long long)blockIdx.x * DM_BLOCK_ITEMS;
+    if (is_edge) {
         int2 e[DM_SLABS];
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             const long long i = base + k * DM_THREADS + tid;
-            e[k] = i < Ne ? edges[i] : make_int2(0, 0);
+            e[k] = make_int2(0, 0);
+            if (!((skip >> k) & 1u) && i < Ne) e[k] = edges[i];
         }
         bool f[DM_SLABS];
 #pragma unroll
-        for (int k = 0; k < DM_SLABS; ++k) f[k] = (base + k * DM_THREADS + tid) < Ne && dm_edge_cross<BITS>(sdf, e[k]);
+        for (int k = 0; k < DM_SLABS; ++k)
+            f[k] = !((skip >> k) & 1u) && (base + k * DM_THREADS + tid) < Ne && dm_edge_cross<BITS>(sdf, e[k]);
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             if (f[k] && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
@@ -135,16 +147,17 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
             c0 += __popcll(m);  // wave-uniform
         }
     } else {
-        const long long base = (long long)(blockIdx.x - nbe) * DM_BLOCK_ITEMS;
         int4 t[DM_SLABS];
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             const long long i = base + k * DM_THREADS + tid;
-            t[k] = i < Nt ? tets[i] : make_int4(0, 0, 0, 0);
+            t[k] = make_int4(0, 0, 0, 0);
+            if (!((skip >> k) & 1u) && i < Nt) t[k] = tets[i];
         }
         int cs[DM_SLABS];
 #pragma unroll
-        for (int k = 0; k < DM_SLABS; ++k) cs[k] = (base + k * DM_THREADS + tid) < Nt ? dm_tet_case<BITS>(sdf, t[k]) : 0;
+        for (int k = 0; k < DM_SLABS; ++k)
+            cs[k] = (!((skip >> k) & 1u) && (base + k * DM_THREADS + tid) < Nt) ? dm_tet_case<BITS>(sdf, t[k]) : 0;
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
             const unsigned long long w0 = __ballot(cs[k] & 1), w1 = __ballot(cs[k] & 2), w2 = __ballot(cs[k] & 4), w3 = __ballot(cs[k] & 8);
@@ -160,13 +173,107 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
     if (tid == 0) {
         int a = 0, b = 0;
         for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
-        if ((int)blockIdx.x < nbe) blk_e[blockIdx.x] = a;
-        else { blk_t1[blockIdx.x - nbe] = a; blk_t2[blockIdx.x - nbe] = b; }
+        if (is_edge) blk_e[blk] = a;
+        else { blk_t1[blk] = a; blk_t2[blk] = b; }
     }
-    if ((int)blockIdx.x < nbe && tid < DM_BLOCK_ITEMS / 64) {  // crossings of this block before word tid
+    if (is_edge && tid < DM_BLOCK_ITEMS / 64) {  // crossings of this block before word tid
         int before = 0;
         for (int j = 0; j < tid; ++j) before += s_pc[j];
-        wlocal[(long long)blockIdx.x * (DM_BLOCK_ITEMS / 64) + tid] = before;
+        wlocal[(long long)blk * (DM_BLOCK_ITEMS / 64) + tid] = before;
+    }
+}
+
+template <bool BITS>
+__global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __restrict__ sdf, const int2* __restrict__ edges,
+                                                                const int4* __restrict__ tets, int Ne, int Nt, int nbe,
+                                                                int* __restrict__ blk_e, int* __restrict__ blk_t1,
+                                                                int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
+                                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
+                                                                unsigned* __restrict__ vbits) {
+    __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
+    __shared__ int s_pc[DM_BLOCK_ITEMS / 64];  // crossings per 64-edge word of this block
+    const bool is_edge = (int)blockIdx.x < nbe;
+    dm_count_block<BITS>(sdf, edges, tets, Ne, Nt, is_edge, is_edge ? (int)blockIdx.x : (int)blockIdx.x - nbe, 0u, blk_e, blk_t1, blk_t2,
+                         edge_bits, tet_bits, wlocal, vbits, s_cnt, s_pc);
+}
+
+// The same pass with a cull in front.  ~99 % of the words hold no crossing, and which vertices a word's 64 rows touch is a property of
+// the grid: ``groups`` [words x 8] (built once per grid, model/geometry/dmtet.py: TetGridTopology.word_groups) lists the <= 8 aligned
+// 16-vertex groups that cover them -- on a grid numbered along its rows (the Kuhn grids; any grid whose generator walks space) 64
+// consecutive tets touch ~48 vertices in 4 short runs.  A word all of whose groups read 0x0000 or all 0xffff in the sign plane has all
+// its vertices on one side: no row of it crosses, its 1 KB of index rows is never read.  What is read instead is 32 B of group ids
+// and 8 two-byte sign fields (cache resident).  Words with more than 8 groups carry 0xffffffff (always processed); a grid where most
+// do (scrambled numbering) is run through dm_count_kernel instead.  G consecutive blocks per work-group: their 4 G words per wave are
+// culled with ALL group ids in flight at once, then ALL sign fields -- two round trips per G blocks instead of per block.
+#define DM_CULL_SLOTS 8
+#define DM_CULL_BLOCKS 4
+
+template <int G>
+__global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigned* __restrict__ sign, const int2* __restrict__ edges,
+                                                                   const int4* __restrict__ tets, int Ne, int Nt, int nbe, int nbt, int nge,
+                                                                   const unsigned* __restrict__ edge_groups,
+                                                                   const unsigned* __restrict__ tet_groups, int* __restrict__ blk_e,
+                                                                   int* __restrict__ blk_t1, int* __restrict__ blk_t2,
+                                                                   unsigned long long* __restrict__ edge_bits,
+                                                                   unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
+                                                                   unsigned* __restrict__ vbits) {
+    __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
+    __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
+    __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
+    constexpr int WPB = DM_BLOCK_ITEMS / 64, ROUNDS = (G * DM_SLABS * DM_CULL_SLOTS + 63) / 64;
+    static_assert(DM_CULL_SLOTS == 8 && DM_SLABS == 4 && DM_THREADS == 256, "one byte of a ballot per word, one nibble of skip bits per block");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool is_edge = (int)blockIdx.x < nge;
+    // block g of this work-group = first + g * step: blocks that hold crossings come in runs (the surface), and a work-group that owned
+    // G neighbours would process a whole run serially while the others write zeros
+    const int nblk = is_edge ? nbe : nbt, step = is_edge ? nge : (int)gridDim.x - nge;
+    const int first = is_edge ? (int)blockIdx.x : (int)blockIdx.x - nge;
+    const unsigned* __restrict__ groups = is_edge ? edge_groups : tet_groups;
+    // entry = (word slot q = g * DM_SLABS + k, group j): lane -> (q = lane / 8 + 8 r, j = lane % 8)
+    unsigned gid[ROUNDS], val[ROUNDS];
+    bool in[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int q = (lane >> 3) + 8 * r, g = q / DM_SLABS, k = q - g * DM_SLABS;
+        in[r] = q < G * DM_SLABS && first + g * step < nblk;
+        // (unconditional loads at a clamped index, then the select: a load under a condition is a branch with its own wait)
+        gid[r] = groups[((long long)(in[r] ? first + g * step : first) * WPB + k * (DM_THREADS / A3D_WAVE) + wave) * DM_CULL_SLOTS + (lane & 7)];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const unsigned field = reinterpret_cast<const unsigned short*>(sign)[gid[r] != 0xFFFFFFFFu ? gid[r] : 0u];
+        val[r] = gid[r] != 0xFFFFFFFFu ? field : 1u;  // 1 = mixed
+    }
+    unsigned skip = 0;  // bit q: word slot q holds no crossing
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const unsigned long long z = __ballot(in[r] && val[r] == 0u), o = __ballot(in[r] && val[r] == 0xFFFFu);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (((z >> (8 * b)) & 0xFFull) == 0xFFull || ((o >> (8 * b)) & 0xFFull) == 0xFFull) skip |= 1u << (8 * r + b);
+    }
+    if (lane < G) s_nib[lane][wave] = (skip >> (DM_SLABS * lane)) & 15u;
+    __syncthreads();
+    bool lds_used = false;
+    for (int g = 0; g < G; ++g) {
+        const int blk = first + g * step;
+        if (blk >= nblk) break;
+        if ((s_nib[g][0] & s_nib[g][1] & s_nib[g][2] & s_nib[g][3]) == 15u) {
+            // no word of this block holds a crossing (most blocks): its outputs are zeros, written by the first threads -- no loads, no
+            // ballots, no barrier
+            if (is_edge) {
+                if (tid < WPB) { edge_bits[(long long)blk * WPB + tid] = 0ull; wlocal[(long long)blk * WPB + tid] = 0; }
+                if (tid == 0) blk_e[blk] = 0;
+            } else {
+                if (tid < 4 * WPB) tet_bits[(long long)blk * 4 * WPB + tid] = 0ull;
+                if (tid == 0) { blk_t1[blk] = 0; blk_t2[blk] = 0; }
+            }
+            continue;
+        }
+        if (lds_used) __syncthreads();  // s_cnt / s_pc of the previous processed block consumed
+        lds_used = true;
+        dm_count_block<true>(sign, edges, tets, Ne, Nt, is_edge, blk, (skip >> (DM_SLABS * g)) & 15u, blk_e, blk_t1, blk_t2, edge_bits, tet_bits,
+                             wlocal, vbits, s_cnt, s_pc);
     }
 }
 
@@ -449,9 +556,16 @@ extern "C" size_t a3d_dmtet_vertex_scratch_bytes(int Nv) {
     return nvc * 128 + nvc * sizeof(int);
 }
 
+extern "C" int a3d_dmtet_word_group_slots(void) { return DM_CULL_SLOTS; }
+extern "C" int a3d_dmtet_word_group_bits(void) { return 4; }  // 16 vertices per group: a two-byte field of the sign plane
+extern "C" int a3d_dmtet_block_items(void) { return DM_BLOCK_ITEMS; }
+
 extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                               int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream) {
+                               int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
+                               const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
+    A3D_CHECK_ARG((edge_groups_or_null == nullptr) == (tet_groups_or_null == nullptr));
+    A3D_CHECK_ARG(!edge_groups_or_null || Nv > 0);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0);
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && ((uintptr_t)vertex_scratch_or_null & 15) == 0));
     A3D_CHECK_ARG(Nv >= 0);  // (Nv = 0: unknown -- the sign-plane path for large grids is then not taken)
@@ -462,9 +576,18 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
     if (vbits && !vertex_scratch_is_clean) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
-    if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
+    if (edge_groups_or_null && (long long)Nv <= 2ll * Ne) {  // (the caller decides: ops.DMTET_CULL_MIN_VERTS)
         unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
-        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256)), dim3(256), 0, s, sdf, Nv, sign);
+        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign);
+        A3D_LAUNCH_CHECK();
+        // (G = 1, 2, 4, 8 blocks per work-group measured within 1 us of each other once the blocks of a work-group are strided)
+        const int nge = a3d_div_up(d.nbe, DM_CULL_BLOCKS), ngt = a3d_div_up(d.nbt, DM_CULL_BLOCKS);
+        hipLaunchKernelGGL(dm_count_cull_kernel<DM_CULL_BLOCKS>, dim3(nge + ngt), dim3(DM_THREADS), 0, s, (const unsigned*)sign, (const int2*)edges,
+                           (const int4*)tets, Ne, Nt, d.nbe, d.nbt, nge, edge_groups_or_null, tet_groups_or_null, d.be, d.b1, d.b2, d.edge_bits,
+                           d.tet_bits, d.wlocal, vbits);
+    } else if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
+        unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
+        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign);
         A3D_LAUNCH_CHECK();
         hipLaunchKernelGGL(dm_count_kernel<true>, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, (const void*)sign, (const int2*)edges,
                            (const int4*)tets, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);

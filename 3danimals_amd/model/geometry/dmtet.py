@@ -50,6 +50,51 @@ class TetGridTopology:
         self.tets32 = idx.to(torch.int32).contiguous()
         self.num_verts = nv
         self._uvs = None
+        self._word_groups = None
+
+    WORD_GROUPS = True  # False: the count pass streams every index row (a3d_dmtet_count without the cull)
+
+    def word_groups(self):
+        """(edge_groups, tet_groups) int32 [blocks * words_per_block, slots] for the culled count pass, or None.
+
+        Row w lists the distinct aligned 2^bits-vertex groups (vertex index >> bits) that the 64 consecutive index rows of word w touch,
+        padded by repetition; -1 in every slot = more than ``slots`` groups (the kernel then always reads the word's rows).  A property
+        of the grid alone, built once.  None when more than half of the words are of that kind (a grid numbered without regard to
+        space): the plain count pass is then the faster one."""
+        if self._word_groups is None:
+            if not self.WORD_GROUPS:
+                return None
+            from ... import _lib
+
+            lib = _lib.lib()
+            slots, bits, block = lib.a3d_dmtet_word_group_slots(), lib.a3d_dmtet_word_group_bits(), lib.a3d_dmtet_block_items()
+            e, t = _word_groups(self.edges32, slots, bits, block), _word_groups(self.tets32, slots, bits, block)
+            dense = (int((e[:, 0] < 0).sum()) + int((t[:, 0] < 0).sum())) / float(e.shape[0] + t.shape[0])
+            self._word_groups = (e, t) if dense <= 0.5 else False
+        return self._word_groups or None
+
+    def words_read(self, sdf: torch.Tensor):
+        """Diagnostic (measurement only): (edge words read, edge words, tet words read, tet words) of the culled count pass for this SDF,
+        by the kernel's own rule -- a word is skipped when all its groups read 0x0000 or all 0xffff in the sign plane -- or None."""
+        groups = self.word_groups()
+        if groups is None:
+            return None
+        from ... import _lib
+
+        bits = _lib.lib().a3d_dmtet_word_group_bits()
+        inside = sdf.detach().reshape(-1) > 0
+        size = 1 << bits
+        pad = (-inside.shape[0]) % size
+        field = torch.cat([inside, inside.new_zeros(pad)]).reshape(-1, size)  # (the plane's padding bits are zeros)
+        state = torch.where(field.all(1), 2, torch.where(field.any(1), 1, 0))  # 0: all outside, 2: all inside, 1: mixed
+        out = []
+        for rows32, tab in zip((self.edges32, self.tets32), groups):
+            t = tab.long()
+            st = torch.where(t >= 0, state[t.clamp(min=0)], torch.ones_like(t))
+            skip = (st == 0).all(1) | (st == 2).all(1)
+            n_words = -(-rows32.shape[0] // 64)
+            out += [int((~skip[:n_words]).sum()), n_words]
+        return tuple(out)
 
     def uvs(self) -> torch.Tensor:
         """Per-tet uv quads [4N^2,2] (reference map_uv, dmtet.py:69-84); same torch expressions, cached."""
@@ -61,6 +106,34 @@ class TetGridTopology:
             pad = 0.9 / n
             self._uvs = torch.stack([tx, ty, tx + pad, ty, tx + pad, ty + pad, tx, ty + pad], dim=-1).view(-1, 2)
         return self._uvs
+
+
+def _word_groups(rows32: torch.Tensor, slots: int, bits: int, block: int, chunk_words: int = 1 << 16) -> torch.Tensor:
+    """See TetGridTopology.word_groups.  ``rows32`` int32 [N, C] (edges: C = 2, tets: C = 4)."""
+    n, c = rows32.shape
+    words_per_block = block // 64
+    nw = -(-n // 64)
+    nwp = -(-n // block) * words_per_block
+    out = torch.full((nwp, slots), -1, dtype=torch.int32, device=rows32.device)
+    for w0 in range(0, nw, chunk_words):  # bounded temporaries: [chunk, 64 C] sorted copies
+        w1 = min(w0 + chunk_words, nw)
+        g = rows32[w0 * 64:min(w1 * 64, n)] >> bits
+        if g.shape[0] < (w1 - w0) * 64:  # the last word of the grid: padded with its own last row
+            g = torch.cat([g, g[-1:].expand((w1 - w0) * 64 - g.shape[0], c)], 0)
+        g = g.reshape(w1 - w0, 64 * c).sort(dim=1).values
+        first = torch.ones_like(g, dtype=torch.bool)
+        first[:, 1:] = g[:, 1:] != g[:, :-1]
+        count = first.sum(1)
+        ok = count <= slots
+        rank = first.cumsum(1) - 1
+        sel = first & ok[:, None]
+        row = torch.arange(w1 - w0, device=g.device)[:, None].expand_as(g)
+        blk = torch.full((w1 - w0, slots), -1, dtype=torch.int32, device=g.device)
+        blk[row[sel], rank[sel]] = g[sel]
+        fill = (torch.arange(slots, device=g.device)[None, :] >= count[:, None]) & ok[:, None]  # unused slots repeat the first group
+        blk = torch.where(fill, blk[:, :1].expand_as(blk), blk)
+        out[w0:w1] = blk
+    return out.contiguous()
 
 
 class DMTet:

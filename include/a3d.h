@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 300 = this header */
+int a3d_version(void); /* 301 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -52,7 +52,18 @@ const char* a3d_last_error(void);
  */
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                    int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv, a3d_stream_t stream);
+                    int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
+                    const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, a3d_stream_t stream);
+/* edge_groups / tet_groups (both or none; static per grid like `edges`): the culled count pass.  Row w of edge_groups
+ * [ceil(Ne / a3d_dmtet_block_items()) * a3d_dmtet_block_items() / 64 rows x a3d_dmtet_word_group_slots()] lists the distinct values of
+ * (vertex index >> a3d_dmtet_word_group_bits()) over the 64 consecutive rows edges[64 w .. 64 w + 63] (unused slots repeat one of
+ * them; rows past the list and rows with more distinct values than slots hold 0xffffffff in every slot); tet_groups the same over
+ * `tets`.  With them the pass takes a sign-plane pre-pass and reads a word's index rows only if its vertex groups do not all lie on one
+ * side of the surface -- on a grid numbered along its rows ~90 % of the 8 B/edge + 16 B/tet stream is never read.  Same outputs bit for
+ * bit.  The reference has no counterpart: it evaluates every tet on every call (dmtet.py:107-118). */
+int a3d_dmtet_word_group_slots(void);
+int a3d_dmtet_word_group_bits(void);
+int a3d_dmtet_block_items(void);
 /* (Nv = number of grid vertices, or 0 if unknown.  Grids of >= 2^20 vertices take a pre-pass that leaves one sign bit per vertex in
  * scratch; the count pass then looks signs up there -- a handful of cache lines per wave instead of one per 32 vertices -- and streams
  * its index rows with four rows per lane in flight.  Same bit planes and counts either way.) */

@@ -91,6 +91,57 @@ def test_dmtet_on_irregular_grids_matches_reference_golden(name, tmp_path, dev, 
     assert torch.equal(f2, faces) and torch.equal(u2, uv_idx)
 
 
+def _extract_all(ops, pos, sdf, topo):
+    v, f, u, ve, idx = ops.dmtet_extract(pos, sdf, topo, surface_vertices=True)
+    return [x.cpu() for x in (v, f, u, ve, idx)]
+
+
+@pytest.mark.parametrize("grid", ["kuhn7", "kuhn24", "kuhn40", "kuhn64", "bcc", "delaunay"])
+def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypatch):
+    """a3d_dmtet_count with the per-grid word groups (sign-plane pre-pass, words whose vertex groups all lie on one side of the surface
+    are never read) against the same entry without them: every output of the extraction bit for bit -- smooth surfaces (most words
+    skipped), noise (none skipped), and the cases a wrong skip would lose: ONE inside vertex, at group and grid boundaries; one
+    outside vertex in a full grid; nothing inside; everything inside."""
+    a3d_pkg = importlib.import_module("3danimals_amd")
+    monkeypatch.setattr(ops, "DMTET_CULL_MIN_VERTS", 0)  # (small grids normally keep the plain pass)
+    if grid.startswith("kuhn"):
+        pos, tets = kuhn(int(grid[4:]))
+    elif grid == "bcc":
+        p, t = a3d_pkg.tetgrid.bcc_grid(9, seed=2)
+        pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    else:
+        p, t = a3d_pkg.tetgrid.delaunay_grid(900, seed=4)
+        pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    pos = pos.to(dev)
+    T = mods["dmtet"].TetGridTopology
+    culled, plain = T(tets.to(dev)), T(tets.to(dev))
+    plain.WORD_GROUPS = False
+    assert plain.word_groups() is None
+    if grid.startswith("kuhn"):
+        e, t = culled.word_groups()  # the cull is live on these grids: (nearly) every word that holds rows has <= 8 groups
+        assert (e[:-16, 0] >= 0).float().mean() > 0.95 and (t[:-16, 0] >= 0).float().mean() > 0.95
+    Nv = pos.shape[0]
+    g = torch.Generator().manual_seed(Nv)
+    centre = pos.mean(0)
+    sdfs = {"sphere": 0.3 * (pos.amax(0) - pos.amin(0)).min() - (pos - centre).norm(dim=1),
+            "quadruped": mods["synthetic"].quadruped_sdf(pos.cpu(), 0.2, noise=0.01, seed=3).to(dev) if grid.startswith("kuhn") else None,
+            "noise": torch.randn(Nv, generator=g).to(dev), "none": -torch.ones(Nv, device=dev), "all": torch.ones(Nv, device=dev),
+            "zeros": torch.zeros(Nv, device=dev)}
+    for v in (0, 15, 16, 17, Nv // 2, Nv - 17, Nv - 16, Nv - 1):
+        one = -torch.ones(Nv, device=dev)
+        one[v] = 1.0
+        sdfs[f"one_in_{v}"] = one
+        sdfs[f"one_out_{v}"] = -one
+    for name, sdf in sdfs.items():
+        if sdf is None:
+            continue
+        a, b = _extract_all(ops, pos, sdf, culled), _extract_all(ops, pos, sdf, plain)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y), (grid, name)
+        if name.startswith("one_in"):
+            assert a[0].shape[0] > 0, (grid, name)
+
+
 @pytest.mark.parametrize("res,kind", [(24, "random"), (32, "quadruped"), (64, "quadruped")])
 def test_dmtet_matches_oracle_larger(res, kind, dev, mods):
     from oracle import dmtet_ref

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 300
+    assert lib.a3d_version() == L.ABI_VERSION == 301
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -474,3 +474,38 @@ def test_weight_modulated_field_matches_reference_state_dict_layout():
     x = torch.randn(7, 3)
     f = torch.randn(128)
     assert torch.allclose(m(x, feat=f[None]), m(x, feat=f[None].repeat(7, 1)), atol=1e-6)  # only the first style row is read
+
+
+@pytest.mark.parametrize("grid", ["kuhn12", "kuhn9", "bcc5", "delaunay"])
+def test_word_groups_cover_every_vertex_of_their_rows(grid):
+    """The static tables of the culled DMTet count (TetGridTopology.word_groups): row w must name the 16-vertex group of EVERY vertex
+    that the 64 index rows of word w touch -- a group missing from a row could let the kernel skip a word that holds a crossing -- or
+    be marked dense; rows past the list are dense; the table is padded to whole 1024-item blocks."""
+    import importlib
+
+    tg = importlib.import_module("3danimals_amd.tetgrid")
+    dm = importlib.import_module("3danimals_amd.model.geometry.dmtet")
+    if grid.startswith("kuhn"):
+        _, tets = tg.kuhn_grid(int(grid[4:]))
+    elif grid == "bcc5":
+        _, tets = tg.bcc_grid(5, seed=3)
+    else:
+        _, tets = tg.delaunay_grid(300, seed=1)
+    edges, _ = tg.build_topology(tets)
+    slots, bits, block = 8, 4, 1024
+    some_sparse = False
+    for rows in (edges, np.asarray(tets, dtype=np.int32)):
+        t = dm._word_groups(torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)), slots, bits, block, chunk_words=7).numpy()
+        n = rows.shape[0]
+        assert t.shape == (-(-n // block) * (block // 64), slots)
+        for w in range(t.shape[0]):
+            if 64 * w >= n:
+                assert (t[w] == -1).all()
+                continue
+            need = set((rows[64 * w:64 * w + 64] >> bits).reshape(-1).tolist())
+            if (t[w] == -1).all():
+                assert len(need) > slots
+            else:
+                assert set(t[w].tolist()) == need
+                some_sparse = True
+    assert some_sparse or not grid.startswith("kuhn")
