@@ -44,7 +44,8 @@ SIGNATURES = {
     "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p, _p, _p,
+                              _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
@@ -83,7 +84,7 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 301  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 302  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

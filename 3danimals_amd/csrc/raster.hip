@@ -25,9 +25,18 @@
 #include "a3d_common.h"
 #include "raster_common.h"
 #include "topo_common.h"
+#include "normals_common.h"
 
 #define RS_COOP_AREA 64  // boxes above this many pixels are rasterised by all 64 lanes of the wave
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+// the vertex-normals job that may ride in the triangle launch (a3d_rast_fwd: normals_*)
+struct RsNormalsJob {
+    const float *v_a, *v_b;
+    const int *off, *adj;
+    float *acc_a, *nrm_a, *acc_b, *nrm_b;
+    int B_a, B_b, wg_per_row;
+};
 
 struct RsFrag {
     float u, v, zw;
@@ -109,8 +118,23 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
                                                      int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards,
                                                      int* __restrict__ cover_group_sum, int cover_groups, int nb_screen,
                                                      const int* __restrict__ topo_off, const int* __restrict__ topo_adj,
-                                                     int* __restrict__ topo_opp) {
+                                                     int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj) {
     const int b = blockIdx.y;
+    if ((int)blockIdx.x >= nb_tri + nb_screen + nb_opp) {
+        // yet more extra work-groups: the vertex normals of the mesh being rasterised (and of a second, small vertex array over the same
+        // triangle list) -- normals.hip's forward pass, which the G-buffer pass of this frame reads next.  As a launch of its own it is
+        // 9 us of dependent gathers plus a launch gap on a latency-bound stretch; here it runs beside the triangle work, which is bound
+        // by the memory-side atomics and leaves the gather path idle.  Batches of 4 index rows keep this branch inside the triangle
+        // path's register budget.
+        const int j = (int)blockIdx.y * nj.wg_per_row + ((int)blockIdx.x - nb_tri - nb_screen - nb_opp);  // flat work-group of the job
+        const int nbv = (V + 255) / 256;
+        if (j >= nbv * (nj.B_a + nj.B_b)) return;
+        const int image = j / nbv, vi = (j - image * nbv) * 256 + (int)threadIdx.x;
+        if (vi >= V) return;
+        if (image < nj.B_a) nr_fwd_vertex<4>(nj.v_a + (long long)image * V * 3, tri, nj.off, nj.adj, F, vi, nj.acc_a, nj.nrm_a, ((long long)image * V + vi) * 3);
+        else nr_fwd_vertex<4>(nj.v_b + (long long)(image - nj.B_a) * V * 3, tri, nj.off, nj.adj, F, vi, nj.acc_b, nj.nrm_b, ((long long)(image - nj.B_a) * V + vi) * 3);
+        return;
+    }
     if ((int)blockIdx.x >= nb_tri + nb_screen) {
         // more extra work-groups (image 0 only): the opposite-vertex table of the silhouette analysis, looked up in the vertex -> face
         // lists the DMTet extraction left (no edge hash on that path).  Each lookup is a chain of five dependent gathers -- inside the
@@ -275,7 +299,9 @@ extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(un
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                             void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
                             float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null,
-                            const int32_t* topo_adj_or_null, int32_t* topo_opp_or_null, a3d_stream_t stream) {
+                            const int32_t* topo_adj_or_null, int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a,
+                            const float* normals_v_b_or_null, int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj,
+                            float* normals_acc_a, float* normals_a, float* normals_acc_b, float* normals_b, a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
@@ -285,6 +311,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     // the covered-pixel block counts ride along when the list's tile order applies and its blocks do not cross images
     A3D_CHECK_ARG(!cover_scratch_or_null || (H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0));
     const int cover_nb = (int)(npix / 256), cover_ng = a3d_div_up(cover_nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE;  // (words of the group-sum area)
+    A3D_CHECK_ARG(F > 0 || !normals_v_a_or_null);  // (no triangle launch to ride in)
     if (F == 0) {
         A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)npix, s));
         if (cover_scratch_or_null) A3D_HIP(hipMemsetAsync(cover_scratch_or_null, 0, sizeof(int) * ((size_t)cover_nb + cover_ng), s));
@@ -296,10 +323,19 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     A3D_CHECK_ARG((topo_opp_or_null == nullptr) == (topo_off_or_null == nullptr) && (topo_opp_or_null == nullptr) == (topo_adj_or_null == nullptr));
     const int nb_tri = a3d_div_up(F, 64), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
     const int nb_opp = topo_opp_or_null ? a3d_div_up(3ll * F, 256) : 0;
-    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + nb_screen + nb_opp, B), dim3(256), 0, s, (const float4*)clip, clip_batch,
+    RsNormalsJob nj = {};
+    if (normals_v_a_or_null) {
+        A3D_CHECK_ARG(normals_B_a > 0 && normals_B_b >= 0 && normals_off && normals_adj && normals_acc_a && normals_a);
+        A3D_CHECK_ARG(normals_B_b == 0 || (normals_v_b_or_null && normals_acc_b && normals_b));
+        nj.v_a = normals_v_a_or_null; nj.v_b = normals_v_b_or_null; nj.off = normals_off; nj.adj = normals_adj;
+        nj.acc_a = normals_acc_a; nj.nrm_a = normals_a; nj.acc_b = normals_acc_b; nj.nrm_b = normals_b;
+        nj.B_a = normals_B_a; nj.B_b = normals_B_b;
+        nj.wg_per_row = a3d_div_up((long long)a3d_div_up(V, 256) * (normals_B_a + normals_B_b), B);
+    }
+    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), 0, s, (const float4*)clip, clip_batch,
                        tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null,
                        a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen,
-                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null);
+                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj);
     A3D_LAUNCH_CHECK();
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,

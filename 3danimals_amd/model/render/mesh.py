@@ -9,6 +9,7 @@ Differences that do not change results on the hot path:
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -20,6 +21,7 @@ from . import util
 LAZY_NORMALS = True  # auto_normals defers the kernel to the first read of Mesh.v_nrm (same values; False = at make_mesh time)
 PAIR_NORMALS = True  # ... and a pending small mesh (<= PAIR_MAX_BATCH images: the canonical one) over the SAME triangle list rides in that launch
 PAIR_MAX_BATCH = 2
+RIDE_NORMALS = os.environ.get("A3D_RIDE_NORMALS", "1") != "0"  # ... and the whole pending pass rides in the rasteriser's triangle launch when the mesh is rendered first (render_mesh)
 _pending_normals = {}  # (storage pointer, shape, version) of t_pos_idx -> [weakref to meshes whose normals are still pending]
 
 
@@ -73,6 +75,30 @@ class Mesh:
     @v_nrm.setter
     def v_nrm(self, value):
         self._v_nrm, self._lazy_nrm = value, None
+
+    # ... or inside the rasteriser's launch: render_mesh asks for the pending pass as a job, hands it to ops.rasterize and gives it back
+    def normals_job(self):
+        """The pending normals of this mesh (and of its pairing partner) as an ops.NormalsJob, or None when there is nothing pending."""
+        if not RIDE_NORMALS or self._v_nrm is not None or self._lazy_nrm is None or self.t_pos_idx is None or not self.v_pos.is_cuda:
+            return None
+        if self.t_pos_idx.shape[-2] == 0:
+            return None
+        job = ops.NormalsJob(self.v_pos, None, self.t_pos_idx)
+        job.partner = self._normals_partner()
+        if job.partner is not None:
+            job.v_b = ops.f32c(job.partner.v_pos.detach())
+        return job
+
+    def take_normals(self, job):
+        """Adopt the results of a job the rasteriser ran (nothing happens if it did not: the lazy path stays armed)."""
+        if not job.done or self._v_nrm is not None:
+            return
+        partner = job.partner
+        with torch.set_grad_enabled(self._lazy_nrm):
+            nrm_a, nrm_b = ops.vertex_normals_attach(self.v_pos, None if partner is None else partner.v_pos, job)
+        self._v_nrm, self._lazy_nrm = nrm_a, None
+        if partner is not None and partner._v_nrm is None and partner._lazy_nrm is not None:
+            partner._v_nrm, partner._lazy_nrm = nrm_b, None
 
     def _normals_partner(self):
         """Another live mesh over the same triangle list whose normals are pending too and which is small (the one canonical mesh beside

@@ -335,7 +335,10 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     if num_layers != 1:  # depth peeling: never used by a config (AnimalModel.py:247); the general, dense path
         return _render_mesh_layers(mesh, clip_f, tri, w2c, view_pos, material, lgt, resolution, spp, num_layers, msaa, background, bsdf, feat,
                                    render_modes, prior_mesh, two_sided_shading, dino_net, class_vector, delta_xy)
-    rast = ops.rasterize(clip_f, tri, full_res)
+    job = mesh.normals_job() if hasattr(mesh, "normals_job") else None  # pending auto_normals: extra work-groups of the triangle launch
+    rast = ops.rasterize(clip_f, tri, full_res, normals_job=job)
+    if job is not None:
+        mesh.take_normals(job)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     LAST_POINTS[0] = None
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,

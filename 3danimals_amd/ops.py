@@ -477,7 +477,7 @@ class _NormalsPair(torch.autograd.Function):
         F = tri32.shape[0]
         out = []
         for v, acc, g in ((v_a, acc_a, g_a), (v_b, acc_b, g_b)):
-            if g is None:
+            if g is None or v is None:
                 out.append(None)
                 continue
             B, V = v.shape[0], v.shape[1]
@@ -488,6 +488,43 @@ class _NormalsPair(torch.autograd.Function):
                  ptr(scratch), ptr(g_v), int(ctx.adjacency.sorted), stream(), tag=f"[B{B}]")
             out.append(g_v)
         return out[0], out[1], None, None
+
+
+class NormalsJob:
+    """The forward pass of vertex_normals_pair(v_a, v_b, tri) as a side job of the rasteriser's triangle launch: hand it to
+    rasterize(normals_job=...), which fills acc / nrm and sets ``done``; vertex_normals_attach then puts the results on the autograd
+    graph.  ``v_b`` may be None."""
+
+    def __init__(self, v_a, v_b, tri):
+        self.tri32 = tri_int32(tri)
+        self.v_a = f32c(v_a.detach())
+        self.v_b = None if v_b is None else f32c(v_b.detach())
+        assert self.v_b is None or self.v_b.shape[1] == self.v_a.shape[1]
+        self.adjacency = vertex_face_adjacency(self.tri32, self.v_a.shape[1])
+        self.acc_a = self.nrm_a = self.acc_b = self.nrm_b = None
+        self.done = False
+
+
+class _NormalsAttach(torch.autograd.Function):
+    """(nrm_a, nrm_b) of a finished NormalsJob as functions of (v_a, v_b): forward hands out the job's buffers, backward is
+    _NormalsPair's."""
+
+    @staticmethod
+    def forward(ctx, v_a, v_b, job):
+        assert job.done
+        ctx.save_for_backward(job.v_a, job.acc_a, job.v_b, job.acc_b, job.tri32)
+        ctx.adjacency = job.adjacency
+        ctx.set_materialize_grads(False)
+        return job.nrm_a, job.nrm_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        return _NormalsPair.backward(ctx, g_a, g_b)[:2] + (None,)
+
+
+def vertex_normals_attach(v_a, v_b, job):
+    """(normals of v_a, normals of v_b or None) computed by ``job`` inside a rasteriser launch, differentiable like vertex_normals_pair."""
+    return _NormalsAttach.apply(v_a, v_b, job)
 
 
 def vertex_normals_pair(v_a, v_b, tri):
@@ -543,7 +580,7 @@ _rast_keys = {}
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, clip, tri32, B, H, W, prev):
+    def forward(ctx, clip, tri32, B, H, W, prev, job):
         require_device(clip, tri32, what="rasterize")
         clip = f32c(clip)
         V, F = clip.shape[1], tri32.shape[0]
@@ -572,8 +609,21 @@ class _Rasterize(torch.autograd.Function):
         topo = _topo_cache.peek(tri32) if F > 0 else None
         lists = getattr(topo, "lists", None) if (topo is not None and topo.opp is None) else None
         opp = torch.empty((F, 3), dtype=torch.int32, device=clip.device) if lists is not None else None
+        # ... and a pending vertex-normals pass over the same triangle list (NormalsJob: the mesh being rasterised + the canonical one)
+        if job is not None and not (F > 0 and job.tri32.data_ptr() == tri32.data_ptr() and job.v_a.shape[1] == V and job.v_a.device == clip.device):
+            job = None  # (stays not done: the caller computes the normals in a launch of their own)
+        nj = [None, 0, None, 0, None, None, None, None, None, None]
+        if job is not None:
+            job.acc_a, job.nrm_a = torch.empty_like(job.v_a), torch.empty_like(job.v_a)
+            if job.v_b is not None:
+                job.acc_b, job.nrm_b = torch.empty_like(job.v_b), torch.empty_like(job.v_b)
+            nj = [ptr(job.v_a), job.v_a.shape[0], ptr(job.v_b), 0 if job.v_b is None else job.v_b.shape[0], ptr(job.adjacency.off),
+                  ptr(job.adjacency.adj), ptr(job.acc_a), ptr(job.nrm_a), ptr(job.acc_b), ptr(job.nrm_b)]
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
-             ptr(aa_screen), ptr(aa_count), ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), ptr(opp), stream())
+             ptr(aa_screen), ptr(aa_count), ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), ptr(opp), *nj,
+             stream(), tag="" if job is None else f"[N{nj[1]}+{nj[3]}]")
+        if job is not None:
+            job.done = True
         if opp is not None:
             topo.opp = opp
         if cover is not None:
@@ -595,16 +645,17 @@ class _Rasterize(torch.autograd.Function):
         g_clip = torch.empty_like(clip)
         call("a3d_rast_bwd", ptr(f32c(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
              ptr(g_clip), stream())
-        return g_clip, None, None, None, None, None
+        return g_clip, None, None, None, None, None, None
 
 
-def rasterize(clip, tri, resolution, batch=None, prev=None):
+def rasterize(clip, tri, resolution, batch=None, prev=None, normals_job=None):
     """clip [B|1,V,4] -> rast [B,H,W,4] = (u, v, z/w, triangle_id+1); differentiable through (u,v).  ``prev`` = the previous
-    depth layer (DepthPeeler.rasterize_next_layer for layer n > 0): the nearest surface strictly behind it is returned."""
+    depth layer (DepthPeeler.rasterize_next_layer for layer n > 0): the nearest surface strictly behind it is returned.
+    ``normals_job``: a NormalsJob over the same triangle list, run as extra work-groups of the triangle launch."""
     if clip.dim() == 2:
         clip = clip[None]
     B = clip.shape[0] if batch is None else batch
-    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]), prev)
+    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]), prev, normals_job)
 
 
 def rasterize_db(clip, tri, rast):

@@ -101,6 +101,9 @@ def algorithmic_bytes(name, d):
     if name.startswith("a3d_normals_fwd_pair["):  # two vertex arrays in one launch, e.g. [B16+B1]: the index data once, the per-image bytes for all
         Bn = sum(int(t.lstrip("B")) for t in name.split("[")[1].rstrip("]").split("+"))
         return 4 * V + 24 * F + Bn * (36 * F + 24 * V)
+    if name.startswith("a3d_rast_fwd[N"):  # the vertex normals of [N<Ba>+<Bb>] images ride in the triangle launch: both passes' bytes
+        Bn = sum(int(t) for t in name.split("[N")[1].rstrip("]").split("+"))
+        return algorithmic_bytes("a3d_rast_fwd", d) + 4 * V + 24 * F + Bn * (36 * F + 24 * V)
     Bn = int(name.split("[B")[1].split("]")[0]) if "[B" in name else B  # batch tag of the normals calls (prior mesh: 1)
     base = name.split("[")[0]
     P = int(d.get("P", 0))

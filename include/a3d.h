@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 301 = this header */
+int a3d_version(void); /* 302 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -211,12 +211,19 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * topo_off / topo_adj / topo_opp (all or none): more extra work-groups fill the opposite-vertex table opp[F,3] of this triangle list from
  * its vertex -> face lists (a3d_aa_topology_from_lists' work, beside the triangle work instead of in a launch of its own) -- for lists
  * that came from a3d_mesh_topology_finalize, which builds no table.
+ * normals_v_a != NULL (F > 0): a3d_normals_fwd_pair's work as still more extra work-groups of the triangle launch -- the vertex normals
+ * of v_a[B_a,V,3] (the mesh being rasterised: auto_normals, mesh.py:276-304, read by the G-buffer pass of the same frame) and, with
+ * B_b > 0, of a second array v_b[B_b,V,3], both over `tri` with the vertex -> face lists normals_off / normals_adj; acc / normals as
+ * a3d_normals_fwd writes them, bit for bit.  The gathers of the normals run beside the memory-side atomics of the triangle work
+ * instead of in a launch of their own.
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
                  float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null, const int32_t* topo_adj_or_null,
-                 int32_t* topo_opp_or_null, a3d_stream_t stream);
+                 int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a, const float* normals_v_b_or_null,
+                 int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj, float* normals_acc_a, float* normals_a,
+                 float* normals_acc_b, float* normals_b, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 

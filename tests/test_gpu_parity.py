@@ -1043,6 +1043,80 @@ def test_fused_gbuffer_backward_table_overflow_falls_back_to_global_atomics(dev,
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=name)
 
 
+
+@pytest.mark.parametrize("with_partner", [True, False])
+def test_normals_riding_in_the_rasteriser_launch_equal_the_stand_alone_pass(with_partner, dev, ops, mods):
+    """ops.rasterize(normals_job=...) runs normals.hip's forward pass as extra work-groups of the triangle launch (batches of 4 index
+    rows instead of 8, for the registers): same normals and same raster buffer bit for bit, same gradients; a job the launch cannot take
+    (another triangle list) is left not done."""
+    verts, faces = quadruped_mesh(20)
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    v_a = (verts[None] + 0.01 * torch.randn(B, *verts.shape, generator=g)).to(dev).requires_grad_(True)
+    v_b = verts[None].clone().to(dev).requires_grad_(True) if with_partner else None
+    tri = faces.to(dev)
+    mvp = mods["synthetic"].random_cameras(B, seed=2)
+    mvp = (mvp[0] if isinstance(mvp, (tuple, list)) else mvp).to(dev)
+    clip = torch.cat([v_a.detach(), torch.ones_like(v_a[..., :1])], -1) @ mvp.transpose(1, 2)
+    ref_rast = ops.rasterize(clip, tri, (64, 64))
+    if with_partner:
+        ref_a, ref_b = ops.vertex_normals_pair(v_a, v_b, tri)
+    else:
+        ref_a, ref_b = ops.vertex_normals(v_a, tri), None
+    job = ops.NormalsJob(v_a, v_b, tri)
+    rast = ops.rasterize(clip, tri, (64, 64), normals_job=job)
+    assert job.done and torch.equal(rast, ref_rast)
+    n_a, n_b = ops.vertex_normals_attach(v_a, v_b, job)
+    assert torch.equal(n_a, ref_a) and (n_b is None) == (ref_b is None) and (n_b is None or torch.equal(n_b, ref_b))
+    w_a, w_b = torch.randn(n_a.shape, generator=g).to(dev), torch.randn(1, *verts.shape, generator=g).to(dev)
+    loss = lambda a, b: (a * w_a).sum() + (0 if b is None else (b * w_b).sum())
+    ins = [v_a] + ([v_b] if with_partner else [])
+    got = torch.autograd.grad(loss(n_a, n_b), ins)
+    want = torch.autograd.grad(loss(ref_a, ref_b), ins)
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    other = ops.NormalsJob(v_a, v_b, tri.flip(0).contiguous())  # a different triangle list than the one being rasterised
+    ops.rasterize(clip, tri, (64, 64), normals_job=other)
+    assert not other.done
+
+
+def test_render_mesh_takes_the_pending_normals_into_the_rasteriser_launch(dev, ops, mods):
+    """make_mesh leaves auto_normals pending; render_mesh hands them to the rasteriser: no a3d_normals_fwd* call, the raster call carries
+    the job (and the canonical mesh's normals with it), images and vertex gradients equal those of the path with the stand-alone launch."""
+    _lib = importlib.import_module("3danimals_amd._lib")
+    M, render = mods["mesh"], mods["render"]
+    B, H, W = 2, 32, 32
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=5)
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    tri = faces[None].to(dev)
+
+    def run(ride):
+        M.RIDE_NORMALS = ride
+        try:
+            posed = (verts[None] + 0.1 * seeded((B, *verts.shape), 21, -1, 1)).to(dev).requires_grad_(True)
+            prior = M.make_mesh(verts[None].to(dev), tri, uvs, uvi, None)
+            shape = M.make_mesh(posed, tri, uvs.expand(B, -1, -1), uvi, None)
+            with _lib.KernelTimer() as timer:
+                out = render.render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), bsdf="diffuse",
+                                         render_modes=["shaded", "geo_normal"], prior_mesh=prior)
+            (g,) = torch.autograd.grad(sum((o * seeded(tuple(o.shape), 7 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out)), posed)
+            return out, g, set(timer.summary()), prior
+        finally:
+            M.RIDE_NORMALS = True
+
+    out_ride, g_ride, names_ride, prior = run(True)
+    out_alone, g_alone, names_alone, _ = run(False)
+    assert not any(n.startswith("a3d_normals_fwd") for n in names_ride), names_ride
+    assert f"a3d_rast_fwd[N{B}+1]" in names_ride, names_ride
+    assert any(n.startswith("a3d_normals_fwd") for n in names_alone) and "a3d_rast_fwd" in names_alone, names_alone
+    assert prior._v_nrm is not None  # the canonical mesh's normals came out of the same launch
+    for x, y in zip(out_ride, out_alone):
+        assert torch.equal(x, y)
+    # (the backward scatters with float atomics: equal up to their order, run to run)
+    np.testing.assert_allclose(g_ride.cpu().numpy(), g_alone.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(g_alone.abs().max()))
+
+
 @pytest.mark.parametrize("grid", ["kuhn24", "kuhn64", "delaunay3k"])
 def test_topology_built_inside_the_dmtet_extraction_equals_the_stand_alone_one(grid, dev, ops, mods):
     """ops.dmtet_extract leaves the mesh topology in the caches (emit launch: int32 list + valence counts; ONE finalize launch: offsets +
