@@ -79,12 +79,13 @@ SIGNATURES = {
     "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p]),
+    "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int,
+                                      _p, _p, _c_int, _p, _p, _c_int, _c_int, _p, _p, _p]),
     "a3d_composite_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p, _c_int, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p,
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 302  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 303  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

@@ -64,14 +64,29 @@ __global__ __launch_bounds__(256) void aa_screen_kernel(const float4* __restrict
     screen[i] = make_float2(p.x / p.w * xh, p.y / p.w * yh);
 }
 
-// one thread per (pixel, direction): blockIdx.y = d (0: right neighbour, 1: lower neighbour)
-__global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restrict__ rast, const float2* __restrict__ screen, int clip_batch,
-                                                         const int* __restrict__ tri, const int* __restrict__ opp, int V, int F, int H,
-                                                         int W, AaRec* __restrict__ work, int capacity, int* __restrict__ count,
-                                                         const int* __restrict__ off, const int* __restrict__ adj) {
+// what the analysis reads and writes (kernel argument of its stand-alone launch and of the compositor launch it can ride in)
+struct AaAnalyzeJob {
+    const float4* rast;
+    const float2* screen;
+    const int *tri, *opp, *off, *adj;
+    AaRec* work;
+    int* count;
+    int clip_batch, V, F, H, W, capacity, B;
+};
+
+// one thread per (pixel, direction): work-group (bx, d, b) of a (ceil(H W / 256), 2, B) grid; d = 0: right neighbour, 1: lower neighbour
+__device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned bx, int d, int b) {
+    const float4* __restrict__ rast = a.rast;
+    const float2* __restrict__ screen = a.screen;
+    const int* __restrict__ tri = a.tri;
+    const int* __restrict__ opp = a.opp;
+    const int* __restrict__ off = a.off;
+    const int* __restrict__ adj = a.adj;
+    AaRec* __restrict__ work = a.work;
+    int* __restrict__ count = a.count;
+    const int clip_batch = a.clip_batch, V = a.V, F = a.F, H = a.H, W = a.W, capacity = a.capacity;
     const unsigned hw = (unsigned)H * (unsigned)W;
-    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
-    const int d = blockIdx.y, b = blockIdx.z;
+    const unsigned rem = bx * 256u + threadIdx.x;
     const long long i = (long long)b * hw + rem;
     AaRec rec;
     bool emit = false;
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
     const unsigned long long m = __ballot(emit);
     if (m) {
         // work-group L of the launch appends to segment L % AA_SHARDS; a segment holds 256 records for each of its work-groups
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned lin = bx + ((hw + 255u) / 256u) * ((unsigned)d + 2u * (unsigned)b);
         const int shard = (int)(lin & (AA_SHARDS - 1));
         const int seg_cap = capacity / AA_SHARDS;
         int basei = 0;
@@ -156,6 +171,8 @@ __global__ __launch_bounds__(256) void aa_analyze_kernel(const float4* __restric
         }
     }
 }
+
+__global__ __launch_bounds__(256) void aa_analyze_kernel(AaAnalyzeJob a) { aa_analyze_body(a, blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
 
 // consumers: exclusive prefix of the segment fills into LDS (call with all threads of the block), then record r -> its slot
 __device__ __forceinline__ int aa_segment_offsets(const int* __restrict__ count, int capacity, int* s_off) {
@@ -330,8 +347,19 @@ struct CaJob {
 // contiguous run.  (j / C1 for j < 256*C1 as a float multiply: exact in that range, and an integer division per element -- ~40
 // instructions, 150 in 64 bits -- made this pass instruction bound: 39 us for the 17-channel image.)  C + 1 == 4: one 16-byte texel
 // per thread.  Stores are non-temporal: the image is far larger than the L2s (17-channel image: 20.3 -> 17.2 us).
-__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix) {
+// Extra work-groups (blockIdx.x >= nb_compose): the silhouette analysis of this frame (aa_analyze_body) when it has not run yet -- the
+// blend launch that follows is its first consumer, and this pass, which only moves pixels, leaves the gather path idle: as a launch
+// of its own the analysis is 15 us of kernel plus a launch gap, here it adds ~5.
+__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an) {
     __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
+    if (blockIdx.x >= nb_compose) {
+        const unsigned nbx = ((unsigned)an.H * (unsigned)an.W + 255u) / 256u, total = nbx * 2u * (unsigned)an.B;
+        const unsigned j = blockIdx.y * (gridDim.x - nb_compose) + (blockIdx.x - nb_compose);  // flat work-group of the analysis
+        if (j >= total) return;
+        const unsigned b = j / (2u * nbx), r = j - b * 2u * nbx;
+        aa_analyze_body(an, r % nbx, (int)(r / nbx), (int)b);
+        return;
+    }
     const CaJob& job = blockIdx.y ? jb : ja;
     const CaSrc& s = job.s;
     float* __restrict__ out = job.out;
@@ -520,8 +548,10 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
                            0.5f * W, 0.5f * H, (float2*)screen, count);
         A3D_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, (const float4*)rast, (const float2*)screen,
-                       clip_batch, tri, opp, V, F, H, W, (AaRec*)work, capacity, count, off_or_null, adj_or_null);
+    AaAnalyzeJob an;
+    an.rast = (const float4*)rast; an.screen = (const float2*)screen; an.tri = tri; an.opp = opp; an.off = off_or_null; an.adj = adj_or_null;
+    an.work = (AaRec*)work; an.count = count; an.clip_batch = clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B;
+    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, an);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -566,9 +596,23 @@ static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* b
 }
 
 extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null,
-                                    int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, const void* work,
-                                    const int32_t* count, int capacity, int B, int H, int W, a3d_stream_t stream) {
+                                    int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
+                                    int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null,
+                                    const float* analyze_screen, int analyze_clip_batch, const int32_t* analyze_tri,
+                                    const int32_t* analyze_opp_or_null, int V, int F, const int32_t* analyze_off_or_null,
+                                    const int32_t* analyze_adj_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
+    AaAnalyzeJob an = {};
+    unsigned nb_an = 0;
+    if (analyze_rast_or_null) {  // a3d_aa_analyze(prepared = 1)'s launch rides in the compose launch
+        A3D_CHECK_ARG(analyze_screen && analyze_tri && V > 0 && F > 0 && (analyze_clip_batch == 1 || analyze_clip_batch == B));
+        A3D_CHECK_ARG(analyze_opp_or_null || (analyze_off_or_null && analyze_adj_or_null));
+        A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535);
+        an.rast = (const float4*)analyze_rast_or_null; an.screen = (const float2*)analyze_screen; an.tri = analyze_tri; an.opp = analyze_opp_or_null;
+        an.off = analyze_off_or_null; an.adj = analyze_adj_or_null; an.work = (AaRec*)work; an.count = count;
+        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B;
+        nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
+    }
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
     const bool two = out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 + 1 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B)));
@@ -576,7 +620,8 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
     const CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
     const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr) : ja;
     const unsigned n_pix = (unsigned)B * ja.s.hw;
-    hipLaunchKernelGGL(ca_compose_kernel, dim3(a3d_div_up(n_pix, 256), two ? 2 : 1), dim3(256), 0, s, ja, jb, n_pix);
+    const unsigned nb_compose = (unsigned)a3d_div_up(n_pix, 256), rows = two ? 2u : 1u;
+    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + (nb_an + rows - 1) / rows, rows), dim3(256), 0, s, ja, jb, n_pix, nb_compose, an);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ca_blend_kernel, dim3(512, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, W);
     A3D_LAUNCH_CHECK();

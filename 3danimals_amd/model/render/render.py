@@ -19,6 +19,8 @@ The texture / DINO / light MLPs (``material.sample``, ``dino_net.sample``, ``lgt
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ... import ops
@@ -32,7 +34,8 @@ POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple
 LAST_RAST = [None]
 LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path handed from stage to stage in the last render_mesh call
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
-FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
+FUSED_COVER_GBUFFER = True
+DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
@@ -361,7 +364,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     fuse_keys = [k for k in dict.fromkeys(render_modes) if can_fuse and k in rendered and k in ANTIALIASED_MODES]
     if fuse_keys:
         tri32 = ops.tri_int32(tri)
-        analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))
+        analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]), defer=DEFER_ANALYSIS)  # runs inside the first compositor call
 
         def bg_of(k):
             if k not in ("shaded", "geo_normal", "shading"):

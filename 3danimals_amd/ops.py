@@ -973,9 +973,11 @@ def rows_add_relu_(y, rows, img):
 
 # ---------------------------------------------------------------------------------------------- antialias
 class AAAnalysis:
-    """Silhouette-crossing work list for one (rast, clip, topology); shared by every colour buffer."""
+    """Silhouette-crossing work list for one (rast, clip, topology); shared by every colour buffer.
+    ``defer``: do not launch now -- the first composite_antialias over this analysis runs it inside its own first launch (possible when
+    the rasteriser prepared the screen positions and counters for this clip); every other consumer calls ensure() first."""
 
-    def __init__(self, rast, clip, topo: AATopology):
+    def __init__(self, rast, clip, topo: AATopology, defer=False):
         require_device(rast, clip, what="antialias")
         self.rast, self.clip, self.topo = f32c(rast.detach()), f32c(clip.detach()), topo
         B, H, W = rast.shape[:3]
@@ -985,16 +987,35 @@ class AAAnalysis:
         dev = rast.device
         self.work = torch.empty((self.capacity, 4), dtype=torch.int32, device=dev)
         prep = _aa_prepared.take(self.rast)  # (one analysis per prepared pair: the counters are consumed)
-        prepared = prep is not None and prep[0] == _IdentityCache.key(self.clip)
-        if prepared:
-            screen, self.count = prep[1], prep[2]
+        self.prepared = prep is not None and prep[0] == _IdentityCache.key(self.clip)
+        if self.prepared:
+            self.screen, self.count = prep[1], prep[2]
         else:
             self.count = torch.empty((shards,), dtype=torch.int32, device=dev)
-            screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
-        lists = getattr(topo, "lists", None)
-        call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), B, self.clip.shape[1],
-             topo.tri.shape[0], H, W, ptr(screen), ptr(self.work), self.capacity, ptr(self.count), int(prepared),
+            self.screen = torch.empty((self.clip.shape[0], self.clip.shape[1], 2), dtype=torch.float32, device=dev)
+        self.pending = True
+        if not (defer and self.prepared and topo.tri.shape[0] > 0):
+            self.ensure()
+
+    def ride_args(self):
+        """Arguments that make a3d_composite_aa_fwd run the pending analysis in its first launch (marks it done), or the nulls."""
+        if not self.pending:
+            return [None, None, 0, None, None, 0, 0, None, None]
+        self.pending = False
+        topo, lists = self.topo, getattr(self.topo, "lists", None)
+        return [ptr(self.rast), ptr(self.screen), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.clip.shape[1], topo.tri.shape[0],
+                ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj)]
+
+    def ensure(self):
+        """Run the analysis now if it has not run yet (stand-alone launch)."""
+        if not self.pending:
+            return self
+        self.pending = False
+        topo, lists = self.topo, getattr(self.topo, "lists", None)
+        call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.B, self.clip.shape[1],
+             topo.tri.shape[0], self.H, self.W, ptr(self.screen), ptr(self.work), self.capacity, ptr(self.count), int(self.prepared),
              ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), stream())
+        return self
 
 
 class _Antialias(torch.autograd.Function):
@@ -1002,7 +1023,7 @@ class _Antialias(torch.autograd.Function):
     def forward(ctx, color, clip, analysis):
         require_device(color, what="antialias")
         color = f32c(color)
-        a = analysis
+        a = analysis.ensure()
         B, H, W, C = color.shape
         assert (B, H, W) == (a.B, a.H, a.W)
         out = torch.empty_like(color)
@@ -1047,8 +1068,10 @@ class _CompositeAntialias(torch.autograd.Function):
         vals, bg, C, out = prep(vals, bg)
         vals2, bg2, C2, out2 = prep(vals2, bg2)
         tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
+        ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
         call("a3d_composite_aa_fwd", ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
-             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W, stream(), tag=tag)
+             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W, *ride, stream(),
+             tag=tag + ("[+analysis]" if ride[0] is not None else ""))
         ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
         ctx.analysis, ctx.tag = a, tag
         if vals2 is None:

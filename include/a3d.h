@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 302 = this header */
+int a3d_version(void); /* 303 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -341,8 +341,13 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
  * bwd: g_vals[P,C] (fully written: g_out at the covered pixels + the blend adjoints; no dense colour gradient exists) -- likewise
  *   g_vals2 -- and g_clip[clip_batch,V,4] (zeroed by callee; both buffers add to it).  The backgrounds receive no gradient. */
 int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null, int C2,
-                         const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, const void* work,
-                         const int32_t* count, int capacity, int B, int H, int W, a3d_stream_t stream);
+                         const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
+                         int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null, const float* analyze_screen,
+                         int analyze_clip_batch, const int32_t* analyze_tri, const int32_t* analyze_opp_or_null, int V, int F,
+                         const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, a3d_stream_t stream);
+/* analyze_rast != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
+ * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
+ * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */
 int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
                          const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch, float* g_vals2,
                          const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count, int capacity,

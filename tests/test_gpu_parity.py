@@ -608,6 +608,53 @@ def test_antialias_run_to_run_difference_is_bounded_by_the_blend_order(fused, de
         assert float((gp - gp0).abs().max()) <= 2e-5 * float(gp0.abs().max())
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_silhouette_analysis_riding_in_the_compositor_launch_leaves_the_same_records(two, dev, ops):
+    """AAAnalysis(defer=True): the analysis runs as extra work-groups of the compositor's first launch instead of a launch of its own.
+    Same crossing records (as a set: the append order is the atomics'), same images up to the blend order, and nothing is launched
+    before the compositor call."""
+    _lib = importlib.import_module("3danimals_amd._lib")
+    B, H, W = 3, 96, 96
+    _, faces, clip, _ = _scene(B, seed=11)
+    tri, clip_d = faces.to(dev), clip.to(dev)
+    topo = ops.aa_topology(ops.tri_int32(tri), clip.shape[1])
+
+    def records(a):
+        cnt = a.count.cpu().numpy()
+        seg = a.capacity // cnt.shape[0]
+        w = a.work.cpu().numpy()
+        rows = np.concatenate([w[i * seg:i * seg + min(int(c), seg)] for i, c in enumerate(cnt)])
+        return rows[np.lexsort(rows.T[::-1])]
+
+    def run(defer):
+        rast = ops.rasterize(clip_d, tri, (H, W))  # (prepares the screen positions and the counters for this clip)
+        pix, inv = ops.covered_pixels(rast, return_inverse=True)
+        vals = seeded((pix.shape[0], 3), 3, 0.3, 1.0).to(dev)
+        vals2 = seeded((pix.shape[0], 16), 4, 0.0, 1.0).to(dev) if two else None
+        with _lib.KernelTimer() as timer:
+            a = ops.AAAnalysis(rast, clip_d, topo, defer=defer)
+            assert a.pending == defer and (not defer or not timer.records)
+            out = ops.composite_antialias(vals, pix, inv, None, clip_d, a, vals2=vals2)
+        assert not a.pending
+        names = set(timer.summary())
+        assert ("a3d_aa_analyze" in names) != defer and any(n.endswith("[+analysis]") for n in names) == defer, names
+        return records(a), (out if two else (out,))
+
+    rec_ride, out_ride = run(True)
+    rec_alone, out_alone = run(False)
+    assert rec_ride.shape[0] > 100 and np.array_equal(rec_ride, rec_alone)
+    for x, y in zip(out_ride, out_alone):
+        assert float((x - y).abs().max()) <= 2.4e-7
+    # a second compositor call over the same analysis finds it done
+    rast = ops.rasterize(clip_d, tri, (H, W))
+    pix, inv = ops.covered_pixels(rast, return_inverse=True)
+    a = ops.AAAnalysis(rast, clip_d, topo, defer=True)
+    v = seeded((pix.shape[0], 3), 3, 0.3, 1.0).to(dev)
+    o1 = ops.composite_antialias(v, pix, inv, None, clip_d, a)
+    o2 = ops.composite_antialias(v, pix, inv, None, clip_d, a)
+    assert float((o1 - o2).abs().max()) <= 2.4e-7
+
+
 def test_antialias_known_answer_vertical_edge(dev, ops):
     """A surface covering x < k+0.3: pixel k (centre k+0.5, uncovered) takes 0.3 of its covered left neighbour."""
     H = W = 16
