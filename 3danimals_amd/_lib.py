@@ -16,12 +16,13 @@ SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
-    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p]),
+    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _p]),
     "a3d_dmtet_word_group_slots": (_c_int, []),
     "a3d_dmtet_word_group_bits": (_c_int, []),
     "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
-    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p,
+                                _c_int, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p]),
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _c_int, _p]),
@@ -33,7 +34,7 @@ SIGNATURES = {
                                    _p]),
     "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
-    "a3d_normals_fwd_pair": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p]),
+    "a3d_normals_fwd_pair": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _c_int, _p]),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p, _p, _p,
-                              _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p]),
+                              _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
@@ -75,17 +76,17 @@ SIGNATURES = {
     "a3d_aa_shards": (_c_int, []),
     "a3d_aa_capacity": (_c_int, [_c_int, _c_int, _c_int]),
     "a3d_aa_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p]),
-    "a3d_aa_topology_from_lists": (_c_int, [_p, _c_int, _p, _p, _p, _p]),
-    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p]),
+    "a3d_aa_topology_from_lists": (_c_int, [_p, _c_int, _p, _p, _p, _c_int, _p]),
+    "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int,
-                                      _p, _p, _c_int, _p, _p, _c_int, _c_int, _p, _p, _p]),
+                                      _p, _p, _c_int, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_composite_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p, _c_int, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p,
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 303  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 304  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 
@@ -143,6 +144,9 @@ class KernelTimer:
         return out
 
 
+_SYNC_EVERY_CALL = os.environ.get("A3D_SYNC_CALLS", "0") == "1"
+
+
 def call(name: str, *args, tag: str = ""):
     """Invoke an int-returning entry point and raise on a non-zero status (``tag`` only labels KernelTimer records)."""
     timer = KernelTimer.active
@@ -150,6 +154,11 @@ def call(name: str, *args, tag: str = ""):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
     rc = getattr(lib(), name)(*args)
+    if _SYNC_EVERY_CALL:  # debugging aid (A3D_SYNC_CALLS=1): a device fault is reported at the entry point that caused it
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:
+            raise A3DError(f"{name}{tag}: device fault surfaced after this call: {e}") from e
     if timer is not None:
         b.record()
         timer.records.setdefault(name + tag, []).append((a, b))

@@ -71,7 +71,7 @@ struct AaAnalyzeJob {
     const int *tri, *opp, *off, *adj;
     AaRec* work;
     int* count;
-    int clip_batch, V, F, H, W, capacity, B;
+    int clip_batch, V, F, H, W, capacity, B, stride;  // stride: layout of off / adj (topo_common.h: vf_list)
 };
 
 // one thread per (pixel, direction): work-group (bx, d, b) of a (ceil(H W / 256), 2, B) grid; d = 0: right neighbour, 1: lower neighbour
@@ -134,7 +134,7 @@ __device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned 
                     if (bstr && (fabsf(bdy) >= fabsf(bdx)) && (dc > -0.0625f) && (dc < 1.0625f)) {
                         // silhouette: the vertex opposite to edge di in the adjacent triangle lies on the same side as the own third vertex
                         // (no neighbour: the own vertex, i.e. always a silhouette)
-                        int o = opp ? opp[3 * t + di] : aa_opposite_from_lists(tri, off, adj, F, t, di);
+                        int o = opp ? opp[3 * t + di] : aa_opposite_from_lists(tri, off, adj, a.stride, F, t, di);
                         o = o >= 0 ? o : (di == 0 ? v0 : (di == 1 ? v1 : v2));
                         const float2 bo = sb[o];
                         const float ox = bo.x - fx, oy = bo.y - fy;
@@ -512,25 +512,27 @@ extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int
 
 // the whole table from the lists (every corner looked up the way a3d_aa_analyze does it for the pairs it needs): same table, bit for bit,
 // as a3d_aa_topology's hash -- checks the list walk against the hash and the oracle, and serves callers that have the lists anyway
-__global__ __launch_bounds__(256) void aa_opp_from_lists_kernel(const int* __restrict__ tri, int F, const int* __restrict__ off,
+__global__ __launch_bounds__(256) void aa_opp_from_lists_kernel(int stride, const int* __restrict__ tri, int F, const int* __restrict__ off,
                                                                 const int* __restrict__ adj, int* __restrict__ opp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 3 * F) opp[idx] = aa_opposite_from_lists(tri, off, adj, F, idx / 3, idx - 3 * (idx / 3));
+    if (idx < 3 * F) opp[idx] = aa_opposite_from_lists(tri, off, adj, stride, F, idx / 3, idx - 3 * (idx / 3));
 }
 
-extern "C" int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp, a3d_stream_t stream) {
-    A3D_CHECK_ARG(F >= 0 && (long long)3 * F < 0x7fffffffll);
+extern "C" int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp, int lists_stride,
+                                          a3d_stream_t stream) {
+    A3D_CHECK_ARG(F >= 0 && (long long)3 * F < 0x7fffffffll && lists_stride >= 0);
     if (F == 0) return A3D_OK;
     A3D_CHECK_ARG(tri && off && adj && opp);
-    hipLaunchKernelGGL(aa_opp_from_lists_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, (hipStream_t)stream, tri, F, off, adj, opp);
+    hipLaunchKernelGGL(aa_opp_from_lists_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, (hipStream_t)stream, lists_stride, tri, F, off, adj, opp);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp_or_null, int B, int V,
                               int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared,
-                              const int32_t* off_or_null, const int32_t* adj_or_null, a3d_stream_t stream) {
+                              const int32_t* off_or_null, const int32_t* adj_or_null, int lists_stride, a3d_stream_t stream) {
     const int32_t* opp = opp_or_null;
+    A3D_CHECK_ARG(lists_stride >= 0);
     A3D_CHECK_ARG(rast && clip && screen && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
@@ -550,7 +552,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     }
     AaAnalyzeJob an;
     an.rast = (const float4*)rast; an.screen = (const float2*)screen; an.tri = tri; an.opp = opp; an.off = off_or_null; an.adj = adj_or_null;
-    an.work = (AaRec*)work; an.count = count; an.clip_batch = clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B;
+    an.work = (AaRec*)work; an.count = count; an.clip_batch = clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = lists_stride;
     hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, an);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
@@ -600,7 +602,7 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
                                     int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null,
                                     const float* analyze_screen, int analyze_clip_batch, const int32_t* analyze_tri,
                                     const int32_t* analyze_opp_or_null, int V, int F, const int32_t* analyze_off_or_null,
-                                    const int32_t* analyze_adj_or_null, a3d_stream_t stream) {
+                                    const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream) {
     A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
     AaAnalyzeJob an = {};
     unsigned nb_an = 0;
@@ -610,7 +612,8 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
         A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535);
         an.rast = (const float4*)analyze_rast_or_null; an.screen = (const float2*)analyze_screen; an.tri = analyze_tri; an.opp = analyze_opp_or_null;
         an.off = analyze_off_or_null; an.adj = analyze_adj_or_null; an.work = (AaRec*)work; an.count = count;
-        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B;
+        A3D_CHECK_ARG(analyze_lists_stride >= 0);
+        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = analyze_lists_stride;
         nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
     }
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));

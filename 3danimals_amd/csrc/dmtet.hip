@@ -282,10 +282,12 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
 // bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts, const unsigned* __restrict__ vbits,
-                                                       int* __restrict__ vchunk, int nvc) {
+                                                       int* __restrict__ vchunk, int nvc, int* __restrict__ clear, int n_clear) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int which = blockIdx.x;
+    // the valence counters of the mesh this extraction is about to emit (a3d_dmtet_emit: topo_count), zeroed here: no memset launch
+    for (int z = blockIdx.x * 1024 + tid; z < n_clear; z += gridDim.x * 1024) clear[z] = 0;
     if (which == 3) {  // surface-adjacent grid vertices: bits per 1024-vertex chunk (32 words), exclusive prefix over the chunks -> counts[3]
         const int per = (nvc + 1023) / 1024;
         const int lo = min(tid * per, nvc), hi = min(lo + per, nvc);
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              long long* __restrict__ faces, long long* __restrict__ uv_idx, int nbt,
                                                              unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
                                                              long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear,
-                                                             int* __restrict__ tri32, int* __restrict__ topo_cnt, int wg_per_block) {
+                                                             int* __restrict__ tri32, int* __restrict__ topo_cnt, int wg_per_block,
+                                                             int* __restrict__ topo_adj, int topo_stride, int F) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
@@ -484,7 +487,18 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                 // thread holds anyway (fire-and-forget adds; this used to be a launch of its own over the finished list)
                 const int fi = (int)(slot + q);
                 tri32[3 * fi] = ids[0]; tri32[3 * fi + 1] = ids[1]; tri32[3 * fi + 2] = ids[2];
-                atomicAdd(topo_cnt + ids[0], 1); atomicAdd(topo_cnt + ids[1], 1); atomicAdd(topo_cnt + ids[2], 1);
+                if (topo_adj) {
+                    // ... or the WHOLE of it: the valence of a surface vertex is bounded by the grid (at most two triangles from each
+                    // tet around its edge), so every vertex owns topo_stride slots and the returned count is the entry's place in its
+                    // list -- no scan, no second launch.  Three returning atomics in flight per face thread (+2 us on this launch
+                    // against the 11 us entry point it makes unnecessary); the lists are unordered, their readers sort the keys.
+                    const int s0 = atomicAdd(topo_cnt + ids[0], 1), s1 = atomicAdd(topo_cnt + ids[1], 1), s2 = atomicAdd(topo_cnt + ids[2], 1);
+                    if (s0 < topo_stride) topo_adj[(long long)ids[0] * topo_stride + s0] = fi;
+                    if (s1 < topo_stride) topo_adj[(long long)ids[1] * topo_stride + s1] = F + fi;
+                    if (s2 < topo_stride) topo_adj[(long long)ids[2] * topo_stride + s2] = 2 * F + fi;
+                } else {
+                    atomicAdd(topo_cnt + ids[0], 1); atomicAdd(topo_cnt + ids[1], 1); atomicAdd(topo_cnt + ids[2], 1);
+                }
             }
             // reference dmtet.py:91-96 with face_gidx = 2t + q
             uo[0] = 4ll * t;
@@ -562,7 +576,9 @@ extern "C" int a3d_dmtet_block_items(void) { return DM_BLOCK_ITEMS; }
 
 extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                                int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
-                               const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, a3d_stream_t stream) {
+                               const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int32_t* words_to_clear_or_null,
+                               int n_words_to_clear, a3d_stream_t stream) {
+    A3D_CHECK_ARG(n_words_to_clear >= 0 && (n_words_to_clear == 0 || words_to_clear_or_null));
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG((edge_groups_or_null == nullptr) == (tet_groups_or_null == nullptr));
     A3D_CHECK_ARG(!edge_groups_or_null || Nv > 0);
@@ -596,7 +612,8 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
                            (const int4*)tets, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
     }
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc);
+    hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc,
+                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -604,7 +621,8 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
 extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                               void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                              int32_t* tri32_or_null, int32_t* topo_count_or_null, a3d_stream_t stream) {
+                              int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
+                              a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
@@ -612,6 +630,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && n_surf >= 0 && (n_surf == 0 || surf_idx_or_null)));
     A3D_CHECK_ARG(!g_sdf_to_clear_or_null || Nv > 0);
     A3D_CHECK_ARG((tri32_or_null == nullptr) == (topo_count_or_null == nullptr));
+    A3D_CHECK_ARG(!topo_adj_or_null || (tri32_or_null && topo_stride > 0 && (long long)V * topo_stride < 0x7fffffffll));
     if (V == 0) {  // no crossing edge, hence no surface tet and no flagged vertex
         if (g_sdf_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_sdf_to_clear_or_null, 0, sizeof(float) * (size_t)Nv, (hipStream_t)stream));
         return A3D_OK;
@@ -625,7 +644,8 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     hipLaunchKernelGGL(dm_emit_kernel, dim3(wgpb * (d.nbe + nbt) + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
-                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb);
+                       g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb, topo_adj_or_null,
+                       topo_stride, n1 + 2 * n2);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void nr_adj_fill_kernel(const int* __restrict_
 __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v, const int* __restrict__ tri, const int* __restrict__ off,
                                                      const int* __restrict__ adj, int V, int F, float* __restrict__ acc,
                                                      float* __restrict__ nrm, int B1, const float* __restrict__ v2,
-                                                     float* __restrict__ acc2, float* __restrict__ nrm2) {
+                                                     float* __restrict__ acc2, float* __restrict__ nrm2, int stride) {
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
     long long vb = (long long)blockIdx.y * V;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v
         v = v2; acc = acc2; nrm = nrm2;
         vb = (long long)((int)blockIdx.y - B1) * V;
     }
-    nr_fwd_vertex<NR_SLOTS>(v + vb * 3, tri, off, adj, F, vi, acc, nrm, (vb + vi) * 3);
+    nr_fwd_vertex<NR_SLOTS>(v + vb * 3, tri, off, adj, stride, F, vi, acc, nrm, (vb + vi) * 3);
 }
 
 // d(normalize(acc))/d(acc) applied to g_nrm; zero where the default normal was substituted
@@ -78,14 +78,15 @@ __device__ __forceinline__ void nr_bwd_entry(int c, const float g0[3], const flo
 
 __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g_acc, const float* __restrict__ v, const int* __restrict__ tri,
                                                      const int* __restrict__ off, const int* __restrict__ adj, int V, int F,
-                                                     float* __restrict__ g_v) {
+                                                     float* __restrict__ g_v, int stride) {
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
     const long long vb = (long long)blockIdx.y * V;
     const float* vp = v + vb * 3;
     const float* gp = g_acc + vb * 3;
     float ox = 0.f, oy = 0.f, oz = 0.f;
-    const int lo = off[vi], cnt = off[vi + 1] - lo;
+    int lo, cnt;
+    vf_list(off, stride, vi, lo, cnt);
     if (cnt > 0) {
     int keys[NR_SLOTS];
     nr_first_keys(adj, lo, cnt, keys);
@@ -149,38 +150,36 @@ extern "C" int a3d_normals_adjacency(const int32_t* tri, int V, int F, int32_t* 
 }
 
 extern "C" int a3d_normals_fwd(const float* v, const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* acc,
-                               float* nrm, int lists_sorted, a3d_stream_t stream) {
-    A3D_CHECK_ARG(v && off && acc && nrm && B > 0 && V > 0 && F >= 0);
+                               float* nrm, int lists_stride, a3d_stream_t stream) {
+    A3D_CHECK_ARG(v && off && acc && nrm && B > 0 && V > 0 && F >= 0 && lists_stride >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
-    (void)lists_sorted;  // (kept in the ABI: the kernels order the keys themselves, a sorted list is simply an easy input)
     hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, (hipStream_t)stream, v, tri, off, adj, V, F, acc, nrm, B,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, lists_stride);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_normals_fwd_pair(const float* v_a, int B_a, const float* v_b, int B_b, const int32_t* tri, const int32_t* off,
                                     const int32_t* adj, int V, int F, float* acc_a, float* nrm_a, float* acc_b, float* nrm_b,
-                                    a3d_stream_t stream) {
-    A3D_CHECK_ARG(v_a && v_b && off && acc_a && nrm_a && acc_b && nrm_b && B_a > 0 && B_b > 0 && B_a + B_b <= 65535 && V > 0 && F >= 0);
+                                    int lists_stride, a3d_stream_t stream) {
+    A3D_CHECK_ARG(v_a && v_b && off && acc_a && nrm_a && acc_b && nrm_b && B_a > 0 && B_b > 0 && B_a + B_b <= 65535 && V > 0 && F >= 0 && lists_stride >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipLaunchKernelGGL(nr_fwd_kernel, dim3(a3d_div_up(V, 256), B_a + B_b), dim3(256), 0, (hipStream_t)stream, v_a, tri, off, adj, V, F, acc_a,
-                       nrm_a, B_a, v_b, acc_b, nrm_b);
+                       nrm_a, B_a, v_b, acc_b, nrm_b, lists_stride);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float* acc, const float* v, const int32_t* tri, const int32_t* off,
-                               const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, int lists_sorted,
+                               const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, int lists_stride,
                                a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0);
+    A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0 && lists_stride >= 0);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * V;
     hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, n, g_acc_scratch);
     A3D_LAUNCH_CHECK();
-    (void)lists_sorted;
-    hipLaunchKernelGGL(nr_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v);
+    hipLaunchKernelGGL(nr_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v, lists_stride);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -61,11 +61,12 @@ __device__ __forceinline__ void nr_first_keys(const int* __restrict__ adj, int l
 // that cannot afford the registers -- the rasteriser's triangle kernel runs at 72).  Same operations in the same order either way.
 template <int BATCH>
 __device__ __forceinline__ void nr_fwd_vertex(const float* __restrict__ vp, const int* __restrict__ tri, const int* __restrict__ off,
-                                              const int* __restrict__ adj, int F, int vi, float* __restrict__ acc, float* __restrict__ nrm,
-                                              long long o) {
+                                              const int* __restrict__ adj, int stride, int F, int vi, float* __restrict__ acc,
+                                              float* __restrict__ nrm, long long o) {
     static_assert(NR_SLOTS % BATCH == 0, "whole batches");
     float x = 0.f, y = 0.f, z = 0.f;
-    const int lo = off[vi], cnt = off[vi + 1] - lo;
+    int lo, cnt;
+    vf_list(off, stride, vi, lo, cnt);
     if (cnt > 0) {  // (an isolated vertex -- or F == 0 -- touches neither adj nor tri)
     int keys[NR_SLOTS];
     nr_first_keys(adj, lo, cnt, keys);

@@ -35,7 +35,7 @@ struct RsNormalsJob {
     const float *v_a, *v_b;
     const int *off, *adj;
     float *acc_a, *nrm_a, *acc_b, *nrm_b;
-    int B_a, B_b, wg_per_row;
+    int B_a, B_b, wg_per_row, stride;  // stride: layout of off / adj (topo_common.h: vf_list), also of topo_off / topo_adj
 };
 
 struct RsFrag {
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         if (j >= nbv * (nj.B_a + nj.B_b)) return;
         const int image = j / nbv, vi = (j - image * nbv) * 256 + (int)threadIdx.x;
         if (vi >= V) return;
-        if (image < nj.B_a) nr_fwd_vertex<4>(nj.v_a + (long long)image * V * 3, tri, nj.off, nj.adj, F, vi, nj.acc_a, nj.nrm_a, ((long long)image * V + vi) * 3);
-        else nr_fwd_vertex<4>(nj.v_b + (long long)(image - nj.B_a) * V * 3, tri, nj.off, nj.adj, F, vi, nj.acc_b, nj.nrm_b, ((long long)(image - nj.B_a) * V + vi) * 3);
+        if (image < nj.B_a) nr_fwd_vertex<4>(nj.v_a + (long long)image * V * 3, tri, nj.off, nj.adj, nj.stride, F, vi, nj.acc_a, nj.nrm_a, ((long long)image * V + vi) * 3);
+        else nr_fwd_vertex<4>(nj.v_b + (long long)(image - nj.B_a) * V * 3, tri, nj.off, nj.adj, nj.stride, F, vi, nj.acc_b, nj.nrm_b, ((long long)(image - nj.B_a) * V + vi) * 3);
         return;
     }
     if ((int)blockIdx.x >= nb_tri + nb_screen) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         // analysis it doubled that kernel's time (13 -> 24 us); here it runs beside the triangle work of the same launch for free.
         if (b != 0) return;
         const int idx = ((int)blockIdx.x - nb_tri - nb_screen) * 256 + threadIdx.x;
-        if (idx < 3 * F) topo_opp[idx] = aa_opposite_from_lists(tri, topo_off, topo_adj, F, idx / 3, idx - 3 * (idx / 3));
+        if (idx < 3 * F) topo_opp[idx] = aa_opposite_from_lists(tri, topo_off, topo_adj, nj.stride, F, idx / 3, idx - 3 * (idx / 3));
         return;
     }
     // the covered-pixel list's group sums, accumulated by the resolve launch that follows: zeroed here (no memset launch)
@@ -301,7 +301,8 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
                             float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null,
                             const int32_t* topo_adj_or_null, int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a,
                             const float* normals_v_b_or_null, int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj,
-                            float* normals_acc_a, float* normals_a, float* normals_acc_b, float* normals_b, a3d_stream_t stream) {
+                            float* normals_acc_a, float* normals_a, float* normals_acc_b, float* normals_b, int lists_stride,
+                            a3d_stream_t stream) {
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
@@ -324,6 +325,8 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     const int nb_tri = a3d_div_up(F, 64), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
     const int nb_opp = topo_opp_or_null ? a3d_div_up(3ll * F, 256) : 0;
     RsNormalsJob nj = {};
+    A3D_CHECK_ARG(lists_stride >= 0);
+    nj.stride = lists_stride;
     if (normals_v_a_or_null) {
         A3D_CHECK_ARG(normals_B_a > 0 && normals_B_b >= 0 && normals_off && normals_adj && normals_acc_a && normals_a);
         A3D_CHECK_ARG(normals_B_b == 0 || (normals_v_b_or_null && normals_acc_b && normals_b));

@@ -89,13 +89,22 @@ __device__ __forceinline__ void aa_consider_face(int key, int u0, int u1, int u2
     }
 }
 
+// The lists come in two layouts.  CSR (stride 0): list v = adj[off[v] .. off[v + 1]) -- a3d_normals_adjacency, a3d_mesh_topology[_finalize].
+// Fixed stride (stride > 0): list v = adj[v * stride ..], off[v] = its length -- written by the DMTet emit launch itself, whose grid bounds
+// the valence (a crossing edge is shared by at most `tets per edge` tets, each with at most two triangles at it): no scan, no launch.
+__device__ __forceinline__ void vf_list(const int* __restrict__ off, int stride, int v, int& lo, int& n) {
+    if (stride > 0) { lo = v * stride; n = min(off[v], stride); }
+    else { lo = off[v]; n = off[v + 1] - lo; }
+}
+
 __device__ __forceinline__ int aa_opposite_from_lists(const int* __restrict__ tri, const int* __restrict__ off, const int* __restrict__ adj,
-                                                      int F, int f, int i) {
+                                                      int stride, int F, int f, int i) {
     const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
     if (a == b) return -1;
     const int d = a < b ? 0 : 1;
     int slot[2] = {AA_NONE, AA_NONE};
-    const int lo = off[a], n = off[a + 1] - lo;
+    int lo, n;
+    vf_list(off, stride, a, lo, n);
     // up to eight entries at once: all keys in flight, then all index rows in flight (two round trips instead of two per entry)
     int keys[8], rows[8][3];
 #pragma unroll

@@ -51,6 +51,16 @@ class TetGridTopology:
         self.num_verts = nv
         self._uvs = None
         self._word_groups = None
+        self._face_list_stride = None
+
+    def face_list_stride(self) -> int:
+        """Slots per surface vertex that hold its whole vertex -> face list whatever the SDF: a surface vertex sits on a grid edge, every
+        tet around that edge contributes at most two triangles at it, so 2 x (the largest number of tets around one edge) bounds the
+        valence (12 on the Kuhn grids); rounded up to a multiple of 8.  Static per grid."""
+        if self._face_list_stride is None:
+            most = int(torch.bincount(self.tet2edge32.reshape(-1).long()).max())
+            self._face_list_stride = -(-2 * most // 8) * 8
+        return self._face_list_stride
 
     WORD_GROUPS = True  # False: the count pass streams every index row (a3d_dmtet_count without the cull)
 

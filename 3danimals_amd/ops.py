@@ -7,6 +7,7 @@ with find_unused_parameters=False in the reference.  Noth
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -97,7 +98,7 @@ def opposite_vertices_from_lists(adjacency) -> torch.Tensor:
     """opp[F,3] from the vertex -> face lists (a3d_aa_topology_from_lists): the table a3d_aa_topology builds with its hash."""
     tri32 = adjacency.tri
     opp = torch.empty((tri32.shape[0], 3), dtype=torch.int32, device=tri32.device)
-    call("a3d_aa_topology_from_lists", ptr(tri32), tri32.shape[0], ptr(adjacency.off), ptr(adjacency.adj), ptr(opp), stream())
+    call("a3d_aa_topology_from_lists", ptr(tri32), tri32.shape[0], ptr(adjacency.off), ptr(adjacency.adj), ptr(opp), adjacency.stride, stream())
     return opp
 
 
@@ -155,6 +156,8 @@ def _topology_sets(dev, F, V):
 
 
 DMTET_CULL_MIN_VERTS = 1 << 17
+DMTET_EMIT_LISTS = os.environ.get("A3D_EMIT_LISTS", "1") != "0"  # the emit launch writes the vertex -> face lists itself (no finalize launch)
+DMTET_EMIT_LISTS_MAX_STRIDE = 32
 _dm_vertex_scratch = {}
 _dm_grad_buffers = _IdentityCache(maxsize=2)  # vert_edge of an extraction -> its cleared SDF gradient buffer
 
@@ -182,34 +185,55 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     # static per grid: lets the count pass skip the words off the surface.  Three launches (sign plane, culled count, scan) against two:
     # R = 64 (2.7e5 vertices) 14 vs 18 us back to back and equal inside the step, R = 128 32 vs 88 us; small grids keep the plain pass
     groups = grid.word_groups() if (Nv >= DMTET_CULL_MIN_VERTS and hasattr(grid, "word_groups")) else None
+    # mesh topology inside the extraction (DMTET_TOPOLOGY).  Preferred form: the emit launch writes the int32 triangle list AND the vertex ->
+    # face lists themselves, every vertex owning ``stride`` slots (the grid bounds the valence: grid.face_list_stride()); the valence
+    # counters it appends through are zeroed by the count call -- sized by a guess at V (the last extraction on this grid), since V is
+    # only known after the read-back.  No launch of its own; the normals / antialiasing find the lists in the caches.
+    stride = grid.face_list_stride() if (DMTET_TOPOLOGY and DMTET_EMIT_LISTS and hasattr(grid, "face_list_stride")) else 0
+    counters = None
+    if 0 < stride <= DMTET_EMIT_LISTS_MAX_STRIDE:
+        guess = getattr(grid, "_last_surface_vertices", 0)
+        counters = torch.empty(max(1024, -(-int(1.25 * guess) // 1024) * 1024), dtype=torch.int32, device=dev)
     call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
-         ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, stream())
+         ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), 0 if counters is None else counters.shape[0],
+         stream())
     V, n1, n2, n_surf = counts.tolist()  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
     F = n1 + 2 * n2
+    if counters is not None:
+        grid._last_surface_vertices = V
     verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
     vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
     faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
     uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
     idx = torch.empty((n_surf,), dtype=torch.int64, device=dev) if surface_vertices else None
     g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
-    # mesh topology inside the extraction (DMTET_TOPOLOGY): the emit launch writes the int32 triangle list and counts the valences; ONE
-    # more launch (a3d_mesh_topology_finalize) leaves the vertex -> face lists in the caches the normals / antialiasing look them up in
-    # (the silhouette analysis finds its opposite vertices in the same lists: no hash, no table) -- instead of the conversion kernel +
-    # the four launches of a3d_mesh_topology on first use
-    topo = _topology_sets(dev, F, V) if (DMTET_TOPOLOGY and F > 0 and 0 < V <= _lib.lib().a3d_mesh_topology_finalize_max_vertices()) else None
-    tri32 = cur = nxt = None
+    emit_lists = counters is not None and F > 0 and 0 < V <= counters.shape[0] and V * stride < 2 ** 31
+    # fallback (the guess at V was too small, or a grid with very many tets around an edge): the emit launch only counts the valences and
+    # ONE more launch (a3d_mesh_topology_finalize) scans them and fills CSR lists -- instead of the conversion kernel + the four
+    # launches of a3d_mesh_topology on first use
+    topo = None
+    if not emit_lists and DMTET_TOPOLOGY and F > 0 and 0 < V <= _lib.lib().a3d_mesh_topology_finalize_max_vertices():
+        topo = _topology_sets(dev, F, V)
+    tri32 = cur = nxt = lists_adj = None
     if topo is not None:
         cur, nxt = topo["sets"][topo["cur"]], topo["sets"][1 - topo["cur"]]
+    if emit_lists:
+        cur, lists_adj = counters, torch.empty(V * stride, dtype=torch.int32, device=dev)
+    if cur is not None:
         tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
     try:
         call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
              ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
-             ptr(cur), stream())
-        if topo is not None:
+             ptr(cur), ptr(lists_adj), stride if emit_lists else 0, stream())
+        adj = None
+        if emit_lists:
+            adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))
+        elif topo is not None:
             adj = VertexFaceAdjacency(tri32, V, build=False)
             adj.sorted = False
             call("a3d_mesh_topology_finalize", ptr(tri32), V, F, ptr(cur), ptr(adj.off), ptr(adj.adj), ptr(nxt), topo["vcap"], stream())
             topo["cur"] ^= 1
+        if adj is not None:
             _adj_cache.put(tri32, adj)
             _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
             _tri32_cache.put(faces, tri32)
@@ -401,13 +425,19 @@ def skin_weights(v, bones, B, temperature):
 
 # ---------------------------------------------------------------------------------------------- normals
 class VertexFaceAdjacency:
-    """CSR vertex -> incident (corner, face) entries of one triangle list, built by a3d_normals_adjacency."""
+    """Vertex -> incident (corner, face) entries of one triangle list: CSR, built by a3d_normals_adjacency / a3d_mesh_topology[_finalize],
+    or -- ``lists`` -- fixed stride, as the DMTet emit launch writes them."""
 
-    def __init__(self, tri32: torch.Tensor, num_vertices: int, build: bool = True):
+    def __init__(self, tri32: torch.Tensor, num_vertices: int, build: bool = True, lists=None):
         require_device(tri32, what="normals_adjacency")
         F, V = tri32.shape[0], int(num_vertices)
         self.tri, self.num_vertices = tri32, V
-        self.sorted = True  # lists stored in ascending key order (False for the lists a3d_mesh_topology_finalize leaves)
+        self.sorted = True  # lists stored in ascending key order (False for the lists a3d_mesh_topology_finalize / the DMTet emit leave)
+        self.stride = 0  # 0: CSR (off[V+1]); S > 0: list v = adj[v*S .. v*S + off[v]) -- written by the DMTet emit launch (include/a3d.h: lists_stride)
+        if lists is not None:  # (list lengths, slots, stride) as a3d_dmtet_emit wrote them
+            self.off, self.adj, self.stride = lists
+            self.sorted = False
+            return
         self.off = torch.empty(V + 1, dtype=torch.int32, device=tri32.device)
         self.adj = torch.empty(max(3 * F, 1), dtype=torch.int32, device=tri32.device)
         if build:
@@ -435,7 +465,7 @@ class _Normals(torch.autograd.Function):
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
         acc = torch.empty_like(v)
         nrm = torch.empty_like(v)
-        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), int(adjacency.sorted),
+        call("a3d_normals_fwd", ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(acc), ptr(nrm), adjacency.stride,
              stream(), tag=f"[B{B}]")
         ctx.save_for_backward(v, acc, tri32)
         ctx.adjacency = adjacency
@@ -450,7 +480,7 @@ class _Normals(torch.autograd.Function):
         if g_nrm.dtype != torch.float32 or g_nrm.stride(2) != 1 or g_nrm.stride(0) != V * g_nrm.stride(1):  # rows must be evenly strided
             g_nrm = f32c(g_nrm)
         call("a3d_normals_bwd", ptr(g_nrm), g_nrm.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-             ptr(scratch), ptr(g_v), int(ctx.adjacency.sorted), stream(), tag=f"[B{B}]")
+             ptr(scratch), ptr(g_v), ctx.adjacency.stride, stream(), tag=f"[B{B}]")
         return g_v, None, None
 
 
@@ -465,7 +495,7 @@ class _NormalsPair(torch.autograd.Function):
         assert v_b.shape[1] == V
         acc_a, nrm_a, acc_b, nrm_b = torch.empty_like(v_a), torch.empty_like(v_a), torch.empty_like(v_b), torch.empty_like(v_b)
         call("a3d_normals_fwd_pair", ptr(v_a), v_a.shape[0], ptr(v_b), v_b.shape[0], ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), V, F,
-             ptr(acc_a), ptr(nrm_a), ptr(acc_b), ptr(nrm_b), stream(), tag=f"[B{v_a.shape[0]}+B{v_b.shape[0]}]")
+             ptr(acc_a), ptr(nrm_a), ptr(acc_b), ptr(nrm_b), adjacency.stride, stream(), tag=f"[B{v_a.shape[0]}+B{v_b.shape[0]}]")
         ctx.save_for_backward(v_a, acc_a, v_b, acc_b, tri32)
         ctx.adjacency = adjacency
         ctx.set_materialize_grads(False)
@@ -485,7 +515,7 @@ class _NormalsPair(torch.autograd.Function):
                 g = f32c(g)
             scratch, g_v = torch.empty_like(v), torch.empty_like(v)
             call("a3d_normals_bwd", ptr(g), g.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-                 ptr(scratch), ptr(g_v), int(ctx.adjacency.sorted), stream(), tag=f"[B{B}]")
+                 ptr(scratch), ptr(g_v), ctx.adjacency.stride, stream(), tag=f"[B{B}]")
             out.append(g_v)
         return out[0], out[1], None, None
 
@@ -613,6 +643,9 @@ class _Rasterize(torch.autograd.Function):
         if job is not None and not (F > 0 and job.tri32.data_ptr() == tri32.data_ptr() and job.v_a.shape[1] == V and job.v_a.device == clip.device):
             job = None  # (stays not done: the caller computes the normals in a launch of their own)
         nj = [None, 0, None, 0, None, None, None, None, None, None]
+        stride = lists.stride if lists is not None else (job.adjacency.stride if job is not None else 0)
+        if job is not None and lists is not None and lists is not job.adjacency and lists.stride != job.adjacency.stride:
+            job = None  # (one layout per launch)
         if job is not None:
             job.acc_a, job.nrm_a = torch.empty_like(job.v_a), torch.empty_like(job.v_a)
             if job.v_b is not None:
@@ -621,7 +654,7 @@ class _Rasterize(torch.autograd.Function):
                   ptr(job.adjacency.adj), ptr(job.acc_a), ptr(job.nrm_a), ptr(job.acc_b), ptr(job.nrm_b)]
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
              ptr(aa_screen), ptr(aa_count), ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), ptr(opp), *nj,
-             stream(), tag="" if job is None else f"[N{nj[1]}+{nj[3]}]")
+             stride, stream(), tag="" if job is None else f"[N{nj[1]}+{nj[3]}]")
         if job is not None:
             job.done = True
         if opp is not None:
@@ -1000,11 +1033,11 @@ class AAAnalysis:
     def ride_args(self):
         """Arguments that make a3d_composite_aa_fwd run the pending analysis in its first launch (marks it done), or the nulls."""
         if not self.pending:
-            return [None, None, 0, None, None, 0, 0, None, None]
+            return [None, None, 0, None, None, 0, 0, None, None, 0]
         self.pending = False
         topo, lists = self.topo, getattr(self.topo, "lists", None)
         return [ptr(self.rast), ptr(self.screen), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.clip.shape[1], topo.tri.shape[0],
-                ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj)]
+                ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), 0 if lists is None else lists.stride]
 
     def ensure(self):
         """Run the analysis now if it has not run yet (stand-alone launch)."""
@@ -1014,7 +1047,7 @@ class AAAnalysis:
         topo, lists = self.topo, getattr(self.topo, "lists", None)
         call("a3d_aa_analyze", ptr(self.rast), ptr(self.clip), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.B, self.clip.shape[1],
              topo.tri.shape[0], self.H, self.W, ptr(self.screen), ptr(self.work), self.capacity, ptr(self.count), int(self.prepared),
-             ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), stream())
+             ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), 0 if lists is None else lists.stride, stream())
         return self
 
 

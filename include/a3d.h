@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 303 = this header */
+int a3d_version(void); /* 304 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -53,7 +53,9 @@ const char* a3d_last_error(void);
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                     int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
-                    const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, a3d_stream_t stream);
+                    const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int32_t* words_to_clear_or_null,
+                    int n_words_to_clear, a3d_stream_t stream);
+/* words_to_clear: n 4-byte words zeroed by the last launch of the call (the valence counters a3d_dmtet_emit's topo_count wants zero). */
 /* edge_groups / tet_groups (both or none; static per grid like `edges`): the culled count pass.  Row w of edge_groups
  * [ceil(Ne / a3d_dmtet_block_items()) * a3d_dmtet_block_items() / 64 rows x a3d_dmtet_word_group_slots()] lists the distinct values of
  * (vertex index >> a3d_dmtet_word_group_bits()) over the 64 consecutive rows edges[64 w .. 64 w + 63] (unused slots repeat one of
@@ -70,10 +72,14 @@ int a3d_dmtet_block_items(void);
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                   int32_t* tri32_or_null, int32_t* topo_count_or_null, a3d_stream_t stream);
+                   int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride, a3d_stream_t stream);
 /* tri32 / topo_count (both or none): the emit launch also writes the int32 copy of faces that the render kernels read and counts the
  * valences of the surface vertices (topo_count[>= V], zero on entry) -- the first step of the mesh topology, which
- * a3d_mesh_topology_finalize completes in one launch (the stand-alone a3d_mesh_topology needs four). */
+ * a3d_mesh_topology_finalize completes in one launch (the stand-alone a3d_mesh_topology needs four).
+ * topo_adj[V * topo_stride] (with tri32 / topo_count): the emit launch completes the topology ITSELF -- face f's corner c appends the key
+ * c*F + f to the list of its vertex at adj[v * topo_stride + (old count)], topo_count[v] ends as the list length (lists_stride =
+ * topo_stride layout, see a3d_normals_*).  topo_stride must be >= the largest possible valence: 2 x the largest number of tets around
+ * one edge of the grid (a static property; 12 on the Kuhn grids); entries past it would be dropped. */
 /* Optional, for callers that evaluate the SDF network with a graph only where the surface's gradient can reach (DMTetGeometry.
  * _get_mesh_surface_backward): with vertex_scratch (a3d_dmtet_vertex_scratch_bytes(Nv) bytes, 16-byte aligned) a3d_dmtet_count also
  * flags the grid vertices at the ends of crossing edges and returns their number in counts[3] -- the same read-back as V, n1, n2 --
@@ -145,18 +151,21 @@ int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const flo
  */
 int a3d_normals_adjacency(const int32_t* tri /*[F,3]*/, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream);
 int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, const int32_t* off, const int32_t* adj, int B, int V, int F,
-                    float* acc, float* nrm, int lists_sorted, a3d_stream_t stream);
+                    float* acc, float* nrm, int lists_stride, a3d_stream_t stream);
 int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apart*/, int g_nrm_stride, const float* acc, const float* v,
                     const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3]*/,
-                    float* g_v /*[B,V,3]*/, int lists_sorted, a3d_stream_t stream);
+                    float* g_v /*[B,V,3]*/, int lists_stride, a3d_stream_t stream);
 /* Two vertex arrays over ONE triangle list in one launch (e.g. the canonical mesh beside the B posed meshes of an iteration: a launch
  * of its own for one image is pure latency); results identical to two a3d_normals_fwd calls. */
 int a3d_normals_fwd_pair(const float* v_a /*[B_a,V,3]*/, int B_a, const float* v_b /*[B_b,V,3]*/, int B_b, const int32_t* tri,
                          const int32_t* off, const int32_t* adj, int V, int F, float* acc_a, float* nrm_a, float* acc_b, float* nrm_b,
-                         a3d_stream_t stream);
-/* lists_sorted: informational (1 = every list of adj is stored in ascending key order: a3d_normals_adjacency, a3d_mesh_topology; 0 = any
- * order: a3d_mesh_topology_finalize).  The kernels take a vertex's list into registers, order the keys there and issue all gathers at
- * once, so the sums run in ascending key order -- the same bits -- either way. */
+                         int lists_stride, a3d_stream_t stream);
+/* lists_stride: the layout of the vertex -> (corner, face) lists (off, adj), wherever this header takes them.
+ *   0 : CSR -- list v = adj[off[v] .. off[v+1]), off[V+1] (a3d_normals_adjacency, a3d_mesh_topology, a3d_mesh_topology_finalize);
+ *   S > 0 : fixed stride -- list v = adj[v*S .. v*S + off[v]), off[V] = the list lengths (a3d_dmtet_emit with topo_adj: the emit launch
+ *   writes the lists itself, no scan and no further launch).
+ * The lists may be stored in any order: the kernels take a vertex's list into registers, order the keys there and issue all gathers
+ * at once, so the sums run in ascending key order -- the reference's scatter_add_ order, the same bits -- either way. */
 
 /* ------------------------------------------------------------------------------------------------
  * Per-point shading arithmetic -- replaces the elementwise part of shade(), /root/reference/model/render/render.py:71-93:
@@ -223,7 +232,7 @@ int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, i
                  float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null, const int32_t* topo_adj_or_null,
                  int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a, const float* normals_v_b_or_null,
                  int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj, float* normals_acc_a, float* normals_a,
-                 float* normals_acc_b, float* normals_b, a3d_stream_t stream);
+                 float* normals_acc_b, float* normals_b, int lists_stride /* of topo_* and normals_* */, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 
@@ -320,11 +329,11 @@ size_t a3d_aa_hash_bytes(int F);
 int a3d_aa_shards(void);
 int a3d_aa_capacity(int B, int H, int W);
 int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream);
-int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp,
+int a3d_aa_topology_from_lists(const int32_t* tri, int F, const int32_t* off, const int32_t* adj, int32_t* opp, int lists_stride,
                                a3d_stream_t stream); /* the same table from the vertex -> face lists (no hash) */
 int a3d_aa_analyze(const float* rast, const float* clip, int clip_batch, const int32_t* tri, const int32_t* opp_or_null, int B, int V,
                    int F, int H, int W, float* screen, void* work, int capacity, int32_t* count, int prepared,
-                   const int32_t* off_or_null, const int32_t* adj_or_null, a3d_stream_t stream);
+                   const int32_t* off_or_null, const int32_t* adj_or_null, int lists_stride, a3d_stream_t stream);
 /* (opp_or_null = NULL with off / adj = the vertex -> face lists of a3d_normals_adjacency / a3d_mesh_topology[_finalize]: the opposite
  * vertex is looked up in the lists, only for the pixel pairs that passed every geometric test -- same records as with the table) */
 int a3d_aa_fwd(const float* color, int C, const void* work, const int32_t* count, int capacity, int B, int H, int W, float* out,
@@ -344,7 +353,7 @@ int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int 
                          const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
                          int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null, const float* analyze_screen,
                          int analyze_clip_batch, const int32_t* analyze_tri, const int32_t* analyze_opp_or_null, int V, int F,
-                         const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, a3d_stream_t stream);
+                         const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream);
 /* analyze_rast != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
  * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
  * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */

@@ -59,7 +59,7 @@ def main():
 
             def run():
                 ops.call("a3d_dmtet_count", ops.ptr(sdf), ops.ptr(topo.edges32), ops.ptr(topo.tets32), Ne, Nt, ops.ptr(scratch), ops.ptr(counts), None, 0,
-                         Nv, ops.ptr(gr[0]) if gr else None, ops.ptr(gr[1]) if gr else None, ops.stream())
+                         Nv, ops.ptr(gr[0]) if gr else None, ops.ptr(gr[1]) if gr else None, None, 0, ops.stream())
 
             for _ in range(5):
                 run()
