@@ -369,7 +369,9 @@ extern "C" int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch
         A3D_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t) * (size_t)B, s));
     }
     const int chunks = a3d_div_up(V, SK_THREADS);
-    int cpb = a3d_div_up((long long)chunks * B, 4096);
+    // ~768 work-groups: every work-group ends in K*12 returning atomics on its image's transform gradient and a ticket, which serialise
+    // per address -- V = 24k, B = 16 (1504 chunks): one chunk per work-group 41 us, two 32, three 33, four 40; V = 6k (384 chunks): 20 vs 22
+    int cpb = a3d_div_up((long long)chunks * B, 768);
     if (cpb < 1) cpb = 1;
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
     hipLaunchKernelGGL((sk_bwd_kernel<5, true>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, -1.f / temperature, cpb,
