@@ -15,7 +15,8 @@ from collections import defaultdict
 
 # entry point -> (kernels of one call, kernel whose dispatch count = number of calls)
 ENTRY = {
-    "a3d_dmtet_count": (["dm_count_kernel", "dm_scan_kernel"], "dm_count_kernel"),
+    # (the culled form -- sign plane, culled count, scan -- on grids with word groups; the plain count otherwise)
+    "a3d_dmtet_count": (["dm_sign_kernel", "dm_count_cull_kernel", "dm_count_kernel", "dm_scan_kernel"], "dm_scan_kernel"),
     "a3d_dmtet_emit": (["dm_emit_kernel"], "dm_emit_kernel"),
     "a3d_dmtet_bwd": (["dm_bwd_kernel"], "dm_bwd_kernel"),
     "a3d_skin_fwd": (["sk_fwd_kernel<20, false>", "sk_fwd_kernel<32, false>", "sk_fwd_kernel<64, false>"], None),
@@ -30,6 +31,7 @@ ENTRY = {
                           "nr_adj_scan_kernel"),
     "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
     "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel"], "nr_bwd_kernel"),
+    # (the triangle launch also carries the vertex normals of the step: nr_fwd's work as extra work-groups)
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
     "a3d_cover_count": (["cv_count_kernel"], "cv_count_kernel"),
     "a3d_cover_emit": (["cv_emit_kernel"], "cv_emit_kernel"),
@@ -48,7 +50,7 @@ ENTRY = {
     "a3d_aa_analyze": (["aa_screen_kernel", "aa_analyze_kernel"], "aa_analyze_kernel"),
     "a3d_aa_fwd": (["aa_fwd_kernel"], "aa_fwd_kernel"),
     "a3d_aa_bwd": (["aa_copy_zero_kernel", "aa_bwd_kernel"], "aa_bwd_kernel"),
-    # (one call per step handles the 4- and the 17-channel buffer together)
+    # (one call per step handles the 4- and the 17-channel buffer together; its compose launch also carries the silhouette analysis)
     "a3d_composite_aa_fwd": (["ca_compose_kernel", "ca_blend_kernel"], "ca_blend_kernel"),
     "a3d_composite_aa_bwd": (["ca_gather_kernel", "ca_bwd_kernel"], "ca_bwd_kernel"),
     "a3d_flow_loss_fwd": (["fl_fwd_kernel", "fl_finish_kernel"], "fl_fwd_kernel"),
