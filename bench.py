@@ -122,7 +122,7 @@ def algorithmic_bytes(name, d):
         "a3d_dmtet_count": dm_count,
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
-        "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F,  # (+ the int32 triangle list of the render kernels)
+        "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V),  # (+ the vertex -> face lists it now writes itself)  # (+ the int32 triangle list of the render kernels)
         "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
