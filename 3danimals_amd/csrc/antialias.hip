@@ -93,12 +93,13 @@ __device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned 
     if (rem < hw) {
         const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);  // (a 64-bit division costs ~150 instructions)
         if (d == 0 ? (x + 1 < W) : (y + 1 < H)) {
-            const float4 r0 = rast[i];
-            const float4 r1 = rast[i + (d == 0 ? 1 : W)];
-            const int id0 = (int)r0.w - 1, id1 = (int)r1.w - 1;
+            // (only depth and id of the two texels: the second half of each 16-byte texel, 8 bytes instead of 16 per read)
+            const float2 r0 = reinterpret_cast<const float2*>(rast + i)[1];
+            const float2 r1 = reinterpret_cast<const float2*>(rast + i + (d == 0 ? 1 : W))[1];
+            const int id0 = (int)r0.y - 1, id1 = (int)r1.y - 1;
             if (id0 != id1) {
                 int t = id0 >= 0 ? id0 : id1;
-                if (id0 >= 0 && id1 >= 0) t = (r0.z < r1.z) ? id0 : id1;
+                if (id0 >= 0 && id1 >= 0) t = (r0.x < r1.x) ? id0 : id1;
                 const bool use1 = (t == id1);
                 if (t >= 0 && t < F) {
                     const float xh = 0.5f * W, yh = 0.5f * H;

@@ -6,13 +6,18 @@
 // an exclusive prefix sum of the "sign crossing" flag over the static list.  So:
 //   count : wave-ballot popcounts of the crossing flag per 1024-edge block and of the 1-/2-triangle case
 //           per 1024-tet block, the ballots themselves kept as bit planes (1 bit/edge, 4 bits/tet), then one
-//           work-group scan per block-sum array (-> V, n1, n2)
+//           work-group scan per block-sum array (-> V, n1, n2).  With the grid's static word groups (round 3) the pass is
+//           CULLED: a sign-plane pre-pass, then a word of 64 index rows is read only if the <= 8 sixteen-vertex groups that
+//           cover its vertices do not all lie on one side of the surface -- 96-98 % of the index stream is never read.
 //   emit  : ONE launch over the bit planes: a crossing edge's vertex id is block prefix + word prefix + popcount below its bit;
-//           crossing edges place their vertex, surface tets read their tet2edge row and write int64 faces.
+//           crossing edges place their vertex, surface tets read their tet2edge row and write int64 faces -- and (round 3) the int32
+//           triangle list of the render kernels and the mesh's vertex -> face lists, every vertex owning a fixed number of slots
+//           (the grid bounds the valence), so that no topology launch follows.
 //           (Until round 2 the emit re-gathered every SDF value and re-read both index arrays in two launches
 //           chained through an edge -> vertex table: 23 us of kernel time against 8 now.)
-// Integer/byte work: 8 B/edge + 16 B/tet of streaming reads plus ~1e7 L2-resident 4-byte SDF gathers in the count
-// pass (TA line rate bound), ~1 MB of bit planes in the emit pass.  This TU is compiled with -ffp-contract=off: the vertex placement
+// Integer/byte work: streaming form 8 B/edge + 16 B/tet of reads plus ~1e7 L2-resident 4-byte SDF gathers in the count pass (TA
+// line rate bound), culled form 32 B per 64 rows of group ids + the rows of the few words that are read; ~1 MB of bit planes in the
+// emit pass.  This TU is compiled with -ffp-contract=off: the vertex placement
 // must round exactly like the reference's separate torch kernels (mul, mul, add).
 #include "a3d_common.h"
 

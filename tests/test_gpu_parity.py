@@ -1164,6 +1164,48 @@ def test_render_mesh_takes_the_pending_normals_into_the_rasteriser_launch(dev, o
     np.testing.assert_allclose(g_ride.cpu().numpy(), g_alone.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(g_alone.abs().max()))
 
 
+@pytest.mark.parametrize("grid", ["kuhn20", "bcc", "delaunay"])
+def test_emitted_vertex_face_lists_never_overflow_their_stride_even_on_noise(grid, dev, ops, mods):
+    """The fixed-stride lists of the DMTet emit rest on a bound: a surface vertex sits on a grid edge, every tet around that edge gives
+    at most two triangles at it, so valence <= 2 x (most tets around one edge) = TetGridTopology.face_list_stride() (rounded up).  White
+    noise as the SDF is the worst case (every tet a surface tet): no list is longer than the stride, every list complete, the normals
+    through them equal those through the stand-alone CSR lists bit for bit."""
+    a3d_pkg = importlib.import_module("3danimals_amd")
+    if grid.startswith("kuhn"):
+        pos, tets = kuhn(int(grid[4:]))
+    elif grid == "bcc":
+        p, t = a3d_pkg.tetgrid.bcc_grid(9, seed=2)
+        pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    else:
+        p, t = a3d_pkg.tetgrid.delaunay_grid(1500, seed=4)
+        pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    topo = mods["dmtet"].TetGridTopology(tets.to(dev))
+    stride = topo.face_list_stride()
+    most = int(torch.bincount(topo.tet2edge32.reshape(-1).long()).max())
+    assert stride % 8 == 0 and 2 * most <= stride < 2 * most + 8
+    pos_d = pos.to(dev)
+    seen = 0
+    for trial in range(3):
+        sdf = torch.randn(pos.shape[0], generator=torch.Generator().manual_seed(70 + trial)).to(dev)
+        verts, faces, _, _ = ops.dmtet_extract(pos_d, sdf, topo)  # (the first extraction on a grid has no guess at V: CSR fallback)
+        V, F = verts.shape[0], faces.shape[0]
+        tri32 = ops.tri_int32(faces)
+        adj = ops._adj_cache.peek(tri32)
+        ref_adj, _ = ops.mesh_topology(tri32.clone(), V)
+        valence = torch.diff(ref_adj.off.long())
+        assert int(valence.max()) <= 2 * most
+        if adj is None or not adj.stride:
+            continue
+        seen += 1
+        assert adj.stride == stride and torch.equal(adj.off[:V].long(), valence)
+        vv = verts[None].clone().requires_grad_(True)
+        n1, n2 = ops._Normals.apply(vv, tri32, adj), ops._Normals.apply(vv, tri32, ref_adj)
+        assert torch.equal(n1, n2)
+        w = seeded((1, V, 3), 9, -1, 1).to(dev)
+        assert torch.equal(torch.autograd.grad((n1 * w).sum(), vv)[0], torch.autograd.grad((n2 * w).sum(), vv)[0])
+    assert seen >= 1 or stride > ops.DMTET_EMIT_LISTS_MAX_STRIDE
+
+
 @pytest.mark.parametrize("grid", ["kuhn24", "kuhn64", "delaunay3k"])
 def test_topology_built_inside_the_dmtet_extraction_equals_the_stand_alone_one(grid, dev, ops, mods):
     """ops.dmtet_extract leaves the mesh topology in the caches (emit launch: int32 list + the vertex -> face lists, stride slots per
