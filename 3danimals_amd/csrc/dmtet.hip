@@ -58,8 +58,10 @@ __device__ __forceinline__ bool dm_edge_cross(const void* __restrict__ src, int2
 
 // every wave leaves DM_SIGN_WORDS words: lane l reads the vertices base + 64 j + l, all loads in flight, one ballot per word
 #define DM_SIGN_WORDS 4
-__global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits) {
+__global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits,
+                                                      int* __restrict__ list_len) {
     const int lane = threadIdx.x & 63;
+    if (list_len && blockIdx.x == 0 && threadIdx.x < 2) list_len[16 * threadIdx.x] = 0;  // (the two append counters of the count launch)
     const long long w0 = ((long long)blockIdx.x * (256 / 64) + (threadIdx.x >> 6)) * DM_SIGN_WORDS;  // first word of this wave
     float x[DM_SIGN_WORDS];
 #pragma unroll
@@ -86,7 +88,8 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
                                                int Ne, int Nt, bool is_edge, int blk, unsigned skip, int* __restrict__ blk_e,
                                                int* __restrict__ blk_t1, int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
-                                               unsigned* __restrict__ vbits, int (*s_cnt)[DM_THREADS / A3D_WAVE], int* s_pc) {
+                                               unsigned* __restrict__ vbits, int (*s_cnt)[DM_THREADS / A3D_WAVE], int* s_pc,
+                                               int* __restrict__ list_len = nullptr, int* __restrict__ list = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
     const long long base = (long long)blk * DM_BLOCK_ITEMS;
@@ -180,6 +183,9 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
         for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
         if (is_edge) blk_e[blk] = a;
         else { blk_t1[blk] = a; blk_t2[blk] = b; }
+        // the blocks that hold something, in any order: the emit launch then has one work-group set per listed block instead of one
+        // per block of the grid (R = 128: ~1.4k of 27k)
+        if (list && (a | b) != 0) list[atomicAdd(list_len, 1)] = blk;
     }
     if (is_edge && tid < DM_BLOCK_ITEMS / 64) {  // crossings of this block before word tid
         int before = 0;
@@ -221,7 +227,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
                                                                    int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                                    unsigned long long* __restrict__ edge_bits,
                                                                    unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
-                                                                   unsigned* __restrict__ vbits) {
+                                                                   unsigned* __restrict__ vbits, int* __restrict__ list_len,
+                                                                   int* __restrict__ elist, int* __restrict__ tlist) {
     __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
     __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
         if (lds_used) __syncthreads();  // s_cnt / s_pc of the previous processed block consumed
         lds_used = true;
         dm_count_block<true>(sign, edges, tets, Ne, Nt, is_edge, blk, (skip >> (DM_SLABS * g)) & 15u, blk_e, blk_t1, blk_t2, edge_bits, tet_bits,
-                             wlocal, vbits, s_cnt, s_pc);
+                             wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist);
     }
 }
 
@@ -287,7 +294,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
 // bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts, const unsigned* __restrict__ vbits,
-                                                       int* __restrict__ vchunk, int nvc, int* __restrict__ clear, int n_clear) {
+                                                       int* __restrict__ vchunk, int nvc, int* __restrict__ clear, int n_clear,
+                                                       const int* __restrict__ list_len) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int which = blockIdx.x;
@@ -339,6 +347,9 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
     if (tid == 1023) {
         counts[which] = run;
         if (which == 0 && !vbits) counts[3] = 0;
+        // how many edge / tet blocks the count launch listed as non-empty (-1: no lists, a3d_dmtet_emit covers every block)
+        if (which == 1) counts[4] = list_len ? list_len[0] : -1;
+        if (which == 2) counts[5] = list_len ? list_len[16] : -1;
     }
 }
 
@@ -391,7 +402,9 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
                                                              long long* __restrict__ surf_idx, float* __restrict__ clear, int n_clear,
                                                              int* __restrict__ tri32, int* __restrict__ topo_cnt, int wg_per_block,
-                                                             int* __restrict__ topo_adj, int topo_stride, int F) {
+                                                             int* __restrict__ topo_adj, int topo_stride, int F,
+                                                             const int* __restrict__ elist, const int* __restrict__ tlist, int n_eblocks,
+                                                             int n_tblocks, int nvc) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
@@ -400,14 +413,19 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     // vertex ids), and four of them in series per work-group made the launch pure latency at the bench size (16 us for ~1 MB; four
     // times the work-groups overlap them: 12.8 us).  wg_per_block = 1: all four slabs in one work-group, for grids whose block count
     // alone fills the machine many times over (R = 128: 27k blocks; 107k work-groups cost 62 us against 41 us)
-    if ((int)blockIdx.x >= wg_per_block * (nbe + nbt)) {
-        dm_surface_vertices_chunk((int)blockIdx.x - wg_per_block * (nbe + nbt), vbits, vchunk, Nv, surf_idx, s_pre);
+    // n_eblocks / n_tblocks work-group sets: every block of the grid (elist / tlist null), or only the blocks the culled count pass
+    // listed as non-empty (any order: a block's outputs go to places its prefixes name)
+    if ((int)blockIdx.x >= wg_per_block * (n_eblocks + n_tblocks)) {
+        const int c = (int)blockIdx.x - wg_per_block * (n_eblocks + n_tblocks);
+        if (c < nvc) dm_surface_vertices_chunk(c, vbits, vchunk, Nv, surf_idx, s_pre);  // (past the chunks: work-groups that only clear)
         return;
     }
     constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
-    const int blk = blockIdx.x / wg_per_block;
+    const int set = blockIdx.x / wg_per_block;
+    const bool is_edge = set < n_eblocks;
+    const int blk = is_edge ? (elist ? elist[set] : set) : nbe + (tlist ? tlist[set - n_eblocks] : set - n_eblocks);
     const int slab0 = (blockIdx.x % wg_per_block) * (DM_SLABS / wg_per_block), slab1 = slab0 + DM_SLABS / wg_per_block;
-    if (blk < nbe) {
+    if (is_edge) {
         const long long base = (long long)blk * DM_BLOCK_ITEMS;
         // this wave's (up to four) words at once: ~99 % of the blocks hold no crossing edge, and finding that out must not take a
         // dependent load per slab
@@ -544,6 +562,7 @@ struct DmScratch {
     unsigned long long *edge_bits, *tet_bits;
     int nbe, nbt;
     size_t sign_off;
+    int *list_len, *elist, *tlist;  // non-empty blocks of the culled count pass: two append counters (64 bytes apart), the two lists
 };
 
 #define DM_SIGN_PLANE_MIN_NV (1 << 20)  // below this the pre-pass launch costs what the cheaper gathers save (R = 64: 2.7e5 vertices)
@@ -561,7 +580,11 @@ static size_t dm_split_scratch(void* scratch, int Ne, int Nt, DmScratch* d) {
     d->b1 = d->be + d->nbe;
     d->b2 = d->b1 + d->nbt;
     d->sign_off = (sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + 4) + 63) & ~(size_t)63;
-    return d->sign_off + ((size_t)Ne / 4 + 64);  // + a sign plane for up to 2 Ne grid vertices (large grids: DM_SIGN_PLANE_MIN_NV)
+    const size_t list_off = (d->sign_off + ((size_t)Ne / 4 + 64) + 63) & ~(size_t)63;  // (after a sign plane for up to 2 Ne grid vertices)
+    d->list_len = (int*)((char*)scratch + list_off);
+    d->elist = d->list_len + 32;
+    d->tlist = d->elist + d->nbe;
+    return list_off + sizeof(int) * (32 + (size_t)d->nbe + d->nbt);
 }
 
 extern "C" size_t a3d_dmtet_scratch_bytes(int Ne, int Nt) {
@@ -597,18 +620,20 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
     if (vbits && !vertex_scratch_is_clean) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
+    const int* list_len = nullptr;
     if (edge_groups_or_null && (long long)Nv <= 2ll * Ne) {  // (the caller decides: ops.DMTET_CULL_MIN_VERTS)
         unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
-        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign);
+        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign, d.list_len);
         A3D_LAUNCH_CHECK();
+        list_len = d.list_len;
         // (G = 1, 2, 4, 8 blocks per work-group measured within 1 us of each other once the blocks of a work-group are strided)
         const int nge = a3d_div_up(d.nbe, DM_CULL_BLOCKS), ngt = a3d_div_up(d.nbt, DM_CULL_BLOCKS);
         hipLaunchKernelGGL(dm_count_cull_kernel<DM_CULL_BLOCKS>, dim3(nge + ngt), dim3(DM_THREADS), 0, s, (const unsigned*)sign, (const int2*)edges,
                            (const int4*)tets, Ne, Nt, d.nbe, d.nbt, nge, edge_groups_or_null, tet_groups_or_null, d.be, d.b1, d.b2, d.edge_bits,
-                           d.tet_bits, d.wlocal, vbits);
+                           d.tet_bits, d.wlocal, vbits, d.list_len, d.elist, d.tlist);
     } else if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
         unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
-        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign);
+        hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign, (int*)nullptr);
         A3D_LAUNCH_CHECK();
         hipLaunchKernelGGL(dm_count_kernel<true>, dim3(d.nbe + d.nbt), dim3(DM_THREADS), 0, s, (const void*)sign, (const int2*)edges,
                            (const int4*)tets, Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits);
@@ -618,7 +643,7 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     }
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc,
-                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0);
+                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0, list_len);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -627,7 +652,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                               void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
                               int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
-                              a3d_stream_t stream) {
+                              int n_edge_blocks_listed, int n_tet_blocks_listed, a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
@@ -645,12 +670,18 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     unsigned* vbits = (unsigned*)vertex_scratch_or_null;
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
     const int nbt = (n1 + n2) > 0 ? d.nbt : 0;
-    const int wgpb = (d.nbe + nbt) <= 8192 ? DM_SLABS : 1;
-    hipLaunchKernelGGL(dm_emit_kernel, dim3(wgpb * (d.nbe + nbt) + nvc), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
+    // counts[4], counts[5] of a3d_dmtet_count: the non-empty blocks its culled pass listed in the scratch (-1: none listed)
+    const bool listed = n_edge_blocks_listed >= 0 && n_tet_blocks_listed >= 0;
+    A3D_CHECK_ARG(!listed || (n_edge_blocks_listed <= d.nbe && n_tet_blocks_listed <= d.nbt));
+    const int ne = listed ? n_edge_blocks_listed : d.nbe, nt = listed ? (nbt ? n_tet_blocks_listed : 0) : nbt;
+    const int wgpb = (ne + nt) <= 8192 ? DM_SLABS : 1;
+    // (a short block list must not leave the clear of the dense SDF gradient to a handful of work-groups: <= 16 floats per thread)
+    const int wg_work = wgpb * (ne + nt) + nvc, wg_clear = g_sdf_to_clear_or_null ? a3d_div_up(Nv, DM_THREADS * 16) : 0;
+    hipLaunchKernelGGL(dm_emit_kernel, dim3(wg_work > wg_clear ? wg_work : wg_clear), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf, (const int2*)edges, tet2edge,
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
                        g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb, topo_adj_or_null,
-                       topo_stride, n1 + 2 * n2);
+                       topo_stride, n1 + 2 * n2, listed ? (const int*)d.elist : nullptr, listed ? (const int*)d.tlist : nullptr, ne, nt, nvc);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

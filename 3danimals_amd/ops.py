@@ -181,7 +181,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         vclean = vscratch is not None
         if vscratch is None:
             vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
-    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    counts = torch.empty(6, dtype=torch.int32, device=dev)
     # static per grid: lets the count pass skip the words off the surface.  Three launches (sign plane, culled count, scan) against two:
     # R = 64 (2.7e5 vertices) 14 vs 18 us back to back and equal inside the step, R = 128 32 vs 88 us; small grids keep the plain pass
     groups = grid.word_groups() if (Nv >= DMTET_CULL_MIN_VERTS and hasattr(grid, "word_groups")) else None
@@ -197,7 +197,9 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
          ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), 0 if counters is None else counters.shape[0],
          stream())
-    V, n1, n2, n_surf = counts.tolist()  # the one host sync of DMTet (the reference syncs here too, dmtet.py:110)
+    # the one host sync of DMTet (the reference syncs here too, dmtet.py:110); listed_*: how many non-empty blocks the culled count
+    # pass listed for the emit launch (-1: none listed)
+    V, n1, n2, n_surf, listed_e, listed_t = counts.tolist()
     F = n1 + 2 * n2
     if counters is not None:
         grid._last_surface_vertices = V
@@ -224,7 +226,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     try:
         call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
              ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
-             ptr(cur), ptr(lists_adj), stride if emit_lists else 0, stream())
+             ptr(cur), ptr(lists_adj), stride if emit_lists else 0, listed_e, listed_t, stream())
         adj = None
         if emit_lists:
             adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 304 = this header */
+int a3d_version(void); /* 305 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -42,8 +42,10 @@ const char* a3d_last_error(void);
  * Two phases with one 16-byte read-back in between (output sizes are data dependent; the reference
  * synchronises at the same place, dmtet.py:110):
  *   a3d_dmtet_count : counts[0]=V crossing edges, counts[1]=n1 one-triangle tets, counts[2]=n2 two-triangle
- *                     tets (F = n1 + 2 n2); scratch = a3d_dmtet_scratch_bytes(Ne,Nt) bytes, 8-byte aligned; it carries the
- *                     block scans and the crossing / case bit planes from count to emit.
+ *                     tets (F = n1 + 2 n2), counts[3] = flagged grid vertices (vertex_scratch; else 0), counts[4], counts[5] = the
+ *                     numbers of non-empty edge / tet blocks listed for the emit launch (-1, -1 without word groups);
+ *                     scratch = a3d_dmtet_scratch_bytes(Ne,Nt) bytes, 8-byte aligned; it carries the block scans, the crossing /
+ *                     case bit planes and those lists from count to emit.
  *   a3d_dmtet_emit  : verts[V,3] (vertex v = v-th crossing edge in `edges` order, placed at the SDF zero
  *                     crossing with the reference's operation order), vert_edge[V] (edge row, for backward),
  *                     faces[F,3] int64 (1-triangle tets first, then 2-triangle tets, dmtet.py:140-143),
@@ -52,7 +54,7 @@ const char* a3d_last_error(void);
  */
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
-                    int32_t* counts /*[4]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
+                    int32_t* counts /*[6]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
                     const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int32_t* words_to_clear_or_null,
                     int n_words_to_clear, a3d_stream_t stream);
 /* words_to_clear: n 4-byte words zeroed by the last launch of the call (the valence counters a3d_dmtet_emit's topo_count wants zero). */
@@ -72,7 +74,11 @@ int a3d_dmtet_block_items(void);
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                   int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride, a3d_stream_t stream);
+                   int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
+                   int n_edge_blocks_listed, int n_tet_blocks_listed, a3d_stream_t stream);
+/* n_*_blocks_listed = counts[4], counts[5] of the a3d_dmtet_count call that filled `scratch`: with the culled count pass (word groups)
+ * the blocks that hold a crossing edge / a surface tet are listed there and the emit launch covers those alone (~5 % of the grid's
+ * blocks); -1, -1 (what the plain count pass reports) = every block. */
 /* tri32 / topo_count (both or none): the emit launch also writes the int32 copy of faces that the render kernels read and counts the
  * valences of the surface vertices (topo_count[>= V], zero on entry) -- the first step of the mesh topology, which
  * a3d_mesh_topology_finalize completes in one launch (the stand-alone a3d_mesh_topology needs four).

@@ -51,7 +51,7 @@ def main():
                 print(f"R={res} {name} words skipped {skip.float().mean():.4f}, blocks fully skipped {skip.all(1).float().mean():.4f}")
         Ne, Nt, Nv = topo.edges32.shape[0], topo.tets32.shape[0], pos.shape[0]
         scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
-        counts = torch.empty(4, dtype=torch.int32, device=dev)
+        counts = torch.empty(6, dtype=torch.int32, device=dev)
         groups = topo.word_groups()
         for label, gr in (("plain", None), ("culled", groups)):
             if label == "culled" and gr is None:
