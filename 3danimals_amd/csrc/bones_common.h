@@ -246,7 +246,11 @@ __device__ __forceinline__ void bn_chain_products(const float (*s_L)[13], const 
     }
 }
 
-// s_mem: (4*K*D + K*K) words of LDS
+// s_mem: (4*K*D + K*K) words of LDS.
+// PARTIAL = false: g_M is the complete transform gradient of the image in global memory (read with agent-scope loads), g_angles is
+// written.  PARTIAL = true: g_M is ONE work-group's share of it, in LDS, and the result is ADDED to g_angles (zero on entry) -- the
+// adjoint is linear in g_M, so the sum over the work-groups of adjoint(share) is adjoint(sum): no work-group has to wait for the others.
+template <bool PARTIAL>
 __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const float* __restrict__ g_extra, const float* __restrict__ PS,
                                                     const float* __restrict__ bb, const float* __restrict__ aa, const int* __restrict__ chain,
                                                     int K, int D, float* __restrict__ g_angles, float* s_mem) {
@@ -264,7 +268,7 @@ __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const floa
             float g[12], P[12], S[12];
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                g[q] = __hip_atomic_load(g_M + 12 * k + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g[q] = PARTIAL ? g_M[12 * k + q] : __hip_atomic_load(g_M + 12 * k + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (g_extra) g[q] += g_extra[12 * k + q];
                 P[q] = PS[(long long)w * 24 + q];
                 S[q] = PS[(long long)w * 24 + 12 + q];
@@ -282,6 +286,7 @@ __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const floa
             const int w = s_pos[k * K + i];
             g += w >= 0 ? s_c[w][comp] : 0.f;
         }
-        g_angles[3 * i + comp] = g;
+        if (PARTIAL) atomicAdd(g_angles + 3 * i + comp, g);
+        else g_angles[3 * i + comp] = g;
     }
 }

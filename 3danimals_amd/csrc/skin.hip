@@ -48,7 +48,7 @@ __device__ __forceinline__ float sk_logit(const SkBone& b, float px, float py, f
 // POSE (a3d_skin_pose_fwd): ``T`` is an OUTPUT -- every work-group composes the K chain transforms of its image itself (links built
 // once into LDS, every bone multiplies the <= 8 links of its chain: the work of bones.hip's bn_fwd_kernel, ~1 us per work-group, all
 // work-groups at once) instead of reading the result of a separate launch; the first work-group of an image also writes them out for
-// the backward and for posed_bones.  ``angles`` [B,K,3], ``chain`` [K,D]; ``clear`` then also covers the backward's tickets.
+// the backward and for posed_bones.  ``angles`` [B,K,3], ``chain`` [K,D]; ``clear`` = the backward's angle-gradient accumulator.
 template <int KMAX, bool POSE>
 __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restrict__ v, int v_batch, const float* __restrict__ bones,
                                                             int bones_batch, float* T, int V, int K,
@@ -154,18 +154,19 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
 // phase 2 (wave = bone group): g_T[b,k] = sum_v w_k(v) * g(v) (x) [v,1] -- a [K x V].[V x 12] product per image.  Wave w owns the bones
 //          [w*KG, (w+1)*KG); every lane keeps KG x 12 partial sums in registers while it strides over the chunk's vertices in LDS, and
 //          the cross-lane reduction happens once per block (KG*12 butterfly sums), not once per vertex.
-// POSE (a3d_skin_pose_bwd): the work-group that finishes an image LAST (a ticket per image, taken after a device-scope fence behind the
-// work-group's g_T atomics) goes on to run the adjoint of the chain composition for that image (bones_common.h: bn_chain_adjoint, the
-// work of bones.hip's bn_bwd_kernel) on the now complete g_T[b] -- one launch and one launch gap less on a latency-bound stretch.  Per
-// image ~24 work-groups meet at one ticket, at different times: the contention that rules such tickets out for 4096-work-group launches
-//  does not arise.
+// POSE (a3d_skin_pose_bwd): the adjoint of the chain composition (bones_common.h: bn_chain_adjoint_ps, the work of bones.hip's
+// bn_bwd_kernel) runs in this launch too.  It is LINEAR in the transform gradient, so every work-group applies it to its own share of
+// g_T[b] -- straight from LDS, never written out -- and adds the resulting K x 3 angle gradients to g_angles[b] (zero on entry) with
+// fire-and-forget atomics: sum over work-groups of adjoint(share) = adjoint(sum).  No work-group waits for another.  (Until the middle
+// of round 3 the shares met in global memory through K*12 returning atomics per work-group and the work-group that took an image's
+// last ticket ran the adjoint once, alone: 14 us of parallel work + 9 us of serial tail; before that, a launch of its own.)
 template <int KG, bool POSE>
 __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
                                                             const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
                                                             int V, int K, float neg_inv_temp, int chunks_per_block, float* __restrict__ g_v,
                                                             float* g_T, const float* __restrict__ angles, const int* __restrict__ chain, int D,
-                                                            int* __restrict__ ticket, const float* __restrict__ g_T_extra,
-                                                            float* __restrict__ g_angles, const float* __restrict__ PS) {
+                                                            const float* __restrict__ g_T_extra, float* __restrict__ g_angles,
+                                                            const float* __restrict__ PS) {
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     __shared__ float s_w[4 * KG][SK_THREADS];
@@ -258,34 +259,26 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
             if ((lane & 15) == 0) s_red[lane >> 4][wave][kk * 12 + q] = r;
         }
     __syncthreads();
+    __shared__ float s_gT[POSE ? 4 * KG * 12 : 1];  // POSE: this work-group's share of g_T[b]
     for (int t = threadIdx.x; t < (SK_THREADS / 64) * KG * 12; t += SK_THREADS) {
         const int w = t / (KG * 12), j = t - w * (KG * 12);
         const int k = w * KG + j / 12;
         if (k < K) {
-            float* dst = g_T + ((long long)b * K + k) * 12 + (j % 12);
-            const float val = s_red[0][w][j] + s_red[1][w][j] + s_red[2][w][j] + s_red[3][w][j];
+            float val = s_red[0][w][j] + s_red[1][w][j] + s_red[2][w][j] + s_red[3][w][j];
             if (POSE) {
-                // RETURNING form, and the returned value is consumed: the wave then waits until the device-scope atomic has been performed
-                // at the memory side, which is what orders it before the ticket below.  (A __threadfence() here is a write-back +
-                // invalidate of the whole L2 of the XCD on gfx950 -- buffer_wbl2 / buffer_inv -- and took this kernel from 14 to 46 us.)
-                const float old = __hip_atomic_fetch_add(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("" ::"v"(old));
+                // (a gradient that reaches the transforms directly -- posed_bones -- joins the first work-group's share)
+                if (g_T_extra && blockIdx.x == 0) val += g_T_extra[((long long)b * K + k) * 12 + (j % 12)];
+                s_gT[k * 12 + (j % 12)] = val;
             } else {
-                atomicAdd(dst, val);
+                atomicAdd(g_T + ((long long)b * K + k) * 12 + (j % 12), val);
             }
         }
     }
     if (POSE) {
         __shared__ float s_adj[POSE ? 4 * 20 * BN_MAXD + 20 * 20 : 1];
-        __shared__ int s_last;
-        __syncthreads();  // every thread's atomics have returned
-        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
         __syncthreads();
-        if (!s_last) return;
-        // (bn_chain_adjoint_ps reads g_T with agent-scope loads, which do not hit in this XCD's L2)
-        bn_chain_adjoint_ps(g_T + (long long)b * K * 12, g_T_extra ? g_T_extra + (long long)b * K * 12 : nullptr,
-                            PS + (long long)b * K * D * 24, bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6),
-                            angles + (long long)b * K * 3, chain, K, D, g_angles + (long long)b * K * 3, s_adj);
+        bn_chain_adjoint_ps<true>(s_gT, nullptr, PS + (long long)b * K * D * 24, bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6),
+                                  angles + (long long)b * K * 3, chain, K, D, g_angles + (long long)b * K * 3, s_adj);
     }
 }
 
@@ -325,11 +318,10 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
     const float* nf = nullptr;
     const int* ni = nullptr;
-    int* nt = nullptr;
     float* ng = nullptr;
-    if (K <= 20) hipLaunchKernelGGL((sk_bwd_kernel<5, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
-    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_kernel<8, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
-    else hipLaunchKernelGGL((sk_bwd_kernel<16, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nt, nf, ng, nf);
+    if (K <= 20) hipLaunchKernelGGL((sk_bwd_kernel<5, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nf, ng, nf);
+    else if (K <= 32) hipLaunchKernelGGL((sk_bwd_kernel<8, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nf, ng, nf);
+    else hipLaunchKernelGGL((sk_bwd_kernel<16, false>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, nit, cpb, g_v_or_null, g_T, nf, ni, 0, nf, ng, nf);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -339,43 +331,38 @@ extern "C" int a3d_skin_pose_max_bones(void) { return 20; }
 
 extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain,
                                  int B, int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null,
-                                 float* g_T_to_clear_or_null, int32_t* ticket_to_clear_or_null, a3d_stream_t stream) {
+                                 float* g_angles_to_clear_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(v && bones && angles && chain && out && T_out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= 20 && D > 0 && D <= BN_MAXD && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
-    // g_T[B,K,12] and the B tickets are cleared as ONE run of 4-byte words: the caller allocates them back to back
-    A3D_CHECK_ARG((g_T_to_clear_or_null == nullptr) == (ticket_to_clear_or_null == nullptr));
-    A3D_CHECK_ARG(!g_T_to_clear_or_null || (void*)ticket_to_clear_or_null == (void*)(g_T_to_clear_or_null + (size_t)B * K * 12));
+    // (g_angles[B,K,3] of the backward, which accumulates into it: cleared here, one memset less on the backward path)
     const int ngroups = a3d_div_up(V, SK_THREADS / 4), groups = a3d_div_up(ngroups, 128);  // four lanes per vertex; <= 128 work-groups per image
     const dim3 grid(a3d_div_up(ngroups, groups), B), block(SK_THREADS);
-    const int ncl = g_T_to_clear_or_null ? B * K * 12 + B : 0;
+    const int ncl = g_angles_to_clear_or_null ? B * K * 3 : 0;
     float* no_w = nullptr;
     hipLaunchKernelGGL((sk_fwd_kernel<20, true>), grid, block, 0, (hipStream_t)stream, v, v_batch, bones, bones_batch, T_out, V, K,
-                       -1.f / temperature, out, no_w, g_T_to_clear_or_null, ncl, angles, chain, D, chain_products_or_null, groups);
+                       -1.f / temperature, out, no_w, g_angles_to_clear_or_null, ncl, angles, chain, D, chain_products_or_null, groups);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
 
 extern "C" int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T,
                                  const float* chain_products, const float* angles, const int32_t* chain, int B, int V, int K, int D,
-                                 float temperature, float* g_v_or_null, float* g_T, int32_t* ticket, int scratch_is_clear,
-                                 const float* g_T_extra_or_null, float* g_angles, a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_out && v && bones && T && chain_products && angles && chain && g_T && ticket && g_angles);
+                                 float temperature, float* g_v_or_null, const float* g_T_extra_or_null, float* g_angles,
+                                 int g_angles_is_clear, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && v && bones && T && chain_products && angles && chain && g_angles);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= 20 && D > 0 && D <= BN_MAXD && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     hipStream_t s = (hipStream_t)stream;
-    if (!scratch_is_clear) {
-        A3D_HIP(hipMemsetAsync(g_T, 0, sizeof(float) * (size_t)B * K * 12, s));
-        A3D_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t) * (size_t)B, s));
-    }
+    if (!g_angles_is_clear) A3D_HIP(hipMemsetAsync(g_angles, 0, sizeof(float) * (size_t)B * K * 3, s));
     const int chunks = a3d_div_up(V, SK_THREADS);
-    // ~768 work-groups: every work-group ends in K*12 returning atomics on its image's transform gradient and a ticket, which serialise
-    // per address -- V = 24k, B = 16 (1504 chunks): one chunk per work-group 41 us, two 32, three 33, four 40; V = 6k (384 chunks): 20 vs 22
+    // work-groups per image x B ~ 768: each ends in a chain adjoint of its own (~2 us) and K*3 atomics onto its image's angle gradient
     int cpb = a3d_div_up((long long)chunks * B, 768);
     if (cpb < 1) cpb = 1;
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
+    float* no_gT = nullptr;
     hipLaunchKernelGGL((sk_bwd_kernel<5, true>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, -1.f / temperature, cpb,
-                       g_v_or_null, g_T, angles, chain, D, ticket, g_T_extra_or_null, g_angles, chain_products);
+                       g_v_or_null, no_gT, angles, chain, D, g_T_extra_or_null, g_angles, chain_products);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

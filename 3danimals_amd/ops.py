@@ -368,17 +368,13 @@ class _SkinPose(torch.autograd.Function):
         assert v.shape[0] in (1, B) and bones.shape[0] in (1, B) and bones.shape[1] == K and chain.shape[0] == K and chain.dtype == torch.int32
         out = torch.empty((B, V, 3), dtype=torch.float32, device=v.device)
         T = torch.empty((B, K, 12), dtype=torch.float32, device=v.device)
-        # g_T and the per-image tickets of the backward: one buffer, cleared by the forward launch when a backward can follow
-        scratch = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            scratch = torch.empty((B * K * 12 + B,), dtype=torch.float32, device=v.device)
-        g_T = None if scratch is None else scratch[: B * K * 12]
-        ticket = None if scratch is None else scratch[B * K * 12:]
-        products = None if scratch is None else torch.empty((B, K, D, 2, 12), dtype=torch.float32, device=v.device)
+        # the backward accumulates the angle gradients with atomics: its buffer is allocated now and cleared by the forward launch
+        g_angles = torch.empty_like(angles) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]) else None
+        products = None if g_angles is None else torch.empty((B, K, D, 2, 12), dtype=torch.float32, device=v.device)
         call("a3d_skin_pose_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(angles), ptr(chain), B, V, K, D, float(temperature),
-             ptr(out), ptr(T), ptr(products), ptr(g_T), ptr(ticket), stream())
+             ptr(out), ptr(T), ptr(products), ptr(g_angles), stream())
         ctx.save_for_backward(v, bones, angles, chain, T, products)
-        ctx.scratch = scratch
+        ctx.g_angles = g_angles
         ctx.temperature = float(temperature)
         ctx.set_materialize_grads(False)
         return out, T
@@ -390,14 +386,12 @@ class _SkinPose(torch.autograd.Function):
         if g_out is None:  # only the transforms were used downstream
             g_out = torch.zeros((B, V, 3), dtype=torch.float32, device=v.device)
         g_v = torch.empty((B, V, 3), dtype=torch.float32, device=v.device) if ctx.needs_input_grad[0] else None
-        scratch, ctx.scratch = ctx.scratch, None  # the cleared buffer serves ONE backward
-        clear = scratch is not None
-        if scratch is None:
-            scratch = torch.empty((B * K * 12 + B,), dtype=torch.float32, device=v.device)
-        g_angles = torch.empty_like(angles)
+        g_angles, ctx.g_angles = ctx.g_angles, None  # the cleared buffer serves ONE backward
+        clear = g_angles is not None
+        if g_angles is None:
+            g_angles = torch.empty_like(angles)
         call("a3d_skin_pose_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), ptr(products), ptr(angles), ptr(chain), B, V, K, D,
-             ctx.temperature, ptr(g_v), ptr(scratch[: B * K * 12]), ptr(scratch[B * K * 12:]), int(clear),
-             ptr(None if g_T_ext is None else f32c(g_T_ext)), ptr(g_angles), stream())
+             ctx.temperature, ptr(g_v), ptr(None if g_T_ext is None else f32c(g_T_ext)), ptr(g_angles), int(clear), stream())
         if g_v is not None and v.shape[0] == 1 and B > 1:
             g_v = g_v.sum(0, keepdim=True)
         return g_v, None, g_angles, None, None

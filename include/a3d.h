@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 305 = this header */
+int a3d_version(void); /* 306 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -132,20 +132,19 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
  * (chain composition :389-417 + the per-vertex blend :377, :419-431), for K <= a3d_skin_pose_max_bones() bones and chains of D <= 8
  * links (every configuration of the reference: 20 bones, depth <= 8).  Forward: every work-group of the skinning launch composes the K
  * transforms of its image in LDS; T_out[B,K,12] receives them (backward, posed_bones), chain_products (when a backward will follow) the
- * prefix / suffix products of every chain position, which the backward's tail needs.  Backward: g_v as a3d_skin_bwd; the work-group that
- * finishes an image last (ticket[b], after a device-scope fence) runs the chain adjoint on the complete g_T[b] (+ g_T_extra[b]: a gradient
- * that reached the transforms directly, e.g. through posed_bones; may be null) -> g_angles[B,K,3], fully written.
- * g_T[B,K,12] floats and ticket[B] ints must be allocated back to back (one buffer of B*K*12 + B words); the forward clears both when
- * handed them (then scratch_is_clear = 1), otherwise the backward memsets them.
+ * prefix / suffix products of every chain position, which the backward needs.  Backward: g_v as a3d_skin_bwd; the chain adjoint is
+ * linear in the transform gradient, so every work-group applies it to its own share of g_T[b] (kept in LDS; + g_T_extra[b] once: a
+ * gradient that reached the transforms directly, e.g. through posed_bones; may be null) and ADDS the result to g_angles[B,K,3] with
+ * atomics: g_angles must be zero on entry -- the forward clears it when handed the buffer (then g_angles_is_clear = 1), otherwise the
+ * backward memsets it.
  */
 int a3d_skin_pose_max_bones(void);
 int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int B,
                       int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null /*[B,K,D,2,12]*/,
-                      float* g_T_to_clear_or_null, int32_t* ticket_to_clear_or_null, a3d_stream_t stream);
+                      float* g_angles_to_clear_or_null, a3d_stream_t stream);
 int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T,
                       const float* chain_products, const float* angles, const int32_t* chain, int B, int V, int K, int D, float temperature,
-                      float* g_v_or_null, float* g_T, int32_t* ticket, int scratch_is_clear, const float* g_T_extra_or_null, float* g_angles,
-                      a3d_stream_t stream);
+                      float* g_v_or_null, const float* g_T_extra_or_null, float* g_angles, int g_angles_is_clear, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Area-weighted vertex normals -- replaces auto_normals, /root/reference/model/render/mesh.py:276-304.
