@@ -509,3 +509,22 @@ def test_word_groups_cover_every_vertex_of_their_rows(grid):
                 assert set(t[w].tolist()) == need
                 some_sparse = True
     assert some_sparse or not grid.startswith("kuhn")
+
+
+def test_bench_credits_ride_along_work_to_the_call_that_carries_it():
+    """bench.algorithmic_bytes: a call that carries another pass as extra work-groups ([N..] = vertex normals in the rasteriser's launch,
+    [+analysis] = the silhouette analysis in the compositor's) is credited both passes' bytes -- the sum of the two stand-alone figures --
+    and the culled DMTet count only what it still moves."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = dict(B=16, V=6000, F=12000, H=256, W=256, Nv=274625, Ne=1872064, Nt=1572864, K=20, P=200000)
+    ab = bench.algorithmic_bytes
+    assert ab("a3d_rast_fwd[N16+1]", d) == ab("a3d_rast_fwd", d) + ab("a3d_normals_fwd_pair[B16+B1]", d)
+    assert ab("a3d_composite_aa_fwd[C4+C17][+analysis]", d) == ab("a3d_composite_aa_fwd[C4+C17]", d) + ab("a3d_aa_analyze", d)
+    assert ab("a3d_composite_aa_fwd[C4+C17]", d) == ab("a3d_composite_aa_fwd[C4]", d) + ab("a3d_composite_aa_fwd[C17]", d)
+    streamed = ab("a3d_dmtet_count", d)
+    culled = ab("a3d_dmtet_count", {**d, "dm_words_read": (1130, 29251, 980, 24576)})
+    assert streamed > 42e6 and 5e6 < culled < 7e6
