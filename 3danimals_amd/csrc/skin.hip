@@ -73,6 +73,13 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     }
     __syncthreads();
     if (POSE) {
+        // one EXTRA work-group per image (the last one; no vertices) leaves the prefix / suffix products of every chain position for the
+        // backward (bn_chain_adjoint_ps).  Inside a vertex work-group those 2K serial product chains sat in front of a barrier all
+        // 256 threads wait at, and that work-group was the slowest of its image
+        if (PS && blockIdx.x == gridDim.x - 1) {
+            bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * K * D * 24);
+            return;
+        }
         // the K chain products (K threads, ~8 dependent LDS round trips) run WHILE the rest of the work-group computes its vertices'
         // K logits, which only need the bones; the blend below waits for both at one barrier
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -84,9 +91,6 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
             bn_store(s_T + 12 * k, acc);
             if (blockIdx.x == 0) bn_store(T + ((long long)b * K + k) * 12, acc);
         }
-        // one work-group per image (not the one that writes T) leaves the prefix / suffix products of every chain position for the
-        // backward's tail (bn_chain_adjoint_ps): off the critical path here, ~7 us off it there
-        if (PS && blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * K * D * 24);
     }
     // FOUR lanes per vertex (a quad), each with a quarter of the bones: the K logits are a sqrt + an exp each and a thread that does all
     // twenty is ~2000 dependent instructions with 1.5 waves per SIMD to hide them behind (the kernel took 9 us for 1 MB); four times
@@ -337,7 +341,7 @@ extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     // (g_angles[B,K,3] of the backward, which accumulates into it: cleared here, one memset less on the backward path)
     const int ngroups = a3d_div_up(V, SK_THREADS / 4), groups = a3d_div_up(ngroups, 128);  // four lanes per vertex; <= 128 work-groups per image
-    const dim3 grid(a3d_div_up(ngroups, groups), B), block(SK_THREADS);
+    const dim3 grid(a3d_div_up(ngroups, groups) + (chain_products_or_null ? 1 : 0), B), block(SK_THREADS);  // (+ the products work-group)
     const int ncl = g_angles_to_clear_or_null ? B * K * 3 : 0;
     float* no_w = nullptr;
     hipLaunchKernelGGL((sk_fwd_kernel<20, true>), grid, block, 0, (hipStream_t)stream, v, v_batch, bones, bones_batch, T_out, V, K,
