@@ -448,9 +448,19 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, cons
     const int nloc = (int)min(256ll, P - base) * C, C1 = C + 1;
     const float rc = 1.f / (float)C;
     float* o = job.g_vals + base * C;
-    for (int j = threadIdx.x; j < nloc; j += 256) {
-        const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C;
-        o[j] = g_out[(long long)s_pix[pl] * C1 + c];
+    // four elements per thread in flight: written as a plain loop every load waited for the store before it (the compiler cannot rule
+    // out that g_vals aliases g_out), i.e. C dependent round trips per work-group
+    for (int j0 = threadIdx.x; j0 < nloc; j0 += 4 * 256) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 256 * k, jc = j < nloc ? j : j0;
+            const int pl = (int)(((float)jc + 0.5f) * rc), c = jc - pl * C;
+            v[k] = g_out[(long long)s_pix[pl] * C1 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j0 + 256 * k < nloc) o[j0 + 256 * k] = v[k];
     }
 }
 
