@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
     __shared__ float s_red[16][17];
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < P;
+    // the images this work-group's points belong to: img[first] .. img[last] (one, except at the ~B image boundaries of the list) -- read
+    // up front: after the per-point work they would be one more dependent round trip
+    const long long first = (long long)blockIdx.x * blockDim.x, last = min(first + (long long)blockDim.x, P) - 1;
+    const long long b_first = img ? img[first] : 0, b_last = img ? img[last] : 0;
     float gp[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k) gp[k] = 0.f;
@@ -169,9 +173,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
         }
         return;
     }
-    // the images this work-group's points belong to: img[first] .. img[last] (one, except at the ~B image boundaries of the list)
-    const long long first = (long long)blockIdx.x * blockDim.x, last = min(first + (long long)blockDim.x, P) - 1;
-    const long long b_first = img[first], b_last = img[last], b_lo = min(b_first, b_last), b_hi = max(b_first, b_last);
+    const long long b_lo = min(b_first, b_last), b_hi = max(b_first, b_last);
     const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 4;
     for (long long bi = b_lo; bi <= b_hi; ++bi) {  // uniform bounds
         const bool mine = live && row == bi;
