@@ -950,6 +950,31 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     assert rep["max_abs_image_err"] < 2e-5, rep["images"]  # measured: <= 1e-5; a regression shows long before the 1e-4 bar
 
 
+def test_training_step_runs_in_thirteen_hot_path_calls(dev):
+    """The structure DESIGN.md section 4 describes, pinned: a steady-state magicpony training step at the bench size calls exactly these
+    13 hot-path entry points (7 forward, 6 backward), once each -- no topology launch (the DMTet emit writes the lists), no normals
+    launch (they ride in the rasteriser's), no analysis launch (it rides in the compositor's) -- and the forward-only step 7."""
+    _lib = importlib.import_module("3danimals_amd._lib")
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    scene = pipeline.SyntheticScene(grid_res=64, batch=16, resolution=(256, 256), device=dev, seed=0, workload="magicpony", deform=True)
+    scene.step(backward=True, optimizer_step=True)  # (the first extraction on a grid has no guess at V: topology through the fallback)
+    hot = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
+           "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_")
+
+    def calls(backward):
+        with _lib.KernelTimer() as timer:
+            scene.step(backward=backward, optimizer_step=backward)
+        return {n: c for n, (c, _) in timer.summary().items() if n.startswith(hot)}
+
+    train = calls(True)
+    assert train == {"a3d_dmtet_count": 1, "a3d_dmtet_emit": 1, "a3d_skin_pose_fwd": 1, "a3d_rast_fwd[N16+1]": 1, "a3d_cover_gbuffer_fwd": 1,
+                     "a3d_shade_fwd": 1, "a3d_composite_aa_fwd[C4+C17][+analysis]": 1, "a3d_composite_aa_bwd[C4+C17]": 1, "a3d_shade_bwd": 1,
+                     "a3d_gbuffer_bwd": 1, "a3d_normals_bwd[B16]": 1, "a3d_skin_pose_bwd": 1, "a3d_dmtet_bwd": 1}, train
+    with torch.no_grad():
+        fwd = calls(False)
+    assert sorted(fwd) == sorted(k for k in train if "bwd" not in k), fwd
+
+
 @pytest.mark.parametrize("res,H,W", [(16, 64, 64), (8, 160, 128), (16, 256, 256)])
 def test_fused_gbuffer_matches_generic_path_and_gradients(res, H, W, dev, mods, ops):
     """csrc/gbuffer.hip (one kernel forward; gather backward with the rasteriser backward folded in) against the modular
