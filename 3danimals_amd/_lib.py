@@ -29,6 +29,7 @@ SIGNATURES = {
     "a3d_bone_transforms_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_bone_transforms_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_skin_pose_max_bones": (_c_int, []),
+    "a3d_skin_pose_products_floats": (_c_size_t, [_c_int, _c_int]),
     "a3d_skin_pose_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p, _p]),
     "a3d_skin_pose_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _c_int, _p]),
     "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
@@ -85,7 +86,7 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 306  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 307  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

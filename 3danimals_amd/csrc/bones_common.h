@@ -146,6 +146,59 @@ __device__ __forceinline__ void bn_link_adjoint(const float* g, const float* P, 
     for (int q = 0; q < 9; ++q) { gx += GRot[q] * dX[q]; gy += GRot[q] * dY[q]; gz += GRot[q] * dZ[q]; }
         }
 
+// d L / d angle_c (c = x, y, z) of one link, as three row-major 3x4 blocks: L = [R Rot R^T | t - R Rot R^T t]  =>
+// dL = [R dRot R^T | -(R dRot R^T) t].  With them the adjoint of a link is <P^T g S^T, dL_c>: 36 multiply-adds, no sin / cos, no
+// normalisation -- computed once per link by the forward (a3d_skin_pose_fwd) instead of once per (bone, chain position) pair and
+// work-group by the backward.
+__device__ __forceinline__ void bn_link_derivatives(const float* __restrict__ bone, const float* __restrict__ ang, float* __restrict__ out) {
+    float R[9], t[3];
+    bn_rest(bone, R, t);
+    const float x = ang[0], y = ang[1], z = ang[2];
+    const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
+    const float dR[3][9] = {{0.f, 0.f, 0.f,
+                             cx * sy * cz - sx * sz, -cx * sy * sz - sx * cz, -cx * cy,
+                             sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy},
+                            {-sy * cz, sy * sz, cy,
+                             sx * cy * cz, -sx * cy * sz, sx * sy,
+                             -cx * cy * cz, cx * cy * sz, -cx * sy},
+                            {-cy * sz, -cy * cz, 0.f,
+                             -sx * sy * sz + cx * cz, -sx * sy * cz - cx * sz, 0.f,
+                             cx * sy * sz + sx * cz, cx * sy * cz - sx * sz, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float T1[9];
+        bn_mat3(R, dR[c], T1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float lr[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) lr[q] = T1[3 * r] * R[3 * q] + T1[3 * r + 1] * R[3 * q + 1] + T1[3 * r + 2] * R[3 * q + 2];  // (T1 . R^T)
+            out[12 * c + 4 * r] = lr[0]; out[12 * c + 4 * r + 1] = lr[1]; out[12 * c + 4 * r + 2] = lr[2];
+            out[12 * c + 4 * r + 3] = -(lr[0] * t[0] + lr[1] * t[1] + lr[2] * t[2]);
+        }
+    }
+}
+
+// the same adjoint as bn_link_adjoint from the precomputed derivatives dL[3][12] of the link
+__device__ __forceinline__ void bn_link_adjoint_dl(const float* g, const float* P, const float* S, const float* __restrict__ dL, float& gx,
+                                                   float& gy, float& gz) {
+    float T1[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T1[4 * r + c] = P[r] * g[c] + P[4 + r] * g[4 + c] + P[8 + r] * g[8 + c];
+    float GL[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            GL[4 * r + c] = T1[4 * r] * S[4 * c] + T1[4 * r + 1] * S[4 * c + 1] + T1[4 * r + 2] * S[4 * c + 2] + T1[4 * r + 3] * S[4 * c + 3];
+        GL[4 * r + 3] = T1[4 * r + 3];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) { gx += GL[q] * dL[q]; gy += GL[q] * dL[12 + q]; gz += GL[q] * dL[24 + q]; }
+}
+
 // Adjoint of the chain composition for ONE instance, run by a whole work-group (any size): g_M [K,12] -> g_angles [K,3].
 // phase 1 links -> LDS; phase 2 (thread = bone, two threads per bone) prefix products P_j = L_0..L_{j-1} and suffix products
 // S_j = L_{j+1}..L_{D-1} of its chain -> LDS; phase 3 (thread = (bone, chain position)) the adjoint of one link pushed through the
@@ -246,14 +299,15 @@ __device__ __forceinline__ void bn_chain_products(const float (*s_L)[13], const 
     }
 }
 
-// s_mem: (4*K*D + K*K) words of LDS.
-// PARTIAL = false: g_M is the complete transform gradient of the image in global memory (read with agent-scope loads), g_angles is
-// written.  PARTIAL = true: g_M is ONE work-group's share of it, in LDS, and the result is ADDED to g_angles (zero on entry) -- the
-// adjoint is linear in g_M, so the sum over the work-groups of adjoint(share) is adjoint(sum): no work-group has to wait for the others.
-template <bool PARTIAL>
-__device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const float* __restrict__ g_extra, const float* __restrict__ PS,
-                                                    const float* __restrict__ bb, const float* __restrict__ aa, const int* __restrict__ chain,
-                                                    int K, int D, float* __restrict__ g_angles, float* s_mem) {
+// Floats per image of the buffer a3d_skin_pose_fwd leaves for the backward: PS[K][D][2][12] (bn_chain_products) + dL[K][3][12]
+// (bn_link_derivatives).
+__host__ __device__ static inline size_t bn_products_floats(int K, int D) { return (size_t)K * D * 24 + (size_t)K * 36; }
+
+// s_mem: (4*K*D + K*K) words of LDS.  g_M is ONE work-group's share of the image's transform gradient, in LDS; the result is ADDED to
+// g_angles (zero on entry): the adjoint is linear in g_M, so the sum over the work-groups of adjoint(share) is adjoint(sum) and no
+// work-group has to wait for the others.  PS / dL: the precomputed products and link derivatives of this image.
+__device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const float* __restrict__ PS, const float* __restrict__ dL,
+                                                    const int* __restrict__ chain, int K, int D, float* __restrict__ g_angles, float* s_mem) {
     float (*s_c)[3] = (float (*)[3])s_mem;       // [K*D][3]
     int* s_chain = (int*)(s_mem + 3 * K * D);    // [K*D]
     int* s_pos = s_chain + K * D;                // [K*K]
@@ -265,15 +319,16 @@ __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const floa
         float gx = 0.f, gy = 0.f, gz = 0.f;
         if (i >= 0) {
             s_pos[k * K + i] = w;
-            float g[12], P[12], S[12];
+            float g[12], P[12], S[12], d[36];
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                g[q] = PARTIAL ? g_M[12 * k + q] : __hip_atomic_load(g_M + 12 * k + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (g_extra) g[q] += g_extra[12 * k + q];
+                g[q] = g_M[12 * k + q];
                 P[q] = PS[(long long)w * 24 + q];
                 S[q] = PS[(long long)w * 24 + 12 + q];
             }
-            bn_link_adjoint(g, P, S, bb + 6 * i, aa + 3 * i, gx, gy, gz);
+#pragma unroll
+            for (int q = 0; q < 36; ++q) d[q] = dL[36 * i + q];
+            bn_link_adjoint_dl(g, P, S, d, gx, gy, gz);
         }
         s_c[w][0] = gx; s_c[w][1] = gy; s_c[w][2] = gz;
     }
@@ -286,7 +341,6 @@ __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const floa
             const int w = s_pos[k * K + i];
             g += w >= 0 ? s_c[w][comp] : 0.f;
         }
-        if (PARTIAL) atomicAdd(g_angles + 3 * i + comp, g);
-        else g_angles[3 * i + comp] = g;
+        atomicAdd(g_angles + 3 * i + comp, g);
     }
 }

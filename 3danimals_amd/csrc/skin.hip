@@ -77,7 +77,14 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
         // backward (bn_chain_adjoint_ps).  Inside a vertex work-group those 2K serial product chains sat in front of a barrier all
         // 256 threads wait at, and that work-group was the slowest of its image
         if (PS && blockIdx.x == gridDim.x - 1) {
-            bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * K * D * 24);
+            float* out = PS + (long long)b * bn_products_floats(K, D);
+            // (second wave: the link derivatives the backward's adjoint multiplies with -- sin / cos and normalisations once per link
+            // here instead of once per (bone, chain position) pair and work-group there)
+            if (threadIdx.x >= 64 && (int)threadIdx.x < 64 + K) {
+                const int i = threadIdx.x - 64;
+                bn_link_derivatives(bb + 6 * i, angles + ((long long)b * K + i) * 3, out + (long long)K * D * 24 + 36 * i);
+            }
+            bn_chain_products(s_L, s_chain, K, D, out);
             return;
         }
         // the K chain products (K threads, ~8 dependent LDS round trips) run WHILE the rest of the work-group computes its vertices'
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
 template <int KG, bool POSE>
 __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ v, int v_batch,
                                                             const float* __restrict__ bones, int bones_batch, const float* __restrict__ T,
-                                                            int V, int K, float neg_inv_temp, int chunks_per_block, float* __restrict__ g_v,
+                                                            int V, int K, float neg_inv_temp, int verts_per_wg, float* __restrict__ g_v,
                                                             float* g_T, const float* __restrict__ angles, const int* __restrict__ chain, int D,
                                                             const float* __restrict__ g_T_extra, float* __restrict__ g_angles,
                                                             const float* __restrict__ PS) {
@@ -186,14 +193,14 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
         for (int q = 0; q < 12; ++q) acc[kk][q] = 0.f;
     const float* vb = v + (v_batch == 1 ? 0ll : (long long)b * V * 3);
     const float* gb = g_out + (long long)b * V * 3;
-    for (int ch = 0; ch < chunks_per_block; ++ch) {
-        const int base = (blockIdx.x * chunks_per_block + ch) * SK_THREADS;
-        if (base >= V) break;  // uniform
+    // this work-group's vertices [lo, hi), 256 at a time (the last trip may be partial)
+    const int lo = blockIdx.x * verts_per_wg, hi = min(lo + verts_per_wg, V);
+    for (int base = lo; base < hi; base += SK_THREADS) {
         __syncthreads();       // previous chunk's LDS fully consumed (also orders sk_stage on the first trip)
         {
             const int i = base + threadIdx.x;
             float px = 0.f, py = 0.f, pz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-            const bool ok = i < V;
+            const bool ok = i < hi;
             if (ok) {
                 px = vb[3ll * i]; py = vb[3ll * i + 1]; pz = vb[3ll * i + 2];
                 gx = gb[3ll * i]; gy = gb[3ll * i + 1]; gz = gb[3ll * i + 2];
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
     if (POSE) {
         __shared__ float s_adj[POSE ? 4 * 20 * BN_MAXD + 20 * 20 : 1];
         __syncthreads();
-        bn_chain_adjoint_ps<true>(s_gT, nullptr, PS + (long long)b * K * D * 24, bones + (bones_batch == 1 ? 0ll : (long long)b * K * 6),
-                                  angles + (long long)b * K * 3, chain, K, D, g_angles + (long long)b * K * 3, s_adj);
+        const float* ps = PS + (long long)b * bn_products_floats(K, D);
+        bn_chain_adjoint_ps(s_gT, ps, ps + (long long)K * D * 24, chain, K, D, g_angles + (long long)b * K * 3, s_adj);
     }
 }
 
@@ -320,6 +327,7 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
     int cpb = a3d_div_up((long long)chunks * B, 4096);
     if (cpb < 1) cpb = 1;
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
+    cpb *= SK_THREADS;  // (the kernel takes vertices per work-group)
     const float* nf = nullptr;
     const int* ni = nullptr;
     float* ng = nullptr;
@@ -332,6 +340,7 @@ extern "C" int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, con
 
 // ---- kinematic chain + skinning in ONE launch each way (K <= 20 bones, chains of D <= 8 links: every configuration of the reference)
 extern "C" int a3d_skin_pose_max_bones(void) { return 20; }
+extern "C" size_t a3d_skin_pose_products_floats(int K, int D) { return bn_products_floats(K < 0 ? 0 : K, D < 0 ? 0 : D); }
 
 extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain,
                                  int B, int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null,
@@ -359,15 +368,17 @@ extern "C" int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
     hipStream_t s = (hipStream_t)stream;
     if (!g_angles_is_clear) A3D_HIP(hipMemsetAsync(g_angles, 0, sizeof(float) * (size_t)B * K * 3, s));
+    // ~768 work-groups of whole 256-vertex chunks: every work-group pays a fixed part (bones + transforms into LDS, the K*12-value
+    // cross-lane reduction, a chain adjoint of its own: 1.4 + 2.7 us) besides its chunks -- V = 24k, B = 16 (1504 chunks): one chunk
+    // per work-group 41 us, two 29, three 33.5; V = 6k (384 chunks): one 16, two 21.  (Balancing the CUs instead -- 256 work-groups of
+    // 1.5 chunks at V = 6k -- measured 20.5: the chunks of a work-group run one after the other and the kernel is bound by that chain.)
     const int chunks = a3d_div_up(V, SK_THREADS);
-    // ~768 work-groups: every one pays a fixed part (bones + transforms into LDS, the K*12-value cross-lane reduction, a chain adjoint
-    // of its own) besides its chunks -- V = 24k, B = 16 (1504 chunks): one chunk per work-group 41 us, two 32, three 33.5; V = 6k (384
-    // chunks): 19 vs 21
     int cpb = a3d_div_up((long long)chunks * B, 768);
     if (cpb < 1) cpb = 1;
+    const int vpw = cpb * SK_THREADS;
     const dim3 grid(a3d_div_up(chunks, cpb), B), block(SK_THREADS);
     float* no_gT = nullptr;
-    hipLaunchKernelGGL((sk_bwd_kernel<5, true>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, -1.f / temperature, cpb,
+    hipLaunchKernelGGL((sk_bwd_kernel<5, true>), grid, block, 0, s, g_out, v, v_batch, bones, bones_batch, T, V, K, -1.f / temperature, vpw,
                        g_v_or_null, no_gT, angles, chain, D, g_T_extra_or_null, g_angles, chain_products);
     A3D_LAUNCH_CHECK();
     return A3D_OK;

@@ -370,7 +370,7 @@ class _SkinPose(torch.autograd.Function):
         T = torch.empty((B, K, 12), dtype=torch.float32, device=v.device)
         # the backward accumulates the angle gradients with atomics: its buffer is allocated now and cleared by the forward launch
         g_angles = torch.empty_like(angles) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]) else None
-        products = None if g_angles is None else torch.empty((B, K, D, 2, 12), dtype=torch.float32, device=v.device)
+        products = None if g_angles is None else torch.empty((B, _lib.lib().a3d_skin_pose_products_floats(K, D)), dtype=torch.float32, device=v.device)
         call("a3d_skin_pose_fwd", ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(angles), ptr(chain), B, V, K, D, float(temperature),
              ptr(out), ptr(T), ptr(products), ptr(g_angles), stream())
         ctx.save_for_backward(v, bones, angles, chain, T, products)

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 306 = this header */
+int a3d_version(void); /* 307 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -132,15 +132,17 @@ int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int bones_batc
  * (chain composition :389-417 + the per-vertex blend :377, :419-431), for K <= a3d_skin_pose_max_bones() bones and chains of D <= 8
  * links (every configuration of the reference: 20 bones, depth <= 8).  Forward: every work-group of the skinning launch composes the K
  * transforms of its image in LDS; T_out[B,K,12] receives them (backward, posed_bones), chain_products (when a backward will follow) the
- * prefix / suffix products of every chain position, which the backward needs.  Backward: g_v as a3d_skin_bwd; the chain adjoint is
+ * prefix / suffix products of every chain position and the derivative of every link by its three angles, which the backward needs
+ * (one extra work-group per image computes them beside the vertex work).  Backward: g_v as a3d_skin_bwd; the chain adjoint is
  * linear in the transform gradient, so every work-group applies it to its own share of g_T[b] (kept in LDS; + g_T_extra[b] once: a
  * gradient that reached the transforms directly, e.g. through posed_bones; may be null) and ADDS the result to g_angles[B,K,3] with
  * atomics: g_angles must be zero on entry -- the forward clears it when handed the buffer (then g_angles_is_clear = 1), otherwise the
  * backward memsets it.
  */
 int a3d_skin_pose_max_bones(void);
+size_t a3d_skin_pose_products_floats(int K, int D); /* floats PER IMAGE of chain_products: K*D*24 (prefix / suffix products) + K*36 (d link / d angle) */
 int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* angles, const int32_t* chain, int B,
-                      int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null /*[B,K,D,2,12]*/,
+                      int V, int K, int D, float temperature, float* out, float* T_out, float* chain_products_or_null /*[B, a3d_skin_pose_products_floats(K, D)]*/,
                       float* g_angles_to_clear_or_null, a3d_stream_t stream);
 int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch, const float* bones, int bones_batch, const float* T,
                       const float* chain_products, const float* angles, const int32_t* chain, int B, int V, int K, int D, float temperature,
