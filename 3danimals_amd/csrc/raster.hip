@@ -7,7 +7,8 @@
 //   clear   : keys[B,H,W] (u64) <- ~0       (hipMemsetAsync, 8 B/pixel; skipped when the caller hands back the buffer of the
 //             previous call on the same stream: the resolve re-arms every key it consumes)
 //   tri     : 4 lanes per (image, triangle): 12 B of indices + 3 x 16 B vertex gathers (L2 resident), the
-//             conservative pixel box, then the box's pixels are shared out over the 4 lanes; every covered pixel
+//             conservative pixel box; the candidate pixels of a wave's 16 triangles are then POOLED (prefix of the box sizes,
+//             triangle data through LDS) and dealt out evenly over the 64 lanes; every covered pixel
 //             does atomicMin(keys[pixel], order(z/w) << 32 | id).  min over (depth, id) is order independent, so
 //             the image is deterministic with no sorting or binning, and the work is balanced over all 256 CUs
 //             no matter where on screen the object is.  Boxes above 64 px are found with a ballot and
@@ -112,7 +113,8 @@ __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, 
     }
 }
 
-// 4 lanes per (image, triangle); blockDim = 256 = 64 triangles
+// LPT lanes per (image, triangle); blockDim = 256 = 256 / LPT triangles
+template <int LPT>
 __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
                                                      int H, int W, unsigned long long* __restrict__ keys, const float4* __restrict__ prev,
                                                      int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards,
@@ -158,8 +160,9 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         aa_screen[(long long)b * V + i] = make_float2(p.x / p.w * (0.5f * W), p.y / p.w * (0.5f * H));
         return;
     }
-    const int f = blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int sub = threadIdx.x & 3, lane = threadIdx.x & 63;
+    constexpr int TPW = 64 / LPT;  // triangles per wave
+    const int f = blockIdx.x * (256 / LPT) + (int)threadIdx.x / LPT;
+    const int sub = threadIdx.x % LPT, lane = threadIdx.x & 63;
     const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
     unsigned long long* kb = keys + (long long)b * H * W;
     const float4* pv = prev ? prev + (long long)b * H * W : nullptr;
@@ -174,15 +177,44 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
             area = rs_box(p0, p1, p2, H, W, x0, y0, bw);
         }
     }
-    if (area > 0 && area <= RS_COOP_AREA) {  // (a culled box may carry bw <= 0)
-        // candidate i of the box is (x0 + i % bw, y0 + i / bw); walked incrementally (an integer division costs ~40 instructions)
-        int cx = sub, cy = 0;
-        while (cx >= bw) { cx -= bw; ++cy; }
-        for (int i = sub; i < area; i += 4) {
-            rs_test_pixel(p0, p1, p2, x0 + cx, y0 + cy, W, xs, xo, ys, yo, (unsigned)f, kb, pv);
-            cx += 4;
-            while (cx >= bw) { cx -= bw; ++cy; }
+    // Small boxes (<= RS_COOP_AREA candidates; a culled box may carry bw <= 0): the candidates of the wave's TPW triangles are POOLED and
+    // dealt out evenly over its 64 lanes.  (Each triangle's lanes walking their own box made the wave as slow as its largest box: ~10
+    // trips of the fragment test where the pooled form needs ceil(sum / 64); the fragment tests, not the atomics, were 11.6 of this
+    // kernel's 18.8 us.)  Triangle data and the prefix of the box sizes go through LDS, one slice per wave.
+    // LPT: the set-up (two dependent gathers + the box) is latency bound and wants many waves -- 4 lanes per triangle at B F = 1.9e5
+    // (16.9 us against 22.1 with one) --, but is pure repetition once the waves suffice: one lane per triangle at B F = 7.7e5 (19.8 us
+    // against 28.6 with four).
+    __shared__ float4 s_p[4][TPW][3];
+    __shared__ int4 s_box[4][TPW];  // x0, y0, bw, f
+    __shared__ int s_pre[4][TPW + 1];
+    const int wv = threadIdx.x >> 6, q = lane / LPT;  // this wave's slice, this lane's triangle slot
+    const int small = (area > 0 && area <= RS_COOP_AREA) ? area : 0;
+    if (sub == 0) {
+        s_p[wv][q][0] = p0; s_p[wv][q][1] = p1; s_p[wv][q][2] = p2;
+        s_box[wv][q] = make_int4(x0, y0, bw, f);
+    }
+    {   // inclusive scan of the TPW box sizes (held by the lanes LPT q)
+        int incl = small;
+#pragma unroll
+        for (int d = LPT; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
         }
+        if (sub == 0) s_pre[wv][q + 1] = incl;
+        if (lane == 0) s_pre[wv][0] = 0;
+    }
+    __syncthreads();
+    const int total = s_pre[wv][TPW];
+    for (int c = lane; c < total; c += 64) {
+        int j = 0;  // the triangle slot that owns candidate c: largest j with pre[j] <= c
+#pragma unroll
+        for (int step = TPW / 2; step > 0; step >>= 1)
+            if (s_pre[wv][j + step] <= c) j += step;
+        const int4 bx = s_box[wv][j];
+        const int i = c - s_pre[wv][j];
+        // i / bw for i < 64, bw <= 64: (i + 0.5) / bw is at least 1/128 away from an integer, 1 ulp of the reciprocal is irrelevant
+        const int cy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z)), cx = i - cy * bx.z;
+        rs_test_pixel(s_p[wv][j][0], s_p[wv][j][1], s_p[wv][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
     }
     // large boxes: one representative lane per triangle (sub == 0) votes, the whole wave walks the box
     unsigned long long big = __ballot(area > RS_COOP_AREA && sub == 0);
@@ -322,7 +354,11 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     A3D_CHECK_ARG((aa_screen_or_null == nullptr) == (aa_count_or_null == nullptr) && a3d_aa_shards() <= 256);
     A3D_CHECK_ARG((topo_opp_or_null == nullptr) == (topo_off_or_null == nullptr) && (topo_opp_or_null == nullptr) == (topo_adj_or_null == nullptr));
-    const int nb_tri = a3d_div_up(F, 64), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
+    // lanes per triangle (rs_tri_kernel), by the number of (image, triangle) pairs -- measured 1.9e5 pairs: 16.9 / 17.7 / 22.0 us with
+    // 4 / 2 / 1 lanes, 7.7e5 pairs: 28.4 / 21.6 / 19.9
+    const long long pairs = (long long)B * F;
+    const int lpt = pairs <= 300000 ? 4 : (pairs <= 600000 ? 2 : 1);
+    const int nb_tri = a3d_div_up(F, 256 / lpt), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
     const int nb_opp = topo_opp_or_null ? a3d_div_up(3ll * F, 256) : 0;
     RsNormalsJob nj = {};
     A3D_CHECK_ARG(lists_stride >= 0);
@@ -335,10 +371,14 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
         nj.B_a = normals_B_a; nj.B_b = normals_B_b;
         nj.wg_per_row = a3d_div_up((long long)a3d_div_up(V, 256) * (normals_B_a + normals_B_b), B);
     }
-    hipLaunchKernelGGL(rs_tri_kernel, dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), 0, s, (const float4*)clip, clip_batch,
-                       tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null,
-                       a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen,
-                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj);
+#define RS_LAUNCH_TRI(LPT_) \
+    hipLaunchKernelGGL(rs_tri_kernel<LPT_>, dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), 0, s, (const float4*)clip, clip_batch, \
+                       tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null, \
+                       a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen, \
+                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj); \
+
+    if (lpt == 4) { RS_LAUNCH_TRI(4) } else if (lpt == 2) { RS_LAUNCH_TRI(2) } else { RS_LAUNCH_TRI(1) }
+#undef RS_LAUNCH_TRI
     A3D_LAUNCH_CHECK();
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
