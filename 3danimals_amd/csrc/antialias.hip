@@ -74,25 +74,19 @@ struct AaAnalyzeJob {
     int clip_batch, V, F, H, W, capacity, B, stride;  // stride: layout of off / adj (topo_common.h: vf_list)
 };
 
-// one thread per (pixel, direction): work-group (bx, d, b) of a (ceil(H W / 256), 2, B) grid; d = 0: right neighbour, 1: lower neighbour
-__device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned bx, int d, int b) {
+// One pixel pair (pixel i = image b, row y, column x; its right (d = 0) or lower (d = 1) neighbour, which the caller has established
+// to exist): true + the record if the pair straddles a silhouette edge.
+__device__ __forceinline__ bool aa_pair_record(const AaAnalyzeJob& a, long long i, int b, int x, int y, int d, AaRec& rec) {
     const float4* __restrict__ rast = a.rast;
     const float2* __restrict__ screen = a.screen;
     const int* __restrict__ tri = a.tri;
     const int* __restrict__ opp = a.opp;
     const int* __restrict__ off = a.off;
     const int* __restrict__ adj = a.adj;
-    AaRec* __restrict__ work = a.work;
-    int* __restrict__ count = a.count;
-    const int clip_batch = a.clip_batch, V = a.V, F = a.F, H = a.H, W = a.W, capacity = a.capacity;
-    const unsigned hw = (unsigned)H * (unsigned)W;
-    const unsigned rem = bx * 256u + threadIdx.x;
-    const long long i = (long long)b * hw + rem;
-    AaRec rec;
+    const int clip_batch = a.clip_batch, V = a.V, F = a.F, H = a.H, W = a.W;
     bool emit = false;
-    if (rem < hw) {
-        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);  // (a 64-bit division costs ~150 instructions)
-        if (d == 0 ? (x + 1 < W) : (y + 1 < H)) {
+    {
+        {
             // (only depth and id of the two texels: the second half of each 16-byte texel, 8 bytes instead of 16 per read)
             const float2 r0 = reinterpret_cast<const float2*>(rast + i)[1];
             const float2 r1 = reinterpret_cast<const float2*>(rast + i + (d == 0 ? 1 : W))[1];
@@ -154,23 +148,72 @@ __device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned 
             }
         }
     }
-    // wave-aggregated append into one of AA_SHARDS segments of the work list: a single append counter serialises every wave of the
-    // launch on one address (~12 ns per returning atomic: 31 of this kernel's 46 us on the bench workload)
+    return emit;
+}
+
+// wave-aggregated append into segment ``shard`` of the work list: a single append counter would serialise every wave of the launch on
+// one address (~12 ns per returning atomic: 31 of the analysis' 46 us on the bench workload, round 1)
+__device__ __forceinline__ void aa_append(const AaAnalyzeJob& a, bool emit, const AaRec& rec, int shard) {
     const unsigned long long m = __ballot(emit);
     if (m) {
-        // work-group L of the launch appends to segment L % AA_SHARDS; a segment holds 256 records for each of its work-groups
-        const unsigned lin = bx + ((hw + 255u) / 256u) * ((unsigned)d + 2u * (unsigned)b);
-        const int shard = (int)(lin & (AA_SHARDS - 1));
-        const int seg_cap = capacity / AA_SHARDS;
+        const int seg_cap = a.capacity / AA_SHARDS;
         int basei = 0;
         const int leader = __ffsll((long long)m) - 1;
-        if (a3d_lane_id() == leader) basei = atomicAdd(count + shard, __popcll(m));
+        if (a3d_lane_id() == leader) basei = atomicAdd(a.count + shard, __popcll(m));
         basei = __shfl(basei, leader);
         if (emit) {
             const int slot = basei + a3d_wave_prefix(m);
-            if (slot < seg_cap) work[(long long)shard * seg_cap + slot] = rec;
+            if (slot < seg_cap) a.work[(long long)shard * seg_cap + slot] = rec;
         }
     }
+}
+
+// one thread per (pixel, direction): work-group (bx, d, b) of a (ceil(H W / 256), 2, B) grid; d = 0: right neighbour, 1: lower neighbour.
+// Work-group L of that grid appends to segment L % AA_SHARDS; a segment holds 256 records for each of its work-groups.
+// Two phases: every thread compares the triangle ids of its pair (two 8-byte reads); the pairs that differ (~15 % of them: with
+// triangles the size of a pixel an id discontinuity is the rule inside the object) are POOLED through LDS and worked off by the first
+// ceil(n / 64) waves with full lanes -- the long path (triangle, three screen positions, the opposite vertex: five dependent
+// gathers, ~200 instructions) used to run in every wave that held a single such pair, at ~15 % of its lanes.
+__device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned bx, int d, int b) {
+    __shared__ unsigned s_cand[256];
+    __shared__ int s_ncand;
+    const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+    const unsigned rem = bx * 256u + threadIdx.x;
+    if (threadIdx.x == 0) s_ncand = 0;
+    __syncthreads();
+    bool cand = false;
+    unsigned xy = 0;
+    if (rem < hw) {
+        const unsigned y = rem / (unsigned)a.W, x = rem - y * (unsigned)a.W;  // (a 64-bit division costs ~150 instructions)
+        if (d == 0 ? ((int)x + 1 < a.W) : ((int)y + 1 < a.H)) {
+            const long long i = (long long)b * hw + rem;
+            const float w0 = reinterpret_cast<const float*>(a.rast + i)[3], w1 = reinterpret_cast<const float*>(a.rast + i + (d == 0 ? 1 : a.W))[3];
+            cand = (int)w0 != (int)w1;
+            xy = (y << 16) | x;
+        }
+    }
+    {
+        const unsigned long long m = __ballot(cand);
+        int base = 0;
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            if (a3d_lane_id() == leader) base = atomicAdd(&s_ncand, __popcll(m));
+            base = __shfl(base, leader);
+        }
+        if (cand) s_cand[base + a3d_wave_prefix(m)] = xy;
+    }
+    __syncthreads();
+    const int n = s_ncand;
+    const unsigned lin = bx + ((hw + 255u) / 256u) * ((unsigned)d + 2u * (unsigned)b);
+    if ((int)(threadIdx.x & ~63u) >= n) return;  // (whole waves without work leave; the ballots of aa_append see whole waves)
+    AaRec rec;
+    bool emit = false;
+    if ((int)threadIdx.x < n) {
+        const unsigned c = s_cand[threadIdx.x];
+        const int y = (int)(c >> 16), x = (int)(c & 0xFFFFu);
+        emit = aa_pair_record(a, (long long)b * hw + (unsigned)y * (unsigned)a.W + (unsigned)x, b, x, y, d, rec);
+    }
+    aa_append(a, emit, rec, (int)(lin & (AA_SHARDS - 1)));
 }
 
 __global__ __launch_bounds__(256) void aa_analyze_kernel(AaAnalyzeJob a) { aa_analyze_body(a, blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
