@@ -22,7 +22,7 @@ SIGNATURES = {
     "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
     "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p,
-                                _c_int, _c_int, _c_int, _p]),
+                                _c_int, _c_int, _c_int, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p]),
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _c_int, _p]),
@@ -86,7 +86,7 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 307  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 308  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

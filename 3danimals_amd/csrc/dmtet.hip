@@ -404,9 +404,23 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              int* __restrict__ tri32, int* __restrict__ topo_cnt, int wg_per_block,
                                                              int* __restrict__ topo_adj, int topo_stride, int F,
                                                              const int* __restrict__ elist, const int* __restrict__ tlist, int n_eblocks,
-                                                             int n_tblocks, int nvc) {
+                                                             int n_tblocks, int nvc, const int* __restrict__ dev_counts, int cap_V,
+                                                             int cap_F, int cap_surf) {
     __shared__ int s_pre[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // SPECULATIVE launch (dev_counts = the counts of a3d_dmtet_count, still on the device: the host has not read them yet and sized
+    // buffers and grid by a guess): the sizes come from there; if anything does not fit, NO work-group touches anything and the host,
+    // which sees the same numbers a moment later, launches again with exact sizes.  n_eblocks / n_tblocks then are the capacities the
+    // grid was sized for.
+    int live_e = n_eblocks, live_t = n_tblocks;
+    if (dev_counts) {
+        const int dV = dev_counts[0], d1 = dev_counts[1], d2 = dev_counts[2], dS = dev_counts[3], dE = dev_counts[4], dT = dev_counts[5];
+        if (dV > cap_V || d1 + 2 * d2 > cap_F || (vbits && dS > cap_surf) || dE < 0 || dE > n_eblocks || dT > n_tblocks) return;
+        n1 = d1;
+        F = d1 + 2 * d2;
+        live_e = dE;
+        live_t = (d1 + d2) > 0 ? dT : 0;
+    }
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
     for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
     // wg_per_block = 4: one SLAB (256 items) per work-group -- a slab is a chain of three dependent gathers (bit planes -> index row ->
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
     const int set = blockIdx.x / wg_per_block;
     const bool is_edge = set < n_eblocks;
+    if (is_edge ? set >= live_e : set - n_eblocks >= live_t) return;  // (speculative launch: sets past the listed blocks)
     const int blk = is_edge ? (elist ? elist[set] : set) : nbe + (tlist ? tlist[set - n_eblocks] : set - n_eblocks);
     const int slab0 = (blockIdx.x % wg_per_block) * (DM_SLABS / wg_per_block), slab1 = slab0 + DM_SLABS / wg_per_block;
     if (is_edge) {
@@ -652,8 +667,11 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                               void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
                               int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
-                              int n_edge_blocks_listed, int n_tet_blocks_listed, a3d_stream_t stream) {
+                              int n_edge_blocks_listed, int n_tet_blocks_listed, const int32_t* device_counts_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
+    const bool spec = device_counts_or_null != nullptr;  // V, n1 (= F), n_surf, n_*_blocks_listed are CAPACITIES; n2 is ignored
+    A3D_CHECK_ARG(!spec || (n_edge_blocks_listed >= 0 && n_tet_blocks_listed >= 0 && V > 0));
+    if (spec) n2 = 0;
     A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
@@ -669,6 +687,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     dm_split_scratch((void*)scratch, Ne, Nt, &d);
     unsigned* vbits = (unsigned*)vertex_scratch_or_null;
     const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
+    const int cap_F = n1 + 2 * n2;
     const int nbt = (n1 + n2) > 0 ? d.nbt : 0;
     // counts[4], counts[5] of a3d_dmtet_count: the non-empty blocks its culled pass listed in the scratch (-1: none listed)
     const bool listed = n_edge_blocks_listed >= 0 && n_tet_blocks_listed >= 0;
@@ -681,7 +700,8 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
                        Ne, Nt, d.nbe, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, n1, verts, vert_edge, (long long*)faces,
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
                        g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb, topo_adj_or_null,
-                       topo_stride, n1 + 2 * n2, listed ? (const int*)d.elist : nullptr, listed ? (const int*)d.tlist : nullptr, ne, nt, nvc);
+                       topo_stride, n1 + 2 * n2, listed ? (const int*)d.elist : nullptr, listed ? (const int*)d.tlist : nullptr, ne, nt, nvc,
+                       device_counts_or_null, V, cap_F, n_surf);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -158,6 +158,7 @@ def _topology_sets(dev, F, V):
 DMTET_CULL_MIN_VERTS = 1 << 17
 DMTET_EMIT_LISTS = os.environ.get("A3D_EMIT_LISTS", "1") != "0"  # the emit launch writes the vertex -> face lists itself (no finalize launch)
 DMTET_EMIT_LISTS_MAX_STRIDE = 32
+DMTET_SPECULATIVE_EMIT = os.environ.get("A3D_SPECULATIVE_EMIT", "1") != "0"  # the emit launch enqueued before the counts read-back (sizes guessed from the last extraction)
 _dm_vertex_scratch = {}
 _dm_grad_buffers = _IdentityCache(maxsize=2)  # vert_edge of an extraction -> its cleared SDF gradient buffer
 
@@ -197,52 +198,84 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
          ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), 0 if counters is None else counters.shape[0],
          stream())
+    def alloc(Vn, Fn, n_surf_n):
+        return (torch.empty((Vn, 3), dtype=torch.float32, device=dev), torch.empty((Vn,), dtype=torch.int32, device=dev),
+                torch.empty((Fn, 3), dtype=torch.int64, device=dev), torch.empty((Fn, 3), dtype=torch.int64, device=dev),
+                torch.empty((n_surf_n,), dtype=torch.int64, device=dev) if surface_vertices else None)
+
+    g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
+    # SPECULATIVE emit: with the numbers of the previous extraction on this grid as a guess (+25 %), the emit launch is enqueued BEFORE
+    # the host reads the counts -- the kernel takes the true sizes from the device, the GPU does not idle across the read-back, and the
+    # host's wait overlaps the launch.  If anything outgrew its capacity the launch left every buffer untouched and the exact path
+    # below runs as if nothing had happened.
+    spec = None
+    last = getattr(grid, "_last_counts", None)
+    if DMTET_SPECULATIVE_EMIT and last is not None and groups is not None and counters is not None and stride > 0:
+        cap = lambda n, unit: max(unit, -(-int(1.25 * n) // unit) * unit)
+        nbe, nbt = -(-Ne // 1024), -(-Nt // 1024)
+        capV, capF, capS = min(cap(last[0], 256), counters.shape[0]), cap(last[1] + 2 * last[2], 256), cap(last[3], 256)
+        capE, capT = min(cap(last[4], 16), nbe), min(cap(last[5], 16), nbt)
+        if last[0] > 0 and last[1] + last[2] > 0 and last[4] >= 0 and capV * stride < 2 ** 31:
+            bufs = alloc(capV, capF, capS)
+            tri32_b = torch.empty((capF, 3), dtype=torch.int32, device=dev)
+            adj_b = torch.empty(capV * stride, dtype=torch.int32, device=dev)
+            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), capV, capF, 0, ptr(bufs[0]),
+                 ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(vscratch), Nv, capS if surface_vertices else 0, ptr(bufs[4]), ptr(g_sdf), ptr(tri32_b),
+                 ptr(counters), ptr(adj_b), stride, capE, capT, ptr(counts), stream())
+            spec = (capV, capF, capS, capE, capT, bufs, tri32_b, adj_b)
     # the one host sync of DMTet (the reference syncs here too, dmtet.py:110); listed_*: how many non-empty blocks the culled count
     # pass listed for the emit launch (-1: none listed)
     V, n1, n2, n_surf, listed_e, listed_t = counts.tolist()
     F = n1 + 2 * n2
+    grid._last_counts = (V, n1, n2, n_surf, listed_e, listed_t)
     if counters is not None:
         grid._last_surface_vertices = V
-    verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
-    vert_edge = torch.empty((V,), dtype=torch.int32, device=dev)
-    faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
-    uv_idx = torch.empty((F, 3), dtype=torch.int64, device=dev)
-    idx = torch.empty((n_surf,), dtype=torch.int64, device=dev) if surface_vertices else None
-    g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
-    emit_lists = counters is not None and F > 0 and 0 < V <= counters.shape[0] and V * stride < 2 ** 31
-    # fallback (the guess at V was too small, or a grid with very many tets around an edge): the emit launch only counts the valences and
-    # ONE more launch (a3d_mesh_topology_finalize) scans them and fills CSR lists -- instead of the conversion kernel + the four
-    # launches of a3d_mesh_topology on first use
-    topo = None
-    if not emit_lists and DMTET_TOPOLOGY and F > 0 and 0 < V <= _lib.lib().a3d_mesh_topology_finalize_max_vertices():
-        topo = _topology_sets(dev, F, V)
-    tri32 = cur = nxt = lists_adj = None
-    if topo is not None:
-        cur, nxt = topo["sets"][topo["cur"]], topo["sets"][1 - topo["cur"]]
-    if emit_lists:
-        cur, lists_adj = counters, torch.empty(V * stride, dtype=torch.int32, device=dev)
-    if cur is not None:
-        tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
-    try:
-        call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
-             ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
-             ptr(cur), ptr(lists_adj), stride if emit_lists else 0, listed_e, listed_t, stream())
-        adj = None
+    if spec is not None and V > 0 and F > 0 and V <= spec[0] and F <= spec[1] and (not surface_vertices or n_surf <= spec[2]) \
+            and 0 <= listed_e <= spec[3] and listed_t <= spec[4]:
+        bufs, tri32_b, adj_b = spec[5], spec[6], spec[7]
+        verts, vert_edge, faces, uv_idx = bufs[0][:V], bufs[1][:V], bufs[2][:F], bufs[3][:F]
+        idx = bufs[4][:n_surf] if surface_vertices else None
+        tri32 = tri32_b[:F]
+        adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, adj_b, stride))
+        _adj_cache.put(tri32, adj)
+        _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
+        _tri32_cache.put(faces, tri32)
+    else:
+        verts, vert_edge, faces, uv_idx, idx = alloc(V, F, n_surf)
+        emit_lists = counters is not None and F > 0 and 0 < V <= counters.shape[0] and V * stride < 2 ** 31
+        # fallback (the guess at V was too small, or a grid with very many tets around an edge): the emit launch only counts the valences
+        # and ONE more launch (a3d_mesh_topology_finalize) scans them and fills CSR lists -- instead of the conversion kernel + the four
+        # launches of a3d_mesh_topology on first use
+        topo = None
+        if not emit_lists and DMTET_TOPOLOGY and F > 0 and 0 < V <= _lib.lib().a3d_mesh_topology_finalize_max_vertices():
+            topo = _topology_sets(dev, F, V)
+        tri32 = cur = nxt = lists_adj = None
+        if topo is not None:
+            cur, nxt = topo["sets"][topo["cur"]], topo["sets"][1 - topo["cur"]]
         if emit_lists:
-            adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))
-        elif topo is not None:
-            adj = VertexFaceAdjacency(tri32, V, build=False)
-            adj.sorted = False
-            call("a3d_mesh_topology_finalize", ptr(tri32), V, F, ptr(cur), ptr(adj.off), ptr(adj.adj), ptr(nxt), topo["vcap"], stream())
-            topo["cur"] ^= 1
-        if adj is not None:
-            _adj_cache.put(tri32, adj)
-            _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
-            _tri32_cache.put(faces, tri32)
-    except Exception:
-        if topo is not None:  # a half-used scratch pair must not be taken for clean
-            _topo_sets.pop(topo["key"], None)
-        raise
+            cur, lists_adj = counters, torch.empty(V * stride, dtype=torch.int32, device=dev)
+        if cur is not None:
+            tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
+        try:
+            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
+                 ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
+                 ptr(cur), ptr(lists_adj), stride if emit_lists else 0, listed_e, listed_t, None, stream())
+            adj = None
+            if emit_lists:
+                adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))
+            elif topo is not None:
+                adj = VertexFaceAdjacency(tri32, V, build=False)
+                adj.sorted = False
+                call("a3d_mesh_topology_finalize", ptr(tri32), V, F, ptr(cur), ptr(adj.off), ptr(adj.adj), ptr(nxt), topo["vcap"], stream())
+                topo["cur"] ^= 1
+            if adj is not None:
+                _adj_cache.put(tri32, adj)
+                _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
+                _tri32_cache.put(faces, tri32)
+        except Exception:
+            if topo is not None:  # a half-used scratch pair must not be taken for clean
+                _topo_sets.pop(topo["key"], None)
+            raise
     if g_sdf is not None:
         _dm_grad_buffers.put(vert_edge, g_sdf)
     if not surface_vertices:

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 307 = this header */
+int a3d_version(void); /* 308 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -75,10 +75,15 @@ int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, con
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
                    int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
-                   int n_edge_blocks_listed, int n_tet_blocks_listed, a3d_stream_t stream);
+                   int n_edge_blocks_listed, int n_tet_blocks_listed, const int32_t* device_counts_or_null, a3d_stream_t stream);
 /* n_*_blocks_listed = counts[4], counts[5] of the a3d_dmtet_count call that filled `scratch`: with the culled count pass (word groups)
  * the blocks that hold a crossing edge / a surface tet are listed there and the emit launch covers those alone (~5 % of the grid's
- * blocks); -1, -1 (what the plain count pass reports) = every block. */
+ * blocks); -1, -1 (what the plain count pass reports) = every block.
+ * device_counts != NULL: a SPECULATIVE call, made before the host has read `counts` -- the GPU does not idle across the read-back.
+ * V, n1 (read as F), n_surf and the two listed counts then are CAPACITIES (of the output buffers / of the launch, e.g. the previous
+ * extraction's numbers + 25 %), n2 is ignored, and the kernel takes the true numbers from device_counts (= `counts` of the count call on
+ * the same stream).  If any of them exceeds its capacity the launch leaves every buffer untouched: the caller compares the counts it
+ * reads back with the capacities and, in that case, calls again with exact sizes. */
 /* tri32 / topo_count (both or none): the emit launch also writes the int32 copy of faces that the render kernels read and counts the
  * valences of the surface vertices (topo_count[>= V], zero on entry) -- the first step of the mesh topology, which
  * a3d_mesh_topology_finalize completes in one launch (the stand-alone a3d_mesh_topology needs four).

@@ -1189,6 +1189,36 @@ def test_render_mesh_takes_the_pending_normals_into_the_rasteriser_launch(dev, o
     np.testing.assert_allclose(g_ride.cpu().numpy(), g_alone.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(g_alone.abs().max()))
 
 
+def test_speculative_dmtet_emit_equals_the_exact_one(dev, ops, mods, monkeypatch):
+    """ops.dmtet_extract enqueues the emit launch BEFORE the host has read the counts, with buffers and grid sized by the previous
+    extraction on the grid + 25 %; the kernel takes the true sizes from the device.  A sequence of surfaces that shrink, grow slowly,
+    outgrow the guess (the launch must then leave everything untouched and the exact path take over), vanish and come back: every output
+    equal to the exact path's, bit for bit, and the mesh topology usable either way."""
+    monkeypatch.setattr(ops, "DMTET_CULL_MIN_VERTS", 0)
+    pos, tets = kuhn(40)
+    pos_d = pos.to(dev)
+    T = mods["dmtet"].TetGridTopology
+    spec_topo, exact_topo = T(tets.to(dev)), T(tets.to(dev))
+    radii = (2.0, 1.9, 2.1, 1.2, 3.1, 3.0, -1.0, 2.5, 2.45)  # (-1: no surface at all)
+    took = []
+    for trial, r in enumerate(radii):
+        sdf = (r - pos.norm(dim=-1) + 0.05 * seeded((pos.shape[0],), 90 + trial, -1, 1)).to(dev)
+        monkeypatch.setattr(ops, "DMTET_SPECULATIVE_EMIT", True)
+        a = ops.dmtet_extract(pos_d, sdf, spec_topo, surface_vertices=True)
+        tri_a = ops._tri32_cache.peek(a[1]) if a[1].shape[0] else None
+        monkeypatch.setattr(ops, "DMTET_SPECULATIVE_EMIT", False)
+        b = ops.dmtet_extract(pos_d, sdf, exact_topo, surface_vertices=True)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y), (trial, r)
+        took.append(a[0].shape[0] > 0 and a[0].untyped_storage().nbytes() > a[0].numel() * 4)  # a view into a larger buffer = speculative
+        if a[1].shape[0]:
+            n_a = ops.vertex_normals(a[0][None], a[1])
+            n_b = ops.vertex_normals(b[0][None], b[1])
+            assert torch.equal(n_a, n_b) and tri_a is not None and torch.equal(tri_a.long(), a[1])
+    # first extraction: no guess; 1, 2, 3: within the guess; 4: outgrown; 5: fits again; 6: empty; 7: the guess was an empty mesh; 8: fits
+    assert took == [False, True, True, True, False, True, False, False, True], took
+
+
 @pytest.mark.parametrize("grid", ["kuhn20", "bcc", "delaunay"])
 def test_emitted_vertex_face_lists_never_overflow_their_stride_even_on_noise(grid, dev, ops, mods):
     """The fixed-stride lists of the DMTet emit rest on a bound: a surface vertex sits on a grid edge, every tet around that edge gives
@@ -1272,7 +1302,7 @@ def test_topology_built_inside_the_dmtet_extraction_equals_the_stand_alone_one(g
         if adj.stride:  # written by the emit launch itself: list v = adj[v * stride ..], off[v] = its length; the grid bounds the valence
             assert adj.stride == topo.face_list_stride() and adj.stride >= int(np.diff(ref_off).max())
             assert np.array_equal(adj.off[:V].cpu().numpy(), np.diff(ref_off))
-            slots = adj.adj.cpu().numpy().reshape(V, adj.stride)
+            slots = adj.adj[: V * adj.stride].cpu().numpy().reshape(V, adj.stride)  # (a speculative emit sized the buffer by a guess at V)
             a = np.concatenate([slots[v, : ref_off[v + 1] - ref_off[v]] for v in range(V)])
         else:  # valence counts from the emit launch, offsets + lists from ONE finalize launch (CSR)
             assert torch.equal(adj.off, ref_adj.off)
