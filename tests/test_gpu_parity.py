@@ -1189,6 +1189,59 @@ def test_render_mesh_takes_the_pending_normals_into_the_rasteriser_launch(dev, o
     np.testing.assert_allclose(g_ride.cpu().numpy(), g_alone.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(g_alone.abs().max()))
 
 
+@pytest.mark.parametrize("seed,B,hw,res,zoom", [(0, 1, (64, 64), 12, 1.0), (1, 3, (40, 72), 16, 1.0), (2, 2, (128, 96), 20, 1.0), (3, 5, (24, 24), 12, 1.0),
+                                                (4, 2, (30, 50), 16, 3.5), (5, 4, (256, 256), 28, 1.6), (6, 1, (8, 8), 8, 1.0)])
+def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(seed, B, hw, res, zoom, dev, ops, mods, monkeypatch):
+    """SDF -> DMTet -> make_mesh -> render_mesh -> loss -> backward, three consecutive frames of a moving surface, with everything this
+    round folded into other launches switched ON (culled count, lists from the emit launch, speculative emit, normals in the rasteriser
+    launch, covered-pixel list with the G-buffer, the analysis in the compositor, fused compositor) against everything OFF (the modular
+    entry points one by one).  Same meshes bit for bit, same images up to the antialiasing's blend order, same gradients on the SDF and
+    the pose offsets up to the order of the float atomics -- whatever the batch, the image shape (incl. no multiple of 8, and a surface
+    that reaches far outside the frustum: zoom) and the grid."""
+    M, R, D = mods["mesh"], mods["render"], mods["dmtet"]
+    H, W = hw
+    pos, tets = kuhn(res)
+    pos_d = pos.to(dev)
+    centre, ext = pos.mean(0), float((pos.amax(0) - pos.amin(0)).max())
+    synthetic = importlib.import_module("3danimals_amd.synthetic")
+    mvp, w2c, campos = (t.to(dev) for t in synthetic.random_cameras(B, seed=seed))
+    switches = [(ops, "DMTET_CULL_MIN_VERTS", 0, 1 << 30), (ops, "DMTET_EMIT_LISTS", True, False), (ops, "DMTET_SPECULATIVE_EMIT", True, False),
+                (ops, "DMTET_TOPOLOGY", True, False), (M, "RIDE_NORMALS", True, False), (R, "FUSED_COVER_GBUFFER", True, False),
+                (R, "DEFER_ANALYSIS", True, False), (R, "FUSED_COMPOSITE", True, False)]
+
+    def run(on):
+        for mod, name, a, b in switches:
+            monkeypatch.setattr(mod, name, a if on else b)
+        grid = D.TetGridTopology(tets.to(dev))
+        frames = []
+        for t in range(3):
+            sdf = ((0.30 + 0.04 * t) * ext - (pos - centre).norm(dim=-1) + 0.03 * ext * seeded((pos.shape[0],), 50 + seed, -1, 1)).to(dev).requires_grad_(True)
+            verts, faces, uv_idx = ops.dmtet(pos_d, sdf, grid)
+            V = verts.shape[0]
+            offs = (0.02 * ext * seeded((B, V, 3), 60 + seed + t, -1, 1)).to(dev).requires_grad_(True)
+            posed = (verts[None] - centre.to(dev)) * (2.0 * zoom / ext) + offs
+            uvs = torch.zeros(1, 4, 2, device=dev)
+            uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+            prior = M.make_mesh(((verts[None] - centre.to(dev)) * (2.0 * zoom / ext)), faces[None], uvs, uvi, None)
+            shape = M.make_mesh(posed, faces[None], uvs.expand(B, -1, -1), uvi, None)
+            out = R.render_mesh(None, shape, mvp, w2c, campos, None, None, (H, W), bsdf="diffuse", render_modes=["shaded", "geo_normal"],
+                                prior_mesh=prior)
+            loss = sum((o * seeded(tuple(o.shape), 70 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out))
+            g_sdf, g_offs = torch.autograd.grad(loss, [sdf, offs])
+            frames.append((verts.detach(), faces, [o.detach() for o in out], g_sdf, g_offs))
+        return frames
+
+    a, b = run(True), run(False)
+    for t, (fa, fb) in enumerate(zip(a, b)):
+        assert fa[1].shape[0] > 50 and torch.equal(fa[0], fb[0]) and torch.equal(fa[1], fb[1]), t
+        for x, y in zip(fa[2], fb[2]):
+            assert float((x - y).abs().max()) <= 5e-7, (t, float((x - y).abs().max()))
+        for x, y in zip(fa[3:], fb[3:]):
+            scale = float(y.abs().max())
+            assert scale > 0
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5 * scale)
+
+
 def test_speculative_dmtet_emit_equals_the_exact_one(dev, ops, mods, monkeypatch):
     """ops.dmtet_extract enqueues the emit launch BEFORE the host has read the counts, with buffers and grid sized by the previous
     extraction on the grid + 25 %; the kernel takes the true sizes from the device.  A sequence of surfaces that shrink, grow slowly,
