@@ -292,16 +292,56 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
 // three work-groups, one per block-sum array: in-place exclusive scan, totals to counts[0..2].  With the count pass's wlocal (crossings
 // of the same block before a 64-edge word) a surface vertex id is blk_e[e >> 10] + wlocal[e >> 6] + popcount(edge_bits[e >> 6] below
 // bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
+#define DM_SCAN_LDS 24576  // block sums a scan work-group stages through LDS (96 KB of the CU's 160)
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts, const unsigned* __restrict__ vbits,
                                                        int* __restrict__ vchunk, int nvc, int* __restrict__ clear, int n_clear,
                                                        const int* __restrict__ list_len) {
     __shared__ int s_wave[16];
+    __shared__ int s_arr[DM_SCAN_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int which = blockIdx.x;
     // the valence counters of the mesh this extraction is about to emit (a3d_dmtet_emit: topo_count), zeroed here: no memset launch
     for (int z = blockIdx.x * 1024 + tid; z < n_clear; z += gridDim.x * 1024) clear[z] = 0;
     if (which == 3) {  // surface-adjacent grid vertices: bits per 1024-vertex chunk (32 words), exclusive prefix over the chunks -> counts[3]
+        if (nvc <= DM_SCAN_LDS) {
+            // the plane is read with consecutive lanes on consecutive 16 bytes (eight lanes = one chunk, their popcounts met through
+            // shuffles) and the chunk counts scanned in LDS.  One thread per chunk run -- lanes 384 bytes apart at R = 128 -- made every
+            // load instruction 64 separate lines, and this single work-group the slowest of the launch: 12 of the scan's 13 us there
+            const uint4* plane = reinterpret_cast<const uint4*>(vbits);
+            const int n16 = nvc * 8;
+            for (int i0 = tid; i0 < n16; i0 += 8 * 1024) {
+                uint4 x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = plane[i0 + 1024 * k < n16 ? i0 + 1024 * k : i0];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int c = __popc(x[k].x) + __popc(x[k].y) + __popc(x[k].z) + __popc(x[k].w);
+                    c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+                    if ((lane & 7) == 0 && i0 + 1024 * k < n16) s_arr[(i0 + 1024 * k) >> 3] = c;
+                }
+            }
+            __syncthreads();
+            const int per = ((nvc + 1023) / 1024) | 1;
+            const int lo = min(tid * per, nvc), hi = min(lo + per, nvc);
+            int mine = 0;
+            for (int i = lo; i < hi; ++i) mine += s_arr[i];
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            int run = incl - mine;
+            for (int w = 0; w < wave; ++w) run += s_wave[w];
+            for (int i = lo; i < hi; ++i) { const int v = s_arr[i]; s_arr[i] = run; run += v; }
+            __syncthreads();
+            for (int i = tid; i < nvc; i += 1024) vchunk[i] = s_arr[i];
+            if (tid == 1023) counts[3] = run;
+            return;
+        }
         const int per = (nvc + 1023) / 1024;
         const int lo = min(tid * per, nvc), hi = min(lo + per, nvc);
         for (int c = lo; c < hi; ++c) {
@@ -329,10 +369,26 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
     int* arr = which == 0 ? blk_e : (which == 1 ? blk_t1 : blk_t2);
     const int n = which == 0 ? nbe : nbt;
     // every thread owns a contiguous run of ceil(n / 1024) block sums: one pass, one barrier (a loop over 1024-element slabs with
-    // three barriers each cost 19 us at n = 1.5e4, the R = 128 grid)
-    const int per = (n + 1023) / 1024;
+    // three barriers each cost 19 us at n = 1.5e4, the R = 128 grid).  Up to DM_SCAN_LDS sums the array goes through LDS: read and
+    // written back with coalesced accesses, eight in flight per thread -- the runs themselves, read from memory, are 60-byte strides
+    // between lanes and, at 15 elements per run, eight dependent round trips (13.8 us of the R = 128 count call)
+    const bool staged = n <= DM_SCAN_LDS;
+    if (staged) {
+        for (int i0 = tid; i0 < n; i0 += 8 * 1024) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = arr[i0 + 1024 * k < n ? i0 + 1024 * k : i0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + 1024 * k < n) s_arr[i0 + 1024 * k] = v[k];
+        }
+        __syncthreads();
+    }
+    const int per = staged ? (((n + 1023) / 1024) | 1) : (n + 1023) / 1024;  // (odd: the runs of consecutive lanes start in different banks)
     const int lo = min(tid * per, n), hi = min(lo + per, n);
-    const int mine = a3d_run_sum(arr, lo, hi);
+    int mine = 0;
+    if (staged) for (int i = lo; i < hi; ++i) mine += s_arr[i];
+    else mine = a3d_run_sum(arr, lo, hi);
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -343,7 +399,17 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
     __syncthreads();
     int run = incl - mine;
     for (int w = 0; w < wave; ++w) run += s_wave[w];
-    run = a3d_run_scan<false>(arr, arr, lo, hi, run);
+    if (staged) {
+        for (int i = lo; i < hi; ++i) { const int v = s_arr[i]; s_arr[i] = run; run += v; }
+        __syncthreads();
+        for (int i0 = tid; i0 < n; i0 += 8 * 1024) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + 1024 * k < n) arr[i0 + 1024 * k] = s_arr[i0 + 1024 * k];
+        }
+    } else {
+        run = a3d_run_scan<false>(arr, arr, lo, hi, run);
+    }
     if (tid == 1023) {
         counts[which] = run;
         if (which == 0 && !vbits) counts[3] = 0;

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--res", type=int, nargs="+", default=[64, 128])
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--surf", action="store_true")
     ap.add_argument("--sdf", default="quadruped", choices=["quadruped", "ellipsoid", "none", "noise"])
     args = ap.parse_args()
     a3d = importlib.import_module("3danimals_amd")
@@ -53,13 +54,15 @@ def main():
         scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
         counts = torch.empty(6, dtype=torch.int32, device=dev)
         groups = topo.word_groups()
+        # --surf: with the bit plane of the surface-adjacent grid vertices (the count call's fourth scan work-group), as the training step
+        vscratch = torch.zeros(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev) if args.surf else None
         for label, gr in (("plain", None), ("culled", groups)):
             if label == "culled" and gr is None:
                 continue
 
             def run():
-                ops.call("a3d_dmtet_count", ops.ptr(sdf), ops.ptr(topo.edges32), ops.ptr(topo.tets32), Ne, Nt, ops.ptr(scratch), ops.ptr(counts), None, 0,
-                         Nv, ops.ptr(gr[0]) if gr else None, ops.ptr(gr[1]) if gr else None, None, 0, ops.stream())
+                ops.call("a3d_dmtet_count", ops.ptr(sdf), ops.ptr(topo.edges32), ops.ptr(topo.tets32), Ne, Nt, ops.ptr(scratch), ops.ptr(counts),
+                         ops.ptr(vscratch), 1, Nv, ops.ptr(gr[0]) if gr else None, ops.ptr(gr[1]) if gr else None, None, 0, ops.stream())
 
             for _ in range(5):
                 run()
