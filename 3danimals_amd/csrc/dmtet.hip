@@ -81,6 +81,20 @@ __global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ 
 // index row for a tet or edge that is not on the surface (~1 % are): edge_bits[word] = crossing flags of 64 consecutive edges,
 // tet_bits[word*4 + j] = bit j of the marching-tets case of 64 consecutive tets.
 //
+// Flags of the grid vertices at the ends of crossing edges (the only ones the surface's gradient reaches), one bit per vertex.  Straight
+// into the plane every crossing edge is two device atomics, and a word of the plane -- 32 neighbouring vertices, each on ~7 crossing
+// edges -- takes dozens of them: same-address atomics serialise at the memory side, and in the culled pass, where the few blocks
+// that hold crossings ARE the critical path, draining them was a third of the kernel (R = 64: 8.4 us without the plane, 12.6 with).
+// A work-group therefore ORs into a window of the plane kept in LDS (edges are sorted by their first vertex: a block's vertices start
+// at its first edge's and span about one grid layer) and flushes the non-zero words once per block; what falls outside the window
+// (irregular grids) goes to the plane directly.
+#define DM_VWIN 1024  // words: 32k vertices
+__device__ __forceinline__ void dm_flag_vertex(unsigned* __restrict__ vbits, unsigned* s_vwin, int vbase, int v) {
+    const unsigned w = (unsigned)((v >> 5) - vbase);
+    if (s_vwin && w < (unsigned)DM_VWIN) atomicOr(s_vwin + w, 1u << (v & 31));
+    else atomicOr(vbits + (v >> 5), 1u << (v & 31));
+}
+
 // One 1024-item block (16 words; wave w owns the words k*4 + w).  ``skip`` (wave-uniform): bit k set = word k of this wave is known to
 // hold no crossing (dm_count_cull_kernel below) -- its index rows are not loaded, its bits are written as zeros.
 template <bool BITS>
@@ -89,10 +103,12 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
                                                int* __restrict__ blk_t1, int* __restrict__ blk_t2, unsigned long long* __restrict__ edge_bits,
                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
                                                unsigned* __restrict__ vbits, int (*s_cnt)[DM_THREADS / A3D_WAVE], int* s_pc,
-                                               int* __restrict__ list_len = nullptr, int* __restrict__ list = nullptr) {
+                                               int* __restrict__ list_len = nullptr, int* __restrict__ list = nullptr,
+                                               unsigned* s_vwin = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
     const long long base = (long long)blk * DM_BLOCK_ITEMS;
+    const int vbase = (is_edge && vbits && s_vwin) ? (edges[base < Ne ? base : 0].x >> 5) : 0;  // (uniform; in flight with the rows below)
     if (!BITS) {
         // SDF values gathered directly (grids below DM_SIGN_PLANE_MIN_NV vertices): row by row -- the pass is bound by the ~1e7 4-byte
         // gathers (TA line rate), and more of them in flight per lane only made it slower (17.7 -> 22 us at R = 64)
@@ -102,9 +118,9 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
                 long long i = base + k * DM_THREADS + tid;
                 const int2 e = i < Ne ? edges[i] : make_int2(0, 0);
                 const bool f = i < Ne && dm_edge_cross<false>(sdf, e);
-                if (f && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
-                    atomicOr(vbits + (e.x >> 5), 1u << (e.x & 31));
-                    atomicOr(vbits + (e.y >> 5), 1u << (e.y & 31));
+                if (f && vbits) {
+                    dm_flag_vertex(vbits, s_vwin, vbase, e.x);
+                    dm_flag_vertex(vbits, s_vwin, vbase, e.y);
                 }
                 const unsigned long long m = __ballot(f);
                 if (lane == 0) {
@@ -143,9 +159,9 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
             f[k] = !((skip >> k) & 1u) && (base + k * DM_THREADS + tid) < Ne && dm_edge_cross<BITS>(sdf, e[k]);
 #pragma unroll
         for (int k = 0; k < DM_SLABS; ++k) {
-            if (f[k] && vbits) {  // the grid vertices at the ends of crossing edges: the only ones the surface's gradient reaches
-                atomicOr(vbits + (e[k].x >> 5), 1u << (e[k].x & 31));
-                atomicOr(vbits + (e[k].y >> 5), 1u << (e[k].y & 31));
+            if (f[k] && vbits) {
+                dm_flag_vertex(vbits, s_vwin, vbase, e[k].x);
+                dm_flag_vertex(vbits, s_vwin, vbase, e[k].y);
             }
             const unsigned long long m = __ballot(f[k]);
             if (lane == 0) {
@@ -178,6 +194,12 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
     }
     if (lane == 0) { s_cnt[0][wave] = c0; s_cnt[1][wave] = c1; }
     __syncthreads();
+    if (is_edge && vbits && s_vwin) {  // the window's non-zero words to the plane; left zeroed for the work-group's next block
+        for (int i = tid; i < DM_VWIN; i += DM_THREADS) {
+            const unsigned m = s_vwin[i];
+            if (m) { atomicOr(vbits + vbase + i, m); s_vwin[i] = 0u; }
+        }
+    }
     if (tid == 0) {
         int a = 0, b = 0;
         for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
@@ -232,6 +254,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
     __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
     __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
+    __shared__ unsigned s_vwin[DM_VWIN];
     constexpr int WPB = DM_BLOCK_ITEMS / 64, ROUNDS = (G * DM_SLABS * DM_CULL_SLOTS + 63) / 64;
     static_assert(DM_CULL_SLOTS == 8 && DM_SLABS == 4 && DM_THREADS == 256, "one byte of a ballot per word, one nibble of skip bits per block");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,6 +288,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
             if (((z >> (8 * b)) & 0xFFull) == 0xFFull || ((o >> (8 * b)) & 0xFFull) == 0xFFull) skip |= 1u << (8 * r + b);
     }
     if (lane < G) s_nib[lane][wave] = (skip >> (DM_SLABS * lane)) & 15u;
+    if (vbits && is_edge)
+        for (int i = tid; i < DM_VWIN; i += DM_THREADS) s_vwin[i] = 0u;
     __syncthreads();
     bool lds_used = false;
     for (int g = 0; g < G; ++g) {
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
         if (lds_used) __syncthreads();  // s_cnt / s_pc of the previous processed block consumed
         lds_used = true;
         dm_count_block<true>(sign, edges, tets, Ne, Nt, is_edge, blk, (skip >> (DM_SLABS * g)) & 15u, blk_e, blk_t1, blk_t2, edge_bits, tet_bits,
-                             wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist);
+                             wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist, s_vwin);
     }
 }
 
