@@ -39,6 +39,30 @@ DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhoue
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
+# Shading only the covered pixels makes the sizes of the networks' activations follow the silhouette ([P,256] rows: ~5 GB per step at
+# B = 16), where the reference's dense [B,H,W] inputs never change size.  The caching allocator keeps every block it ever handed out:
+# when P outgrows a bucket, the ~40 activation blocks of the old size are too small for the new requests and stay cached for good
+# -- measured on a steadily growing shape: 5.5 GB reserved after the first step, 208 GB after 1200, for 1 GB in use and a 10 GB peak
+# (tools/mem_growth.py).  So whenever a point count appears that no earlier step had, the cache is given back to the driver if it
+# exceeds ALLOCATOR_TRIM_RATIO x the peak of what was ever in use (a device synchronisation and a few hundred hipFree calls, at most
+# once per new size; 0 = never, env A3D_ALLOCATOR_TRIM_RATIO).
+ALLOCATOR_TRIM_RATIO = float(os.environ.get("A3D_ALLOCATOR_TRIM_RATIO", "3"))
+_point_counts_seen = set()
+
+
+def _trim_allocator_cache(n_points, device):
+    if ALLOCATOR_TRIM_RATIO <= 0 or n_points in _point_counts_seen or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return False
+    if len(_point_counts_seen) >= 4096:
+        _point_counts_seen.clear()
+    _point_counts_seen.add(n_points)
+    in_use_peak = max(torch.cuda.max_memory_allocated(device), 1 << 30)
+    if torch.cuda.memory_reserved(device) <= ALLOCATOR_TRIM_RATIO * in_use_peak:
+        return False
+    torch.cuda.empty_cache()
+    return True
+
+
 def interpolate(attr, rast, attr_idx, rast_db=None):
     """dr.interpolate wrapper of the reference (render.py:23-24): (values, None) -- or (values, pixel differentials of every attribute)
     when ``rast_db`` is given, which no caller on this path does."""
@@ -167,6 +191,7 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     # the GEMM shapes then repeat from step to step, which is what rocBLAS/hipBLASLt kernel selection and TunableOp key on.
     n_pts = pix.shape[0]
     n_pad = (-n_pts) % POINT_BUCKET if POINT_BUCKET else 0
+    _trim_allocator_cache(n_pts + n_pad, pix.device)
     if n_pad:
         img_p = torch.cat((img, img.new_full((n_pad,), b - 1)))  # padding rows ride with the last image: the index stays non-decreasing
         tex_in = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))

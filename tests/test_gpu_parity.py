@@ -754,6 +754,34 @@ def test_render_mesh_flow_and_empty_mesh_assert(dev, mods):
         mods["render"].render_mesh(None, empty, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), render_modes=["shaded"])
 
 
+def test_allocator_cache_is_given_back_when_new_point_counts_have_stranded_it(dev, mods, monkeypatch):
+    """Shading only the covered pixels makes the activation sizes follow the silhouette; every outgrown size strands its cached blocks
+    (tools/mem_growth.py: 208 GB reserved after 1200 steps of a growing shape).  render._trim_allocator_cache: a point count no earlier
+    step had + a cache above ALLOCATOR_TRIM_RATIO x the peak in use -> the cache goes back to the driver; a known count, a small cache
+    or ratio 0 -> nothing happens."""
+    R = mods["render"]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    monkeypatch.setattr(R, "_point_counts_seen", set())
+    base = torch.cuda.memory_reserved(dev)
+    for k in range(24):  # 24 blocks of growing size, each freed again: ~5 GB cached, < 1 GB ever in use at once
+        del_me = torch.empty((200 + 8 * k) << 20, dtype=torch.uint8, device=dev)
+        del del_me
+    stranded = torch.cuda.memory_reserved(dev) - base
+    assert stranded > 4 << 30
+    monkeypatch.setattr(R, "ALLOCATOR_TRIM_RATIO", 0.0)
+    assert not R._trim_allocator_cache(8192, dev) and torch.cuda.memory_reserved(dev) - base == stranded
+    monkeypatch.setattr(R, "ALLOCATOR_TRIM_RATIO", 3.0)
+    assert R._trim_allocator_cache(8192, dev)
+    assert torch.cuda.memory_reserved(dev) - base < 1 << 30
+    keep = torch.empty(5 << 30, dtype=torch.uint8, device=dev)  # in use, not cache: nothing to give back
+    assert not R._trim_allocator_cache(16384, dev)
+    del keep
+    assert not R._trim_allocator_cache(16384, dev)  # (a count seen before strands nothing new: not even looked at)
+    torch.cuda.empty_cache()
+
+
 def test_render_mesh_with_nothing_on_screen(dev, mods):
     """A mesh pushed entirely out of the frustum: no covered pixel (P = 0) through the fused path -- rasterise, covered-pixel list,
     G-buffer, shading, fused compositor -- forward returns the background with alpha 0 and the backward runs to zero gradients."""
