@@ -28,7 +28,6 @@
 #include "topo_common.h"
 #include "normals_common.h"
 
-#define RS_COOP_AREA 64  // boxes above this many pixels are rasterised by all 64 lanes of the wave
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 // the vertex-normals job that may ride in the triangle launch (a3d_rast_fwd: normals_*)
@@ -177,10 +176,13 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
             area = rs_box(p0, p1, p2, H, W, x0, y0, bw);
         }
     }
-    // Small boxes (<= RS_COOP_AREA candidates; a culled box may carry bw <= 0): the candidates of the wave's TPW triangles are POOLED and
-    // dealt out evenly over its 64 lanes.  (Each triangle's lanes walking their own box made the wave as slow as its largest box: ~10
-    // trips of the fragment test where the pooled form needs ceil(sum / 64); the fragment tests, not the atomics, were 11.6 of this
-    // kernel's 18.8 us.)  Triangle data and the prefix of the box sizes go through LDS, one slice per wave.
+    // The candidate pixels of the work-group's 256 / LPT triangles are POOLED and dealt out evenly over its 256 lanes (a culled box
+    // carries area 0).  (Each triangle's lanes walking their own box made a wave as slow as its largest box: ~10 trips of the fragment
+    // test where the pooled form needs ceil(sum / lanes); the fragment tests, not the atomics, were 11.6 of this kernel's 18.8 us.)
+    // Pooled per work-group, boxes of any size: per wave, with boxes above 64 pixels walked by the whole wave one after the other
+    // (with an integer division per pixel), a mesh that training had driven into spikes -- a few triangles of thousands of pixels,
+    // every tenth above 64 -- took the launch from 36 to 190 us; a 9000-pixel box is 35 trips of the work-group now, not 140 of a wave.
+    // Triangle data and the prefix of the box sizes go through LDS, one slice per wave.
     // LPT: the set-up (two dependent gathers + the box) is latency bound and wants many waves -- 4 lanes per triangle at B F = 1.9e5
     // (16.9 us against 22.1 with one) --, but is pure repetition once the waves suffice: one lane per triangle at B F = 7.7e5 (19.8 us
     // against 28.6 with four).
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     __shared__ int4 s_box[4][TPW];  // x0, y0, bw, f
     __shared__ int s_pre[4][TPW + 1];
     const int wv = threadIdx.x >> 6, q = lane / LPT;  // this wave's slice, this lane's triangle slot
-    const int small = (area > 0 && area <= RS_COOP_AREA) ? area : 0;
+    const int mine = area > 0 ? area : 0;
     if (sub == 0) {
         s_p[wv][q][0] = p0; s_p[wv][q][1] = p1; s_p[wv][q][2] = p2;
         s_box[wv][q] = make_int4(x0, y0, bw, f);
     }
     {   // inclusive scan of the TPW box sizes (held by the lanes LPT q)
-        int incl = small;
+        int incl = mine;
 #pragma unroll
         for (int d = LPT; d < 64; d <<= 1) {
             const int o = __shfl_up(incl, d, 64);
@@ -204,30 +206,24 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         if (lane == 0) s_pre[wv][0] = 0;
     }
     __syncthreads();
-    const int total = s_pre[wv][TPW];
-    for (int c = lane; c < total; c += 64) {
-        int j = 0;  // the triangle slot that owns candidate c: largest j with pre[j] <= c
+    // candidate c of the work-group: first the wave slice (three compares on the four totals), then the slot inside it
+    const int t0 = s_pre[0][TPW], t1 = t0 + s_pre[1][TPW], t2 = t1 + s_pre[2][TPW], total = t2 + s_pre[3][TPW];
+    for (int c = threadIdx.x; c < total; c += 256) {
+        const int w = c < t1 ? (c < t0 ? 0 : 1) : (c < t2 ? 2 : 3);
+        const int cw = c - (w == 0 ? 0 : (w == 1 ? t0 : (w == 2 ? t1 : t2)));
+        int j = 0;  // the triangle slot that owns the candidate: largest j with pre[j] <= cw
 #pragma unroll
         for (int step = TPW / 2; step > 0; step >>= 1)
-            if (s_pre[wv][j + step] <= c) j += step;
-        const int4 bx = s_box[wv][j];
-        const int i = c - s_pre[wv][j];
-        // i / bw for i < 64, bw <= 64: (i + 0.5) / bw is at least 1/128 away from an integer, 1 ulp of the reciprocal is irrelevant
-        const int cy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z)), cx = i - cy * bx.z;
-        rs_test_pixel(s_p[wv][j][0], s_p[wv][j][1], s_p[wv][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
-    }
-    // large boxes: one representative lane per triangle (sub == 0) votes, the whole wave walks the box
-    unsigned long long big = __ballot(area > RS_COOP_AREA && sub == 0);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        float4 c0, c1, c2;
-        c0.x = __shfl(p0.x, src); c0.y = __shfl(p0.y, src); c0.z = __shfl(p0.z, src); c0.w = __shfl(p0.w, src);
-        c1.x = __shfl(p1.x, src); c1.y = __shfl(p1.y, src); c1.z = __shfl(p1.z, src); c1.w = __shfl(p1.w, src);
-        c2.x = __shfl(p2.x, src); c2.y = __shfl(p2.y, src); c2.z = __shfl(p2.z, src); c2.w = __shfl(p2.w, src);
-        const int cx0 = __shfl(x0, src), cy0 = __shfl(y0, src), cbw = __shfl(bw, src), carea = __shfl(area, src);
-        const unsigned cf = (unsigned)__shfl(f, src);
-        for (int i = lane; i < carea; i += 64) rs_test_pixel(c0, c1, c2, cx0 + i % cbw, cy0 + i / cbw, W, xs, xo, ys, yo, cf, kb, pv);
+            if (s_pre[w][j + step] <= cw) j += step;
+        const int4 bx = s_box[w][j];
+        const int i = cw - s_pre[w][j];
+        // i / bw through the reciprocal: (i + 0.5) / bw is at least 0.5 / bw away from an integer and the product is off by ~2.4e-7 of
+        // its value (< area / bw): exact for every box below ~1e6 pixels; larger ones (whole frames of >= 1024^2) divide
+        int cy;
+        if (i < (1 << 20)) cy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z));
+        else cy = i / bx.z;
+        const int cx = i - cy * bx.z;
+        rs_test_pixel(s_p[w][j][0], s_p[w][j][1], s_p[w][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
     }
 }
 
