@@ -17,12 +17,14 @@ SIGNATURES = {
     "a3d_last_error": (ctypes.c_char_p, []),
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
     "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _p]),
+    "a3d_dmtet_count_ordered": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
     "a3d_dmtet_word_group_slots": (_c_int, []),
     "a3d_dmtet_word_group_bits": (_c_int, []),
     "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
     "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p,
                                 _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_dmtet_emit_sparse": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p]),
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _c_int, _p]),
@@ -86,7 +88,23 @@ SIGNATURES = {
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
 }
 
-ABI_VERSION = 308  # a3d_version() of the library these signatures belong to (include/a3d.h)
+
+
+class DmtetOrder(ctypes.Structure):
+    """a3d_dmtet_order of include/a3d.h (field for field; tests/test_host_cpu.py compares the two)."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("group_slots", ctypes.c_int32), ("vertex_of_rank", _p), ("edges_ranked", _p), ("edge_of_row", _p),
+                ("tets_ranked", _p), ("tet_of_row", _p), ("edge_groups", _p), ("tet_groups", _p)]
+
+
+class DmtetEmitOpts(ctypes.Structure):
+    """a3d_dmtet_emit_opts of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("Nv", ctypes.c_int32), ("vertex_scratch", _p), ("surf_idx", _p), ("g_sdf_to_clear", _p), ("tri32", _p),
+                ("topo_count", _p), ("topo_adj", _p), ("device_counts", _p), ("n_surf", ctypes.c_int32), ("topo_stride", ctypes.c_int32)]
+
+
+ABI_VERSION = 400  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

@@ -314,6 +314,129 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
     }
 }
 
+// ------------------------------------------------------------------------------------------------ count, grid in any numbering
+// A grid file written by an external mesher (the reference's data/tets/{128,256}_tets.npz, Quartet) numbers its vertices and orders its
+// rows without regard to space: 64 consecutive rows of `edges` / `tets` then touch ~70 / ~250 vertices anywhere in the grid, two words
+// in three hold a crossing, and the cull above has nothing to skip -- while the OUTPUT order (vertex = rank of its crossing edge in
+// the sorted list, faces in tet order) is defined by exactly that numbering.  So the signs are evaluated in an order of OUR choosing
+// and only the results are carried back:
+//   * static per grid (a3d_dmtet_order; model/geometry/dmtet.py: TetGridTopology.spatial_order): the vertices ranked along a Morton
+//     curve through their positions, the edge rows rewritten in ranks and sorted by (lower rank, higher rank), the tet rows rewritten
+//     in ranks (corner order kept: the case index depends on it) and sorted by their lowest rank, each row with the index of the
+//     row it came from, and the word-group tables of THOSE lists (16 slots: 92 % of the words of a scrambled BCC lattice skip);
+//   * dm_sign_order_kernel: one sign bit per RANK (sdf gathered through vertex_of_rank: Nv four-byte gathers), and the planes and
+//     block sums of the original order zeroed by the same launch;
+//   * dm_count_order_kernel: the cull over the ranked rows, wave by wave, no LDS, no barrier; a crossing edge / a surface tet (~1 % of
+//     the rows of the ~8 % of the words that are read at all) ORs its bit(s) into the plane of the ORIGINAL order at the row it came
+//     from and adds one to that row's block sum -- fire-and-forget atomics, about 2 V + 3 T of them;
+//   * the scan launch, as before, plus work-groups that leave wlocal (crossings of the same block before a word) from the finished
+//     edge plane, which the streaming pass gets from its ballots.
+// From there on (a3d_dmtet_emit) nothing differs: same planes (a tet with all four corners inside reads as case 0 instead of 15; both
+// mean "no triangle"), same prefixes, same output bits.
+__global__ __launch_bounds__(256) void dm_sign_order_kernel(const float* __restrict__ sdf, const int* __restrict__ vertex_of_rank, int Nv,
+                                                            unsigned long long* __restrict__ bits, uint4* __restrict__ clear,
+                                                            long long n_clear16) {
+    const int lane = threadIdx.x & 63;
+    const long long w0 = ((long long)blockIdx.x * (256 / 64) + (threadIdx.x >> 6)) * DM_SIGN_WORDS;  // first word of this wave
+    int v[DM_SIGN_WORDS];
+#pragma unroll
+    for (int j = 0; j < DM_SIGN_WORDS; ++j) {
+        const long long r = (w0 + j) * 64 + lane;
+        v[j] = vertex_of_rank[r < Nv ? r : 0];
+    }
+    for (long long z = (long long)blockIdx.x * 256 + threadIdx.x; z < n_clear16; z += (long long)gridDim.x * 256) clear[z] = make_uint4(0u, 0u, 0u, 0u);
+    float x[DM_SIGN_WORDS];
+#pragma unroll
+    for (int j = 0; j < DM_SIGN_WORDS; ++j) x[j] = sdf[v[j]];
+#pragma unroll
+    for (int j = 0; j < DM_SIGN_WORDS; ++j) {
+        const unsigned long long m = __ballot((w0 + j) * 64 + lane < Nv && x[j] > 0.f);
+        if (lane == 0 && (w0 + j) * 64 < Nv) bits[w0 + j] = m;
+    }
+}
+
+#define DM_ORDER_WORDS 16  // words per wave, strided over the list: the words that hold crossings come in runs (the surface)
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void dm_count_order_kernel(const unsigned* __restrict__ sign, const int2* __restrict__ edges_r,
+                                                             const int* __restrict__ edge_of_row, const int4* __restrict__ tets_r,
+                                                             const int* __restrict__ tet_of_row, const int* __restrict__ vertex_of_rank,
+                                                             int Ne, int Nt, int nwe, int nwt, int waves_e, int waves_t,
+                                                             const unsigned* __restrict__ edge_groups, const unsigned* __restrict__ tet_groups,
+                                                             int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
+                                                             unsigned long long* __restrict__ edge_bits,
+                                                             unsigned long long* __restrict__ tet_bits, unsigned* __restrict__ vbits) {
+    static_assert(SLOTS == 8 || SLOTS == 16, "group ids per word");
+    static_assert(DM_BLOCK_ITEMS == 1024, "block of a row = row >> 10");
+    constexpr int WPR = 64 / SLOTS, ROUNDS = DM_ORDER_WORDS / WPR;  // words per round of 64 lanes
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_g >= waves_e + waves_t) return;
+    const bool is_edge = wave_g < waves_e;
+    const int wv = is_edge ? wave_g : wave_g - waves_e, nwaves = is_edge ? waves_e : waves_t, nw = is_edge ? nwe : nwt;
+    const unsigned* __restrict__ groups = is_edge ? edge_groups : tet_groups;
+    // word q of this wave = q * nwaves + wv; entry = (word, slot): lane -> (q = lane / SLOTS + WPR r, slot = lane % SLOTS); all group
+    // ids in flight, then all sign fields (unconditional loads at a clamped index, select afterwards)
+    unsigned gid[ROUNDS], val[ROUNDS];
+    bool in[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long w = (long long)(lane / SLOTS + WPR * r) * nwaves + wv;
+        in[r] = w < nw;
+        gid[r] = groups[(in[r] ? w : (long long)wv) * SLOTS + (lane % SLOTS)];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const unsigned field = reinterpret_cast<const unsigned short*>(sign)[gid[r] != 0xFFFFFFFFu ? gid[r] : 0u];
+        val[r] = gid[r] != 0xFFFFFFFFu ? field : 1u;  // 1 = mixed
+    }
+    unsigned todo = 0;  // bit q: word q exists and may hold a crossing
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const unsigned long long z = __ballot(in[r] && val[r] == 0u), o = __ballot(in[r] && val[r] == 0xFFFFu), e = __ballot(in[r]);
+        constexpr unsigned long long M = SLOTS == 16 ? 0xFFFFull : 0xFFull;
+#pragma unroll
+        for (int b = 0; b < WPR; ++b) {
+            const bool all_out = ((z >> (SLOTS * b)) & M) == M, all_in = ((o >> (SLOTS * b)) & M) == M, exists = ((e >> (SLOTS * b)) & 1ull) != 0;
+            if (exists && !all_out && !all_in) todo |= 1u << (WPR * r + b);
+        }
+    }
+    while (todo) {  // (wave-uniform)
+        const int q = __ffs(todo) - 1;
+        todo &= todo - 1u;
+        const long long i = ((long long)q * nwaves + wv) * 64 + lane;
+        if (is_edge) {
+            const bool ok = i < Ne;
+            const int2 e = edges_r[ok ? i : 0];
+            const int orig = edge_of_row[ok ? i : 0];
+            if (ok && dm_edge_cross<true>(sign, e)) {
+                atomicOr(edge_bits + (orig >> 6), 1ull << (orig & 63));
+                atomicAdd(blk_e + (orig >> 10), 1);
+                if (vbits) {  // the grid vertices at the ends of crossing edges, in the numbering of the file
+                    const int a = vertex_of_rank[e.x], b = vertex_of_rank[e.y];
+                    atomicOr(vbits + (a >> 5), 1u << (a & 31));
+                    atomicOr(vbits + (b >> 5), 1u << (b & 31));
+                }
+            }
+        } else {
+            const bool ok = i < Nt;
+            const int4 t = tets_r[ok ? i : 0];
+            const int orig = tet_of_row[ok ? i : 0];
+            const int cs = ok ? dm_tet_case<true>(sign, t) : 0;
+            const unsigned n = DM_NTRI(cs);
+            if (n) {
+                unsigned long long* w = tet_bits + 4ll * (orig >> 6);
+                const unsigned long long bit = 1ull << (orig & 63);
+                if (cs & 1) atomicOr(w + 0, bit);
+                if (cs & 2) atomicOr(w + 1, bit);
+                if (cs & 4) atomicOr(w + 2, bit);
+                if (cs & 8) atomicOr(w + 3, bit);
+                atomicAdd((n == 1u ? blk_t1 : blk_t2) + (orig >> 10), 1);
+            }
+        }
+    }
+}
+
 // three work-groups, one per block-sum array: in-place exclusive scan, totals to counts[0..2].  With the count pass's wlocal (crossings
 // of the same block before a 64-edge word) a surface vertex id is blk_e[e >> 10] + wlocal[e >> 6] + popcount(edge_bits[e >> 6] below
 // bit e & 63): three small loads, no edge -> vertex table.  (Extending this scan to words here, 29k of them in one work-group, cost 22 us.)
@@ -321,13 +444,41 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
 __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2,
                                                        int nbe, int nbt, int* __restrict__ counts, const unsigned* __restrict__ vbits,
                                                        int* __restrict__ vchunk, int nvc, int* __restrict__ clear, int n_clear,
-                                                       const int* __restrict__ list_len) {
+                                                       const int* __restrict__ list_len, const unsigned long long* __restrict__ edge_bits,
+                                                       int* __restrict__ wlocal, int n_scans, const unsigned long long* __restrict__ tet_bits,
+                                                       int* __restrict__ tlocal) {
     __shared__ int s_wave[16];
     __shared__ int s_arr[DM_SCAN_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int which = blockIdx.x;
     // the valence counters of the mesh this extraction is about to emit (a3d_dmtet_emit: topo_count), zeroed here: no memset launch
     for (int z = blockIdx.x * 1024 + tid; z < n_clear; z += gridDim.x * 1024) clear[z] = 0;
+    if (which >= n_scans) {
+        // (ordered count pass only) wlocal from the finished edge plane: thread = word, the 16 words of a block = 16 neighbouring lanes
+        static_assert(DM_BLOCK_ITEMS / 64 == 16, "a block's words are one 16-lane row");
+        // and tlocal (one- / two-triangle tets of the same block before a word, 16 + 16 bits) from the tet planes
+        const int wg_e = (nbe * 16 + 1023) / 1024;
+        const bool is_edge = which - n_scans < wg_e;
+        const long long w = (long long)(which - n_scans - (is_edge ? 0 : wg_e)) * 1024 + tid;
+        int c = 0;
+        if (is_edge) {
+            if (w < (long long)nbe * 16) c = __popcll(edge_bits[w]);
+        } else if (w < (long long)nbt * 16) {
+            const ulonglong2 pa = reinterpret_cast<const ulonglong2*>(tet_bits)[2 * w], pb = reinterpret_cast<const ulonglong2*>(tet_bits)[2 * w + 1];
+            const unsigned long long odd = pa.x ^ pa.y ^ pb.x ^ pb.y;
+            c = __popcll(odd) | (__popcll(~odd & (pa.x | pa.y | pb.x | pb.y) & ~(pa.x & pa.y & pb.x & pb.y)) << 16);
+        }
+        int incl = c;  // (both halves at once: neither sum reaches 2^16)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int up = __shfl_up(incl, o, 16);
+            if ((lane & 15) >= o) incl += up;
+        }
+        if (is_edge) {
+            if (w < (long long)nbe * 16) wlocal[w] = incl - c;
+        } else if (w < (long long)nbt * 16) tlocal[w] = incl - c;
+        return;
+    }
     if (which == 3) {  // surface-adjacent grid vertices: bits per 1024-vertex chunk (32 words), exclusive prefix over the chunks -> counts[3]
         if (nvc <= DM_SCAN_LDS) {
             // the plane is read with consecutive lanes on consecutive 16 bytes (eight lanes = one chunk, their popcounts met through
@@ -483,6 +634,73 @@ __device__ __forceinline__ int dm_vertex_of_edge(int eid, const unsigned long lo
     return blk_e[eid / DM_BLOCK_ITEMS] + wlocal[eid >> 6] + __popcll(word & ((1ull << (eid & 63)) - 1ull));
 }
 
+// the surface vertex of crossing edge i (reference dmtet.py:124-131: w = flip([s_a, -s_b]) / (s_a + (-s_b)); v = p_a*w_a + p_b*w_b)
+__device__ __forceinline__ void dm_place_vertex(long long i, int vid, const float* __restrict__ pos, const float* __restrict__ sdf,
+                                                const int2* __restrict__ edges, float* __restrict__ verts, int* __restrict__ vert_edge) {
+    const int2 e = edges[i];
+    const float sa = sdf[e.x], sb = sdf[e.y];
+    const float nsb = -sb;
+    const float den = sa + nsb;
+    const float wa = nsb / den, wb = sa / den;
+    const float* pa = pos + 3ll * e.x;
+    const float* pb = pos + 3ll * e.y;
+    float* o = verts + 3ll * vid;
+    o[0] = pa[0] * wa + pb[0] * wb;
+    o[1] = pa[1] * wa + pb[1] * wb;
+    o[2] = pa[2] * wa + pb[2] * wb;
+    vert_edge[vid] = (int)i;
+}
+
+// the n (1 or 2) triangles of surface tet t (case cs), faces slot .. slot + n - 1
+__device__ __forceinline__ void dm_write_faces(long long t, int cs, unsigned n, long long slot, const int* __restrict__ tet2edge,
+                                               const unsigned long long* __restrict__ edge_bits, const int* __restrict__ wlocal,
+                                               const int* __restrict__ blk_e, long long* __restrict__ faces, long long* __restrict__ uv_idx,
+                                               int* __restrict__ tri32, int* __restrict__ topo_cnt, int* __restrict__ topo_adj,
+                                               int topo_stride, int F) {
+    const int* te = tet2edge + 6ll * t;
+    int ev[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ev[j] = te[j];
+    const signed char* row = c_tri_table[cs];
+    for (unsigned q = 0; q < n; ++q) {
+        long long* fo = faces + 3 * (slot + q);
+        long long* uo = uv_idx + 3 * (slot + q);
+        int ids[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int slot_e = row[3 * q + j];
+            int eid = ev[0];
+#pragma unroll
+            for (int s = 1; s < 6; ++s) eid = (slot_e == s) ? ev[s] : eid;  // register select, no scratch
+            ids[j] = dm_vertex_of_edge(eid, edge_bits, wlocal, blk_e);
+            fo[j] = (long long)ids[j];
+        }
+        if (tri32) {
+            // the first half of the mesh topology (topology.hip: a3d_mesh_topology_finalize does the rest in ONE launch): the int32
+            // triangle list the render kernels read and the valence counts of the vertex -> face lists, from the three ids this
+            // thread holds anyway (fire-and-forget adds; this used to be a launch of its own over the finished list)
+            const int fi = (int)(slot + q);
+            tri32[3 * fi] = ids[0]; tri32[3 * fi + 1] = ids[1]; tri32[3 * fi + 2] = ids[2];
+            if (topo_adj) {
+                // ... or the WHOLE of it: the valence of a surface vertex is bounded by the grid (at most two triangles from each
+                // tet around its edge), so every vertex owns topo_stride slots and the returned count is the entry's place in its
+                // list -- no scan, no second launch.  Three returning atomics in flight per face thread (+2 us on this launch
+                // against the 11 us entry point it makes unnecessary); the lists are unordered, their readers sort the keys.
+                const int s0 = atomicAdd(topo_cnt + ids[0], 1), s1 = atomicAdd(topo_cnt + ids[1], 1), s2 = atomicAdd(topo_cnt + ids[2], 1);
+                if (s0 < topo_stride) topo_adj[(long long)ids[0] * topo_stride + s0] = fi;
+                if (s1 < topo_stride) topo_adj[(long long)ids[1] * topo_stride + s1] = F + fi;
+                if (s2 < topo_stride) topo_adj[(long long)ids[2] * topo_stride + s2] = 2 * F + fi;
+            } else {
+                atomicAdd(topo_cnt + ids[0], 1); atomicAdd(topo_cnt + ids[1], 1); atomicAdd(topo_cnt + ids[2], 1);
+            }
+        }
+        // reference dmtet.py:91-96 with face_gidx = 2t + q
+        uo[0] = 4ll * t;
+        uo[1] = 4ll * t + q + 1;
+        uo[2] = 4ll * t + q + 2;
+    }
+}
+
 __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __restrict__ pos, const float* __restrict__ sdf,
                                                              const int2* __restrict__ edges, const int* __restrict__ tet2edge, int Ne, int Nt,
                                                              int nbe, const int* __restrict__ blk_e, const int* __restrict__ blk_t1,
@@ -546,20 +764,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
             const unsigned long long word = words[k];
             if (!((word >> lane) & 1ull)) continue;
             const long long i = base + k * DM_THREADS + tid;
-            const int vid = blk_e[blk] + wlocal[wi] + a3d_wave_prefix(word);
-            const int2 e = edges[i];
-            const float sa = sdf[e.x], sb = sdf[e.y];
-            // reference dmtet.py:124-131: w = flip([s_a, -s_b]) / (s_a + (-s_b)); v = p_a*w_a + p_b*w_b
-            const float nsb = -sb;
-            const float den = sa + nsb;
-            const float wa = nsb / den, wb = sa / den;
-            const float* pa = pos + 3ll * e.x;
-            const float* pb = pos + 3ll * e.y;
-            float* o = verts + 3ll * vid;
-            o[0] = pa[0] * wa + pb[0] * wb;
-            o[1] = pa[1] * wa + pb[1] * wb;
-            o[2] = pa[2] * wa + pb[2] * wb;
-            vert_edge[vid] = (int)i;
+            dm_place_vertex(i, blk_e[blk] + wlocal[wi] + a3d_wave_prefix(word), pos, sdf, edges, verts, vert_edge);
         }
         return;
     }
@@ -591,49 +796,76 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
         const unsigned n = DM_NTRI(cs);
         if (n == 0u) continue;
         const long long t = base + k * DM_THREADS + tid;
-        const int* te = tet2edge + 6ll * t;
-        int ev[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) ev[j] = te[j];
         const long long slot = (n == 1u) ? (long long)(run1 + a3d_wave_prefix(m1)) : (long long)n1 + 2ll * (run2 + a3d_wave_prefix(m2));
-        const signed char* row = c_tri_table[cs];
-        for (unsigned q = 0; q < n; ++q) {
-            long long* fo = faces + 3 * (slot + q);
-            long long* uo = uv_idx + 3 * (slot + q);
-            int ids[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                int slot_e = row[3 * q + j];
-                int eid = ev[0];
-#pragma unroll
-                for (int s = 1; s < 6; ++s) eid = (slot_e == s) ? ev[s] : eid;  // register select, no scratch
-                ids[j] = dm_vertex_of_edge(eid, edge_bits, wlocal, blk_e);
-                fo[j] = (long long)ids[j];
-            }
-            if (tri32) {
-                // the first half of the mesh topology (topology.hip: a3d_mesh_topology_finalize does the rest in ONE launch): the int32
-                // triangle list the render kernels read and the valence counts of the vertex -> face lists, from the three ids this
-                // thread holds anyway (fire-and-forget adds; this used to be a launch of its own over the finished list)
-                const int fi = (int)(slot + q);
-                tri32[3 * fi] = ids[0]; tri32[3 * fi + 1] = ids[1]; tri32[3 * fi + 2] = ids[2];
-                if (topo_adj) {
-                    // ... or the WHOLE of it: the valence of a surface vertex is bounded by the grid (at most two triangles from each
-                    // tet around its edge), so every vertex owns topo_stride slots and the returned count is the entry's place in its
-                    // list -- no scan, no second launch.  Three returning atomics in flight per face thread (+2 us on this launch
-                    // against the 11 us entry point it makes unnecessary); the lists are unordered, their readers sort the keys.
-                    const int s0 = atomicAdd(topo_cnt + ids[0], 1), s1 = atomicAdd(topo_cnt + ids[1], 1), s2 = atomicAdd(topo_cnt + ids[2], 1);
-                    if (s0 < topo_stride) topo_adj[(long long)ids[0] * topo_stride + s0] = fi;
-                    if (s1 < topo_stride) topo_adj[(long long)ids[1] * topo_stride + s1] = F + fi;
-                    if (s2 < topo_stride) topo_adj[(long long)ids[2] * topo_stride + s2] = 2 * F + fi;
-                } else {
-                    atomicAdd(topo_cnt + ids[0], 1); atomicAdd(topo_cnt + ids[1], 1); atomicAdd(topo_cnt + ids[2], 1);
-                }
-            }
-            // reference dmtet.py:91-96 with face_gidx = 2t + q
-            uo[0] = 4ll * t;
-            uo[1] = 4ll * t + q + 1;
-            uo[2] = 4ll * t + q + 2;
+        dm_write_faces(t, cs, n, slot, tet2edge, edge_bits, wlocal, blk_e, faces, uv_idx, tri32, topo_cnt, topo_adj, topo_stride, F);
+    }
+}
+
+// The emit launch for SPARSE planes (the ordered count pass: the ~1 % surface items of a grid in a random numbering are spread evenly
+// over the planes -- at the "256" class 1.5 crossing edges per 1024-edge block -- so every block holds something, a list of non-empty
+// blocks saves nothing, and a work-group per block is 27k work-groups that each run a chain of five dependent gathers for one or two
+// items: 62 us).  Thread = WORD of a plane: the word loads of a wave are one coalesced read, a thread whose word is empty (9 in 10) is
+// done, the others walk their one to three set bits; the in-block prefixes come from the scan launch (wlocal; tlocal = the same
+// for the one- / two-triangle tets, packed 16 + 16 bits).  The grid does not depend on the counts, so the speculative form (sizes
+// from dev_counts) needs no block capacities.
+__global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* __restrict__ pos, const float* __restrict__ sdf,
+                                                                   const int2* __restrict__ edges, const int* __restrict__ tet2edge, int nwe,
+                                                                   int nwt, const int* __restrict__ blk_e, const int* __restrict__ blk_t1,
+                                                                   const int* __restrict__ blk_t2, const unsigned long long* __restrict__ edge_bits,
+                                                                   const unsigned long long* __restrict__ tet_bits, const int* __restrict__ wlocal,
+                                                                   const int* __restrict__ tlocal, int n1, float* __restrict__ verts,
+                                                                   int* __restrict__ vert_edge, long long* __restrict__ faces,
+                                                                   long long* __restrict__ uv_idx, unsigned* __restrict__ vbits,
+                                                                   const int* __restrict__ vchunk, int Nv, long long* __restrict__ surf_idx,
+                                                                   float* __restrict__ clear, int n_clear, int* __restrict__ tri32,
+                                                                   int* __restrict__ topo_cnt, int* __restrict__ topo_adj, int topo_stride, int F,
+                                                                   int wg_e, int wg_t, int nvc, const int* __restrict__ dev_counts, int cap_V,
+                                                                   int cap_F, int cap_surf) {
+    __shared__ int s_pre[32];
+    const int tid = threadIdx.x;
+    bool faces_live = F > 0;
+    if (dev_counts) {
+        const int dV = dev_counts[0], d1 = dev_counts[1], d2 = dev_counts[2], dS = dev_counts[3];
+        if (dV > cap_V || d1 + 2 * d2 > cap_F || (vbits && dS > cap_surf)) return;
+        n1 = d1;
+        F = d1 + 2 * d2;
+        faces_live = F > 0;
+    }
+    for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
+    const int b = blockIdx.x;
+    if (b >= wg_e + wg_t) {
+        if (b - wg_e - wg_t < nvc) dm_surface_vertices_chunk(b - wg_e - wg_t, vbits, vchunk, Nv, surf_idx, s_pre);
+        return;
+    }
+    if (b < wg_e) {
+        const int w = b * DM_THREADS + tid;
+        unsigned long long word = w < nwe ? edge_bits[w] : 0ull;
+        if (!word) return;
+        int vid = blk_e[w >> 4] + wlocal[w];
+        while (word) {
+            const int bit = __ffsll((long long)word) - 1;
+            word &= word - 1ull;
+            dm_place_vertex(64ll * w + bit, vid++, pos, sdf, edges, verts, vert_edge);
         }
+        return;
+    }
+    const int w = (b - wg_e) * DM_THREADS + tid;
+    if (w >= nwt || !faces_live) return;
+    const ulonglong2 pa = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w], pb = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w + 1];
+    const unsigned long long w0 = pa.x, w1 = pa.y, w2 = pb.x, w3 = pb.y;
+    const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
+    const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
+    unsigned long long mm = m1 | m2;
+    if (!mm) return;
+    const int tl = tlocal[w];
+    int run1 = blk_t1[w >> 4] + (tl & 0xFFFF), run2 = blk_t2[w >> 4] + (tl >> 16);
+    while (mm) {
+        const int bit = __ffsll((long long)mm) - 1;
+        mm &= mm - 1ull;
+        const int cs = (int)((w0 >> bit) & 1ull) | ((int)((w1 >> bit) & 1ull) << 1) | ((int)((w2 >> bit) & 1ull) << 2) | ((int)((w3 >> bit) & 1ull) << 3);
+        const unsigned n = DM_NTRI(cs);
+        const long long slot = (n == 1u) ? (long long)(run1++) : (long long)n1 + 2ll * (run2++);
+        dm_write_faces(64ll * w + bit, cs, n, slot, tet2edge, edge_bits, wlocal, blk_e, faces, uv_idx, tri32, topo_cnt, topo_adj, topo_stride, F);
     }
 }
 
@@ -664,7 +896,7 @@ __global__ __launch_bounds__(256) void dm_bwd_kernel(const float* __restrict__ g
 
 // ------------------------------------------------------------------------------------------------ C ABI
 struct DmScratch {
-    int *be, *b1, *b2, *wlocal;
+    int *be, *b1, *b2, *wlocal, *tlocal;
     unsigned long long *edge_bits, *tet_bits;
     int nbe, nbt;
     size_t sign_off;
@@ -685,7 +917,8 @@ static size_t dm_split_scratch(void* scratch, int Ne, int Nt, DmScratch* d) {
     d->be = p + nwe;
     d->b1 = d->be + d->nbe;
     d->b2 = d->b1 + d->nbt;
-    d->sign_off = (sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + 4) + 63) & ~(size_t)63;
+    d->tlocal = d->b2 + d->nbt;  // (ordered pass only) one- / two-triangle tets of the same block before a word, 16 + 16 bits
+    d->sign_off = (sizeof(unsigned long long) * (nwe + 4 * nwt) + sizeof(int) * (nwe + d->nbe + 2 * (size_t)d->nbt + nwt + 4) + 63) & ~(size_t)63;
     const size_t list_off = (d->sign_off + ((size_t)Ne / 4 + 64) + 63) & ~(size_t)63;  // (after a sign plane for up to 2 Ne grid vertices)
     d->list_len = (int*)((char*)scratch + list_off);
     d->elist = d->list_len + 32;
@@ -749,7 +982,50 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
     }
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(dm_scan_kernel, dim3(vbits ? 4 : 3), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe, d.nbt, counts, vbits, vchunk, nvc,
-                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0, list_len);
+                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0, list_len, (const unsigned long long*)nullptr,
+                       (int*)nullptr, vbits ? 4 : 3, (const unsigned long long*)nullptr, (int*)nullptr);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_dmtet_count_ordered(const float* sdf, int Nv, int Ne, int Nt, const a3d_dmtet_order* order, void* scratch,
+                                       int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean,
+                                       int32_t* words_to_clear_or_null, int n_words_to_clear, a3d_stream_t stream) {
+    A3D_CHECK_ARG(order && order->size >= sizeof(a3d_dmtet_order));  // (a newer caller may append fields; an older, shorter struct is refused)
+    A3D_CHECK_ARG(order->group_slots == 8 || order->group_slots == 16);
+    A3D_CHECK_ARG(order->vertex_of_rank && order->edges_ranked && order->edge_of_row && order->tets_ranked && order->tet_of_row &&
+                  order->edge_groups && order->tet_groups);
+    A3D_CHECK_ARG(n_words_to_clear >= 0 && (n_words_to_clear == 0 || words_to_clear_or_null));
+    A3D_CHECK_ARG(sdf && scratch && counts && ((uintptr_t)scratch & 15) == 0);
+    A3D_CHECK_ARG(Ne > 0 && Nt > 0 && Nv > 0 && (long long)Nv <= 2ll * Ne);
+    A3D_CHECK_ARG(!vertex_scratch_or_null || ((uintptr_t)vertex_scratch_or_null & 15) == 0);
+    DmScratch d;
+    dm_split_scratch(scratch, Ne, Nt, &d);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* vbits = (unsigned*)vertex_scratch_or_null;
+    const int nvc = vbits ? a3d_div_up(Nv, 1024) : 0;
+    int* vchunk = vbits ? (int*)(vbits + 32ll * nvc) : nullptr;
+    if (vbits && !vertex_scratch_is_clean) A3D_HIP(hipMemsetAsync(vbits, 0, 128 * (size_t)nvc, s));
+    unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
+    // planes, wlocal and block sums are one stretch of the scratch that ends where the sign plane begins (a multiple of 64 bytes)
+    hipLaunchKernelGGL(dm_sign_order_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, order->vertex_of_rank, Nv, sign,
+                       (uint4*)scratch, (long long)(d.sign_off / 16));
+    A3D_LAUNCH_CHECK();
+    const int nwe = d.nbe * (DM_BLOCK_ITEMS / 64), nwt = d.nbt * (DM_BLOCK_ITEMS / 64);  // rows of the group tables (padded to whole blocks)
+    const int waves_e = a3d_div_up(nwe, DM_ORDER_WORDS), waves_t = a3d_div_up(nwt, DM_ORDER_WORDS);
+    const dim3 grid(a3d_div_up(waves_e + waves_t, 4));
+#define DM_ORDER_LAUNCH(SLOTS)                                                                                                              \
+    hipLaunchKernelGGL(dm_count_order_kernel<SLOTS>, grid, dim3(256), 0, s, (const unsigned*)sign, (const int2*)order->edges_ranked,        \
+                       order->edge_of_row, (const int4*)order->tets_ranked, order->tet_of_row, order->vertex_of_rank, Ne, Nt, nwe, nwt,     \
+                       waves_e, waves_t, order->edge_groups, order->tet_groups, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, vbits)
+    if (order->group_slots == 16) DM_ORDER_LAUNCH(16);
+    else DM_ORDER_LAUNCH(8);
+#undef DM_ORDER_LAUNCH
+    A3D_LAUNCH_CHECK();
+    const int n_scans = vbits ? 4 : 3;
+    hipLaunchKernelGGL(dm_scan_kernel, dim3(n_scans + a3d_div_up(nwe, 1024) + a3d_div_up(nwt, 1024)), dim3(1024), 0, s, d.be, d.b1, d.b2, d.nbe,
+                       d.nbt, counts, vbits, vchunk, nvc, words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0, (const int*)nullptr,
+                       (const unsigned long long*)d.edge_bits, d.wlocal, n_scans, (const unsigned long long*)d.tet_bits, d.tlocal);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -793,6 +1069,45 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
                        g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb, topo_adj_or_null,
                        topo_stride, n1 + 2 * n2, listed ? (const int*)d.elist : nullptr, listed ? (const int*)d.tlist : nullptr, ne, nt, nvc,
                        device_counts_or_null, V, cap_F, n_surf);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
+                                     const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces,
+                                     int64_t* uv_idx, const a3d_dmtet_emit_opts* opts_or_null, a3d_stream_t stream) {
+    a3d_dmtet_emit_opts o = {};
+    if (opts_or_null) {
+        A3D_CHECK_ARG(opts_or_null->size >= sizeof(a3d_dmtet_emit_opts));
+        o = *opts_or_null;
+    }
+    A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
+    const bool spec = o.device_counts != nullptr;  // V, n1 (read as F) and n_surf then are CAPACITIES; n2 is ignored
+    if (spec) n2 = 0;
+    A3D_CHECK_ARG(!spec || V > 0);
+    A3D_CHECK_ARG(Ne > 0 && Nt > 0 && V >= 0 && n1 >= 0 && n2 >= 0);
+    A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
+    A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
+    A3D_CHECK_ARG(!o.vertex_scratch || (o.Nv > 0 && o.n_surf >= 0 && (o.n_surf == 0 || o.surf_idx)));
+    A3D_CHECK_ARG(!o.g_sdf_to_clear || o.Nv > 0);
+    A3D_CHECK_ARG((o.tri32 == nullptr) == (o.topo_count == nullptr));
+    A3D_CHECK_ARG(!o.topo_adj || (o.tri32 && o.topo_stride > 0 && (long long)V * o.topo_stride < 0x7fffffffll));
+    if (V == 0) {  // no crossing edge, hence no surface tet and no flagged vertex
+        if (o.g_sdf_to_clear) A3D_HIP(hipMemsetAsync(o.g_sdf_to_clear, 0, sizeof(float) * (size_t)o.Nv, (hipStream_t)stream));
+        return A3D_OK;
+    }
+    DmScratch d;
+    dm_split_scratch((void*)scratch, Ne, Nt, &d);
+    unsigned* vbits = (unsigned*)o.vertex_scratch;
+    const int nvc = vbits ? a3d_div_up(o.Nv, 1024) : 0;
+    const int nwe = d.nbe * (DM_BLOCK_ITEMS / 64), nwt = d.nbt * (DM_BLOCK_ITEMS / 64);
+    const int wg_e = a3d_div_up(nwe, DM_THREADS), wg_t = a3d_div_up(nwt, DM_THREADS);
+    const int wg_work = wg_e + wg_t + nvc, wg_clear = o.g_sdf_to_clear ? a3d_div_up(o.Nv, DM_THREADS * 16) : 0;
+    hipLaunchKernelGGL(dm_emit_words_kernel, dim3(wg_work > wg_clear ? wg_work : wg_clear), dim3(DM_THREADS), 0, (hipStream_t)stream, pos, sdf,
+                       (const int2*)edges, tet2edge, nwe, nwt, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, d.tlocal, n1, verts, vert_edge,
+                       (long long*)faces, (long long*)uv_idx, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, o.Nv,
+                       (long long*)o.surf_idx, o.g_sdf_to_clear, o.g_sdf_to_clear ? o.Nv : 0, o.tri32, o.topo_count, o.topo_adj, o.topo_stride,
+                       n1 + 2 * n2, wg_e, wg_t, nvc, o.device_counts, V, n1 + 2 * n2, o.n_surf);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -11,6 +11,7 @@
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import warnings
 
@@ -36,7 +37,9 @@ SURFACE_BUCKET = 1024  # row padding of the surface-adjacent SDF re-evaluation (
 class TetGridTopology:
     """Static per-grid device buffers the kernels stream: tets/edges/tet2edge as int32."""
 
-    def __init__(self, indices: torch.Tensor):
+    def __init__(self, indices: torch.Tensor, positions: torch.Tensor = None):
+        """``positions`` [Nv,3] (optional; any scale): where the grid's vertices are -- only ever used to choose an order of evaluation
+        (spatial_order), never for a result.  Without them the first extraction's own ``pos_nx3`` is taken."""
         idx = indices.long()
         dev = idx.device
         nv = int(idx.max().item()) + 1
@@ -52,6 +55,8 @@ class TetGridTopology:
         self._uvs = None
         self._word_groups = None
         self._face_list_stride = None
+        self._positions = positions.detach() if positions is not None else None
+        self._order = None
 
     def face_list_stride(self) -> int:
         """Slots per surface vertex that hold its whole vertex -> face list whatever the SDF: a surface vertex sits on a grid edge, every
@@ -83,22 +88,85 @@ class TetGridTopology:
             self._word_groups = (e, t) if dense <= 0.5 else False
         return self._word_groups or None
 
+    SPATIAL_ORDER = True  # False: a grid numbered without regard to space takes the plain count pass (a3d_dmtet_count, no tables)
+    ORDER_SLOTS = 16
+
+    def spatial_order(self, positions: torch.Tensor = None):
+        """The static tables of a3d_dmtet_count_ordered (include/a3d.h: a3d_dmtet_order) for a grid whose file numbering ignores space --
+        the reference's Quartet grids (dmtet.py:214-226) -- or None (switched off, or most words of the ranked lists need more than
+        ORDER_SLOTS groups: then nothing is gained over the plain pass).  Vertices ranked along a Morton curve through ``positions``
+        (16 bits per axis); edge rows rewritten in ranks and sorted by (lower, higher) rank; tet rows rewritten in ranks with their corner
+        order kept and sorted by (lowest, second lowest) rank; the word groups of those two lists.  Built once per grid; the positions
+        decide how much of the grid a later call can skip, never what it returns."""
+        if self._order is None:
+            pos = positions if positions is not None else self._positions
+            if not self.SPATIAL_ORDER or pos is None:
+                return None
+            from ... import _lib
+
+            lib = _lib.lib()
+            bits, block = lib.a3d_dmtet_word_group_bits(), lib.a3d_dmtet_block_items()
+            nv, dev = self.num_verts, self.tets32.device
+            p = pos.detach().to(dev, torch.float64).reshape(-1, 3)[:nv]
+            lo = p.amin(0)
+            q = ((p - lo) / (p.amax(0) - lo).max().clamp(min=1e-30) * 65535.0).round().long().clamp(0, 65535)
+            key = _interleave3(q[:, 0]) | (_interleave3(q[:, 1]) << 1) | (_interleave3(q[:, 2]) << 2)
+            vertex_of_rank = torch.argsort(key, stable=True)
+            rank = torch.empty_like(vertex_of_rank)
+            rank[vertex_of_rank] = torch.arange(nv, device=dev)
+            er = rank[self.edges32.long()]
+            er = torch.stack([er.amin(1), er.amax(1)], 1)
+            e_row = torch.argsort(er[:, 0] * nv + er[:, 1], stable=True)
+            tr = rank[self.tets32.long()]
+            two = tr.sort(1).values[:, :2]
+            t_row = torch.argsort(two[:, 0] * nv + two[:, 1], stable=True)
+            edges_ranked, tets_ranked = er[e_row].to(torch.int32).contiguous(), tr[t_row].to(torch.int32).contiguous()
+            eg, tg = _word_groups(edges_ranked, self.ORDER_SLOTS, bits, block), _word_groups(tets_ranked, self.ORDER_SLOTS, bits, block)
+            dense = (int((eg[:, 0] < 0).sum()) + int((tg[:, 0] < 0).sum())) / float(eg.shape[0] + tg.shape[0])
+            if dense > 0.5:
+                self._order = False
+            else:
+                tensors = dict(vertex_of_rank=vertex_of_rank.to(torch.int32).contiguous(), edges_ranked=edges_ranked,
+                               edge_of_row=e_row.to(torch.int32).contiguous(), tets_ranked=tets_ranked,
+                               tet_of_row=t_row.to(torch.int32).contiguous(), edge_groups=eg, tet_groups=tg)
+                struct = _lib.DmtetOrder(size=ctypes.sizeof(_lib.DmtetOrder), group_slots=self.ORDER_SLOTS,
+                                         **{k: v.data_ptr() for k, v in tensors.items()})
+                self._order = (struct, tensors)  # (the struct holds raw pointers: the tensors live as long as it does)
+        return self._order or None
+
+    def count_pass(self, num_verts: int = None, positions: torch.Tensor = None) -> str:
+        """Which count pass an extraction on this grid takes: 'plain' (a3d_dmtet_count streaming every index row: small grids, or
+        nothing better available), 'culled' (a3d_dmtet_count with the word groups of the file's own row order: grids numbered along
+        space) or 'ordered' (a3d_dmtet_count_ordered: any numbering)."""
+        from ... import ops
+
+        nv = self.num_verts if num_verts is None else num_verts
+        if nv < ops.DMTET_CULL_MIN_VERTS:
+            return "plain"
+        if self.word_groups() is not None:
+            return "culled"
+        return "ordered" if self.spatial_order(positions) is not None else "plain"
+
     def words_read(self, sdf: torch.Tensor):
         """Diagnostic (measurement only): (edge words read, edge words, tet words read, tet words) of the culled count pass for this SDF,
         by the kernel's own rule -- a word is skipped when all its groups read 0x0000 or all 0xffff in the sign plane -- or None."""
-        groups = self.word_groups()
-        if groups is None:
-            return None
         from ... import _lib
 
-        bits = _lib.lib().a3d_dmtet_word_group_bits()
+        groups, rows = self.word_groups(), (self.edges32, self.tets32)
         inside = sdf.detach().reshape(-1) > 0
+        if groups is None:
+            if self._order:  # the ordered pass: the same rule over the ranked lists and the sign plane in rank order
+                t = self._order[1]
+                groups, rows, inside = (t["edge_groups"], t["tet_groups"]), (t["edges_ranked"], t["tets_ranked"]), inside[t["vertex_of_rank"].long()]
+            else:
+                return None
+        bits = _lib.lib().a3d_dmtet_word_group_bits()
         size = 1 << bits
         pad = (-inside.shape[0]) % size
         field = torch.cat([inside, inside.new_zeros(pad)]).reshape(-1, size)  # (the plane's padding bits are zeros)
         state = torch.where(field.all(1), 2, torch.where(field.any(1), 1, 0))  # 0: all outside, 2: all inside, 1: mixed
         out = []
-        for rows32, tab in zip((self.edges32, self.tets32), groups):
+        for rows32, tab in zip(rows, groups):
             t = tab.long()
             st = torch.where(t >= 0, state[t.clamp(min=0)], torch.ones_like(t))
             skip = (st == 0).all(1) | (st == 2).all(1)
@@ -116,6 +184,17 @@ class TetGridTopology:
             pad = 0.9 / n
             self._uvs = torch.stack([tx, ty, tx + pad, ty, tx + pad, ty + pad, tx, ty + pad], dim=-1).view(-1, 2)
         return self._uvs
+
+
+def _interleave3(x: torch.Tensor) -> torch.Tensor:
+    """Bits of x (int64, < 2^21) spread to every third position."""
+    x = x & 0x1FFFFF
+    x = (x | (x << 32)) & 0x1F00000000FFFF
+    x = (x | (x << 16)) & 0x1F0000FF0000FF
+    x = (x | (x << 8)) & 0x100F00F00F00F00F
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3
+    x = (x | (x << 2)) & 0x1249249249249249
+    return x  # (the y / z copies are shifted by the caller)
 
 
 def _word_groups(rows32: torch.Tensor, slots: int, bits: int, block: int, chunk_words: int = 1 << 16) -> torch.Tensor:
@@ -274,7 +353,7 @@ class DMTetGeometry(torch.nn.Module):
 
     def generate_edges(self):
         with torch.no_grad():
-            self.topology = TetGridTopology(self.indices)
+            self.topology = TetGridTopology(self.indices, positions=self.verts)
             self.all_edges = self.topology.all_edges
 
     @torch.no_grad()

@@ -6,6 +6,7 @@ with find_unused_parameters=False in the reference.  Noth
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from collections import OrderedDict
@@ -163,6 +164,36 @@ _dm_vertex_scratch = {}
 _dm_grad_buffers = _IdentityCache(maxsize=2)  # vert_edge of an extraction -> its cleared SDF gradient buffer
 
 
+def _dmtet_count(sdf_c, pos_c, grid, scratch, counts, vscratch, vclean, counters):
+    """The count call of an extraction, by the pass the grid takes (TetGridTopology.count_pass): 'plain' / 'culled' = a3d_dmtet_count
+    without / with the word groups of the file's own row order, 'ordered' = a3d_dmtet_count_ordered (any numbering).  -> the pass."""
+    Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], sdf_c.shape[0]
+    which = grid.count_pass(Nv, pos_c) if hasattr(grid, "count_pass") else "plain"
+    n_clear = 0 if counters is None else counters.shape[0]
+    if which == "ordered":
+        order = grid.spatial_order(pos_c)[0]
+        call("a3d_dmtet_count_ordered", ptr(sdf_c), Nv, Ne, Nt, ctypes.addressof(order), ptr(scratch), ptr(counts), ptr(vscratch), int(vclean),
+             ptr(counters), n_clear, stream())
+    else:
+        groups = grid.word_groups() if which == "culled" else None
+        call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
+             ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), n_clear, stream())
+    grid._last_count_pass = which
+    return which
+
+
+def dmtet_count_only(pos, sdf, grid, surface_vertices=False):
+    """The count call alone (measurement: tools/bench_dmtet.py); -> counts int32 [6] on the device.  With ``surface_vertices`` the flagged
+    vertex plane is left dirty (no emit clears it), so every call pays its memset like a first call does."""
+    pos_c, sdf_c = f32c(pos.detach()), f32c(sdf.detach()).reshape(-1)
+    dev, Nv = pos_c.device, pos_c.shape[0]
+    scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(grid.edges32.shape[0], grid.tets32.shape[0]), dtype=torch.uint8, device=dev)
+    vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev) if surface_vertices else None
+    counts = torch.empty(6, dtype=torch.int32, device=dev)
+    _dmtet_count(sdf_c, pos_c, grid, scratch, counts, vscratch, False, None)
+    return counts
+
+
 def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V]).
     ``surface_vertices``: also the sorted int64 list of the grid vertices at the ends of sign-crossing edges (their count rides in the
@@ -183,9 +214,9 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         if vscratch is None:
             vscratch = torch.empty(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
     counts = torch.empty(6, dtype=torch.int32, device=dev)
-    # static per grid: lets the count pass skip the words off the surface.  Three launches (sign plane, culled count, scan) against two:
-    # R = 64 (2.7e5 vertices) 14 vs 18 us back to back and equal inside the step, R = 128 32 vs 88 us; small grids keep the plain pass
-    groups = grid.word_groups() if (Nv >= DMTET_CULL_MIN_VERTS and hasattr(grid, "word_groups")) else None
+    # (which count pass runs is decided by the grid: static tables let it skip the words off the surface.  Three launches (sign plane,
+    # culled count, scan) against two: R = 64 (2.7e5 vertices) 14 vs 18 us back to back and equal inside the step, R = 128 32 vs 88 us;
+    # small grids keep the plain pass)
     # mesh topology inside the extraction (DMTET_TOPOLOGY).  Preferred form: the emit launch writes the int32 triangle list AND the vertex ->
     # face lists themselves, every vertex owning ``stride`` slots (the grid bounds the valence: grid.face_list_stride()); the valence
     # counters it appends through are zeroed by the count call -- sized by a guess at V (the last extraction on this grid), since V is
@@ -195,33 +226,45 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     if 0 < stride <= DMTET_EMIT_LISTS_MAX_STRIDE:
         guess = getattr(grid, "_last_surface_vertices", 0)
         counters = torch.empty(max(1024, -(-int(1.25 * guess) // 1024) * 1024), dtype=torch.int32, device=dev)
-    call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
-         ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), 0 if counters is None else counters.shape[0],
-         stream())
+    which = _dmtet_count(sdf_c, pos_c, grid, scratch, counts, vscratch, vclean, counters)
+
     def alloc(Vn, Fn, n_surf_n):
         return (torch.empty((Vn, 3), dtype=torch.float32, device=dev), torch.empty((Vn,), dtype=torch.int32, device=dev),
                 torch.empty((Fn, 3), dtype=torch.int64, device=dev), torch.empty((Fn, 3), dtype=torch.int64, device=dev),
                 torch.empty((n_surf_n,), dtype=torch.int64, device=dev) if surface_vertices else None)
 
     g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
+
+    def emit(Vn, n1n, n2n, bufs, n_surf_n, tri32_t, cnt_t, adj_t, stride_n, listed, dev_counts):
+        """a3d_dmtet_emit, or after the ordered count pass (surface items spread evenly over the planes) a3d_dmtet_emit_sparse."""
+        if which == "ordered":
+            opts = _lib.DmtetEmitOpts(size=ctypes.sizeof(_lib.DmtetEmitOpts), Nv=Nv, vertex_scratch=ptr(vscratch), surf_idx=ptr(bufs[4]),
+                                      g_sdf_to_clear=ptr(g_sdf), tri32=ptr(tri32_t), topo_count=ptr(cnt_t), topo_adj=ptr(adj_t),
+                                      device_counts=ptr(dev_counts), n_surf=n_surf_n if surface_vertices else 0, topo_stride=stride_n)
+            call("a3d_dmtet_emit_sparse", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), Vn, n1n, n2n,
+                 ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ctypes.addressof(opts), stream())
+        else:
+            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), Vn, n1n, n2n, ptr(bufs[0]),
+                 ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(vscratch), Nv, n_surf_n if surface_vertices else 0, ptr(bufs[4]), ptr(g_sdf),
+                 ptr(tri32_t), ptr(cnt_t), ptr(adj_t), stride_n, listed[0], listed[1], ptr(dev_counts), stream())
+
     # SPECULATIVE emit: with the numbers of the previous extraction on this grid as a guess (+25 %), the emit launch is enqueued BEFORE
     # the host reads the counts -- the kernel takes the true sizes from the device, the GPU does not idle across the read-back, and the
     # host's wait overlaps the launch.  If anything outgrew its capacity the launch left every buffer untouched and the exact path
     # below runs as if nothing had happened.
     spec = None
     last = getattr(grid, "_last_counts", None)
-    if DMTET_SPECULATIVE_EMIT and last is not None and groups is not None and counters is not None and stride > 0:
+    if DMTET_SPECULATIVE_EMIT and last is not None and which in ("culled", "ordered") and counters is not None and stride > 0:
         cap = lambda n, unit: max(unit, -(-int(1.25 * n) // unit) * unit)
-        nbe, nbt = -(-Ne // 1024), -(-Nt // 1024)
+        items = _lib.lib().a3d_dmtet_block_items()
+        nbe, nbt = -(-Ne // items), -(-Nt // items)
         capV, capF, capS = min(cap(last[0], 256), counters.shape[0]), cap(last[1] + 2 * last[2], 256), cap(last[3], 256)
         capE, capT = min(cap(last[4], 16), nbe), min(cap(last[5], 16), nbt)
-        if last[0] > 0 and last[1] + last[2] > 0 and last[4] >= 0 and capV * stride < 2 ** 31:
+        if last[0] > 0 and last[1] + last[2] > 0 and (last[4] >= 0 or which == "ordered") and capV * stride < 2 ** 31:
             bufs = alloc(capV, capF, capS)
             tri32_b = torch.empty((capF, 3), dtype=torch.int32, device=dev)
             adj_b = torch.empty(capV * stride, dtype=torch.int32, device=dev)
-            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), capV, capF, 0, ptr(bufs[0]),
-                 ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(vscratch), Nv, capS if surface_vertices else 0, ptr(bufs[4]), ptr(g_sdf), ptr(tri32_b),
-                 ptr(counters), ptr(adj_b), stride, capE, capT, ptr(counts), stream())
+            emit(capV, capF, 0, bufs, capS, tri32_b, counters, adj_b, stride, (capE, capT), counts)
             spec = (capV, capF, capS, capE, capT, bufs, tri32_b, adj_b)
     # the one host sync of DMTet (the reference syncs here too, dmtet.py:110); listed_*: how many non-empty blocks the culled count
     # pass listed for the emit launch (-1: none listed)
@@ -231,7 +274,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     if counters is not None:
         grid._last_surface_vertices = V
     if spec is not None and V > 0 and F > 0 and V <= spec[0] and F <= spec[1] and (not surface_vertices or n_surf <= spec[2]) \
-            and 0 <= listed_e <= spec[3] and listed_t <= spec[4]:
+            and (which == "ordered" or (0 <= listed_e <= spec[3] and listed_t <= spec[4])):
         bufs, tri32_b, adj_b = spec[5], spec[6], spec[7]
         verts, vert_edge, faces, uv_idx = bufs[0][:V], bufs[1][:V], bufs[2][:F], bufs[3][:F]
         idx = bufs[4][:n_surf] if surface_vertices else None
@@ -257,9 +300,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         if cur is not None:
             tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
         try:
-            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), V, n1, n2, ptr(verts),
-                 ptr(vert_edge), ptr(faces), ptr(uv_idx), ptr(vscratch), Nv, n_surf if surface_vertices else 0, ptr(idx), ptr(g_sdf), ptr(tri32),
-                 ptr(cur), ptr(lists_adj), stride if emit_lists else 0, listed_e, listed_t, None, stream())
+            emit(V, n1, n2, (verts, vert_edge, faces, uv_idx, idx), n_surf, tri32, cur, lists_adj, stride if emit_lists else 0, (listed_e, listed_t), None)
             adj = None
             if emit_lists:
                 adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))

@@ -101,9 +101,11 @@ class SyntheticScene(torch.nn.Module):
 
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
                  embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None,
-                 workload="magicpony", num_frames=1, deform=False, pose_seed=0):
+                 workload="magicpony", num_frames=1, deform=False, pose_seed=0, grid=None):
         """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
         data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter.
+        ``grid``: a tetgrid.named_grid name ('bcc51s' = the reference's "128" Quartet class in a file's arbitrary numbering) instead of
+        the Kuhn grid of ``grid_res`` cells.
         ``pose_seed`` != 0 draws other cameras / articulations with the SAME networks (per-rank poses: unequal covered-pixel counts)."""
         super().__init__()
         assert workload in WORKLOADS, workload
@@ -121,10 +123,14 @@ class SyntheticScene(torch.nn.Module):
         freq = dict(sdf=8, texture=10, dino=8, deform=10)
         if embedder_freq is not None:
             freq = {k: embedder_freq for k in freq}
+        if grid is not None:
+            *grid, grid_res = tetgrid.named_grid(grid)
+            grid = tuple(grid)
+        else:
+            grid = tetgrid.kuhn_grid(grid_res)
         if leg_radius is None:  # keep the legs a few cells thick on coarse grids
             leg_radius = max(0.2, 1.6 * spatial_scale / grid_res)
         scalar = 2 * math.pi / spatial_scale * 0.9
-        grid = tetgrid.kuhn_grid(grid_res)
         self.netShape = _SyntheticGeometry(grid_res, spatial_scale, num_layers=layers["sdf"], hidden_size=net_width, embedder_freq=freq["sdf"],
                                            jitter_grid=jitter_grid, symmetrize=True, device=dev, tet_grid=grid, leg_radius=leg_radius,
                                            condition_choice="mod" if workload == "fauna" else None)

@@ -83,26 +83,27 @@ def bcc_grid(res: int, seed=None):
     cx = (np.arange(res, dtype=np.float64) + 0.5) / res - 0.5
     centres = np.stack(np.meshgrid(cx, cx, cx, indexing="ij"), -1).reshape(-1, 3)
     vertices = np.concatenate([corners, centres]).astype(np.float32)
-    corner = lambda i, j, k: (i * n + j) * n + k
-    centre = lambda i, j, k: n ** 3 + (i * res + j) * res + k
-    tets = []
+    # corner (i,j,k) -> (i n + j) n + k, centre (i,j,k) -> n^3 + (i res + j) res + k.  Rows in the order axis, i, j, k, ring edge
+    # (vectorised over (i,j,k): the "256" class is 1.3e7 tets)
+    gi, gj, gk = [a.reshape(-1) for a in np.meshgrid(np.arange(res - 1), np.arange(res), np.arange(res), indexing="ij")]
+    per_axis = []
     for axis in range(3):
         u, v = [a for a in range(3) if a != axis]
-        for i in range(res - 1):  # the face between cell i and cell i + 1 along ``axis``
-            for j in range(res):
-                for k in range(res):
-                    lo, hi = [0, 0, 0], [0, 0, 0]
-                    lo[axis], lo[u], lo[v] = i, j, k
-                    hi[axis], hi[u], hi[v] = i + 1, j, k
-                    c0, c1 = centre(*lo), centre(*hi)
-                    ring = []
-                    for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):  # the face's four corners in cyclic order
-                        q = [0, 0, 0]
-                        q[axis], q[u], q[v] = i + 1, j + du, k + dv
-                        ring.append(corner(*q))
-                    for e in range(4):
-                        tets.append((c0, c1, ring[e], ring[(e + 1) % 4]))
-    indices = np.asarray(tets, dtype=np.int64)
+
+        def cell(di, du, dv):  # integer coordinates with the face's (axis, u, v) components put in place
+            q = np.zeros((gi.size, 3), dtype=np.int64)
+            q[:, axis], q[:, u], q[:, v] = gi + di, gj + du, gk + dv
+            return q
+
+        lo, hi = cell(0, 0, 0), cell(1, 0, 0)  # the face between cell i and cell i + 1 along ``axis``
+        c0 = n ** 3 + (lo[:, 0] * res + lo[:, 1]) * res + lo[:, 2]
+        c1 = n ** 3 + (hi[:, 0] * res + hi[:, 1]) * res + hi[:, 2]
+        ring = []
+        for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):  # the face's four corners in cyclic order
+            q = cell(1, du, dv)
+            ring.append((q[:, 0] * n + q[:, 1]) * n + q[:, 2])
+        per_axis.append(np.stack([np.stack([c0, c1, ring[e], ring[(e + 1) % 4]], -1) for e in range(4)], 1).reshape(-1, 4))
+    indices = np.concatenate(per_axis).astype(np.int64)
     if seed is not None:
         vertices, indices = scramble(vertices, indices, seed)
     return vertices, indices
@@ -131,6 +132,24 @@ def scramble(vertices: np.ndarray, indices: np.ndarray, seed: int):
     idx = idx[rng.permutation(idx.shape[0])]
     order = np.argsort(rng.random(idx.shape), axis=1)
     return out_v, np.take_along_axis(idx, order, axis=1).astype(np.int64)
+
+
+def named_grid(name: str):
+    """'kuhnR' / 'bccR' / 'delaunayN', with a trailing 's' for a scrambled numbering (seed 7): (vertices, indices, cells per axis).
+    bcc51s ~ the vertex / tet counts of the reference's "128" Quartet grid (2.7e5 / 1.6e6), bcc102s ~ its "256" grid (2.2e6 / 1.3e7),
+    in the arbitrary numbering such a file has."""
+    import re
+
+    m = re.fullmatch(r"(kuhn|bcc|delaunay)(\d+)(s?)", name)
+    if not m:
+        raise ValueError(f"unknown grid {name!r} (kuhnR, bccR, delaunayN, optional trailing s = scrambled numbering)")
+    kind, res, scr = m.group(1), int(m.group(2)), m.group(3) == "s"
+    if kind == "kuhn":
+        p, t = kuhn_grid(res)
+        return (*(scramble(p, t, 7) if scr else (p, t)), res)
+    if kind == "bcc":
+        return (*bcc_grid(res, seed=7 if scr else None), res)
+    return (*delaunay_grid(res, seed=7), max(2, round(res ** (1 / 3))))
 
 
 def save_tets_npz(path: str, vertices: np.ndarray, indices: np.ndarray) -> None:

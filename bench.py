@@ -57,7 +57,11 @@ PMC_WORKLOAD = "magicpony grid64 batch16 256x256 train"  # what tools/pmc_traffi
 
 
 def workload_signature(args, batch):
-    return f"{args.workload} grid{args.grid_res} batch{batch} {args.resolution}x{args.resolution} {'forward' if args.forward_only else 'train'}"
+    return f"{args.workload} grid{grid_name(args).replace('kuhn', '')} batch{batch} {args.resolution}x{args.resolution} {'forward' if args.forward_only else 'train'}"
+
+
+def grid_name(args):
+    return args.grid if args.grid else f"kuhn{args.grid_res}"
 
 
 def pmc_traffic(signature=PMC_WORKLOAD):
@@ -118,8 +122,13 @@ def algorithmic_bytes(name, d):
         dm_count = 4 * Nv + 2 * (Nv // 8) + 32 * (nwe + nwt) + 64 * (8 * we + 16 * wt) + dm_planes
     else:
         dm_count = 4 * Nv + 8 * Ne + 16 * Nt + dm_planes  # sdf, both index arrays in; bit planes + word prefixes out
+    we, nwe, wt, nwt = d.get("dm_words_read") or (0, Ne // 64, 0, Nt // 64)
     table = {
         "a3d_dmtet_count": dm_count,
+        # ordered pass: sdf + rank table in, sign plane out and in, 64 B of group ids per word in, the rows (ranks + source row) of the
+        # words that are read, the planes cleared, set bit by bit and read once more for the in-block prefixes
+        "a3d_dmtet_count_ordered": 8 * Nv + 2 * (Nv // 8) + 64 * (nwe + nwt) + 64 * (12 * we + 20 * wt) + 2 * dm_planes + Nt // 16,
+        "a3d_dmtet_emit_sparse": dm_planes + Nt // 16 + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V),
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
         "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V),  # (+ the vertex -> face lists it now writes itself)  # (+ the int32 triangle list of the render kernels)
@@ -215,15 +224,16 @@ def roofline_of(kernels, dims, signature=PMC_WORKLOAD):
     roof["in_scope_note"] = ("us_per_step is the figure comparable across rounds (round 1: 645.0): fused entry points (compositor, per-image shading rows, "
                              "bit-plane DMTet emit, culled DMTet count) are credited only the bytes they still move, so algorithmic_MB_per_step fell "
                              "with the time")
-    if dims.get("dm_words_read") and "a3d_dmtet_count" in scope:
+    cnt = next((k for k in ("a3d_dmtet_count", "a3d_dmtet_count_ordered") if k in scope), None)
+    if dims.get("dm_words_read") and cnt:
         # the culled count pass no longer streams the index arrays: its credit fell ~8x with its time ~2x, which LOWERS the aggregate
         # fraction although the step got faster.  For comparison with the records before it: the same time under the old credit.
         streamed = algorithmic_bytes("a3d_dmtet_count", {**dims, "dm_words_read": None})
         agg = roof["in_scope"]
-        mb = agg["algorithmic_MB_per_step"] + (streamed / 1e6 - scope["a3d_dmtet_count"]["algorithmic_MB"]) * scope["a3d_dmtet_count"]["launches_per_step"]
+        mb = agg["algorithmic_MB_per_step"] + (streamed / 1e6 - scope[cnt]["algorithmic_MB"]) * scope[cnt]["launches_per_step"]
         we, nwe, wt, nwt = dims["dm_words_read"]
-        roof["dmtet_count_cull"] = dict(edge_words_read=we, edge_words=nwe, tet_words_read=wt, tet_words=nwt,
-                                        credited_MB=scope["a3d_dmtet_count"]["algorithmic_MB"], streamed_MB=round(streamed / 1e6, 3),
+        roof["dmtet_count_cull"] = dict(entry_point=cnt, edge_words_read=we, edge_words=nwe, tet_words_read=wt, tet_words=nwt,
+                                        credited_MB=scope[cnt]["algorithmic_MB"], streamed_MB=round(streamed / 1e6, 3),
                                         in_scope_frac_if_credited_as_streamed=round(mb * 1e6 / (agg["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
     roof["fastest_in_scope"] = dict(kernel=top, achieved=scope[top]["GBps"], unit="GB/s", frac=round(scope[top]["GBps"] / HBM_PEAK_GBS, 4),
                                     launch_us=scope[top]["mean_us"])
@@ -280,7 +290,7 @@ def parity_and_cpu_baseline(scene, args, threads):
         parity["loss_rel_err"] = rel
     parity["pass"] = check.passes(rep)
     cpu_baseline = dict(value=round(n / sec, 4), unit="images/s", cores=threads, kind="port",
-                        sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {scene.frames} frames of this workload ({scene.workload}: Kuhn R={args.grid_res} "
+                        sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {scene.frames} frames of this workload ({scene.workload}: grid {grid_name(args)} "
                                f"DMTet, LBS, {args.resolution}x{args.resolution} raster+shade+antialias, losses), 1 warm-up + median of {args.cpu_runs} runs, "
                                f"torch {threads} threads of {os.cpu_count()} logical cores, {sec:.1f} s per run")
     return parity, cpu_baseline
@@ -351,6 +361,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images (sequences for ponymation) per GPU; default 16 (8 sequences)")
     ap.add_argument("--frames", type=int, default=8, help="frames per sequence (ponymation only)")
     ap.add_argument("--grid-res", type=int, default=64)
+    ap.add_argument("--grid", default=None, help="a named tet grid instead of the Kuhn grid of --grid-res cells: bcc51s / bcc102s = BCC lattices "
+                    "(Quartet's family) of the reference's '128' / '256' class in a random numbering (tetgrid.named_grid)")
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--workload", choices=("magicpony", "fauna", "ponymation"), default="magicpony")
     ap.add_argument("--networks", choices=("fast", "reference", "both"), default="both",
@@ -402,7 +414,7 @@ def main():
     frames = args.frames if args.workload == "ponymation" else 1
 
     def make_scene():
-        return pipeline.SyntheticScene(grid_res=args.grid_res, batch=batch, resolution=(args.resolution, args.resolution), device=dev, seed=0,
+        return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=batch, resolution=(args.resolution, args.resolution), device=dev, seed=0,
                                        data_seed=1000 * rank, workload=args.workload, num_frames=frames,
                                        deform=(args.workload == "magicpony" and not args.no_deform),
                                        pose_seed=(rank if args.per_rank_poses else 0))
@@ -517,12 +529,12 @@ def main():
         covered_per_rank, ranks = [int(v) for v in t.tolist()], dist.get_world_size()
 
     if rank == 0:
-        what = {"magicpony": "train_magicpony_horse-like synthetic step: DMTet(Kuhn R=%d)+deformation+LBS(20 bones)+3x make_mesh+raster/interp/antialias "
-                             "+ SDF/texture/DINO/light/deform MLPs + photometric/mask/DINO losses + regularisers, fwd+bwd+Adam" % args.grid_res,
-                "fauna": "train_fauna per-rank synthetic step: conditioned SDF (CoordMLP_Mod, 128-d embedding) + DMTet(Kuhn R=%d) + bones re-estimated "
-                         "every iteration (bone_y_threshold 0.4) + LBS + main render + random-view mask render + losses, fwd+bwd+Adam" % args.grid_res,
-                "ponymation": "train_ponymation stage-2-like synthetic step with rendering: DMTet(Kuhn R=%d) + [B,F] LBS + B*F frames rendered with "
-                              "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % args.grid_res}[args.workload]
+        what = {"magicpony": "train_magicpony_horse-like synthetic step: DMTet(%s)+deformation+LBS(20 bones)+3x make_mesh+raster/interp/antialias "
+                             "+ SDF/texture/DINO/light/deform MLPs + photometric/mask/DINO losses + regularisers, fwd+bwd+Adam" % grid_name(args),
+                "fauna": "train_fauna per-rank synthetic step: conditioned SDF (CoordMLP_Mod, 128-d embedding) + DMTet(%s) + bones re-estimated "
+                         "every iteration (bone_y_threshold 0.4) + LBS + main render + random-view mask render + losses, fwd+bwd+Adam" % grid_name(args),
+                "ponymation": "train_ponymation stage-2-like synthetic step with rendering: DMTet(%s) + [B,F] LBS + B*F frames rendered with "
+                              "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % grid_name(args)}[args.workload]
         line = {
             "metric": "train images/sec fwd+bwd @256x256 b16" if train else "test images/sec forward only @256x256 b8 (BASELINE configs[1])",
             "value": round(images / elapsed, 3),
@@ -540,12 +552,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
-                       "resolution": [args.resolution, args.resolution], "grid": f"kuhn{args.grid_res}", "parallelism": f"dp{world}",
+                       "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
                        "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)",
                        "per_rank_data": ("per-rank poses/cameras, image features and targets (covered pixels differ per rank)" if args.per_rank_poses else
                                          "same poses/cameras on every rank (equal work per GPU: covered-pixel imbalance across ranks is NOT in this "
                                          "figure), per-rank image features and targets")},
+            # (scalars lifted to the top level so that a record that keeps only top-level scalars still has them)
+            "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None),
+            "in_scope_us_per_step": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["us_per_step"],
+            "in_scope_frac": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["frac"],
+            "in_scope_calls_per_step": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["entry_point_calls_per_step"],
+            "dropin_images_per_s": None if dropin is None else dropin["value"],
+            "parity_pass": None if parity is None else bool(parity.get("pass")),
             "roofline": roofline,
             "host_syncs": host_syncs,
             "parity": parity,

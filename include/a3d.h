@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 308 = this header */
+int a3d_version(void); /* 400 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -68,6 +68,27 @@ int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets,
 int a3d_dmtet_word_group_slots(void);
 int a3d_dmtet_word_group_bits(void);
 int a3d_dmtet_block_items(void);
+/* The culled count pass for a grid in ANY numbering (a file from an external mesher: the reference's data/tets/{128,256}_tets.npz,
+ * /root/reference/model/geometry/dmtet.py:214-226, data/tets/generate_tets.py:31-47).  The output order of DMTet is defined by the file's
+ * numbering (vertex = rank of its crossing edge in the sorted `edges`, faces in `tets` order: dmtet.py:115-121,140-143), but on such a
+ * grid 64 consecutive rows are anywhere in space and the word groups above cull nothing.  So the caller ranks the vertices along a
+ * space-filling curve once (static per grid) and hands over the rows rewritten in ranks, each with the row it came from; the pass
+ * evaluates signs and culls in THAT order and sets the crossing / case bits at the rows of the ORIGINAL order.  Same scratch contents
+ * as a3d_dmtet_count leaves (no block lists: counts[4] = counts[5] = -1), same counts, same a3d_dmtet_emit afterwards, same output bits. */
+typedef struct a3d_dmtet_order {
+    uint32_t size;                 /* sizeof(a3d_dmtet_order) of the caller's header (fields are only ever appended) */
+    int32_t group_slots;           /* slots per row of edge_groups / tet_groups: 8 or 16 */
+    const int32_t* vertex_of_rank; /* [Nv]   grid vertex at rank r (a permutation) */
+    const int32_t* edges_ranked;   /* [Ne,2] the rows of `edges` with both entries replaced by ranks, in any row order (best: sorted) */
+    const int32_t* edge_of_row;    /* [Ne]   row of `edges` that edges_ranked[i] came from */
+    const int32_t* tets_ranked;    /* [Nt,4] the rows of `tets` in ranks, corner order KEPT (the case index depends on it), any row order */
+    const int32_t* tet_of_row;     /* [Nt]   row of `tets` that tets_ranked[i] came from */
+    const uint32_t* edge_groups;   /* word groups (see a3d_dmtet_count) of edges_ranked, group_slots per row */
+    const uint32_t* tet_groups;    /* ... of tets_ranked */
+} a3d_dmtet_order;
+int a3d_dmtet_count_ordered(const float* sdf, int Nv, int Ne, int Nt, const a3d_dmtet_order* order, void* scratch /*16-byte aligned*/,
+                            int32_t* counts /*[6]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean,
+                            int32_t* words_to_clear_or_null, int n_words_to_clear, a3d_stream_t stream);
 /* (Nv = number of grid vertices, or 0 if unknown.  Grids of >= 2^20 vertices take a pre-pass that leaves one sign bit per vertex in
  * scratch; the count pass then looks signs up there -- a handful of cache lines per wave instead of one per 32 vertices -- and streams
  * its index rows with four rows per lane in flight.  Same bit planes and counts either way.) */
@@ -76,6 +97,27 @@ int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, con
                    void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
                    int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
                    int n_edge_blocks_listed, int n_tet_blocks_listed, const int32_t* device_counts_or_null, a3d_stream_t stream);
+/* The emit launch for SPARSE planes -- after a3d_dmtet_count_ordered, where the surface items of a randomly numbered grid are spread
+ * evenly over the planes (one or two per 1024-row block at the "256" class) and a work-group per block is all latency: thread = 64-row
+ * word of a plane instead.  Same outputs as a3d_dmtet_emit, bit for bit; `scratch` must come from a3d_dmtet_count_ordered (whose scan
+ * launch also leaves the in-block prefixes of the tet planes, which this launch reads).  The optional groups of a3d_dmtet_emit travel in
+ * a struct (same meaning, see there): */
+typedef struct a3d_dmtet_emit_opts {
+    uint32_t size;                /* sizeof(a3d_dmtet_emit_opts) of the caller's header (fields are only ever appended) */
+    int32_t Nv;                   /* grid vertices (needed with vertex_scratch / g_sdf_to_clear) */
+    void* vertex_scratch;         /* the flagged-vertex plane of the count call, or NULL */
+    int64_t* surf_idx;            /* [n_surf] sorted list of the flagged vertices (with vertex_scratch) */
+    float* g_sdf_to_clear;        /* [Nv] zeroed by the launch, or NULL */
+    int32_t* tri32;               /* [F,3] int32 copy of faces, or NULL (with topo_count) */
+    int32_t* topo_count;          /* [>= V] valence counters, zero on entry */
+    int32_t* topo_adj;            /* [V * topo_stride] vertex -> face lists, or NULL */
+    const int32_t* device_counts; /* speculative launch: `counts` of the count call, still on the device; V, n1 (= F), n_surf are capacities */
+    int32_t n_surf;
+    int32_t topo_stride;
+} a3d_dmtet_emit_opts;
+int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
+                          const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
+                          const a3d_dmtet_emit_opts* opts_or_null, a3d_stream_t stream);
 /* n_*_blocks_listed = counts[4], counts[5] of the a3d_dmtet_count call that filled `scratch`: with the culled count pass (word groups)
  * the blocks that hold a crossing edge / a surface tet are listed there and the emit launch covers those alone (~5 % of the grid's
  * blocks); -1, -1 (what the plain count pass reports) = every block.

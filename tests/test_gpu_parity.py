@@ -96,7 +96,7 @@ def _extract_all(ops, pos, sdf, topo):
     return [x.cpu() for x in (v, f, u, ve, idx)]
 
 
-@pytest.mark.parametrize("grid", ["kuhn7", "kuhn24", "kuhn40", "kuhn64", "bcc", "delaunay"])
+@pytest.mark.parametrize("grid", ["kuhn7", "kuhn24", "kuhn40", "kuhn64", "bcc", "delaunay", "kuhn20s"])
 def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypatch):
     """a3d_dmtet_count with the per-grid word groups (sign-plane pre-pass, words whose vertex groups all lie on one side of the surface
     are never read) against the same entry without them: every output of the extraction bit for bit -- smooth surfaces (most words
@@ -104,7 +104,10 @@ def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypat
     outside vertex in a full grid; nothing inside; everything inside."""
     a3d_pkg = importlib.import_module("3danimals_amd")
     monkeypatch.setattr(ops, "DMTET_CULL_MIN_VERTS", 0)  # (small grids normally keep the plain pass)
-    if grid.startswith("kuhn"):
+    if grid == "kuhn20s":  # a Kuhn grid in a random numbering
+        p, t = a3d_pkg.tetgrid.scramble(*a3d_pkg.tetgrid.kuhn_grid(20), 11)
+        pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    elif grid.startswith("kuhn"):
         pos, tets = kuhn(int(grid[4:]))
     elif grid == "bcc":
         p, t = a3d_pkg.tetgrid.bcc_grid(9, seed=2)
@@ -114,10 +117,16 @@ def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypat
         pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
     pos = pos.to(dev)
     T = mods["dmtet"].TetGridTopology
-    culled, plain = T(tets.to(dev)), T(tets.to(dev))
-    plain.WORD_GROUPS = False
-    assert plain.word_groups() is None
-    if grid.startswith("kuhn"):
+    # culled: what the grid picks by itself (its own row order where that is spatial, else the ranked lists); ordered: the ranked lists
+    # forced (a3d_dmtet_count_ordered, also on the Kuhn grids); plain: no tables at all
+    culled, ordered, plain = T(tets.to(dev)), T(tets.to(dev), positions=pos), T(tets.to(dev))
+    plain.WORD_GROUPS = plain.SPATIAL_ORDER = ordered.WORD_GROUPS = False
+    assert plain.word_groups() is None and plain.count_pass(positions=pos) == "plain" and ordered.count_pass() == "ordered"
+    spatial = grid.startswith("kuhn") and not grid.endswith("s")
+    assert culled.count_pass(positions=pos) == ("culled" if spatial else "ordered")
+    eo, to = (ordered.spatial_order()[1][k] for k in ("edge_groups", "tet_groups"))
+    assert (eo[:-16, 0] >= 0).float().mean() > 0.9 and (to[:-16, 0] >= 0).float().mean() > 0.9  # 16 slots hold (nearly) every word of the ranked lists
+    if spatial:
         e, t = culled.word_groups()  # the cull is live on these grids: (nearly) every word that holds rows has <= 8 groups
         assert (e[:-16, 0] >= 0).float().mean() > 0.95 and (t[:-16, 0] >= 0).float().mean() > 0.95
     Nv = pos.shape[0]
@@ -135,9 +144,11 @@ def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypat
     for name, sdf in sdfs.items():
         if sdf is None:
             continue
-        a, b = _extract_all(ops, pos, sdf, culled), _extract_all(ops, pos, sdf, plain)
-        for x, y in zip(a, b):
+        a, b, c = _extract_all(ops, pos, sdf, culled), _extract_all(ops, pos, sdf, plain), _extract_all(ops, pos, sdf, ordered)
+        assert (culled._last_count_pass, plain._last_count_pass, ordered._last_count_pass) == (culled.count_pass(), "plain", "ordered")
+        for x, y, z in zip(a, b, c):
             assert x.shape == y.shape and torch.equal(x, y), (grid, name)
+            assert x.shape == z.shape and torch.equal(x, z), (grid, name, "ordered")
         if name.startswith("one_in"):
             assert a[0].shape[0] > 0, (grid, name)
 
@@ -156,6 +167,43 @@ def test_dmtet_matches_oracle_larger(res, kind, dev, mods):
     assert np.array_equal(faces.cpu().numpy(), rf.numpy()) and np.array_equal(uv_idx.cpu().numpy(), ru.numpy())
     assert np.array_equal(verts.detach().cpu().numpy(), rv.numpy())
     # gradients w.r.t. sdf AND pos against autograd through the oracle
+    sdf_c, pos_c = sdf.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    rv2, _, _, _ = dmtet_ref.marching_tets(pos_c, sdf_c, tets)
+    wgt = seeded(rv.shape, 5, -1, 1)
+    gs_ref, gp_ref = torch.autograd.grad((rv2 * wgt).sum(), [sdf_c, pos_c])
+    gs, gp = torch.autograd.grad((verts * wgt.to(dev)).sum(), [sdf_d, pos_d])
+    np.testing.assert_allclose(gs.cpu().numpy(), gs_ref.numpy(), rtol=2e-4, atol=2e-4 * float(gs_ref.abs().max()))
+    np.testing.assert_allclose(gp.cpu().numpy(), gp_ref.numpy(), rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("grid,kind,want", [("bcc51s", "quadruped", "ordered"), ("bcc51s", "noise", "ordered"), ("bcc102s", "quadruped", "ordered"),
+                                            ("kuhn128", "quadruped", "culled")])
+def test_dmtet_on_the_reference_grid_classes_at_real_size_matches_the_oracle(grid, kind, want, dev, mods):
+    """DMTet.__call__ against oracle/dmtet_ref (sort + unique, the reference's own formulation: dmtet.py:104-155) on grids of the size and
+    KIND the reference trains on -- data/tets/{128,256}_tets.npz are Quartet BCC-derived meshes in an external mesher's numbering
+    (dmtet.py:214-226, generate_tets.py:31-47): bcc51s = 2.7e5 vertices / 1.6e6 tets, bcc102s = 2.2e6 / 1.3e7, randomly numbered,
+    rows shuffled, row entries permuted -- and on the Kuhn R = 128 grid: faces / uv_idx / verts bit for bit, d/dsdf and d/dpos against
+    autograd through the oracle; the count pass that ran is asserted ('ordered' = a3d_dmtet_count_ordered + a3d_dmtet_emit_sparse)."""
+    from oracle import dmtet_ref
+
+    tg = importlib.import_module("3danimals_amd.tetgrid")
+    p, t, _ = tg.named_grid(grid)
+    pos, tets = torch.from_numpy(p), torch.from_numpy(t).long()
+    scale = 7.0 / float((pos.amax(0) - pos.amin(0)).max())
+    if kind == "quadruped":
+        sdf = mods["synthetic"].quadruped_sdf(pos * scale, 0.2, noise=0.002, seed=3)
+    else:  # white noise: half the edges cross (nothing to cull; V ~ 9e5, F ~ 2e6)
+        sdf = torch.randn(pos.shape[0], generator=torch.Generator().manual_seed(11))
+    rv, rf, _, ru = dmtet_ref.marching_tets(pos, sdf, tets)
+    assert rf.shape[0] > 8000
+    sdf_d, pos_d = sdf.to(dev).requires_grad_(True), pos.to(dev).requires_grad_(True)
+    dm = mods["dmtet"].DMTet()
+    tets_d = tets.to(dev)
+    for it in range(2):  # (the second extraction takes the speculative emit: sizes guessed from the first)
+        verts, faces, _, uv_idx = dm(pos_d, sdf_d, tets_d)
+        assert dm.topology(tets_d)._last_count_pass == want
+        assert np.array_equal(faces.cpu().numpy(), rf.numpy()) and np.array_equal(uv_idx.cpu().numpy(), ru.numpy()), it
+        assert np.array_equal(verts.detach().cpu().numpy(), rv.numpy()), it
     sdf_c, pos_c = sdf.clone().requires_grad_(True), pos.clone().requires_grad_(True)
     rv2, _, _, _ = dmtet_ref.marching_tets(pos_c, sdf_c, tets)
     wgt = seeded(rv.shape, 5, -1, 1)
@@ -956,9 +1004,19 @@ def test_workload_steps_vs_oracle_step(workload, kw, dev):
     _gradients_close(pairs)
 
 
-@pytest.mark.parametrize("workload,kw,n", [("magicpony", dict(deform=True), 16), ("fauna", {}, 16), ("ponymation", dict(num_frames=8, batch=8), 64)])
+@pytest.mark.parametrize("workload,kw,n", [
+    ("magicpony", dict(deform=True), 16), ("fauna", {}, 16), ("ponymation", dict(num_frames=8, batch=8), 64),
+    # round 4: the reference's real grid class at its real size -- a BCC lattice (Quartet's family) of the "128" class in a random
+    # numbering (dmtet.py:214-226, data/tets/generate_tets.py:31-47): the ordered count pass + the sparse emit inside the step
+    ("magicpony", dict(deform=True, grid="bcc51s"), 16),
+    # BASELINE configs[1] (test_magicpony_horse.yaml:14: forward only, batch 8) at both grid classes, and the training step at the
+    # "256" class (config/model/magicpony.yaml:31-33: grid_res 256 ~ Kuhn R = 128); 2-image oracle sample at R = 128, as bench.py does
+    ("magicpony", dict(deform=True, batch=8, forward_only=True), 8),
+    ("magicpony", dict(deform=True, batch=8, forward_only=True, grid_res=128), 2),
+    ("magicpony", dict(deform=True, grid_res=128), 2),
+], ids=["magicpony", "fauna", "ponymation", "magicpony-bcc51s", "magicpony-fwd-b8", "magicpony-fwd-b8-grid128", "magicpony-grid128"])
 def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
-    """BASELINE configs 3 / 4 / 5 at FULL size (batch 16 resp. 8 sequences x 8 frames, 256x256, Kuhn R=64 grid, the networks at the
+    """BASELINE configs 2 / 3 / 4 / 5 at FULL size (batch 16 resp. 8 sequences x 8 frames, 256x256, Kuhn R=64 grid, the networks at the
     reference's sizes), fixed weights (no optimiser step before the check): every stage of the step re-done by the CPU oracle from the
     HIP output of the stage before it (oracle/check.py) -- index buffers bit-exact, triangle ids bit-exact on the same clip-space
     vertices, every rendered buffer ('shaded', 'dino_pred', 'flow', the random-view mask) within 1e-4 absolute with NO pixel excluded."""
@@ -966,11 +1024,19 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
 
     pipeline = importlib.import_module("3danimals_amd.pipeline")
     kw = dict(kw)
-    scene = pipeline.SyntheticScene(grid_res=64, batch=kw.pop("batch", 16), resolution=(256, 256), device=dev, seed=0, workload=workload, **kw)
-    out = scene.step(backward=True, optimizer_step=False)
+    forward_only = kw.pop("forward_only", False)
+    scene = pipeline.SyntheticScene(grid_res=kw.pop("grid_res", 64), batch=kw.pop("batch", 16), resolution=(256, 256), device=dev, seed=0,
+                                    workload=workload, **kw)
+    want_pass = {"bcc51s": "ordered"}.get(kw.get("grid"), "culled")
+    out = scene.step(backward=not forward_only, optimizer_step=False)
+    assert scene.netShape.topology._last_count_pass == want_pass
     rep = check.compare_step(scene, out, n_images=n, end_to_end=False)
     assert rep["faces_equal"] and rep["num_faces"] > 8000, rep
-    assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 5e-6 and rep["max_abs_posed_normal_err"] < 2e-5, rep
+    assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 5e-6, rep
+    # vertex normals: within 2e-5 of the float32 oracle, or -- on the BCC surface, whose sliver triangles make some sums ill-conditioned
+    # (1e-4 between ANY two float32 summation orders) -- as close to the float64 result as the oracle's own float32 is
+    n64 = rep["posed_normal_err_vs_float64"]
+    assert rep["max_abs_posed_normal_err"] < 2e-5 or (kw.get("grid") and n64["hip"] <= 1.5 * n64["oracle_float32"] + 1e-5), (rep["max_abs_posed_normal_err"], n64)
     assert rep["raster_ids_equal"] and rep["raster"]["max_abs_err"] <= 2e-6, rep["raster"]
     assert rep["gbuffer"]["max_abs_err"] < 1e-5, rep["gbuffer"]
     assert set(rep["images"]) >= {"shaded", "dino_pred"} | ({"flow"} if workload == "ponymation" else set()) | ({"mask_random"} if workload == "fauna" else set())

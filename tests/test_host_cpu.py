@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 308
+    assert lib.a3d_version() == L.ABI_VERSION == 400
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -528,3 +528,79 @@ def test_bench_credits_ride_along_work_to_the_call_that_carries_it():
     streamed = ab("a3d_dmtet_count", d)
     culled = ab("a3d_dmtet_count", {**d, "dm_words_read": (1130, 29251, 980, 24576)})
     assert streamed > 42e6 and 5e6 < culled < 7e6
+
+
+# ------------------------------------------------------------------------------------------------ DMTet count in any numbering
+@pytest.mark.parametrize("grid", ["bcc6s", "delaunay", "kuhn9s", "kuhn9"])
+def test_spatial_order_tables_reproduce_the_planes_of_the_file_order(grid):
+    """The static tables of a3d_dmtet_count_ordered (TetGridTopology.spatial_order), replayed on the CPU by the kernel's own rule: signs
+    looked up by rank, words culled by their groups, crossing / case bits scattered to the row each ranked row came from -- must give
+    the crossing flags and marching-tets cases of the file's own `edges` / `tets` order for every SDF, and a culled word must hold
+    no crossing.  Also: the tables are permutations, the corner order of a tet row survives the ranking."""
+    import importlib
+
+    tg = importlib.import_module("3danimals_amd.tetgrid")
+    dm = importlib.import_module("3danimals_amd.model.geometry.dmtet")
+    if grid == "bcc6s":
+        pos, tets = tg.bcc_grid(6, seed=3)
+    elif grid == "delaunay":
+        pos, tets = tg.delaunay_grid(400, seed=1)
+    else:
+        pos, tets = tg.kuhn_grid(9)
+        if grid.endswith("s"):
+            pos, tets = tg.scramble(pos, tets, 5)
+    topo = dm.TetGridTopology(torch.from_numpy(tets), positions=torch.from_numpy(pos))
+    struct, t = topo.spatial_order()
+    nv, ne, nt = topo.num_verts, topo.edges32.shape[0], topo.tets32.shape[0]
+    assert struct.size == ctypes.sizeof(struct) and struct.group_slots == 16 and struct.edge_groups == t["edge_groups"].data_ptr()
+    vor, eor, tor = t["vertex_of_rank"].long(), t["edge_of_row"].long(), t["tet_of_row"].long()
+    for perm, n in ((vor, nv), (eor, ne), (tor, nt)):
+        assert torch.equal(perm.sort().values, torch.arange(n))
+    assert torch.equal(vor[t["tets_ranked"].long()], topo.tets32.long()[tor])  # corner order kept
+    assert torch.equal(vor[t["edges_ranked"].long()].sort(1).values, topo.edges32.long()[eor])
+    # neighbouring ranks are neighbouring in space: the point of the ranking (mean step along the curve << the grid's extent)
+    p = torch.from_numpy(pos)[vor]
+    assert (p[1:] - p[:-1]).norm(dim=1).mean() < 0.25 * float((p.amax(0) - p.amin(0)).max())
+    g = torch.Generator().manual_seed(7)
+    centre = torch.from_numpy(pos).mean(0)
+    sdfs = [0.3 - (torch.from_numpy(pos) - centre).norm(dim=1), torch.randn(nv, generator=g), -torch.ones(nv), torch.ones(nv)]
+    one = -torch.ones(nv)
+    one[nv // 3] = 1.0
+    sdfs += [one, -one]
+    culled_any = False
+    for sdf in sdfs:
+        inside = sdf > 0
+        sign_r = inside[vor]  # the sign plane, in rank order
+        pad = (-nv) % 16
+        field = torch.cat([sign_r, torch.zeros(pad, dtype=torch.bool)]).reshape(-1, 16)
+        state = torch.where(field.all(1), 2, torch.where(field.any(1), 1, 0))
+        for rows, of_row, groups, want in (
+                (t["edges_ranked"].long(), eor, t["edge_groups"].long(), (inside[topo.edges32.long()[:, 0]] != inside[topo.edges32.long()[:, 1]]).long()),
+                (t["tets_ranked"].long(), tor, t["tet_groups"].long(), (inside[topo.tets32.long()] * torch.tensor([1, 2, 4, 8])).sum(1))):
+            n = rows.shape[0]
+            st = torch.where(groups >= 0, state[groups.clamp(min=0)], torch.ones_like(groups))
+            skip = ((st == 0).all(1) | (st == 2).all(1))[: -(-n // 64)]
+            read = (~skip).repeat_interleave(64)[:n]
+            s = sign_r[rows]
+            val = (s[:, 0] != s[:, 1]).long() if rows.shape[1] == 2 else (s * torch.tensor([1, 2, 4, 8])).sum(1)
+            if rows.shape[1] == 4:
+                val = torch.where(val == 15, 0, val)  # (all four inside: no bit is set, the emit reads it as case 0 -- no triangle either way)
+                want = torch.where(want == 15, 0, want)
+            got = torch.zeros(n, dtype=torch.long)
+            got[of_row[read]] = val[read]
+            assert torch.equal(got, want), grid
+            culled_any |= bool(skip.any())
+    assert culled_any
+
+
+@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts")])
+def test_abi_structs_match_the_header_field_for_field(struct, cls):
+    """The option structs of include/a3d.h against their ctypes mirrors: names, order, pointer / int32 / uint32 kind; `size` first."""
+    L = importlib.import_module("3danimals_amd._lib")
+    header = open(os.path.join(ROOT, "include", "a3d.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [(re.sub(r"\s+", " ", d.strip()).rsplit(" ", 1)) for d in body.split(";") if d.strip()]
+    kinds = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32}
+    want = [(name.lstrip("*"), ctypes.c_void_p if "*" in decl + name else kinds[decl]) for decl, name in fields]
+    assert [(n, t) for n, t in getattr(L, cls)._fields_] == want and want[0] == ("size", ctypes.c_uint32)

@@ -1,35 +1,46 @@
-"""Event-timed a3d_dmtet_count / a3d_dmtet_emit on the synthetic grids: culled against plain count pass.
+"""Event-timed a3d_dmtet_count / whole extraction (count + emit + read-back) on synthetic grids.
 
-    python tools/bench_dmtet.py [--res 64 128] [--iters 50]
+    python tools/bench_dmtet.py [--grid kuhn64 kuhn128 bcc51s bcc102s] [--iters 50] [--surf]
+
+``kuhnR``: the spatially numbered Kuhn grid of R^3 cells; ``bccR``: the BCC lattice (Quartet's family) in its generator's numbering;
+``bccRs``: the same with a random vertex numbering, shuffled rows and permuted row entries -- the numbering an external mesher's file
+has (the reference's data/tets/{128,256}_tets.npz: bcc51s ~ the "128" class, bcc102s ~ the "256" class).
+Every line says which count pass ran (``dmtet_pass``).
 """
 import argparse
 import importlib
-import sys
+import json
 import os
+import re
+import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def make_grid(name, tetgrid):
+    return tetgrid.named_grid(name)[:2]
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--res", type=int, nargs="+", default=[64, 128])
+    ap.add_argument("--grid", nargs="+", default=["kuhn64", "kuhn128"])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--surf", action="store_true")
     ap.add_argument("--sdf", default="quadruped", choices=["quadruped", "ellipsoid", "none", "noise"])
+    ap.add_argument("--passes", nargs="+", default=["plain", "auto"], help="plain: no static tables; ordered: the ranked lists forced; auto: what ops.dmtet_extract picks")
+    ap.add_argument("--json", default=None)
     args = ap.parse_args()
     a3d = importlib.import_module("3danimals_amd")
     ops = importlib.import_module("3danimals_amd.ops")
     dm = importlib.import_module("3danimals_amd.model.geometry.dmtet")
     syn = importlib.import_module("3danimals_amd.synthetic")
-    _lib = importlib.import_module("3danimals_amd._lib")
     dev = torch.device("cuda:0")
-    ops.DMTET_CULL_MIN_VERTS = 0
-    for res in args.res:
-        p, t = a3d.tetgrid.kuhn_grid(res)
+    records = []
+    for name in args.grid:
+        p, t = make_grid(name, a3d.tetgrid)
         pos, tets = torch.from_numpy(p).to(dev), torch.from_numpy(t).long().to(dev)
-        topo = dm.TetGridTopology(tets)
         scale = 7.0 / float((pos.amax(0) - pos.amin(0)).max())
         if args.sdf == "quadruped":
             sdf = syn.quadruped_sdf((pos * scale).cpu(), 0.2, noise=0.0)
@@ -40,40 +51,43 @@ def main():
         else:
             sdf = torch.randn(pos.shape[0])
         sdf = sdf.to(dev).contiguous().float()
-        if groups_stats := topo.word_groups():
-            sign16 = (sdf > 0).cpu()
-            pad = (-sign16.shape[0]) % 16
-            f = torch.cat([sign16, torch.zeros(pad, dtype=torch.bool)]).reshape(-1, 16)
-            state = torch.where(f.all(1), 2, torch.where(f.any(1), 1, 0))  # 0 out, 2 in, 1 mixed
-            for name, tab in zip(("edge", "tet"), groups_stats):
-                tab = tab.cpu().long()
-                st = torch.where(tab >= 0, state[tab.clamp(min=0)], torch.ones_like(tab))
-                skip = ((st == 0).all(1) | (st == 2).all(1)).reshape(-1, 16)
-                print(f"R={res} {name} words skipped {skip.float().mean():.4f}, blocks fully skipped {skip.all(1).float().mean():.4f}")
-        Ne, Nt, Nv = topo.edges32.shape[0], topo.tets32.shape[0], pos.shape[0]
-        scratch = torch.empty(_lib.lib().a3d_dmtet_scratch_bytes(Ne, Nt), dtype=torch.uint8, device=dev)
-        counts = torch.empty(6, dtype=torch.int32, device=dev)
-        groups = topo.word_groups()
-        # --surf: with the bit plane of the surface-adjacent grid vertices (the count call's fourth scan work-group), as the training step
-        vscratch = torch.zeros(_lib.lib().a3d_dmtet_vertex_scratch_bytes(Nv), dtype=torch.uint8, device=dev) if args.surf else None
-        for label, gr in (("plain", None), ("culled", groups)):
-            if label == "culled" and gr is None:
-                continue
+        for label in args.passes:
+            topo = dm.TetGridTopology(tets, positions=pos)
+            if label == "plain":
+                topo.WORD_GROUPS = topo.SPATIAL_ORDER = False
+            elif label == "ordered":
+                topo.WORD_GROUPS = False
+            Ne, Nt, Nv = topo.edges32.shape[0], topo.tets32.shape[0], pos.shape[0]
 
-            def run():
-                ops.call("a3d_dmtet_count", ops.ptr(sdf), ops.ptr(topo.edges32), ops.ptr(topo.tets32), Ne, Nt, ops.ptr(scratch), ops.ptr(counts),
-                         ops.ptr(vscratch), 1, Nv, ops.ptr(gr[0]) if gr else None, ops.ptr(gr[1]) if gr else None, None, 0, ops.stream())
+            def extract():
+                return ops.dmtet_extract(pos, sdf, topo, surface_vertices=args.surf, for_backward=args.surf)
 
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-            print(f"R={res} Nv={Nv} Ne={Ne} Nt={Nt} count[{label}]: {1e3 * e0.elapsed_time(e1) / args.iters:.1f} us  counts={counts.tolist()}", flush=True)
+            out = extract()
+            which = topo.count_pass()
+            rec = dict(grid=name, Nv=Nv, Ne=Ne, Nt=Nt, requested=label, dmtet_pass=which, V=int(out[0].shape[0]), F=int(out[1].shape[0]))
+            for what, fn in (("count", lambda: ops.dmtet_count_only(pos, sdf, topo, surface_vertices=args.surf)), ("extract", extract)):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                rec[what + "_us"] = round(1e3 * e0.elapsed_time(e1) / args.iters, 1)
+            _lib = importlib.import_module("3danimals_amd._lib")
+            with _lib.KernelTimer() as kt:  # per entry point, live HIP events (what bench.py reports)
+                for _ in range(args.iters):
+                    extract()
+            rec["entry_us"] = {k: round(1e3 * ms, 1) for k, (n, ms) in kt.summary().items()}
+            if (wr := topo.words_read(sdf)) is not None:
+                rec["words_read"] = dict(edge=wr[0], edge_words=wr[1], tet=wr[2], tet_words=wr[3])
+            print(json.dumps(rec), flush=True)
+            records.append(rec)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(records, f, indent=1)
 
 
 if __name__ == "__main__":
