@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
     }
 }
 
-extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * 16; }
+extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * (8 + 4 * AA_VALS); }
 
 extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int32_t* opp, a3d_stream_t stream) {
     A3D_CHECK_ARG(F >= 0 && V > 0);
@@ -556,7 +556,7 @@ extern "C" int a3d_aa_topology(const int32_t* tri, int F, int V, void* hash, int
     unsigned long long* keys = (unsigned long long*)hash;
     int* vals = (int*)(keys + n);
     A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * n, s));
-    A3D_HIP(hipMemsetAsync(vals, 0x7F, sizeof(int) * 2 * (size_t)n, s));
+    A3D_HIP(hipMemsetAsync(vals, 0x7F, sizeof(int) * AA_VALS * (size_t)n, s));
     hipLaunchKernelGGL(aa_hash_insert_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, n - 1, keys, vals);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(aa_hash_lookup_kernel, dim3(a3d_div_up(3ll * F, 256)), dim3(256), 0, s, tri, F, n - 1, keys, vals, opp);

@@ -804,8 +804,8 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
 // The emit launch for SPARSE planes (the ordered count pass: the ~1 % surface items of a grid in a random numbering are spread evenly
 // over the planes -- at the "256" class 1.5 crossing edges per 1024-edge block -- so every block holds something, a list of non-empty
 // blocks saves nothing, and a work-group per block is 27k work-groups that each run a chain of five dependent gathers for one or two
-// items: 62 us).  Thread = WORD of a plane: the word loads of a wave are one coalesced read, a thread whose word is empty (9 in 10) is
-// done, the others walk their one to three set bits; the in-block prefixes come from the scan launch (wlocal; tlocal = the same
+// items: 62 us).  Thread = WORD of a plane: the word loads of a wave are one coalesced read, a work-group whose 256 words are all empty
+// is done, the others pool their set bits (see below); the in-block prefixes come from the scan launch (wlocal; tlocal = the same
 // for the one- / two-triangle tets, packed 16 + 16 bits).  The grid does not depend on the counts, so the speculative form (sizes
 // from dev_counts) needs no block capacities.
 __global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* __restrict__ pos, const float* __restrict__ sdf,
@@ -822,7 +822,9 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* 
                                                                    int wg_e, int wg_t, int nvc, const int* __restrict__ dev_counts, int cap_V,
                                                                    int cap_F, int cap_surf) {
     __shared__ int s_pre[32];
-    const int tid = threadIdx.x;
+    __shared__ unsigned short s_items[DM_THREADS * 64];  // (word of this work-group) << 6 | bit, 32 KB
+    __shared__ int s_wave[DM_THREADS / A3D_WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     bool faces_live = F > 0;
     if (dev_counts) {
         const int dV = dev_counts[0], d1 = dev_counts[1], d2 = dev_counts[2], dS = dev_counts[3];
@@ -837,35 +839,59 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* 
         if (b - wg_e - wg_t < nvc) dm_surface_vertices_chunk(b - wg_e - wg_t, vbits, vchunk, Nv, surf_idx, s_pre);
         return;
     }
-    if (b < wg_e) {
-        const int w = b * DM_THREADS + tid;
-        unsigned long long word = w < nwe ? edge_bits[w] : 0ull;
-        if (!word) return;
-        int vid = blk_e[w >> 4] + wlocal[w];
-        while (word) {
-            const int bit = __ffsll((long long)word) - 1;
-            word &= word - 1ull;
-            dm_place_vertex(64ll * w + bit, vid++, pos, sdf, edges, verts, vert_edge);
-        }
-        return;
+    // The set bits of the work-group's 256 words are POOLED: every thread lists its word's bits in LDS (pure ALU + LDS stores), then
+    // the items are dealt out evenly over the 256 lanes -- a word with forty crossings (a plane in a spatial row order: the surface
+    // sits in a few dense words) costs forty LDS stores instead of forty serial chains of dependent gathers in one lane (125 us on
+    // the BCC lattice in its generator's numbering); on sparse planes the pool is a few dozen items and one round.
+    const bool is_edge = b < wg_e;
+    const int w = (is_edge ? b : b - wg_e) * DM_THREADS + tid;
+    unsigned long long mine = 0ull;  // the bits of this thread's word that are items
+    if (is_edge) {
+        if (w < nwe) mine = edge_bits[w];
+    } else if (w < nwt && faces_live) {
+        const ulonglong2 pa = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w], pb = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w + 1];
+        mine = (pa.x | pa.y | pb.x | pb.y) & ~(pa.x & pa.y & pb.x & pb.y);  // surface tets: neither case 0 nor case 15
     }
-    const int w = (b - wg_e) * DM_THREADS + tid;
-    if (w >= nwt || !faces_live) return;
-    const ulonglong2 pa = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w], pb = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * w + 1];
-    const unsigned long long w0 = pa.x, w1 = pa.y, w2 = pb.x, w3 = pb.y;
-    const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
-    const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
-    unsigned long long mm = m1 | m2;
-    if (!mm) return;
-    const int tl = tlocal[w];
-    int run1 = blk_t1[w >> 4] + (tl & 0xFFFF), run2 = blk_t2[w >> 4] + (tl >> 16);
-    while (mm) {
-        const int bit = __ffsll((long long)mm) - 1;
-        mm &= mm - 1ull;
-        const int cs = (int)((w0 >> bit) & 1ull) | ((int)((w1 >> bit) & 1ull) << 1) | ((int)((w2 >> bit) & 1ull) << 2) | ((int)((w3 >> bit) & 1ull) << 3);
-        const unsigned n = DM_NTRI(cs);
-        const long long slot = (n == 1u) ? (long long)(run1++) : (long long)n1 + 2ll * (run2++);
-        dm_write_faces(64ll * w + bit, cs, n, slot, tet2edge, edge_bits, wlocal, blk_e, faces, uv_idx, tri32, topo_cnt, topo_adj, topo_stride, F);
+    const int c = __popcll(mine);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int off = incl - c, total = 0;
+#pragma unroll
+    for (int k = 0; k < DM_THREADS / A3D_WAVE; ++k) {
+        if (k < wave) off += s_wave[k];
+        total += s_wave[k];
+    }
+    if (total == 0) return;  // (uniform)
+    while (mine) {
+        s_items[off++] = (unsigned short)((tid << 6) | (__ffsll((long long)mine) - 1));
+        mine &= mine - 1ull;
+    }
+    __syncthreads();
+    const int w_base = (is_edge ? b : b - wg_e) * DM_THREADS;
+    for (int j = tid; j < total; j += DM_THREADS) {
+        const int it = s_items[j], wj = w_base + (it >> 6), bit = it & 63;
+        if (is_edge) {
+            const unsigned long long word = edge_bits[wj];
+            dm_place_vertex(64ll * wj + bit, blk_e[wj >> 4] + wlocal[wj] + __popcll(word & ((1ull << bit) - 1ull)), pos, sdf, edges, verts, vert_edge);
+        } else {
+            const ulonglong2 pa = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * wj], pb = reinterpret_cast<const ulonglong2*>(tet_bits)[2ll * wj + 1];
+            const unsigned long long w0 = pa.x, w1 = pa.y, w2 = pb.x, w3 = pb.y;
+            const unsigned long long odd = w0 ^ w1 ^ w2 ^ w3;
+            const unsigned long long m1 = odd, m2 = ~odd & (w0 | w1 | w2 | w3) & ~(w0 & w1 & w2 & w3);
+            const unsigned long long below = (1ull << bit) - 1ull;
+            const int cs = (int)((w0 >> bit) & 1ull) | ((int)((w1 >> bit) & 1ull) << 1) | ((int)((w2 >> bit) & 1ull) << 2) | ((int)((w3 >> bit) & 1ull) << 3);
+            const unsigned n = DM_NTRI(cs);
+            const int tl = tlocal[wj];
+            const long long slot = (n == 1u) ? (long long)(blk_t1[wj >> 4] + (tl & 0xFFFF) + __popcll(m1 & below))
+                                             : (long long)n1 + 2ll * (blk_t2[wj >> 4] + (tl >> 16) + __popcll(m2 & below));
+            dm_write_faces(64ll * wj + bit, cs, n, slot, tet2edge, edge_bits, wlocal, blk_e, faces, uv_idx, tri32, topo_cnt, topo_adj, topo_stride, F);
+        }
     }
 }
 

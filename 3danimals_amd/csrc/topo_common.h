@@ -6,6 +6,7 @@
 
 #define AA_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define AA_NONE 0x7F7F7F7F
+#define AA_VALS 4  // ints per hash slot: lowest code per traversal direction [0..1], minus the highest code per direction [2..3]
 
 static inline unsigned aa_slots(int F) {
     unsigned n = 64;
@@ -20,7 +21,12 @@ __device__ __forceinline__ unsigned aa_hash(unsigned long long k) {
 }
 
 // corner i of face f owns the edge opposite to it, (a, b) = (tri[f][(i+1)%3], tri[f][(i+2)%3]); the table keeps, per undirected edge and
-// per traversal direction, the smallest code f*4+i that claimed it (atomicMin => deterministic)
+// per traversal direction, the smallest AND the largest code f*4+i that claimed it (atomicMin => deterministic).  The neighbour of a
+// face across an edge: the lowest code that traverses it the OTHER way (a consistently wound mesh); else, of the codes that traverse
+// it the SAME way, the lowest that is not the face itself, else the highest that is not (round 4: with the lowest alone, of two
+// faces that traverse a shared edge in the same direction -- a mesh wound inconsistently, e.g. marching tets over a grid file whose
+// tets are not uniformly oriented -- only one found the other, and the other took its interior edges for silhouettes; nvdiffrast's
+// hash stores the first two opposite vertices of an undirected edge whatever the winding)
 __device__ __forceinline__ void aa_insert_edge_ab(int a, int b, int code, unsigned mask, unsigned long long* __restrict__ keys,
                                                   int* __restrict__ vals) {
     if (a == b) return;
@@ -31,7 +37,8 @@ __device__ __forceinline__ void aa_insert_edge_ab(int a, int b, int code, unsign
     for (unsigned probe = 0; probe <= mask; ++probe) {
         const unsigned long long old = atomicCAS(&keys[h], AA_EMPTY_KEY, key);
         if (old == AA_EMPTY_KEY || old == key) {
-            atomicMin(&vals[2 * h + d], code);
+            atomicMin(&vals[AA_VALS * h + d], code);
+            atomicMin(&vals[AA_VALS * h + 2 + d], -code);
             return;
         }
         h = (h + 1) & mask;
@@ -42,6 +49,14 @@ __device__ __forceinline__ void aa_insert_edge(const int* __restrict__ tri, int 
                                                int* __restrict__ vals) {
     const int f = idx / 3, i = idx - 3 * f;
     aa_insert_edge_ab(tri[3 * f + (i + 1) % 3], tri[3 * f + (i + 2) % 3], f * 4 + i, mask, keys, vals);
+}
+
+// the rule above: opposite = lowest code of the other direction, same_lo / same_hi = lowest / highest code (-1: none) of the own direction
+__device__ __forceinline__ int aa_pick_neighbour(int own, int opposite, int same_lo, int same_hi) {
+    if (opposite != AA_NONE) return opposite;
+    if (same_lo != AA_NONE && same_lo != own) return same_lo;
+    if (same_hi >= 0 && same_hi != own) return same_hi;
+    return AA_NONE;
 }
 
 // vertex opposite to corner idx's edge in the adjacent triangle (-1: boundary edge)
@@ -57,11 +72,8 @@ __device__ __forceinline__ int aa_lookup_edge(const int* __restrict__ tri, int i
     for (unsigned probe = 0; probe <= mask; ++probe) {
         const unsigned long long k = keys[h];
         if (k == key) {
-            int other = vals[2 * h + (1 - d)];
-            if (other == AA_NONE) {
-                const int same = vals[2 * h + d];
-                if (same != AA_NONE && same != f * 4 + i) other = same;
-            }
+            const int nhi = vals[AA_VALS * h + 2 + d];
+            const int other = aa_pick_neighbour(f * 4 + i, vals[AA_VALS * h + (1 - d)], vals[AA_VALS * h + d], nhi == AA_NONE ? -1 : -nhi);
             return other != AA_NONE ? tri[3 * (other >> 2) + (other & 3)] : -1;
         }
         if (k == AA_EMPTY_KEY) return -1;
@@ -71,10 +83,10 @@ __device__ __forceinline__ int aa_lookup_edge(const int* __restrict__ tri, int i
 }
 
 // The same answer WITHOUT a hash, from the vertex -> (corner, face) lists (any storage order): every face that holds both end points of
-// the edge is found in a's list; per traversal direction the lowest code f'*4+i' is kept, exactly what the hash's atomicMin leaves.
+// the edge is found in a's list; per traversal direction the lowest and the highest code f'*4+i' are kept, exactly what the hash's atomicMins leave.
 // ~valence x (1 + 3) L2-resident loads: for callers that need a few thousand lookups (the silhouette analysis asks only for pixel
 // pairs that passed every geometric test), not a table for all 3F corners.
-__device__ __forceinline__ void aa_consider_face(int key, int u0, int u1, int u2, int F, int a, int b, int slot[2]) {
+__device__ __forceinline__ void aa_consider_face(int key, int u0, int u1, int u2, int F, int a, int b, int slot[4]) {
     const int c = key >= 2 * F ? 2 : (key >= F ? 1 : 0);  // a sits at corner c of face g
     const int g = key - c * F;
 #pragma unroll
@@ -86,6 +98,7 @@ __device__ __forceinline__ void aa_consider_face(int key, int u0, int u1, int u2
         const int dd = ea < eb ? 0 : 1;
         const int code = g * 4 + io;
         slot[dd] = code < slot[dd] ? code : slot[dd];
+        slot[2 + dd] = code > slot[2 + dd] ? code : slot[2 + dd];
     }
 }
 
@@ -102,7 +115,7 @@ __device__ __forceinline__ int aa_opposite_from_lists(const int* __restrict__ tr
     const int a = tri[3 * f + (i + 1) % 3], b = tri[3 * f + (i + 2) % 3];
     if (a == b) return -1;
     const int d = a < b ? 0 : 1;
-    int slot[2] = {AA_NONE, AA_NONE};
+    int slot[4] = {AA_NONE, AA_NONE, -1, -1};  // lowest code per direction, highest code per direction
     int lo, n;
     vf_list(off, stride, a, lo, n);
     // up to eight entries at once: all keys in flight, then all index rows in flight (two round trips instead of two per entry)
@@ -124,11 +137,7 @@ __device__ __forceinline__ int aa_opposite_from_lists(const int* __restrict__ tr
         const int g = key - c * F;
         aa_consider_face(key, tri[3 * g], tri[3 * g + 1], tri[3 * g + 2], F, a, b, slot);
     }
-    int other = slot[1 - d];
-    if (other == AA_NONE) {
-        const int same = slot[d];
-        if (same != AA_NONE && same != f * 4 + i) other = same;
-    }
+    const int other = aa_pick_neighbour(f * 4 + i, slot[1 - d], slot[d], slot[2 + d]);
     return other != AA_NONE ? tri[3 * (other >> 2) + (other & 3)] : -1;
 }
 

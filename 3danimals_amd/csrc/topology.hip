@@ -20,8 +20,8 @@ __global__ __launch_bounds__(256) void tp_init_kernel(int* __restrict__ cursor, 
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         keys[i] = AA_EMPTY_KEY;
-        vals[2 * i] = AA_NONE;
-        vals[2 * i + 1] = AA_NONE;
+#pragma unroll
+        for (int k = 0; k < AA_VALS; ++k) vals[AA_VALS * i + k] = AA_NONE;
     }
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)V; i += stride) cursor[i] = 0;
 }
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void tp_sort_rearm_kernel(const int* __restric
     }
     for (unsigned i = t; i < n; i += stride) {
         keys[i] = AA_EMPTY_KEY;
-        vals[2 * i] = AA_NONE;
-        vals[2 * i + 1] = AA_NONE;
+#pragma unroll
+        for (int k = 0; k < AA_VALS; ++k) vals[AA_VALS * i + k] = AA_NONE;
     }
 }
 

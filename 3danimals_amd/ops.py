@@ -126,7 +126,7 @@ def mesh_topology(tri32: torch.Tensor, num_vertices: int):
     if clean:
         cursor, scratch = kept
     else:
-        cursor = torch.zeros(max(V, nbytes // 16), dtype=torch.int32, device=tri32.device)  # zero beyond V too: later calls of this F class may have more vertices (V <= 3F < slots)
+        cursor = torch.zeros(max(V, nbytes // 24), dtype=torch.int32, device=tri32.device)  # zero beyond V too: later calls of this F class may have more vertices (V <= 3F < slots)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=tri32.device)
     call("a3d_mesh_topology", ptr(tri32), V, F, ptr(adj.off), ptr(adj.adj), ptr(cursor), ptr(scratch), ptr(topo.opp), int(clean), stream())
     if len(_topology_scratch) >= 4:

@@ -122,14 +122,19 @@ def delaunay_grid(num_points: int, seed: int = 0):
     return scramble(pts.astype(np.float32), tets, seed + 1)
 
 
-def scramble(vertices: np.ndarray, indices: np.ndarray, seed: int):
-    """Renumber the vertices by a random permutation, shuffle the tet rows and permute the four indices inside every row."""
+def scramble(vertices: np.ndarray, indices: np.ndarray, seed: int, renumber: bool = True, shuffle_rows: bool = True):
+    """Renumber the vertices by a random permutation, shuffle the tet rows and permute the four indices inside every row.
+    (``renumber`` / ``shuffle_rows`` False: that step left out -- the same random draws either way -- to tell their effects apart.)"""
     rng = np.random.default_rng(seed)
     perm = rng.permutation(vertices.shape[0])  # new id of old vertex v = perm[v]
+    if not renumber:
+        perm = np.arange(vertices.shape[0])
     out_v = np.empty_like(vertices)
     out_v[perm] = vertices
     idx = perm[indices]
-    idx = idx[rng.permutation(idx.shape[0])]
+    rows = rng.permutation(idx.shape[0])
+    if shuffle_rows:
+        idx = idx[rows]
     order = np.argsort(rng.random(idx.shape), axis=1)
     return out_v, np.take_along_axis(idx, order, axis=1).astype(np.int64)
 
@@ -140,16 +145,17 @@ def named_grid(name: str):
     in the arbitrary numbering such a file has."""
     import re
 
-    m = re.fullmatch(r"(kuhn|bcc|delaunay)(\d+)(s?)", name)
+    m = re.fullmatch(r"(kuhn|bcc|delaunay)(\d+)([svt]?)", name)
     if not m:
-        raise ValueError(f"unknown grid {name!r} (kuhnR, bccR, delaunayN, optional trailing s = scrambled numbering)")
-    kind, res, scr = m.group(1), int(m.group(2)), m.group(3) == "s"
-    if kind == "kuhn":
-        p, t = kuhn_grid(res)
-        return (*(scramble(p, t, 7) if scr else (p, t)), res)
-    if kind == "bcc":
-        return (*bcc_grid(res, seed=7 if scr else None), res)
-    return (*delaunay_grid(res, seed=7), max(2, round(res ** (1 / 3))))
+        raise ValueError(f"unknown grid {name!r} (kuhnR, bccR, delaunayN, optional trailing s = scrambled numbering; v / t = only the "
+                         "vertex numbering / only the tet rows scrambled)")
+    kind, res, scr = m.group(1), int(m.group(2)), m.group(3)
+    if kind == "delaunay":
+        return (*delaunay_grid(res, seed=7), max(2, round(res ** (1 / 3))))
+    p, t = kuhn_grid(res) if kind == "kuhn" else bcc_grid(res)
+    if scr:
+        p, t = scramble(p, t, 7, renumber=scr in "sv", shuffle_rows=scr in "st")
+    return p, t, res
 
 
 def save_tets_npz(path: str, vertices: np.ndarray, indices: np.ndarray) -> None:

@@ -108,10 +108,14 @@ def edge_opposites(tri: np.ndarray) -> np.ndarray:
     """opp[f,i] = vertex opposite edge i of face f in the adjacent face, or -1 (mesh boundary).
 
     Edge i of a face (v0,v1,v2) is the one NOT containing v_i: (v_{i+1}, v_{i+2}).  Each undirected
-    edge keeps, per traversal direction, the lowest (face*4+corner) code that uses it; a face's
-    neighbour across an edge is the entry stored for the opposite direction, else a different face
-    stored for the same direction, else none.  (Specification shared with aa_topology in
-    3danimals_amd/csrc/antialias.hip.)
+    edge keeps, per traversal direction, the lowest and the highest (face*4+corner) code that uses it;
+    a face's neighbour across an edge is the lowest code of the opposite direction, else -- a mesh that
+    is not consistently wound -- a different face of the same direction (the lowest code, or the
+    highest when the face itself is the lowest), else none.  nvdiffrast keeps the first two opposite
+    vertices that arrive for an undirected edge whatever the winding (antialias.cu evhashInsert /
+    evhashFind); on a 2-manifold both rules name the one other face.  (Specification shared with
+    aa_topology in 3danimals_amd/csrc/topo_common.h.  Until round 3 only the lowest code per direction
+    was kept: of two faces traversing a shared edge the same way only one found the other.)
     """
     tri = np.asarray(tri, dtype=np.int64)
     F = tri.shape[0]
@@ -121,9 +125,11 @@ def edge_opposites(tri: np.ndarray) -> np.ndarray:
             a, b = int(tri[f, (i + 1) % 3]), int(tri[f, (i + 2) % 3])
             key, d = ((a, b), 0) if a < b else ((b, a), 1)
             code = f * 4 + i
-            slot = table.setdefault(key, [None, None])
+            slot = table.setdefault(key, [None, None, None, None])
             if slot[d] is None or code < slot[d]:
                 slot[d] = code
+            if slot[2 + d] is None or code > slot[2 + d]:
+                slot[2 + d] = code
     opp = np.full((F, 3), -1, dtype=np.int32)
     for f in range(F):
         for i in range(3):
@@ -134,8 +140,8 @@ def edge_opposites(tri: np.ndarray) -> np.ndarray:
             slot = table[key]
             code = f * 4 + i
             other = slot[1 - d]
-            if other is None and slot[d] is not None and slot[d] != code:
-                other = slot[d]
+            if other is None:
+                other = slot[d] if slot[d] != code else (slot[2 + d] if slot[2 + d] != code else None)
             if other is not None:
                 opp[f, i] = tri[other // 4, other % 4]
     return opp

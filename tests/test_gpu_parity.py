@@ -560,10 +560,19 @@ def test_aa_topology_matches_oracle(dev, ops):
     assert np.array_equal(topo.opp.cpu().numpy(), raster_ref.edge_opposites(cut.numpy()))
     # the same table from the vertex -> face lists (what the silhouette analysis walks when it is given lists instead of a table):
     # degenerate faces, boundary edges and the non-manifold fan included
-    for tri in (faces, cut):
+    # (round 4) ... and the same meshes wound inconsistently: a random half of the faces flipped -- every face still finds its one
+    # neighbour across a manifold edge, through the hash and through the lists
+    flip = torch.rand(faces.shape[0], generator=torch.Generator().manual_seed(2)) < 0.5
+    flipped = torch.where(flip[:, None], faces[:, [0, 2, 1]], faces)
+    assert (raster_ref.edge_opposites(flipped.numpy()) >= 0).all()
+    topo = ops.AATopology(flipped.to(dev).int().contiguous(), int(flipped.max()) + 1)
+    assert np.array_equal(topo.opp.cpu().numpy(), raster_ref.edge_opposites(flipped.numpy()))
+    for tri in (faces, cut, flipped, torch.cat([flipped[: len(faces) // 2], cut[-4:]])):
         tri32 = tri.to(dev).int().contiguous()
         lists = ops.VertexFaceAdjacency(tri32, int(tri.max()) + 1)
         assert np.array_equal(ops.opposite_vertices_from_lists(lists).cpu().numpy(), raster_ref.edge_opposites(tri.numpy()))
+        adj, topo2 = ops.mesh_topology(tri32.clone(), int(tri.max()) + 1)  # (both tables in one entry point: the same hash)
+        assert np.array_equal(topo2.opp.cpu().numpy(), raster_ref.edge_opposites(tri.numpy()))
 
 
 def test_antialias_analysis_from_lists_equals_the_table_based_one(dev, ops):

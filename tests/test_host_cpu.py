@@ -604,3 +604,23 @@ def test_abi_structs_match_the_header_field_for_field(struct, cls):
     kinds = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32}
     want = [(name.lstrip("*"), ctypes.c_void_p if "*" in decl + name else kinds[decl]) for decl, name in fields]
     assert [(n, t) for n, t in getattr(L, cls)._fields_] == want and want[0] == ("size", ctypes.c_uint32)
+
+
+def test_oracle_edge_opposites_do_not_depend_on_the_winding():
+    """On a closed 2-manifold every edge has exactly one other face, whichever way the two traverse it: flipping the winding of any
+    subset of the faces must leave the opposite VERTICES unchanged (as sets per face: the flip permutes a face's own corners)."""
+    from oracle import dmtet_ref
+
+    pos, tets = kuhn(6)
+    sdf = 0.3 - pos.norm(dim=1)
+    _, faces, _, _ = dmtet_ref.marching_tets(pos, sdf, tets)
+    tri = faces.numpy()
+    opp = raster_ref.edge_opposites(tri)
+    assert (opp >= 0).all()
+    rng = np.random.default_rng(0)
+    flip = rng.random(tri.shape[0]) < 0.5
+    tri_f = np.where(flip[:, None], tri[:, [0, 2, 1]], tri)
+    opp_f = raster_ref.edge_opposites(tri_f)
+    assert (opp_f >= 0).all()
+    back = np.where(flip[:, None], opp_f[:, [0, 2, 1]], opp_f)  # corner i of the flipped face = corner (0, 2, 1)[i] of the original
+    assert np.array_equal(back, opp)
