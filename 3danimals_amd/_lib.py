@@ -207,6 +207,33 @@ def require_device(*tensors, what: str = "op"):
             raise A3DError(f"{what}: tensor on {t.device} while the current device is cuda:{cur}; wrap the call in torch.cuda.device(...)")
 
 
+def fp32_region(fn):
+    """The reference calls this path inside torch.autocast when mixed_precision is set (Trainer.py:208-218, AnimalModel.py:382-444) and
+    forces .float() where it enters nvdiffrast (render.py:265,292).  Functions of the path that do their arithmetic in torch (camera /
+    bone algebra: a handful of small matmuls) are wrapped with this: under autocast they run with autocast off on float32 copies of
+    their half-precision tensor arguments, so that the path returns the same float32 results with and without mixed precision --
+    a bf16 clip-space matmul would move vertices by 1e-2 of a pixel.  No effect (one flag test) outside autocast."""
+    import functools
+
+    def cast(x):
+        if torch.is_tensor(x):
+            return x.float() if x.is_floating_point() and x.dtype in (torch.float16, torch.bfloat16) else x
+        if isinstance(x, (list, tuple)):
+            return type(x)(cast(v) for v in x)
+        if isinstance(x, dict):
+            return {k: cast(v) for k, v in x.items()}
+        return x
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        if not torch.is_autocast_enabled():
+            return fn(*args, **kwargs)
+        with torch.autocast("cuda", enabled=False):
+            return fn(*cast(args), **cast(kwargs))
+
+    return wrapped
+
+
 def f32c(t):
     """float32, contiguous (no copy when already so)."""
     if t.dtype != torch.float32:

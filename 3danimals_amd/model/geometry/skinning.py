@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import ops
+from ..._lib import fp32_region
 from . import util  # noqa: F401  (public attribute of the reference module)
 
 
@@ -73,6 +74,7 @@ def _masked_quantiles(x, mask, qs):
 
 # ------------------------------------------------------------------------------------------------ bone estimation
 @torch.no_grad()
+@fp32_region
 def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bones=0, body_bones_mode="z_minmax", compute_kinematic_chain=True,
                    aux=None, attach_legs_to_body=True, legs_to_body_joint_indices=None, bone_y_threshold=None):
     """Heuristic skeleton from the rest-pose vertices (reference :50-248).
@@ -217,6 +219,7 @@ def _axis_angle_rotation(axis: str, angle: torch.Tensor) -> torch.Tensor:
     return torch.stack(flat, -1).reshape(angle.shape + (3, 3))
 
 
+@fp32_region
 def euler_angles_to_matrix(euler_angles: torch.Tensor, convention: str) -> torch.Tensor:
     """Euler angles (radians) [...,3] -> rotation matrices [...,3,3] (reference :315-340)."""
     if euler_angles.dim() == 0 or euler_angles.shape[-1] != 3:
@@ -306,6 +309,7 @@ def _chain_index32(kinematic_tree, device):
     return hit
 
 
+@fp32_region
 def bone_transforms_torch(bones, kinematic_tree, deform_params):
     """(torch formulation; skinning() itself uses the HIP kernel csrc/bones.hip, this one documents and cross-checks it.)
     World transform of every bone for every image: [B*F, K, 4, 4].
@@ -362,6 +366,7 @@ class _LazyAux(dict):
 FUSED_POSE = True  # chain composition inside the skinning launches (a3d_skin_pose_*); False = a3d_bone_transforms_* + a3d_skin_*
 
 
+@fp32_region
 def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bones=False, temperature=1):
     """Linear-blend skinning (reference :369-439).
 

@@ -24,6 +24,7 @@ import os
 import torch
 
 from ... import ops
+from ..._lib import fp32_region
 from . import light, util
 from . import renderutils as ru
 
@@ -48,6 +49,9 @@ FUSED_SHADING = True  # shading normal + camera normal + directional light of th
 # once per new size; 0 = never, env A3D_ALLOCATOR_TRIM_RATIO).
 ALLOCATOR_TRIM_RATIO = float(os.environ.get("A3D_ALLOCATOR_TRIM_RATIO", "3"))
 _point_counts_seen = set()
+
+
+_matmul_fp32 = fp32_region(torch.matmul)  # camera algebra of the path: float32 also inside the caller's autocast region (see _lib.fp32_region)
 
 
 def _trim_allocator_cache(n_points, device):
@@ -94,7 +98,7 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
     gb_normal = ru.prepare_shading_normal(gb_pos, view_pos, None, gb_normal, gb_tangent, gb_geometric_normal,
                                           two_sided_shading=two_sided_shading, opengl=True, use_python=True)
     b, h, w, _ = gb_normal.shape
-    cam_normal = util.safe_normalize(torch.matmul(gb_normal.view(b, -1, 3), w2c[:, :3, :3].transpose(2, 1))).view(b, h, w, 3)
+    cam_normal = util.safe_normalize(_matmul_fp32(gb_normal.view(b, -1, 3), w2c[:, :3, :3].transpose(2, 1))).view(b, h, w, 3)
 
     bsdf = _resolve_bsdf(bsdf, material)
     shading = None
@@ -108,7 +112,7 @@ def shade(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_pos, w2c, v
     depth = None
     if render_modes is not None and "depth" in render_modes:
         hom = torch.cat([gb_pos, torch.ones_like(gb_pos[..., :1])], dim=-1)
-        depth = torch.matmul(hom.view(b, -1, 4), w2c.transpose(-1, -2)).view(b, h, w, 4)[..., 2]
+        depth = _matmul_fp32(hom.view(b, -1, 4), w2c.transpose(-1, -2)).view(b, h, w, 4)[..., 2]
         dmin, dmax = depth.amin(dim=(1, 2), keepdim=True), depth.amax(dim=(1, 2), keepdim=True)
         depth = ((depth - dmin) / (dmax - dmin)).unsqueeze(-1)
 

@@ -3,6 +3,8 @@ platform); both values take the torch path below -- the one every config of the 
 import torch
 import torch.nn.functional as F
 
+from ...._lib import fp32_region
+
 NORMAL_THRESHOLD = 0.1  # reference renderutils/bsdf.py:13
 
 
@@ -10,6 +12,7 @@ def _dot(x, y):
     return torch.sum(x * y, -1, keepdim=True)
 
 
+@fp32_region
 def xfm_points(points, matrix, use_python=False):
     """[B|1,V,3] x [B,4,4] -> homogeneous [B,V,4] = [p,1] . M^T (reference ops.py:524-525).
 
@@ -21,6 +24,7 @@ def xfm_points(points, matrix, use_python=False):
     return out
 
 
+@fp32_region
 def xfm_vectors(vectors, matrix, use_python=False):
     """Direction transform (w = 0), reference ops.py:533-549."""
     out = torch.matmul(F.pad(vectors, pad=(0, 1), mode="constant", value=0.0), torch.transpose(matrix, 1, 2))[..., 0:3].contiguous()

@@ -1347,3 +1347,20 @@ def gemm_nn_relumask(a, b, x=None):
     c = torch.empty((M, 256), dtype=torch.float32, device=a.device)
     call("a3d_gemm_nn_relumask", ptr(a), ptr(b), ptr(x), M, 256, K, ptr(c), stream())
     return c
+
+
+# ---------------------------------------------------------------------------------------------- mixed precision
+def _amp_wrap_functions():
+    """Every autograd.Function of this module runs its forward with autocast OFF on float32 copies of half-precision inputs, and its
+    backward in the same state (torch.amp.custom_fwd / custom_bwd): the kernels are float32, so are their outputs and the gradients
+    they return -- autograd casts a gradient back to the dtype of a bf16 / fp16 input.  What the reference does by hand with .float()
+    at the nvdiffrast boundary (render.py:265,292) under Trainer.py:208-218's autocast."""
+    from torch.amp import custom_bwd, custom_fwd
+
+    for obj in list(globals().values()):
+        if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function and obj.__module__ == __name__:
+            obj.forward = staticmethod(custom_fwd(obj.forward, device_type="cuda", cast_inputs=torch.float32))
+            obj.backward = staticmethod(custom_bwd(obj.backward, device_type="cuda"))
+
+
+_amp_wrap_functions()

@@ -2485,3 +2485,81 @@ def test_field_stack_matches_layer_by_layer_path(with_feat, dev):
     assert torch.allclose(oa, ob, atol=2e-6)
     for u, v in zip(ga, gb):
         assert float((u - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ mixed precision (round 4)
+class _StubField(torch.nn.Module):
+    """Stands for a texture / DINO / light network evaluated under the caller's autocast: a deterministic elementwise function of its
+    inputs whose values are bf16 numbers -- returned AS bf16 when autocast is on (what an nn.Linear gives there), as the same numbers in
+    float32 otherwise.  So both runs hand the path identical values, in the dtype the reference's call pattern produces."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.coef = torch.nn.Parameter(torch.linspace(0.3, 2.9, channels * 3).reshape(channels, 3))
+        self.dtypes_seen = []
+
+    def _out(self, y):
+        y = y.bfloat16()
+        self.dtypes_seen.append(torch.is_autocast_enabled())
+        return y if torch.is_autocast_enabled() else y.float()
+
+    def sample(self, x, feat=None, feat_index=None):
+        y = 0.5 + 0.5 * torch.sin((x.float()[:, None, :] * self.coef[None]).sum(-1))
+        if feat is not None:
+            y = y * (0.75 + 0.25 * torch.tanh(feat.float().mean(-1, keepdim=True)))
+        return self._out(y)
+
+    def forward(self, feat):  # as a light: [B,5] = direction(3), ambient, diffuse
+        f = feat.float().mean(-1, keepdim=True)
+        d = torch.nn.functional.normalize(torch.cat([torch.sin(f), torch.cos(f), 1 + 0 * f], -1), dim=-1)
+        return self._out(torch.cat([d, 0.3 + 0 * f, 0.6 + 0.1 * torch.tanh(f)], -1))
+
+
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_path_inside_autocast_returns_the_float32_results(amp_dtype, dev, mods):
+    """The reference's mixed-precision call pattern (Trainer.py:208-218: mixed_precision bf16 / fp16; AnimalModel.py:382-444: netBase /
+    netInstance / render / losses inside torch.autocast; .float() only at the nvdiffrast boundary, render.py:265,292; GradScaler-scaled
+    loss, AnimalModel.py:192-204): estimate_bones, skinning, make_mesh (+ normals) and render_mesh (+ backward) called inside
+    torch.autocast with half-precision image features and half-precision network outputs arriving at shade -- every output float32 and
+    equal to the run without autocast on the same numbers; gradients finite, in the dtype of their leaves, equal to the float32 run's
+    up to the rounding of the half-precision leaves' gradients."""
+    B, H, W = 2, 64, 64
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=3)
+    sk, M, R = mods["skinning"], mods["mesh"], mods["render"]
+    bones, tree, _ = sk.estimate_bones(verts[None, None], n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    bg = seeded((B, H, W, 3), 13, 0, 1).to(dev)
+    feat32 = seeded((B, 16), 12, -1, 1).to(amp_dtype).float()  # numbers that exist in the half-precision format
+
+    def run(amp):
+        tex, dino, lgt = _StubField(9).to(dev), _StubField(16).to(dev), _StubField(5).to(dev)
+        rest = verts[None, None].to(dev).clone().requires_grad_(True)
+        ang = seeded((B, 1, 20, 3), 9, -0.4, 0.4).to(dev).requires_grad_(True)
+        cam = mvp.to(dev).clone().requires_grad_(True)
+        feat = (feat32.to(dev).to(amp_dtype) if amp else feat32.to(dev)).requires_grad_(True)
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp):
+            bones_d = sk.estimate_bones(rest.detach(), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+")[0]
+            posed, aux = sk.skinning(rest, bones_d, tree, ang, output_posed_bones=True, temperature=0.05)
+            shape = M.make_mesh(posed.view(B, -1, 3), faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+            prior = M.make_mesh(rest.view(1, -1, 3), faces[None].to(dev), uvs, uvi, None)
+            out = R.render_mesh(None, shape, cam, w2c.to(dev), campos.to(dev), tex, lgt, (H, W), background=bg, bsdf="diffuse", feat=feat,
+                                render_modes=["shaded", "dino_pred", "geo_normal"], prior_mesh=prior, dino_net=dino)
+            loss = sum((o.float() * seeded(tuple(o.shape), 40 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out)) + posed.sum() + aux["posed_bones"].sum()
+            loss = loss + shape.v_nrm.sum()
+        scale = 1024.0 if amp else 1.0  # (a GradScaler multiplies the loss before backward and divides the gradients afterwards)
+        grads = torch.autograd.grad(loss * scale, [rest, ang, cam, feat] + list(tex.parameters()) + list(dino.parameters()))
+        assert all(tex.dtypes_seen) == amp and len(tex.dtypes_seen) > 0
+        return bones_d, posed, aux["posed_bones"], shape.v_nrm, out, [g / scale for g in grads], feat
+
+    ref, amp = run(False), run(True)
+    for a, b in zip(ref[:4], amp[:4]):
+        assert b.dtype == torch.float32 and torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+    for name, a, b in zip(("shaded", "dino_pred", "geo_normal"), ref[4], amp[4]):
+        assert b.dtype == torch.float32, name
+        assert float((a - b).abs().max()) < 1e-5, (name, float((a - b).abs().max()))
+    assert amp[6].dtype == amp_dtype and amp[5][3].dtype == amp_dtype  # the half-precision leaf gets a half-precision gradient
+    for i, (a, b) in enumerate(zip(ref[5], amp[5])):
+        assert torch.isfinite(b.float()).all()
+        tol = (2e-2 if amp_dtype == torch.bfloat16 else 4e-3) if i == 3 else 2e-4  # (the feature's gradient is rounded to its dtype)
+        assert float((a.float() - b.float()).abs().max()) <= tol * float(a.abs().max()) + 1e-6, (i, float((a.float() - b.float()).abs().max()), float(a.abs().max()))
