@@ -32,21 +32,37 @@ def sync(device=None):
         torch.cuda.synchronize()
 
 
-def timed_steps(step_fn, steps: int, warmup: int, device=None) -> float:
-    """Run ``warmup`` untimed and exactly ``steps`` timed calls; return the MAX over ranks of the elapsed seconds."""
+def timed_steps(step_fn, steps: int, warmup: int, device=None, per_rank: bool = False):
+    """Run ``warmup`` untimed and exactly ``steps`` timed calls; return the MAX over ranks of the elapsed seconds.
+    ``per_rank``: -> (that maximum, [every rank's own seconds spent issuing and finishing its steps BEFORE the closing barrier]) -- the
+    spread shows which rank the others wait for (unequal covered-pixel counts, a host stall)."""
     for _ in range(warmup):
         step_fn()
     sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    own = None
+    if per_rank:
+        if torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda"):
+            torch.cuda.synchronize()
+        own = time.perf_counter() - t0
     sync(device)
     elapsed = time.perf_counter() - t0
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+    if not per_rank:
+        return elapsed
+    if not multi:
+        return elapsed, [own]
+    ws = dist.get_world_size()
+    t = torch.zeros(ws, dtype=torch.float64, device=device if device is not None else "cpu")
+    t[dist.get_rank()] = own
+    dist.all_reduce(t)
+    return elapsed, [float(v) for v in t.tolist()]
 
 
 def allreduce_mean_grads(params, bucket_bytes: int = 25 << 20):

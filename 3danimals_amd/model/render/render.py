@@ -35,8 +35,8 @@ POINT_BUCKET = 8192  # pad the covered-point list seen by the MLPs to a multiple
 LAST_RAST = [None]
 LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path handed from stage to stage in the last render_mesh call
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
-FUSED_COVER_GBUFFER = True
-DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
+FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
+DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
@@ -46,21 +46,36 @@ FUSED_SHADING = True  # shading normal + camera normal + directional light of th
 # -- measured on a steadily growing shape: 5.5 GB reserved after the first step, 208 GB after 1200, for 1 GB in use and a 10 GB peak
 # (tools/mem_growth.py).  So whenever a point count appears that no earlier step had, the cache is given back to the driver if it
 # exceeds ALLOCATOR_TRIM_RATIO x the peak of what was ever in use (a device synchronisation and a few hundred hipFree calls, at most
-# once per new size; 0 = never, env A3D_ALLOCATOR_TRIM_RATIO).
+# once per new size; 0 = never, env A3D_ALLOCATOR_TRIM_RATIO).  The peak is tracked HERE (memory_allocated sampled at every check and
+# at every new size), not read from max_memory_allocated: a caller that resets torch's peak statistics every epoch would otherwise make
+# every new size look like a reason to trim.  Under data-parallel training the ranks meet a new size at different steps and the rank
+# that trims (milliseconds) keeps the others waiting at the next all-reduce -- at most once per size per rank, and only while its
+# cache is three times what it ever needed; ranks that must not stall set the ratio to 0 and cap the cache with
+# PYTORCH_HIP_ALLOC_CONF=garbage_collection_threshold instead.
 ALLOCATOR_TRIM_RATIO = float(os.environ.get("A3D_ALLOCATOR_TRIM_RATIO", "3"))
 _point_counts_seen = set()
+_in_use_peak = {}
 
 
 _matmul_fp32 = fp32_region(torch.matmul)  # camera algebra of the path: float32 also inside the caller's autocast region (see _lib.fp32_region)
 
 
 def _trim_allocator_cache(n_points, device):
-    if ALLOCATOR_TRIM_RATIO <= 0 or n_points in _point_counts_seen or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+    if ALLOCATOR_TRIM_RATIO <= 0 or device.type != "cuda":
+        return False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    peak = _in_use_peak[key] = max(_in_use_peak.get(key, 1 << 30), torch.cuda.memory_allocated(device))  # (a counter read: no synchronisation)
+    if n_points in _point_counts_seen or torch.cuda.is_current_stream_capturing():
         return False
     if len(_point_counts_seen) >= 4096:
         _point_counts_seen.clear()
     _point_counts_seen.add(n_points)
-    in_use_peak = max(torch.cuda.max_memory_allocated(device), 1 << 30)
+    # (this call sits after the G-buffer and before the networks of a step: the step's own activations are not allocated yet, the
+    # peak is what earlier steps needed -- the previous step's networks are sampled by the NEXT call's memory_allocated only while
+    # their graph is alive, hence also torch's own figure, which cannot be lower than what this process really peaked at since its
+    # last reset)
+    in_use_peak = max(peak, torch.cuda.max_memory_allocated(device))
+    _in_use_peak[key] = in_use_peak
     if torch.cuda.memory_reserved(device) <= ALLOCATOR_TRIM_RATIO * in_use_peak:
         return False
     torch.cuda.empty_cache()

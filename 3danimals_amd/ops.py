@@ -1101,10 +1101,13 @@ class AAAnalysis:
             self.ensure()
 
     def ride_args(self):
-        """Arguments that make a3d_composite_aa_fwd run the pending analysis in its first launch (marks it done), or the nulls."""
+        """Arguments that make a3d_composite_aa_fwd run the pending analysis in its first launch, or the nulls.  The caller marks the
+        analysis done (``pending = False``) once that call has SUCCEEDED: a refused call must not leave an unfilled work list behind
+        that later consumers would take for finished.  Batches the riding form cannot address (B > 65535) run stand-alone now."""
+        if self.pending and self.B > 65535:
+            self.ensure()
         if not self.pending:
             return [None, None, 0, None, None, 0, 0, None, None, 0]
-        self.pending = False
         topo, lists = self.topo, getattr(self.topo, "lists", None)
         return [ptr(self.rast), ptr(self.screen), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.clip.shape[1], topo.tri.shape[0],
                 ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), 0 if lists is None else lists.stride]
@@ -1175,6 +1178,8 @@ class _CompositeAntialias(torch.autograd.Function):
         call("a3d_composite_aa_fwd", ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
              0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W, *ride, stream(),
              tag=tag + ("[+analysis]" if ride[0] is not None else ""))
+        if ride[0] is not None:
+            a.pending = False  # (only now: the call above raises on a refused argument)
         ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
         ctx.analysis, ctx.tag = a, tag
         if vals2 is None:

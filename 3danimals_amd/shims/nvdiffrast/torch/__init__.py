@@ -59,12 +59,52 @@ class _LazyRastDb:
     def __len__(self):
         return len(self.materialize())
 
+    def __setitem__(self, index, value):
+        self.materialize()[index] = value
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __bool__(self):
+        return bool(self.materialize())
+
+    def __repr__(self):
+        return repr(self.materialize()) if self._value is not None else "<rast_db (not computed yet)>"
+
+    def __neg__(self):
+        return -self.materialize()
+
+    def __pos__(self):
+        return self.materialize()
+
+    def __abs__(self):
+        return abs(self.materialize())
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         unwrap = lambda a: a.materialize() if isinstance(a, _LazyRastDb) else a
         args = tuple(type(a)(unwrap(x) for x in a) if isinstance(a, (list, tuple)) else unwrap(a) for a in args)
         kwargs = {k: unwrap(v) for k, v in (kwargs or {}).items()}
         return func(*args, **kwargs)
+
+
+def _lazy_binary(name):
+    def op(self, other):
+        other = other.materialize() if isinstance(other, _LazyRastDb) else other
+        return getattr(self.materialize(), name)(other)
+
+    op.__name__ = name
+    return op
+
+
+# arithmetic and comparisons act on the tensor itself (``rast_db * 2``, ``1 - rast_db``, ``rast_db > 0`` ...): the stand-in is meant for
+# unchanged nvdiffrast callers, not only for the reference's own, which hand the object straight to scale_img / interpolate
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "and", "or", "xor"):
+    setattr(_LazyRastDb, f"__{_n}__", _lazy_binary(f"__{_n}__"))
+    setattr(_LazyRastDb, f"__r{_n}__", _lazy_binary(f"__r{_n}__"))
+for _n in ("lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(_LazyRastDb, f"__{_n}__", _lazy_binary(f"__{_n}__"))
+_LazyRastDb.__hash__ = object.__hash__  # (defining __eq__ would otherwise make the object unhashable)
 
 
 def _rast_db(pos, tri, rast, grad_db):

@@ -383,6 +383,8 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="launch plumbing only: rendezvous, barrier, one all-reduce, the JSON line; no GPU work")
     ap.add_argument("--per-rank-poses", action="store_true", help="different poses / cameras per rank (unequal covered-pixel counts) instead of "
                     "the equal-work default")
+    ap.add_argument("--no-extra-legs", action="store_true", help="--gpus N > 1 only: skip the two extra timed legs of the line (per-rank poses; the "
+                    "Fauna per-rank step) that follow the headline leg")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: spawn the ranks ourselves
@@ -413,14 +415,28 @@ def main():
     batch = args.batch if args.batch is not None else (8 if args.workload == "ponymation" else 16)
     frames = args.frames if args.workload == "ponymation" else 1
 
-    def make_scene():
-        return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=batch, resolution=(args.resolution, args.resolution), device=dev, seed=0,
-                                       data_seed=1000 * rank, workload=args.workload, num_frames=frames,
-                                       deform=(args.workload == "magicpony" and not args.no_deform),
-                                       pose_seed=(rank if args.per_rank_poses else 0))
+    def make_scene(workload=args.workload, per_rank_poses=args.per_rank_poses):
+        b = batch if (workload == args.workload or args.workload != "ponymation") else 16  # (ponymation's --batch counts sequences)
+        return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=b, resolution=(args.resolution, args.resolution), device=dev, seed=0,
+                                       data_seed=1000 * rank, workload=workload, num_frames=frames if workload == "ponymation" else 1,
+                                       deform=(workload == "magicpony" and not args.no_deform),
+                                       pose_seed=(rank if per_rank_poses else 0))
 
     scene = make_scene()
     scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
+    # --gpus N > 1: two more timed legs ride in the same line (and the same launch), so that the first multi-GPU record also says what
+    # the equal-work headline cannot: (i) every rank on its OWN poses / cameras (unequal covered-pixel counts: the slowest rank sets the
+    # step), (ii) the Fauna per-rank step (bones re-estimated in the step, two renders: 4 host read-backs per step on every rank --
+    # where eight Python processes stalling at different moments would show; Trainer.py:170-179,304-308, Fauna.py:111-173).  Their
+    # scenes (and HIP graphs) exist before the process group does, like the headline's.
+    extra_scenes = {}
+    if world > 1 and not args.no_extra_legs and not args.forward_only:
+        if not args.per_rank_poses:
+            extra_scenes["per_rank_poses"] = make_scene(per_rank_poses=True)
+        if args.workload != "fauna":
+            extra_scenes["fauna"] = make_scene(workload="fauna")
+        for sc in extra_scenes.values():
+            sc.netShape.capture_sdf_gradient_graph()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -438,8 +454,28 @@ def main():
 
     # W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides, MAX over ranks
     du = importlib.import_module("3danimals_amd.dist_util")
-    elapsed = du.timed_steps(lambda: scene.step(module=module, backward=train), args.steps, args.warmup, device=dev)
+    tdev = dev if (world == 1 or args.backend == "nccl") else "cpu"
+    elapsed, rank_seconds = du.timed_steps(lambda: scene.step(module=module, backward=train), args.steps, args.warmup, device=dev, per_rank=True)
     images = world * scene.frames * args.steps
+
+    def covered_of(sc):
+        c = int((sc.last["rast"][..., 3] > 0).sum()) if "rast" in sc.last else 0
+        if world == 1:
+            return [c]
+        t = torch.zeros(world, dtype=torch.int64, device=tdev)
+        t[rank] = c
+        dist.all_reduce(t)
+        return [int(v) for v in t.tolist()]
+
+    extra_legs = {}
+    for name, sc in extra_scenes.items():  # (every rank runs the same legs in the same order)
+        mod = torch.nn.parallel.DistributedDataParallel(sc, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
+        t, per_rank = du.timed_steps(lambda: sc.step(module=mod, backward=True), args.steps, args.warmup, device=dev, per_rank=True)
+        extra_legs[name] = dict(value=round(world * sc.frames * args.steps / t, 3), unit="images/s", ms_per_step=round(t / args.steps * 1e3, 3),
+                                ms_per_step_per_rank=[round(v / args.steps * 1e3, 3) for v in per_rank], covered_pixels_per_rank=covered_of(sc),
+                                workload=sc.workload, batch_per_gpu=sc.batch, steps=args.steps, warmup=args.warmup)
+        del mod
+    extra_scenes.clear()
 
     def dims_of(sc):
         prior = sc.last["prior"]
@@ -520,13 +556,7 @@ def main():
                        note="estimate_bones (host logic with read-backs, once per epoch in training) is inside both timings")
 
     # what every rank rendered (covered pixels decide the MLP work): gathered so the line shows the balance across ranks
-    covered = int((scene.last["rast"][..., 3] > 0).sum()) if "rast" in scene.last else 0
-    covered_per_rank, ranks = [covered], 1
-    if world > 1:
-        t = torch.zeros(world, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
-        t[rank] = covered
-        dist.all_reduce(t)
-        covered_per_rank, ranks = [int(v) for v in t.tolist()], dist.get_world_size()
+    covered_per_rank, ranks = covered_of(scene), (dist.get_world_size() if world > 1 else 1)
 
     if rank == 0:
         what = {"magicpony": "train_magicpony_horse-like synthetic step: DMTet(%s)+deformation+LBS(20 bones)+3x make_mesh+raster/interp/antialias "
@@ -548,6 +578,8 @@ def main():
             "rccl_ranks": ranks,
             "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
             "covered_pixels_per_rank": covered_per_rank,
+            "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in rank_seconds],
+            "extra_legs": extra_legs or None,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",

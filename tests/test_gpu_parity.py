@@ -821,6 +821,7 @@ def test_allocator_cache_is_given_back_when_new_point_counts_have_stranded_it(de
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
     monkeypatch.setattr(R, "_point_counts_seen", set())
+    monkeypatch.setattr(R, "_in_use_peak", {})
     base = torch.cuda.memory_reserved(dev)
     for k in range(24):  # 24 blocks of growing size, each freed again: ~5 GB cached, < 1 GB ever in use at once
         del_me = torch.empty((200 + 8 * k) << 20, dtype=torch.uint8, device=dev)
@@ -836,6 +837,10 @@ def test_allocator_cache_is_given_back_when_new_point_counts_have_stranded_it(de
     assert not R._trim_allocator_cache(16384, dev)
     del keep
     assert not R._trim_allocator_cache(16384, dev)  # (a count seen before strands nothing new: not even looked at)
+    # the peak in use is tracked by the module itself: a caller that resets torch's statistics (every epoch, say) does not make the
+    # 5 GB that now sit in the cache -- exactly what the process needed a moment ago -- look like something to give back
+    torch.cuda.reset_peak_memory_stats(dev)
+    assert torch.cuda.memory_reserved(dev) - base >= 5 << 30 and not R._trim_allocator_cache(24576, dev)
     torch.cuda.empty_cache()
 
 
@@ -2309,6 +2314,11 @@ def test_bench_two_ranks_on_one_gpu_through_both_command_shapes(launcher):
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 4 and len(line["covered_pixels_per_rank"]) == 2 and min(line["covered_pixels_per_rank"]) > 0
     assert line["roofline"] is not None and line["roofline"]["in_scope"]["us_per_step"] > 0
+    # (round 4) the same launch also times every rank on its own poses and the Fauna per-rank step, each through its own DDP wrapper
+    legs = line["extra_legs"]
+    assert set(legs) == {"per_rank_poses", "fauna"} and all(v["value"] > 0 and len(v["ms_per_step_per_rank"]) == 2 for v in legs.values())
+    assert len(set(legs["per_rank_poses"]["covered_pixels_per_rank"])) == 2 and min(legs["fauna"]["covered_pixels_per_rank"]) > 0
+    assert legs["fauna"]["workload"] == "fauna" and len(line["ms_per_step_per_rank"]) == 2 and line["dmtet_pass"] in ("plain", "culled", "ordered")
 
 
 def test_render_uv_bake_and_material_export(tmp_path, dev, mods):

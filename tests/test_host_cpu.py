@@ -624,3 +624,25 @@ def test_oracle_edge_opposites_do_not_depend_on_the_winding():
     assert (opp_f >= 0).all()
     back = np.where(flip[:, None], opp_f[:, [0, 2, 1]], opp_f)  # corner i of the flipped face = corner (0, 2, 1)[i] of the original
     assert np.array_equal(back, opp)
+
+
+def test_lazy_rast_db_behaves_like_the_tensor_it_stands_for():
+    """The nvdiffrast stand-in returns rast_db as an object that computes the tensor on first use (the reference discards it,
+    render.py:24): arithmetic, comparisons, indexing (both ways), iteration and torch functions must all act on the tensor."""
+    shim = importlib.import_module("3danimals_amd.shims.nvdiffrast.torch")
+    calls = []
+
+    def make():
+        calls.append(1)
+        return torch.arange(12.0).reshape(3, 4)
+
+    lazy = shim._LazyRastDb(make)
+    assert not calls and "not computed" in repr(lazy)
+    t = torch.arange(12.0).reshape(3, 4)
+    assert torch.equal(lazy * 2, t * 2) and len(calls) == 1
+    assert torch.equal(2 * lazy, t * 2) and torch.equal(1 - lazy, 1 - t) and torch.equal(-lazy, -t) and torch.equal(lazy / 2, t / 2)
+    assert torch.equal(lazy > 5, t > 5) and torch.equal(lazy == t, torch.ones(3, 4, dtype=torch.bool))
+    assert torch.equal(torch.cat([lazy, lazy]), torch.cat([t, t])) and lazy.shape == (3, 4) and len(lazy) == 3
+    lazy[0, 0] = 7.0
+    assert float(lazy[0, 0]) == 7.0 and [r.shape for r in lazy] == [torch.Size([4])] * 3 and len(calls) == 1
+    assert torch.equal(lazy + shim._LazyRastDb(lambda: torch.ones(3, 4)), lazy.materialize() + 1)
