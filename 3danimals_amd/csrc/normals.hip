@@ -45,22 +45,25 @@ __global__ __launch_bounds__(256) void nr_fwd_kernel(const float* __restrict__ v
 }
 
 // d(normalize(acc))/d(acc) applied to g_nrm; zero where the default normal was substituted
+__device__ __forceinline__ void nr_vert_adjoint(float x, float y, float z, float gx, float gy, float gz, float o[3]) {
+    const float d = x * x + y * y + z * z;
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    if (d > 1e-20f) {
+        const float inv = 1.f / sqrtf(d);
+        const float nx = x * inv, ny = y * inv, nz = z * inv;
+        const float dot = nx * gx + ny * gy + nz * gz;
+        o[0] = (gx - nx * dot) * inv; o[1] = (gy - ny * dot) * inv; o[2] = (gz - nz * dot) * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void nr_vert_bwd_kernel(const float* __restrict__ g_nrm, int g_stride, const float* __restrict__ acc,
                                                           long long n, float* __restrict__ g_acc) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float x = acc[3 * i], y = acc[3 * i + 1], z = acc[3 * i + 2];
-    const float d = x * x + y * y + z * z;
-    float ox = 0.f, oy = 0.f, oz = 0.f;
-    if (d > 1e-20f) {
-        const float inv = 1.f / sqrtf(d);
-        const float nx = x * inv, ny = y * inv, nz = z * inv;
-        const float* gr = g_nrm + (long long)g_stride * i;
-        const float gx = gr[0], gy = gr[1], gz = gr[2];
-        const float dot = nx * gx + ny * gy + nz * gz;
-        ox = (gx - nx * dot) * inv; oy = (gy - ny * dot) * inv; oz = (gz - nz * dot) * inv;
-    }
-    g_acc[3 * i] = ox; g_acc[3 * i + 1] = oy; g_acc[3 * i + 2] = oz;
+    const float* gr = g_nrm + (long long)g_stride * i;
+    float o[3];
+    nr_vert_adjoint(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2], gr[0], gr[1], gr[2], o);
+    g_acc[3 * i] = o[0]; g_acc[3 * i + 1] = o[1]; g_acc[3 * i + 2] = o[2];
 }
 
 __device__ __forceinline__ void nr_bwd_entry(int c, const float g0[3], const float g1[3], const float g2[3], const float p0[3], const float p1[3],
@@ -76,14 +79,29 @@ __device__ __forceinline__ void nr_bwd_entry(int c, const float g0[3], const flo
     else { ox -= gax + gbx; oy -= gay + gby; oz -= gaz + gbz; }
 }
 
+// FUSED: no prepass -- the normalisation adjoint of every gathered corner is recomputed from (acc, g_nrm) on the spot (same formula,
+// same bits): 24 B gathered per corner instead of 12 and ~24 adjoints per thread instead of one, for one launch less on a stretch
+// where a launch costs more than the arithmetic (the prepass: 4.9 us of kernel + a gap for 93k threads of work)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g_acc, const float* __restrict__ v, const int* __restrict__ tri,
                                                      const int* __restrict__ off, const int* __restrict__ adj, int V, int F,
-                                                     float* __restrict__ g_v, int stride) {
+                                                     float* __restrict__ g_v, int stride, const float* __restrict__ g_nrm, int g_stride,
+                                                     const float* __restrict__ acc) {
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
     const long long vb = (long long)blockIdx.y * V;
     const float* vp = v + vb * 3;
-    const float* gp = g_acc + vb * 3;
+    const float* gp = FUSED ? nullptr : g_acc + vb * 3;
+    const float* ap = FUSED ? acc + vb * 3 : nullptr;
+    const float* np = FUSED ? g_nrm + vb * g_stride : nullptr;
+    auto corner = [&](int i, float o[3]) {
+        if (FUSED) {
+            const float* gr = np + (long long)g_stride * i;
+            nr_vert_adjoint(ap[3ll * i], ap[3ll * i + 1], ap[3ll * i + 2], gr[0], gr[1], gr[2], o);
+        } else {
+            o[0] = gp[3ll * i]; o[1] = gp[3ll * i + 1]; o[2] = gp[3ll * i + 2];
+        }
+    };
     float ox = 0.f, oy = 0.f, oz = 0.f;
     int lo, cnt;
     vf_list(off, stride, vi, lo, cnt);
@@ -101,10 +119,8 @@ __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g
         for (int k = 0; k < 4; ++k) {
             const int i0 = t[h + k].i0, i1 = t[h + k].i1, i2 = t[h + k].i2;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                p[k][q] = vp[3ll * i0 + q]; p[k][3 + q] = vp[3ll * i1 + q]; p[k][6 + q] = vp[3ll * i2 + q];
-                g[k][q] = gp[3ll * i0 + q]; g[k][3 + q] = gp[3ll * i1 + q]; g[k][6 + q] = gp[3ll * i2 + q];
-            }
+            for (int q = 0; q < 3; ++q) { p[k][q] = vp[3ll * i0 + q]; p[k][3 + q] = vp[3ll * i1 + q]; p[k][6 + q] = vp[3ll * i2 + q]; }
+            corner(i0, g[k]); corner(i1, g[k] + 3); corner(i2, g[k] + 6);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -116,10 +132,8 @@ __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g
         const NrFace tt = nr_decode(last, F, tri);
         float p[9], g[9];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            p[q] = vp[3ll * tt.i0 + q]; p[3 + q] = vp[3ll * tt.i1 + q]; p[6 + q] = vp[3ll * tt.i2 + q];
-            g[q] = gp[3ll * tt.i0 + q]; g[3 + q] = gp[3ll * tt.i1 + q]; g[6 + q] = gp[3ll * tt.i2 + q];
-        }
+        for (int q = 0; q < 3; ++q) { p[q] = vp[3ll * tt.i0 + q]; p[3 + q] = vp[3ll * tt.i1 + q]; p[6 + q] = vp[3ll * tt.i2 + q]; }
+        corner(tt.i0, g); corner(tt.i1, g + 3); corner(tt.i2, g + 6);
         nr_bwd_entry(tt.c, g, g + 3, g + 6, p, p + 3, p + 6, ox, oy, oz);
     }
     }
@@ -177,9 +191,18 @@ extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * V;
-    hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, n, g_acc_scratch);
-    A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nr_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v, lists_stride);
+    // (the one-launch form measured SLOWER inside the step: 24.8 against 17.8 us for the call -- its 24 normalisation adjoints per thread
+    // with correctly rounded sqrt and division are ~1200 more instructions in a kernel that was latency bound but not idle; it stays
+    // behind the knob A3D_EXP=41)
+    if (a3d_exp() != 41) {
+        hipLaunchKernelGGL(nr_vert_bwd_kernel, dim3(a3d_div_up(n, 256)), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, n, g_acc_scratch);
+        A3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nr_bwd_kernel<false>, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_acc_scratch, v, tri, off, adj, V, F, g_v, lists_stride,
+                           (const float*)nullptr, 0, (const float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(nr_bwd_kernel<true>, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, (const float*)nullptr, v, tri, off, adj, V, F, g_v,
+                           lists_stride, g_nrm, g_nrm_stride, acc);
+    }
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

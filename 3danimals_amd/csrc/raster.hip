@@ -29,6 +29,8 @@
 #include "normals_common.h"
 
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define RS_BIG 512          // boxes above this many pixels go through the tile stage
+#define RS_TILE_CHUNK 512   // tiles tested per round of the work-group (survivors <= this: the LDS list cannot overflow)
 
 // the vertex-normals job that may ride in the triangle launch (a3d_rast_fwd: normals_*)
 struct RsNormalsJob {
@@ -160,7 +162,11 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         return;
     }
     constexpr int TPW = 64 / LPT;  // triangles per wave
-    const int f = blockIdx.x * (256 / LPT) + (int)threadIdx.x / LPT;
+    // the four waves of a work-group take their TPW consecutive triangles from four places a quarter of the list apart (wave w: chunk
+    // w nb_tri + blockIdx.x): a run of neighbouring triangles with huge boxes -- a spike of a mesh that training has driven apart --
+    // then loads four times as many work-groups a quarter as much each; the pool below is per work-group whatever it holds, and a
+    // wave's index reads stay one contiguous run
+    const int f = (((int)threadIdx.x >> 6) * nb_tri + (int)blockIdx.x) * TPW + ((int)threadIdx.x & 63) / LPT;
     const int sub = threadIdx.x % LPT, lane = threadIdx.x & 63;
     const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
     unsigned long long* kb = keys + (long long)b * H * W;
@@ -186,14 +192,22 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     // LPT: the set-up (two dependent gathers + the box) is latency bound and wants many waves -- 4 lanes per triangle at B F = 1.9e5
     // (16.9 us against 22.1 with one) --, but is pure repetition once the waves suffice: one lane per triangle at B F = 7.7e5 (19.8 us
     // against 28.6 with four).
+    // (round 4) A box above RS_BIG pixels does not enter the pool: its 8x8 TILES are tested first (below) and only the pixels of the
+    // tiles the triangle can touch are -- a sliver's cost follows its area, not its box (a 9000-pixel box: ~20 of 140 tiles).
     __shared__ float4 s_p[4][TPW][3];
-    __shared__ int4 s_box[4][TPW];  // x0, y0, bw, f
+    __shared__ int4 s_box[4][TPW];  // x0, y0, bw | bh << 16, f
     __shared__ int s_pre[4][TPW + 1];
+    __shared__ unsigned short s_big[256];
+    __shared__ int s_nbig, s_ns;
+    __shared__ int s_tiles[RS_TILE_CHUNK];
+    __shared__ int s_bpre[257], s_wsum[4];
     const int wv = threadIdx.x >> 6, q = lane / LPT;  // this wave's slice, this lane's triangle slot
-    const int mine = area > 0 ? area : 0;
+    const bool big = area > RS_BIG;
+    const int mine = (area > 0 && !big) ? area : 0;
+    if (threadIdx.x == 0) { s_nbig = 0; s_ns = 0; }
     if (sub == 0) {
         s_p[wv][q][0] = p0; s_p[wv][q][1] = p1; s_p[wv][q][2] = p2;
-        s_box[wv][q] = make_int4(x0, y0, bw, f);
+        s_box[wv][q] = make_int4(x0, y0, bw | ((area > 0 ? area / bw : 0) << 16), f);  // (H, W < 2^15: checked by the entry point)
     }
     {   // inclusive scan of the TPW box sizes (held by the lanes LPT q)
         int incl = mine;
@@ -215,7 +229,8 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
 #pragma unroll
         for (int step = TPW / 2; step > 0; step >>= 1)
             if (s_pre[w][j + step] <= cw) j += step;
-        const int4 bx = s_box[w][j];
+        int4 bx = s_box[w][j];
+        bx.z &= 0xFFFF;
         const int i = cw - s_pre[w][j];
         // i / bw through the reciprocal: (i + 0.5) / bw is at least 0.5 / bw away from an integer and the product is off by ~2.4e-7 of
         // its value (< area / bw): exact for every box below ~1e6 pixels; larger ones (whole frames of >= 1024^2) divide
@@ -224,6 +239,89 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         else cy = i / bx.z;
         const int cx = i - cy * bx.z;
         rs_test_pixel(s_p[w][j][0], s_p[w][j][1], s_p[w][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
+    }
+    // ---- the big boxes of this work-group: their TILES are pooled like the pixels above (prefix of the tile counts, a search per
+    // lane), tested, and the pixels of the surviving tiles pooled in turn -- per chunk of RS_TILE_CHUNK tiles, so that the survivor
+    // list lives in 2 KB of LDS.  (One big box after the other, each with its own barriers, made a work-group whose 64 neighbouring
+    // triangles are all big -- a spike of the drifted mesh -- slower than walking their boxes: 152 against 109 us.)
+    if (sub == 0 && big) s_big[atomicAdd(&s_nbig, 1)] = (unsigned short)((wv << 8) | q);  // (LDS; s_nbig was zeroed before the barrier above)
+    __syncthreads();
+    const int nbig = s_nbig;
+    if (nbig == 0) return;  // (uniform)
+    {   // exclusive prefix of the tile counts over the list (nbig <= 256: one entry per thread)
+        int cnt = 0;
+        if ((int)threadIdx.x < nbig) {
+            const int4 bx = s_box[s_big[threadIdx.x] >> 8][s_big[threadIdx.x] & 255];
+            cnt = (((bx.z & 0xFFFF) + 7) >> 3) * (((bx.z >> 16) + 7) >> 3);
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wv; ++k) base += s_wsum[k];
+        s_bpre[threadIdx.x] = base + incl - cnt;
+        if (threadIdx.x == 255) s_bpre[256] = base + incl;
+    }
+    __syncthreads();
+    const int total_tiles = s_bpre[256];
+    const float hx = 0.5f * xs * 8.f, hy = 0.5f * ys * 8.f;  // half a tile in NDC (a tile cut by the box is tested whole: conservative)
+    for (int tb = 0; tb < total_tiles; tb += RS_TILE_CHUNK) {  // (uniform)
+#pragma unroll
+        for (int r = 0; r < RS_TILE_CHUNK / 256; ++r) {
+            const int g = tb + r * 256 + (int)threadIdx.x;
+            bool keep = false;
+            int packed = 0;
+            if (g < total_tiles) {
+                int j = 0;  // the big box that owns tile g: largest j with bpre[j] <= g
+#pragma unroll
+                for (int step = 128; step > 0; step >>= 1)
+                    if (j + step < nbig && s_bpre[j + step] <= g) j += step;
+                const int w = s_big[j] >> 8, qs = s_big[j] & 255, t = g - s_bpre[j];
+                const int4 bx = s_box[w][qs];
+                const int ntx = ((bx.z & 0xFFFF) + 7) >> 3, ty = t / ntx, tx = t - ty * ntx;
+                // The three edge functions of rs_frag are LINEAR in the pixel centre (fx, fy): a_k = C_k + A_k fx + B_k fy (the fx fy
+                // terms cancel); a pixel is inside iff all three are >= 0 or all three <= 0.  Over a tile a_k ranges over its value at
+                // the centre +- (|A_k| hx + |B_k| hy); a tile where some a_k stays < 0 AND some a_k' stays > 0 holds no covered pixel.
+                // tol: the rounding of rs_frag's own products (it evaluates the same polynomial through q = p - f w), a few ulps of
+                // the largest term, taken ~40x wider.
+                const float fx = __builtin_fmaf(xs, (float)(bx.x + 8 * tx) + 3.5f, xo), fy = __builtin_fmaf(ys, (float)(bx.y + 8 * ty) + 3.5f, yo);
+                bool pos = true, neg = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 u = s_p[w][qs][(k + 1) % 3], v = s_p[w][qs][(k + 2) % 3];
+                    const float C = u.x * v.y - u.y * v.x, A = -(u.w * v.y - u.y * v.w), Bc = -(u.x * v.w - u.w * v.x);
+                    const float tol = 5e-6f * ((fabsf(u.x * v.y) + fabsf(u.y * v.x)) + 2.f * (fabsf(u.w * v.y) + fabsf(u.y * v.w)) + 2.f * (fabsf(u.x * v.w) + fabsf(u.w * v.x)));
+                    const float vk = C + A * fx + Bc * fy, ext = fabsf(A) * hx + fabsf(Bc) * hy + tol;
+                    pos = pos && (vk + ext >= 0.f);
+                    neg = neg && (vk - ext <= 0.f);
+                }
+                keep = pos || neg;
+                packed = (j << 24) | t;  // (t < 2^24: a 32767 x 32767 frame has 1.7e7 tiles)
+            }
+            const unsigned long long m = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_ns, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (keep) s_tiles[base + a3d_wave_prefix(m)] = packed;
+        }
+        __syncthreads();
+        const int ns = s_ns;
+        for (int i = threadIdx.x; i < ns * 64; i += 256) {
+            const int e = s_tiles[i >> 6], j = (e >> 24) & 255, t = e & 0xFFFFFF;
+            const int w = s_big[j] >> 8, qs = s_big[j] & 255;
+            const int4 bx = s_box[w][qs];
+            const int bwid = bx.z & 0xFFFF, bh = bx.z >> 16, ntx = (bwid + 7) >> 3, ty = t / ntx, tx = t - ty * ntx;
+            const int cx = 8 * tx + (i & 7), cy = 8 * ty + ((i >> 3) & 7);
+            if (cx < bwid && cy < bh) rs_test_pixel(s_p[w][qs][0], s_p[w][qs][1], s_p[w][qs][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_ns = 0;
+        __syncthreads();
     }
 }
 
@@ -334,7 +432,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
-    A3D_CHECK_ARG((long long)H * W < 0x7fffffffll && B <= 65535);
+    A3D_CHECK_ARG((long long)H * W < 0x7fffffffll && B <= 65535 && H < 32768 && W < 32768);
     hipStream_t s = (hipStream_t)stream;
     const long long npix = (long long)B * H * W;
     // the covered-pixel block counts ride along when the list's tile order applies and its blocks do not cross images

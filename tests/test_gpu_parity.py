@@ -2573,3 +2573,40 @@ def test_path_inside_autocast_returns_the_float32_results(amp_dtype, dev, mods):
         assert torch.isfinite(b.float()).all()
         tol = (2e-2 if amp_dtype == torch.bfloat16 else 4e-3) if i == 3 else 2e-4  # (the feature's gradient is rounded to its dtype)
         assert float((a.float() - b.float()).abs().max()) <= tol * float(a.abs().max()) + 1e-6, (i, float((a.float() - b.float()).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("H,W,kind", [(256, 256, "slivers"), (512, 384, "slivers"), (256, 256, "eye_plane"), (96, 1024, "slivers")])
+def test_rasterize_large_boxes_through_the_tile_stage_bit_exact_vs_oracle(H, W, kind, dev, ops):
+    """Boxes above 512 pixels are not walked pixel by pixel: their 8x8 tiles are tested against the three (linear) edge functions first and
+    only the tiles the triangle can touch are (csrc/raster.hip, round 4).  A tile wrongly rejected would lose covered pixels: random
+    long slivers (boxes of 1e3 .. 1e5 pixels for areas of a few hundred), near-degenerate ones, triangles with unequal w, triangles
+    that straddle the eye plane (box = the whole frame), mixed with small ones, over several images -- triangle ids and (u, v, z/w)
+    bit-exact against oracle/raster_ref.c, which walks every pixel of every box."""
+    from oracle import raster_ref
+
+    g = torch.Generator().manual_seed(H + W + len(kind))
+    B, n_big, n_small = 3, 60, 400
+    centre = torch.rand(B, n_big, 1, 2, generator=g) * 2.4 - 1.2
+    direction = torch.nn.functional.normalize(torch.randn(B, n_big, 1, 2, generator=g), dim=-1)
+    normal = torch.stack([-direction[..., 1], direction[..., 0]], -1)
+    length = 0.2 + 1.8 * torch.rand(B, n_big, 1, 1, generator=g)
+    width = 10 ** (-3.5 + 2.5 * torch.rand(B, n_big, 1, 1, generator=g))  # 3e-4 .. 1e-1 of the frame
+    t = torch.tensor([[-1.0, 0.0], [1.0, -1.0], [0.3, 1.0]]).reshape(1, 1, 3, 2)
+    xy_big = centre + direction * length * t[..., :1] + normal * width * t[..., 1:]
+    xy_small = (torch.rand(B, n_small, 1, 2, generator=g) * 2 - 1) + 0.03 * torch.randn(B, n_small, 3, 2, generator=g)
+    xy = torch.cat([xy_big, xy_small], 1)
+    n = n_big + n_small
+    z = torch.rand(B, n, 3, 1, generator=g) * 1.6 - 0.8
+    w = 0.4 + 2.0 * torch.rand(B, n, 3, 1, generator=g)
+    if kind == "eye_plane":
+        w[:, :6, 0] *= -1.0  # six triangles per image with one vertex behind the eye: every pixel of the frame is a candidate
+    clip = torch.cat([xy * w, z * w, w], -1).reshape(B, 3 * n, 4).contiguous()
+    tri = torch.arange(3 * n, dtype=torch.int32).reshape(n, 3)
+    tri = tri[torch.randperm(n, generator=g)].contiguous()
+    ref = raster_ref.rasterize(clip, tri, (H, W))
+    out = ops.rasterize(clip.to(dev), tri.to(dev), (H, W)).cpu()
+    assert np.array_equal(out[..., 3].numpy(), ref[..., 3].numpy())
+    assert np.array_equal(out.numpy(), ref.numpy())
+    big_ids = set((torch.nonzero((tri[:, 0] < 3 * n_big))[:, 0] + 1).tolist())
+    seen = set(out[..., 3].unique().int().tolist())
+    assert len(seen & big_ids) > n_big // 4 and float((out[..., 3] > 0).float().mean()) > 0.02  # the slivers really are on screen
