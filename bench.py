@@ -128,11 +128,11 @@ def algorithmic_bytes(name, d):
         # ordered pass: sdf + rank table in, sign plane out and in, 64 B of group ids per word in, the rows (ranks + source row) of the
         # words that are read, the planes cleared, set bit by bit and read once more for the in-block prefixes
         "a3d_dmtet_count_ordered": 8 * Nv + 2 * (Nv // 8) + 64 * (nwe + nwt) + 64 * (12 * we + 20 * wt) + 2 * dm_planes + Nt // 16,
-        "a3d_dmtet_emit_sparse": dm_planes + Nt // 16 + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V),
+        "a3d_dmtet_emit_sparse": dm_planes + Nt // 16 + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V) + 4 * Nv,
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
-        "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V),  # (+ the vertex -> face lists it now writes itself)  # (+ the int32 triangle list of the render kernels)
-        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 4 * Nv,
+        "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V) + 4 * Nv,  # (+ the dense SDF gradient it clears for the backward)  # (+ the vertex -> face lists it now writes itself)  # (+ the int32 triangle list of the render kernels)
+        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 8 * V + 24 * V + 2 * 32 * V,  # g_verts, edge row, index pair, 2 sdf, 2 positions in; two atomics out (32 B each on the memory side)
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
         # chain + skinning in one launch: skin_fwd's bytes + the bones / angles in and the transforms (+ chain products) out
@@ -216,7 +216,8 @@ def roofline_of(kernels, dims, signature=PMC_WORKLOAD):
     rec = None if table is None else table.get(dom.split("[")[0])
     traffic = None if rec is None else round(rec["traffic_MB"] * 1e6)
     roof = dict(kernel=dom, bound="hbm", achieved=scope[dom]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(scope[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                traffic=traffic, traffic_stale=stale, traffic_source=traffic_note, launch_us=scope[dom]["mean_us"], launches_per_step=scope[dom]["launches_per_step"],
+                traffic=traffic, traffic_lower_bound=None if rec is None or "traffic_if_all_reads_were_gathers_MB" not in rec else round(rec["traffic_if_all_reads_were_gathers_MB"] * 1e6),
+                traffic_stale=stale, traffic_source=traffic_note, launch_us=scope[dom]["mean_us"], launches_per_step=scope[dom]["launches_per_step"],
                 algorithmic_bytes_per_launch=round(scope[dom]["algorithmic_MB"] * 1e6), in_scope=_aggregate(kernels, IN_SCOPE),
                 with_f3_losses=_aggregate(kernels, IN_SCOPE + F3), mesh=dims)
     # the best-fed streaming kernel of the path, for the other end of the picture

@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch) into HBM traffic per C-ABI call.
 
-usage: python tools/pmc_traffic.py <fetch-dir> <write-dir> <out.json>
+usage: python tools/pmc_traffic.py <fetch-dir> <write-dir> <out.json> [calibration.json]
 
 gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced
-streaming reads, so traffic = 2*FETCH + WRITE (an upper bound for narrow gathers); WRITE_SIZE is uncalibrated (float atomics count
-as writes).  Infinity-Cache hits are counted, i.e. this is memory-side traffic of the L2s, not DRAM traffic.
+streaming reads, so traffic = 2*FETCH + WRITE.  Calibrated in round 4 on known byte counts (tools/pmc_calibrate.sh ->
+profiles/r04_pmc_calibration.json, carried in the output under "calibration"): WRITE_SIZE is EXACT for streaming stores (16- and
+4-byte alike); a scattered 4-byte store and a fire-and-forget 64-bit device atomic each count 32 B of WRITE (and nothing of FETCH), a
+16-lane float atomicAdd onto one 64-byte row 64 B; FETCH_SIZE is halved for every COALESCED load (4-byte lanes too) but counts a
+random 4-byte gather as its full 64-byte line -- so 2*FETCH + WRITE over-counts a gather-dominated kernel by up to 2x; that bound
+(FETCH + WRITE) is reported next to it.  Infinity-Cache hits are counted, i.e. this is memory-side traffic of the L2s, not DRAM
+traffic; lines still dirty in an L2 when a kernel ends are written back later, under another kernel's name.
 """
 import csv
 import glob
@@ -82,21 +87,29 @@ def main():
                 ks = [k for k in ks if not k.startswith("gb_cover")]
             if not ks:
                 return None
-            calls = cnt.get(main_k, 0) if main_k else sum(cnt[k] for k in ks)
+            # (the kernel that runs once per call, by PREFIX: template arguments are part of the name -- an exact match missed
+            # rs_tri_kernel<4> and the sum was divided by the dispatches of both kernels, i.e. halved: round 3's 27 MB for a3d_rast_fwd)
+            calls = sum(cnt[k] for k in cnt if k == main_k or k.startswith(main_k + "<")) if main_k else sum(cnt[k] for k in ks)
             calls = calls or sum(cnt[k] for k in ks)
             return sum(tot[k] for k in ks) / calls
         fe, wr = pick(fetch, fcnt), pick(write, wcnt)
         if fe is None and wr is None:
             continue
         fe, wr = fe or 0.0, wr or 0.0
-        per_call[entry] = dict(fetch_MB_raw=round(fe / 1e6, 2), write_MB=round(wr / 1e6, 2), traffic_MB=round((2 * fe + wr) / 1e6, 2))
+        per_call[entry] = dict(fetch_MB_raw=round(fe / 1e6, 2), write_MB=round(wr / 1e6, 2), traffic_MB=round((2 * fe + wr) / 1e6, 2),
+                               traffic_if_all_reads_were_gathers_MB=round((fe + wr) / 1e6, 2))
     import os
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
 
-    out = dict(kernel_source_sha16=bench.kernel_source_sha16(), workload=bench.PMC_WORKLOAD, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
-                    "MB per C-ABI call; traffic = 2*FETCH (gfx950 correction for wide reads, upper bound for gathers) + WRITE; "
+    calibration = None
+    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        calibration = json.load(open(sys.argv[4]))["factors"]
+    out = dict(kernel_source_sha16=bench.kernel_source_sha16(), workload=bench.PMC_WORKLOAD, calibration=calibration, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench workload B=16 256x256 Kuhn R=64, "
+                    "MB per C-ABI call; traffic = 2*FETCH (gfx950: every coalesced load is tallied at half its bytes; a random gather at its full line, "
+                    "so this is an upper bound for gather-dominated kernels, whose lower bound FETCH + WRITE is given too) + WRITE (exact for stores; 32 B "
+                    "per device atomic or scattered 4-byte store); "
                     "the copy/memset helpers of an entry point (hipMemcpyAsync / hipMemsetAsync) are not included", per_call=per_call)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in per_call.items():

@@ -12,4 +12,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python $REPO/tools/pmc_summary.py /tmp/pmc_${TAG}_FETCH_SIZE rs_ gb_ ip_ aa_ ca_ dm_ sk_ nr_ tp_ ss_ bn_ cv_ sh_ ls_ fl_ he_ gm_ > $REPO/gpurun_out/${TAG}_pmc_fetch_size.txt
 python $REPO/tools/pmc_summary.py /tmp/pmc_${TAG}_WRITE_SIZE rs_ gb_ ip_ aa_ ca_ dm_ sk_ nr_ tp_ ss_ bn_ cv_ sh_ ls_ fl_ he_ gm_ > $REPO/gpurun_out/${TAG}_pmc_write_size.txt
-python $REPO/tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $REPO/gpurun_out/${TAG}_pmc_traffic.json
+CAL=$(ls $REPO/profiles/*_pmc_calibration.json 2>/dev/null | tail -1)
+python $REPO/tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $REPO/gpurun_out/${TAG}_pmc_traffic.json $CAL
