@@ -1,6 +1,6 @@
 #!/bin/bash
 # every committed bench line of a round (run on the GPU box from the repo root):  bash tools/run_bench_lines.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 run() { name=$1; shift; python bench.py "$@" > gpurun_out/${TAG}_bench_${name}.json 2> gpurun_out/${TAG}_bench_${name}.err || (echo "$name FAILED"; tail -5 gpurun_out/${TAG}_bench_${name}.err); tail -c 300 gpurun_out/${TAG}_bench_${name}.json | head -c 0; echo "$name done"; }
 run default
@@ -9,3 +9,10 @@ run fwd_b8_grid128 --forward-only --batch 8 --networks fast --grid-res 128 --cpu
 run grid128 --grid-res 128 --networks fast --cpu-sample-images 2 --cpu-runs 1
 run fauna --workload fauna --networks fast
 run ponymation --workload ponymation --networks fast --cpu-sample-images 8 --cpu-runs 1
+# (round 4) the reference's real grid class in a file's arbitrary numbering: the "128" class in the training step and forward only, the "256" class forward only
+run bcc51s --grid bcc51s --networks fast
+run fwd_b8_bcc51s --grid bcc51s --forward-only --batch 8 --networks fast
+run fwd_b8_bcc102s --grid bcc102s --forward-only --batch 8 --networks fast --cpu-sample-images 2 --cpu-runs 1
+# the long run: 400 timed steps after 100 of warm-up (the mesh the synthetic training drifts into; README quotes it beside the 25-step figure)
+run long400 --steps 400 --warmup 100 --networks fast --no-cpu-baseline
+run long400_fauna --workload fauna --steps 400 --warmup 100 --networks fast --no-cpu-baseline
