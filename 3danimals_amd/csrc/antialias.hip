@@ -361,17 +361,22 @@ extern "C" int a3d_aa_capacity(int B, int H, int W) {
 // blends input colours, never already blended ones), and the backward never materialises a dense colour gradient: the incoming
 // gradient is gathered at the covered pixels and the blend adjoints are added to the point rows directly.
 struct CaSrc {
-    const float* vals;  // [P, C]
-    const int* inv;     // [B*H*W] point of a pixel, -1 = uncovered
+    const float* vals;  // [P, C]; null with ``rast``: every covered pixel has the value 1 in all channels (a3d_mask_aa_*)
+    const int* inv;     // [B*H*W] point of a pixel, -1 = uncovered; null: coverage is read from ``rast``
+    const float4* rast; // [B*H*W] raster texels (covered <=> id channel > 0), only without ``inv``
     const float* bg;    // [bg_batch, H, W, C+1] or null (zeros)
     int bg_shared;      // bg_batch == 1
     int C;
     unsigned hw;
 };
 
+__device__ __forceinline__ int ca_point(const CaSrc& s, unsigned p) {  // >= 0: covered (the point row, 0 without a list); -1: uncovered
+    return s.inv ? s.inv[p] : (s.rast[p].w > 0.f ? 0 : -1);
+}
+
 __device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
-    const int q = s.inv[p];
-    if (q >= 0) return c < s.C ? s.vals[(long long)q * s.C + c] : 1.f;
+    const int q = ca_point(s, p);
+    if (q >= 0) return (c < s.C && s.vals) ? s.vals[(long long)q * s.C + c] : 1.f;
     if (!s.bg) return 0.f;
     const unsigned r = s.bg_shared ? p % s.hw : p;
     return s.bg[(long long)r * (s.C + 1) + c];
@@ -411,9 +416,12 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
     const unsigned base = blockIdx.x * 256u, p = base + threadIdx.x;
     if (s.C == 3 && (((uintptr_t)out | (uintptr_t)s.bg) & 15) == 0) {
         if (p >= n_pix) return;
-        const int q = s.inv[p];
+        const int q = ca_point(s, p);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q >= 0) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
+        if (q >= 0) {
+            if (s.vals) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
+            else v = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
         else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
         v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
         __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out) + p);
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
     }
     const int C1 = s.C + 1;
     if (p < n_pix) {
-        const int q = s.inv[p];
+        const int q = ca_point(s, p);
         s_src[threadIdx.x] = q >= 0 ? q : (s.bg ? -2 - (int)(s.bg_shared ? p % s.hw : p) : -1);
     }
     __syncthreads();
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
             const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
             const int src = s_src[pl];
             v[k] = 0.f;
-            if (src >= 0) v[k] = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
+            if (src >= 0) v[k] = (c < s.C && s.vals) ? s.vals[(long long)src * s.C + c] : 1.f;
             else if (src <= -2) v[k] = s.bg[(long long)(-2 - src) * C1 + c];
         }
         v4f q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         const int pl = (int)(((float)j + 0.5f) * rc), c = j - pl * C1;
         const int src = s_src[pl];
         float v = 0.f;
-        if (src >= 0) v = c < s.C ? s.vals[(long long)src * s.C + c] : 1.f;
+        if (src >= 0) v = (c < s.C && s.vals) ? s.vals[(long long)src * s.C + c] : 1.f;
         else if (src <= -2) v = s.bg[(long long)(-2 - src) * C1 + c];
         o[j] = v;
     }
@@ -526,12 +534,12 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
         const bool use1 = rec.flags & 8, clamped = rec.flags & 16;
         const unsigned p0 = (unsigned)rec.pix0, p1 = p0 + (d ? (unsigned)W : 1u);
         const unsigned dst = rec.alpha > 0.f ? p0 : p1;
-        const int q0 = s.inv[p0], q1 = s.inv[p1];
+        const int q0 = ca_point(s, p0), q1 = ca_point(s, p1);
         float dd = 0.f;
         for (int c = sub; c < C1; c += 32) {
             const float gd = g_out[(long long)dst * C1 + c];
             if (gd != 0.f) {
-                if (c < C) {
+                if (c < C && g_vals) {  // (a constant colour has no adjoint)
                     if (q1 >= 0) atomicAdd(g_vals + (long long)q1 * C + c, rec.alpha * gd);
                     if (q0 >= 0) atomicAdd(g_vals + (long long)q0 * C + c, -rec.alpha * gd);
                 }
@@ -646,7 +654,7 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
 static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* bg, int bg_batch, int H, int W, float* out, const float* g_out,
                     float* g_vals) {
     CaJob j;
-    j.s.vals = vals; j.s.inv = inv; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
+    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
     j.out = out; j.g_out = g_out; j.g_vals = g_vals;
     return j;
 }
@@ -709,6 +717,58 @@ extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C
     A3D_CHECK_ARG(tri);
     hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, (const float4*)clip,
                        clip_batch, tri, V, H, W, g_clip);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+// ---- the texture-less, light-less render: every covered pixel is (1, .., 1), the only thing a caller differentiates is the silhouette
+// (Fauna's random-view mask for the discriminator, /root/reference/model/models/Fauna.py:111-173: render_mesh(material = None, lgt = None,
+// render_modes = ['shaded']) and only the alpha channel leaves).  As a general render that is a covered-pixel list + G-buffer launch, a
+// shading launch, a host read-back of the list's length and a compositor call over [P,3] rows of ones; here the compositor takes its
+// coverage straight from the raster texels: no list, no rows, no read-back -- two launches forward (the silhouette analysis riding in
+// the first as usual), one backward.
+extern "C" int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_batch, float* out, void* work, int32_t* count,
+                               int capacity, int B, int H, int W, const float* analyze_screen_or_null, int analyze_clip_batch,
+                               const int32_t* analyze_tri, const int32_t* analyze_opp_or_null, int V, int F,
+                               const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, int analyze_lists_stride,
+                               a3d_stream_t stream) {
+    A3D_CHECK_ARG(rast && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
+    AaAnalyzeJob an = {};
+    unsigned nb_an = 0;
+    if (analyze_screen_or_null) {  // the records do not exist yet: a3d_aa_analyze(prepared = 1) rides in the compose launch
+        A3D_CHECK_ARG(analyze_tri && V > 0 && F > 0 && (analyze_clip_batch == 1 || analyze_clip_batch == B));
+        A3D_CHECK_ARG(analyze_opp_or_null || (analyze_off_or_null && analyze_adj_or_null));
+        A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535 && analyze_lists_stride >= 0);
+        an.rast = (const float4*)rast; an.screen = (const float2*)analyze_screen_or_null; an.tri = analyze_tri; an.opp = analyze_opp_or_null;
+        an.off = analyze_off_or_null; an.adj = analyze_adj_or_null; an.work = (AaRec*)work; an.count = count;
+        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = analyze_lists_stride;
+        nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CaJob ja = ca_job(nullptr, C, nullptr, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
+    ja.s.rast = (const float4*)rast;
+    const unsigned n_pix = (unsigned)B * ja.s.hw, nb_compose = (unsigned)a3d_div_up(n_pix, 256);
+    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + nb_an, 1), dim3(256), 0, s, ja, ja, n_pix, nb_compose, an);
+    A3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_blend_kernel, dim3(512, 1), dim3(256), 0, s, ja, ja, (const AaRec*)work, count, capacity, W);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
+                               const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F,
+                               int H, int W, float* g_clip, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_out && rast && work && count && clip && g_clip && C > 0 && C <= 4096 && B > 0 && V > 0 && H > 0 && W > 0 && capacity > 0);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
+    hipStream_t s = (hipStream_t)stream;
+    A3D_HIP(hipMemsetAsync(g_clip, 0, sizeof(float) * 4 * (size_t)clip_batch * V, s));
+    if (F == 0) return A3D_OK;
+    A3D_CHECK_ARG(tri);
+    CaJob ja = ca_job(nullptr, C, nullptr, bg_or_null, bg_batch, H, W, nullptr, g_out, nullptr);
+    ja.s.rast = (const float4*)rast;
+    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024, 1), dim3(256), 0, s, ja, ja, (const AaRec*)work, count, capacity, (const float4*)clip, clip_batch,
+                       tri, V, H, W, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

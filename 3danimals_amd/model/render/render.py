@@ -37,6 +37,7 @@ LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path h
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
 FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
+FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
 FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
@@ -388,6 +389,15 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         mesh.take_normals(job)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     LAST_POINTS[0] = None
+    if (FUSED_MASK_RENDER and FUSED_COMPOSITE and material is None and lgt is None and dino_net is None and list(render_modes) == ["shaded"]
+            and spp == 1 and (background is None or not background.requires_grad)):
+        # shade() gives every covered pixel kd = (1,1,1) here (render.py:57-60, :84-85 with lgt None): the image is the coverage, and the only
+        # gradient is the silhouette's.  Fauna's random-view mask (Fauna.py:111-173).  No covered-pixel list, no G-buffer, no read-back.
+        bg = None if background is None else torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
+        tri32 = ops.tri_int32(tri)
+        analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]), defer=DEFER_ANALYSIS)
+        LAST_POINTS[0] = dict(clip=clip_f.detach())
+        return [ops.mask_antialias(rast, clip_f, bg, analysis, 3).permute(0, 3, 1, 2)]
     rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
                             prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
                             class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)

@@ -1230,6 +1230,45 @@ def antialias(color, rast, clip, tri, analysis=None):
 
 
 # ---------------------------------------------------------------------------------------------- reconstruction losses
+class _MaskAntialias(torch.autograd.Function):
+    """lerp(bg, [1, .., 1], coverage) + antialias for a texture-less, light-less render (csrc/antialias.hip: a3d_mask_aa_*): the coverage
+    comes from the raster texels, only the silhouette is differentiated (g_clip)."""
+
+    @staticmethod
+    def forward(ctx, rast, clip, bg, analysis, C):
+        require_device(rast, clip, what="mask_antialias")
+        a = analysis
+        rast_c = f32c(rast.detach())
+        if bg is not None:
+            bg = f32c(bg)
+            assert bg.shape[1:] == (a.H, a.W, C + 1) and bg.shape[0] in (1, a.B)
+        out = torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=rast.device)
+        ride = a.ride_args()  # [rast, screen, clip_batch, tri, opp, V, F, off, adj, stride] or the nulls
+        call("a3d_mask_aa_fwd", ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H,
+             a.W, *ride[1:], stream(), tag=f"[C{C + 1}]" + ("[+analysis]" if ride[0] is not None else ""))
+        if ride[0] is not None:
+            a.pending = False
+        ctx.save_for_backward(rast_c, bg)
+        ctx.analysis, ctx.C = a, C
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        rast_c, bg = ctx.saved_tensors
+        a, C = ctx.analysis, ctx.C
+        g_clip = torch.empty_like(a.clip)
+        call("a3d_mask_aa_bwd", ptr(f32c(g_out)), ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
+             ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip), stream(), tag=f"[C{C + 1}]")
+        return None, g_clip, None, None, None
+
+
+def mask_antialias(rast, clip, background, analysis, channels=3):
+    """[B,H,W,channels+1]: ones where ``rast`` is covered, ``background`` ([1|B,H,W,channels+1] or None = zeros) elsewhere, antialiased
+    with ``analysis`` (an AAAnalysis of the same rast / clip; may still be pending: it then runs inside this op's first launch)."""
+    assert analysis.rast.data_ptr() == f32c(rast.detach()).data_ptr(), "the analysis must belong to this raster buffer"
+    return _MaskAntialias.apply(rast.detach(), clip, background, analysis, int(channels))  # (coverage carries no gradient)
+
+
 class _ReconLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid):

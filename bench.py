@@ -165,6 +165,9 @@ def algorithmic_bytes(name, d):
         # gradient read at the covered pixels, point-row gradient out, vertex gradient out
         "a3d_composite_aa_fwd": 4 * B * HW + 4 * P * max(C - 1, 0) + 4 * C * B * HW,
         "a3d_composite_aa_bwd": 8 * P + 8 * P * max(C - 1, 0) + 16 * B * V,
+        # texture-less render: raster texels in, image out; backward: the silhouette records' share of the image gradient in, vertex gradient out
+        "a3d_mask_aa_fwd": 16 * B * HW + 4 * C * B * HW,
+        "a3d_mask_aa_bwd": 32 * B * V,
         "a3d_shade_fwd": P * (48 + 8 + 12 + 12 + 4 + 12),  # G-buffer row, image index, kd in; normal, shading, shaded out (camera/light rows: 1 KB table)
         "a3d_shade_bwd": P * (48 + 8 + 12 + 28 + 48 + 12),  # + the three incoming gradients; G-buffer and kd gradients out
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,

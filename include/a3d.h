@@ -411,6 +411,18 @@ int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int 
 /* analyze_rast != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
  * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
  * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */
+/* The same for a render without texture and light -- every covered pixel is (1, .., 1, alpha = 1), only the silhouette is differentiated:
+ * Fauna's random-view mask (/root/reference/model/models/Fauna.py:111-173: render_mesh(material = None, lgt = None, ['shaded']), of which
+ * only the alpha channel is used).  Coverage comes straight from the raster texels (id channel > 0): no covered-pixel list, no G-buffer,
+ * no shading, no host read-back.  out[B,H,W,C+1]; analyze_screen != NULL: the silhouette analysis rides in the first launch (the
+ * `screen` / zeroed `count` a3d_rast_fwd prepared, see a3d_composite_aa_fwd).  bwd: g_clip[clip_batch,V,4] (zeroed by callee). */
+int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_batch, float* out, void* work, int32_t* count, int capacity,
+                    int B, int H, int W, const float* analyze_screen_or_null, int analyze_clip_batch, const int32_t* analyze_tri,
+                    const int32_t* analyze_opp_or_null, int V, int F, const int32_t* analyze_off_or_null,
+                    const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream);
+int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
+                    const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H,
+                    int W, float* g_clip, a3d_stream_t stream);
 int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
                          const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch, float* g_vals2,
                          const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count, int capacity,

@@ -106,6 +106,9 @@ def _render_stage(rep, tag, points, rast_hip, posed, nrm, prior_verts, faces, ca
     ids_equal = bool(torch.equal(taps["rast"][..., 3], rast_h[..., 3]))
     rep[f"{tag}raster"] = dict(ids_equal=ids_equal, frac_ids_differ=float((taps["rast"][..., 3] != rast_h[..., 3]).float().mean()),
                                **_err(taps["rast"][..., :3], rast_h[..., :3]))
+    if points.get("gb") is None:  # a render that needed no G-buffer (texture-less, light-less: the image is the coverage)
+        outs = dict(zip(modes, outs))
+        return {mode: _err(o, _cpu(hip_out[mode])[:n]) for mode, o in outs.items() if mode in hip_out}, taps, outs
     gb_hip, pix = _dense(points, "gb", n, H, W)
     covered = torch.zeros(n * H * W, dtype=torch.bool)
     covered[pix] = True

@@ -2610,3 +2610,37 @@ def test_rasterize_large_boxes_through_the_tile_stage_bit_exact_vs_oracle(H, W, 
     big_ids = set((torch.nonzero((tri[:, 0] < 3 * n_big))[:, 0] + 1).tolist())
     seen = set(out[..., 3].unique().int().tolist())
     assert len(seen & big_ids) > n_big // 4 and float((out[..., 3] > 0).float().mean()) > 0.02  # the slivers really are on screen
+
+
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_texture_less_render_through_the_mask_compositor_equals_the_general_path(with_bg, dev, mods, monkeypatch):
+    """render_mesh(material = None, lgt = None, render_modes = ['shaded']) -- Fauna's random-view mask render (Fauna.py:111-173) -- takes
+    its coverage straight from the raster texels (a3d_mask_aa_*: no covered-pixel list, no G-buffer, no shading launch, no host read-back of
+    the list length) instead of compositing [P,3] rows of ones: same image, same gradient to the vertices, and the calls it makes."""
+    _lib = importlib.import_module("3danimals_amd._lib")
+    B, H, W = 3, 96, 96
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=9)
+    M, R = mods["mesh"], mods["render"]
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    bg = seeded((B, H, W, 3), 13, 0, 1).to(dev) if with_bg else None
+    wgt = seeded((B, 4, H, W), 17, -1, 1).to(dev)
+
+    def run(fast):
+        monkeypatch.setattr(R, "FUSED_MASK_RENDER", fast)
+        posed = (verts[None] + 0.05 * seeded((B, *verts.shape), 11, -1, 1)).to(dev).requires_grad_(True)
+        shape = M.make_mesh(posed, faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+        _ = shape.v_nrm  # (normals computed before the render, as in the step: this is the posed meshes' SECOND render)
+        with _lib.KernelTimer() as timer:
+            out = R.render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), background=bg, bsdf="diffuse",
+                                render_modes=["shaded"], two_sided_shading=False)[0]
+            (g,) = torch.autograd.grad((out * wgt).sum(), posed)
+        return out.detach(), g, sorted(timer.summary())
+
+    out_f, g_f, calls_f = run(True)
+    out_g, g_g, calls_g = run(False)
+    assert out_f.shape == (B, 4, H, W) and float((out_f - out_g).abs().max()) < 1e-6
+    assert float((out_f[:, 3] > 0).float().mean()) > 0.05 and float(((out_f[:, 3] > 0.01) & (out_f[:, 3] < 0.99)).float().mean()) > 1e-3
+    assert float(g_g.abs().max()) > 0 and float((g_f - g_g).abs().max()) <= 1e-4 * float(g_g.abs().max())
+    assert calls_f == ["a3d_mask_aa_bwd[C4]", "a3d_mask_aa_fwd[C4][+analysis]", "a3d_rast_fwd"], calls_f
+    assert any(c.startswith("a3d_cover_gbuffer_fwd") for c in calls_g) and any(c.startswith("a3d_composite_aa_fwd") for c in calls_g)
