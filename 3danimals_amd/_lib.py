@@ -22,8 +22,7 @@ SIGNATURES = {
     "a3d_dmtet_word_group_bits": (_c_int, []),
     "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
-    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _p,
-                                _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_dmtet_emit_sparse": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_skin_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p]),
@@ -47,8 +46,7 @@ SIGNATURES = {
     "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _p, _p, _p,
-                              _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p]),
+    "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
@@ -82,9 +80,8 @@ SIGNATURES = {
     "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int,
-                                      _p, _p, _c_int, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
-    "a3d_mask_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
+    "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_mask_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_mask_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_composite_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p, _c_int, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p,
                                       _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
@@ -99,14 +96,32 @@ class DmtetOrder(ctypes.Structure):
                 ("tets_ranked", _p), ("tet_of_row", _p), ("edge_groups", _p), ("tet_groups", _p)]
 
 
+class RastOpts(ctypes.Structure):
+    """a3d_rast_opts of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("lists_stride", ctypes.c_int32), ("prev_rast", _p), ("cover_scratch", _p), ("aa_screen", _p),
+                ("aa_count", _p), ("topo_off", _p), ("topo_adj", _p), ("topo_opp", _p), ("normals_v_a", _p), ("normals_v_b", _p),
+                ("normals_off", _p), ("normals_adj", _p), ("normals_acc_a", _p), ("normals_a", _p), ("normals_acc_b", _p), ("normals_b", _p),
+                ("normals_B_a", ctypes.c_int32), ("normals_B_b", ctypes.c_int32)]
+
+
+class AaRide(ctypes.Structure):
+    """a3d_aa_ride of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("clip_batch", ctypes.c_int32), ("rast", _p), ("screen", _p), ("tri", _p), ("opp", _p), ("off", _p),
+                ("adj", _p), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("lists_stride", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class DmtetEmitOpts(ctypes.Structure):
     """a3d_dmtet_emit_opts of include/a3d.h."""
 
     _fields_ = [("size", ctypes.c_uint32), ("Nv", ctypes.c_int32), ("vertex_scratch", _p), ("surf_idx", _p), ("g_sdf_to_clear", _p), ("tri32", _p),
-                ("topo_count", _p), ("topo_adj", _p), ("device_counts", _p), ("n_surf", ctypes.c_int32), ("topo_stride", ctypes.c_int32)]
+                ("topo_count", _p), ("topo_adj", _p), ("device_counts", _p), ("n_surf", ctypes.c_int32), ("topo_stride", ctypes.c_int32),
+                ("use_block_lists", ctypes.c_int32), ("n_edge_blocks_listed", ctypes.c_int32), ("n_tet_blocks_listed", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
-ABI_VERSION = 400  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 401  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

@@ -659,25 +659,31 @@ static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* b
     return j;
 }
 
+// the riding analysis of a compositor call: the job for the extra work-groups of its first launch, or nothing
+static int ca_ride(const a3d_aa_ride* r, const float* rast_override, void* work, int32_t* count, int capacity, int B, int H, int W, AaAnalyzeJob* an,
+                   unsigned* nb_an) {
+    *an = AaAnalyzeJob{};
+    *nb_an = 0;
+    if (!r) return A3D_OK;
+    A3D_CHECK_ARG(r->size >= sizeof(a3d_aa_ride));
+    const float* rast = rast_override ? rast_override : r->rast;
+    A3D_CHECK_ARG(rast && r->screen && r->tri && r->V > 0 && r->F > 0 && (r->clip_batch == 1 || r->clip_batch == B));
+    A3D_CHECK_ARG(r->opp || (r->off && r->adj));
+    A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535 && r->lists_stride >= 0);
+    an->rast = (const float4*)rast; an->screen = (const float2*)r->screen; an->tri = r->tri; an->opp = r->opp;
+    an->off = r->off; an->adj = r->adj; an->work = (AaRec*)work; an->count = count;
+    an->clip_batch = r->clip_batch; an->V = r->V; an->F = r->F; an->H = H; an->W = W; an->capacity = capacity; an->B = B; an->stride = r->lists_stride;
+    *nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
+    return A3D_OK;
+}
+
 extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null,
                                     int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
-                                    int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null,
-                                    const float* analyze_screen, int analyze_clip_batch, const int32_t* analyze_tri,
-                                    const int32_t* analyze_opp_or_null, int V, int F, const int32_t* analyze_off_or_null,
-                                    const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream) {
+                                    int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
-    AaAnalyzeJob an = {};
-    unsigned nb_an = 0;
-    if (analyze_rast_or_null) {  // a3d_aa_analyze(prepared = 1)'s launch rides in the compose launch
-        A3D_CHECK_ARG(analyze_screen && analyze_tri && V > 0 && F > 0 && (analyze_clip_batch == 1 || analyze_clip_batch == B));
-        A3D_CHECK_ARG(analyze_opp_or_null || (analyze_off_or_null && analyze_adj_or_null));
-        A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535);
-        an.rast = (const float4*)analyze_rast_or_null; an.screen = (const float2*)analyze_screen; an.tri = analyze_tri; an.opp = analyze_opp_or_null;
-        an.off = analyze_off_or_null; an.adj = analyze_adj_or_null; an.work = (AaRec*)work; an.count = count;
-        A3D_CHECK_ARG(analyze_lists_stride >= 0);
-        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = analyze_lists_stride;
-        nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
-    }
+    AaAnalyzeJob an;
+    unsigned nb_an;
+    if (int rc = ca_ride(analyze_or_null, nullptr, work, count, capacity, B, H, W, &an, &nb_an)) return rc;
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
     const bool two = out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 + 1 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B)));
@@ -728,23 +734,12 @@ extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C
 // coverage straight from the raster texels: no list, no rows, no read-back -- two launches forward (the silhouette analysis riding in
 // the first as usual), one backward.
 extern "C" int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_batch, float* out, void* work, int32_t* count,
-                               int capacity, int B, int H, int W, const float* analyze_screen_or_null, int analyze_clip_batch,
-                               const int32_t* analyze_tri, const int32_t* analyze_opp_or_null, int V, int F,
-                               const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, int analyze_lists_stride,
-                               a3d_stream_t stream) {
+                               int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(rast && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (!bg_or_null || bg_batch == 1 || bg_batch == B));
-    AaAnalyzeJob an = {};
-    unsigned nb_an = 0;
-    if (analyze_screen_or_null) {  // the records do not exist yet: a3d_aa_analyze(prepared = 1) rides in the compose launch
-        A3D_CHECK_ARG(analyze_tri && V > 0 && F > 0 && (analyze_clip_batch == 1 || analyze_clip_batch == B));
-        A3D_CHECK_ARG(analyze_opp_or_null || (analyze_off_or_null && analyze_adj_or_null));
-        A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535 && analyze_lists_stride >= 0);
-        an.rast = (const float4*)rast; an.screen = (const float2*)analyze_screen_or_null; an.tri = analyze_tri; an.opp = analyze_opp_or_null;
-        an.off = analyze_off_or_null; an.adj = analyze_adj_or_null; an.work = (AaRec*)work; an.count = count;
-        an.clip_batch = analyze_clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = analyze_lists_stride;
-        nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
-    }
+    AaAnalyzeJob an;
+    unsigned nb_an;
+    if (int rc = ca_ride(analyze_or_null, rast, work, count, capacity, B, H, W, &an, &nb_an)) return rc;
     hipStream_t s = (hipStream_t)stream;
     CaJob ja = ca_job(nullptr, C, nullptr, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
     ja.s.rast = (const float4*)rast;

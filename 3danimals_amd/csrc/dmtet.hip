@@ -1058,9 +1058,19 @@ extern "C" int a3d_dmtet_count_ordered(const float* sdf, int Nv, int Ne, int Nt,
 
 extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                               const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                              void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                              int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
-                              int n_edge_blocks_listed, int n_tet_blocks_listed, const int32_t* device_counts_or_null, a3d_stream_t stream) {
+                              const a3d_dmtet_emit_opts* opts_or_null, a3d_stream_t stream) {
+    a3d_dmtet_emit_opts o = {};
+    if (opts_or_null) {
+        A3D_CHECK_ARG(opts_or_null->size >= sizeof(a3d_dmtet_emit_opts));
+        o = *opts_or_null;
+    }
+    void* vertex_scratch_or_null = o.vertex_scratch;
+    const int Nv = o.Nv, n_surf = o.n_surf, topo_stride = o.topo_stride;
+    int64_t* surf_idx_or_null = o.surf_idx;
+    float* g_sdf_to_clear_or_null = o.g_sdf_to_clear;
+    int32_t *tri32_or_null = o.tri32, *topo_count_or_null = o.topo_count, *topo_adj_or_null = o.topo_adj;
+    const int n_edge_blocks_listed = o.use_block_lists ? o.n_edge_blocks_listed : -1, n_tet_blocks_listed = o.use_block_lists ? o.n_tet_blocks_listed : -1;
+    const int32_t* device_counts_or_null = o.device_counts;
     A3D_CHECK_ARG(pos && sdf && edges && tet2edge && scratch);
     const bool spec = device_counts_or_null != nullptr;  // V, n1 (= F), n_surf, n_*_blocks_listed are CAPACITIES; n2 is ignored
     A3D_CHECK_ARG(!spec || (n_edge_blocks_listed >= 0 && n_tet_blocks_listed >= 0 && V > 0));

@@ -422,13 +422,23 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
 
 extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
 
-extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                            void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                            float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null,
-                            const int32_t* topo_adj_or_null, int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a,
-                            const float* normals_v_b_or_null, int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj,
-                            float* normals_acc_a, float* normals_a, float* normals_acc_b, float* normals_b, int lists_stride,
-                            a3d_stream_t stream) {
+extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
+                            int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream) {
+    a3d_rast_opts o = {};
+    if (opts_or_null) {
+        A3D_CHECK_ARG(opts_or_null->size >= sizeof(a3d_rast_opts));
+        o = *opts_or_null;
+    }
+    const float* prev_rast_or_null = o.prev_rast;
+    void* cover_scratch_or_null = o.cover_scratch;
+    float* aa_screen_or_null = o.aa_screen;
+    int32_t* aa_count_or_null = o.aa_count;
+    const int32_t *topo_off_or_null = o.topo_off, *topo_adj_or_null = o.topo_adj;
+    int32_t* topo_opp_or_null = o.topo_opp;
+    const float *normals_v_a_or_null = o.normals_v_a, *normals_v_b_or_null = o.normals_v_b;
+    const int normals_B_a = o.normals_B_a, normals_B_b = o.normals_B_b, lists_stride = o.lists_stride;
+    const int32_t *normals_off = o.normals_off, *normals_adj = o.normals_adj;
+    float *normals_acc_a = o.normals_acc_a, *normals_a = o.normals_a, *normals_acc_b = o.normals_acc_b, *normals_b = o.normals_b;
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(F == 0 || (tri && scratch));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);

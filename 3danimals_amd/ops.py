@@ -237,16 +237,14 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
 
     def emit(Vn, n1n, n2n, bufs, n_surf_n, tri32_t, cnt_t, adj_t, stride_n, listed, dev_counts):
         """a3d_dmtet_emit, or after the ordered count pass (surface items spread evenly over the planes) a3d_dmtet_emit_sparse."""
-        if which == "ordered":
-            opts = _lib.DmtetEmitOpts(size=ctypes.sizeof(_lib.DmtetEmitOpts), Nv=Nv, vertex_scratch=ptr(vscratch), surf_idx=ptr(bufs[4]),
-                                      g_sdf_to_clear=ptr(g_sdf), tri32=ptr(tri32_t), topo_count=ptr(cnt_t), topo_adj=ptr(adj_t),
-                                      device_counts=ptr(dev_counts), n_surf=n_surf_n if surface_vertices else 0, topo_stride=stride_n)
-            call("a3d_dmtet_emit_sparse", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), Vn, n1n, n2n,
-                 ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ctypes.addressof(opts), stream())
-        else:
-            call("a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt, ptr(scratch), Vn, n1n, n2n, ptr(bufs[0]),
-                 ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(vscratch), Nv, n_surf_n if surface_vertices else 0, ptr(bufs[4]), ptr(g_sdf),
-                 ptr(tri32_t), ptr(cnt_t), ptr(adj_t), stride_n, listed[0], listed[1], ptr(dev_counts), stream())
+        use_lists = which != "ordered" and listed[0] >= 0 and listed[1] >= 0
+        opts = _lib.DmtetEmitOpts(size=ctypes.sizeof(_lib.DmtetEmitOpts), Nv=Nv, vertex_scratch=ptr(vscratch), surf_idx=ptr(bufs[4]),
+                                  g_sdf_to_clear=ptr(g_sdf), tri32=ptr(tri32_t), topo_count=ptr(cnt_t), topo_adj=ptr(adj_t),
+                                  device_counts=ptr(dev_counts), n_surf=n_surf_n if surface_vertices else 0, topo_stride=stride_n,
+                                  use_block_lists=int(use_lists), n_edge_blocks_listed=listed[0] if use_lists else 0,
+                                  n_tet_blocks_listed=listed[1] if use_lists else 0)
+        call("a3d_dmtet_emit_sparse" if which == "ordered" else "a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt,
+             ptr(scratch), Vn, n1n, n2n, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ctypes.addressof(opts), stream())
 
     # SPECULATIVE emit: with the numbers of the previous extraction on this grid as a guess (+25 %), the emit launch is enqueued BEFORE
     # the host reads the counts -- the kernel takes the true sizes from the device, the GPU does not idle across the read-back, and the
@@ -712,7 +710,9 @@ class _Rasterize(torch.autograd.Function):
         # ... and a pending vertex-normals pass over the same triangle list (NormalsJob: the mesh being rasterised + the canonical one)
         if job is not None and not (F > 0 and job.tri32.data_ptr() == tri32.data_ptr() and job.v_a.shape[1] == V and job.v_a.device == clip.device):
             job = None  # (stays not done: the caller computes the normals in a launch of their own)
-        nj = [None, 0, None, 0, None, None, None, None, None, None]
+        opts = _lib.RastOpts(size=ctypes.sizeof(_lib.RastOpts), prev_rast=ptr(prev), cover_scratch=ptr(cover), aa_screen=ptr(aa_screen),
+                             aa_count=ptr(aa_count), topo_off=ptr(None if lists is None else lists.off), topo_adj=ptr(None if lists is None else lists.adj),
+                             topo_opp=ptr(opp))
         stride = lists.stride if lists is not None else (job.adjacency.stride if job is not None else 0)
         if job is not None and lists is not None and lists is not job.adjacency and lists.stride != job.adjacency.stride:
             job = None  # (one layout per launch)
@@ -720,11 +720,13 @@ class _Rasterize(torch.autograd.Function):
             job.acc_a, job.nrm_a = torch.empty_like(job.v_a), torch.empty_like(job.v_a)
             if job.v_b is not None:
                 job.acc_b, job.nrm_b = torch.empty_like(job.v_b), torch.empty_like(job.v_b)
-            nj = [ptr(job.v_a), job.v_a.shape[0], ptr(job.v_b), 0 if job.v_b is None else job.v_b.shape[0], ptr(job.adjacency.off),
-                  ptr(job.adjacency.adj), ptr(job.acc_a), ptr(job.nrm_a), ptr(job.acc_b), ptr(job.nrm_b)]
-        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ptr(prev), ptr(cover),
-             ptr(aa_screen), ptr(aa_count), ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), ptr(opp), *nj,
-             stride, stream(), tag="" if job is None else f"[N{nj[1]}+{nj[3]}]")
+            opts.normals_v_a, opts.normals_B_a, opts.normals_v_b = ptr(job.v_a), job.v_a.shape[0], ptr(job.v_b)
+            opts.normals_B_b = 0 if job.v_b is None else job.v_b.shape[0]
+            opts.normals_off, opts.normals_adj = ptr(job.adjacency.off), ptr(job.adjacency.adj)
+            opts.normals_acc_a, opts.normals_a, opts.normals_acc_b, opts.normals_b = ptr(job.acc_a), ptr(job.nrm_a), ptr(job.acc_b), ptr(job.nrm_b)
+        opts.lists_stride = stride
+        call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ctypes.addressof(opts), stream(),
+             tag="" if job is None else f"[N{opts.normals_B_a}+{opts.normals_B_b}]")
         if job is not None:
             job.done = True
         if opp is not None:
@@ -1101,16 +1103,18 @@ class AAAnalysis:
             self.ensure()
 
     def ride_args(self):
-        """Arguments that make a3d_composite_aa_fwd run the pending analysis in its first launch, or the nulls.  The caller marks the
+        """The a3d_aa_ride struct that makes a3d_composite_aa_fwd / a3d_mask_aa_fwd run the pending analysis in their first launch, or None.  The caller marks the
         analysis done (``pending = False``) once that call has SUCCEEDED: a refused call must not leave an unfilled work list behind
         that later consumers would take for finished.  Batches the riding form cannot address (B > 65535) run stand-alone now."""
         if self.pending and self.B > 65535:
             self.ensure()
         if not self.pending:
-            return [None, None, 0, None, None, 0, 0, None, None, 0]
+            return None
         topo, lists = self.topo, getattr(self.topo, "lists", None)
-        return [ptr(self.rast), ptr(self.screen), self.clip.shape[0], ptr(topo.tri), ptr(topo.opp), self.clip.shape[1], topo.tri.shape[0],
-                ptr(None if lists is None else lists.off), ptr(None if lists is None else lists.adj), 0 if lists is None else lists.stride]
+        return _lib.AaRide(size=ctypes.sizeof(_lib.AaRide), clip_batch=self.clip.shape[0], rast=ptr(self.rast), screen=ptr(self.screen),
+                           tri=ptr(topo.tri), opp=ptr(topo.opp), off=ptr(None if lists is None else lists.off),
+                           adj=ptr(None if lists is None else lists.adj), V=self.clip.shape[1], F=topo.tri.shape[0],
+                           lists_stride=0 if lists is None else lists.stride)
 
     def ensure(self):
         """Run the analysis now if it has not run yet (stand-alone launch)."""
@@ -1176,9 +1180,9 @@ class _CompositeAntialias(torch.autograd.Function):
         tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
         call("a3d_composite_aa_fwd", ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
-             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W, *ride, stream(),
-             tag=tag + ("[+analysis]" if ride[0] is not None else ""))
-        if ride[0] is not None:
+             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W,
+             None if ride is None else ctypes.addressof(ride), stream(), tag=tag + ("[+analysis]" if ride is not None else ""))
+        if ride is not None:
             a.pending = False  # (only now: the call above raises on a refused argument)
         ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
         ctx.analysis, ctx.tag = a, tag
@@ -1243,10 +1247,10 @@ class _MaskAntialias(torch.autograd.Function):
             bg = f32c(bg)
             assert bg.shape[1:] == (a.H, a.W, C + 1) and bg.shape[0] in (1, a.B)
         out = torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=rast.device)
-        ride = a.ride_args()  # [rast, screen, clip_batch, tri, opp, V, F, off, adj, stride] or the nulls
+        ride = a.ride_args()
         call("a3d_mask_aa_fwd", ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H,
-             a.W, *ride[1:], stream(), tag=f"[C{C + 1}]" + ("[+analysis]" if ride[0] is not None else ""))
-        if ride[0] is not None:
+             a.W, None if ride is None else ctypes.addressof(ride), stream(), tag=f"[C{C + 1}]" + ("[+analysis]" if ride is not None else ""))
+        if ride is not None:
             a.pending = False
         ctx.save_for_backward(rast_c, bg)
         ctx.analysis, ctx.C = a, C

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 400 = this header */
+int a3d_version(void); /* 401 = this header */
 const char* a3d_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -92,11 +92,10 @@ int a3d_dmtet_count_ordered(const float* sdf, int Nv, int Ne, int Nt, const a3d_
 /* (Nv = number of grid vertices, or 0 if unknown.  Grids of >= 2^20 vertices take a pre-pass that leaves one sign bit per vertex in
  * scratch; the count pass then looks signs up there -- a handful of cache lines per wave instead of one per 32 vertices -- and streams
  * its index rows with four rows per lane in flight.  Same bit planes and counts either way.) */
+struct a3d_dmtet_emit_opts; /* the optional groups below, by name (defined after the prose that describes them) */
 int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                    const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
-                   void* vertex_scratch_or_null, int Nv, int n_surf, int64_t* surf_idx_or_null, float* g_sdf_to_clear_or_null,
-                   int32_t* tri32_or_null, int32_t* topo_count_or_null, int32_t* topo_adj_or_null, int topo_stride,
-                   int n_edge_blocks_listed, int n_tet_blocks_listed, const int32_t* device_counts_or_null, a3d_stream_t stream);
+                   const struct a3d_dmtet_emit_opts* opts_or_null, a3d_stream_t stream);
 /* The emit launch for SPARSE planes -- after a3d_dmtet_count_ordered, where the surface items of a randomly numbered grid are spread
  * evenly over the planes (one or two per 1024-row block at the "256" class) and a work-group per block is all latency: thread = 64-row
  * word of a plane instead.  Same outputs as a3d_dmtet_emit, bit for bit; `scratch` must come from a3d_dmtet_count_ordered (whose scan
@@ -114,6 +113,10 @@ typedef struct a3d_dmtet_emit_opts {
     const int32_t* device_counts; /* speculative launch: `counts` of the count call, still on the device; V, n1 (= F), n_surf are capacities */
     int32_t n_surf;
     int32_t topo_stride;
+    int32_t use_block_lists;      /* a3d_dmtet_emit only: 1 = cover only the non-empty blocks the culled count pass listed ... */
+    int32_t n_edge_blocks_listed; /* ... = counts[4] of that a3d_dmtet_count call (speculative launch: a capacity) */
+    int32_t n_tet_blocks_listed;  /* ... = counts[5] */
+    int32_t reserved;
 } a3d_dmtet_emit_opts;
 int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                           const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
@@ -281,12 +284,30 @@ int a3d_cover_emit(const float* rast, int B, int H, int W, int tile, const void*
  * instead of in a launch of their own.
  */
 size_t a3d_rast_scratch_bytes(int B, int H, int W); /* 64-bit (depth, id) key per pixel */
+/* The optional groups described above (round 4: by name, in a struct, instead of 19 positional NULLs; every field may be NULL / 0): */
+typedef struct a3d_rast_opts {
+    uint32_t size;                 /* sizeof(a3d_rast_opts) of the caller's header (fields are only ever appended) */
+    int32_t lists_stride;          /* layout of topo_off / topo_adj and normals_off / normals_adj (see a3d_normals_*: 0 = CSR) */
+    const float* prev_rast;        /* depth peeling: the previous layer [B,H,W,4] */
+    void* cover_scratch;           /* the covered-pixel list's block counts and group sums are left here */
+    float* aa_screen;              /* [clip_batch,V,2] with aa_count: what a3d_aa_analyze(prepared = 1) needs first */
+    int32_t* aa_count;             /* [a3d_aa_shards()] */
+    const int32_t* topo_off;       /* with topo_adj and topo_opp: the opposite-vertex table from the vertex -> face lists */
+    const int32_t* topo_adj;
+    int32_t* topo_opp;             /* [F,3] */
+    const float* normals_v_a;      /* [normals_B_a,V,3]: the vertex normals of these meshes ride in the triangle launch */
+    const float* normals_v_b;      /* [normals_B_b,V,3] or NULL: a second vertex array over the same triangle list */
+    const int32_t* normals_off;    /* the vertex -> face lists of `tri` */
+    const int32_t* normals_adj;
+    float* normals_acc_a;          /* outputs as a3d_normals_fwd writes them */
+    float* normals_a;
+    float* normals_acc_b;
+    float* normals_b;
+    int32_t normals_B_a;
+    int32_t normals_B_b;
+} a3d_rast_opts;
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
-                 void* scratch, int scratch_is_clean, const float* prev_rast_or_null, void* cover_scratch_or_null,
-                 float* aa_screen_or_null, int32_t* aa_count_or_null, const int32_t* topo_off_or_null, const int32_t* topo_adj_or_null,
-                 int32_t* topo_opp_or_null, const float* normals_v_a_or_null, int normals_B_a, const float* normals_v_b_or_null,
-                 int normals_B_b, const int32_t* normals_off, const int32_t* normals_adj, float* normals_acc_a, float* normals_a,
-                 float* normals_acc_b, float* normals_b, int lists_stride /* of topo_* and normals_* */, a3d_stream_t stream);
+                 void* scratch, int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 
@@ -403,23 +424,36 @@ int a3d_aa_bwd(const float* g_out, const float* color, int C, const void* work, 
  * (render_mesh antialiases the colour and the feature image of a step).
  * bwd: g_vals[P,C] (fully written: g_out at the covered pixels + the blend adjoints; no dense colour gradient exists) -- likewise
  *   g_vals2 -- and g_clip[clip_batch,V,4] (zeroed by callee; both buffers add to it).  The backgrounds receive no gradient. */
+/* The silhouette analysis riding in the first launch of a compositor call (round 4: by name instead of ten positional arguments): the
+ * arguments of a3d_aa_analyze(prepared = 1) -- rast, the `screen` and zeroed `count` that a3d_rast_fwd left (count is the compositor's own
+ * argument), tri, opp or the vertex -> face lists. */
+typedef struct a3d_aa_ride {
+    uint32_t size;        /* sizeof(a3d_aa_ride) of the caller's header (fields are only ever appended) */
+    int32_t clip_batch;
+    const float* rast;    /* [B,H,W,4] */
+    const float* screen;  /* [clip_batch,V,2] */
+    const int32_t* tri;   /* [F,3] */
+    const int32_t* opp;   /* [F,3] or NULL with off / adj */
+    const int32_t* off;
+    const int32_t* adj;
+    int32_t V;
+    int32_t F;
+    int32_t lists_stride; /* layout of off / adj (see a3d_normals_*) */
+    int32_t reserved;
+} a3d_aa_ride;
 int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null, int C2,
                          const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
-                         int32_t* count, int capacity, int B, int H, int W, const float* analyze_rast_or_null, const float* analyze_screen,
-                         int analyze_clip_batch, const int32_t* analyze_tri, const int32_t* analyze_opp_or_null, int V, int F,
-                         const int32_t* analyze_off_or_null, const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream);
-/* analyze_rast != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
+                         int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, a3d_stream_t stream);
+/* analyze != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
  * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
  * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */
 /* The same for a render without texture and light -- every covered pixel is (1, .., 1, alpha = 1), only the silhouette is differentiated:
  * Fauna's random-view mask (/root/reference/model/models/Fauna.py:111-173: render_mesh(material = None, lgt = None, ['shaded']), of which
  * only the alpha channel is used).  Coverage comes straight from the raster texels (id channel > 0): no covered-pixel list, no G-buffer,
- * no shading, no host read-back.  out[B,H,W,C+1]; analyze_screen != NULL: the silhouette analysis rides in the first launch (the
- * `screen` / zeroed `count` a3d_rast_fwd prepared, see a3d_composite_aa_fwd).  bwd: g_clip[clip_batch,V,4] (zeroed by callee). */
+ * no shading, no host read-back.  out[B,H,W,C+1]; analyze != NULL: the silhouette analysis rides in the first launch (see
+ * a3d_composite_aa_fwd).  bwd: g_clip[clip_batch,V,4] (zeroed by callee). */
 int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_batch, float* out, void* work, int32_t* count, int capacity,
-                    int B, int H, int W, const float* analyze_screen_or_null, int analyze_clip_batch, const int32_t* analyze_tri,
-                    const int32_t* analyze_opp_or_null, int V, int F, const int32_t* analyze_off_or_null,
-                    const int32_t* analyze_adj_or_null, int analyze_lists_stride, a3d_stream_t stream);
+                    int B, int H, int W, const a3d_aa_ride* analyze_or_null /* (its rast = this call's) */, a3d_stream_t stream);
 int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
                     const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H,
                     int W, float* g_clip, a3d_stream_t stream);

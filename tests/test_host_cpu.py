@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 400
+    assert lib.a3d_version() == L.ABI_VERSION == 401
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -593,7 +593,7 @@ def test_spatial_order_tables_reproduce_the_planes_of_the_file_order(grid):
     assert culled_any
 
 
-@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts")])
+@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide")])
 def test_abi_structs_match_the_header_field_for_field(struct, cls):
     """The option structs of include/a3d.h against their ctypes mirrors: names, order, pointer / int32 / uint32 kind; `size` first."""
     L = importlib.import_module("3danimals_amd._lib")

@@ -59,7 +59,7 @@ def main():
     elif what == "rast_fwd":
         out = torch.empty(B, H, W, 4, device=dev)
         scratch = torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
-        fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), 0, None, None, None, None, stream())
+        fn = lambda: L.call("a3d_rast_fwd", ptr(clip), B, ptr(tri32), B, V, F, H, W, ptr(out), ptr(scratch), 0, None, stream())
     elif what == "aa_analyze":
         topo = ops.aa_topology(tri32, V)
         cap = L.lib().a3d_aa_capacity(B, H, W)
