@@ -15,6 +15,7 @@
 // HBM traffic: analyze reads 16 B/pixel; fwd/bwd copy 4C B/pixel in and out; the work list is a few thousand
 // 16-byte records per image.  Compiled with -ffp-contract=off so sign tests agree with the oracle.
 #include "a3d_common.h"
+#include "shade_common.h"
 #include "topo_common.h"
 
 #define AA_SHARDS 256  // segments of the crossing work list (the consumers' work-group size: one thread per segment scans the fill counts)
@@ -364,6 +365,12 @@ struct CaSrc {
     const float* vals;  // [P, C]; null with ``rast``: every covered pixel has the value 1 in all channels (a3d_mask_aa_*)
     const int* inv;     // [B*H*W] point of a pixel, -1 = uncovered; null: coverage is read from ``rast``
     const float4* rast; // [B*H*W] raster texels (covered <=> id channel > 0), only without ``inv``
+    // vals == null with sh_gb (C == 3): the value of point q is kd[q] * shading(q), computed on the spot from the G-buffer row, the image's
+    // camera / light row and kd -- a3d_shade_fwd's arithmetic (shade_common.h) without its launch and without the [P,3] round trip
+    const float* sh_gb;   // [P,12]
+    const float* sh_par;  // [B,17]
+    const float* sh_kd;   // [P,3], row stride sh_kd_stride
+    int sh_kd_stride, sh_two_sided;
     const float* bg;    // [bg_batch, H, W, C+1] or null (zeros)
     int bg_shared;      // bg_batch == 1
     int C;
@@ -374,8 +381,18 @@ __device__ __forceinline__ int ca_point(const CaSrc& s, unsigned p) {  // >= 0: 
     return s.inv ? s.inv[p] : (s.rast[p].w > 0.f ? 0 : -1);
 }
 
+__device__ __forceinline__ float3 ca_shaded(const CaSrc& s, int q, unsigned p) {  // (sh_gb given) the shaded colour of point q = pixel p
+    const ShFwd f = sh_forward(s.sh_gb + 12ll * q, s.sh_par + 17ll * (p / s.hw), 17, s.sh_two_sided);
+    const float* k = s.sh_kd + (long long)s.sh_kd_stride * q;
+    return make_float3(k[0] * f.shading, k[1] * f.shading, k[2] * f.shading);
+}
+
 __device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
     const int q = ca_point(s, p);
+    if (q >= 0 && c < s.C && !s.vals && s.sh_gb) {
+        const float3 v = ca_shaded(s, q, p);
+        return c == 0 ? v.x : (c == 1 ? v.y : v.z);
+    }
     if (q >= 0) return (c < s.C && s.vals) ? s.vals[(long long)q * s.C + c] : 1.f;
     if (!s.bg) return 0.f;
     const unsigned r = s.bg_shared ? p % s.hw : p;
@@ -387,6 +404,8 @@ __device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
 // the larger part of what these latency-bound kernels cost.
 struct CaJob {
     CaSrc s;
+    float* clear;        // forward: n_clear floats zeroed by the compose launch (a3d_ca_shade: the shading backward's per-image rows)
+    int n_clear;
     float* out;          // forward: [B,H,W,C+1]
     const float* g_out;  // backward: [B,H,W,C+1]
     float* g_vals;       // backward: [P,C]
@@ -414,12 +433,14 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
     float* __restrict__ out = job.out;
     typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned base = blockIdx.x * 256u, p = base + threadIdx.x;
+    for (unsigned z = p; z < (unsigned)job.n_clear; z += nb_compose * 256u) job.clear[z] = 0.f;
     if (s.C == 3 && (((uintptr_t)out | (uintptr_t)s.bg) & 15) == 0) {
         if (p >= n_pix) return;
         const int q = ca_point(s, p);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q >= 0) {
             if (s.vals) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
+            else if (s.sh_gb) { const float3 c3 = ca_shaded(s, q, p); v = make_float4(c3.x, c3.y, c3.z, 1.f); }
             else v = make_float4(1.f, 1.f, 1.f, 1.f);
         }
         else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
@@ -654,9 +675,20 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
 static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* bg, int bg_batch, int H, int W, float* out, const float* g_out,
                     float* g_vals) {
     CaJob j;
-    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
-    j.out = out; j.g_out = g_out; j.g_vals = g_vals;
+    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = nullptr; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0;
+    j.s.sh_two_sided = 0; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
+    j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0;
     return j;
+}
+
+// the deferred shading of a compositor call's first buffer (a3d_ca_shade): the job's values come from sh_forward instead of vals
+static int ca_shade(const a3d_ca_shade* sh, int C, const float* vals, CaJob* j, bool forward) {
+    if (!sh) return A3D_OK;
+    A3D_CHECK_ARG(sh->size >= sizeof(a3d_ca_shade));
+    A3D_CHECK_ARG(!vals && C == 3 && sh->gb && sh->par && sh->kd && sh->kd_stride >= 3 && sh->n_clear >= 0 && (sh->n_clear == 0 || sh->clear));
+    j->s.sh_gb = sh->gb; j->s.sh_par = sh->par; j->s.sh_kd = sh->kd; j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
+    if (forward) { j->clear = sh->clear; j->n_clear = sh->n_clear; }
+    return A3D_OK;
 }
 
 // the riding analysis of a compositor call: the job for the extra work-groups of its first launch, or nothing
@@ -679,7 +711,8 @@ static int ca_ride(const a3d_aa_ride* r, const float* rast_override, void* work,
 
 extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null,
                                     int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
-                                    int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, a3d_stream_t stream) {
+                                    int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null,
+                                    const a3d_ca_shade* shade_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
     AaAnalyzeJob an;
     unsigned nb_an;
@@ -688,7 +721,8 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
     const bool two = out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 + 1 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B)));
     hipStream_t s = (hipStream_t)stream;
-    const CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
+    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
+    if (int rc = ca_shade(shade_or_null, C, vals, &ja, true)) return rc;
     const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr) : ja;
     const unsigned n_pix = (unsigned)B * ja.s.hw;
     const unsigned nb_compose = (unsigned)a3d_div_up(n_pix, 256), rows = two ? 2u : 1u;
@@ -703,14 +737,15 @@ extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C
                                     const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch,
                                     float* g_vals2, const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count,
                                     int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W,
-                                    float* g_clip, a3d_stream_t stream) {
+                                    float* g_clip, const a3d_ca_shade* shade_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(g_out && inv && work && count && clip && g_clip && C > 0 && C <= 4096 && B > 0 && V > 0 && H > 0 && W > 0 && P >= 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
-    A3D_CHECK_ARG(P == 0 || (vals && pix && g_vals));
+    A3D_CHECK_ARG(P == 0 || ((vals || shade_or_null) && pix && g_vals));
     const bool two = g_out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B) && (P == 0 || (vals2 && g_vals2))));
     hipStream_t s = (hipStream_t)stream;
-    const CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, nullptr, g_out, g_vals);
+    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, nullptr, g_out, g_vals);
+    if (int rc = ca_shade(shade_or_null, C, vals, &ja, false)) return rc;
     const CaJob jb = two ? ca_job(vals2, C2, inv, bg2_or_null, bg2_batch, H, W, nullptr, g_out2_or_null, g_vals2) : ja;
     {
         const long long nz = 4ll * clip_batch * V;

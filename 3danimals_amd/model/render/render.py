@@ -38,7 +38,8 @@ FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused 
 FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
 FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
-FUSED_SHADING = True  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
+FUSED_SHADING = True
+SHADE_IN_COMPOSITOR = os.environ.get("A3D_SHADE_IN_COMPOSITOR", "1") != "0"  # no a3d_shade_fwd launch when only the composited colour reads its output  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
 # Shading only the covered pixels makes the sizes of the networks' activations follow the silhouette ([P,256] rows: ~5 GB per step at
@@ -189,10 +190,13 @@ class SparseBuffers(dict):
     def __init__(self, pix, bhw, inv=None):
         super().__init__()
         self.pix, self.bhw, self.inv = pix, bhw, inv  # inv: pixel -> row (int32 [B*H*W], -1 = uncovered) when the list came with it
+        self.shade_recipe = None  # ops.ShadeRecipe when self['shaded'] has not been computed yet (the fused compositor does it on the fly)
 
     def dense(self, mode):
         """[B,H,W,C+1] with alpha 1 on covered pixels, zeros elsewhere (the layout render_layer returns in the reference)."""
         b, h, w = self.bhw
+        if mode == "shaded" and self.shade_recipe is not None:
+            self.shade_recipe.materialize()
         vals = self[mode]
         out = torch.zeros(b * h * w, vals.shape[-1] + 1, dtype=vals.dtype, device=vals.device)
         return out.index_copy(0, self.pix, torch.cat((vals, torch.ones_like(vals[:, :1])), dim=-1)).view(b, h, w, -1)
@@ -243,10 +247,15 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     shading = None
     if gb is not None and FUSED_SHADING:  # one HIP kernel each way for the ~30 (+~70 backward) elementwise launches below; the kernels
         # read the image's row through the point -> image index (no [P,17] copy) and reduce its gradient per image themselves
+        recipe = None
         if lgt is None:
             nrm, shaded_col = ops.shade_points(gb, per_image, None, two_sided_shading, img=img), kd
         else:
-            nrm, shading, shaded_col = ops.shade_points(gb, per_image, kd, two_sided_shading, img=img)
+            modes_now = render_modes if render_modes is not None else ["shaded"]
+            # only the composited colour reads what this launch computes (the training modes): leave it to the compositor
+            if SHADE_IN_COMPOSITOR and sparse and inv is not None and all(m in ("shaded", "dino_pred", "flow", "kd", "ks") for m in modes_now):
+                recipe = ops.ShadeRecipe()
+            nrm, shading, shaded_col = ops.shade_points(gb, per_image, kd, two_sided_shading, img=img, recipe=recipe)
     else:
         per_point = _rows_per_point(per_image, img, b)
         rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
@@ -266,6 +275,8 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
     modes = render_modes if render_modes is not None else ["shaded"]
     out = SparseBuffers(pix, (b, h, w), inv)
+    if gb is not None and FUSED_SHADING and recipe is not None and recipe.filled:
+        out.shade_recipe = recipe
     for mode in modes:
         out[mode] = buffers[mode]  # KeyError for an unknown / unavailable mode, like the reference (render.py:127-128)
     return out if sparse else {mode: out.dense(mode) for mode in out}
@@ -425,13 +436,19 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
                 return None
             return background[..., 2:] if (k == "shading" and background.shape[-1] == 4) else background
 
+        recipe = getattr(rendered, "shade_recipe", None)
         for i in range(0, len(fuse_keys), 2):
             ka, kb = fuse_keys[i], (fuse_keys[i + 1] if i + 1 < len(fuse_keys) else None)
+            if kb == "shaded" and recipe is not None:
+                recipe.materialize()  # (only the FIRST buffer of a call can be shaded on the fly)
+            sh = recipe if ka == "shaded" else None
             if kb is None:
-                fused[ka] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis)
+                fused[ka] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, shade=sh)
             else:
                 fused[ka], fused[kb] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
-                                                               vals2=rendered[kb], background2=bg_of(kb))
+                                                               vals2=rendered[kb], background2=bg_of(kb), shade=sh)
+    if isinstance(rendered, SparseBuffers) and rendered.shade_recipe is not None and "shaded" not in fused:
+        rendered.shade_recipe.materialize()  # nobody computed the colour on the fly: run the launch after all
     if LAST_POINTS[0] is not None:
         LAST_POINTS[0]["clip"] = clip_f.detach()
     out_buffers = []

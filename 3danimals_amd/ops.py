@@ -938,7 +938,7 @@ class _ShadePoints(torch.autograd.Function):
     """(shading normal [P,3], shading [P,1], shaded [P,3]) from the G-buffer rows, the camera/light rows and kd."""
 
     @staticmethod
-    def forward(ctx, gb, par, kd, two_sided, img):
+    def forward(ctx, gb, par, kd, two_sided, img, recipe=None):
         require_device(gb, par, img, what="shade_points")
         gb, par = f32c(gb), f32c(par)
         P, ncol = gb.shape[0], par.shape[1]
@@ -957,8 +957,13 @@ class _ShadePoints(torch.autograd.Function):
             shaded = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
         # per-image rows: their gradient is accumulated by the backward with atomics -- allocated now, cleared by the forward launch
         g_par = torch.empty_like(par) if (img is not None and ctx.needs_input_grad[1]) else None
-        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded),
-             ptr(g_par), par.shape[0], stream())
+        if recipe is not None and kd is not None and img is not None and ncol == 17:
+            # DEFERRED (ShadeRecipe): no launch -- the compositor computes kd * shading per covered pixel itself (a3d_ca_shade) and clears
+            # g_par in its first launch; any other reader of the outputs calls recipe.materialize() first, which runs this launch after all
+            recipe.fill(gb, par, kd, kd_stride, int(two_sided), img, g_par, (nrm, shading, shaded))
+        else:
+            call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded),
+                 ptr(g_par), par.shape[0], stream())
         ctx.save_for_backward(gb, par, kd, img)
         ctx.g_par = g_par
         ctx.two_sided, ctx.kd_stride = int(two_sided), kd_stride
@@ -979,17 +984,45 @@ class _ShadePoints(torch.autograd.Function):
         opt = lambda t: None if t is None else f32c(t)
         call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(img), par.shape[0], ptr(kd),
              ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), int(clear), stream())
-        return g_gb, g_par, g_kd, None, None
+        return g_gb, g_par, g_kd, None, None, None
 
 
-def shade_points(gb, par, kd=None, two_sided=True, img=None):
+class ShadeRecipe:
+    """What a3d_shade_fwd would have computed, kept as its inputs: handed to composite_antialias(shade=...) the colour of every covered
+    pixel is computed inside the compositor's launches and a3d_shade_fwd never runs (its [P,3] output stays uninitialised: nobody else
+    may read it before ``materialize()``, which runs the launch after all -- e.g. when the buffer is not composited by the fused op)."""
+
+    def __init__(self):
+        self.filled = self.done = False
+
+    def fill(self, gb, par, kd, kd_stride, two_sided, img, g_par, outs):
+        self.gb, self.par, self.kd, self.kd_stride, self.two_sided, self.img, self.g_par, self.outs = gb, par, kd, kd_stride, two_sided, img, g_par, outs
+        self.filled = True
+
+    def struct(self, clear):
+        """a3d_ca_shade for a compositor call (``clear``: its first launch zeroes g_par -- once: the forward)."""
+        n = self.g_par.numel() if (clear and self.g_par is not None and not self.done) else 0
+        if n:
+            self.done = True  # (the per-image gradient rows are clean from now on, as after a3d_shade_fwd)
+        return _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=self.kd_stride, gb=ptr(self.gb), par=ptr(self.par), kd=ptr(self.kd),
+                            clear=ptr(self.g_par) if n else None, n_clear=n, two_sided=self.two_sided)
+
+    def materialize(self):
+        if self.filled and not getattr(self, "materialized", False):
+            nrm, shading, shaded = self.outs
+            call("a3d_shade_fwd", ptr(self.gb), ptr(self.par), 17, ptr(self.img), ptr(self.kd), self.kd_stride, self.gb.shape[0], self.two_sided,
+                 ptr(nrm), ptr(shading), ptr(shaded), ptr(self.g_par) if not self.done else None, self.par.shape[0], stream())
+            self.materialized = self.done = True
+
+
+def shade_points(gb, par, kd=None, two_sided=True, img=None, recipe=None):
     """Shading normal, Lambert shading and shaded colour at the covered pixels (csrc/shade.hip).
 
     gb [P,12] from :func:`gbuffer`; par rows (w2c rotation 9, view position 3[, light direction 3, ambient, diffuse]): one per point
     [P,12|17], or -- with ``img`` [P] (point -> image, int64, non-decreasing) -- one per image [B,12|17], in which case their gradient is
     reduced per image inside the backward kernel; kd [P,3] (any row stride).  Returns nrm, or (nrm, shading [P,1], shaded [P,3]) when a
-    light is given."""
-    return _ShadePoints.apply(gb, par, kd, two_sided, img)
+    light is given.  ``recipe`` (a ShadeRecipe): defer the launch -- see there."""
+    return _ShadePoints.apply(gb, par, kd, two_sided, img, recipe)
 
 
 # ---------------------------------------------------------------------------------------------- per-image rows <-> points
@@ -1158,7 +1191,7 @@ class _CompositeAntialias(torch.autograd.Function):
     """One or two buffers (vals2 None = one) against the same pixel list and crossing records, in the same launches."""
 
     @staticmethod
-    def forward(ctx, vals, vals2, clip, pix, inv, bg, bg2, analysis):
+    def forward(ctx, vals, vals2, clip, pix, inv, bg, bg2, analysis, shade=None):
         require_device(vals, vals2, pix, inv, what="composite_antialias")
         a = analysis
         P = vals.shape[0]
@@ -1179,9 +1212,13 @@ class _CompositeAntialias(torch.autograd.Function):
         vals2, bg2, C2, out2 = prep(vals2, bg2)
         tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
-        call("a3d_composite_aa_fwd", ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
+        use_shade = shade is not None and shade.filled and not getattr(shade, "materialized", False) and C == 3 and shade.outs[2].data_ptr() == vals.data_ptr()
+        sh = shade.struct(clear=True) if use_shade else None
+        call("a3d_composite_aa_fwd", None if use_shade else ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
              0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W,
-             None if ride is None else ctypes.addressof(ride), stream(), tag=tag + ("[+analysis]" if ride is not None else ""))
+             None if ride is None else ctypes.addressof(ride), None if sh is None else ctypes.addressof(sh), stream(),
+             tag=tag + ("[+shade]" if use_shade else "") + ("[+analysis]" if ride is not None else ""))
+        ctx.shade = shade if use_shade else None
         if ride is not None:
             a.pending = False  # (only now: the call above raises on a refused argument)
         ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
@@ -1204,23 +1241,25 @@ class _CompositeAntialias(torch.autograd.Function):
         g_vals = torch.empty_like(vals)
         g_vals2 = torch.empty_like(vals2) if two else None
         g_clip = torch.empty_like(a.clip)
-        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(g_vals),
+        sh = ctx.shade.struct(clear=False) if ctx.shade is not None else None
+        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), None if sh is not None else ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(g_vals),
              ptr(f32c(g_out2)) if two else None, ptr(vals2), C2, ptr(bg2), 0 if bg2 is None else bg2.shape[0], ptr(g_vals2), ptr(pix), P, ptr(inv),
              ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H,
-             a.W, ptr(g_clip), stream(), tag=ctx.tag)
-        return g_vals, g_vals2, g_clip, None, None, None, None, None
+             a.W, ptr(g_clip), None if sh is None else ctypes.addressof(sh), stream(), tag=ctx.tag)
+        return g_vals, g_vals2, g_clip, None, None, None, None, None, None
 
 
-def composite_antialias(vals, pix, inv, background, clip, analysis, vals2=None, background2=None):
+def composite_antialias(vals, pix, inv, background, clip, analysis, vals2=None, background2=None, shade=None):
     """antialias(lerp(background, [vals, 1], coverage)) for a buffer given as rows ``vals`` [P,C] at the covered pixels ``pix`` (``inv`` =
     the pixel -> row map of covered_pixels(return_inverse=True)): [B,H,W,C+1].  ``background`` [1|B,H,W,C+1] or None (zeros); it gets no
     gradient (callers with a differentiable background composite with torch and call antialias).  With ``vals2`` (and ``background2``) a
-    second buffer over the same pixels is composited and antialiased by the same launches: returns the pair of images."""
+    second buffer over the same pixels is composited and antialiased by the same launches: returns the pair of images.
+    ``shade`` (the ShadeRecipe ``vals`` came from, deferred): the colour is computed inside the launches of this op instead of being read."""
     assert background is None or not background.requires_grad
     assert background2 is None or not background2.requires_grad
     if clip.dim() == 2:
         clip = clip[None]
-    return _CompositeAntialias.apply(vals, vals2, clip, pix, inv, background, background2, analysis)
+    return _CompositeAntialias.apply(vals, vals2, clip, pix, inv, background, background2, analysis, shade)
 
 
 def antialias(color, rast, clip, tri, analysis=None):

@@ -98,6 +98,8 @@ def algorithmic_bytes(name, d):
     rendered per step (images x frames), V / F = surface vertices / faces, P = covered pixels, K = bones.
     """
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
+    if "[+shade]" in name:  # the colour computed on the spot: G-buffer row + kd in (60 B per point) instead of the shaded row (12 B)
+        return algorithmic_bytes(name.replace("[+shade]", ""), d) + 48 * int(d.get("P", 0))
     if name.endswith("[+analysis]"):  # the silhouette analysis rode in this call's first launch: both passes' bytes
         return algorithmic_bytes(name[:-len("[+analysis]")], d) + algorithmic_bytes("a3d_aa_analyze", d)
     if "+C" in name:  # two buffers in one call of the compositor: [C17+C4] = the sum of the single-buffer figures

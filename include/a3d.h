@@ -441,9 +441,27 @@ typedef struct a3d_aa_ride {
     int32_t lists_stride; /* layout of off / adj (see a3d_normals_*) */
     int32_t reserved;
 } a3d_aa_ride;
+/* The shaded colour of the FIRST buffer computed on the spot (round 4): with `shade` and vals = NULL (C = 3) the value of point q is
+ * kd[q] * shading(q) -- a3d_shade_fwd's arithmetic, bit for bit (one shared device function), from the G-buffer row, the image's
+ * camera / light row (ncol 17) and kd -- instead of a [P,3] array that a launch of its own wrote: a3d_shade_fwd is then not called at all
+ * (its other outputs, the shading normal and the shading term, are not produced: for render modes that want them the caller runs it).
+ * `clear`: n_clear floats zeroed by the forward's first launch (the per-image row gradient a3d_shade_bwd accumulates into: that clear was
+ * a3d_shade_fwd's).  The backward takes the same struct (its blend adjoints read the same sources); g_vals is the gradient of the
+ * shaded colour, which a3d_shade_bwd consumes as before. */
+typedef struct a3d_ca_shade {
+    uint32_t size;      /* sizeof(a3d_ca_shade) of the caller's header (fields are only ever appended) */
+    int32_t kd_stride;  /* floats between two rows of kd */
+    const float* gb;    /* [P,12] rows of a3d_cover_gbuffer_fwd / a3d_gbuffer_fwd */
+    const float* par;   /* [B,17] w2c rotation (9) | view position (3) | light direction (3), ambient, diffuse */
+    const float* kd;    /* [P,3] */
+    float* clear;
+    int32_t n_clear;
+    int32_t two_sided;
+} a3d_ca_shade;
 int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null, int C2,
                          const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
-                         int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, a3d_stream_t stream);
+                         int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null,
+                         const a3d_ca_shade* shade_or_null, a3d_stream_t stream);
 /* analyze != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
  * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
  * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */
@@ -461,7 +479,7 @@ int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const flo
                          const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch, float* g_vals2,
                          const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count, int capacity,
                          const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_clip,
-                         a3d_stream_t stream);
+                         const a3d_ca_shade* shade_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM with the ReLU adjoint in the epilogue: C[M,N] = (A[M,K] . B[K,N]) * (X[M,N] > 0), row-major, N = 256,

@@ -1058,10 +1058,11 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     assert rep["max_abs_image_err"] < 2e-5, rep["images"]  # measured: <= 1e-5; a regression shows long before the 1e-4 bar
 
 
-def test_training_step_runs_in_thirteen_hot_path_calls(dev):
+def test_training_step_runs_in_twelve_hot_path_calls(dev):
     """The structure DESIGN.md section 4 describes, pinned: a steady-state magicpony training step at the bench size calls exactly these
-    13 hot-path entry points (7 forward, 6 backward), once each -- no topology launch (the DMTet emit writes the lists), no normals
-    launch (they ride in the rasteriser's), no analysis launch (it rides in the compositor's) -- and the forward-only step 7."""
+    12 hot-path entry points (6 forward, 6 backward), once each -- no topology launch (the DMTet emit writes the lists), no normals
+    launch (they ride in the rasteriser's), no analysis launch (it rides in the compositor's), no shading launch (round 4: the compositor
+    computes the colour of a covered pixel itself) -- and the forward-only step 6."""
     _lib = importlib.import_module("3danimals_amd._lib")
     pipeline = importlib.import_module("3danimals_amd.pipeline")
     scene = pipeline.SyntheticScene(grid_res=64, batch=16, resolution=(256, 256), device=dev, seed=0, workload="magicpony", deform=True)
@@ -1076,7 +1077,7 @@ def test_training_step_runs_in_thirteen_hot_path_calls(dev):
 
     train = calls(True)
     assert train == {"a3d_dmtet_count": 1, "a3d_dmtet_emit": 1, "a3d_skin_pose_fwd": 1, "a3d_rast_fwd[N16+1]": 1, "a3d_cover_gbuffer_fwd": 1,
-                     "a3d_shade_fwd": 1, "a3d_composite_aa_fwd[C4+C17][+analysis]": 1, "a3d_composite_aa_bwd[C4+C17]": 1, "a3d_shade_bwd": 1,
+                     "a3d_composite_aa_fwd[C4+C17][+shade][+analysis]": 1, "a3d_composite_aa_bwd[C4+C17]": 1, "a3d_shade_bwd": 1,
                      "a3d_gbuffer_bwd": 1, "a3d_normals_bwd[B16]": 1, "a3d_skin_pose_bwd": 1, "a3d_dmtet_bwd": 1}, train
     with torch.no_grad():
         fwd = calls(False)
@@ -2644,3 +2645,46 @@ def test_texture_less_render_through_the_mask_compositor_equals_the_general_path
     assert float(g_g.abs().max()) > 0 and float((g_f - g_g).abs().max()) <= 1e-4 * float(g_g.abs().max())
     assert calls_f == ["a3d_mask_aa_bwd[C4]", "a3d_mask_aa_fwd[C4][+analysis]", "a3d_rast_fwd"], calls_f
     assert any(c.startswith("a3d_cover_gbuffer_fwd") for c in calls_g) and any(c.startswith("a3d_composite_aa_fwd") for c in calls_g)
+
+
+def test_shading_inside_the_compositor_equals_the_separate_launch(dev, mods, monkeypatch):
+    """render.SHADE_IN_COMPOSITOR: when only the composited colour reads what a3d_shade_fwd computes (the training modes), the launch is
+    skipped and the compositor computes kd * shading per covered pixel itself (a3d_ca_shade: one shared device function, same bits).
+    Same images, same gradients to vertices, camera, light and texture parameters; one hot-path call less; and a mode that needs the
+    launch's other outputs ('normal', 'shading') still gets them."""
+    import copy
+
+    _lib = importlib.import_module("3danimals_amd._lib")
+    B, H, W = 2, 64, 64
+    verts, faces, _, (mvp, w2c, campos) = _scene(B, seed=3)
+    M, R = mods["mesh"], mods["render"]
+    tex0, dino0, lgt0 = _nets(mods, dev)
+    feat = seeded((B, 16), 12, -1, 1).to(dev)
+    bg = seeded((B, H, W, 3), 13, 0, 1).to(dev)
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+
+    def run(on, modes):
+        monkeypatch.setattr(R, "SHADE_IN_COMPOSITOR", on)
+        tex, dino, lgt = (copy.deepcopy(m).to(dev) for m in (tex0, dino0, lgt0))
+        posed = (verts[None] + 0.05 * seeded((B, *verts.shape), 11, -1, 1)).to(dev).requires_grad_(True)
+        cam = w2c.to(dev).clone().requires_grad_(True)
+        shape = M.make_mesh(posed, faces[None].to(dev), uvs.expand(B, -1, -1), uvi, None)
+        prior = M.make_mesh(verts[None].to(dev), faces[None].to(dev), uvs, uvi, None)
+        with _lib.KernelTimer() as timer:
+            out = R.render_mesh(None, shape, mvp.to(dev), cam, campos.to(dev), tex, lgt, (H, W), background=bg, bsdf="diffuse", feat=feat,
+                                render_modes=modes, prior_mesh=prior, dino_net=dino)
+            loss = sum((o * seeded(tuple(o.shape), 40 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out))
+            grads = torch.autograd.grad(loss, [posed, cam] + list(tex.parameters()) + list(lgt.parameters()))
+        return [o.detach() for o in out], grads, sorted(timer.summary())
+
+    for modes in (["shaded", "dino_pred"], ["dino_pred", "shaded"], ["shaded", "normal", "shading"]):
+        o_on, g_on, calls_on = run(True, modes)
+        o_off, g_off, calls_off = run(False, modes)
+        for a, b in zip(o_on, o_off):
+            assert float((a - b).abs().max()) < 1e-6, modes
+        for a, b in zip(g_on, g_off):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, modes
+        deferred = modes == ["shaded", "dino_pred"]  # (only the FIRST buffer of a compositor call, and only the training modes)
+        assert any("[+shade]" in c for c in calls_on) == deferred, (modes, calls_on)
+        assert ("a3d_shade_fwd" in calls_on) == (not deferred) and "a3d_shade_fwd" in calls_off

@@ -593,7 +593,7 @@ def test_spatial_order_tables_reproduce_the_planes_of_the_file_order(grid):
     assert culled_any
 
 
-@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide")])
+@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide"), ("a3d_ca_shade", "CaShade")])
 def test_abi_structs_match_the_header_field_for_field(struct, cls):
     """The option structs of include/a3d.h against their ctypes mirrors: names, order, pointer / int32 / uint32 kind; `size` first."""
     L = importlib.import_module("3danimals_amd._lib")
