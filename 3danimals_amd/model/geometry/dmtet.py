@@ -89,7 +89,8 @@ class TetGridTopology:
         return self._word_groups or None
 
     SPATIAL_ORDER = True  # False: a grid numbered without regard to space takes the plain count pass (a3d_dmtet_count, no tables)
-    ORDER_SLOTS = 16
+    ORDER_SLOTS = 16  # group ids per word of the ranked lists (8 or 16; 16: one 64-byte line per word, 92 % of a scrambled BCC lattice's words fit)
+    ORDER_MAX_DENSE = 0.5  # above this fraction of words with more groups than slots nothing is gained over the streaming pass
 
     def spatial_order(self, positions: torch.Tensor = None):
         """The static tables of a3d_dmtet_count_ordered (include/a3d.h: a3d_dmtet_order) for a grid whose file numbering ignores space --
@@ -123,7 +124,7 @@ class TetGridTopology:
             edges_ranked, tets_ranked = er[e_row].to(torch.int32).contiguous(), tr[t_row].to(torch.int32).contiguous()
             eg, tg = _word_groups(edges_ranked, self.ORDER_SLOTS, bits, block), _word_groups(tets_ranked, self.ORDER_SLOTS, bits, block)
             dense = (int((eg[:, 0] < 0).sum()) + int((tg[:, 0] < 0).sum())) / float(eg.shape[0] + tg.shape[0])
-            if dense > 0.5:
+            if dense > self.ORDER_MAX_DENSE:
                 self._order = False
             else:
                 tensors = dict(vertex_of_rank=vertex_of_rank.to(torch.int32).contiguous(), edges_ranked=edges_ranked,

@@ -141,10 +141,16 @@ def test_culled_dmtet_count_equals_the_plain_one(grid, dev, ops, mods, monkeypat
         one[v] = 1.0
         sdfs[f"one_in_{v}"] = one
         sdfs[f"one_out_{v}"] = -one
+    # the 8-slot form of the ordered pass (its other template instance; words with more than 8 groups -- most, on these grids -- are read)
+    ordered8 = T(tets.to(dev), positions=pos)
+    ordered8.WORD_GROUPS, ordered8.ORDER_SLOTS, ordered8.ORDER_MAX_DENSE = False, 8, 1.0
+    assert ordered8.count_pass() == "ordered" and ordered8.spatial_order()[0].group_slots == 8
     for name, sdf in sdfs.items():
         if sdf is None:
             continue
         a, b, c = _extract_all(ops, pos, sdf, culled), _extract_all(ops, pos, sdf, plain), _extract_all(ops, pos, sdf, ordered)
+        for x, z in zip(a, _extract_all(ops, pos, sdf, ordered8)):
+            assert x.shape == z.shape and torch.equal(x, z), (grid, name, "ordered, 8 slots")
         assert (culled._last_count_pass, plain._last_count_pass, ordered._last_count_pass) == (culled.count_pass(), "plain", "ordered")
         for x, y, z in zip(a, b, c):
             assert x.shape == y.shape and torch.equal(x, y), (grid, name)
@@ -1299,29 +1305,36 @@ def test_render_mesh_takes_the_pending_normals_into_the_rasteriser_launch(dev, o
 
 
 @pytest.mark.parametrize("seed,B,hw,res,zoom", [(0, 1, (64, 64), 12, 1.0), (1, 3, (40, 72), 16, 1.0), (2, 2, (128, 96), 20, 1.0), (3, 5, (24, 24), 12, 1.0),
-                                                (4, 2, (30, 50), 16, 3.5), (5, 4, (256, 256), 28, 1.6), (6, 1, (8, 8), 8, 1.0)])
+                                                (4, 2, (30, 50), 16, 3.5), (5, 4, (256, 256), 28, 1.6), (6, 1, (8, 8), 8, 1.0),
+                                                (7, 3, (96, 96), -20, 1.0), (8, 2, (256, 256), -28, 1.6)])
 def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(seed, B, hw, res, zoom, dev, ops, mods, monkeypatch):
     """SDF -> DMTet -> make_mesh -> render_mesh -> loss -> backward, three consecutive frames of a moving surface, with everything this
     round folded into other launches switched ON (culled count, lists from the emit launch, speculative emit, normals in the rasteriser
     launch, covered-pixel list with the G-buffer, the analysis in the compositor, fused compositor) against everything OFF (the modular
     entry points one by one).  Same meshes bit for bit, same images up to the antialiasing's blend order, same gradients on the SDF and
     the pose offsets up to the order of the float atomics -- whatever the batch, the image shape (incl. no multiple of 8, and a surface
-    that reaches far outside the frustum: zoom) and the grid."""
+    that reaches far outside the frustum: zoom) and the grid.  res < 0 (round 4): the Kuhn grid of -res cells in a RANDOM numbering (rows
+    shuffled, row entries permuted: a randomly wound surface) -- the ordered count pass + the sparse emit against the streaming pass."""
     M, R, D = mods["mesh"], mods["render"], mods["dmtet"]
     H, W = hw
-    pos, tets = kuhn(res)
+    pos, tets = kuhn(abs(res))
+    if res < 0:
+        tg = importlib.import_module("3danimals_amd.tetgrid")
+        p_np, t_np = tg.scramble(pos.numpy(), tets.numpy(), 3 + seed)
+        pos, tets = torch.from_numpy(p_np), torch.from_numpy(t_np).long()
     pos_d = pos.to(dev)
     centre, ext = pos.mean(0), float((pos.amax(0) - pos.amin(0)).max())
     synthetic = importlib.import_module("3danimals_amd.synthetic")
     mvp, w2c, campos = (t.to(dev) for t in synthetic.random_cameras(B, seed=seed))
     switches = [(ops, "DMTET_CULL_MIN_VERTS", 0, 1 << 30), (ops, "DMTET_EMIT_LISTS", True, False), (ops, "DMTET_SPECULATIVE_EMIT", True, False),
                 (ops, "DMTET_TOPOLOGY", True, False), (M, "RIDE_NORMALS", True, False), (R, "FUSED_COVER_GBUFFER", True, False),
-                (R, "DEFER_ANALYSIS", True, False), (R, "FUSED_COMPOSITE", True, False)]
+                (R, "DEFER_ANALYSIS", True, False), (R, "FUSED_COMPOSITE", True, False), (R, "SHADE_IN_COMPOSITOR", True, False),
+                (R, "FUSED_MASK_RENDER", True, False)]
 
     def run(on):
         for mod, name, a, b in switches:
             monkeypatch.setattr(mod, name, a if on else b)
-        grid = D.TetGridTopology(tets.to(dev))
+        grid = D.TetGridTopology(tets.to(dev), positions=pos_d)
         frames = []
         for t in range(3):
             sdf = ((0.30 + 0.04 * t) * ext - (pos - centre).norm(dim=-1) + 0.03 * ext * seeded((pos.shape[0],), 50 + seed, -1, 1)).to(dev).requires_grad_(True)
@@ -1338,6 +1351,7 @@ def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(see
             loss = sum((o * seeded(tuple(o.shape), 70 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out))
             g_sdf, g_offs = torch.autograd.grad(loss, [sdf, offs])
             frames.append((verts.detach(), faces, [o.detach() for o in out], g_sdf, g_offs))
+        assert grid._last_count_pass == (("ordered" if res < 0 else "culled") if on else "plain")
         return frames
 
     a, b = run(True), run(False)
@@ -1351,16 +1365,21 @@ def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(see
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5 * scale)
 
 
-def test_speculative_dmtet_emit_equals_the_exact_one(dev, ops, mods, monkeypatch):
+@pytest.mark.parametrize("numbering", ["spatial", "random"])
+def test_speculative_dmtet_emit_equals_the_exact_one(numbering, dev, ops, mods, monkeypatch):
     """ops.dmtet_extract enqueues the emit launch BEFORE the host has read the counts, with buffers and grid sized by the previous
     extraction on the grid + 25 %; the kernel takes the true sizes from the device.  A sequence of surfaces that shrink, grow slowly,
     outgrow the guess (the launch must then leave everything untouched and the exact path take over), vanish and come back: every output
     equal to the exact path's, bit for bit, and the mesh topology usable either way."""
     monkeypatch.setattr(ops, "DMTET_CULL_MIN_VERTS", 0)
     pos, tets = kuhn(40)
+    if numbering == "random":  # the ordered count pass + a3d_dmtet_emit_sparse: its speculative form has no block capacities
+        tg = importlib.import_module("3danimals_amd.tetgrid")
+        p_np, t_np = tg.scramble(pos.numpy(), tets.numpy(), 17)
+        pos, tets = torch.from_numpy(p_np), torch.from_numpy(t_np).long()
     pos_d = pos.to(dev)
     T = mods["dmtet"].TetGridTopology
-    spec_topo, exact_topo = T(tets.to(dev)), T(tets.to(dev))
+    spec_topo, exact_topo = T(tets.to(dev), positions=pos_d), T(tets.to(dev), positions=pos_d)
     radii = (2.0, 1.9, 2.1, 1.2, 3.1, 3.0, -1.0, 2.5, 2.45)  # (-1: no surface at all)
     took = []
     for trial, r in enumerate(radii):
