@@ -418,11 +418,17 @@ struct CaJob {
 // Extra work-groups (blockIdx.x >= nb_compose): the silhouette analysis of this frame (aa_analyze_body) when it has not run yet -- the
 // blend launch that follows is its first consumer, and this pass, which only moves pixels, leaves the gather path idle: as a launch
 // of its own the analysis is 15 us of kernel plus a launch gap, here it adds ~5.
-__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an) {
+__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an, int extra_first) {
     __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
-    if (blockIdx.x >= nb_compose) {
+    // (extra_first: the analysis work-groups -- gather chains -- are dispatched BEFORE the pixel movers of their row, not as the launch's tail)
+    unsigned bx = blockIdx.x;
+    if (extra_first) {
+        const unsigned n_extra = gridDim.x - nb_compose;
+        bx = bx < n_extra ? nb_compose + bx : bx - n_extra;
+    }
+    if (bx >= nb_compose) {
         const unsigned nbx = ((unsigned)an.H * (unsigned)an.W + 255u) / 256u, total = nbx * 2u * (unsigned)an.B;
-        const unsigned j = blockIdx.y * (gridDim.x - nb_compose) + (blockIdx.x - nb_compose);  // flat work-group of the analysis
+        const unsigned j = blockIdx.y * (gridDim.x - nb_compose) + (bx - nb_compose);  // flat work-group of the analysis
         if (j >= total) return;
         const unsigned b = j / (2u * nbx), r = j - b * 2u * nbx;
         aa_analyze_body(an, r % nbx, (int)(r / nbx), (int)b);
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
     const CaSrc& s = job.s;
     float* __restrict__ out = job.out;
     typedef float v4f __attribute__((ext_vector_type(4)));
-    const unsigned base = blockIdx.x * 256u, p = base + threadIdx.x;
+    const unsigned base = bx * 256u, p = base + threadIdx.x;
     for (unsigned z = p; z < (unsigned)job.n_clear; z += nb_compose * 256u) job.clear[z] = 0.f;
     if (s.C == 3 && (((uintptr_t)out | (uintptr_t)s.bg) & 15) == 0) {
         if (p >= n_pix) return;
@@ -726,7 +732,7 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
     const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr) : ja;
     const unsigned n_pix = (unsigned)B * ja.s.hw;
     const unsigned nb_compose = (unsigned)a3d_div_up(n_pix, 256), rows = two ? 2u : 1u;
-    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + (nb_an + rows - 1) / rows, rows), dim3(256), 0, s, ja, jb, n_pix, nb_compose, an);
+    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + (nb_an + rows - 1) / rows, rows), dim3(256), 0, s, ja, jb, n_pix, nb_compose, an, a3d_exp() == 43 ? 0 : 1);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ca_blend_kernel, dim3(512, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, W);
     A3D_LAUNCH_CHECK();
@@ -779,7 +785,7 @@ extern "C" int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null
     CaJob ja = ca_job(nullptr, C, nullptr, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
     ja.s.rast = (const float4*)rast;
     const unsigned n_pix = (unsigned)B * ja.s.hw, nb_compose = (unsigned)a3d_div_up(n_pix, 256);
-    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + nb_an, 1), dim3(256), 0, s, ja, ja, n_pix, nb_compose, an);
+    hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + nb_an, 1), dim3(256), 0, s, ja, ja, n_pix, nb_compose, an, a3d_exp() == 43 ? 0 : 1);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ca_blend_kernel, dim3(512, 1), dim3(256), 0, s, ja, ja, (const AaRec*)work, count, capacity, W);
     A3D_LAUNCH_CHECK();

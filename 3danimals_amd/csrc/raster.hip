@@ -121,15 +121,23 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
                                                      int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards,
                                                      int* __restrict__ cover_group_sum, int cover_groups, int nb_screen,
                                                      const int* __restrict__ topo_off, const int* __restrict__ topo_adj,
-                                                     int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj) {
+                                                     int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj, int extra_first) {
     const int b = blockIdx.y;
-    if ((int)blockIdx.x >= nb_tri + nb_screen + nb_opp) {
+    // the riding jobs (dependent-gather chains: vertex normals, opposite-vertex table, screen positions) are DISPATCHED FIRST (extra_first):
+    // their round trips then run under the triangle work instead of as the launch's tail.  bx = the work-group's index in the order the
+    // branches below are written in (triangles first).
+    int bx = (int)blockIdx.x;
+    if (extra_first) {
+        const int n_extra = (int)gridDim.x - nb_tri;
+        bx = bx < n_extra ? nb_tri + bx : bx - n_extra;
+    }
+    if (bx >= nb_tri + nb_screen + nb_opp) {
         // yet more extra work-groups: the vertex normals of the mesh being rasterised (and of a second, small vertex array over the same
         // triangle list) -- normals.hip's forward pass, which the G-buffer pass of this frame reads next.  As a launch of its own it is
         // 9 us of dependent gathers plus a launch gap on a latency-bound stretch; here it runs beside the triangle work, which is bound
         // by the memory-side atomics and leaves the gather path idle.  Batches of 4 index rows keep this branch inside the triangle
         // path's register budget.
-        const int j = (int)blockIdx.y * nj.wg_per_row + ((int)blockIdx.x - nb_tri - nb_screen - nb_opp);  // flat work-group of the job
+        const int j = (int)blockIdx.y * nj.wg_per_row + (bx - nb_tri - nb_screen - nb_opp);  // flat work-group of the job
         const int nbv = (V + 255) / 256;
         if (j >= nbv * (nj.B_a + nj.B_b)) return;
         const int image = j / nbv, vi = (j - image * nbv) * 256 + (int)threadIdx.x;
@@ -138,24 +146,24 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         else nr_fwd_vertex<4>(nj.v_b + (long long)(image - nj.B_a) * V * 3, tri, nj.off, nj.adj, nj.stride, F, vi, nj.acc_b, nj.nrm_b, ((long long)(image - nj.B_a) * V + vi) * 3);
         return;
     }
-    if ((int)blockIdx.x >= nb_tri + nb_screen) {
+    if (bx >= nb_tri + nb_screen) {
         // more extra work-groups (image 0 only): the opposite-vertex table of the silhouette analysis, looked up in the vertex -> face
         // lists the DMTet extraction left (no edge hash on that path).  Each lookup is a chain of five dependent gathers -- inside the
         // analysis it doubled that kernel's time (13 -> 24 us); here it runs beside the triangle work of the same launch for free.
         if (b != 0) return;
-        const int idx = ((int)blockIdx.x - nb_tri - nb_screen) * 256 + threadIdx.x;
+        const int idx = (bx - nb_tri - nb_screen) * 256 + threadIdx.x;
         if (idx < 3 * F) topo_opp[idx] = aa_opposite_from_lists(tri, topo_off, topo_adj, nj.stride, F, idx / 3, idx - 3 * (idx / 3));
         return;
     }
     // the covered-pixel list's group sums, accumulated by the resolve launch that follows: zeroed here (no memset launch)
-    if (cover_group_sum && blockIdx.x == 0 && b == 0)
+    if (cover_group_sum && bx == 0 && b == 0)
         for (int i = threadIdx.x; i < cover_groups; i += blockDim.x) cover_group_sum[i] = 0;
-    if ((int)blockIdx.x >= nb_tri) {
+    if (bx >= nb_tri) {
         // extra work-groups: what the silhouette analysis of this frame needs first -- pixel-space vertex positions, once per (image,
         // vertex), with the operations of antialias.hip's aa_screen_kernel (p.x / p.w * W/2, unfused), and its append counters at zero
-        if (b == 0 && (int)blockIdx.x == nb_tri && (int)threadIdx.x < aa_shards) aa_count[threadIdx.x] = 0;
+        if (b == 0 && bx == nb_tri && (int)threadIdx.x < aa_shards) aa_count[threadIdx.x] = 0;
         if (clip_batch == 1 && b > 0) return;
-        const int i = ((int)blockIdx.x - nb_tri) * 256 + threadIdx.x;
+        const int i = (bx - nb_tri) * 256 + threadIdx.x;
         if (i >= V) return;
         const float4 p = clip[(clip_batch == 1 ? 0ll : (long long)b * V) + i];
         aa_screen[(long long)b * V + i] = make_float2(p.x / p.w * (0.5f * W), p.y / p.w * (0.5f * H));
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     // w nb_tri + blockIdx.x): a run of neighbouring triangles with huge boxes -- a spike of a mesh that training has driven apart --
     // then loads four times as many work-groups a quarter as much each; the pool below is per work-group whatever it holds, and a
     // wave's index reads stay one contiguous run
-    const int f = (((int)threadIdx.x >> 6) * nb_tri + (int)blockIdx.x) * TPW + ((int)threadIdx.x & 63) / LPT;
+    const int f = (((int)threadIdx.x >> 6) * nb_tri + bx) * TPW + ((int)threadIdx.x & 63) / LPT;
     const int sub = threadIdx.x % LPT, lane = threadIdx.x & 63;
     const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
     unsigned long long* kb = keys + (long long)b * H * W;
@@ -479,7 +487,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     hipLaunchKernelGGL(rs_tri_kernel<LPT_>, dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), 0, s, (const float4*)clip, clip_batch, \
                        tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null, \
                        a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen, \
-                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj); \
+                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj, a3d_exp() == 43 ? 0 : 1); \
 
     if (lpt == 4) { RS_LAUNCH_TRI(4) } else if (lpt == 2) { RS_LAUNCH_TRI(2) } else { RS_LAUNCH_TRI(1) }
 #undef RS_LAUNCH_TRI
