@@ -5,7 +5,7 @@ Put ``3danimals_amd/shims`` on ``sys.path`` and the referen
 (render.py:24,264-267,292-294), ``dr.rasterize`` (render.py:351, visualize_results.py:225-229) -- run on MI355X
 without OpenGL or CUDA.  Instanced and range mode, ``grad_db``, ``diff_attrs`` and ``pos_gradient_boost`` are covered; ``dr.texture`` has
 no call site on the reconstruct-and-render path (only EnvironmentLight, Texture2D mips and image_grad use it, all dead code in every
-config) and raises.
+config): its 2-D bilinear / nearest tap is provided in torch, mip-mapped and cube-map sampling raise.
 """
 import importlib
 
@@ -224,8 +224,45 @@ def antialias_construct_topology_hash(tri):
     return _ops.aa_topology(_ops.tri_int32(tri), int(tri.max().item()) + 1)
 
 
-def texture(*args, **kwargs):
-    raise NotImplementedError("dr.texture is not on the reconstruct-and-render path (SURVEY.md section 2 row 12)")
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """dr.texture for 2-D textures WITHOUT mip-mapping: tex [1|B,Th,Tw,C], uv [B,H,W,2] in texture units (0..1, texel centres at
+    (i + 0.5) / size) -> [B,H,W,C]; filter_mode 'nearest' | 'linear' ('auto' = 'linear' when no uv_da / mip_level_bias is given),
+    boundary_mode 'wrap' | 'clamp' | 'zero'.  Plain torch (differentiable w.r.t. tex and uv): no config of the reference reaches
+    dr.texture from the reconstruct-and-render path (the texture is a coordinate MLP, render.py:53-57); this serves the off-path callers
+    that only need a bilinear tap -- texture2d_mip's backward (texture.py:32), image_grad's tap (regularizer.py:24), the FG look-up table
+    (light.py:118).  Mip-mapped and cube-map sampling (Texture2D.sample with uv_da, EnvironmentLight) raise: out of scope (SURVEY.md
+    section 2 row 12)."""
+    if filter_mode == "auto":
+        filter_mode = "linear-mipmap-linear" if (uv_da is not None or mip_level_bias is not None) else "linear"
+    if filter_mode not in ("nearest", "linear"):
+        raise NotImplementedError(f"dr.texture filter_mode {filter_mode!r}: mip-mapped sampling is not on the reconstruct-and-render path")
+    if boundary_mode == "cube" or tex.dim() != 4 or uv.shape[-1] != 2:
+        raise NotImplementedError("dr.texture: cube maps are not on the reconstruct-and-render path")
+    if boundary_mode not in ("wrap", "clamp", "zero"):
+        raise ValueError(f"dr.texture: unknown boundary_mode {boundary_mode!r}")
+    B = uv.shape[0]
+    assert tex.shape[0] in (1, B), "texture batch must be 1 or the uv batch"
+    Th, Tw, C = tex.shape[1:]
+    x, y = uv[..., 0] * Tw - 0.5, uv[..., 1] * Th - 0.5  # continuous texel coordinates (texel i covers [i, i + 1) in texel units)
+    bidx = torch.arange(B, device=uv.device).view(B, *([1] * (uv.dim() - 2))).expand(uv.shape[:-1]) if tex.shape[0] == B else torch.zeros_like(x, dtype=torch.long)
+
+    def tap(ix, iy):
+        if boundary_mode == "wrap":
+            valid, ix, iy = None, ix % Tw, iy % Th
+        else:
+            valid = ((ix >= 0) & (ix < Tw) & (iy >= 0) & (iy < Th)) if boundary_mode == "zero" else None
+            ix, iy = ix.clamp(0, Tw - 1), iy.clamp(0, Th - 1)
+        v = tex[bidx, iy, ix]
+        return v if valid is None else v * valid[..., None].to(v.dtype)
+
+    if filter_mode == "nearest":
+        return tap(torch.floor(x + 0.5).long(), torch.floor(y + 0.5).long())
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = (x - x0)[..., None], (y - y0)[..., None]
+    x0, y0 = x0.long(), y0.long()
+    top = tap(x0, y0) * (1 - fx) + tap(x0 + 1, y0) * fx
+    bot = tap(x0, y0 + 1) * (1 - fx) + tap(x0 + 1, y0 + 1) * fx
+    return top * (1 - fy) + bot * fy
 
 
 def get_log_level():

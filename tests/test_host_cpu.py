@@ -646,3 +646,30 @@ def test_lazy_rast_db_behaves_like_the_tensor_it_stands_for():
     lazy[0, 0] = 7.0
     assert float(lazy[0, 0]) == 7.0 and [r.shape for r in lazy] == [torch.Size([4])] * 3 and len(calls) == 1
     assert torch.equal(lazy + shim._LazyRastDb(lambda: torch.ones(3, 4)), lazy.materialize() + 1)
+
+
+def test_shim_texture_bilinear_tap_known_answers():
+    """The nvdiffrast stand-in's dr.texture (2-D, no mip-mapping: the off-path callers of the reference that only need a bilinear tap):
+    a texel centre returns the texel, the midpoint of four texels their mean, 'clamp' / 'wrap' / 'zero' at the border, 'nearest', gradients
+    to texture and uv from autograd, and the unsupported modes refuse loudly."""
+    dr = importlib.import_module("3danimals_amd.shims.nvdiffrast.torch")
+    tex = torch.arange(2 * 3 * 4 * 2, dtype=torch.float64).reshape(2, 3, 4, 2)  # [B=2, Th=3, Tw=4, C=2]
+    centre = lambda i, j: torch.tensor([(j + 0.5) / 4, (i + 0.5) / 3], dtype=torch.float64)
+    uv = torch.stack([torch.stack([centre(1, 2), (centre(1, 2) + centre(2, 3)) / 2]), torch.stack([centre(0, 0), torch.tensor([-0.3, 0.5], dtype=torch.float64)])])[:, None]
+    out = dr.texture(tex, uv, filter_mode="linear", boundary_mode="clamp")
+    assert out.shape == (2, 1, 2, 2)
+    assert torch.allclose(out[0, 0, 0], tex[0, 1, 2]) and torch.allclose(out[0, 0, 1], (tex[0, 1, 2] + tex[0, 1, 3] + tex[0, 2, 2] + tex[0, 2, 3]) / 4)
+    assert torch.allclose(out[1, 0, 0], tex[1, 0, 0]) and torch.allclose(out[1, 0, 1], tex[1, 1, 0])  # clamped to column 0
+    wrapped = dr.texture(tex, uv, filter_mode="linear", boundary_mode="wrap")[1, 0, 1]
+    # u = -0.3 -> x = -1.7: texels -2 and -1 (= columns 2 and 3 wrapped) with weights 0.7 / 0.3
+    assert torch.allclose(wrapped, 0.7 * tex[1, 1, 2] + 0.3 * tex[1, 1, 3])
+    assert torch.allclose(dr.texture(tex, uv, filter_mode="linear", boundary_mode="zero")[1, 0, 1], torch.zeros(2, dtype=torch.float64))
+    assert torch.allclose(dr.texture(tex, uv, filter_mode="nearest", boundary_mode="clamp")[0, 0, 1], tex[0, 2, 3])  # (.5 rounds up)
+    shared = dr.texture(tex[:1], uv, filter_mode="linear", boundary_mode="clamp")
+    assert torch.allclose(shared[1, 0, 0], tex[0, 0, 0])
+    t, u = tex.clone().requires_grad_(True), uv.clone().requires_grad_(True)
+    dr.texture(t, u, filter_mode="linear", boundary_mode="clamp").sum().backward()
+    assert float(t.grad.sum()) == pytest.approx(2 * 2 * 2) and u.grad.abs().sum() > 0
+    for kw in (dict(filter_mode="linear-mipmap-linear"), dict(boundary_mode="cube"), dict(uv_da=uv)):
+        with pytest.raises(NotImplementedError):
+            dr.texture(tex, uv, **kw)
