@@ -16,7 +16,7 @@ SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
-    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _p]),
+    "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p]),
     "a3d_dmtet_count_ordered": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
     "a3d_dmtet_word_group_slots": (_c_int, []),
     "a3d_dmtet_word_group_bits": (_c_int, []),

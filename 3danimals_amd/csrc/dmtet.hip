@@ -241,7 +241,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
 #define DM_CULL_SLOTS 8
 #define DM_CULL_BLOCKS 4
 
-template <int G>
+template <int G, int SLOTS>
 __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigned* __restrict__ sign, const int2* __restrict__ edges,
                                                                    const int4* __restrict__ tets, int Ne, int Nt, int nbe, int nbt, int nge,
                                                                    const unsigned* __restrict__ edge_groups,
@@ -255,8 +255,10 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
     __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
     __shared__ unsigned s_vwin[DM_VWIN];
-    constexpr int WPB = DM_BLOCK_ITEMS / 64, ROUNDS = (G * DM_SLABS * DM_CULL_SLOTS + 63) / 64;
-    static_assert(DM_CULL_SLOTS == 8 && DM_SLABS == 4 && DM_THREADS == 256, "one byte of a ballot per word, one nibble of skip bits per block");
+    // SLOTS = 8 (grids numbered along their rows: the Kuhn grids) or 16 (round 4: spatially coherent files whose words touch more groups
+    // -- a BCC lattice in its generator's order: 10-13 -- at 64 instead of 32 bytes of table per word)
+    constexpr int WPB = DM_BLOCK_ITEMS / 64, WPR = 64 / SLOTS, ROUNDS = (G * DM_SLABS * SLOTS + 63) / 64;
+    static_assert((SLOTS == 8 || SLOTS == 16) && DM_SLABS == 4 && DM_THREADS == 256, "SLOTS bits of a ballot per word, one nibble of skip bits per block");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool is_edge = (int)blockIdx.x < nge;
     // block g of this work-group = first + g * step: blocks that hold crossings come in runs (the surface), and a work-group that owned
@@ -264,15 +266,15 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
     const int nblk = is_edge ? nbe : nbt, step = is_edge ? nge : (int)gridDim.x - nge;
     const int first = is_edge ? (int)blockIdx.x : (int)blockIdx.x - nge;
     const unsigned* __restrict__ groups = is_edge ? edge_groups : tet_groups;
-    // entry = (word slot q = g * DM_SLABS + k, group j): lane -> (q = lane / 8 + 8 r, j = lane % 8)
+    // entry = (word slot q = g * DM_SLABS + k, group j): lane -> (q = lane / SLOTS + WPR r, j = lane % SLOTS)
     unsigned gid[ROUNDS], val[ROUNDS];
     bool in[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int q = (lane >> 3) + 8 * r, g = q / DM_SLABS, k = q - g * DM_SLABS;
+        const int q = lane / SLOTS + WPR * r, g = q / DM_SLABS, k = q - g * DM_SLABS;
         in[r] = q < G * DM_SLABS && first + g * step < nblk;
         // (unconditional loads at a clamped index, then the select: a load under a condition is a branch with its own wait)
-        gid[r] = groups[((long long)(in[r] ? first + g * step : first) * WPB + k * (DM_THREADS / A3D_WAVE) + wave) * DM_CULL_SLOTS + (lane & 7)];
+        gid[r] = groups[((long long)(in[r] ? first + g * step : first) * WPB + k * (DM_THREADS / A3D_WAVE) + wave) * SLOTS + (lane % SLOTS)];
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -283,9 +285,10 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const unsigned long long z = __ballot(in[r] && val[r] == 0u), o = __ballot(in[r] && val[r] == 0xFFFFu);
+        constexpr unsigned long long M = SLOTS == 16 ? 0xFFFFull : 0xFFull;
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            if (((z >> (8 * b)) & 0xFFull) == 0xFFull || ((o >> (8 * b)) & 0xFFull) == 0xFFull) skip |= 1u << (8 * r + b);
+        for (int b = 0; b < WPR; ++b)
+            if (((z >> (SLOTS * b)) & M) == M || ((o >> (SLOTS * b)) & M) == M) skip |= 1u << (WPR * r + b);
     }
     if (lane < G) s_nib[lane][wave] = (skip >> (DM_SLABS * lane)) & 15u;
     if (vbits && is_edge)
@@ -969,9 +972,10 @@ extern "C" int a3d_dmtet_block_items(void) { return DM_BLOCK_ITEMS; }
 
 extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                                int32_t* counts, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
-                               const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int32_t* words_to_clear_or_null,
-                               int n_words_to_clear, a3d_stream_t stream) {
+                               const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int group_slots,
+                               int32_t* words_to_clear_or_null, int n_words_to_clear, a3d_stream_t stream) {
     A3D_CHECK_ARG(n_words_to_clear >= 0 && (n_words_to_clear == 0 || words_to_clear_or_null));
+    A3D_CHECK_ARG(!edge_groups_or_null || group_slots == 8 || group_slots == 16);
     A3D_CHECK_ARG(sdf && edges && tets && scratch && counts && ((uintptr_t)scratch & 7) == 0);
     A3D_CHECK_ARG((edge_groups_or_null == nullptr) == (tet_groups_or_null == nullptr));
     A3D_CHECK_ARG(!edge_groups_or_null || Nv > 0);
@@ -993,9 +997,13 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
         list_len = d.list_len;
         // (G = 1, 2, 4, 8 blocks per work-group measured within 1 us of each other once the blocks of a work-group are strided)
         const int nge = a3d_div_up(d.nbe, DM_CULL_BLOCKS), ngt = a3d_div_up(d.nbt, DM_CULL_BLOCKS);
-        hipLaunchKernelGGL(dm_count_cull_kernel<DM_CULL_BLOCKS>, dim3(nge + ngt), dim3(DM_THREADS), 0, s, (const unsigned*)sign, (const int2*)edges,
-                           (const int4*)tets, Ne, Nt, d.nbe, d.nbt, nge, edge_groups_or_null, tet_groups_or_null, d.be, d.b1, d.b2, d.edge_bits,
-                           d.tet_bits, d.wlocal, vbits, d.list_len, d.elist, d.tlist);
+#define DM_CULL_LAUNCH(SLOTS)                                                                                                                  \
+    hipLaunchKernelGGL((dm_count_cull_kernel<DM_CULL_BLOCKS, SLOTS>), dim3(nge + ngt), dim3(DM_THREADS), 0, s, (const unsigned*)sign,           \
+                       (const int2*)edges, (const int4*)tets, Ne, Nt, d.nbe, d.nbt, nge, edge_groups_or_null, tet_groups_or_null, d.be, d.b1,    \
+                       d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits, d.list_len, d.elist, d.tlist)
+        if (group_slots == 16) DM_CULL_LAUNCH(16);
+        else DM_CULL_LAUNCH(8);
+#undef DM_CULL_LAUNCH
     } else if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
         unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
         hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign, (int*)nullptr);

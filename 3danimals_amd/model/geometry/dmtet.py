@@ -68,6 +68,7 @@ class TetGridTopology:
         return self._face_list_stride
 
     WORD_GROUPS = True  # False: the count pass streams every index row (a3d_dmtet_count without the cull)
+    WORD_GROUPS_MAX_DENSE = 0.25  # (fraction of words with more groups than slots: those are always read)
 
     def word_groups(self):
         """(edge_groups, tet_groups) int32 [blocks * words_per_block, slots] for the culled count pass, or None.
@@ -82,10 +83,17 @@ class TetGridTopology:
             from ... import _lib
 
             lib = _lib.lib()
-            slots, bits, block = lib.a3d_dmtet_word_group_slots(), lib.a3d_dmtet_word_group_bits(), lib.a3d_dmtet_block_items()
-            e, t = _word_groups(self.edges32, slots, bits, block), _word_groups(self.tets32, slots, bits, block)
-            dense = (int((e[:, 0] < 0).sum()) + int((t[:, 0] < 0).sum())) / float(e.shape[0] + t.shape[0])
-            self._word_groups = (e, t) if dense <= 0.5 else False
+            bits, block = lib.a3d_dmtet_word_group_bits(), lib.a3d_dmtet_block_items()
+            self._word_groups = False
+            # 8 slots (32 B per word) where that holds most words -- grids numbered along their rows --, else 16 (64 B: spatially
+            # coherent files whose words touch more groups, e.g. a BCC lattice in its generator's order); a file whose row order
+            # ignores space fails both and takes the ordered pass (spatial_order)
+            for slots in (lib.a3d_dmtet_word_group_slots(), 16):
+                e, t = _word_groups(self.edges32, slots, bits, block), _word_groups(self.tets32, slots, bits, block)
+                dense = (int((e[:, 0] < 0).sum()) + int((t[:, 0] < 0).sum())) / float(e.shape[0] + t.shape[0])
+                if dense <= self.WORD_GROUPS_MAX_DENSE:
+                    self._word_groups = (e, t)
+                    break
         return self._word_groups or None
 
     SPATIAL_ORDER = True  # False: a grid numbered without regard to space takes the plain count pass (a3d_dmtet_count, no tables)

@@ -177,7 +177,8 @@ def _dmtet_count(sdf_c, pos_c, grid, scratch, counts, vscratch, vclean, counters
     else:
         groups = grid.word_groups() if which == "culled" else None
         call("a3d_dmtet_count", ptr(sdf_c), ptr(grid.edges32), ptr(grid.tets32), Ne, Nt, ptr(scratch), ptr(counts), ptr(vscratch), int(vclean), Nv,
-             ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, ptr(counters), n_clear, stream())
+             ptr(groups[0]) if groups else None, ptr(groups[1]) if groups else None, groups[0].shape[1] if groups else 0, ptr(counters), n_clear,
+             stream())
     grid._last_count_pass = which
     return which
 

@@ -55,11 +55,11 @@ const char* a3d_last_error(void);
 size_t a3d_dmtet_scratch_bytes(int Ne, int Nt);
 int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int32_t* tets, int Ne, int Nt, void* scratch,
                     int32_t* counts /*[6]*/, void* vertex_scratch_or_null, int vertex_scratch_is_clean, int Nv,
-                    const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int32_t* words_to_clear_or_null,
-                    int n_words_to_clear, a3d_stream_t stream);
+                    const uint32_t* edge_groups_or_null, const uint32_t* tet_groups_or_null, int group_slots /* 8 or 16 */,
+                    int32_t* words_to_clear_or_null, int n_words_to_clear, a3d_stream_t stream);
 /* words_to_clear: n 4-byte words zeroed by the last launch of the call (the valence counters a3d_dmtet_emit's topo_count wants zero). */
 /* edge_groups / tet_groups (both or none; static per grid like `edges`): the culled count pass.  Row w of edge_groups
- * [ceil(Ne / a3d_dmtet_block_items()) * a3d_dmtet_block_items() / 64 rows x a3d_dmtet_word_group_slots()] lists the distinct values of
+ * [ceil(Ne / a3d_dmtet_block_items()) * a3d_dmtet_block_items() / 64 rows x group_slots (8, or 16 for files whose words touch more groups)] lists the distinct values of
  * (vertex index >> a3d_dmtet_word_group_bits()) over the 64 consecutive rows edges[64 w .. 64 w + 63] (unused slots repeat one of
  * them; rows past the list and rows with more distinct values than slots hold 0xffffffff in every slot); tet_groups the same over
  * `tets`.  With them the pass takes a sign-plane pre-pass and reads a word's index rows only if its vertex groups do not all lie on one

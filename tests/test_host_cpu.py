@@ -362,8 +362,8 @@ def test_nvdiffrast_shim_surface():
         assert isinstance(dr.RasterizeCudaContext(), type(ctx).__mro__[1])
         for name in ("rasterize", "interpolate", "antialias", "DepthPeeler", "texture"):
             assert hasattr(dr, name)
-        with pytest.raises(NotImplementedError):
-            dr.texture(None, None)
+        with pytest.raises(NotImplementedError):  # (cube maps / mip-mapping: off the path; the 2-D bilinear tap is provided)
+            dr.texture(torch.zeros(6, 2, 2, 1), torch.zeros(1, 1, 1, 3), boundary_mode="cube")
         with pytest.raises(RuntimeError, match="num_vertices, 4"):
             dr.rasterize(ctx, torch.rand(1, 3, 3), torch.zeros(1, 3, dtype=torch.int32), [8, 8])
     finally:
