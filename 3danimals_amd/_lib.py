@@ -36,7 +36,7 @@ SIGNATURES = {
     "a3d_normals_adjacency": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_normals_fwd": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_normals_fwd_pair": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
-    "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
+    "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _c_int, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),

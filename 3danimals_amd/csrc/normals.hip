@@ -141,6 +141,77 @@ __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g
     g_v[o] = ox; g_v[o + 1] = oy; g_v[o + 2] = oz;
 }
 
+// ---- faces first (round 4).  The kernel above re-derives the adjoint of every incident face at every vertex: valence x (3 positions + 3
+// normal adjoints) = ~48 gathers per vertex, i.e. ~24 per face, and on a mesh whose numbering is not spatial (a surface extracted from a
+// BCC lattice or from a scrambled grid file) every one of them is a cache line of its own: 11 -> 21 us.  Here every (image, face) does that
+// work ONCE -- 9 gathers: positions, acc and g_nrm of its three corners; the normalisation adjoint of the pre-pass folded in, three per
+// thread -- and leaves the three corner contributions (36 B) in a face-major scratch; every (image, vertex) then sums its <= 8 entries in
+// ascending key order: the SAME float values in the SAME order as the gather kernel adds them, so the result is bit-identical.
+__global__ __launch_bounds__(256) void nr_face_bwd_kernel(const float* __restrict__ g_nrm, int g_stride, const float* __restrict__ acc,
+                                                          const float* __restrict__ v, const int* __restrict__ tri, int V, int F,
+                                                          float* __restrict__ fadj) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long vb = (long long)blockIdx.y * V;
+    const float* vp = v + vb * 3;
+    const float* ap = acc + vb * 3;
+    const float* np = g_nrm + vb * g_stride;
+    const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+    float p0[3], p1[3], p2[3], g0[3], g1[3], g2[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { p0[q] = vp[3ll * i0 + q]; p1[q] = vp[3ll * i1 + q]; p2[q] = vp[3ll * i2 + q]; }
+    {
+        const float *a0 = ap + 3ll * i0, *a1 = ap + 3ll * i1, *a2 = ap + 3ll * i2;
+        const float *n0 = np + (long long)g_stride * i0, *n1 = np + (long long)g_stride * i1, *n2 = np + (long long)g_stride * i2;
+        const float x0 = a0[0], y0 = a0[1], z0 = a0[2], x1 = a1[0], y1 = a1[1], z1 = a1[2], x2 = a2[0], y2 = a2[1], z2 = a2[2];
+        const float gx0 = n0[0], gy0 = n0[1], gz0 = n0[2], gx1 = n1[0], gy1 = n1[1], gz1 = n1[2], gx2 = n2[0], gy2 = n2[1], gz2 = n2[2];
+        nr_vert_adjoint(x0, y0, z0, gx0, gy0, gz0, g0);
+        nr_vert_adjoint(x1, y1, z1, gx1, gy1, gz1, g1);
+        nr_vert_adjoint(x2, y2, z2, gx2, gy2, gz2, g2);
+    }
+    float* o = fadj + ((long long)blockIdx.y * F + f) * 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // corner c's share, by the gather kernel's own function (same operations, same order)
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        nr_bwd_entry(c, g0, g1, g2, p0, p1, p2, ox, oy, oz);
+        o[3 * c] = ox; o[3 * c + 1] = oy; o[3 * c + 2] = oz;
+    }
+}
+
+__global__ __launch_bounds__(256) void nr_sum_bwd_kernel(const float* __restrict__ fadj, const int* __restrict__ off, const int* __restrict__ adj,
+                                                         int V, int F, float* __restrict__ g_v, int stride) {
+    const int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= V) return;
+    const float* fa = fadj + (long long)blockIdx.y * F * 9;
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    int lo, cnt;
+    vf_list(off, stride, vi, lo, cnt);
+    if (cnt > 0) {
+        int keys[NR_SLOTS];
+        nr_first_keys(adj, lo, cnt, keys);
+        float e[NR_SLOTS][3];
+#pragma unroll
+        for (int k = 0; k < NR_SLOTS; ++k) {  // (all entries in flight; unused slots re-read the first)
+            const int key = k < cnt ? keys[k] : keys[0];
+            const int c = key >= 2 * F ? 2 : (key >= F ? 1 : 0);
+            const float* s = fa + 9ll * (key - c * F) + 3 * c;
+            e[k][0] = s[0]; e[k][1] = s[1]; e[k][2] = s[2];
+        }
+#pragma unroll
+        for (int k = 0; k < NR_SLOTS; ++k)
+            if (k < cnt) { ox += e[k][0]; oy += e[k][1]; oz += e[k][2]; }
+        int last = keys[NR_SLOTS - 1];
+        for (int q = NR_SLOTS; q < cnt; ++q) {
+            last = nr_next_key_mem(adj, lo, cnt, last);
+            const int c = last >= 2 * F ? 2 : (last >= F ? 1 : 0);
+            const float* s = fa + 9ll * (last - c * F) + 3 * c;
+            ox += s[0]; oy += s[1]; oz += s[2];
+        }
+    }
+    const long long o = ((long long)blockIdx.y * V + vi) * 3;
+    g_v[o] = ox; g_v[o + 1] = oy; g_v[o + 2] = oz;
+}
+
 }  // namespace
 
 extern "C" int a3d_normals_adjacency(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream) {
@@ -186,10 +257,20 @@ extern "C" int a3d_normals_fwd_pair(const float* v_a, int B_a, const float* v_b,
 
 extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float* acc, const float* v, const int32_t* tri, const int32_t* off,
                                const int32_t* adj, int B, int V, int F, float* g_acc_scratch, float* g_v, int lists_stride,
-                               a3d_stream_t stream) {
-    A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_acc_scratch && g_v && B > 0 && V > 0 && F >= 0 && lists_stride >= 0);
+                               float* face_scratch_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_nrm && g_nrm_stride >= 3 && acc && v && off && g_v && B > 0 && V > 0 && F >= 0 && lists_stride >= 0 && B <= 65535);
+    A3D_CHECK_ARG(g_acc_scratch || face_scratch_or_null);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
+    if (face_scratch_or_null && F > 0) {  // faces first: every face once, then a sum per vertex (same bits as the gather form below)
+        hipLaunchKernelGGL(nr_face_bwd_kernel, dim3(a3d_div_up(F, 256), B), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, v, tri, V, F, face_scratch_or_null);
+        A3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nr_sum_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, (const float*)face_scratch_or_null, off, adj, V, F, g_v,
+                           lists_stride);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
+    A3D_CHECK_ARG(g_acc_scratch);
     const long long n = (long long)B * V;
     // (the one-launch form measured SLOWER inside the step: 24.8 against 17.8 us for the call -- its 24 normalisation adjoints per thread
     // with correctly rounded sqrt and division are ~1200 more instructions in a kernel that was latency bound but not idle; it stays

@@ -526,6 +526,20 @@ def vertex_face_adjacency(tri32: torch.Tensor, num_vertices: int) -> VertexFaceA
     return adj
 
 
+NORMALS_FACES_FIRST = os.environ.get("A3D_NORMALS_FACES_FIRST", "1") != "0"  # a3d_normals_bwd: every face's adjoint once + a sum per vertex
+
+
+def _normals_bwd_call(g, acc, v, tri32, adjacency, B, V, F):
+    """a3d_normals_bwd for one vertex array -> g_v.  Faces first (a [B,F,9] scratch) unless switched off: same bits, ~half the gathers."""
+    g_v = torch.empty_like(v)
+    faces_first = NORMALS_FACES_FIRST and F > 0
+    face_scratch = torch.empty((B, F, 9), dtype=torch.float32, device=v.device) if faces_first else None
+    scratch = None if faces_first else torch.empty_like(v)
+    call("a3d_normals_bwd", ptr(g), g.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(adjacency.off), ptr(adjacency.adj), B, V, F, ptr(scratch),
+         ptr(g_v), adjacency.stride, ptr(face_scratch), stream(), tag=f"[B{B}]")
+    return g_v
+
+
 class _Normals(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, tri32, adjacency):
@@ -544,13 +558,9 @@ class _Normals(torch.autograd.Function):
     def backward(ctx, g_nrm):
         v, acc, tri32 = ctx.saved_tensors
         B, V, F = v.shape[0], v.shape[1], tri32.shape[0]
-        scratch = torch.empty_like(v)
-        g_v = torch.empty_like(v)
         if g_nrm.dtype != torch.float32 or g_nrm.stride(2) != 1 or g_nrm.stride(0) != V * g_nrm.stride(1):  # rows must be evenly strided
             g_nrm = f32c(g_nrm)
-        call("a3d_normals_bwd", ptr(g_nrm), g_nrm.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-             ptr(scratch), ptr(g_v), ctx.adjacency.stride, stream(), tag=f"[B{B}]")
-        return g_v, None, None
+        return _normals_bwd_call(g_nrm, acc, v, tri32, ctx.adjacency, B, V, F), None, None
 
 
 class _NormalsPair(torch.autograd.Function):
@@ -582,10 +592,7 @@ class _NormalsPair(torch.autograd.Function):
             B, V = v.shape[0], v.shape[1]
             if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(0) != V * g.stride(1):
                 g = f32c(g)
-            scratch, g_v = torch.empty_like(v), torch.empty_like(v)
-            call("a3d_normals_bwd", ptr(g), g.stride(1), ptr(acc), ptr(v), ptr(tri32), ptr(ctx.adjacency.off), ptr(ctx.adjacency.adj), B, V, F,
-                 ptr(scratch), ptr(g_v), ctx.adjacency.stride, stream(), tag=f"[B{B}]")
-            out.append(g_v)
+            out.append(_normals_bwd_call(g, acc, v, tri32, ctx.adjacency, B, V, F))
         return out[0], out[1], None, None
 
 

@@ -144,7 +144,8 @@ def algorithmic_bytes(name, d):
         "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
         "a3d_mesh_topology_finalize": 12 * F + 4 * V + (4 * V + 12 * F),  # int32 triangle list + valence counts in; offsets + lists out
         "a3d_normals_fwd": 4 * V + 24 * F + Bn * (36 * F + 24 * V),  # CSR + indices once; per image position gathers, acc + nrm out
-        "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 36 * F + 60 * V),
+        # faces first: per image the three corners' positions, acc and normal gradients per face in, 36 B per face out and in again, 12 B per vertex out
+        "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 72 * F + 72 * F + 12 * V),
         "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
         "a3d_rast_bwd": B * (32 * HW + 16 * V),
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),

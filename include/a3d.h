@@ -210,8 +210,9 @@ int a3d_normals_adjacency(const int32_t* tri /*[F,3]*/, int V, int F, int32_t* o
 int a3d_normals_fwd(const float* v /*[B,V,3]*/, const int32_t* tri /*[F,3]*/, const int32_t* off, const int32_t* adj, int B, int V, int F,
                     float* acc, float* nrm, int lists_stride, a3d_stream_t stream);
 int a3d_normals_bwd(const float* g_nrm /*B*V rows of 3, g_nrm_stride floats apart*/, int g_nrm_stride, const float* acc, const float* v,
-                    const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3]*/,
-                    float* g_v /*[B,V,3]*/, int lists_stride, a3d_stream_t stream);
+                    const int32_t* tri, const int32_t* off, const int32_t* adj, int B, int V, int F, float* g_acc_scratch /*[B,V,3] or NULL with face_scratch*/,
+                    float* g_v /*[B,V,3]*/, int lists_stride, float* face_scratch_or_null /*[B,F,9]: faces first -- every face's adjoint once, then a
+                    sum per vertex in the same key order: same bits, ~half the gathers, for meshes whose numbering is not spatial*/, a3d_stream_t stream);
 /* Two vertex arrays over ONE triangle list in one launch (e.g. the canonical mesh beside the B posed meshes of an iteration: a launch
  * of its own for one image is pure latency); results identical to two a3d_normals_fwd calls. */
 int a3d_normals_fwd_pair(const float* v_a /*[B_a,V,3]*/, int B_a, const float* v_b /*[B_b,V,3]*/, int B_b, const int32_t* tri,

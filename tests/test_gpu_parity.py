@@ -2712,3 +2712,48 @@ def test_shading_inside_the_compositor_equals_the_separate_launch(dev, mods, mon
         deferred = modes == ["shaded", "dino_pred"]  # (only the FIRST buffer of a compositor call, and only the training modes)
         assert any("[+shade]" in c for c in calls_on) == deferred, (modes, calls_on)
         assert ("a3d_shade_fwd" in calls_on) == (not deferred) and "a3d_shade_fwd" in calls_off
+
+
+@pytest.mark.parametrize("numbering", ["spatial", "random"])
+def test_normals_backward_faces_first_is_bit_identical_to_the_gather_form(numbering, dev, ops, mods, monkeypatch):
+    """a3d_normals_bwd with face_scratch (every face's corner adjoints once, then a per-vertex sum in ascending key order) against the
+    gather form (every vertex re-derives its incident faces' adjoints): the same float values added in the same order -- equal bits --
+    on a spatially numbered marching-tets surface and on the randomly numbered, randomly wound one a scrambled grid file gives; CSR and
+    fixed-stride lists; valences above eight (a fan)."""
+    from oracle import dmtet_ref
+
+    tg = importlib.import_module("3danimals_amd.tetgrid")
+    pos, tets = kuhn(14)
+    if numbering == "random":
+        p_np, t_np = tg.scramble(pos.numpy(), tets.numpy(), 4)
+        pos, tets = torch.from_numpy(p_np), torch.from_numpy(t_np).long()
+    ext = float((pos.amax(0) - pos.amin(0)).max())
+    sdf = 0.31 * ext - (pos - pos.mean(0)).norm(dim=1) + 0.02 * ext * seeded((pos.shape[0],), 5, -1, 1)
+    verts, faces, _, _ = dmtet_ref.marching_tets(pos, sdf, tets)
+    assert verts.shape[0] > 500
+    fan = torch.tensor([[0, k, k + 1] for k in range(1, 14)])  # vertex 0 gains 13 more faces: valence > 8
+    meshes = [(verts, faces), (verts, torch.cat([faces, fan]))]
+    B = 3
+    for v0, f in meshes:
+        v = (v0[None] + 0.01 * seeded((B, *v0.shape), 8, -1, 1)).to(dev)
+        g = seeded((B, v0.shape[0], 3), 9, -1, 1).to(dev)
+        outs = []
+        for faces_first in (True, False):
+            monkeypatch.setattr(ops, "NORMALS_FACES_FIRST", faces_first)
+            vv = v.clone().requires_grad_(True)
+            n = ops.vertex_normals(vv, f.to(dev))
+            (gv,) = torch.autograd.grad((n * g).sum(), vv)
+            outs.append(gv)
+        assert float(outs[0].abs().max()) > 0 and torch.equal(outs[0], outs[1])
+    # ... and through the fixed-stride lists a DMTet extraction leaves (the training path)
+    grid = mods["dmtet"].TetGridTopology(tets.to(dev), positions=pos.to(dev))
+    for _ in range(2):
+        ve, fa, _ = ops.dmtet(pos.to(dev), sdf.to(dev), grid)
+    outs = []
+    for faces_first in (True, False):
+        monkeypatch.setattr(ops, "NORMALS_FACES_FIRST", faces_first)
+        vv = (ve[None].expand(B, -1, -1) + 0.0).clone().requires_grad_(True)
+        n = ops.vertex_normals(vv, fa)
+        (gv,) = torch.autograd.grad((n * g[:, : ve.shape[0]]).sum(), vv)
+        outs.append(gv)
+    assert torch.equal(outs[0], outs[1])
