@@ -673,3 +673,34 @@ def test_shim_texture_bilinear_tap_known_answers():
     for kw in (dict(filter_mode="linear-mipmap-linear"), dict(boundary_mode="cube"), dict(uv_da=uv)):
         with pytest.raises(NotImplementedError):
             dr.texture(tex, uv, **kw)
+
+
+def test_option_structs_of_an_older_header_are_refused_before_anything_is_launched():
+    """Every option struct of the ABI starts with its own size; an entry point that is handed a struct SHORTER than the one it was built
+    with (a caller compiled against an older header) must refuse with A3D_EINVAL and say so -- before it touches a pointer or the GPU
+    (this runs without one: the pointers below are never dereferenced)."""
+    L = importlib.import_module("3danimals_amd._lib")
+    lib = L.lib()
+    fake = 0x1000  # non-NULL, never dereferenced
+    short = lambda cls: cls(size=ctypes.sizeof(cls) - 4)
+    cases = {
+        "a3d_rast_fwd": lambda o: lib.a3d_rast_fwd(fake, 1, fake, 1, 3, 1, 8, 8, fake, fake, 0, ctypes.addressof(o), None),
+        "a3d_dmtet_emit": lambda o: lib.a3d_dmtet_emit(fake, fake, fake, fake, 6, 1, fake, 1, 1, 0, fake, fake, fake, fake, ctypes.addressof(o), None),
+        "a3d_dmtet_emit_sparse": lambda o: lib.a3d_dmtet_emit_sparse(fake, fake, fake, fake, 6, 1, fake, 1, 1, 0, fake, fake, fake, fake, ctypes.addressof(o), None),
+        "a3d_dmtet_count_ordered": lambda o: lib.a3d_dmtet_count_ordered(fake, 4, 6, 1, ctypes.addressof(o), fake, fake, None, 0, None, 0, None),
+        "a3d_composite_aa_fwd": lambda o: lib.a3d_composite_aa_fwd(fake, 3, None, 0, fake, None, 0, None, 0, None, fake, fake, fake, 4096, 1, 8, 8,
+                                                                   ctypes.addressof(o), None, None),
+        "a3d_mask_aa_fwd": lambda o: lib.a3d_mask_aa_fwd(fake, 3, None, 0, fake, fake, fake, 4096, 1, 8, 8, ctypes.addressof(o), None),
+    }
+    structs = {"a3d_rast_fwd": L.RastOpts, "a3d_dmtet_emit": L.DmtetEmitOpts, "a3d_dmtet_emit_sparse": L.DmtetEmitOpts,
+               "a3d_dmtet_count_ordered": L.DmtetOrder, "a3d_composite_aa_fwd": L.AaRide, "a3d_mask_aa_fwd": L.AaRide}
+    for name, fn in cases.items():
+        o = short(structs[name])
+        rc = fn(o)
+        assert rc != 0, name
+        msg = lib.a3d_last_error().decode()
+        assert "size" in msg and "invalid argument" in msg, (name, msg)  # (names the entry point or the helper that checks its struct)
+    # the shading struct of the compositor (checked after the riding analysis, which is absent here)
+    sh = short(L.CaShade)
+    assert lib.a3d_composite_aa_fwd(None, 3, None, 0, fake, None, 0, None, 0, None, fake, fake, fake, 4096, 1, 8, 8, None, ctypes.addressof(sh), None) != 0
+    assert "size" in lib.a3d_last_error().decode()
