@@ -80,11 +80,10 @@ SIGNATURES = {
     "a3d_aa_analyze": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p]),
     "a3d_aa_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
-    "a3d_composite_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_composite_aa_fwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_mask_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_mask_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
-    "a3d_composite_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p, _c_int, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p,
-                                      _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_composite_aa_bwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
 }
 
 
@@ -110,6 +109,13 @@ class AaRide(ctypes.Structure):
 
     _fields_ = [("size", ctypes.c_uint32), ("clip_batch", ctypes.c_int32), ("rast", _p), ("screen", _p), ("tri", _p), ("opp", _p), ("off", _p),
                 ("adj", _p), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("lists_stride", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class CaBuffer(ctypes.Structure):
+    """a3d_ca_buffer of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("C", ctypes.c_int32), ("vals", _p), ("bg", _p), ("out", _p), ("g_out", _p), ("g_vals", _p),
+                ("bg_batch", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class CaShade(ctypes.Structure):

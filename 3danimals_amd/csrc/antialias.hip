@@ -715,10 +715,15 @@ static int ca_ride(const a3d_aa_ride* r, const float* rast_override, void* work,
     return A3D_OK;
 }
 
-extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null,
-                                    int C2, const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
+extern "C" int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int32_t* inv, void* work,
                                     int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null,
                                     const a3d_ca_shade* shade_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(first && first->size >= sizeof(a3d_ca_buffer) && (!second_or_null || second_or_null->size >= sizeof(a3d_ca_buffer)));
+    const float *vals = first->vals, *bg_or_null = first->bg, *vals2_or_null = second_or_null ? second_or_null->vals : nullptr;
+    const float* bg2_or_null = second_or_null ? second_or_null->bg : nullptr;
+    const int C = first->C, bg_batch = first->bg_batch, C2 = second_or_null ? second_or_null->C : 0, bg2_batch = second_or_null ? second_or_null->bg_batch : 0;
+    float *out = first->out, *out2_or_null = second_or_null ? second_or_null->out : nullptr;
+    A3D_CHECK_ARG(!second_or_null || out2_or_null);
     A3D_CHECK_ARG(inv && work && count && out && C > 0 && C + 1 <= 4096 && B > 0 && H > 0 && W > 0 && capacity > 0);
     AaAnalyzeJob an;
     unsigned nb_an;
@@ -739,11 +744,19 @@ extern "C" int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or
     return A3D_OK;
 }
 
-extern "C" int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
-                                    const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch,
-                                    float* g_vals2, const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count,
-                                    int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W,
-                                    float* g_clip, const a3d_ca_shade* shade_or_null, a3d_stream_t stream) {
+extern "C" int a3d_composite_aa_bwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int64_t* pix, int64_t P,
+                                    const int32_t* inv, const void* work, const int32_t* count, int capacity, const float* clip, int clip_batch,
+                                    const int32_t* tri, int B, int V, int F, int H, int W, float* g_clip, const a3d_ca_shade* shade_or_null,
+                                    a3d_stream_t stream) {
+    A3D_CHECK_ARG(first && first->size >= sizeof(a3d_ca_buffer) && (!second_or_null || second_or_null->size >= sizeof(a3d_ca_buffer)));
+    const float *g_out = first->g_out, *vals = first->vals, *bg_or_null = first->bg;
+    const int C = first->C, bg_batch = first->bg_batch;
+    float* g_vals = first->g_vals;
+    const float *g_out2_or_null = second_or_null ? second_or_null->g_out : nullptr, *vals2 = second_or_null ? second_or_null->vals : nullptr;
+    const float* bg2_or_null = second_or_null ? second_or_null->bg : nullptr;
+    const int C2 = second_or_null ? second_or_null->C : 0, bg2_batch = second_or_null ? second_or_null->bg_batch : 0;
+    float* g_vals2 = second_or_null ? second_or_null->g_vals : nullptr;
+    A3D_CHECK_ARG(!second_or_null || g_out2_or_null);
     A3D_CHECK_ARG(g_out && inv && work && count && clip && g_clip && C > 0 && C <= 4096 && B > 0 && V > 0 && H > 0 && W > 0 && P >= 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
     A3D_CHECK_ARG(P == 0 || ((vals || shade_or_null) && pix && g_vals));

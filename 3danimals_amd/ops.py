@@ -1222,9 +1222,10 @@ class _CompositeAntialias(torch.autograd.Function):
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
         use_shade = shade is not None and shade.filled and not getattr(shade, "materialized", False) and C == 3 and shade.outs[2].data_ptr() == vals.data_ptr()
         sh = shade.struct(clear=True) if use_shade else None
-        call("a3d_composite_aa_fwd", None if use_shade else ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(out), ptr(vals2), C2, ptr(bg2),
-             0 if bg2 is None else bg2.shape[0], ptr(out2), ptr(inv), ptr(a.work), ptr(a.count), a.capacity, a.B, a.H, a.W,
-             None if ride is None else ctypes.addressof(ride), None if sh is None else ctypes.addressof(sh), stream(),
+        buf = lambda v, c, g, o: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), out=ptr(o), bg_batch=0 if g is None else g.shape[0])
+        first, second = buf(None if use_shade else vals, C, bg, out), (buf(vals2, C2, bg2, out2) if vals2 is not None else None)
+        call("a3d_composite_aa_fwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(inv), ptr(a.work), ptr(a.count),
+             a.capacity, a.B, a.H, a.W, None if ride is None else ctypes.addressof(ride), None if sh is None else ctypes.addressof(sh), stream(),
              tag=tag + ("[+shade]" if use_shade else "") + ("[+analysis]" if ride is not None else ""))
         ctx.shade = shade if use_shade else None
         if ride is not None:
@@ -1250,10 +1251,14 @@ class _CompositeAntialias(torch.autograd.Function):
         g_vals2 = torch.empty_like(vals2) if two else None
         g_clip = torch.empty_like(a.clip)
         sh = ctx.shade.struct(clear=False) if ctx.shade is not None else None
-        call("a3d_composite_aa_bwd", ptr(f32c(g_out)), None if sh is not None else ptr(vals), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(g_vals),
-             ptr(f32c(g_out2)) if two else None, ptr(vals2), C2, ptr(bg2), 0 if bg2 is None else bg2.shape[0], ptr(g_vals2), ptr(pix), P, ptr(inv),
-             ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H,
-             a.W, ptr(g_clip), None if sh is None else ctypes.addressof(sh), stream(), tag=ctx.tag)
+        g_out, g_out2 = f32c(g_out), (f32c(g_out2) if two else None)
+        buf = lambda v, c, g, go, gv: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), g_out=ptr(go), g_vals=ptr(gv),
+                                                    bg_batch=0 if g is None else g.shape[0])
+        first = buf(None if sh is not None else vals, C, bg, g_out, g_vals)
+        second = buf(vals2, C2, bg2, g_out2, g_vals2) if two else None
+        call("a3d_composite_aa_bwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(pix), P, ptr(inv), ptr(a.work),
+             ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip),
+             None if sh is None else ctypes.addressof(sh), stream(), tag=ctx.tag)
         return g_vals, g_vals2, g_clip, None, None, None, None, None, None
 
 

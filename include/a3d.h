@@ -459,10 +459,21 @@ typedef struct a3d_ca_shade {
     int32_t n_clear;
     int32_t two_sided;
 } a3d_ca_shade;
-int a3d_composite_aa_fwd(const float* vals, int C, const float* bg_or_null, int bg_batch, float* out, const float* vals2_or_null, int C2,
-                         const float* bg2_or_null, int bg2_batch, float* out2_or_null, const int32_t* inv, void* work,
-                         int32_t* count, int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null,
-                         const a3d_ca_shade* shade_or_null, a3d_stream_t stream);
+/* One buffer of a compositor call (round 4: the two buffers of a call by name instead of ten / twelve positional arguments). */
+typedef struct a3d_ca_buffer {
+    uint32_t size;       /* sizeof(a3d_ca_buffer) of the caller's header (fields are only ever appended) */
+    int32_t C;           /* channels of vals; the image has C + 1 */
+    const float* vals;   /* [P,C] (NULL with a3d_ca_shade, first buffer only) */
+    const float* bg;     /* [bg_batch,H,W,C+1] or NULL = zeros */
+    float* out;          /* forward: [B,H,W,C+1] */
+    const float* g_out;  /* backward: [B,H,W,C+1] */
+    float* g_vals;       /* backward: [P,C], fully written */
+    int32_t bg_batch;    /* 1 or B */
+    int32_t reserved;
+} a3d_ca_buffer;
+int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int32_t* inv, void* work, int32_t* count,
+                         int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, const a3d_ca_shade* shade_or_null,
+                         a3d_stream_t stream);
 /* analyze != NULL: the records do not exist yet -- a3d_aa_analyze(prepared = 1)'s launch (same arguments: rast, the `screen` and
  * zeroed `count` that a3d_rast_fwd left, tri, opp or the lists) runs as extra work-groups of this call's first launch, which only moves
  * pixels; the blend launch that follows is the first consumer of `work` / `count`.  Same records as the stand-alone analysis. */
@@ -476,11 +487,9 @@ int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_ba
 int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
                     const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H,
                     int W, float* g_clip, a3d_stream_t stream);
-int a3d_composite_aa_bwd(const float* g_out, const float* vals, int C, const float* bg_or_null, int bg_batch, float* g_vals,
-                         const float* g_out2_or_null, const float* vals2, int C2, const float* bg2_or_null, int bg2_batch, float* g_vals2,
-                         const int64_t* pix, int64_t P, const int32_t* inv, const void* work, const int32_t* count, int capacity,
-                         const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* g_clip,
-                         const a3d_ca_shade* shade_or_null, a3d_stream_t stream);
+int a3d_composite_aa_bwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int64_t* pix, int64_t P, const int32_t* inv,
+                         const void* work, const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B,
+                         int V, int F, int H, int W, float* g_clip, const a3d_ca_shade* shade_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM with the ReLU adjoint in the epilogue: C[M,N] = (A[M,K] . B[K,N]) * (X[M,N] > 0), row-major, N = 256,

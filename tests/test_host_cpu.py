@@ -593,7 +593,7 @@ def test_spatial_order_tables_reproduce_the_planes_of_the_file_order(grid):
     assert culled_any
 
 
-@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide"), ("a3d_ca_shade", "CaShade")])
+@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide"), ("a3d_ca_shade", "CaShade"), ("a3d_ca_buffer", "CaBuffer")])
 def test_abi_structs_match_the_header_field_for_field(struct, cls):
     """The option structs of include/a3d.h against their ctypes mirrors: names, order, pointer / int32 / uint32 kind; `size` first."""
     L = importlib.import_module("3danimals_amd._lib")
@@ -688,10 +688,11 @@ def test_option_structs_of_an_older_header_are_refused_before_anything_is_launch
         "a3d_dmtet_emit": lambda o: lib.a3d_dmtet_emit(fake, fake, fake, fake, 6, 1, fake, 1, 1, 0, fake, fake, fake, fake, ctypes.addressof(o), None),
         "a3d_dmtet_emit_sparse": lambda o: lib.a3d_dmtet_emit_sparse(fake, fake, fake, fake, 6, 1, fake, 1, 1, 0, fake, fake, fake, fake, ctypes.addressof(o), None),
         "a3d_dmtet_count_ordered": lambda o: lib.a3d_dmtet_count_ordered(fake, 4, 6, 1, ctypes.addressof(o), fake, fake, None, 0, None, 0, None),
-        "a3d_composite_aa_fwd": lambda o: lib.a3d_composite_aa_fwd(fake, 3, None, 0, fake, None, 0, None, 0, None, fake, fake, fake, 4096, 1, 8, 8,
-                                                                   ctypes.addressof(o), None, None),
+        "a3d_composite_aa_fwd": lambda o: lib.a3d_composite_aa_fwd(ctypes.addressof(good_buf), None, fake, fake, fake, 4096, 1, 8, 8, ctypes.addressof(o),
+                                                                   None, None),
         "a3d_mask_aa_fwd": lambda o: lib.a3d_mask_aa_fwd(fake, 3, None, 0, fake, fake, fake, 4096, 1, 8, 8, ctypes.addressof(o), None),
     }
+    good_buf = L.CaBuffer(size=ctypes.sizeof(L.CaBuffer), C=3, vals=fake, out=fake)
     structs = {"a3d_rast_fwd": L.RastOpts, "a3d_dmtet_emit": L.DmtetEmitOpts, "a3d_dmtet_emit_sparse": L.DmtetEmitOpts,
                "a3d_dmtet_count_ordered": L.DmtetOrder, "a3d_composite_aa_fwd": L.AaRide, "a3d_mask_aa_fwd": L.AaRide}
     for name, fn in cases.items():
@@ -702,5 +703,9 @@ def test_option_structs_of_an_older_header_are_refused_before_anything_is_launch
         assert "size" in msg and "invalid argument" in msg, (name, msg)  # (names the entry point or the helper that checks its struct)
     # the shading struct of the compositor (checked after the riding analysis, which is absent here)
     sh = short(L.CaShade)
-    assert lib.a3d_composite_aa_fwd(None, 3, None, 0, fake, None, 0, None, 0, None, fake, fake, fake, 4096, 1, 8, 8, None, ctypes.addressof(sh), None) != 0
+    no_vals = L.CaBuffer(size=ctypes.sizeof(L.CaBuffer), C=3, out=fake)
+    assert lib.a3d_composite_aa_fwd(ctypes.addressof(no_vals), None, fake, fake, fake, 4096, 1, 8, 8, None, ctypes.addressof(sh), None) != 0
+    assert "size" in lib.a3d_last_error().decode()
+    short_buf = short(L.CaBuffer)
+    assert lib.a3d_composite_aa_fwd(ctypes.addressof(short_buf), None, fake, fake, fake, 4096, 1, 8, 8, None, None, None) != 0
     assert "size" in lib.a3d_last_error().decode()
