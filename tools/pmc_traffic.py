@@ -35,7 +35,7 @@ ENTRY = {
     "a3d_mesh_topology": (["tp_init_kernel", "tp_count_insert_kernel", "nr_adj_scan_kernel", "tp_fill_lookup_kernel", "nr_adj_sort_kernel"],
                           "nr_adj_scan_kernel"),
     "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
-    "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel"], "nr_bwd_kernel"),
+    "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel", "nr_face_bwd_kernel", "nr_sum_bwd_kernel"], "nr_sum_bwd_kernel"),
     # (the triangle launch also carries the vertex normals of the step: nr_fwd's work as extra work-groups)
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
     "a3d_cover_count": (["cv_count_kernel"], "cv_count_kernel"),
@@ -57,7 +57,9 @@ ENTRY = {
     "a3d_aa_bwd": (["aa_copy_zero_kernel", "aa_bwd_kernel"], "aa_bwd_kernel"),
     # (one call per step handles the 4- and the 17-channel buffer together; its compose launch also carries the silhouette analysis)
     "a3d_composite_aa_fwd": (["ca_compose_kernel", "ca_blend_kernel"], "ca_blend_kernel"),
-    "a3d_composite_aa_bwd": (["ca_gather_kernel", "ca_bwd_kernel"], "ca_bwd_kernel"),
+    "a3d_composite_aa_bwd": (["ca_gather_kernel", "ca_bwd_kernel"], "ca_gather_kernel"),
+    "a3d_dmtet_count_ordered": (["dm_sign_order_kernel", "dm_count_order_kernel", "dm_scan_kernel"], "dm_count_order_kernel"),
+    "a3d_dmtet_emit_sparse": (["dm_emit_words_kernel"], "dm_emit_words_kernel"),
     "a3d_flow_loss_fwd": (["fl_fwd_kernel", "fl_finish_kernel"], "fl_fwd_kernel"),
     "a3d_flow_loss_bwd": (["fl_bwd_kernel"], "fl_bwd_kernel"),
 }
