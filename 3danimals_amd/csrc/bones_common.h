@@ -53,12 +53,27 @@ __device__ __forceinline__ void bn_rest(const float* __restrict__ bone, float R[
     t[0] = bone[0]; t[1] = bone[1]; t[2] = bone[2];
 }
 
-__device__ __forceinline__ void bn_euler(const float* __restrict__ ang, float Rot[9]) {  // Rx(x) Ry(y) Rz(z)
-    const float cx = cosf(ang[0]), sx = sinf(ang[0]), cy = cosf(ang[1]), sy = sinf(ang[1]), cz = cosf(ang[2]), sz = sinf(ang[2]);
+// sine / cosine of the three Euler angles of a link (sx, cx, sy, cy, sz, cz)
+struct BnTrig {
+    float sx, cx, sy, cy, sz, cz;
+};
+
+__device__ __forceinline__ BnTrig bn_trig(const float* __restrict__ ang) {
+    BnTrig t;
+    sincosf(ang[0], &t.sx, &t.cx);
+    sincosf(ang[1], &t.sy, &t.cy);
+    sincosf(ang[2], &t.sz, &t.cz);
+    return t;
+}
+
+__device__ __forceinline__ void bn_euler_from(const BnTrig& g, float Rot[9]) {  // Rx(x) Ry(y) Rz(z)
+    const float cx = g.cx, sx = g.sx, cy = g.cy, sy = g.sy, cz = g.cz, sz = g.sz;
     Rot[0] = cy * cz;                 Rot[1] = -cy * sz;                Rot[2] = sy;
     Rot[3] = sx * sy * cz + cx * sz;  Rot[4] = -sx * sy * sz + cx * cz; Rot[5] = -sx * cy;
     Rot[6] = -cx * sy * cz + sx * sz; Rot[7] = cx * sy * sz + sx * cz;  Rot[8] = cx * cy;
 }
+
+__device__ __forceinline__ void bn_euler(const float* __restrict__ ang, float Rot[9]) { bn_euler_from(bn_trig(ang), Rot); }
 
 __device__ __forceinline__ void bn_mat3(const float A[9], const float B[9], float C[9]) {
 #pragma unroll
@@ -67,10 +82,10 @@ __device__ __forceinline__ void bn_mat3(const float A[9], const float B[9], floa
         for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
 }
 
-__device__ __forceinline__ A34 bn_link(const float* __restrict__ bone, const float* __restrict__ ang) {
-    float R[9], t[3], Rot[9], T1[9], Lr[9];
-    bn_rest(bone, R, t);
-    bn_euler(ang, Rot);
+// the link of a bone from its rest frame (bn_rest) and the sines / cosines of its angles: [R Rot R^T | t - R Rot R^T t]
+__device__ __forceinline__ A34 bn_link_from(const float R[9], const float t[3], const BnTrig& g) {
+    float Rot[9], T1[9], Lr[9];
+    bn_euler_from(g, Rot);
     bn_mat3(R, Rot, T1);
     // Lr = T1 . R^T
 #pragma unroll
@@ -84,6 +99,12 @@ __device__ __forceinline__ A34 bn_link(const float* __restrict__ bone, const flo
         L.m[4 * r + 3] = t[r] - (Lr[3 * r] * t[0] + Lr[3 * r + 1] * t[1] + Lr[3 * r + 2] * t[2]);
     }
     return L;
+}
+
+__device__ __forceinline__ A34 bn_link(const float* __restrict__ bone, const float* __restrict__ ang) {
+    float R[9], t[3];
+    bn_rest(bone, R, t);
+    return bn_link_from(R, t, bn_trig(ang));
 }
 
 __device__ __forceinline__ void bn_store(float* __restrict__ dst, const A34& a) {
@@ -150,33 +171,41 @@ __device__ __forceinline__ void bn_link_adjoint(const float* g, const float* P, 
 // dL = [R dRot R^T | -(R dRot R^T) t].  With them the adjoint of a link is <P^T g S^T, dL_c>: 36 multiply-adds, no sin / cos, no
 // normalisation -- computed once per link by the forward (a3d_skin_pose_fwd) instead of once per (bone, chain position) pair and
 // work-group by the backward.
+// (one angle c of the three: 12 floats to out)
+__device__ __forceinline__ void bn_link_derivative_from(const float R[9], const float t[3], const BnTrig& g, int c, float* __restrict__ out) {
+    const float cx = g.cx, sx = g.sx, cy = g.cy, sy = g.sy, cz = g.cz, sz = g.sz;
+    float dR[9];
+    if (c == 0) {
+        dR[0] = 0.f; dR[1] = 0.f; dR[2] = 0.f;
+        dR[3] = cx * sy * cz - sx * sz; dR[4] = -cx * sy * sz - sx * cz; dR[5] = -cx * cy;
+        dR[6] = sx * sy * cz + cx * sz; dR[7] = -sx * sy * sz + cx * cz; dR[8] = -sx * cy;
+    } else if (c == 1) {
+        dR[0] = -sy * cz; dR[1] = sy * sz; dR[2] = cy;
+        dR[3] = sx * cy * cz; dR[4] = -sx * cy * sz; dR[5] = sx * sy;
+        dR[6] = -cx * cy * cz; dR[7] = cx * cy * sz; dR[8] = -cx * sy;
+    } else {
+        dR[0] = -cy * sz; dR[1] = -cy * cz; dR[2] = 0.f;
+        dR[3] = -sx * sy * sz + cx * cz; dR[4] = -sx * sy * cz - cx * sz; dR[5] = 0.f;
+        dR[6] = cx * sy * sz + sx * cz; dR[7] = cx * sy * cz - sx * sz; dR[8] = 0.f;
+    }
+    float T1[9];
+    bn_mat3(R, dR, T1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float lr[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lr[q] = T1[3 * r] * R[3 * q] + T1[3 * r + 1] * R[3 * q + 1] + T1[3 * r + 2] * R[3 * q + 2];  // (T1 . R^T)
+        out[4 * r] = lr[0]; out[4 * r + 1] = lr[1]; out[4 * r + 2] = lr[2];
+        out[4 * r + 3] = -(lr[0] * t[0] + lr[1] * t[1] + lr[2] * t[2]);
+    }
+}
+
 __device__ __forceinline__ void bn_link_derivatives(const float* __restrict__ bone, const float* __restrict__ ang, float* __restrict__ out) {
     float R[9], t[3];
     bn_rest(bone, R, t);
-    const float x = ang[0], y = ang[1], z = ang[2];
-    const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
-    const float dR[3][9] = {{0.f, 0.f, 0.f,
-                             cx * sy * cz - sx * sz, -cx * sy * sz - sx * cz, -cx * cy,
-                             sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy},
-                            {-sy * cz, sy * sz, cy,
-                             sx * cy * cz, -sx * cy * sz, sx * sy,
-                             -cx * cy * cz, cx * cy * sz, -cx * sy},
-                            {-cy * sz, -cy * cz, 0.f,
-                             -sx * sy * sz + cx * cz, -sx * sy * cz - cx * sz, 0.f,
-                             cx * sy * sz + sx * cz, cx * sy * cz - sx * sz, 0.f}};
+    const BnTrig g = bn_trig(ang);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float T1[9];
-        bn_mat3(R, dR[c], T1);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            float lr[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) lr[q] = T1[3 * r] * R[3 * q] + T1[3 * r + 1] * R[3 * q + 1] + T1[3 * r + 2] * R[3 * q + 2];  // (T1 . R^T)
-            out[12 * c + 4 * r] = lr[0]; out[12 * c + 4 * r + 1] = lr[1]; out[12 * c + 4 * r + 2] = lr[2];
-            out[12 * c + 4 * r + 3] = -(lr[0] * t[0] + lr[1] * t[1] + lr[2] * t[2]);
-        }
-    }
+    for (int c = 0; c < 3; ++c) bn_link_derivative_from(R, t, g, c, out + 12 * c);
 }
 
 // the same adjoint as bn_link_adjoint from the precomputed derivatives dL[3][12] of the link
@@ -280,20 +309,27 @@ static inline size_t bn_bwd_lds(int K, int D) { return sizeof(float) * ((size_t)
 // that finishes an image last is one parallel phase over the K*D (bone, position) pairs and the per-link sums -- ~3 us instead of ~10.
 // PS[K][D][2][12]: P_j and S_j of bone k's chain (identity for padded positions).
 __device__ __forceinline__ void bn_chain_products(const float (*s_L)[13], const int* s_chain, int K, int D, float* __restrict__ PS) {
+    // thread = (bone, direction).  The chain's link indices are read up front and padded positions multiply by the identity: with
+    // ``i = s_chain[..]; if (i >= 0) run = run . L[i]`` inside the loop every step was two dependent LDS round trips behind a branch
+    // (0.46 us per step -- this work-group was the last of its launch to finish)
     for (int w = threadIdx.x; w < 2 * K; w += blockDim.x) {
         const int k = w >> 1;
+        const bool suffix = w & 1;
+        int idx[BN_MAXD];
+#pragma unroll
+        for (int j = 0; j < BN_MAXD; ++j) idx[j] = j < D ? s_chain[k * D + j] : -1;
         A34 run = bn_identity();
-        if ((w & 1) == 0) {
-            for (int j = 0; j < D; ++j) {
-                bn_store(PS + ((long long)(k * D + j) * 2) * 12, run);
-                const int i = s_chain[k * D + j];
-                if (i >= 0) run = bn_mul(run, bn_load(s_L[i]));
-            }
-        } else {
-            for (int j = D - 1; j >= 0; --j) {
-                bn_store(PS + ((long long)(k * D + j) * 2 + 1) * 12, run);
-                const int i = s_chain[k * D + j];
-                if (i >= 0) run = bn_mul(bn_load(s_L[i]), run);
+#pragma unroll
+        for (int jj = 0; jj < BN_MAXD; ++jj) {
+            const int j = suffix ? D - 1 - jj : jj;  // (suffix: positions D-1 .. 0; idx[] is indexed with constants below)
+            if (jj < D) {
+                bn_store(PS + ((long long)(k * D + j) * 2 + (suffix ? 1 : 0)) * 12, run);
+                int i = -1;
+#pragma unroll
+                for (int q = 0; q < BN_MAXD; ++q) i = q == j ? idx[q] : i;
+                A34 L = bn_load(s_L[i >= 0 ? i : 0]);
+                if (i < 0) L = bn_identity();
+                run = suffix ? bn_mul(L, run) : bn_mul(run, L);
             }
         }
     }
@@ -307,14 +343,17 @@ __host__ __device__ static inline size_t bn_products_floats(int K, int D) { retu
 // g_angles (zero on entry): the adjoint is linear in g_M, so the sum over the work-groups of adjoint(share) is adjoint(sum) and no
 // work-group has to wait for the others.  PS / dL: the precomputed products and link derivatives of this image.
 __device__ __forceinline__ void bn_chain_adjoint_ps(const float* g_M, const float* __restrict__ PS, const float* __restrict__ dL,
-                                                    const int* __restrict__ chain, int K, int D, float* __restrict__ g_angles, float* s_mem) {
+                                                    const int* __restrict__ chain, int K, int D, float* __restrict__ g_angles, float* s_mem,
+                                                    int chain_of_thread = -2) {
+    // chain_of_thread (optional): chain[threadIdx.x], loaded by the caller long before (-2: not given) -- the rows of PS / dL below hang on
+    // it, and a load issued here is a round trip of its own in front of theirs
     float (*s_c)[3] = (float (*)[3])s_mem;       // [K*D][3]
     int* s_chain = (int*)(s_mem + 3 * K * D);    // [K*D]
     int* s_pos = s_chain + K * D;                // [K*K]
     for (int w = threadIdx.x; w < K * K; w += blockDim.x) s_pos[w] = -1;
     __syncthreads();
     for (int w = threadIdx.x; w < K * D; w += blockDim.x) {
-        const int k = w / D, i = chain[w];
+        const int k = w / D, i = (chain_of_thread != -2 && w == (int)threadIdx.x) ? chain_of_thread : chain[w];
         s_chain[w] = i;
         float gx = 0.f, gy = 0.f, gz = 0.f;
         if (i >= 0) {
