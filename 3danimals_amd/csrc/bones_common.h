@@ -111,6 +111,14 @@ __device__ __forceinline__ void bn_store(float* __restrict__ dst, const A34& a) 
 #pragma unroll
     for (int q = 0; q < 12; ++q) dst[q] = a.m[q];
 }
+// (16-byte aligned destination: three 16-byte stores instead of twelve scalar ones -- a scattered store costs its lane a line request
+// whatever its width)
+__device__ __forceinline__ void bn_store16(float* __restrict__ dst, const A34& a) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    d[0] = make_float4(a.m[0], a.m[1], a.m[2], a.m[3]);
+    d[1] = make_float4(a.m[4], a.m[5], a.m[6], a.m[7]);
+    d[2] = make_float4(a.m[8], a.m[9], a.m[10], a.m[11]);
+}
 __device__ __forceinline__ A34 bn_load(const float* __restrict__ src) {
     A34 a;
 #pragma unroll
@@ -323,7 +331,7 @@ __device__ __forceinline__ void bn_chain_products(const float (*s_L)[13], const 
         for (int jj = 0; jj < BN_MAXD; ++jj) {
             const int j = suffix ? D - 1 - jj : jj;  // (suffix: positions D-1 .. 0; idx[] is indexed with constants below)
             if (jj < D) {
-                bn_store(PS + ((long long)(k * D + j) * 2 + (suffix ? 1 : 0)) * 12, run);
+                bn_store16(PS + ((long long)(k * D + j) * 2 + (suffix ? 1 : 0)) * 12, run);  // (PS: 16-byte aligned, a3d_skin_pose_fwd checks)
                 int i = -1;
 #pragma unroll
                 for (int q = 0; q < BN_MAXD; ++q) i = q == j ? idx[q] : i;

@@ -450,13 +450,13 @@ extern "C" int a3d_skin_pose_fwd(const float* v, int v_batch, const float* bones
     A3D_CHECK_ARG(v && bones && angles && chain && out && T_out);
     A3D_CHECK_ARG(B > 0 && V > 0 && K > 0 && K <= 20 && D > 0 && D <= BN_MAXD && temperature > 0.f);
     A3D_CHECK_ARG((v_batch == 1 || v_batch == B) && (bones_batch == 1 || bones_batch == B));
+    A3D_CHECK_ARG(((uintptr_t)chain_products_or_null & 15) == 0);  // (its 3x4 blocks are written 16 bytes at a time; an image's share is a multiple of 16 bytes)
     // (g_angles[B,K,3] of the backward, which accumulates into it: cleared here, one memset less on the backward path)
     // 64-vertex groups (four lanes per vertex), as many per work-group as leave ~1024 work-groups in the launch: every work-group
     // composes its image's chains itself (~900 instructions in its first wave), and the launch is bound by the instructions it issues
     // -- B = 16: V = 6k one group per work-group 11.8 us, two 9.6, three 10.5; V = 24k three 23.6, six 22.6, twelve 27.0
     const int ngroups = a3d_div_up(V, SK_THREADS / 4);
-    const int target = a3d_exp() == 51 ? 768 : (a3d_exp() == 52 ? 512 : (a3d_exp() == 54 ? 1536 : 1024));
-    int groups = a3d_exp() == 55 ? a3d_div_up(ngroups, 128) : (int)a3d_div_up((long long)ngroups * B, target);
+    int groups = (int)a3d_div_up((long long)ngroups * B, 1024);
     if (groups < 1) groups = 1;
     const dim3 grid(a3d_div_up(ngroups, groups) + (chain_products_or_null ? 1 : 0), B), block(SK_THREADS);  // (+ the products work-group)
     const int ncl = g_angles_to_clear_or_null ? B * K * 3 : 0;

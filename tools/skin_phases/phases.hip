@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
         report(name, st, n_wg, phase, n_stamps);
     };
     {
-        const int ngroups = (V + 63) / 64, groups = (ngroups + 127) / 128;
+        const int ngroups = (V + 63) / 64, groups = std::max(1, (int)(((long long)ngroups * B + 1023) / 1024));  // (a3d_skin_pose_fwd's rule)
         const int gx = (ngroups + groups - 1) / groups + 1;
         static const char* const ph[] = {"", "links + bones into LDS (-> barrier)", "chain products (thread 0's bone)", "barrier (all chains done)", "", "logits, softmax, blend, store"};
         // (stamp 4 is unused in the forward: 3 -> 5 is reported under slot 5 by copying 3 into 4 below)
