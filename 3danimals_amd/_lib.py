@@ -7,7 +7,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liba3d_hip.so")
+# (A3D_LIB: another build of the same ABI -- tools/kernel_phases.py points it at the instrumented liba3d_hip_prof.so)
+LIB_PATH = os.environ.get("A3D_LIB") or os.path.join(_HERE, "lib", "liba3d_hip.so")
 
 _c_int, _c_float, _c_size_t, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 

@@ -40,6 +40,40 @@ static inline int a3d_div_up(long long a, long long b) { return (int)((a + b - 1
 int a3d_exp(void);
 
 #ifdef __HIPCC__
+// ---- phase stamps inside kernels (tools/kernel_phases.py; the library proper is built WITHOUT them: build.py --profile makes a second,
+// instrumented liba3d_hip_prof.so).  A3D_STAMP(kernel id within the TU, slot 0..7): thread 0 of every work-group writes the 100 MHz wall
+// clock to buf[work-group][slot] when the TU's active kernel id is that one; A3D_STAMP_CLOCK the shader clock (for the frequency the
+// launch ran at).  A3D_PROFILE_TU(name) defines the TU's setter a3d_profile_set_<name>(buf, kid).  What this is for: every hot-path
+// kernel here is bound by dependent round trips, barriers or the instructions of its longest-lived work-group, not by bytes, and the
+// counters say so only in aggregate -- the stamps say which phase of which work-group.
+#ifdef A3D_PROFILE
+static __device__ unsigned long long* a3d_prof_buf;
+static __device__ int a3d_prof_kid = -1;
+#define A3D_PROF_MAX_WG 65536
+#define A3D_STAMP_(kid, slot, what)                                                                                              \
+    do {                                                                                                                         \
+        if (a3d_prof_kid == (kid) && threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {                                 \
+            const size_t wg_ = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);                   \
+            if (wg_ < A3D_PROF_MAX_WG) a3d_prof_buf[wg_ * 8 + (slot)] = what;                                                    \
+        }                                                                                                                        \
+    } while (0)
+#define A3D_STAMP(kid, slot) A3D_STAMP_(kid, slot, wall_clock64())
+#define A3D_STAMP_CLOCK(kid, slot) A3D_STAMP_(kid, slot, clock64())
+#define A3D_PROFILE_TU(tu)                                                                                                       \
+    extern "C" int a3d_profile_set_##tu(void* buf, int kid) {                                                                    \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(a3d_prof_buf), &buf, sizeof(buf)) != hipSuccess) return A3D_EHIP;                       \
+        return hipMemcpyToSymbol(HIP_SYMBOL(a3d_prof_kid), &kid, sizeof(kid)) == hipSuccess ? A3D_OK : A3D_EHIP;                 \
+    }
+#else
+#define A3D_STAMP(kid, slot) \
+    do {                     \
+    } while (0)
+#define A3D_STAMP_CLOCK(kid, slot) \
+    do {                           \
+    } while (0)
+#define A3D_PROFILE_TU(tu)
+#endif
+
 // lanes below me in the wave that have the bit set: ballot + mbcnt (wave64)
 __device__ __forceinline__ int a3d_lane_id() { return (int)__lane_id(); }
 

@@ -420,6 +420,7 @@ struct CaJob {
 // of its own the analysis is 15 us of kernel plus a launch gap, here it adds ~5.
 __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an, int extra_first) {
     __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = ca_compose_kernel, 1 = ca_blend_kernel, 2 = ca_gather_kernel, 3 = ca_bwd_kernel)
     // (extra_first: the analysis work-groups -- gather chains -- are dispatched BEFORE the pixel movers of their row, not as the launch's tail)
     unsigned bx = blockIdx.x;
     if (extra_first) {
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         if (j >= total) return;
         const unsigned b = j / (2u * nbx), r = j - b * 2u * nbx;
         aa_analyze_body(an, r % nbx, (int)(r / nbx), (int)b);
+        A3D_STAMP(0, 4);  // (analysis work-groups end at slot 4, pixel movers at slot 5)
         return;
     }
     const CaJob& job = blockIdx.y ? jb : ja;
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
         v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
         __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out) + p);
+        A3D_STAMP(0, 5);
         return;
     }
     const int C1 = s.C + 1;
@@ -487,15 +490,18 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         else if (src <= -2) v = s.bg[(long long)(-2 - src) * C1 + c];
         o[j] = v;
     }
+    A3D_STAMP(0, 5);
 }
 
 __global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const AaRec* __restrict__ work, const int* __restrict__ count,
                                                        int capacity, int W) {
     __shared__ int s_off[AA_SHARDS + 1];
+    A3D_STAMP(1, 0);
     const CaJob& job = blockIdx.y ? jb : ja;
     const CaSrc& s = job.s;
     float* __restrict__ out = job.out;
     const int n = aa_segment_offsets(count, capacity, s_off);
+    A3D_STAMP(1, 1);
     const unsigned C1 = (unsigned)s.C + 1u;
     const unsigned total = (unsigned)n * C1;  // (n <= capacity records, C1 <= 4096)
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const
         const float d = ca_pre(s, p1, c) - ca_pre(s, p0, c);
         if (d != 0.f) atomicAdd(out + (long long)dst * C1 + c, rec.alpha * d);
     }
+    A3D_STAMP(1, 5);
 }
 
 // g_vals[p, :C] = g_out[pix[p], :C] (the select's adjoint), 256 points per work-group (same index arithmetic as the compositor); the
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const
 __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, const long long* __restrict__ pix, long long P,
                                                         float* __restrict__ zero, long long nz) {
     __shared__ unsigned s_pix[256];
+    A3D_STAMP(2, 0);
     const CaJob& job = blockIdx.y ? jb : ja;
     const int C = job.s.C;
     const float* __restrict__ g_out = job.g_out;
@@ -522,6 +530,7 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, cons
     if (blockIdx.y == 0)
         for (long long i = p; i < nz; i += (long long)gridDim.x * 256) zero[i] = 0.f;
     __syncthreads();
+    A3D_STAMP(2, 1);
     if (base >= P) return;
     const int nloc = (int)min(256ll, P - base) * C, C1 = C + 1;
     const float rc = 1.f / (float)C;
@@ -540,6 +549,7 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, cons
         for (int k = 0; k < 4; ++k)
             if (j0 + 256 * k < nloc) o[j0 + 256 * k] = v[k];
     }
+    A3D_STAMP(2, 5);
 }
 
 // aa_bwd_kernel on the composited image: colours come from the sources, colour adjoints go to the point rows
@@ -547,11 +557,13 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
                                                      int capacity, const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
                                                      int V, int H, int W, float* __restrict__ g_clip) {
     __shared__ int s_off[AA_SHARDS + 1];
+    A3D_STAMP(3, 0);
     const CaJob& job = blockIdx.y ? jb : ja;
     const CaSrc& s = job.s;
     const float* __restrict__ g_out = job.g_out;
     float* __restrict__ g_vals = job.g_vals;
     const int n = aa_segment_offsets(count, capacity, s_off);
+    A3D_STAMP(3, 1);
     const float xh = 0.5f * W, yh = 0.5f * H;
     const int C = s.C, C1 = s.C + 1;
     const int sub = threadIdx.x & 31, groups = (gridDim.x * blockDim.x) >> 5;
@@ -578,6 +590,7 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
         if (sub != 0 || clamped || dd == 0.f) continue;
         aa_edge_adjoint(rec, p0, d, di, use1, dd, clip, clip_batch, tri, V, H, W, xh, yh, g_clip);
     }
+    A3D_STAMP(3, 5);
 }
 
 extern "C" size_t a3d_aa_hash_bytes(int F) { return (size_t)aa_slots(F < 1 ? 1 : F) * (8 + 4 * AA_VALS); }
@@ -821,3 +834,5 @@ extern "C" int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, con
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(antialias)

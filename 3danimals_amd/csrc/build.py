@@ -1,6 +1,6 @@
 """Build liba3d_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python 3danimals_amd/csrc/build.py [--force]
+    python 3danimals_amd/csrc/build.py [--force] [--profile]
 
 One object per .hip file, linked into 3danimals_amd/lib/liba3d_hip.so (in-tree, git-ignored, travels to the
 GPU box with the snapshot).  raster/dmtet/antialias/normals are compiled with -ffp-contract=off: their arithmetic is
@@ -53,19 +53,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, profile=False):
+    """profile: the instrumented twin liba3d_hip_prof.so (-DA3D_PROFILE: phase stamps inside the kernels, a3d_common.h) that
+    tools/kernel_phases.py loads instead of the library; never loaded by the package on its own."""
+    lib = os.path.join(LIB_DIR, "liba3d_hip_prof.so") if profile else LIB
+    obj_dir = os.path.join(OBJ_DIR, "prof") if profile else OBJ_DIR
     os.makedirs(LIB_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(HERE, "topo_common.h"), os.path.join(HERE, "raster_common.h"), os.path.join(HERE, "cover_common.h"), os.path.join(HERE, "bones_common.h"), os.path.join(HERE, "normals_common.h"), os.path.join(HERE, "shade_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra)
+            jobs.append([hipcc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra + (["-DA3D_PROFILE"] if profile else []))
 
     def run(cmd):
         if verbose:
@@ -74,10 +78,10 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, profile="--profile" in sys.argv))

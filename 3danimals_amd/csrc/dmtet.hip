@@ -60,6 +60,7 @@ __device__ __forceinline__ bool dm_edge_cross(const void* __restrict__ src, int2
 #define DM_SIGN_WORDS 4
 __global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits,
                                                       int* __restrict__ list_len) {
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = dm_sign_kernel, 1 = dm_count_cull_kernel, 3 = dm_emit_kernel, 4 = dm_bwd_kernel)
     const int lane = threadIdx.x & 63;
     if (list_len && blockIdx.x == 0 && threadIdx.x < 2) list_len[16 * threadIdx.x] = 0;  // (the two append counters of the count launch)
     const long long w0 = ((long long)blockIdx.x * (256 / 64) + (threadIdx.x >> 6)) * DM_SIGN_WORDS;  // first word of this wave
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ 
         const unsigned long long m = __ballot((w0 + j) * 64 + lane < Nv && x[j] > 0.f);
         if (lane == 0 && (w0 + j) * 64 < Nv) bits[w0 + j] = m;
     }
+    A3D_STAMP(0, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ count
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
     __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
     __shared__ unsigned s_vwin[DM_VWIN];
+    A3D_STAMP(1, 0);
     // SLOTS = 8 (grids numbered along their rows: the Kuhn grids) or 16 (round 4: spatially coherent files whose words touch more groups
     // -- a BCC lattice in its generator's order: 10-13 -- at 64 instead of 32 bytes of table per word)
     constexpr int WPB = DM_BLOCK_ITEMS / 64, WPR = 64 / SLOTS, ROUNDS = (G * DM_SLABS * SLOTS + 63) / 64;
@@ -290,10 +293,12 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
         for (int b = 0; b < WPR; ++b)
             if (((z >> (SLOTS * b)) & M) == M || ((o >> (SLOTS * b)) & M) == M) skip |= 1u << (WPR * r + b);
     }
+    A3D_STAMP(1, 1);
     if (lane < G) s_nib[lane][wave] = (skip >> (DM_SLABS * lane)) & 15u;
     if (vbits && is_edge)
         for (int i = tid; i < DM_VWIN; i += DM_THREADS) s_vwin[i] = 0u;
     __syncthreads();
+    A3D_STAMP(1, 2);
     bool lds_used = false;
     for (int g = 0; g < G; ++g) {
         const int blk = first + g * step;
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
         dm_count_block<true>(sign, edges, tets, Ne, Nt, is_edge, blk, (skip >> (DM_SLABS * g)) & 15u, blk_e, blk_t1, blk_t2, edge_bits, tet_bits,
                              wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist, s_vwin);
     }
+    A3D_STAMP(1, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ count, grid in any numbering
@@ -719,6 +725,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              int n_tblocks, int nvc, const int* __restrict__ dev_counts, int cap_V,
                                                              int cap_F, int cap_surf) {
     __shared__ int s_pre[32];
+    A3D_STAMP(3, 0);  // (only work-groups that reach a stage stamp it: most leave at one of the early exits)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // SPECULATIVE launch (dev_counts = the counts of a3d_dmtet_count, still on the device: the host has not read them yet and sized
     // buffers and grid by a guess): the sizes come from there; if anything does not fit, NO work-group touches anything and the host,
@@ -735,6 +742,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     }
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
     for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
+    A3D_STAMP(3, 1);
     // wg_per_block = 4: one SLAB (256 items) per work-group -- a slab is a chain of three dependent gathers (bit planes -> index row ->
     // vertex ids), and four of them in series per work-group made the launch pure latency at the bench size (16 us for ~1 MB; four
     // times the work-groups overlap them: 12.8 us).  wg_per_block = 1: all four slabs in one work-group, for grids whose block count
@@ -802,6 +810,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
         const long long slot = (n == 1u) ? (long long)(run1 + a3d_wave_prefix(m1)) : (long long)n1 + 2ll * (run2 + a3d_wave_prefix(m2));
         dm_write_faces(t, cs, n, slot, tet2edge, edge_bits, wlocal, blk_e, faces, uv_idx, tri32, topo_cnt, topo_adj, topo_stride, F);
     }
+    A3D_STAMP(3, 5);
 }
 
 // The emit launch for SPARSE planes (the ordered count pass: the ~1 % surface items of a grid in a random numbering are spread evenly
@@ -903,6 +912,7 @@ __global__ __launch_bounds__(256) void dm_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ sdf, const int2* __restrict__ edges,
                                                      const int* __restrict__ vert_edge, int V, float* __restrict__ g_pos,
                                                      float* __restrict__ g_sdf) {
+    A3D_STAMP(4, 0);
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     int2 e = edges[vert_edge[v]];
@@ -921,6 +931,7 @@ __global__ __launch_bounds__(256) void dm_bwd_kernel(const float* __restrict__ g
         atomicAdd(g_pos + 3ll * e.x + 0, gx * wa); atomicAdd(g_pos + 3ll * e.x + 1, gy * wa); atomicAdd(g_pos + 3ll * e.x + 2, gz * wa);
         atomicAdd(g_pos + 3ll * e.y + 0, gx * wb); atomicAdd(g_pos + 3ll * e.y + 1, gy * wb); atomicAdd(g_pos + 3ll * e.y + 2, gz * wb);
     }
+    A3D_STAMP(4, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -1170,3 +1181,5 @@ extern "C" int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float
     }
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(dmtet)

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
                                                            float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
     __shared__ int wave_n[4];
     __shared__ int s_off;
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = gb_cover_fwd_kernel, 1 = gb_bwd_kernel)
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     for (long long z = k; z < n_zero4; z += (long long)gridDim.x * 256) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long flat = k < n ? cv_flat(k, H, W, 8) : 0;
@@ -126,8 +127,10 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
     const unsigned long long m = __ballot(on);
     if ((threadIdx.x & 63) == 0) wave_n[wave] = __popcll(m);
     __syncthreads();
+    A3D_STAMP(0, 1);
     if (!on) {
         if (inv && k < n) inv[flat] = -1;
+        A3D_STAMP(0, 5);
         return;
     }
     int o = s_off + a3d_wave_prefix(m);
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
     pix[o] = flat;
     if (inv) inv[flat] = o;
     gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out);
+    A3D_STAMP(0, 5);
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     __shared__ int s_used[GB_SLOTS];   // claimed slots, in claim order
     __shared__ float s_stage[GB_ENTRIES * ST];
     __shared__ int s_n[2];             // staged entries, used slots
+    A3D_STAMP(1, 0);
     for (int i = threadIdx.x; i < GB_SLOTS; i += blockDim.x) { s_key[i] = -1; s_head[i] = -1; }
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         }
         gb_pixel_adjoint<NC>(t, p0, p1, p2, r.x, r.y, g, px, py, H, W, want_clip, acc, ex, ge);
     }
+    A3D_STAMP(1, 1);
     // neighbouring list entries on the same triangle of the same image: the even lane takes the odd lane's sums, a third fewer entries
     const int tkey = live ? b * F + f : -1 - (int)threadIdx.x;  // (B*F < 2^31 is checked by the entry point)
     const int tkey1 = gb_xor1(tkey);
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     }
     // stage: each (pixel, corner) row goes to LDS with plain stores and is linked into the list of its vertex (one integer exchange);
     // entries are handed out per wave (one counter update per wave, not per lane)
+    A3D_STAMP(1, 2);
     const unsigned long long amask = __ballot(active);
     int wbase = 0;
     if (a3d_lane_id() == 0 && amask) wbase = atomicAdd(&s_n[0], 3 * __popcll(amask));
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         }
     }
     __syncthreads();
+    A3D_STAMP(1, 3);
     // the claimed slots, compacted (ballot + one counter update per wave)
     for (int sidx = threadIdx.x; sidx < GB_SLOTS; sidx += blockDim.x) {
         const bool used = s_key[sidx] >= 0;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     // reduce + flush: 16 lanes per vertex, lane = component, so the twelve atomics of a vertex are ONE 64-byte line request
     // (line-coalesced device atomics are ~10x cheaper than the same number of scattered ones, see the header); two vertices in
     // flight per group so that the list walks (one LDS round trip per entry) overlap
+    A3D_STAMP(1, 4);
     const int n_used = s_n[1];
     const int k = threadIdx.x & 15, kk = k < NC ? k : ST - 1;
     const bool lane_on = gb_comp_on(k, NC, want_prior != 0, want_clip);
@@ -414,6 +423,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
             if (slot_b >= 0) atomicAdd(g_rows + (long long)GB_ROW * s_key[slot_b] + gb_col(k), sum_b);
         }
     }
+    A3D_STAMP(1, 5);
 }
 
 extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
@@ -494,3 +504,5 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(gbuffer)

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void nr_bwd_kernel(const float* __restrict__ g
 __global__ __launch_bounds__(256) void nr_face_bwd_kernel(const float* __restrict__ g_nrm, int g_stride, const float* __restrict__ acc,
                                                           const float* __restrict__ v, const int* __restrict__ tri, int V, int F,
                                                           float* __restrict__ fadj) {
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = nr_face_bwd_kernel, 1 = nr_sum_bwd_kernel)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const long long vb = (long long)blockIdx.y * V;
@@ -176,10 +177,12 @@ __global__ __launch_bounds__(256) void nr_face_bwd_kernel(const float* __restric
         nr_bwd_entry(c, g0, g1, g2, p0, p1, p2, ox, oy, oz);
         o[3 * c] = ox; o[3 * c + 1] = oy; o[3 * c + 2] = oz;
     }
+    A3D_STAMP(0, 5);
 }
 
 __global__ __launch_bounds__(256) void nr_sum_bwd_kernel(const float* __restrict__ fadj, const int* __restrict__ off, const int* __restrict__ adj,
                                                          int V, int F, float* __restrict__ g_v, int stride) {
+    A3D_STAMP(1, 0);
     const int vi = blockIdx.x * blockDim.x + threadIdx.x;
     if (vi >= V) return;
     const float* fa = fadj + (long long)blockIdx.y * F * 9;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void nr_sum_bwd_kernel(const float* __restrict
     }
     const long long o = ((long long)blockIdx.y * V + vi) * 3;
     g_v[o] = ox; g_v[o + 1] = oy; g_v[o + 2] = oz;
+    A3D_STAMP(1, 5);
 }
 
 }  // namespace
@@ -287,3 +291,5 @@ extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(normals)

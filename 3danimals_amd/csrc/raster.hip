@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
                                                      const int* __restrict__ topo_off, const int* __restrict__ topo_adj,
                                                      int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj, int extra_first) {
     const int b = blockIdx.y;
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = rs_tri_kernel -- triangle work-groups only stamp 1..5 --, 1 = rs_resolve_kernel)
     // the riding jobs (dependent-gather chains: vertex normals, opposite-vertex table, screen positions) are DISPATCHED FIRST (extra_first):
     // their round trips then run under the triangle work instead of as the launch's tail.  bx = the work-group's index in the order the
     // branches below are written in (triangles first).
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         if (lane == 0) s_pre[wv][0] = 0;
     }
     __syncthreads();
+    A3D_STAMP(0, 1);
     // candidate c of the work-group: first the wave slice (three compares on the four totals), then the slot inside it
     const int t0 = s_pre[0][TPW], t1 = t0 + s_pre[1][TPW], t2 = t1 + s_pre[2][TPW], total = t2 + s_pre[3][TPW];
     for (int c = threadIdx.x; c < total; c += 256) {
@@ -252,9 +254,11 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     // lane), tested, and the pixels of the surviving tiles pooled in turn -- per chunk of RS_TILE_CHUNK tiles, so that the survivor
     // list lives in 2 KB of LDS.  (One big box after the other, each with its own barriers, made a work-group whose 64 neighbouring
     // triangles are all big -- a spike of the drifted mesh -- slower than walking their boxes: 152 against 109 us.)
+    A3D_STAMP(0, 2);
     if (sub == 0 && big) s_big[atomicAdd(&s_nbig, 1)] = (unsigned short)((wv << 8) | q);  // (LDS; s_nbig was zeroed before the barrier above)
     __syncthreads();
     const int nbig = s_nbig;
+    A3D_STAMP(0, 5);  // (work-groups with big boxes go on: their end is not stamped)
     if (nbig == 0) return;  // (uniform)
     {   // exclusive prefix of the tile counts over the list (nbig <= 256: one entry per thread)
         int cnt = 0;
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
                                                          int H, int W, unsigned long long* __restrict__ keys,
                                                          float4* __restrict__ rast, int* __restrict__ cover_block_count) {
     __shared__ int s_wave[4];
+    A3D_STAMP(1, 0);
     const unsigned hw = (unsigned)H * (unsigned)W;
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_frame = k < hw;
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
             if (c) atomicAdd(cover_block_count + (long long)gridDim.x * gridDim.y + (long long)(blk / A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, c);
         }
     }
+    A3D_STAMP(1, 5);
 }
 
 // backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; FOUR lanes per pixel, lane = component of the 16-byte gradient
@@ -516,3 +522,5 @@ extern "C" int a3d_rast_bwd(const float* g_rast, const float* rast, const float*
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(raster)

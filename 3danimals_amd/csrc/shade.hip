@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ kd, int kd_stride, long long P, int two_sided,
                                                      float* __restrict__ g_gb, float* __restrict__ g_par, float* __restrict__ g_kd) {
     __shared__ float s_red[16][17];
+    A3D_STAMP(0, 0);  // (A3D_STAMP kernel id 0 = sh_bwd_kernel)
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < P;
     // the images this work-group's points belong to: img[first] .. img[last] (one, except at the ~B image boundaries of the list) -- read
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
         go[2] = make_float4(g_a.z, 0.f, 0.f, 0.f);
         gp[9] = g_d.x; gp[10] = g_d.y; gp[11] = g_d.z;
     }
+    A3D_STAMP(0, 1);
     if (!img) {
         if (live) {
             float* gpr = g_par + (long long)ncol * p;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ g
         }
         __syncthreads();
     }
+    A3D_STAMP(0, 5);
 }
 
 }  // namespace
@@ -166,3 +169,5 @@ extern "C" int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const f
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(shade)

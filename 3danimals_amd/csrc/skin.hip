@@ -12,24 +12,7 @@
 #define SK_THREADS 256
 #define SK_MAXK 64
 
-// tools/skin_phases (a stand-alone harness that includes this file with SK_PROFILE defined): thread 0 of every work-group stamps the
-// 100 MHz wall clock at the phase boundaries below.  The library is built without it.
-#ifdef SK_PROFILE
-__device__ unsigned long long* sk_prof;  // [work-groups of the launch][8]
-#define SK_STAMP(slot)                                                                                                              \
-    do {                                                                                                                            \
-        if (sk_prof && threadIdx.x == 0) {                                                                                          \
-            unsigned long long* p_ = sk_prof + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;                                   \
-            p_[slot] = wall_clock64();                                                                                              \
-            if ((slot) == 0) p_[6] = clock64();  /* shader clock at the first and the last stamp: the frequency the launch ran at */ \
-            if ((slot) == 5) p_[7] = clock64();                                                                                     \
-        }                                                                                                                           \
-    } while (0)
-#else
-#define SK_STAMP(slot) \
-    do {               \
-    } while (0)
-#endif
+// A3D_STAMP (a3d_common.h; tools/skin_phases, tools/kernel_phases.py): kernel ids of this file: 0 = sk_fwd_kernel, 1 = sk_bwd_kernel.
 
 struct SkBone {
     float ax, ay, az, dx, dy, dz, inv_len2;
@@ -81,7 +64,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     __shared__ SkBone s_bone[SK_MAXK];
     __shared__ float s_T[SK_MAXK * 12];
     const int b = blockIdx.y;
-    SK_STAMP(0);
+    A3D_STAMP(0, 0);
+    A3D_STAMP_CLOCK(0, 6);
     // the backward's per-image transform gradient (accumulated there with atomics) cleared here: one memset less on the backward path
     for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; z < n_clear; z += gridDim.x * gridDim.y * blockDim.x) clear[z] = 0.f;
     __shared__ float s_L[POSE ? SK_MAXK : 1][13];
@@ -122,14 +106,14 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
         sk_stage(bb, T + (long long)b * K * 12, K, s_bone, s_T);
     }
     __syncthreads();
-    SK_STAMP(1);
+    A3D_STAMP(0, 1);
     if (POSE) {
         // one EXTRA work-group per image (the last one; no vertices) leaves the prefix / suffix products of every chain position for the
         // backward (bn_chain_adjoint_ps).  Inside a vertex work-group those 2K serial product chains sat in front of a barrier all
         // 256 threads wait at, and that work-group was the slowest of its image
         if (products_wg) {
             bn_chain_products(s_L, s_chain, K, D, PS + (long long)b * bn_products_floats(K, D));
-            SK_STAMP(5);
+            A3D_STAMP(0, 5);
             return;
         }
         // the K chain products, FOUR lanes per bone (lane c keeps column c of the running product: 3 values; the other columns come
@@ -169,7 +153,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
                 To[c] = r0; To[4 + c] = r1; To[8 + c] = r2;
             }
         }
-        SK_STAMP(2);
+        A3D_STAMP(0, 2);
     }
     // ``groups`` consecutive 64-vertex groups per work-group: 1 at the bench size; more for large meshes, where a work-group per 64
     // vertices would repeat the chain composition above thousands of times (R = 128 grid: 374 work-groups per image)
@@ -195,7 +179,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
     // (the logits of the first group only need the bones: they run beside the chain products above, and the one barrier both wait at is here)
     if (POSE && gi == 0) {
         __syncthreads();  // s_T complete (the blend below only reads it)
-        SK_STAMP(3);
+        A3D_STAMP(0, 3);
     }
     float s = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
 #pragma unroll
@@ -231,7 +215,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_fwd_kernel(const float* __restr
         }
     }
     }
-    SK_STAMP(5);
+    A3D_STAMP(0, 5);
+    A3D_STAMP_CLOCK(0, 7);
 }
 
 // ---- backward, one kernel, two phases per 256-vertex chunk.
@@ -261,7 +246,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
     __shared__ float s_w[4 * KG][SK_THREADS + 4];
     __shared__ float s_x[6][SK_THREADS + 4];  // px py pz gx gy gz
     const int b = blockIdx.y;
-    SK_STAMP(0);
+    A3D_STAMP(1, 0);
+    A3D_STAMP_CLOCK(1, 6);
     const float* vb = v + (v_batch == 1 ? 0ll : (long long)b * V * 3);
     const float* gb = g_out + (long long)b * V * 3;
     // this work-group's vertices [lo, hi), 256 at a time (the last trip may be partial)
@@ -359,10 +345,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        SK_STAMP(1);
+        A3D_STAMP(1, 1);
         matrix_phase();
     }
-    SK_STAMP(2);
+    A3D_STAMP(1, 2);
     // the four waves' tiles meet in LDS (lane l, register r of a tile = bone 4 (l / 16) + r, column l % 16), and thread (bone, component)
     // adds the block's total to g_T: consecutive threads -> consecutive floats, i.e. the block's K*12 atomics are K*12/16 line requests
     // (line-coalesced device atomics are ~10x cheaper than scattered ones)
@@ -372,7 +358,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_red[wave][16 * tI + 4 * mk + r][mi] = acc[tI][r];
     __syncthreads();
-    SK_STAMP(3);
+    A3D_STAMP(1, 3);
     __shared__ float s_gT[POSE ? 4 * KG * 12 : 1];  // POSE: this work-group's share of g_T[b]
     for (int t = threadIdx.x; t < K * 12; t += SK_THREADS) {
         const int k = t / 12, q = t - 12 * k;
@@ -388,11 +374,12 @@ __global__ __launch_bounds__(SK_THREADS) void sk_bwd_kernel(const float* __restr
     if (POSE) {
         __shared__ float s_adj[POSE ? 4 * 20 * BN_MAXD + 20 * 20 : 1];
         __syncthreads();
-        SK_STAMP(4);
+        A3D_STAMP(1, 4);
         const float* ps = PS + (long long)b * bn_products_floats(K, D);
         bn_chain_adjoint_ps(s_gT, ps, ps + (long long)K * D * 24, chain, K, D, g_angles + (long long)b * K * 3, s_adj, my_chain);
     }
-    SK_STAMP(5);
+    A3D_STAMP(1, 5);
+    A3D_STAMP_CLOCK(1, 7);
 }
 
 extern "C" int a3d_skin_fwd(const float* v, int v_batch, const float* bones, int bones_batch, const float* T, int B, int V, int K,
@@ -499,3 +486,5 @@ extern "C" int a3d_skin_pose_bwd(const float* g_out, const float* v, int v_batch
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(skin)

@@ -1,8 +1,9 @@
 // Where the microseconds of the two skinning launches go: a stand-alone harness (no Python, no torch) that compiles csrc/skin.hip with
-// SK_PROFILE -- thread 0 of every work-group stamps the 100 MHz wall clock at the phase boundaries -- and runs a3d_skin_pose_fwd /
+// A3D_PROFILE (a3d_common.h: thread 0 of every work-group stamps the 100 MHz wall clock at the phase boundaries; tools/kernel_phases.py
+// does the same for every kernel of the library inside the real step) and runs a3d_skin_pose_fwd /
 // a3d_skin_pose_bwd at the bench size (B = 16, V = 5928, K = 20 bones, chains of <= 8 links) or the one given on the command line.
 //
-//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSK_PROFILE -I include -I 3danimals_amd/csrc tools/skin_phases/phases.hip \
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -DA3D_PROFILE -I include -I 3danimals_amd/csrc tools/skin_phases/phases.hip \
 //           3danimals_amd/csrc/common.hip -o gpurun_out/skin_phases && gpurun_out/skin_phases [B V K D]
 //
 // Prints, per launch: the event-timed duration without stamps (mean of 200), the spread of the work-groups' start times, and for
@@ -122,16 +123,15 @@ int main(int argc, char** argv) {
     const int max_wg = 1 << 16;
     unsigned long long* d_st;
     CK(hipMalloc(&d_st, sizeof(unsigned long long) * 8 * max_wg));
-    auto profile = [&](auto fn, const char* name, int n_wg, const char* const* phase, int n_stamps) {
+    auto profile = [&](auto fn, const char* name, int n_wg, const char* const* phase, int n_stamps, int kid) {
         for (int rep = 0; rep < 3; ++rep) {  // (the last repetition is reported)
             CK(hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 8 * max_wg, s));
             CK(hipStreamSynchronize(s));
-            CK(hipMemcpyToSymbol(HIP_SYMBOL(sk_prof), &d_st, sizeof(d_st)));
+            if (a3d_profile_set_skin(d_st, kid)) exit(1);
             fn();
             CK(hipStreamSynchronize(s));
         }
-        unsigned long long* none = nullptr;
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(sk_prof), &none, sizeof(none)));
+        if (a3d_profile_set_skin(nullptr, -1)) exit(1);
         std::vector<unsigned long long> st((size_t)8 * n_wg);
         CK(hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         report(name, st, n_wg, phase, n_stamps);
@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
         const int gx = (ngroups + groups - 1) / groups + 1;
         static const char* const ph[] = {"", "links + bones into LDS (-> barrier)", "chain products (thread 0's bone)", "barrier (all chains done)", "", "logits, softmax, blend, store"};
         // (stamp 4 is unused in the forward: 3 -> 5 is reported under slot 5 by copying 3 into 4 below)
-        profile([&]() { fwd(); }, "sk_fwd_kernel<20, true>", gx * B, ph, 4);
+        profile([&]() { fwd(); }, "sk_fwd_kernel<20, true>", gx * B, ph, 4, 0);
         // the vertex phase separately
         std::vector<unsigned long long> st((size_t)8 * gx * B);
         CK(hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -164,7 +164,7 @@ int main(int argc, char** argv) {
         if (cpb < 1) cpb = 1;
         const int gx = (chunks + cpb - 1) / cpb;
         static const char* const ph[] = {"", "stage + softmax weights, g_v (phase 1)", "bone-group sums over the chunk (phase 2)", "DPP + LDS reduction (-> barrier)", "share of g_T into LDS (-> barrier)", "chain adjoint + atomics on g_angles"};
-        profile([&]() { bwd(); }, "sk_bwd_kernel<5, true>", gx * B, ph, 6);
+        profile([&]() { bwd(); }, "sk_bwd_kernel<5, true>", gx * B, ph, 6, 1);
     }
     return 0;
 }
