@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         if (j >= total) return;
         const unsigned b = j / (2u * nbx), r = j - b * 2u * nbx;
         aa_analyze_body(an, r % nbx, (int)(r / nbx), (int)b);
-        A3D_STAMP(0, 4);  // (analysis work-groups end at slot 4, pixel movers at slot 5)
+        A3D_STAMP(0, 4);  // (analysis work-groups end at slot 4, the movers of the first buffer at slot 5, of the second at slot 3)
         return;
     }
     const CaJob& job = blockIdx.y ? jb : ja;
@@ -463,10 +463,16 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         s_src[threadIdx.x] = q >= 0 ? q : (s.bg ? -2 - (int)(s.bg_shared ? p % s.hw : p) : -1);
     }
     __syncthreads();
+    A3D_STAMP(0, 1);
     const int nloc = (int)min(256u, n_pix - base) * C1;
     const float rc = 1.f / (float)C1;
     float* o = out + (long long)base * C1;
-    // 16 bytes per lane (the run starts on a 16-byte boundary: 256 * C1 floats per work-group); a ragged tail goes float by float
+    // 16 bytes per lane (the run starts on a 16-byte boundary: 256 * C1 floats per work-group); a ragged tail goes float by float.
+    // (Round 4, tools/kernel_phases.py: the launch holds ~1500 work-groups at any time -- 8192 of the analysis at 3.7 us each, 4096 of
+    // the 18-channel image at 4.7, 4096 of the 4-channel one at 2.1 -- and ends when the last has been through; it is bound by what the
+    // memory system returns to that many waiters (3.6 TB/s, mostly writes), not by any work-group's own chain.  Measured and dropped:
+    // the loads of three / five of the stores below issued first, unconditionally at clamped indices -- loop 3.6 -> 4.2 us, launch 38.9
+    // -> 40.8 (five: 94 registers, two waves per SIMD fewer, 54); 2 / 4 / 8 tiles per work-group -- call 50.1 -> 52.0 / 57.7 / 84.4.)
     const int n4 = (((uintptr_t)out & 15) == 0) ? (nloc & ~3) : 0;
     for (int j0 = 4 * threadIdx.x; j0 < n4; j0 += 1024) {
         float v[4];
@@ -490,7 +496,8 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         else if (src <= -2) v = s.bg[(long long)(-2 - src) * C1 + c];
         o[j] = v;
     }
-    A3D_STAMP(0, 5);
+    if (blockIdx.y) A3D_STAMP(0, 3);
+    else A3D_STAMP(0, 5);
 }
 
 __global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const AaRec* __restrict__ work, const int* __restrict__ count,

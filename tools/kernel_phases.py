@@ -37,7 +37,8 @@ KERNELS = {
     "sh_bwd": ("shade", 0, {1: "per-point adjoint + stores", 5: "per-image row reduction + atomics"}),
     "nr_face_bwd": ("normals", 0, {5: "whole kernel"}),
     "nr_sum_bwd": ("normals", 1, {5: "whole kernel"}),
-    "ca_compose": ("antialias", 0, {4: "analysis work-groups", 5: "pixel movers"}),
+    "ca_compose": ("antialias", 0, {1: "pixel -> source map into LDS (-> barrier; generic path)", 3: "movers of the second buffer: loads + stores",
+                                    4: "analysis work-groups (whole)", 5: "movers of the first buffer (4 floats per pixel: whole; else loads + stores)"}),
     "ca_blend": ("antialias", 1, {1: "segment offsets", 5: "blends (atomics)"}),
     "ca_gather": ("antialias", 2, {1: "list -> LDS (-> barrier)", 5: "gather + store"}),
     "ca_bwd": ("antialias", 3, {1: "segment offsets", 5: "records: colour adjoints + edge adjoints (atomics)"}),
