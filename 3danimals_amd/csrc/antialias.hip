@@ -169,31 +169,39 @@ __device__ __forceinline__ void aa_append(const AaAnalyzeJob& a, bool emit, cons
     }
 }
 
-// one thread per (pixel, direction): work-group (bx, d, b) of a (ceil(H W / 256), 2, B) grid; d = 0: right neighbour, 1: lower neighbour.
-// Work-group L of that grid appends to segment L % AA_SHARDS; a segment holds 256 records for each of its work-groups.
-// Two phases: every thread compares the triangle ids of its pair (two 8-byte reads); the pairs that differ (~15 % of them: with
-// triangles the size of a pixel an id discontinuity is the rule inside the object) are POOLED through LDS and worked off by the first
-// ceil(n / 64) waves with full lanes -- the long path (triangle, three screen positions, the opposite vertex: five dependent
-// gathers, ~200 instructions) used to run in every wave that held a single such pair, at ~15 % of its lanes.
-__device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned bx, int d, int b) {
-    __shared__ unsigned s_cand[256];
+// One thread per pixel, BOTH its pairs (right neighbour d = 0, lower neighbour d = 1): work-group (bx, b) of a (ceil(H W / 256), B) grid.
+// Work-group L of that grid appends to segment L % AA_SHARDS; a segment holds 512 records for each of its work-groups.
+// Two phases: every thread compares the triangle id of its pixel with the two neighbours' (three 4-byte reads); the pairs that differ
+// (~15 % of them: with triangles the size of a pixel an id discontinuity is the rule inside the object) are POOLED through LDS and
+// worked off by the first ceil(n / 64) waves with full lanes -- the long path (triangle, three screen positions, the opposite vertex:
+// five dependent gathers, ~200 instructions) used to run in every wave that held a single such pair, at ~15 % of its lanes.
+// (Until round 4 a work-group took ONE direction of its 256 pixels: twice the work-groups, each texel's id read by both.  Wherever the
+// analysis rides -- the compositor's first launch -- the launch is bound by the work-groups it has to seat, tools/kernel_phases.py:
+// 8192 analysis work-groups of 3.7 us were half of its residency.)
+__device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned bx, int b) {
+    __shared__ unsigned s_cand[512];  // (y << 16 | x) | d << 31
     __shared__ int s_ncand;
     const unsigned hw = (unsigned)a.H * (unsigned)a.W;
     const unsigned rem = bx * 256u + threadIdx.x;
     if (threadIdx.x == 0) s_ncand = 0;
     __syncthreads();
-    bool cand = false;
+    bool cand0 = false, cand1 = false;
     unsigned xy = 0;
     if (rem < hw) {
         const unsigned y = rem / (unsigned)a.W, x = rem - y * (unsigned)a.W;  // (a 64-bit division costs ~150 instructions)
-        if (d == 0 ? ((int)x + 1 < a.W) : ((int)y + 1 < a.H)) {
-            const long long i = (long long)b * hw + rem;
-            const float w0 = reinterpret_cast<const float*>(a.rast + i)[3], w1 = reinterpret_cast<const float*>(a.rast + i + (d == 0 ? 1 : a.W))[3];
-            cand = (int)w0 != (int)w1;
-            xy = (y << 16) | x;
-        }
+        const long long i = (long long)b * hw + rem;
+        const bool has0 = (int)x + 1 < a.W, has1 = (int)y + 1 < a.H;
+        // (unconditional reads at clamped positions, the selects after them)
+        const float w0 = reinterpret_cast<const float*>(a.rast + i)[3];
+        const float wr = reinterpret_cast<const float*>(a.rast + (has0 ? i + 1 : i))[3];
+        const float wd = reinterpret_cast<const float*>(a.rast + (has1 ? i + a.W : i))[3];
+        cand0 = has0 && (int)w0 != (int)wr;
+        cand1 = has1 && (int)w0 != (int)wd;
+        xy = (y << 16) | x;
     }
-    {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const bool cand = d ? cand1 : cand0;
         const unsigned long long m = __ballot(cand);
         int base = 0;
         if (m) {
@@ -201,23 +209,25 @@ __device__ __forceinline__ void aa_analyze_body(const AaAnalyzeJob& a, unsigned 
             if (a3d_lane_id() == leader) base = atomicAdd(&s_ncand, __popcll(m));
             base = __shfl(base, leader);
         }
-        if (cand) s_cand[base + a3d_wave_prefix(m)] = xy;
+        if (cand) s_cand[base + a3d_wave_prefix(m)] = xy | ((unsigned)d << 31);
     }
     __syncthreads();
     const int n = s_ncand;
-    const unsigned lin = bx + ((hw + 255u) / 256u) * ((unsigned)d + 2u * (unsigned)b);
-    if ((int)(threadIdx.x & ~63u) >= n) return;  // (whole waves without work leave; the ballots of aa_append see whole waves)
-    AaRec rec;
-    bool emit = false;
-    if ((int)threadIdx.x < n) {
-        const unsigned c = s_cand[threadIdx.x];
-        const int y = (int)(c >> 16), x = (int)(c & 0xFFFFu);
-        emit = aa_pair_record(a, (long long)b * hw + (unsigned)y * (unsigned)a.W + (unsigned)x, b, x, y, d, rec);
+    const unsigned lin = bx + ((hw + 255u) / 256u) * (unsigned)b;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        if (c0 + (int)(threadIdx.x & ~63u) >= n) break;  // (whole waves without work leave; the ballots of aa_append see whole waves)
+        AaRec rec;
+        bool emit = false;
+        if (c0 + (int)threadIdx.x < n) {
+            const unsigned c = s_cand[c0 + threadIdx.x];
+            const int d = (int)(c >> 31), y = (int)((c >> 16) & 0x7FFFu), x = (int)(c & 0xFFFFu);
+            emit = aa_pair_record(a, (long long)b * hw + (unsigned)y * (unsigned)a.W + (unsigned)x, b, x, y, d, rec);
+        }
+        aa_append(a, emit, rec, (int)(lin & (AA_SHARDS - 1)));
     }
-    aa_append(a, emit, rec, (int)(lin & (AA_SHARDS - 1)));
 }
 
-__global__ __launch_bounds__(256) void aa_analyze_kernel(AaAnalyzeJob a) { aa_analyze_body(a, blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+__global__ __launch_bounds__(256) void aa_analyze_kernel(AaAnalyzeJob a) { aa_analyze_body(a, blockIdx.x, (int)blockIdx.y); }
 
 // consumers: exclusive prefix of the segment fills into LDS (call with all threads of the block), then record r -> its slot
 __device__ __forceinline__ int aa_segment_offsets(const int* __restrict__ count, int capacity, int* s_off) {
@@ -347,11 +357,12 @@ __global__ __launch_bounds__(256) void aa_copy_zero_kernel(const float* __restri
 
 extern "C" int a3d_aa_shards(void) { return AA_SHARDS; }
 
-// records the work list must hold for a [B,H,W] frame: AA_SHARDS segments of 256 records per analysis work-group mapped to them
+// records the work list must hold for a [B,H,W] frame: AA_SHARDS segments of 512 records (256 pixels x 2 directions) per analysis
+// work-group mapped to them
 extern "C" int a3d_aa_capacity(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return AA_SHARDS;
-    const long long groups = 2ll * B * a3d_div_up((long long)H * W, 256);
-    return (int)(a3d_div_up(groups, AA_SHARDS) * 256 * AA_SHARDS);
+    const long long groups = (long long)B * a3d_div_up((long long)H * W, 256);
+    return (int)(a3d_div_up(groups, AA_SHARDS) * 512 * AA_SHARDS);
 }
 
 // ---- compositing fused with the antialiasing -------------------------------------------------------------------------------------------
@@ -428,11 +439,11 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
         bx = bx < n_extra ? nb_compose + bx : bx - n_extra;
     }
     if (bx >= nb_compose) {
-        const unsigned nbx = ((unsigned)an.H * (unsigned)an.W + 255u) / 256u, total = nbx * 2u * (unsigned)an.B;
+        const unsigned nbx = ((unsigned)an.H * (unsigned)an.W + 255u) / 256u, total = nbx * (unsigned)an.B;
         const unsigned j = blockIdx.y * (gridDim.x - nb_compose) + (bx - nb_compose);  // flat work-group of the analysis
         if (j >= total) return;
-        const unsigned b = j / (2u * nbx), r = j - b * 2u * nbx;
-        aa_analyze_body(an, r % nbx, (int)(r / nbx), (int)b);
+        const unsigned b = j / nbx;
+        aa_analyze_body(an, j - b * nbx, (int)b);
         A3D_STAMP(0, 4);  // (analysis work-groups end at slot 4, the movers of the first buffer at slot 5, of the second at slot 3)
         return;
     }
@@ -644,7 +655,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     A3D_CHECK_ARG(lists_stride >= 0);
     A3D_CHECK_ARG(rast && clip && screen && work && count && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
-    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll);
+    A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && H < 32768 && W < 65536);  // (a candidate pair is packed as y << 16 | x | d << 31)
     hipStream_t s = (hipStream_t)stream;
     A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W));
     if (F == 0) {
@@ -662,7 +673,7 @@ extern "C" int a3d_aa_analyze(const float* rast, const float* clip, int clip_bat
     AaAnalyzeJob an;
     an.rast = (const float4*)rast; an.screen = (const float2*)screen; an.tri = tri; an.opp = opp; an.off = off_or_null; an.adj = adj_or_null;
     an.work = (AaRec*)work; an.count = count; an.clip_batch = clip_batch; an.V = V; an.F = F; an.H = H; an.W = W; an.capacity = capacity; an.B = B; an.stride = lists_stride;
-    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), 2, B), dim3(256), 0, s, an);
+    hipLaunchKernelGGL(aa_analyze_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, an);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -727,11 +738,11 @@ static int ca_ride(const a3d_aa_ride* r, const float* rast_override, void* work,
     const float* rast = rast_override ? rast_override : r->rast;
     A3D_CHECK_ARG(rast && r->screen && r->tri && r->V > 0 && r->F > 0 && (r->clip_batch == 1 || r->clip_batch == B));
     A3D_CHECK_ARG(r->opp || (r->off && r->adj));
-    A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535 && r->lists_stride >= 0);
+    A3D_CHECK_ARG(capacity >= a3d_aa_capacity(B, H, W) && B <= 65535 && r->lists_stride >= 0 && H < 32768 && W < 65536);
     an->rast = (const float4*)rast; an->screen = (const float2*)r->screen; an->tri = r->tri; an->opp = r->opp;
     an->off = r->off; an->adj = r->adj; an->work = (AaRec*)work; an->count = count;
     an->clip_batch = r->clip_batch; an->V = r->V; an->F = r->F; an->H = H; an->W = W; an->capacity = capacity; an->B = B; an->stride = r->lists_stride;
-    *nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * 2u * (unsigned)B;
+    *nb_an = (unsigned)a3d_div_up((long long)H * W, 256) * (unsigned)B;
     return A3D_OK;
 }
 
