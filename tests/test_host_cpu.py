@@ -76,6 +76,21 @@ def test_header_prototypes_match_the_ctypes_signatures_in_arity_and_kind():
     assert sum(len(ps) for _, ps in protos.values()) > 400
 
 
+def test_product_library_carries_no_phase_stamps():
+    """The in-kernel phase stamps (csrc/a3d_common.h: A3D_STAMP, tools/kernel_phases.py) live in a second library built with -DA3D_PROFILE;
+    the library the package loads exports none of their setters -- and the instrumented twin, when it has been built, exports one per
+    instrumented translation unit on top of the same ABI."""
+    L = importlib.import_module("3danimals_amd._lib")
+    lib = L.lib()
+    tus = ("dmtet", "skin", "raster", "gbuffer", "shade", "normals", "antialias")
+    assert not any(hasattr(lib, f"a3d_profile_set_{t}") for t in tus)
+    prof = os.path.join(ROOT, "3danimals_amd", "lib", "liba3d_hip_prof.so")
+    if os.path.exists(prof) and os.path.getmtime(prof) >= os.path.getmtime(L.LIB_PATH) - 3600:
+        twin = ctypes.CDLL(prof)
+        assert all(hasattr(twin, f"a3d_profile_set_{t}") for t in tus)
+        assert all(hasattr(twin, name) for name in L.SIGNATURES)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     L = importlib.import_module("3danimals_amd._lib")
     monkeypatch.setattr(L, "_lib", None)

@@ -11,4 +11,7 @@ bash tools/prof_bench.sh ${TAG}_bcc51s 20 5 --grid bcc51s > /dev/null 2>&1
 python tools/bench_dmtet.py --grid kuhn64 bcc51s kuhn128 bcc102s --surf --passes plain auto --json gpurun_out/${TAG}_dmtet_grids.json > gpurun_out/${TAG}_dmtet_grids.txt 2>&1
 python tools/numbering_diag.py --grids kuhn64 kuhn64s bcc51 bcc51s --json gpurun_out/${TAG}_numbering.json > /dev/null 2>&1
 python tools/long_run_diag.py 600 2>&1 | grep "^[0-9]" > gpurun_out/${TAG}_long_run_diag.txt
+bash tools/pmc_issue.sh $TAG > /dev/null 2>&1          # issue / stall / parked shares of every kernel's wave cycles
+python 3danimals_amd/csrc/build.py --profile > /dev/null 2>&1 && python tools/kernel_phases.py 2>/dev/null | grep -v Warning > gpurun_out/${TAG}_kernel_phases.txt   # phase stamps inside the kernels, real step
+(hipcc --offload-arch=gfx950 -O3 -std=c++17 -DA3D_PROFILE -fhip-fp32-correctly-rounded-divide-sqrt -I include -I 3danimals_amd/csrc tools/skin_phases/phases.hip 3danimals_amd/csrc/common.hip -o gpurun_out/skin_phases 2>/dev/null && (gpurun_out/skin_phases; gpurun_out/skin_phases 16 23800) > gpurun_out/${TAG}_skin_phases.txt 2>&1; rm -f gpurun_out/skin_phases)
 tail -3 gpurun_out/${TAG}_lines.log
