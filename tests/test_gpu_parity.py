@@ -1656,7 +1656,8 @@ def test_nvdiffrast_shim_range_mode_and_gradient_boost(dev):
         (g1,) = torch.autograd.grad(aa.sum(), pos)
         aa3 = dr.antialias(col, rast, pos, tri, pos_gradient_boost=3.0)
         (g3,) = torch.autograd.grad(aa3.sum(), pos)
-        assert torch.equal(aa, aa3) and float(g1.abs().max()) > 0
+        # (two analyses of one frame list their records in the order their waves' atomics landed: a pixel that takes two blends may sum them either way)
+        assert float((aa - aa3).abs().max()) <= 2.4e-7 and float(g1.abs().max()) > 0
         torch.testing.assert_close(g3, 3.0 * g1, rtol=1e-5, atol=1e-6 * float(g1.abs().max()))
         with pytest.raises(RuntimeError, match="range mode"):
             dr.rasterize(ctx, pos, tri, [H, W], ranges=ranges.to(dev))

@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
         int cpb = (int)(((long long)chunks * B + 767) / 768);
         if (cpb < 1) cpb = 1;
         const int gx = (chunks + cpb - 1) / cpb;
-        static const char* const ph[] = {"", "stage + softmax weights, g_v (phase 1)", "bone-group sums over the chunk (phase 2)", "DPP + LDS reduction (-> barrier)", "share of g_T into LDS (-> barrier)", "chain adjoint + atomics on g_angles"};
+        static const char* const ph[] = {"", "stage + softmax weights, g_v (phase 1)", "g_T on the matrix pipe (phase 2)", "the waves' tiles into LDS (-> barrier)", "share of g_T into LDS (-> barrier)", "chain adjoint + atomics on g_angles"};
         profile([&]() { bwd(); }, "sk_bwd_kernel<5, true>", gx * B, ph, 6, 1);
     }
     return 0;
