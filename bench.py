@@ -98,6 +98,7 @@ def algorithmic_bytes(name, d):
     rendered per step (images x frames), V / F = surface vertices / faces, P = covered pixels, K = bones.
     """
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
+    Bv = int(d.get("skin_v_batch", 1))
     if "[+shade]" in name:  # the colour computed on the spot: G-buffer row + kd in (60 B per point) instead of the shaded row (12 B)
         return algorithmic_bytes(name.replace("[+shade]", ""), d) + 48 * int(d.get("P", 0))
     if name.endswith("[+analysis]"):  # the silhouette analysis rode in this call's first launch: both passes' bytes
@@ -138,8 +139,9 @@ def algorithmic_bytes(name, d):
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
         # chain + skinning in one launch: skin_fwd's bytes + the bones / angles in and the transforms (+ chain products) out
-        "a3d_skin_pose_fwd": 12 * V + 12 * B * V + B * K * (12 + 48 + 24) + B * K * 8 * 96,
-        "a3d_skin_pose_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K + B * K * (12 + 48 + 12 + 24) + B * K * 8 * 96,
+        # (rest vertices in and -- backward -- their gradient out: per image when the instance deformation moved them (Bv = B), else once)
+        "a3d_skin_pose_fwd": 12 * Bv * V + 12 * B * V + B * K * (12 + 48 + 24) + B * K * 8 * 96,
+        "a3d_skin_pose_bwd": 12 * B * V + 12 * Bv * V + 12 * Bv * V + 48 * B * K + B * K * (12 + 48 + 12 + 24) + B * K * 8 * 96,
         "a3d_normals_adjacency": 24 * F + 4 * V,  # triangle list in, CSR out
         "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
         "a3d_mesh_topology_finalize": 12 * F + 4 * V + (4 * V + 12 * F),  # int32 triangle list + valence counts in; offsets + lists out
@@ -490,7 +492,8 @@ def main():
                     Nv=int(sc.netShape.verts.shape[0]), Ne=int(sc.netShape.topology.edges32.shape[0]),
                     Nt=int(sc.netShape.topology.tets32.shape[0]), K=int(sc.bones.shape[2]),
                     P=int((sc.last["rast"][..., 3] > 0).sum()) if "rast" in sc.last else 0,
-                    dm_words_read=sc.netShape.topology.words_read(sc.netShape.current_sdf))
+                    dm_words_read=sc.netShape.topology.words_read(sc.netShape.current_sdf),
+                    skin_v_batch=sc.frames if getattr(sc, "deform", False) else 1)  # (instance deformation: rest vertices per image)
 
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
