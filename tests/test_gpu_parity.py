@@ -435,6 +435,38 @@ def test_fused_pose_skinning_equals_the_two_launch_path(B, F, shared, dev, mods)
             np.testing.assert_allclose(g2.cpu().numpy(), gf.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale, err_msg=f"{which}/{name} second backward")
 
 
+@pytest.mark.parametrize("K", [7, 20, 28, 40])
+def test_skin_blend_for_any_skeleton_size_vs_torch(K, dev, ops):
+    """a3d_skin_fwd / a3d_skin_bwd (the blend alone: transforms given) against plain torch fp32 for skeletons below, at and above the
+    reference's 20 bones -- the kernels come in three sizes (<= 20, <= 32, <= 64 bones), the backward's transform gradient is a matrix
+    product over 16-bone tiles (fp32 MFMA), and only K = 20 is exercised by the reference's configurations.  Weights = softmax over the
+    bones of -distance(point, bone segment) / temperature on a DETACHED copy of the vertices (skinning.py:377)."""
+    B, V, temp = 3, 777, 0.07
+    v = seeded((B, V, 3), 31, -1, 1).to(dev).requires_grad_(True)
+    bones = seeded((B, K, 2, 3), 32, -1, 1).to(dev)
+    T = (torch.eye(3, 4).reshape(1, 1, 12) + 0.3 * seeded((B, K, 12), 33, -1, 1)).to(dev).requires_grad_(True)
+    wgt = seeded((B, V, 3), 34, -1, 1).to(dev)
+
+    def ref(v, T):
+        a, d = bones[:, :, 0][:, :, None], (bones[:, :, 1] - bones[:, :, 0])[:, :, None]  # [B,K,1,3]
+        r = v.detach()[:, None] - a  # [B,K,V,3]
+        t = ((r * d).sum(-1) * (1.0 / (d * d).sum(-1).clamp_min(1e-6))).clamp(0, 1)
+        s_ = t[..., None] * d - r
+        w = torch.softmax(-torch.sqrt((s_ * s_).sum(-1) + 1e-6) / temp, dim=1)  # [B,K,V]
+        R = T.reshape(B, K, 3, 4)
+        posed = torch.einsum("bkij,bvj->bkvi", R[..., :3], v) + R[..., 3][:, :, None]
+        return (w[..., None] * posed).sum(1)
+
+    out = ops.skin(v, bones, T, temp)
+    want = ref(v, T)
+    assert float((out - want).abs().max()) <= 2e-5, float((out - want).abs().max())
+    g = torch.autograd.grad((out * wgt).sum(), [v, T])
+    gw = torch.autograd.grad((want * wgt).sum(), [v, T])
+    for x, y, name in zip(g, gw, ("vertices", "transforms")):
+        scale = float(y.abs().max())
+        assert scale > 0 and float((x - y).abs().max()) <= 2e-5 * scale, (name, float((x - y).abs().max()), scale)
+
+
 # ------------------------------------------------------------------------------------------------ rasterise
 def _scene(B, res=16, seed=1):
     from oracle import render_ref
