@@ -148,11 +148,12 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         return;
     }
     if (bx >= nb_tri + nb_screen) {
-        // more extra work-groups (image 0 only): the opposite-vertex table of the silhouette analysis, looked up in the vertex -> face
-        // lists the DMTet extraction left (no edge hash on that path).  Each lookup is a chain of five dependent gathers -- inside the
-        // analysis it doubled that kernel's time (13 -> 24 us); here it runs beside the triangle work of the same launch for free.
-        if (b != 0) return;
-        const int idx = (bx - nb_tri - nb_screen) * 256 + threadIdx.x;
+        // more extra work-groups: the opposite-vertex table of the silhouette analysis (one per mesh, not per image: its ceil(3 F / 256)
+        // work-groups are spread over the B rows of the grid, nb_opp per row -- as "image 0 only" every other row carried that many
+        // work-groups that left at once, 2085 of the launch's 5856 on the bench mesh, all dispatched before the triangle work), looked up
+        // in the vertex -> face lists the DMTet extraction left (no edge hash on that path).  Each lookup is a chain of five dependent
+        // gathers -- inside the analysis it doubled that kernel's time (13 -> 24 us); here it runs beside the triangle work for free.
+        const int idx = ((int)blockIdx.y * nb_opp + (bx - nb_tri - nb_screen)) * 256 + threadIdx.x;
         if (idx < 3 * F) topo_opp[idx] = aa_opposite_from_lists(tri, topo_off, topo_adj, nj.stride, F, idx / 3, idx - 3 * (idx / 3));
         return;
     }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     int x0 = 0, y0 = 0, bw = 1, area = 0;
-    if (f < F) {
+    if (f < F && sub == 0) {  // (the triangle's first lane alone: the other LPT - 1 only take their share of the pooled pixels below)
         const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
         if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
             p0 = pb[i0]; p1 = pb[i1]; p2 = pb[i2];
@@ -477,7 +478,7 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     const long long pairs = (long long)B * F;
     const int lpt = pairs <= 300000 ? 4 : (pairs <= 600000 ? 2 : 1);
     const int nb_tri = a3d_div_up(F, 256 / lpt), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
-    const int nb_opp = topo_opp_or_null ? a3d_div_up(3ll * F, 256) : 0;
+    const int nb_opp = topo_opp_or_null ? a3d_div_up(a3d_div_up(3ll * F, 256), B) : 0;  // (per row of the grid)
     RsNormalsJob nj = {};
     A3D_CHECK_ARG(lists_stride >= 0);
     nj.stride = lists_stride;
