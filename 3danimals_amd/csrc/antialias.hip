@@ -481,7 +481,11 @@ __global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, uns
     // 16 bytes per lane (the run starts on a 16-byte boundary: 256 * C1 floats per work-group); a ragged tail goes float by float.
     // (Round 4, tools/kernel_phases.py: the launch holds ~1500 work-groups at any time -- 8192 of the analysis at 3.7 us each, 4096 of
     // the 18-channel image at 4.7, 4096 of the 4-channel one at 2.1 -- and ends when the last has been through; it is bound by what the
-    // memory system returns to that many waiters (3.6 TB/s, mostly writes), not by any work-group's own chain.  Measured and dropped:
+    // memory system returns to that many waiters, not by any work-group's own chain: while its movers store they store at ~6.5 TB/s
+    // between them (a frame-sized fill alone reaches 6.2: tools/bw_probe), but a work-group also holds its seat for the 1.4 us its
+    // pixel -> source map takes to arrive, and the 4-channel image's work-groups hold theirs for 2.4 us to write 4 KB -- 3.9 TB/s over
+    // the launch.  Measured and dropped: a zero-fill path for the three work-groups in four that hold background only (same 3.6 us of
+    // stores: they wait on the same write path), the pixel / channel split stepped instead of recomputed per float;
     // the loads of three / five of the stores below issued first, unconditionally at clamped indices -- loop 3.6 -> 4.2 us, launch 38.9
     // -> 40.8 (five: 94 registers, two waves per SIMD fewer, 54); 2 / 4 / 8 tiles per work-group -- call 50.1 -> 52.0 / 57.7 / 84.4.)
     const int n4 = (((uintptr_t)out & 15) == 0) ? (nloc & ~3) : 0;
