@@ -429,7 +429,10 @@ struct CaJob {
 // Extra work-groups (blockIdx.x >= nb_compose): the silhouette analysis of this frame (aa_analyze_body) when it has not run yet -- the
 // blend launch that follows is its first consumer, and this pass, which only moves pixels, leaves the gather path idle: as a launch
 // of its own the analysis is 15 us of kernel plus a launch gap, here it adds ~5.
-__global__ __launch_bounds__(256) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an, int extra_first) {
+// (8 waves per SIMD asked for: the launch is bound by the work-groups it can seat -- see the loop below -- and the 67 registers the riding
+// analysis and the on-the-fly shading need leave 7; at 64 a few values of those two paths spill to scratch (72 bytes per lane) and the call
+// is 3 us shorter, 46.0-47.4 -> 43.0-43.8.  The same request on ca_bwd_kernel, 83 registers: 6 waves 24.9 against 23.1 us, 8 waves 28.5.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void ca_compose_kernel(CaJob ja, CaJob jb, unsigned n_pix, unsigned nb_compose, AaAnalyzeJob an, int extra_first) {
     __shared__ int s_src[256];  // >= 0: point row; -1: zero; <= -2: background texel -(v + 2)
     A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = ca_compose_kernel, 1 = ca_blend_kernel, 2 = ca_gather_kernel, 3 = ca_bwd_kernel)
     // (extra_first: the analysis work-groups -- gather chains -- are dispatched BEFORE the pixel movers of their row, not as the launch's tail)
