@@ -194,11 +194,15 @@ class KernelTimer:
 
 
 _SYNC_EVERY_CALL = os.environ.get("A3D_SYNC_CALLS", "0") == "1"
+_TRACE_FILE = open(os.environ["A3D_TRACE_CALLS"], "w") if os.environ.get("A3D_TRACE_CALLS") else None  # debugging aid: every entry point's name, flushed BEFORE the call (a device fault that aborts the process leaves the culprit as the last line; use with A3D_SYNC_CALLS=1)
 
 
 def call(name: str, *args, tag: str = ""):
     """Invoke an int-returning entry point and raise on a non-zero status (``tag`` only labels KernelTimer records)."""
     timer = KernelTimer.active
+    if _TRACE_FILE is not None:
+        _TRACE_FILE.write(f"{name}{tag} {args}\n")
+        _TRACE_FILE.flush()
     if timer is not None:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
