@@ -91,6 +91,22 @@ def test_product_library_carries_no_phase_stamps():
         assert all(hasattr(twin, name) for name in L.SIGNATURES)
 
 
+def test_phase_tool_registry_matches_the_stamps_in_the_sources():
+    """tools/kernel_phases.py names every kernel it can stamp by (translation unit, kernel id, {slot: label}); the ids and slots are
+    whatever A3D_STAMP(id, slot) the sources carry -- an edit on one side only would print phases that do not exist."""
+    src = open(os.path.join(ROOT, "tools", "kernel_phases.py")).read()
+    table = src[src.index("KERNELS = {"):src.index("MAX_WG")]
+    entries = re.findall(r'"(\w+)": \("(\w+)", (\d+), \{(.*?)\}\)', table, flags=re.S)
+    assert len(entries) >= 15
+    for name, tu, kid, labels in entries:
+        code = open(os.path.join(ROOT, "3danimals_amd", "csrc", tu + ".hip")).read()
+        assert f"A3D_PROFILE_TU({tu})" in code, tu
+        stamped = {int(m) for m in re.findall(r"A3D_STAMP\(%s, (\d)\)" % kid, code)}
+        assert 0 in stamped, (name, "no start stamp")
+        for slot in re.findall(r"(\d): \"", labels):
+            assert int(slot) in stamped, (name, tu, kid, slot)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     L = importlib.import_module("3danimals_amd._lib")
     monkeypatch.setattr(L, "_lib", None)
