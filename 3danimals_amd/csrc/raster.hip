@@ -229,7 +229,9 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         if (sub == 0) s_pre[wv][q + 1] = incl;
         if (lane == 0) s_pre[wv][0] = 0;
     }
-    __syncthreads();
+    // (the barrier also says whether the work-group holds a big box at all: the usual one does not and ends after its pooled pixels,
+    // without the second barrier the big boxes' list needs -- 0.8 us of every work-group's ~7 in a launch bound by seats x lifetime)
+    const int any_big = __syncthreads_or(big);
     A3D_STAMP(0, 1);
     // candidate c of the work-group: first the wave slice (three compares on the four totals), then the slot inside it
     const int t0 = s_pre[0][TPW], t1 = t0 + s_pre[1][TPW], t2 = t1 + s_pre[2][TPW], total = t2 + s_pre[3][TPW];
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     // list lives in 2 KB of LDS.  (One big box after the other, each with its own barriers, made a work-group whose 64 neighbouring
     // triangles are all big -- a spike of the drifted mesh -- slower than walking their boxes: 152 against 109 us.)
     A3D_STAMP(0, 2);
+    if (!any_big) return;  // (uniform)
     if (sub == 0 && big) s_big[atomicAdd(&s_nbig, 1)] = (unsigned short)((wv << 8) | q);  // (LDS; s_nbig was zeroed before the barrier above)
     __syncthreads();
     const int nbig = s_nbig;
