@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     for (long long z = k; z < n_zero4; z += (long long)gridDim.x * 256) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long flat = k < n ? cv_flat(k, H, W, 8) : 0;
+    // Three work-groups in four cover background only, and the block counts say so before a texel is read: such a work-group writes its
+    // 256 map entries and leaves -- no 4 KB of texels, no list offset, no barrier (the launch is bound by seats x lifetime, and these
+    // held theirs for a texel round trip + the offset's loads to write -1).
+    if (block_count[blockIdx.x] == 0) {  // (uniform)
+        if (inv && k < n) inv[flat] = -1;
+        A3D_STAMP(0, 5);
+        return;
+    }
     const float4 r = k < n ? rast[flat] : make_float4(0.f, 0.f, 0.f, 0.f);  // (issued before the offset's loads: the latencies overlap)
     const int wave = threadIdx.x >> 6;
     if (wave == 0) {

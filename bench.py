@@ -153,8 +153,9 @@ def algorithmic_bytes(name, d):
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
         "a3d_interp_bwd": B * (16 * HW + 4 * C * HW + 16 * HW + 4 * C * V),
         "a3d_gbuffer_fwd": P * (8 + 16 + 48),
-        # list + map + rows in one launch: every texel in (16 B/pixel), list + pixel -> entry map + rows out
-        "a3d_cover_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P,
+        # list + map + rows in one launch: the texels of the 256-pixel blocks that hold a covered pixel in (16 B/pixel; the empty blocks are
+        # known from the rasteriser's block counts, 4 B each), list + pixel -> entry map + rows out
+        "a3d_cover_gbuffer_fwd": 16 * 256 * int(d.get("cover_blocks", B * HW // 256)) + 4 * (B * HW // 256) + 8 * P + 4 * B * HW + 48 * P,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
@@ -183,6 +184,15 @@ def algorithmic_bytes(name, d):
         "a3d_aa_bwd": B * 8 * C * HW + B * 16 * V,
     }
     return table.get(base)
+
+
+def _cover_blocks(rast):
+    """256-pixel blocks (four 8x8 tiles, tile-row-major: the covered-pixel list's order) of the frame that hold a covered pixel."""
+    Bf, H, W = rast.shape[:3]
+    if H % 8 or W % 8 or (H * W) % 256:
+        return Bf * H * W // 256
+    tiles = (rast[..., 3] > 0).reshape(Bf, H // 8, 8, W // 8, 8).any(dim=4).any(dim=2)
+    return int(tiles.reshape(Bf, -1, 4).any(dim=-1).sum())
 
 
 def algorithmic_flops(name, d):
@@ -493,7 +503,8 @@ def main():
                     Nt=int(sc.netShape.topology.tets32.shape[0]), K=int(sc.bones.shape[2]),
                     P=int((sc.last["rast"][..., 3] > 0).sum()) if "rast" in sc.last else 0,
                     dm_words_read=sc.netShape.topology.words_read(sc.netShape.current_sdf),
-                    skin_v_batch=sc.frames if getattr(sc, "deform", False) else 1)  # (instance deformation: rest vertices per image)
+                    skin_v_batch=sc.frames if getattr(sc, "deform", False) else 1,  # (instance deformation: rest vertices per image)
+                    cover_blocks=_cover_blocks(sc.last["rast"]) if "rast" in sc.last else 0)
 
     # ---- per-kernel timing pass (same workload, separate from the headline timing so the events do not perturb it)
     roofline, kernels = None, {}
