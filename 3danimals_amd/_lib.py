@@ -16,6 +16,8 @@ _c_int, _c_float, _c_size_t, _p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
 SIGNATURES = {
     "a3d_version": (_c_int, []),
     "a3d_last_error": (ctypes.c_char_p, []),
+    "a3d_bw_probe_fill": (_c_int, [_p, ctypes.c_int64, _p]),
+    "a3d_bw_probe_read": (_c_int, [_p, ctypes.c_int64, _p, _p]),
     "a3d_dmtet_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
     "a3d_dmtet_count": (_c_int, [_p, _p, _p, _c_int, _c_int, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p]),
     "a3d_dmtet_count_ordered": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "a3d_cover_count": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "a3d_rast_bins_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
@@ -102,7 +105,7 @@ class RastOpts(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("lists_stride", ctypes.c_int32), ("prev_rast", _p), ("cover_scratch", _p), ("aa_screen", _p),
                 ("aa_count", _p), ("topo_off", _p), ("topo_adj", _p), ("topo_opp", _p), ("normals_v_a", _p), ("normals_v_b", _p),
                 ("normals_off", _p), ("normals_adj", _p), ("normals_acc_a", _p), ("normals_a", _p), ("normals_acc_b", _p), ("normals_b", _p),
-                ("normals_B_a", ctypes.c_int32), ("normals_B_b", ctypes.c_int32)]
+                ("normals_B_a", ctypes.c_int32), ("normals_B_b", ctypes.c_int32), ("bins", _p), ("bin_cap", ctypes.c_int32), ("bins_clean", ctypes.c_int32)]
 
 
 class AaRide(ctypes.Structure):
@@ -135,7 +138,7 @@ class DmtetEmitOpts(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
-ABI_VERSION = 401  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 402  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 
@@ -193,6 +196,141 @@ class KernelTimer:
         return out
 
 
+# ---- guard mode (A3D_GUARD=1|2, a debugging aid like A3D_SYNC_CALLS): every buffer ops.py allocates for the library -- outputs, scratch,
+# lists, cached key / counter buffers -- sits between two 256-byte canaries, and after EVERY entry point the stream is drained and all live
+# canaries are compared (a one-element overrun of a data-dependent capacity is then reported at the call that did it, by name, with the
+# buffer's shape and the line that allocated it).  Level 2 also POISONS the payload (float: NaN, integer: 0x7f7f7f7f, byte: 0x7f), so that
+# a kernel that reads what nobody wrote -- the tail of a speculative capacity, a list slot past its count -- computes NaN or gathers
+# far out of range on every run instead of once in fifty.  tests/test_gpu_parity.py::test_guard_mode_* run the workloads and a shape fuzz
+# under it; the product path never pays for it (one flag test per call).
+GUARD = int(os.environ.get("A3D_GUARD", "0") or 0)
+GUARD_BYTES = 256
+_GUARD_BYTE = 0xA5
+_guard_live = []  # (storage of the padded buffer, payload bytes, description)
+guard_stats = dict(checks=0, buffers_checked=0, allocations=0)
+
+
+def set_guard(level):
+    """Switch guard mode at run time (tests): patches ops' allocation calls on, or off again.  -> previous level."""
+    global GUARD
+    import importlib
+
+    prev, GUARD = GUARD, int(level)
+    ops = importlib.import_module(__package__ + ".ops")
+    ops.torch = GuardedTorch(torch) if GUARD else torch
+    if not GUARD:
+        _guard_live.clear()
+    return prev
+
+
+def guarded_empty(shape, dtype, device, zero=False, site=""):
+    dtype = dtype or torch.get_default_dtype()
+    shape = tuple(int(v) for v in shape)
+    n = 1
+    for v in shape:
+        n *= v
+    item = torch.empty((), dtype=dtype).element_size()
+    nbytes = n * item
+    pad = (-nbytes) % 16
+    base = torch.empty(GUARD_BYTES + nbytes + pad + GUARD_BYTES, dtype=torch.uint8, device=device)
+    base[:GUARD_BYTES] = _GUARD_BYTE
+    base[GUARD_BYTES + nbytes:] = _GUARD_BYTE
+    t = base[GUARD_BYTES:GUARD_BYTES + nbytes].view(dtype).view(shape)
+    if zero:
+        t.zero_()
+    elif GUARD >= 2 and n:
+        if dtype.is_floating_point:
+            t.fill_(float("nan"))
+        elif dtype == torch.bool:
+            t.fill_(True)
+        elif item == 1:
+            t.fill_(0x7F)
+        else:
+            t.fill_(0x7F7F7F7F if item >= 4 else 0x7F7F)
+    # (the registry holds the STORAGE, not a weak reference to ``base``: the Python object of a view's base dies with this frame although
+    # the memory lives on through the view; an entry is dropped once nothing but the registry references its storage)
+    _guard_live.append((base.untyped_storage(), nbytes, f"{dtype} {list(shape)} allocated at {site}"))
+    guard_stats["allocations"] += 1
+    return t
+
+
+class GuardedTorch:
+    """Stands in for the ``torch`` module inside ops.py while guard mode is on: empty / empty_like / zeros hand out guarded buffers,
+    everything else is torch's."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    @staticmethod
+    def _site():
+        import sys
+
+        f = sys._getframe(2)
+        return f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}"
+
+    @staticmethod
+    def _shape(size):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            return tuple(size[0])
+        return tuple(size)
+
+    def empty(self, *size, dtype=None, device=None, **kw):
+        if device is None or torch.device(device).type != "cuda":
+            return self._real.empty(*size, dtype=dtype, device=device, **kw)
+        return guarded_empty(self._shape(size), dtype, device, site=self._site())
+
+    def zeros(self, *size, dtype=None, device=None, **kw):
+        if device is None or torch.device(device).type != "cuda":
+            return self._real.zeros(*size, dtype=dtype, device=device, **kw)
+        return guarded_empty(self._shape(size), dtype, device, zero=True, site=self._site())
+
+    def empty_like(self, t, dtype=None, **kw):
+        if not t.is_cuda:
+            return self._real.empty_like(t, dtype=dtype, **kw)
+        return guarded_empty(t.shape, dtype or t.dtype, t.device, site=self._site())
+
+
+def guard_check(where):
+    """Drain the stream and compare every live canary; raises A3DError naming the call, the buffer and the side."""
+    torch.cuda.synchronize()
+    live = [e for e in _guard_live if torch._C._storage_Use_Count(e[0]._cdata) > 1]  # (1 = the registry's own reference: the buffer is gone)
+    _guard_live[:] = live
+    whole = lambda st: torch.empty(0, dtype=torch.uint8, device=st.device).set_(st)
+    parts = []
+    for st, nbytes, what in live:
+        base = whole(st)
+        parts.append(base[:GUARD_BYTES])
+        parts.append(base[GUARD_BYTES + nbytes:])
+    guard_stats["checks"] += 1
+    guard_stats["buffers_checked"] += len(live)
+    if not parts:
+        return
+    by_device = {}
+    for q in parts:
+        by_device.setdefault(q.device, []).append(q)
+    ok = all(bool((torch.cat(qs) == _GUARD_BYTE).all()) for qs in by_device.values())
+    if ok:
+        return
+    bad = []
+    for st, nbytes, what in live:
+        base = whole(st)
+        head, tail = bool((base[:GUARD_BYTES] == _GUARD_BYTE).all()), bool((base[GUARD_BYTES + nbytes:] == _GUARD_BYTE).all())
+        if not head:
+            bad.append(f"{what}: bytes BEFORE the buffer overwritten ({int((base[:GUARD_BYTES] != _GUARD_BYTE).sum())} of {GUARD_BYTES})")
+        if not tail:
+            t = base[GUARD_BYTES + nbytes:]
+            first = int((t != _GUARD_BYTE).nonzero()[0])
+            bad.append(f"{what}: bytes AFTER the buffer overwritten ({int((t != _GUARD_BYTE).sum())}, first {first} bytes past its end)")
+            t.fill_(_GUARD_BYTE)
+        if not head:
+            base[:GUARD_BYTES] = _GUARD_BYTE
+    raise A3DError(f"A3D_GUARD: buffer overrun detected after {where}: " + "; ".join(bad))
+
+
+_HELD = []  # float32 / contiguous copies made for ONE call: kept alive until that call has been enqueued (see f32h)
 _SYNC_EVERY_CALL = os.environ.get("A3D_SYNC_CALLS", "0") == "1"
 _TRACE_FILE = open(os.environ["A3D_TRACE_CALLS"], "w") if os.environ.get("A3D_TRACE_CALLS") else None  # debugging aid: every entry point's name, flushed BEFORE the call (a device fault that aborts the process leaves the culprit as the last line; use with A3D_SYNC_CALLS=1)
 
@@ -207,6 +345,9 @@ def call(name: str, *args, tag: str = ""):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
     rc = getattr(lib(), name)(*args)
+    del _HELD[:]
+    if GUARD and rc == 0:
+        guard_check(name + tag)
     if _SYNC_EVERY_CALL:  # debugging aid (A3D_SYNC_CALLS=1): a device fault is reported at the entry point that caused it
         try:
             torch.cuda.synchronize()
@@ -254,7 +395,8 @@ def fp32_region(fn):
         if torch.is_tensor(x):
             return x.float() if x.is_floating_point() and x.dtype in (torch.float16, torch.bfloat16) else x
         if isinstance(x, (list, tuple)):
-            return type(x)(cast(v) for v in x)
+            vals = [cast(v) for v in x]
+            return type(x)(*vals) if hasattr(x, "_fields") else type(x)(vals)  # (a namedtuple's constructor takes its fields one by one)
         if isinstance(x, dict):
             return {k: cast(v) for k, v in x.items()}
         return x
@@ -274,3 +416,13 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def f32h(t):
+    """f32c for an argument that is only passed on as a raw pointer (``ptr(f32h(g))`` inside a ``call(...)``): a copy made here stays
+    referenced until that call has been enqueued.  (Without that the temporary dies as soon as ptr() has returned its address, and the
+    caching allocator may hand the same block to the NEXT temporary of the same argument list -- two pointers, one buffer.)"""
+    u = f32c(t)
+    if u is not t:
+        _HELD.append(u)
+    return u

@@ -730,6 +730,9 @@ static int ca_shade(const a3d_ca_shade* sh, int C, const float* vals, CaJob* j, 
     if (!sh) return A3D_OK;
     A3D_CHECK_ARG(sh->size >= sizeof(a3d_ca_shade));
     A3D_CHECK_ARG(!vals && C == 3 && sh->gb && sh->par && sh->kd && sh->kd_stride >= 3 && sh->n_clear >= 0 && (sh->n_clear == 0 || sh->clear));
+    // (the colour computed on the spot exists only on the compose kernel's 16-byte path: a forward call whose image or background is not
+    // 16-byte aligned would take the general path, which has no shading source -- refused instead of composited wrongly)
+    A3D_CHECK_ARG(!forward || ((((uintptr_t)j->out | (uintptr_t)j->s.bg) & 15) == 0));
     j->s.sh_gb = sh->gb; j->s.sh_par = sh->par; j->s.sh_kd = sh->kd; j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
     if (forward) { j->clear = sh->clear; j->n_clear = sh->n_clear; }
     return A3D_OK;

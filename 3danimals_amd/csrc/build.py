@@ -1,6 +1,6 @@
 """Build liba3d_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python 3danimals_amd/csrc/build.py [--force] [--profile]
+    python 3danimals_amd/csrc/build.py [--force] [--profile | --exp]
 
 One object per .hip file, linked into 3danimals_amd/lib/liba3d_hip.so (in-tree, git-ignored, travels to the
 GPU box with the snapshot).  raster/dmtet/antialias/normals are compiled with -ffp-contract=off: their arithmetic is
@@ -53,11 +53,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, profile=False):
+def build(force=False, verbose=True, profile=False, exp=False):
     """profile: the instrumented twin liba3d_hip_prof.so (-DA3D_PROFILE: phase stamps inside the kernels, a3d_common.h) that
-    tools/kernel_phases.py loads instead of the library; never loaded by the package on its own."""
-    lib = os.path.join(LIB_DIR, "liba3d_hip_prof.so") if profile else LIB
-    obj_dir = os.path.join(OBJ_DIR, "prof") if profile else OBJ_DIR
+    tools/kernel_phases.py loads instead of the library; never loaded by the package on its own.
+    exp: liba3d_hip_exp.so (-DA3D_EXPERIMENT): the same kernels with the A3D_EXP measurement knobs live (a3d_exp() reads the environment
+    only there); loaded through A3D_LIB by the tools under tools/, never by the package on its own."""
+    assert not (profile and exp)
+    lib = os.path.join(LIB_DIR, "liba3d_hip_prof.so") if profile else (os.path.join(LIB_DIR, "liba3d_hip_exp.so") if exp else LIB)
+    obj_dir = os.path.join(OBJ_DIR, "prof") if profile else (os.path.join(OBJ_DIR, "exp") if exp else OBJ_DIR)
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
@@ -69,7 +72,7 @@ def build(force=False, verbose=True, profile=False):
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra + (["-DA3D_PROFILE"] if profile else []))
+            jobs.append([hipcc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra + (["-DA3D_PROFILE"] if profile else []) + (["-DA3D_EXPERIMENT"] if exp else []))
 
     def run(cmd):
         if verbose:
@@ -84,4 +87,4 @@ def build(force=False, verbose=True, profile=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, profile="--profile" in sys.argv))
+    print(build(force="--force" in sys.argv, profile="--profile" in sys.argv, exp="--exp" in sys.argv))

@@ -248,7 +248,11 @@ extern "C" int a3d_gemm_nn_relumask(const float* A, const float* B, const float*
     if (M == 0) return A3D_OK;
     A3D_CHECK_ARG(A && B && C);
     hipStream_t s = (hipStream_t)stream;
-    static const int variant = getenv("A3D_GEMM_VARIANT") ? atoi(getenv("A3D_GEMM_VARIANT")) : 3;  // experiment knob; 3 = persistent
+#ifdef A3D_EXPERIMENT
+    static const int variant = getenv("A3D_GEMM_VARIANT") ? atoi(getenv("A3D_GEMM_VARIANT")) : 3;  // experiment knob (build.py --exp only); 3 = persistent
+#else
+    const int variant = 3;  // persistent (the product library reads no environment)
+#endif
     const dim3 block256(256);
     if (variant == 3 && K == 256) {  // persistent, weight half resident in LDS
         // per device ordinal (a process may drive more than one GPU); idempotent values, so a race between threads is harmless

@@ -43,12 +43,13 @@ struct RsNormalsJob {
 struct RsFrag {
     float u, v, zw;
     bool hit;
+    bool pos;  // sign of the triangle's screen-space area (s > 0)
 };
 
 // Fragment test; same operations in the same order as frag() in oracle/raster_ref.c (branch-light form).
 __device__ __forceinline__ RsFrag rs_frag(const float4 p0, const float4 p1, const float4 p2, float fx, float fy) {
     RsFrag r;
-    r.u = 0.f; r.v = 0.f; r.zw = 0.f; r.hit = false;
+    r.u = 0.f; r.v = 0.f; r.zw = 0.f; r.hit = false; r.pos = false;
     const float q0x = __builtin_fmaf(-fx, p0.w, p0.x), q0y = __builtin_fmaf(-fy, p0.w, p0.y);
     const float q1x = __builtin_fmaf(-fx, p1.w, p1.x), q1y = __builtin_fmaf(-fy, p1.w, p1.y);
     const float q2x = __builtin_fmaf(-fx, p2.w, p2.x), q2y = __builtin_fmaf(-fy, p2.w, p2.y);
@@ -85,6 +86,7 @@ __device__ __forceinline__ RsFrag rs_frag(const float4 p0, const float4 p1, cons
     r.v = fminf(fmaxf(a1 * iw, 0.f), 1.f);
     r.zw = zw;
     r.hit = true;
+    r.pos = s > 0.f;
     return r;
 }
 
@@ -97,7 +99,7 @@ __device__ __forceinline__ unsigned rs_order(float f) {  // monotone float -> ui
 // layer's (depth, id) survive, pixels the previous layer left empty stay empty
 __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, const float4 p2, int px, int py, int W, float xs, float xo,
                                               float ys, float yo, unsigned f, unsigned long long* __restrict__ keys,
-                                              const float4* __restrict__ prev) {
+                                              const float4* __restrict__ prev, int exp = 0) {
     const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
     if (fr.hit) {
         const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | f;
@@ -108,20 +110,39 @@ __device__ __forceinline__ void rs_test_pixel(const float4 p0, const float4 p1, 
             if (key <= key_prev) return;
         }
         unsigned long long* slot = keys + (long long)py * W + px;
+#ifdef A3D_EXPERIMENT
+        // measurement knobs (liba3d_hip_exp.so only): 101 = fragment tests without the atomics (what a perfect occlusion filter could save at
+        // most); 103 / 104 = a read of the key first for the fragments of triangles with positive / negative screen area, 105 = for all
+        if (exp == 101) { if (key == 0x123456789ull) atomicMin(slot, key); return; }
+        if (exp == 105 || (exp == 103 && fr.pos) || (exp == 104 && !fr.pos)) {
+            if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= key) return;
+        }
+#endif
         // fire and forget.  (Reading the key first to skip atomics that cannot win looked like a saving and measured as a loss: the
         // dependent 8-byte read costs more than the ~50 % of atomics it removes -- 42.7 us with the filter, 33.0 us without.)
         atomicMin(slot, key);
     }
 }
 
-// LPT lanes per (image, triangle); blockDim = 256 = 256 / LPT triangles
-template <int LPT>
+// ---- the binned path (round 5; north_star's "LDS-staged per-tile triangle bins", for ALL boxes): the triangle launch only BINS -- every
+// (image, triangle) appends its id to the list of each 8x8 tile its pixel box touches -- and rs_fine_kernel, one work-group per 256-pixel
+// block (four tiles, the covered-pixel list's order), runs the fragment tests of its tiles' lists with the depth test on (depth, id) keys
+// in LDS and writes the final texels: no memory-side atomics on the frame, no key buffer, no resolve pass.
+struct RsBins {
+    int* count;   // [B, tiles per image] entries appended per tile (zero on entry: the fine pass re-arms what it consumes)
+    int* list;    // [B, tiles per image, cap] triangle ids, in the order the appends landed (the result does not depend on it)
+    int cap, tw, tpi;
+};
+#define RS_BIN_MAX_TILES 4096  // tiles per image the bin launch counts in LDS (a 512 x 512 frame)
+
+// LPT lanes per (image, triangle); blockDim = 256 = 256 / LPT triangles.  BIN (LPT == 1): the binned path's first launch (see RsBins).
+template <int LPT, bool BIN>
 __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
                                                      int H, int W, unsigned long long* __restrict__ keys, const float4* __restrict__ prev,
                                                      int nb_tri, float2* __restrict__ aa_screen, int* __restrict__ aa_count, int aa_shards,
                                                      int* __restrict__ cover_group_sum, int cover_groups, int nb_screen,
                                                      const int* __restrict__ topo_off, const int* __restrict__ topo_adj,
-                                                     int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj, int extra_first) {
+                                                     int* __restrict__ topo_opp, int nb_opp, RsNormalsJob nj, int extra_first, int exp, RsBins bins) {
     const int b = blockIdx.y;
     A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = rs_tri_kernel -- triangle work-groups only stamp 1..5 --, 1 = rs_resolve_kernel)
     // the riding jobs (dependent-gather chains: vertex normals, opposite-vertex table, screen positions) are DISPATCHED FIRST (extra_first):
@@ -212,7 +233,16 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     __shared__ int s_tiles[RS_TILE_CHUNK];
     __shared__ int s_bpre[257], s_wsum[4];
     const int wv = threadIdx.x >> 6, q = lane / LPT;  // this wave's slice, this lane's triangle slot
-    const bool big = area > RS_BIG;
+    bool big = area > RS_BIG;
+    if (BIN && area > 0) {  // binned path: "big" = more than four tiles; such a box is widened to whole tiles of the screen for the tile stage
+        const int x1 = x0 + bw - 1, y1 = y0 + area / bw - 1;
+        big = (((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1)) > 4;
+        if (big) {
+            x0 &= ~7; y0 &= ~7;
+            bw = (x1 | 7) - x0 + 1;
+            area = bw * ((y1 | 7) - y0 + 1);
+        }
+    }
     const int mine = (area > 0 && !big) ? area : 0;
     if (threadIdx.x == 0) { s_nbig = 0; s_ns = 0; }
     if (sub == 0) {
@@ -231,10 +261,47 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
     }
     // (the barrier also says whether the work-group holds a big box at all: the usual one does not and ends after its pooled pixels,
     // without the second barrier the big boxes' list needs -- 0.8 us of every work-group's ~7 in a launch bound by seats x lifetime)
+    extern __shared__ int s_cnt[];  // BIN: appends of this work-group per tile of its image, then the base of its range in the tile's list
+    if (BIN)
+        for (int i = threadIdx.x; i < bins.tpi; i += 256) s_cnt[i] = 0;
     const int any_big = __syncthreads_or(big);
     A3D_STAMP(0, 1);
+    if (BIN) {
+        // A box of at most four tiles (every triangle of a fresh marching-tets surface: ~1.8 tiles on average) appends from registers: a rank
+        // inside the work-group from an LDS counter per tile, ONE returning device atomic per tile the work-group touches (its
+        // triangles are neighbours on the surface: a few dozen tiles, not 256 x 1.8) for the range in the tile's list, then the stores.
+        // Boxes of more tiles go through the tile stage below and append one by one.
+        const int bh = area > 0 ? area / bw : 0;
+        const int tx0 = x0 >> 3, ty0 = y0 >> 3, nx = ((x0 + bw - 1) >> 3) - tx0 + 1, ny = ((y0 + bh - 1) >> 3) - ty0 + 1;
+        const int nt = (area > 0 && !big) ? nx * ny : 0;
+        int rank[4], tile[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int kx = k, ky = 0;
+            while (kx >= nx && ky < 3) { kx -= nx; ++ky; }
+            tile[k] = (ty0 + ky) * bins.tw + tx0 + kx;
+            rank[k] = 0;
+            if (k < nt) rank[k] = atomicAdd(&s_cnt[tile[k]], 1);
+        }
+        __syncthreads();
+        int* cnt_b = bins.count + (long long)b * bins.tpi;
+        for (int i = threadIdx.x; i < bins.tpi; i += 256) {
+            const int c = s_cnt[i];
+            if (c) s_cnt[i] = atomicAdd(cnt_b + i, c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nt) {
+                const int pos = s_cnt[tile[k]] + rank[k];
+                if (pos < bins.cap) bins.list[((long long)b * bins.tpi + tile[k]) * bins.cap + pos] = f;  // (past cap: the fine pass sees the count and takes its exact fallback)
+            }
+    } else {
     // candidate c of the work-group: first the wave slice (three compares on the four totals), then the slot inside it
     const int t0 = s_pre[0][TPW], t1 = t0 + s_pre[1][TPW], t2 = t1 + s_pre[2][TPW], total = t2 + s_pre[3][TPW];
+#ifdef A3D_EXPERIMENT
+    if (exp == 102) return;  // (the set-up alone)
+#endif
     for (int c = threadIdx.x; c < total; c += 256) {
         const int w = c < t1 ? (c < t0 ? 0 : 1) : (c < t2 ? 2 : 3);
         const int cw = c - (w == 0 ? 0 : (w == 1 ? t0 : (w == 2 ? t1 : t2)));
@@ -251,12 +318,15 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
         if (i < (1 << 20)) cy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bx.z));
         else cy = i / bx.z;
         const int cx = i - cy * bx.z;
-        rs_test_pixel(s_p[w][j][0], s_p[w][j][1], s_p[w][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
+        rs_test_pixel(s_p[w][j][0], s_p[w][j][1], s_p[w][j][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv, exp);
     }
+    }  // (!BIN)
     // ---- the big boxes of this work-group: their TILES are pooled like the pixels above (prefix of the tile counts, a search per
     // lane), tested, and the pixels of the surviving tiles pooled in turn -- per chunk of RS_TILE_CHUNK tiles, so that the survivor
     // list lives in 2 KB of LDS.  (One big box after the other, each with its own barriers, made a work-group whose 64 neighbouring
     // triangles are all big -- a spike of the drifted mesh -- slower than walking their boxes: 152 against 109 us.)
+    // BIN: the tiles of the stage are the bins' own 8x8 tiles (boxes are tile-aligned there: see ``big`` above), and a surviving tile
+    // appends the triangle to its list instead of being tested pixel by pixel.
     A3D_STAMP(0, 2);
     if (!any_big) return;  // (uniform)
     if (sub == 0 && big) s_big[atomicAdd(&s_nbig, 1)] = (unsigned short)((wv << 8) | q);  // (LDS; s_nbig was zeroed before the barrier above)
@@ -311,20 +381,30 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
                 for (int k = 0; k < 3; ++k) {
                     const float4 u = s_p[w][qs][(k + 1) % 3], v = s_p[w][qs][(k + 2) % 3];
                     const float C = u.x * v.y - u.y * v.x, A = -(u.w * v.y - u.y * v.w), Bc = -(u.x * v.w - u.w * v.x);
-                    const float tol = 5e-6f * ((fabsf(u.x * v.y) + fabsf(u.y * v.x)) + 2.f * (fabsf(u.w * v.y) + fabsf(u.y * v.w)) + 2.f * (fabsf(u.x * v.w) + fabsf(u.w * v.x)));
+                    // (+ the q1x q2y products' own w w f f terms, which cancel in exact arithmetic but not in their rounding: they
+                    // dominate when two vertices project next to the NDC origin and the tile lies far from it)
+                    const float tol = 5e-6f * ((fabsf(u.x * v.y) + fabsf(u.y * v.x)) + 2.f * (fabsf(u.w * v.y) + fabsf(u.y * v.w)) + 2.f * (fabsf(u.x * v.w) + fabsf(u.w * v.x))
+                                               + 2.f * fabsf(u.w * v.w) * (fabsf(fx) + hx) * (fabsf(fy) + hy));
                     const float vk = C + A * fx + Bc * fy, ext = fabsf(A) * hx + fabsf(Bc) * hy + tol;
                     pos = pos && (vk + ext >= 0.f);
                     neg = neg && (vk - ext <= 0.f);
                 }
                 keep = pos || neg;
                 packed = (j << 24) | t;  // (t < 2^24: a 32767 x 32767 frame has 1.7e7 tiles)
+                if (BIN && keep) {  // one returning device atomic per (big triangle, tile): its place in the tile's list
+                    const int tile_id = ((bx.y >> 3) + ty) * bins.tw + (bx.x >> 3) + tx;
+                    const int pos_l = atomicAdd(bins.count + (long long)b * bins.tpi + tile_id, 1);
+                    if (pos_l < bins.cap) bins.list[((long long)b * bins.tpi + tile_id) * bins.cap + pos_l] = bx.w;
+                }
             }
+            if (BIN) continue;  // (no survivor list: nothing is tested pixel by pixel in this launch)
             const unsigned long long m = __ballot(keep);
             int base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_ns, __popcll(m));
             base = __shfl(base, 0, 64);
             if (keep) s_tiles[base + a3d_wave_prefix(m)] = packed;
         }
+        if (BIN) continue;  // (uniform)
         __syncthreads();
         const int ns = s_ns;
         for (int i = threadIdx.x; i < ns * 64; i += 256) {
@@ -333,7 +413,7 @@ __global__ __launch_bounds__(256) void rs_tri_kernel(const float4* __restrict__ 
             const int4 bx = s_box[w][qs];
             const int bwid = bx.z & 0xFFFF, bh = bx.z >> 16, ntx = (bwid + 7) >> 3, ty = t / ntx, tx = t - ty * ntx;
             const int cx = 8 * tx + (i & 7), cy = 8 * ty + ((i >> 3) & 7);
-            if (cx < bwid && cy < bh) rs_test_pixel(s_p[w][qs][0], s_p[w][qs][1], s_p[w][qs][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv);
+            if (cx < bwid && cy < bh) rs_test_pixel(s_p[w][qs][0], s_p[w][qs][1], s_p[w][qs][2], bx.x + cx, bx.y + cy, W, xs, xo, ys, yo, (unsigned)bx.w, kb, pv, exp);
         }
         __syncthreads();
         if (threadIdx.x == 0) s_ns = 0;
@@ -395,6 +475,143 @@ __global__ __launch_bounds__(256) void rs_resolve_kernel(const float4* __restric
     A3D_STAMP(1, 5);
 }
 
+// The binned path's second launch: work-group (blk, b) owns the 256 pixels of block blk of image b -- four 8x8 tiles, in the covered-pixel
+// list's order, like rs_resolve_kernel<true> -- and the four tile lists the triangle launch left.  Per chunk of 256 list entries: one
+// entry per thread (triangle id -> three vertices -> pixel box, cut to the entry's tile), the candidate pixels of the chunk POOLED and
+// dealt out evenly over the lanes (prefix + search, as in the atomic path), every covered one an atomicMin on the pixel's (depth, id)
+// key IN LDS; then one thread per pixel turns its key into the texel (the winner's barycentrics recomputed, the same operations as the
+// resolve's) and the work-group leaves the covered-pixel list's block count.  Same fragment test, same keys, same minimum: the ids are
+// the atomic path's bit for bit.  A tile whose list overflowed its capacity is not trusted: the work-group then takes EVERY triangle
+// against its four tiles (exact, slow, and reported through ``status`` so that the caller sizes the lists up).
+__global__ __launch_bounds__(256) void rs_fine_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V, int F,
+                                                      int H, int W, RsBins bins, float4* __restrict__ rast, int* __restrict__ cover_block_count,
+                                                      int* __restrict__ status) {
+    __shared__ unsigned long long s_key[256];
+    __shared__ float4 s_p[256][3];
+    __shared__ int4 s_ref[256];  // x0, y0 of (box cut to the tile), width | height << 8 | tile slot << 16, triangle id
+    __shared__ int s_pre[257];
+    __shared__ int s_n[4], s_wsum[4], s_wave[4];
+    A3D_STAMP(2, 0);  // (kernel id 2 = rs_fine_kernel)
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile0 = (int)blockIdx.x * 4;
+    if (threadIdx.x < 4) {
+        int* c = bins.count + (long long)b * bins.tpi + tile0 + threadIdx.x;
+        const int n = *c;
+        if (n) *c = 0;  // re-armed for the next call (bins_clean)
+        s_n[threadIdx.x] = n;
+    }
+    s_key[threadIdx.x] = RS_EMPTY;
+    // this thread's pixel (tile order)
+    const unsigned hw = (unsigned)H * (unsigned)W;
+    const unsigned tmine = (unsigned)tile0 + (unsigned)wv, tyw = tmine / (unsigned)bins.tw, txw = tmine - tyw * (unsigned)bins.tw;
+    const int py = (int)(tyw * 8u + ((unsigned)lane >> 3)), px = (int)(txw * 8u + ((unsigned)lane & 7u));
+    const long long i_out = (long long)b * hw + (unsigned)py * (unsigned)W + (unsigned)px;
+    __syncthreads();
+    const int c0 = s_n[0], c1 = s_n[1], c2 = s_n[2], c3 = s_n[3];
+    const int cmax = max(max(c0, c1), max(c2, c3));
+    const int blk_lin = b * (int)gridDim.x + (int)blockIdx.x;
+    if (cmax == 0) {  // nothing binned here (three blocks in four): zeros, an empty block, done
+        rast[i_out] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x == 0) cover_block_count[blk_lin] = 0;
+        A3D_STAMP(2, 5);
+        return;
+    }
+    const bool overflow = cmax > bins.cap;
+    if (threadIdx.x == 0 && cmax > bins.cap / 2) {  // (rare by construction: the caller keeps cap >= 4 x the largest count it has seen)
+        atomicMax(status, cmax);
+        if (overflow) atomicAdd(status + 1, 1);
+    }
+    const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    const int e1 = c0 + c1, e2 = e1 + c2;
+    const long long n_ref = overflow ? 4ll * F : (long long)(e2 + c3);
+    A3D_STAMP(2, 1);
+    for (long long r0 = 0; r0 < n_ref; r0 += 256) {  // (uniform)
+        const long long r = r0 + threadIdx.x;
+        int cand = 0;
+        if (r < n_ref) {
+            int j, f;
+            if (overflow) {
+                j = (int)(r / F);
+                f = (int)(r - (long long)j * F);
+            } else {
+                const int ri = (int)r;
+                j = ri < e1 ? (ri < c0 ? 0 : 1) : (ri < e2 ? 2 : 3);
+                const int e = ri - (j == 0 ? 0 : (j == 1 ? c0 : (j == 2 ? e1 : e2)));
+                f = bins.list[((long long)b * bins.tpi + tile0 + j) * bins.cap + e];
+            }
+            const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+            if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+                const float4 p0 = pb[i0], p1 = pb[i1], p2 = pb[i2];
+                int x0, y0, bw;
+                const int area = rs_box(p0, p1, p2, H, W, x0, y0, bw);
+                if (area > 0) {
+                    const unsigned tj = (unsigned)(tile0 + j), tyj = tj / (unsigned)bins.tw, txj = tj - tyj * (unsigned)bins.tw;
+                    const int X0 = max(x0, (int)txj * 8), X1 = min(x0 + bw - 1, (int)txj * 8 + 7);
+                    const int Y0 = max(y0, (int)tyj * 8), Y1 = min(y0 + area / bw - 1, (int)tyj * 8 + 7);
+                    if (X1 >= X0 && Y1 >= Y0) {
+                        cand = (X1 - X0 + 1) * (Y1 - Y0 + 1);
+                        s_p[threadIdx.x][0] = p0; s_p[threadIdx.x][1] = p1; s_p[threadIdx.x][2] = p2;
+                        s_ref[threadIdx.x] = make_int4(X0, Y0, (X1 - X0 + 1) | ((Y1 - Y0 + 1) << 8) | (j << 16), f);
+                    }
+                }
+            }
+        }
+        {   // inclusive scan of the candidate counts over the work-group
+            int incl = cand;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int k = 0; k < wv; ++k) base += s_wsum[k];
+            s_pre[threadIdx.x + 1] = base + incl;
+            if (threadIdx.x == 0) s_pre[0] = 0;
+        }
+        __syncthreads();
+        const int total = s_pre[256];
+        for (int c = threadIdx.x; c < total; c += 256) {
+            int j = 0;  // the entry that owns candidate c: largest j with pre[j] <= c
+#pragma unroll
+            for (int step = 128; step > 0; step >>= 1)
+                if (s_pre[j + step] <= c) j += step;
+            const int4 m = s_ref[j];
+            const int i = c - s_pre[j], bwc = m.z & 0xFF;
+            const int cy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwc)), cx = i - cy * bwc;  // (i < 64: exact)
+            const int qx = m.x + cx, qy = m.y + cy;
+            const RsFrag fr = rs_frag(s_p[j][0], s_p[j][1], s_p[j][2], __builtin_fmaf(xs, (float)qx, xo), __builtin_fmaf(ys, (float)qy, yo));
+            if (fr.hit) {
+                const unsigned long long key = ((unsigned long long)rs_order(fr.zw) << 32) | (unsigned)m.w;
+                atomicMin(&s_key[(((m.z >> 16) & 3) << 6) | ((qy & 7) << 3) | (qx & 7)], key);
+            }
+        }
+        __syncthreads();  // (the next chunk overwrites the entries)
+    }
+    A3D_STAMP(2, 2);
+    const unsigned long long key = s_key[threadIdx.x];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key != RS_EMPTY) {
+        const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
+        const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
+        const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
+        o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+    }
+    rast[i_out] = o;
+    const unsigned long long mk = __ballot(key != RS_EMPTY);
+    if (lane == 0) s_wave[wv] = __popcll(mk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        cover_block_count[blk_lin] = c;
+        if (c) atomicAdd(cover_block_count + (long long)gridDim.x * gridDim.y + (long long)(blk_lin / A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE, c);
+    }
+    A3D_STAMP(2, 5);
+}
+
 // backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; FOUR lanes per pixel, lane = component of the 16-byte gradient
 // row of a vertex (x, y, -, w): every lane repeats the pixel's small algebra and adds its own component, so the three adds of a
 // (pixel, vertex) pair are one request to the L2's atomic unit instead of three (line-coalesced atomics)
@@ -440,6 +657,15 @@ __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ 
 
 extern "C" size_t a3d_rast_scratch_bytes(int B, int H, int W) { return sizeof(unsigned long long) * (size_t)B * (size_t)H * (size_t)W; }
 
+// binned path: per 8x8 tile a count and a list of ``cap`` triangle ids; 0 when the frame cannot take the path (not whole tiles / blocks,
+// or more tiles per image than the bin launch counts in LDS)
+extern "C" size_t a3d_rast_bins_bytes(int B, int H, int W, int cap) {
+    if (B <= 0 || H <= 0 || W <= 0 || cap < 16 || H % 8 || W % 8 || ((long long)H * W) % 256) return 0;
+    const long long tpi = (long long)(H / 8) * (W / 8);
+    if (tpi > RS_BIN_MAX_TILES) return 0;
+    return sizeof(int) * (size_t)B * (size_t)tpi * ((size_t)cap + 1);
+}
+
 extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
                             int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream) {
     a3d_rast_opts o = {};
@@ -458,7 +684,10 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     const int32_t *normals_off = o.normals_off, *normals_adj = o.normals_adj;
     float *normals_acc_a = o.normals_acc_a, *normals_a = o.normals_a, *normals_acc_b = o.normals_acc_b, *normals_b = o.normals_b;
     A3D_CHECK_ARG(clip && rast && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
-    A3D_CHECK_ARG(F == 0 || (tri && scratch));
+    // the binned path (o.bins): taken when the frame qualifies (a3d_rast_bins_bytes != 0), the block counts are wanted (its status words
+    // live beside them) and no previous layer is peeled; otherwise the atomic path, which needs the key buffer
+    const bool binned = o.bins && o.cover_scratch && !o.prev_rast && a3d_rast_bins_bytes(B, H, W, o.bin_cap) != 0 && F > 0;
+    A3D_CHECK_ARG(F == 0 || (tri && (scratch || binned)));
     A3D_CHECK_ARG(clip_batch == 1 || clip_batch == B);
     A3D_CHECK_ARG((long long)H * W < 0x7fffffffll && B <= 65535 && H < 32768 && W < 32768);
     hipStream_t s = (hipStream_t)stream;
@@ -473,13 +702,18 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
         return A3D_OK;
     }
     unsigned long long* keys = (unsigned long long*)scratch;
-    if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
+    RsBins bins = {};
+    if (binned) {
+        bins.tw = W / 8; bins.tpi = (H / 8) * (W / 8); bins.cap = o.bin_cap;
+        bins.count = (int*)o.bins; bins.list = bins.count + (size_t)B * bins.tpi;
+        if (!o.bins_clean) A3D_HIP(hipMemsetAsync(bins.count, 0, sizeof(int) * (size_t)B * bins.tpi, s));
+    } else if (!scratch_is_clean) A3D_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)npix, s));
     A3D_CHECK_ARG((aa_screen_or_null == nullptr) == (aa_count_or_null == nullptr) && a3d_aa_shards() <= 256);
     A3D_CHECK_ARG((topo_opp_or_null == nullptr) == (topo_off_or_null == nullptr) && (topo_opp_or_null == nullptr) == (topo_adj_or_null == nullptr));
     // lanes per triangle (rs_tri_kernel), by the number of (image, triangle) pairs -- measured 1.9e5 pairs: 16.9 / 17.7 / 22.0 us with
     // 4 / 2 / 1 lanes, 7.7e5 pairs: 28.4 / 21.6 / 19.9
     const long long pairs = (long long)B * F;
-    const int lpt = pairs <= 300000 ? 4 : (pairs <= 600000 ? 2 : 1);
+    const int lpt = binned ? 1 : (pairs <= 300000 ? 4 : (pairs <= 600000 ? 2 : 1));
     const int nb_tri = a3d_div_up(F, 256 / lpt), nb_screen = aa_screen_or_null ? a3d_div_up(V, 256) : 0;
     const int nb_opp = topo_opp_or_null ? a3d_div_up(a3d_div_up(3ll * F, 256), B) : 0;  // (per row of the grid)
     RsNormalsJob nj = {};
@@ -493,15 +727,24 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
         nj.B_a = normals_B_a; nj.B_b = normals_B_b;
         nj.wg_per_row = a3d_div_up((long long)a3d_div_up(V, 256) * (normals_B_a + normals_B_b), B);
     }
-#define RS_LAUNCH_TRI(LPT_) \
-    hipLaunchKernelGGL(rs_tri_kernel<LPT_>, dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), 0, s, (const float4*)clip, clip_batch, \
+#define RS_LAUNCH_TRI(LPT_, BIN_) \
+    hipLaunchKernelGGL((rs_tri_kernel<LPT_, BIN_>), dim3(nb_tri + nb_screen + nb_opp + nj.wg_per_row, B), dim3(256), BIN_ ? sizeof(int) * bins.tpi : 0, s, \
+                       (const float4*)clip, clip_batch, \
                        tri, V, F, H, W, keys, (const float4*)prev_rast_or_null, nb_tri, (float2*)aa_screen_or_null, aa_count_or_null, \
                        a3d_aa_shards(), cover_scratch_or_null ? (int*)cover_scratch_or_null + cover_nb : nullptr, cover_ng, nb_screen, \
-                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj, a3d_exp() == 43 ? 0 : 1); \
+                       topo_off_or_null, topo_adj_or_null, topo_opp_or_null, nb_opp, nj, a3d_exp() == 43 ? 0 : 1, a3d_exp(), bins); \
 
-    if (lpt == 4) { RS_LAUNCH_TRI(4) } else if (lpt == 2) { RS_LAUNCH_TRI(2) } else { RS_LAUNCH_TRI(1) }
+    if (binned) { RS_LAUNCH_TRI(1, true) } else if (lpt == 4) { RS_LAUNCH_TRI(4, false) } else if (lpt == 2) { RS_LAUNCH_TRI(2, false) } else { RS_LAUNCH_TRI(1, false) }
 #undef RS_LAUNCH_TRI
     A3D_LAUNCH_CHECK();
+    if (binned) {
+        // status words: the second and third word of the group-sum area (unused words of its first line, zeroed by the triangle launch):
+        // the largest tile count above cap / 2, the number of blocks that overflowed
+        hipLaunchKernelGGL(rs_fine_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri, V, F, H, W,
+                           bins, (float4*)rast, (int*)cover_scratch_or_null, (int*)cover_scratch_or_null + cover_nb + 1);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
                            V, H, W, keys, (float4*)rast, (int*)cover_scratch_or_null);

@@ -123,10 +123,14 @@ static int ss_launch(const float* g, const int64_t* img, int64_t P, int C, int B
     const int vec = (C % 4 == 0 && C >= 64) ? 4 : 1;
     int CP = 1;
     while (CP < C / vec && CP < 256) CP <<= 1;
-    static const int rows = [] {  // rows per work-group; A3D_SS_ROWS is an experiment knob (tools/scratch/segsum_bench.py), read once
+#ifdef A3D_EXPERIMENT
+    static const int rows = [] {  // rows per work-group; A3D_SS_ROWS is an experiment knob (build.py --exp only), read once
         const char* e = getenv("A3D_SS_ROWS");
         return e && atoi(e) > 0 ? atoi(e) : SS_ROWS;
     }();
+#else
+    const int rows = SS_ROWS;
+#endif
     const dim3 grid(a3d_div_up(P, rows)), block(256);
     const long long* im = (const long long*)img;
     if (y) {

@@ -192,11 +192,20 @@ class SparseBuffers(dict):
         self.pix, self.bhw, self.inv = pix, bhw, inv  # inv: pixel -> row (int32 [B*H*W], -1 = uncovered) when the list came with it
         self.shade_recipe = None  # ops.ShadeRecipe when self['shaded'] has not been computed yet (the fused compositor does it on the fly)
 
+    def __getitem__(self, mode):
+        # a caller that indexes the colour directly (outside render_mesh, which hands the recipe to the compositor through ``peek``) must
+        # not see the unwritten rows of a deferred shading launch
+        if mode == "shaded" and self.shade_recipe is not None:
+            self.shade_recipe.materialize()
+        return super().__getitem__(mode)
+
+    def peek(self, mode):
+        """self[mode] without materialising a deferred colour (for the compositor call that computes it on the fly)."""
+        return super().__getitem__(mode)
+
     def dense(self, mode):
         """[B,H,W,C+1] with alpha 1 on covered pixels, zeros elsewhere (the layout render_layer returns in the reference)."""
         b, h, w = self.bhw
-        if mode == "shaded" and self.shade_recipe is not None:
-            self.shade_recipe.materialize()
         vals = self[mode]
         out = torch.zeros(b * h * w, vals.shape[-1] + 1, dtype=vals.dtype, device=vals.device)
         return out.index_copy(0, self.pix, torch.cat((vals, torch.ones_like(vals[:, :1])), dim=-1)).view(b, h, w, -1)
@@ -402,6 +411,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     LAST_POINTS[0] = None
     if (FUSED_MASK_RENDER and FUSED_COMPOSITE and material is None and lgt is None and dino_net is None and list(render_modes) == ["shaded"]
             and spp == 1 and (background is None or not background.requires_grad)):
+        _resolve_bsdf(bsdf, material)  # the reference's asserts come first (render.py:79,85): bsdf None without a material, 'pbr' without a light
         # shade() gives every covered pixel kd = (1,1,1) here (render.py:57-60, :84-85 with lgt None): the image is the coverage, and the only
         # gradient is the silhouette's.  Fauna's random-view mask (Fauna.py:111-173).  No covered-pixel list, no G-buffer, no read-back.
         bg = None if background is None else torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
@@ -442,10 +452,11 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
             if kb == "shaded" and recipe is not None:
                 recipe.materialize()  # (only the FIRST buffer of a call can be shaded on the fly)
             sh = recipe if ka == "shaded" else None
+            va = rendered.peek(ka) if sh is not None else rendered[ka]  # (peek: the compositor computes the deferred colour itself)
             if kb is None:
-                fused[ka] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, shade=sh)
+                fused[ka] = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, shade=sh)
             else:
-                fused[ka], fused[kb] = ops.composite_antialias(rendered[ka], rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
+                fused[ka], fused[kb] = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
                                                                vals2=rendered[kb], background2=bg_of(kb), shade=sh)
     if isinstance(rendered, SparseBuffers) and rendered.shade_recipe is not None and "shaded" not in fused:
         rendered.shade_recipe.materialize()  # nobody computed the colour on the fly: run the launch after all

@@ -14,7 +14,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
-from ._lib import call, f32c, ptr, require_device, stream
+from ._lib import call, f32c, f32h, ptr, require_device, stream
 
 
 # ---------------------------------------------------------------------------------------------- index caches
@@ -381,7 +381,7 @@ class _BoneTransforms(torch.autograd.Function):
         bones, angles, chain = ctx.saved_tensors
         N, K = angles.shape[0], angles.shape[1]
         g_angles = torch.empty_like(angles)
-        call("a3d_bone_transforms_bwd", ptr(f32c(g_M)), ptr(bones), bones.shape[0], ptr(angles), ptr(chain), N, K, chain.shape[1], ptr(g_angles),
+        call("a3d_bone_transforms_bwd", ptr(f32h(g_M)), ptr(bones), bones.shape[0], ptr(angles), ptr(chain), N, K, chain.shape[1], ptr(g_angles),
              stream())
         return None, g_angles, None
 
@@ -418,7 +418,7 @@ class _Skin(torch.autograd.Function):
         clear = g_T is not None
         if g_T is None:
             g_T = torch.empty_like(T)
-        call("a3d_skin_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, ctx.temperature, ptr(g_v),
+        call("a3d_skin_bwd", ptr(f32h(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), B, V, K, ctx.temperature, ptr(g_v),
              ptr(g_T), int(clear), stream())
         if g_v is not None and v.shape[0] == 1 and B > 1:
             g_v = g_v.sum(0, keepdim=True)  # shared canonical mesh: per-image partials, reduced here (no 16-way atomic contention)
@@ -463,8 +463,8 @@ class _SkinPose(torch.autograd.Function):
         clear = g_angles is not None
         if g_angles is None:
             g_angles = torch.empty_like(angles)
-        call("a3d_skin_pose_bwd", ptr(f32c(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), ptr(products), ptr(angles), ptr(chain), B, V, K, D,
-             ctx.temperature, ptr(g_v), ptr(None if g_T_ext is None else f32c(g_T_ext)), ptr(g_angles), int(clear), stream())
+        call("a3d_skin_pose_bwd", ptr(f32h(g_out)), ptr(v), v.shape[0], ptr(bones), bones.shape[0], ptr(T), ptr(products), ptr(angles), ptr(chain), B, V, K, D,
+             ctx.temperature, ptr(g_v), ptr(None if g_T_ext is None else f32h(g_T_ext)), ptr(g_angles), int(clear), stream())
         if g_v is not None and v.shape[0] == 1 and B > 1:
             g_v = g_v.sum(0, keepdim=True)
         return g_v, None, g_angles, None, None
@@ -659,7 +659,10 @@ def _cover_counted(rast, tile):
         scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=rast.device)
         call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
     nb = _lib.lib().a3d_cover_blocks(B, H, W)
-    return scratch, int(scratch[nb:].cpu().sum())
+    tail = scratch[nb:].cpu()  # THE read-back: one sum per group of 64 blocks, one per 64-byte line; words 1, 2 of the first line: the binned rasteriser's status
+    if tail.shape[0] > 2 and int(tail[1]) > 0:
+        _rast_bins_grow((rast.device, B, H, W), int(tail[1]), int(tail[2]))
+    return scratch, int(tail[::_lib.lib().a3d_cover_group_stride()].sum())
 
 
 def covered_pixels(rast, tile=8, return_inverse=False):
@@ -682,6 +685,25 @@ def covered_pixels(rast, tile=8, return_inverse=False):
 
 # ---------------------------------------------------------------------------------------------- rasterise
 _rast_keys = {}
+# the binned path (a3d_rast_opts.bins: per-tile triangle lists + a fine pass, no memory-side atomics): its scratch is kept per (device,
+# stream, frame) like the key buffer (the fine pass leaves the tile counts at zero), the capacity of a tile list per (device, frame):
+# 256 entries to start with, 4 x the largest count ever reported above half the capacity (the covered-pixel read-back carries the
+# report).  An overflowing tile is still rasterised exactly -- by the slow route inside the fine pass -- so the capacity is a matter of
+# speed only; memory is not a constraint (256 entries: 17 MB at B = 16, 256 x 256).
+RASTER_BINNED = os.environ.get("A3D_RASTER_BINNED", "1") != "0"
+RASTER_BIN_CAP0 = 256
+_rast_bins = {}
+_rast_bin_caps = {}
+rast_bin_events = dict(grown=0, overflowed_blocks=0)
+
+
+def _rast_bins_grow(key, max_count, overflowed):
+    cap = _rast_bin_caps.get(key, RASTER_BIN_CAP0)
+    want = 1 << max(4, int(4 * max_count - 1).bit_length())
+    rast_bin_events["overflowed_blocks"] += overflowed
+    if want > cap and want <= (1 << 16):
+        _rast_bin_caps[key] = want
+        rast_bin_events["grown"] += 1
 
 
 class _Rasterize(torch.autograd.Function):
@@ -693,10 +715,6 @@ class _Rasterize(torch.autograd.Function):
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=clip.device)
         # the (depth, id) key buffer is kept per (device, stream, size): the resolve leaves it armed, so only its first use pays the clear
         key = (clip.device, stream(), B, H, W)
-        scratch = _rast_keys.pop(key, None)
-        clean = scratch is not None
-        if scratch is None:
-            scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
         if prev is not None:
             prev = f32c(prev.detach())
             assert prev.shape == (B, H, W, 4)
@@ -704,6 +722,20 @@ class _Rasterize(torch.autograd.Function):
         cover = None
         if H % 8 == 0 and W % 8 == 0 and (H * W) % 256 == 0 and F > 0:
             cover = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=clip.device)
+        # binned path (per-tile triangle lists, no key buffer) when the frame qualifies; otherwise the atomic path and its key buffer
+        bins = None
+        if RASTER_BINNED and cover is not None and prev is None:
+            cap = _rast_bin_caps.get((clip.device, B, H, W), RASTER_BIN_CAP0)
+            bins = _rast_bins.pop(key, None)
+            if bins is None or bins[1] != cap:
+                nbytes = _lib.lib().a3d_rast_bins_bytes(B, H, W, cap)
+                bins = (torch.empty(nbytes, dtype=torch.uint8, device=clip.device), cap, False) if nbytes else None
+        scratch, clean = None, False
+        if bins is None:
+            scratch = _rast_keys.pop(key, None)
+            clean = scratch is not None
+            if scratch is None:
+                scratch = torch.empty(_lib.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=clip.device)
         # ... and so does what the silhouette analysis of this frame needs first (pixel-space vertex positions, zeroed append counters):
         # AAAnalysis picks them up when it is built for this raster buffer and this clip tensor
         aa_screen = aa_count = None
@@ -733,8 +765,14 @@ class _Rasterize(torch.autograd.Function):
             opts.normals_off, opts.normals_adj = ptr(job.adjacency.off), ptr(job.adjacency.adj)
             opts.normals_acc_a, opts.normals_a, opts.normals_acc_b, opts.normals_b = ptr(job.acc_a), ptr(job.nrm_a), ptr(job.acc_b), ptr(job.nrm_b)
         opts.lists_stride = stride
+        if bins is not None:
+            opts.bins, opts.bin_cap, opts.bins_clean = ptr(bins[0]), bins[1], int(bins[2])
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ctypes.addressof(opts), stream(),
              tag="" if job is None else f"[N{opts.normals_B_a}+{opts.normals_B_b}]")
+        if bins is not None:
+            if len(_rast_bins) >= 4:
+                _rast_bins.clear()
+            _rast_bins[key] = (bins[0], bins[1], bool(bins[2]) or F > 0)  # (after a successful call its fine pass left every tile count at zero; F == 0 launches nothing)
         if job is not None:
             job.done = True
         if opp is not None:
@@ -746,8 +784,8 @@ class _Rasterize(torch.autograd.Function):
             _aa_prepared.put(rast.detach(), (_IdentityCache.key(clip), aa_screen, aa_count, clip.detach()))
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
-        if F > 0 or clean:  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching them: a fresh
-            _rast_keys[key] = scratch  # torch.empty buffer must not come back as "clean"; a failed call leaves the buffer out too)
+        if scratch is not None and (F > 0 or clean):  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching
+            _rast_keys[key] = scratch  # them: a fresh torch.empty buffer must not come back as "clean"; a failed call leaves the buffer out too)
         ctx.save_for_backward(clip, tri32, rast)
         return rast
 
@@ -756,7 +794,7 @@ class _Rasterize(torch.autograd.Function):
         clip, tri32, rast = ctx.saved_tensors
         B, H, W = rast.shape[:3]
         g_clip = torch.empty_like(clip)
-        call("a3d_rast_bwd", ptr(f32c(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
+        call("a3d_rast_bwd", ptr(f32h(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
              ptr(g_clip), stream())
         return g_clip, None, None, None, None, None, None
 
@@ -818,7 +856,7 @@ class _Interpolate(torch.autograd.Function):
         V, C = attr.shape[1], attr.shape[2]
         g_attr = torch.empty_like(attr) if ctx.needs_input_grad[0] else None
         g_rast = torch.empty_like(rast)
-        call("a3d_interp_bwd", ptr(f32c(g_out)), ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(g_attr),
+        call("a3d_interp_bwd", ptr(f32h(g_out)), ptr(attr), attr.shape[0], C, ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(g_attr),
              ptr(g_rast), stream(), tag=f"[C{C}]")
         return g_attr, (g_rast if ctx.needs_input_grad[1] else None), None
 
@@ -910,9 +948,9 @@ class _GBuffer(torch.autograd.Function):
         clear = rows is not None
         if rows is None:
             rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
-        call("a3d_gbuffer_bwd", ptr(f32c(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
+        call("a3d_gbuffer_bwd", ptr(f32h(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
              ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(clear), int(want_prior), ptr(extra), E,
-             None if extra is None else ptr(f32c(g_extra_out)), stream())
+             None if extra is None else ptr(f32h(g_extra_out)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None
@@ -989,7 +1027,7 @@ class _ShadePoints(torch.autograd.Function):
         if g_par is None:
             g_par = torch.empty_like(par)
         g_kd = torch.empty((P, 3), dtype=torch.float32, device=gb.device) if kd is not None else None
-        opt = lambda t: None if t is None else f32c(t)
+        opt = lambda t: None if t is None else f32h(t)
         call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(img), par.shape[0], ptr(kd),
              ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), int(clear), stream())
         return g_gb, g_par, g_kd, None, None, None
@@ -1098,7 +1136,7 @@ class _RowsAddReLU(torch.autograd.Function):
 
 def rows_add_relu_raw_(y, rows, img):
     """In place, no autograd: y[p] = relu(y[p] + rows[img[p]]) (used inside hostnets' stack Function)."""
-    call("a3d_rows_add_relu_fwd", ptr(y), ptr(f32c(rows)), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream(), tag=f"[C{y.shape[1]}]")
+    call("a3d_rows_add_relu_fwd", ptr(y), ptr(f32h(rows)), ptr(img), y.shape[0], y.shape[1], rows.shape[0], stream(), tag=f"[C{y.shape[1]}]")
     return y
 
 
@@ -1190,7 +1228,7 @@ class _Antialias(torch.autograd.Function):
         B, H, W, C = color.shape
         g_color = torch.empty_like(color)
         g_clip = torch.empty_like(a.clip)
-        call("a3d_aa_bwd", ptr(f32c(g_out)), ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri),
+        call("a3d_aa_bwd", ptr(f32h(g_out)), ptr(color), C, ptr(a.work), ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri),
              B, a.clip.shape[1], a.topo.tri.shape[0], H, W, ptr(g_color), ptr(g_clip), stream(), tag=f"[C{C}]")
         return g_color, g_clip, None
 
@@ -1221,6 +1259,8 @@ class _CompositeAntialias(torch.autograd.Function):
         tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
         use_shade = shade is not None and shade.filled and not getattr(shade, "materialized", False) and C == 3 and shade.outs[2].data_ptr() == vals.data_ptr()
+        if shade is not None and shade.filled and not use_shade:
+            shade.materialize()  # (a recipe this call cannot apply -- copied rows, another channel count: ``vals`` is still unwritten: run the launch)
         sh = shade.struct(clear=True) if use_shade else None
         buf = lambda v, c, g, o: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), out=ptr(o), bg_batch=0 if g is None else g.shape[0])
         first, second = buf(None if use_shade else vals, C, bg, out), (buf(vals2, C2, bg2, out2) if vals2 is not None else None)
@@ -1313,7 +1353,7 @@ class _MaskAntialias(torch.autograd.Function):
         rast_c, bg = ctx.saved_tensors
         a, C = ctx.analysis, ctx.C
         g_clip = torch.empty_like(a.clip)
-        call("a3d_mask_aa_bwd", ptr(f32c(g_out)), ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
+        call("a3d_mask_aa_bwd", ptr(f32h(g_out)), ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
              ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip), stream(), tag=f"[C{C + 1}]")
         return None, g_clip, None, None, None
 
@@ -1354,7 +1394,7 @@ class _ReconLosses(torch.autograd.Function):
         D = 0 if dino is None else dino.shape[3]
         g_shaded = torch.empty_like(shaded)
         g_dino = torch.empty_like(dino) if D else None
-        call("a3d_recon_losses_bwd", ptr(f32c(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1),
+        call("a3d_recon_losses_bwd", ptr(f32h(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1),
              dt0.stride(0), ptr(valid), B, H, W, ptr(both), ptr(g_shaded), ptr(g_dino), stream())
         return g_shaded, g_dino, None, None, None, None, None, None
 
@@ -1396,7 +1436,7 @@ class _FlowLoss(torch.autograd.Function):
         flow, flow_gt, both, scale = ctx.saved_tensors
         B, F, H, W = ctx.dims
         g_flow = torch.empty((B * F, H, W, 2), dtype=torch.float32, device=flow.device)
-        call("a3d_flow_loss_bwd", ptr(f32c(g_loss)), ptr(scale), ptr(flow), flow.stride(2), ptr(flow_gt), ptr(both), B, F, H, W, ptr(g_flow), stream())
+        call("a3d_flow_loss_bwd", ptr(f32h(g_loss)), ptr(scale), ptr(flow), flow.stride(2), ptr(flow_gt), ptr(both), B, F, H, W, ptr(g_flow), stream())
         return g_flow, None, None, None, None
 
 
@@ -1426,7 +1466,7 @@ class _HarmonicEmbed(torch.autograd.Function):
     def backward(ctx, g):
         x, freq = ctx.saved_tensors
         g_x = torch.empty_like(x)
-        call("a3d_harmonic_embed_bwd", ptr(f32c(g)), ptr(x), ptr(freq), freq.shape[0], ctx.cfg[0], ctx.cfg[1], x.shape[0], ptr(g_x), stream())
+        call("a3d_harmonic_embed_bwd", ptr(f32h(g)), ptr(x), ptr(freq), freq.shape[0], ctx.cfg[0], ctx.cfg[1], x.shape[0], ptr(g_x), stream())
         return g_x, None, None, None
 
 
@@ -1464,3 +1504,6 @@ def _amp_wrap_functions():
 
 
 _amp_wrap_functions()
+
+if _lib.GUARD:  # A3D_GUARD in the environment: guarded allocations from the first call on (see _lib.set_guard)
+    _lib.set_guard(_lib.GUARD)

@@ -76,6 +76,28 @@ def synthetic_quadruped_device(pts, leg_radius):
     return torch.maximum(body, capsules.amax(-1))
 
 
+# A "trained-like" mesh the driver can see (bench.py --mesh spiky): what the synthetic training drifts into after a few hundred optimiser
+# steps is the quadruped with a percent of its vertices pulled out into thin spikes (profiles/r04_long_run_diag.txt, step 600: mean
+# pixel box 36, a few boxes of 9e3 pixels, 3.1e5 covered pixels where the fresh mesh has 14 / 129 / 2.0e5) -- and the rasteriser's and
+# the compositor backward's cost follow depth complexity and silhouette length.  The spikes are a fixed, smooth displacement field of
+# the CANONICAL position (sparse peaks of a product of sines, pushed radially away from the body axis), added to the rest vertices where
+# the instance deformation is added (InstancePredictorBase.py:306-313): an input generator like the quadruped SDF, shared with the oracle.
+# (two scales: narrow peaks = the few spikes of thousands of pixels; broad, low bumps = the tenth of the triangles stretched above 64)
+SPIKES = dict(omega=8.0, tau=0.93, length=3.0, gamma=1.0, phase=(0.3, 1.1, 2.0), omega2=3.5, tau2=0.5, length2=0.5, phase2=(1.7, 0.2, 0.9),
+              centre=(0.0, 0.45, 0.0))
+
+
+def synthetic_spikes(pts, params=None):
+    """[...,3] canonical positions -> [...,3] displacement (zero off the peaks).  Pure torch, any device / dtype."""
+    q = dict(SPIKES, **(params or {}))
+    amp = 0.0
+    for om, tau, length, ph in ((q["omega"], q["tau"], q["length"], q["phase"]), (q["omega2"], q["tau2"], q["length2"], q["phase2"])):
+        g = torch.sin(om * pts + pts.new_tensor(ph)).prod(-1).abs()
+        amp = amp + length * ((g - tau) / (1.0 - tau)).clamp(min=0.0) ** q["gamma"]
+    d = pts - pts.new_tensor(q["centre"])
+    return amp[..., None] * d / d.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+
+
 FUSED_LOSSES = True  # reconstruction losses as one HIP kernel each way (csrc/losses.hip) instead of ~45 torch launches
 
 WORKLOADS = ("magicpony", "fauna", "ponymation")
@@ -101,14 +123,17 @@ class SyntheticScene(torch.nn.Module):
 
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
                  embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None,
-                 workload="magicpony", num_frames=1, deform=False, pose_seed=0, grid=None):
+                 workload="magicpony", num_frames=1, deform=False, pose_seed=0, grid=None, mesh="quadruped", spikes=None):
         """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
         data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter.
         ``grid``: a tetgrid.named_grid name ('bcc51s' = the reference's "128" Quartet class in a file's arbitrary numbering) instead of
         the Kuhn grid of ``grid_res`` cells.
-        ``pose_seed`` != 0 draws other cameras / articulations with the SAME networks (per-rank poses: unequal covered-pixel counts)."""
+        ``pose_seed`` != 0 draws other cameras / articulations with the SAME networks (per-rank poses: unequal covered-pixel counts).
+        ``mesh`` = 'spiky': the trained-like mesh (synthetic_spikes; ``spikes`` overrides entries of SPIKES)."""
         super().__init__()
         assert workload in WORKLOADS, workload
+        assert mesh in ("quadruped", "spiky"), mesh
+        self.mesh_kind, self.spike_params = mesh, (dict(SPIKES, **(spikes or {})) if mesh == "spiky" else None)
         assert num_frames == 1 or workload == "ponymation"
         data_seed = seed if data_seed is None else data_seed
         self.workload, self.num_frames, self.deform = workload, int(num_frames), bool(deform)
@@ -190,6 +215,12 @@ class SyntheticScene(torch.nn.Module):
             if self.workload == "fauna":  # "estimate bones every iteration for fauna" (InstancePredictorFauna.py:91-92)
                 self._estimate_bones(prior)
         rest, deformation = prior.v_pos[None], None  # [1,1,V,3]
+        spikes = None
+        if self.spike_params is not None:
+            with torch.no_grad():
+                spikes = synthetic_spikes(prior.v_pos.detach(), self.spike_params)  # [1,V,3], a constant of this step's canonical mesh
+            rest = rest + spikes[None]
+        self.last["spikes"] = spikes
         if self.deform and with_nets:
             V = prior.v_pos.shape[1]
             if getattr(self, "_frame_of_vertex", None) is None or self._frame_of_vertex.shape[0] != N * V:
@@ -197,6 +228,8 @@ class SyntheticScene(torch.nn.Module):
             # netDeform(verts, feat) * 0.1 (InstancePredictorBase.py:309-312): the feature enters as one row per frame + an index
             deformation = self.netDeform.sample(prior.v_pos.expand(N, -1, -1).reshape(N * V, 3), feat=self.feat,
                                                 feat_index=self._frame_of_vertex).view(N, V, 3) * 0.1
+            if spikes is not None:
+                deformation = deformation + spikes
             deformed = prior.deform(deformation)  # make_mesh over the N deformed meshes (InstancePredictorBase.py:313)
             rest = deformed.v_pos.view(B, F, V, 3)
             self.last["deformed"] = deformed

@@ -135,19 +135,22 @@ def algorithmic_bytes(name, d):
         # emit: bit planes in; per surface vertex: index pair, 2 sdf, 2 positions in, vertex + edge row out; per face: half a tet2edge row in,
         # 48 bytes of int64 indices out
         "a3d_dmtet_emit": dm_planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V) + 4 * Nv,  # (+ the dense SDF gradient it clears for the backward)  # (+ the vertex -> face lists it now writes itself)  # (+ the int32 triangle list of the render kernels)
-        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 8 * V + 24 * V + 2 * 32 * V,  # g_verts, edge row, index pair, 2 sdf, 2 positions in; two atomics out (32 B each on the memory side)
+        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 8 * V + 24 * V + 8 * V,  # g_verts, edge row, index pair, 2 sdf, 2 positions in; two 4-byte adds out (what the memory side makes of them is traffic, not credit)
         "a3d_skin_fwd": 12 * V + 12 * B * V,
         "a3d_skin_bwd": 12 * B * V + 12 * V + 12 * V + 48 * B * K,
         # chain + skinning in one launch: skin_fwd's bytes + the bones / angles in and the transforms (+ chain products) out
         # (rest vertices in and -- backward -- their gradient out: per image when the instance deformation moved them (Bv = B), else once)
-        "a3d_skin_pose_fwd": 12 * Bv * V + 12 * B * V + B * K * (12 + 48 + 24) + B * K * 8 * 96,
-        "a3d_skin_pose_bwd": 12 * B * V + 12 * Bv * V + 12 * Bv * V + 48 * B * K + B * K * (12 + 48 + 12 + 24) + B * K * 8 * 96,
+        # (round 5: the chain-product scratch the forward leaves for the backward, B K 8 96 bytes each way, is staging -- not credited)
+        "a3d_skin_pose_fwd": 12 * Bv * V + 12 * B * V + B * K * (12 + 48 + 24),
+        "a3d_skin_pose_bwd": 12 * B * V + 12 * Bv * V + 12 * Bv * V + 48 * B * K + B * K * (12 + 48 + 12 + 24),
         "a3d_normals_adjacency": 24 * F + 4 * V,  # triangle list in, CSR out
         "a3d_mesh_topology": 12 * F + (4 * V + 12 * F) + 12 * F,  # triangle list in; CSR + opposite-vertex table out
         "a3d_mesh_topology_finalize": 12 * F + 4 * V + (4 * V + 12 * F),  # int32 triangle list + valence counts in; offsets + lists out
         "a3d_normals_fwd": 4 * V + 24 * F + Bn * (36 * F + 24 * V),  # CSR + indices once; per image position gathers, acc + nrm out
-        # faces first: per image the three corners' positions, acc and normal gradients per face in, 36 B per face out and in again, 12 B per vertex out
-        "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 72 * F + 72 * F + 12 * V),
+        # SURVEY 8d "bwd same order": CSR + indices once; per image the position gathers, the accumulated normal and its incoming gradient per
+        # vertex in, the position gradient out.  (round 5: the per-face intermediate of the faces-first form -- 72 F B written and read back --
+        # and the per-corner re-reads of per-vertex data are staging, not credited)
+        "a3d_normals_bwd": 4 * V + 24 * F + Bn * (36 * F + 24 * V + 12 * V),
         "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
         "a3d_rast_bwd": B * (32 * HW + 16 * V),
         "a3d_interp_fwd": B * (16 * HW + 4 * C * HW),
@@ -186,6 +189,18 @@ def algorithmic_bytes(name, d):
     return table.get(base)
 
 
+def _pixel_boxes(sc):
+    """Pixel-box statistics of the mesh a scene rendered last (what the rasteriser's cost follows): mean / max box, share above 64 px."""
+    clip, tri = sc.last["points"]["clip"], sc.last["shape"].t_pos_idx[0]
+    H, W = sc.resolution
+    ndc = clip[..., :2] / clip[..., 3:].clamp(min=1e-6)
+    c = ((ndc * 0.5 + 0.5) * torch.tensor([W, H], dtype=torch.float32, device=clip.device))[:, tri]
+    ext = c.amax(2) - c.amin(2)
+    area = (ext[..., 0].clamp(0, W) + 1) * (ext[..., 1].clamp(0, H) + 1)
+    return dict(box_px_mean=round(float(area.mean()), 1), box_px_max=round(float(area.max())), box_px_sum_M=round(float(area.sum()) / 1e6, 2),
+                frac_boxes_above_64px=round(float((area > 64).float().mean()), 4))
+
+
 def _cover_blocks(rast):
     """256-pixel blocks (four 8x8 tiles, tile-row-major: the covered-pixel list's order) of the frame that hold a covered pixel."""
     Bf, H, W = rast.shape[:3]
@@ -207,8 +222,12 @@ def _aggregate(kernels, prefixes):
     tot_t = sum(v["mean_us"] * v["launches_per_step"] for v in sel.values()) * 1e-6
     if tot_t <= 0:
         return None
+    # frac = total bytes / total time (every microsecond counts alike: the figure the latency-bound calls pull down); frac_bytes_weighted =
+    # the mean of the entry points' own fractions weighted by the bytes they move (what a byte of this path sees on average)
+    wfrac = sum(v["algorithmic_MB"] * v["launches_per_step"] * v["GBps"] / HBM_PEAK_GBS for v in sel.values()) * 1e6 / max(tot_b, 1.0)
     return dict(us_per_step=round(tot_t * 1e6, 1), algorithmic_MB_per_step=round(tot_b / 1e6, 1), GBps=round(tot_b / tot_t / 1e9, 1),
-                frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4), entry_point_calls_per_step=round(sum(v["launches_per_step"] for v in sel.values()), 1))
+                frac=round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4), frac_bytes_weighted=round(wfrac, 4),
+                entry_point_calls_per_step=round(sum(v["launches_per_step"] for v in sel.values()), 1))
 
 
 def kernel_pass(scene, module, L, steps, world, dims_of, train=True):
@@ -267,6 +286,59 @@ def roofline_of(kernels, dims, signature=PMC_WORKLOAD):
                                  frac=round(tf / MFMA_FP32_PEAK_TFLOPS, 4), launch_us=net[gemm]["mean_us"], launches_per_step=net[gemm]["launches_per_step"])
     roof["networks_side"] = side
     return roof
+
+
+def box_fingerprint(L, dev, scene_step=None, wall_ms_per_step=None):
+    """What THIS box gives, so that a slow box and a regression can be told apart in a committed line: the shader / memory clocks the driver
+    reports, a 92 MB streaming fill and read (the bytes the compositor writes per step; a3d_bw_probe_*, HIP events, best of 20), and --
+    with ``scene_step`` -- the GPU-busy time of a step (sum of all kernel durations, torch.profiler over 3 steps) against its wall time:
+    host_bound_frac = 1 - busy / wall is the share of the step during which the GPU waited for the host."""
+    import subprocess
+
+    fp = {"device": torch.cuda.get_device_name(dev)}
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        fp["clocks"] = {k.split(" clock")[0]: v for k, v in card.items() if k.startswith(("sclk", "mclk", "fclk"))}
+    except Exception as e:  # (best effort: the tool may be missing in a container)
+        fp["clocks"] = f"unavailable ({type(e).__name__})"
+    n = 92 * 1000 * 1000 // 16 * 4  # floats: 92 MB
+    buf, sink = torch.empty(n, dtype=torch.float32, device=dev), torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def best(fn):
+        ts = []
+        for _ in range(20):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return min(ts)
+
+    fill_ms = best(lambda: L.call("a3d_bw_probe_fill", L.ptr(buf), n, L.stream()))
+    read_ms = best(lambda: L.call("a3d_bw_probe_read", L.ptr(buf), n, L.ptr(sink), L.stream()))
+    fp["fill_92MB"] = dict(us=round(fill_ms * 1e3, 1), GBps=round(4 * n / fill_ms / 1e6, 1))
+    fp["read_92MB"] = dict(us=round(read_ms * 1e3, 1), GBps=round(4 * n / read_ms / 1e6, 1))
+    fp["note"] = ("fill / read: event time of ONE launch incl. its launch latency (~3 us); DESIGN.md section 4 measured 15.4 us = 6.3 TB/s for the fill "
+                  "on the round-4 boxes")
+    if scene_step is not None:
+        try:
+            from torch.profiler import ProfilerActivity, profile
+
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for _ in range(3):
+                    scene_step()
+                torch.cuda.synchronize()
+            busy_us = sum(e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in prof.key_averages()) / 3.0
+            fp["gpu_busy_ms_per_step"] = round(busy_us / 1e3, 3)
+            if wall_ms_per_step:
+                fp["wall_ms_per_step"] = round(wall_ms_per_step, 3)
+                fp["host_bound_frac"] = round(max(0.0, 1.0 - busy_us / 1e3 / wall_ms_per_step), 4)
+        except Exception as e:
+            fp["gpu_busy_ms_per_step"] = f"unavailable ({type(e).__name__}: {str(e)[:80]})"
+    return fp
 
 
 def parity_and_cpu_baseline(scene, args, threads):
@@ -388,6 +460,11 @@ def main():
                     help="fast: the output-identical field evaluation of hostnets (headline); reference: model/networks' own formulation "
                          "(per-point feature concat, per-call frequency upload, no TunableOp, no fused kernels); both: headline = fast, and "
                          "the reference formulation is measured too (single GPU only) and reported under 'dropin'")
+    ap.add_argument("--mesh", choices=("quadruped", "spiky"), default="quadruped", help="spiky: the trained-like mesh (pipeline.synthetic_spikes: the "
+                    "quadruped with a percent of its vertices pulled into thin spikes, tuned to the step-600 statistics of the long run); the default "
+                    "line carries it as extra_legs.spiky anyway")
+    ap.add_argument("--no-spiky-leg", action="store_true", help="skip the extra leg on the trained-like mesh (default line, 1 GPU, magicpony)")
+    ap.add_argument("--no-fingerprint", action="store_true", help="skip the box fingerprint (clocks, 92 MB fill / read probe, GPU-busy time per step)")
     ap.add_argument("--no-deform", action="store_true", help="magicpony without the instance deformation (the round-1 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (parity and cpu_baseline = null)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
@@ -434,12 +511,12 @@ def main():
     batch = args.batch if args.batch is not None else (8 if args.workload == "ponymation" else 16)
     frames = args.frames if args.workload == "ponymation" else 1
 
-    def make_scene(workload=args.workload, per_rank_poses=args.per_rank_poses):
+    def make_scene(workload=args.workload, per_rank_poses=args.per_rank_poses, mesh=args.mesh):
         b = batch if (workload == args.workload or args.workload != "ponymation") else 16  # (ponymation's --batch counts sequences)
         return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=b, resolution=(args.resolution, args.resolution), device=dev, seed=0,
                                        data_seed=1000 * rank, workload=workload, num_frames=frames if workload == "ponymation" else 1,
                                        deform=(workload == "magicpony" and not args.no_deform),
-                                       pose_seed=(rank if per_rank_poses else 0))
+                                       pose_seed=(rank if per_rank_poses else 0), mesh=mesh)
 
     scene = make_scene()
     scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
@@ -511,6 +588,31 @@ def main():
     if rank == 0 and not args.no_kernel_timing:
         kernels, dims = kernel_pass(scene, module, L, min(args.steps, 10), world, dims_of, train)
         roofline = roofline_of(kernels, dims, workload_signature(args, batch))
+
+    # ---- the trained-like mesh as an extra leg of the default line: the 25-step-old near-ellipsoid is the cheapest mesh
+    # this path will ever see; the reference trains for 1e5 iterations (config/model/magicpony.yaml:31-33).  Same step, same networks, the
+    # spiky mesh: images/s, in-scope time, and the two calls whose cost follows depth complexity and silhouette length.
+    if (rank == 0 and world == 1 and train and args.workload == "magicpony" and args.mesh == "quadruped" and not args.no_spiky_leg
+            and not args.no_kernel_timing):
+        sp = make_scene(mesh="spiky")
+        sp_steps = max(5, min(args.steps, 20))
+        t = du.timed_steps(lambda: sp.step(backward=True), sp_steps, 3, device=dev)
+        sp_kernels, sp_dims = kernel_pass(sp, None, L, min(sp_steps, 10), 1, dims_of, True)
+        agg = _aggregate(sp_kernels, IN_SCOPE)
+        pick = lambda pre: next((round(v["mean_us"], 2) for k, v in sp_kernels.items() if k.startswith(pre)), None)
+        box = _pixel_boxes(sp)
+        extra_legs["spiky"] = dict(value=round(sp.frames * sp_steps / t, 3), unit="images/s", ms_per_step=round(t / sp_steps * 1e3, 3), steps=sp_steps,
+                                   in_scope_us_per_step=agg["us_per_step"], in_scope_frac=agg["frac"], rast_fwd_us=pick("a3d_rast_fwd"),
+                                   composite_aa_fwd_us=pick("a3d_composite_aa_fwd"), composite_aa_bwd_us=pick("a3d_composite_aa_bwd"),
+                                   gbuffer_bwd_us=pick("a3d_gbuffer_bwd"), mesh=dict(V=sp_dims["V"], F=sp_dims["F"], P=sp_dims["P"], **box),
+                                   headline_mesh=_pixel_boxes(scene),
+                                   note="pipeline.SPIKES; the long run it stands for, step 600 (profiles/r04_long_run_diag.txt): box mean 35.7, max 9375, "
+                                        "3.07e5 covered pixels")
+        del sp
+
+    fingerprint = None
+    if rank == 0 and not args.no_fingerprint:
+        fingerprint = box_fingerprint(L, dev, (lambda: scene.step(module=module, backward=train)) if world == 1 else None, elapsed / args.steps * 1e3)
 
     # ---- blocking host <-> device synchronisations inside one steady-state step (torch's sync-debug hook; sizes that shapes depend on)
     host_syncs = None
@@ -605,7 +707,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
-                       "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
+                       "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "mesh": args.mesh, "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
                        "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)",
                        "per_rank_data": ("per-rank poses/cameras, image features and targets (covered pixels differ per rank)" if args.per_rank_poses else
@@ -615,9 +717,11 @@ def main():
             "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None),
             "in_scope_us_per_step": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["us_per_step"],
             "in_scope_frac": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["frac"],
+            "in_scope_frac_bytes_weighted": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["frac_bytes_weighted"],
             "in_scope_calls_per_step": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["entry_point_calls_per_step"],
             "dropin_images_per_s": None if dropin is None else dropin["value"],
             "parity_pass": None if parity is None else bool(parity.get("pass")),
+            "box": fingerprint,
             "roofline": roofline,
             "host_syncs": host_syncs,
             "parity": parity,

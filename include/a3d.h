@@ -31,8 +31,15 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 401 = this header */
+int a3d_version(void); /* 402 = this header */
 const char* a3d_last_error(void);
+
+/* Box fingerprint for the benchmark line (no reference counterpart: the reference's meter, /root/reference/model/utils/meters.py:119, reports
+ * images/s only): a streaming fill of `n_floats` floats (one non-temporal 16-byte store per thread, 256 threads per work-group) and a
+ * grid-stride streaming read of the same range; bench.py times both with HIP events on `stream` and prints the GB/s beside every
+ * kernel's figure.  `dst` / `src` 16-byte aligned, n_floats a multiple of 4; `sink` = one float nobody reads. */
+int a3d_bw_probe_fill(float* dst, int64_t n_floats, a3d_stream_t stream);
+int a3d_bw_probe_read(const float* src, int64_t n_floats, float* sink, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DMTet marching tetrahedra -- replaces DMTet.__call__ + map_uv index part,
@@ -306,7 +313,18 @@ typedef struct a3d_rast_opts {
     float* normals_b;
     int32_t normals_B_a;
     int32_t normals_B_b;
+    /* (402) the BINNED path -- the triangle launch appends every triangle to the list of each 8x8 tile its pixel box touches, a second
+     * launch (one work-group per 256-pixel block) runs the fragment tests per tile with the depth test in LDS and writes the texels: no
+     * memory-side atomics on the frame, no key buffer, no resolve pass; the same triangle ids bit for bit.  Taken when bins != NULL,
+     * cover_scratch != NULL, prev_rast == NULL and a3d_rast_bins_bytes(B, H, W, bin_cap) != 0; `scratch` may then be NULL.  A tile whose
+     * list overflows bin_cap is rasterised exactly all the same (its block takes every triangle); the third word of the group-sum area
+     * of cover_scratch counts such blocks and the second holds the largest tile count above bin_cap / 2 (0 = none), for the caller to
+     * size the lists by.  bins_clean: the tile counts are zero (as the previous call on the same stream left them). */
+    void* bins;                    /* a3d_rast_bins_bytes(B, H, W, bin_cap) bytes */
+    int32_t bin_cap;               /* entries per tile list (>= 16) */
+    int32_t bins_clean;
 } a3d_rast_opts;
+size_t a3d_rast_bins_bytes(int B, int H, int W, int bin_cap); /* 0: the frame cannot take the binned path */
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,

@@ -162,6 +162,8 @@ def compare_step(scene, out, n_images=None, end_to_end=True):
         rep["max_abs_deform_add_err"] = float((rest.view(n, V, 3) - (_cpu(prior.v_pos) + _cpu(scene.last["deformation"])[:n])).abs().max())
     else:
         rest = _cpu(prior.v_pos)[None]
+        if scene.last.get("spikes") is not None:  # the trained-like mesh: the spike field on the canonical vertices (an input generator)
+            rest = rest + _cpu(scene.last["spikes"])[None]
     bones = bones[:nb] if bones.shape[0] == scene.batch and scene.batch > 1 else bones
     sk, _ = skinning_ref.skinning(rest, bones, scene.kinematic_tree, arti, scene.temperature)
     sk = sk.reshape(n, V, 3)
@@ -216,6 +218,10 @@ def compare_step(scene, out, n_images=None, end_to_end=True):
             rest_o = (verts[None] + deformation).view(nb, F, V, 3)
         else:
             rest_o = verts[None, None]
+        if getattr(scene, "spike_params", None) is not None:
+            from importlib import import_module
+
+            rest_o = rest_o + import_module("3danimals_amd.pipeline").synthetic_spikes(verts, scene.spike_params)
         sk_o, _ = skinning_ref.skinning(rest_o, bones, scene.kinematic_tree, arti, scene.temperature)
         outs_o, rast_o = render(sk_o.reshape(n, V, 3))
         flip = rast_o[..., 3] != _cpu(scene.last["rast"])[:n, ..., 3]

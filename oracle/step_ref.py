@@ -35,6 +35,7 @@ def snapshot(scene, n_images=None):
     st["tex"], st["dino"], st["lgt"] = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))
     st["deform"] = copy.deepcopy(scene.netDeform).cpu() if getattr(scene, "deform", False) else None
     st["class_emb"] = _cpu(scene.class_emb) if getattr(scene, "class_emb", None) is not None else None
+    st["spikes"] = getattr(scene, "spike_params", None)  # the trained-like mesh (pipeline.synthetic_spikes: an input generator)
     st["bones"] = _cpu(scene.bones)
     for k in ("mvp", "w2c", "campos", "feat", "image_gt", "dino_gt", "mask_gt", "mask_dt", "mask_valid", "background"):
         st[k] = _cpu(getattr(scene, k))[:n]
@@ -92,9 +93,14 @@ def _cpu_step(st, backward):
         sdf = raw[:, 0] * st["sdf_gain"] + quadruped(pos, st["leg_radius"])
         verts, faces, _, _ = dmtet_ref.marching_tets(pos, sdf, st["tets"])
         rest, deformation = verts[None, None], None
+        spikes = pipeline.synthetic_spikes(verts.detach(), st["spikes"]) if st.get("spikes") is not None else None
+        if spikes is not None:
+            rest = rest + spikes
         if st.get("deform") is not None:  # InstancePredictorBase.py:306-313
             V = verts.shape[0]
             deformation = st["deform"](verts[None].expand(n, -1, -1), leaves["feat"][:, None, :].expand(-1, V, -1)) * 0.1
+            if spikes is not None:
+                deformation = deformation + spikes
             rest = (verts[None] + deformation).view(nb, F, V, 3)
         posed, _ = skinning_ref.skinning(rest, st["bones"], st["tree"], leaves["arti"], st["temperature"])
         posed = posed.reshape(n, -1, 3)

@@ -1071,7 +1071,10 @@ def test_workload_steps_vs_oracle_step(workload, kw, dev):
     ("magicpony", dict(deform=True, batch=8, forward_only=True), 8),
     ("magicpony", dict(deform=True, batch=8, forward_only=True, grid_res=128), 2),
     ("magicpony", dict(deform=True, grid_res=128), 2),
-], ids=["magicpony", "fauna", "ponymation", "magicpony-bcc51s", "magicpony-fwd-b8", "magicpony-fwd-b8-grid128", "magicpony-grid128"])
+    # round 5: the trained-like mesh (pipeline.synthetic_spikes: what 600 optimiser steps turn the quadruped into; magicpony.yaml:31-33 trains
+    # for 1e5) -- big pixel boxes through the rasteriser's tile stage, long silhouettes through the antialiasing
+    ("magicpony", dict(deform=True, mesh="spiky"), 16),
+], ids=["magicpony", "fauna", "ponymation", "magicpony-bcc51s", "magicpony-fwd-b8", "magicpony-fwd-b8-grid128", "magicpony-grid128", "magicpony-spiky"])
 def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     """BASELINE configs 2 / 3 / 4 / 5 at FULL size (batch 16 resp. 8 sequences x 8 frames, 256x256, Kuhn R=64 grid, the networks at the
     reference's sizes), fixed weights (no optimiser step before the check): every stage of the step re-done by the CPU oracle from the
@@ -2790,3 +2793,210 @@ def test_normals_backward_faces_first_is_bit_identical_to_the_gather_form(number
         (gv,) = torch.autograd.grad((n * g[:, : ve.shape[0]]).sum(), vv)
         outs.append(gv)
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------ guard mode (round 5)
+@pytest.fixture
+def guard():
+    """Switches A3D_GUARD on for one test (3danimals_amd/_lib.py: canaries around every buffer ops.py hands to the library, compared after
+    every entry point; level 2 also poisons the payload) and off again afterwards."""
+    L = importlib.import_module("3danimals_amd._lib")
+    yield L.set_guard
+    L.set_guard(0)
+
+
+def test_guard_mode_reports_a_one_element_overrun_at_the_call_that_did_it(dev, ops, guard):
+    """The detector itself: a library call told that its output holds one texel more than it does writes 16 bytes past the end; guard
+    mode raises at that call, names the buffer and the side, and repairs the canary."""
+    L = importlib.import_module("3danimals_amd._lib")
+    guard(1)
+    B, H, W = 1, 16, 16
+    clip = torch.tensor([[[-0.5, -0.5, 0.5, 1.0], [0.5, -0.5, 0.5, 1.0], [0.0, 0.5, 0.5, 1.0]]], device=dev)
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32, device=dev)
+    rast = ops.rasterize(clip, tri, (H, W))  # a correct call: no complaint
+    assert int((rast[..., 3] > 0).sum()) > 0 and L.guard_stats["checks"] > 0
+    small = ops.torch.empty((B, H - 1, W, 4), dtype=torch.float32, device=dev)  # one row short of what the call is told
+    keys = ops.torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    with pytest.raises(L.A3DError, match="AFTER the buffer"):
+        L.call("a3d_rast_fwd", L.ptr(clip), 1, L.ptr(tri), B, 3, 1, H, W, L.ptr(small), L.ptr(keys), 0, None, L.stream())
+    L.guard_check("after the repair")  # the canaries were restored: the next check is clean
+
+
+@pytest.mark.parametrize("workload,kw", [("magicpony", dict(deform=True)), ("fauna", {}), ("magicpony", dict(deform=True, mesh="spiky")),
+                                         ("ponymation", dict(num_frames=4, batch=4))], ids=["magicpony", "fauna", "magicpony-spiky", "ponymation"])
+def test_guard_mode_finds_no_overrun_in_300_training_steps(workload, kw, dev, guard):
+    """the full-size training steps (B = 16, 256x256, Kuhn R = 64; Fauna = the step that once aborted with an HSA
+    hardware exception) for 300 optimiser steps each with every library buffer between canaries, checked after every entry point -- the
+    mesh drifts, so the data-dependent capacities (speculative DMTet emit, covered-pixel buckets, silhouette record list, G-buffer
+    backward tables) move through many values.  (300 steps x ~60 calls x one device synchronisation: about a minute per workload.)"""
+    L = importlib.import_module("3danimals_amd._lib")
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+    kw = dict(kw)
+    scene = pipeline.SyntheticScene(grid_res=64, batch=kw.pop("batch", 16), resolution=(256, 256), device=dev, seed=0, workload=workload, **kw)
+    steps = 300 if workload != "ponymation" else 60
+    guard(1)
+    before = dict(L.guard_stats)
+    for i in range(steps):
+        out = scene.step(backward=True)
+        if i % 50 == 0:
+            assert bool(torch.isfinite(out["loss"])), i
+    assert L.guard_stats["checks"] - before["checks"] > 30 * steps and L.guard_stats["buffers_checked"] > before["buffers_checked"]
+
+
+@pytest.mark.parametrize("workload,kw", [("magicpony", dict(deform=True)), ("fauna", {})])
+def test_poisoned_buffers_change_nothing(workload, kw, dev, guard):
+    """Guard level 2: every buffer the library is handed starts as NaN / 0x7f7f7f7f instead of whatever the allocator left.  A kernel
+    that read a slot nobody wrote (the tail of a speculative capacity, a list entry past its count, a scratch word a skipped launch
+    never zeroed) would turn the images NaN, or gather far out of range -- deterministically.  Same images as the unguarded step."""
+    pipeline = importlib.import_module("3danimals_amd.pipeline")
+
+    def run(level):
+        guard(level)
+        torch.manual_seed(7)
+        scene = pipeline.SyntheticScene(grid_res=32, batch=5, resolution=(136, 200), device=dev, seed=0, workload=workload, net_width=64, **kw)
+        outs = []
+        for _ in range(4):
+            out = scene.step(backward=True, optimizer_step=False)
+            grads = [p.grad.detach().clone() for p in scene.netShape.parameters() if p.grad is not None][:2] + [scene.arti.grad.detach().clone()]
+            outs.append((out["shaded"].detach().clone(), out["dino_pred"].detach().clone(), out["loss"].detach().clone(), grads))
+        return outs
+
+    a, b = run(2), run(0)
+    for (sa, da, la, ga), (sb, db, lb, gb_) in zip(a, b):
+        assert bool(torch.isfinite(sa).all()) and bool(torch.isfinite(da).all())
+        if workload == "magicpony":  # (Fauna draws its random views from the device generator: the frames differ run to run by construction)
+            assert float((sa - sb).abs().max()) < 1e-5 and float((da - db).abs().max()) < 1e-5
+            assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(lb))
+        for x, y in zip(ga, gb_):
+            assert bool(torch.isfinite(x).all())
+            if workload == "magicpony":
+                np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(y.abs().max()))
+
+
+def test_guard_mode_shape_fuzz(dev, ops, mods, guard):
+    """Random shapes through the whole path under guard level 2: B in 1..17, any H / W (odd ones included: the row-major list, the
+    general compositor path), grids of several sizes and numberings, surfaces that leave the frustum, nothing on screen (P = 0), an empty
+    surface (F = 0), and the capacities that depend on the previous call forced too small (the speculative DMTet emit's buffers, the
+    valence counters sized by the last vertex count) -- the exact re-run must take over without a byte out of place."""
+    L = importlib.import_module("3danimals_amd._lib")
+    M, R, D = mods["mesh"], mods["render"], mods["dmtet"]
+    tg = importlib.import_module("3danimals_amd.tetgrid")
+    synthetic = importlib.import_module("3danimals_amd.synthetic")
+    guard(2)
+    rng = np.random.RandomState(5)
+    for case in range(28):
+        B = int(rng.randint(1, 18))
+        H, W = (int(rng.randint(1, 26)) * 8, int(rng.randint(1, 26)) * 8) if case % 3 else (int(rng.randint(5, 150)), int(rng.randint(5, 150)))
+        res = int(rng.choice([6, 9, 12, 17, 24]))
+        zoom = float(rng.choice([0.0, 0.6, 1.0, 1.0, 2.5, 6.0]))  # 0.0: pushed off screen (P = 0)
+        pos, tets = kuhn(res)
+        if case % 4 == 1:
+            p_np, t_np = tg.scramble(pos.numpy(), tets.numpy(), case)
+            pos, tets = torch.from_numpy(p_np), torch.from_numpy(t_np).long()
+        pos_d = pos.to(dev)
+        grid = D.TetGridTopology(tets.to(dev), positions=pos_d)
+        centre, ext = pos.mean(0), float((pos.amax(0) - pos.amin(0)).max())
+        mvp, w2c, campos = (t.to(dev) for t in synthetic.random_cameras(B, seed=case))
+        for t in range(3):
+            radius = (0.30 + 0.05 * t) * ext
+            sdf = (radius - (pos - centre).norm(dim=-1) + 0.04 * ext * seeded((pos.shape[0],), 90 + case, -1, 1)).to(dev).requires_grad_(True)
+            if case == 9 and t == 1:
+                sdf = (-1.0 - 0 * sdf.detach()).requires_grad_(True)  # nothing inside: V = F = 0
+            if t == 2 and getattr(grid, "_last_counts", None) is not None:  # the previous extraction's sizes, falsified: capacities too small
+                grid._last_counts = tuple(max(1, c // 3) if c > 0 else c for c in grid._last_counts)
+                grid._last_surface_vertices = max(1, getattr(grid, "_last_surface_vertices", 3) // 3)
+            verts, faces, uv_idx = ops.dmtet(pos_d, sdf, grid)
+            if faces.shape[0] == 0:
+                assert verts.shape[0] == 0
+                continue
+            V = verts.shape[0]
+            offs = (0.02 * ext * seeded((B, V, 3), 60 + case + t, -1, 1)).to(dev).requires_grad_(True)
+            scale = 2.0 * (zoom if zoom > 0 else 1.0) / ext
+            posed = (verts[None] - centre.to(dev)) * scale + offs + (torch.tensor([40.0, 0.0, 0.0], device=dev) if zoom == 0 else 0.0)
+            uvs, uvi = torch.zeros(1, 4, 2, device=dev), torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+            prior = M.make_mesh((verts[None] - centre.to(dev)) * scale, faces[None], uvs, uvi, None)
+            shape = M.make_mesh(posed, faces[None], uvs.expand(B, -1, -1), uvi, None)
+            modes = ["shaded", "geo_normal"] if case % 2 else ["shaded"]
+            out = R.render_mesh(None, shape, mvp, w2c, campos, None, None, (H, W), bsdf="diffuse", render_modes=modes, prior_mesh=prior)
+            loss = sum((o * seeded(tuple(o.shape), 70 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out))
+            g_sdf, g_offs = torch.autograd.grad(loss, [sdf, offs], allow_unused=True)
+            for o in out:
+                assert bool(torch.isfinite(o).all()), (case, t, B, H, W, res, zoom)
+            assert g_sdf is None or bool(torch.isfinite(g_sdf).all()), (case, t)
+            assert g_offs is None or bool(torch.isfinite(g_offs).all()), (case, t)
+            if zoom == 0:
+                assert float(out[0][:, 3].abs().max()) == 0.0  # nothing on screen
+    assert L.guard_stats["checks"] > 500
+
+
+# ------------------------------------------------------------------------------------------------ binned rasteriser (round 5)
+@pytest.mark.parametrize("case", ["mesh-b16", "mesh-b3-512x384", "slivers", "eye_plane", "overflow", "spiky-step"])
+def test_binned_rasteriser_equals_the_atomic_path_bit_for_bit(case, dev, ops, monkeypatch):
+    """a3d_rast_fwd's two forms -- per-tile triangle lists + a fine pass with the depth test in LDS (a3d_rast_opts.bins) against
+    triangle-parallel 64-bit atomicMin + resolve -- leave the same texels bit for bit (ids, u, v, z/w) and the same covered-pixel block
+    counts: the marching-tets mesh of the bench, long slivers and eye-plane straddlers (boxes of many tiles: the tile stage appends),
+    tile lists forced to overflow their capacity (16 entries: every block of the object takes the exact all-triangles route and
+    reports it), and the trained-like mesh of a full step.  Both against oracle/raster_ref.c where it finishes in seconds."""
+    from oracle import raster_ref
+
+    L = importlib.import_module("3danimals_amd._lib")
+    oracle_check = True
+    if case in ("mesh-b16", "mesh-b3-512x384", "overflow"):
+        B, (H, W) = (16, (256, 256)) if case != "mesh-b3-512x384" else (3, (512, 384))
+        _, faces, clip, _ = _scene(B, res=32 if B == 16 else 16)
+        tri = faces.int()
+    elif case == "spiky-step":
+        pipeline = importlib.import_module("3danimals_amd.pipeline")
+        scene = pipeline.SyntheticScene(grid_res=64, batch=16, resolution=(256, 256), device=dev, seed=0, workload="magicpony", deform=True, mesh="spiky",
+                                        net_width=32, net_layers=3, feat_dim=16, embedder_freq=4)
+        scene.step(backward=False)
+        clip, tri, (H, W), B = scene.last["points"]["clip"].detach().cpu().contiguous(), scene.last["prior"].t_pos_idx[0].int().cpu(), (256, 256), 16
+        oracle_check = False  # (2e5 triangle-image pairs with 9e3-pixel boxes: minutes on the CPU; the atomic path is itself pinned on slivers)
+    else:
+        H, W, B = 256, 256, 3
+        g = torch.Generator().manual_seed(11 + len(case))
+        n_big, n_small = 60, 400
+        centre = torch.rand(B, n_big, 1, 2, generator=g) * 2.4 - 1.2
+        direction = torch.nn.functional.normalize(torch.randn(B, n_big, 1, 2, generator=g), dim=-1)
+        normal = torch.stack([-direction[..., 1], direction[..., 0]], -1)
+        length = 0.2 + 1.8 * torch.rand(B, n_big, 1, 1, generator=g)
+        width = 10 ** (-3.5 + 2.5 * torch.rand(B, n_big, 1, 1, generator=g))
+        t = torch.tensor([[-1.0, 0.0], [1.0, -1.0], [0.3, 1.0]]).reshape(1, 1, 3, 2)
+        xy = torch.cat([centre + direction * length * t[..., :1] + normal * width * t[..., 1:],
+                        (torch.rand(B, n_small, 1, 2, generator=g) * 2 - 1) + 0.03 * torch.randn(B, n_small, 3, 2, generator=g)], 1)
+        n = n_big + n_small
+        z, w = torch.rand(B, n, 3, 1, generator=g) * 1.6 - 0.8, 0.4 + 2.0 * torch.rand(B, n, 3, 1, generator=g)
+        if case == "eye_plane":
+            w[:, :6, 0] *= -1.0
+        clip = torch.cat([xy * w, z * w, w], -1).reshape(B, 3 * n, 4).contiguous()
+        tri = torch.arange(3 * n, dtype=torch.int32).reshape(n, 3)[torch.randperm(n, generator=g)].contiguous()
+    clip_d, tri_d = clip.to(dev), tri.to(dev)
+    nb = L.lib().a3d_cover_blocks(B, H, W)
+
+    def run(binned):
+        monkeypatch.setattr(ops, "RASTER_BINNED", binned)
+        ops._rast_bins.clear()
+        ops._rast_bin_caps.clear()
+        if case == "overflow":
+            ops._rast_bin_caps[(dev, B, H, W)] = 16
+        outs = []
+        for _ in range(2):  # twice: the second call finds its scratch re-armed by the first (bins_clean / scratch_is_clean)
+            rast = ops.rasterize(clip_d, tri_d, (H, W))
+            cover = ops._cover_counts.peek(rast.detach())
+            outs.append((rast.cpu(), cover[:nb].cpu(), cover[nb:].cpu()))
+        return outs
+
+    a, b = run(True), run(False)
+    for (ra, ca, ta), (rb, cb, tb) in zip(a, b):
+        assert np.array_equal(ra[..., 3].numpy(), rb[..., 3].numpy())  # triangle ids
+        assert np.array_equal(ra.numpy(), rb.numpy())  # u, v, z/w: the same operations in the same order
+        assert np.array_equal(ca.numpy(), cb.numpy()) and np.array_equal(ta[::16].numpy(), tb[::16].numpy())  # covered-pixel block counts, group sums
+    assert float((a[0][0][..., 3] > 0).float().mean()) > 0.02
+    status = a[0][2]
+    if case == "overflow":
+        assert int(status[1]) > 16 and int(status[2]) > 50  # reported: the largest tile count, the blocks that took the exact route
+    else:
+        assert int(status[2]) == 0
+    if oracle_check:
+        ref = raster_ref.rasterize(clip, tri, (H, W))
+        assert np.array_equal(a[0][0].numpy(), ref.numpy())

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 401
+    assert lib.a3d_version() == L.ABI_VERSION == 402
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -559,6 +559,69 @@ def test_bench_credits_ride_along_work_to_the_call_that_carries_it():
     streamed = ab("a3d_dmtet_count", d)
     culled = ab("a3d_dmtet_count", {**d, "dm_words_read": (1130, 29251, 980, 24576)})
     assert streamed > 42e6 and 5e6 < culled < 7e6
+
+
+def test_bench_credit_table_is_frozen_against_the_survey_formulas():
+    """SURVEY.md section 8(d) defines the algorithmic bytes of every stage; bench.algorithmic_bytes must credit exactly those -- inputs read
+    once, outputs written once, index data shared over the batch once; NO staging: not the per-face intermediate of the normals backward,
+    not the chain products the skinning forward leaves for its backward, not the 32 bytes the memory side makes of a 4-byte atomic.  The
+    table is restated here formula by formula, so that a credit cannot move between rounds without this test moving with it (VERDICT r4
+    weak 8: a3d_normals_bwd went 19.7 -> 35.7 MB with a kernel rewrite)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod_frozen", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, V, F, H, W, Nv, Ne, Nt, K, P = 16, 5928, 11852, 256, 256, 274625, 1872064, 1572864, 20, 199956
+    HW = H * W
+    nblk = 1100
+    d = dict(B=B, V=V, F=F, H=H, W=W, Nv=Nv, Ne=Ne, Nt=Nt, K=K, P=P, skin_v_batch=B, cover_blocks=nblk)
+    planes = Ne // 8 + Nt // 2 + Ne // 16
+    want = {
+        # 8d "DMTet per call", streaming form: sdf + both index arrays in, bit planes out (the culled form: test above)
+        "a3d_dmtet_count": 4 * Nv + 8 * Ne + 16 * Nt + planes,
+        "a3d_dmtet_emit": planes + 56 * V + 72 * F + 12 * F + (12 * F + 4 * V) + 4 * Nv,
+        "a3d_dmtet_bwd": 12 * V + 4 * V + 8 * V + 8 * V + 24 * V + 8 * V,
+        # 8d "Skinning fwd per image: 12 V (1/B or 1) + 12 V", + the bones / angles / transforms of the fused chain; bwd: g_out, v, g_v
+        "a3d_skin_pose_fwd": 12 * B * V + 12 * B * V + B * K * (12 + 48 + 24),
+        "a3d_skin_pose_bwd": 12 * B * V + 12 * B * V + 12 * B * V + 48 * B * K + B * K * (12 + 48 + 12 + 24),
+        # 8d "Normals fwd per image: 12 F idx (once per step) + 36 F gathers + 12 V write; bwd same order"
+        "a3d_normals_fwd[B16]": 4 * V + 24 * F + B * (36 * F + 24 * V),
+        "a3d_normals_bwd[B16]": 4 * V + 24 * F + B * (36 * F + 36 * V),
+        # 8d "Rasterise fwd per image: 16 V + 12 F + 16 HW"
+        "a3d_rast_fwd": B * (16 * V + 16 * HW) + 12 * F,
+        "a3d_cover_gbuffer_fwd": 16 * 256 * nblk + 4 * (B * HW // 256) + 8 * P + 4 * B * HW + 48 * P,
+        "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
+        "a3d_shade_bwd": P * (48 + 8 + 12 + 28 + 48 + 12),
+        "a3d_composite_aa_fwd[C4]": 4 * B * HW + 4 * P * 3 + 4 * 4 * B * HW,
+        "a3d_composite_aa_fwd[C17]": 4 * B * HW + 4 * P * 16 + 4 * 17 * B * HW,
+        "a3d_composite_aa_bwd[C4]": 8 * P + 8 * P * 3 + 16 * B * V,
+        "a3d_aa_analyze": B * 16 * HW + B * 16 * V,
+    }
+    for name, bytes_ in want.items():
+        assert bench.algorithmic_bytes(name, d) == bytes_, (name, bench.algorithmic_bytes(name, d), bytes_)
+    # the figures the round-4 review recomputed by hand (MB at the bench mesh): nothing credited beyond them
+    assert 9e6 < want["a3d_normals_bwd[B16]"] < 20e6 and want["a3d_skin_pose_fwd"] < 2.4e6 and want["a3d_skin_pose_bwd"] < 3.5e6
+
+
+def test_product_library_ignores_the_experiment_knob(monkeypatch):
+    """The A3D_EXP measurement knobs (tools/kernel_lab.py) are compiled into the experiment / profile builds only (csrc/build.py --exp /
+    --profile): the library the package loads never reads the environment, so no setting of a measurement can change what it computes."""
+    src = open(os.path.join(ROOT, "3danimals_amd", "csrc", "common.hip")).read()
+    body = src.split("int a3d_exp(void) {")[1].split("\n}")[0]
+    assert "#if defined(A3D_EXPERIMENT) || defined(A3D_PROFILE)" in body and body.count("getenv") == 1 and body.index("getenv") < body.index("#else")
+    import glob
+
+    for path in glob.glob(os.path.join(ROOT, "3danimals_amd", "csrc", "*.hip")):  # every getenv sits behind the experiment macro
+        text = open(path).read()
+        for m in re.finditer(r"getenv\(", text):
+            before = text[: m.start()]
+            assert before.rfind("#if") > max(before.rfind("#endif"), before.rfind("#else")) and "A3D_EXPERIMENT" in before[before.rfind("#if"):], os.path.basename(path)
+    import subprocess
+
+    lib = os.path.join(ROOT, "3danimals_amd", "lib", "liba3d_hip.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in syms, "the product library must not read the environment"
 
 
 # ------------------------------------------------------------------------------------------------ DMTet count in any numbering
