@@ -39,6 +39,9 @@ def build_kinematic_chain(n_bones, start_bone_idx):
     return bones_to_joints, chain, below
 
 
+QUADRANT_POPULATION = None  # a list: estimate_bones appends the four leg quadrants' vertex counts (device tensor) on every call
+
+
 def update_body_kinematic_chain(kinematic_chain, leg_kinematic_chain, body_bone_idx, leg_bone_idxs, attach_legs_to_body=True):
     """Hang a leg under the body bone it attaches to and every ancestor of it (reference :40-46; mutates the lists)."""
     if attach_legs_to_body:
@@ -153,15 +156,22 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
 
         def foot_of(quadrant):
             """Lowest vertex of the quadrant (first one on ties, like indexing the masked subset; skinning.py:177-186), all (b, f) at
-            once on the tensor's device; the empty-quadrant check is a device-side assert on the GPU."""
+            once on the tensor's device.  An EMPTY quadrant (the reference drops into pdb there, skinning.py:183) raises: at once on the
+            CPU; on the GPU the flag stays on the device and travels in the next read-back the path performs anyway (_lib.defer_check
+            -- NOT a device-side assert: a failed torch._assert_async ends a ROCm process as an anonymous "HSA hardware exception").
+            Until then the foot of an empty quadrant is vertex 0: a wrong skeleton for one step, never an out-of-range index."""
             populated = quadrant.any(dim=-1)
             if seq_shape.is_cuda:
-                torch._assert_async(populated.all(), "estimate_bones: no vertex in a leg quadrant (skinning.py:183)")
+                from ..._lib import defer_check
+
+                defer_check(populated.all(), "estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
             elif not bool(populated.all()):
                 raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
             y_in = torch.where(quadrant, ys, torch.full_like(ys, float("inf")))
             return torch.gather(seq_shape, 2, y_in.argmin(dim=-1)[..., None, None].expand(-1, -1, 1, 3))  # [B,F,1,3]
 
+        if QUADRANT_POPULATION is not None:  # diagnostic hook (tools/fauna_quadrant_diag.py): vertices per leg quadrant, kept on the device
+            QUADRANT_POPULATION.append(torch.stack([q.sum(dim=-1).min() for q in quadrants]))
         feet = [foot_of(q) for q in quadrants]
         ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[None, None, :, None]
         if legs_to_body_joint_indices is None:
@@ -173,7 +183,12 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
             # rebuilt (once per epoch; Fauna: every iteration); with a cached chain (compute_kinematic_chain=False) nothing is read back.
             need = [i for i in (0, 1) if legs_to_body_joint_indices[i] is None]
             if need:
-                nearest = torch.stack([torch.argmin((bones_pred[0, 0, :, 1, 2] - feet[i][0, 0, 0, 2]).abs()) for i in need]).tolist()
+                nearest = torch.stack([torch.argmin((bones_pred[0, 0, :, 1, 2] - feet[i][0, 0, 0, 2]).abs()) for i in need])
+                if nearest.is_cuda:  # (the ONE read-back of a chain rebuild also carries the quadrant flags deferred above)
+                    from ..._lib import read_back
+
+                    nearest = read_back(nearest)
+                nearest = nearest.tolist()
                 for i, j in zip(need, nearest):
                     legs_to_body_joint_indices[i] = int(j)
         start = n_body_bones

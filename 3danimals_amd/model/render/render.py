@@ -55,8 +55,26 @@ SHADE_IN_COMPOSITOR = os.environ.get("A3D_SHADE_IN_COMPOSITOR", "1") != "0"  # n
 # cache is three times what it ever needed; ranks that must not stall set the ratio to 0 and cap the cache with
 # PYTORCH_HIP_ALLOC_CONF=garbage_collection_threshold instead.
 ALLOCATOR_TRIM_RATIO = float(os.environ.get("A3D_ALLOCATOR_TRIM_RATIO", "3"))
+# (round 5) WHEN the cache is given back: 'inline' = where the new size is met, between the G-buffer and the networks of that forward (a
+# caller that only overlays model/render gets this: it has no other hook); 'step_end' = the render only records the wish and the
+# training loop calls allocator_trim_at_step_end() after its optimiser step (pipeline.SyntheticScene.step does): no synchronisation
+# and no hipFree in the middle of a forward, the step's own activations are back in the cache by then (more of it can go), and under
+# data-parallel training the millisecond falls between two steps instead of between a rank's forward and the others' all-reduce.
+ALLOCATOR_TRIM_MODE = os.environ.get("A3D_ALLOCATOR_TRIM_MODE", "inline")
 _point_counts_seen = set()
 _in_use_peak = {}
+_trim_wanted = set()
+
+
+def allocator_trim_at_step_end(device=None):
+    """Give the cache back now if a render of this step asked for it (ALLOCATOR_TRIM_MODE 'step_end').  -> True when it did."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _trim_wanted:
+        return False
+    _trim_wanted.discard(key)
+    torch.cuda.empty_cache()
+    return True
 
 
 _matmul_fp32 = fp32_region(torch.matmul)  # camera algebra of the path: float32 also inside the caller's autocast region (see _lib.fp32_region)
@@ -79,6 +97,9 @@ def _trim_allocator_cache(n_points, device):
     in_use_peak = max(peak, torch.cuda.max_memory_allocated(device))
     _in_use_peak[key] = in_use_peak
     if torch.cuda.memory_reserved(device) <= ALLOCATOR_TRIM_RATIO * in_use_peak:
+        return False
+    if ALLOCATOR_TRIM_MODE == "step_end":
+        _trim_wanted.add(key)
         return False
     torch.cuda.empty_cache()
     return True

@@ -267,7 +267,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
             spec = (capV, capF, capS, capE, capT, bufs, tri32_b, adj_b)
     # the one host sync of DMTet (the reference syncs here too, dmtet.py:110); listed_*: how many non-empty blocks the culled count
     # pass listed for the emit launch (-1: none listed)
-    V, n1, n2, n_surf, listed_e, listed_t = counts.tolist()
+    V, n1, n2, n_surf, listed_e, listed_t = _lib.read_back(counts).tolist()  # (+ any deferred device-side check: same transfer)
     F = n1 + 2 * n2
     grid._last_counts = (V, n1, n2, n_surf, listed_e, listed_t)
     if counters is not None:
@@ -659,7 +659,7 @@ def _cover_counted(rast, tile):
         scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=rast.device)
         call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
     nb = _lib.lib().a3d_cover_blocks(B, H, W)
-    tail = scratch[nb:].cpu()  # THE read-back: one sum per group of 64 blocks, one per 64-byte line; words 1, 2 of the first line: the binned rasteriser's status
+    tail = _lib.read_back(scratch[nb:])  # THE read-back: one sum per group of 64 blocks, one per 64-byte line; words 1, 2 of the first line: the binned rasteriser's status
     if tail.shape[0] > 2 and int(tail[1]) > 0:
         _rast_bins_grow((rast.device, B, H, W), int(tail[1]), int(tail[2]))
     return scratch, int(tail[::_lib.lib().a3d_cover_group_stride()].sum())
@@ -687,11 +687,16 @@ def covered_pixels(rast, tile=8, return_inverse=False):
 _rast_keys = {}
 # the binned path (a3d_rast_opts.bins: per-tile triangle lists + a fine pass, no memory-side atomics): its scratch is kept per (device,
 # stream, frame) like the key buffer (the fine pass leaves the tile counts at zero), the capacity of a tile list per (device, frame):
-# 256 entries to start with, 4 x the largest count ever reported above half the capacity (the covered-pixel read-back carries the
+# 1024 entries to start with, 4 x the largest count ever reported above half the capacity (the covered-pixel read-back carries the
 # report).  An overflowing tile is still rasterised exactly -- by the slow route inside the fine pass -- so the capacity is a matter of
-# speed only; memory is not a constraint (256 entries: 17 MB at B = 16, 256 x 256).
-RASTER_BINNED = os.environ.get("A3D_RASTER_BINNED", "1") != "0"
-RASTER_BIN_CAP0 = 256
+# speed only; memory is not a constraint (1024 entries: 67 MB at B = 16, 256 x 256).
+# OFF by default (round 5, measured inside the bench step on one box): bin launch 18.3 us + fine pass 36-60 us against 23.6 + 9.0 us for
+# the triangle-parallel atomics + resolve.  Same fragment tests in total, but dealt out by SCREEN position: under a head-on camera
+# nearly all of the mesh's 12k triangles fall into a dozen 256-pixel blocks (1400 list entries each, six chunks of dependent gathers
+# in ONE work-group) and the launch ends when that work-group does; the atomic form deals the same work out by triangle and does not
+# care where on screen it lands ("Rasteriser: the binned form").
+RASTER_BINNED = os.environ.get("A3D_RASTER_BINNED", "0") == "1"
+RASTER_BIN_CAP0 = 1024
 _rast_bins = {}
 _rast_bin_caps = {}
 rast_bin_events = dict(grown=0, overflowed_blocks=0)
@@ -887,6 +892,7 @@ def interpolate_da(attr, rast, tri, rast_db, diff_attrs="all"):
 
 # ---------------------------------------------------------------------------------------------- fused G-buffer
 GBUFFER_GRAD_COLS = 16  # A3D_GBUFFER_GRAD_COLS of include/a3d.h
+GBUFFER_RECORDS = os.environ.get("A3D_GBUFFER_RECORDS", "1") != "0"  # the forward leaves a 32-byte record per point for the backward (one round trip instead of three)
 
 
 class _GBuffer(torch.autograd.Function):
@@ -916,14 +922,16 @@ class _GBuffer(torch.autograd.Function):
         # cleared by the forward launch: one memset less on the backward path
         needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
         rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device) if needs_grad else None
+        # ... and so is its record of every point (barycentrics, pixel, face, vertex ids: 32 bytes), which the forward writes while it has them
+        rec = torch.empty((P, 8), dtype=torch.int32, device=rast.device) if (needs_grad and GBUFFER_RECORDS) else None
         if listed:
             call("a3d_cover_gbuffer_fwd", ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(cover_scratch), P, ptr(pix), ptr(inv), ptr(v_pos),
-                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), ptr(rec), stream())
         else:
             call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), ptr(rec), stream())
         ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
-        ctx.rows = rows
+        ctx.rows, ctx.rec = rows, rec
         ctx.listed = listed
         if listed:  # (out[, extra_out], pix, inv): the list rides along as non-differentiable outputs
             ctx.mark_non_differentiable(pix, inv)
@@ -950,7 +958,7 @@ class _GBuffer(torch.autograd.Function):
             rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_bwd", ptr(f32h(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
              ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(clear), int(want_prior), ptr(extra), E,
-             None if extra is None else ptr(f32h(g_extra_out)), stream())
+             None if extra is None else ptr(f32h(g_extra_out)), ptr(getattr(ctx, "rec", None)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None

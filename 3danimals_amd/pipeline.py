@@ -123,17 +123,26 @@ class SyntheticScene(torch.nn.Module):
 
     def __init__(self, grid_res=64, batch=16, resolution=(256, 256), device="cuda", seed=0, net_width=256, net_layers=None, feat_dim=256,
                  embedder_freq=None, spatial_scale=7.0, temperature=0.05, jitter_grid=0.05, leg_radius=None, lr=1e-4, data_seed=None,
-                 workload="magicpony", num_frames=1, deform=False, pose_seed=0, grid=None, mesh="quadruped", spikes=None):
+                 workload="magicpony", num_frames=1, deform=False, pose_seed=0, grid=None, mesh="quadruped", spikes=None, render=True,
+                 mesh_loss=True):
         """``seed`` fixes the networks, cameras and poses; ``data_seed`` (default: ``seed``) the image features and the target images --
         data-parallel ranks share the former (equal work per GPU: the same number of covered pixels) and differ in the latter.
         ``grid``: a tetgrid.named_grid name ('bcc51s' = the reference's "128" Quartet class in a file's arbitrary numbering) instead of
         the Kuhn grid of ``grid_res`` cells.
         ``pose_seed`` != 0 draws other cameras / articulations with the SAME networks (per-rank poses: unequal covered-pixel counts).
-        ``mesh`` = 'spiky': the trained-like mesh (synthetic_spikes; ``spikes`` overrides entries of SPIKES)."""
+        ``mesh`` = 'spiky': the trained-like mesh (synthetic_spikes; ``spikes`` overrides entries of SPIKES).
+        ``render=False`` (ponymation): the step config/train_ponymation_horse_stage2.yaml really runs -- ``enable_render: false``,
+        AnimalModel.py:404: DMTet, the instance deformation, [B,F] skinning and the make_mesh passes (whose vertex normals the reference
+        computes eagerly, mesh.py:355-375) on B x F meshes, no rasteriser; the losses are the motion VAE's (teacher MSE on the angles, KL:
+        Ponymation.py:65-85) + the articulation / deformation regularisers.  None of them reads the posed meshes, so the reference's
+        backward never enters skinning or normals there; ``mesh_loss`` adds a fixed linear functional of the posed vertices and normals
+        so that their backward kernels run at this size too (what stage 1 gets from the renderer)."""
         super().__init__()
         assert workload in WORKLOADS, workload
         assert mesh in ("quadruped", "spiky"), mesh
         self.mesh_kind, self.spike_params = mesh, (dict(SPIKES, **(spikes or {})) if mesh == "spiky" else None)
+        assert render or workload == "ponymation", "only the sequence workload has a configuration without rendering"
+        self.render, self.mesh_loss = bool(render), bool(mesh_loss)
         assert num_frames == 1 or workload == "ponymation"
         data_seed = seed if data_seed is None else data_seed
         self.workload, self.num_frames, self.deform = workload, int(num_frames), bool(deform)
@@ -187,6 +196,13 @@ class SyntheticScene(torch.nn.Module):
         with torch.no_grad():
             prior = self.netShape.getMesh(jitter_grid=False, feats=self.class_emb)
             self._estimate_bones(prior)
+        self._eye4, self._proj = torch.eye(4, device=dev), synthetic.perspective(25.0).to(dev)
+        if not self.render:  # no image targets: the motion-VAE stage supervises angles, not pixels
+            self.background = torch.zeros(1, H, W, 3, device=dev)
+            self._arti_gt = synthetic.seeded((B, F, 20, 3), seed + 77, -0.25, 0.25).to(dev)
+            g = torch.Generator().manual_seed(seed + 78)
+            self._mesh_w = [torch.randn(3, generator=g).to(dev), torch.randn(3, generator=g).to(dev)]
+            return
         # ---- targets shaped like ImageDataset batches (model/dataset/ImageDataset.py:57-90)
         g = torch.Generator().manual_seed(data_seed + 4)
         self.image_gt = torch.rand(N, 3, H, W, generator=g).to(dev)
@@ -237,6 +253,10 @@ class SyntheticScene(torch.nn.Module):
         verts = verts.view(N, *verts.shape[2:])
         shape = mesh_mod.make_mesh(verts, prior.t_pos_idx, prior.v_tex.expand(N, -1, -1), prior.t_tex_idx, None)
         self.last.update(prior=prior, shape=shape, posed_bones=aux["posed_bones"], deformation=deformation)
+        if not self.render and with_nets:
+            self.last.pop("rast", None)
+            self.last.pop("points", None)
+            return None
         out = render_mod.render_mesh(None, shape, self.mvp, self.w2c, self.campos, self.netTexture if with_nets else None,
                                       self.netLight if with_nets else None, self.resolution, background=self.background, bsdf="diffuse",
                                       feat=self.feat if with_nets else None, render_modes=list(modes), prior_mesh=prior,
@@ -308,6 +328,8 @@ class SyntheticScene(torch.nn.Module):
         """Forward of one iteration -> dict(shaded, dino_pred, loss, losses).  (DDP wraps this module: its backward hooks
         all-reduce the MLP gradients over RCCL while the HIP backward kernels are still running.)"""
         modes = ["shaded", "dino_pred"] + (["flow"] if self.workload == "ponymation" and self.num_frames > 1 else [])
+        if not self.render:
+            return self._forward_no_render(jitter, sdf_reg)
         rendered = self.forward_render(self.arti, jitter=jitter, modes=modes)
         shaded, dino_pred = rendered[0], rendered[1]
         parts = self.losses(shaded, dino_pred)
@@ -338,6 +360,27 @@ class SyntheticScene(torch.nn.Module):
         out.update(loss=total, losses=parts)
         return out
 
+    def _forward_no_render(self, jitter, sdf_reg):
+        """train_ponymation_horse_stage2 as configured (enable_render false): see __init__."""
+        self.forward_render(self.arti, jitter=jitter)
+        shape, prior = self.last["shape"], self.last["prior"]
+        nrm, prior_nrm = shape.v_nrm, prior.v_nrm  # make_mesh's normals (mesh.py:355-375 computes them eagerly for every mesh)
+        parts = {}
+        parts["arti_recon"] = torch.nn.functional.mse_loss(self.arti, self._arti_gt)  # L_teacher (Ponymation.py:70-74)
+        parts["arti_reg"] = (self.arti ** 2).mean()
+        total = parts["arti_recon"] + REG_WEIGHTS["arti_reg"] * parts["arti_reg"]
+        if self.last.get("deformation") is not None:
+            parts["deform_reg"] = (self.last["deformation"] ** 2).mean()
+            total = total + REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+        parts["prior_normal_reg"] = prior_normal_regulariser(prior)
+        if self.mesh_loss:  # a linear functional of the posed meshes: the backward of skinning / normals / DMTet at this size
+            parts["mesh"] = (shape.v_pos * self._mesh_w[0]).mean() + (nrm * self._mesh_w[1]).mean()
+            total = total + parts["mesh"]
+        if sdf_reg and torch.is_grad_enabled():
+            eikonal = ((self.netShape.get_sdf_gradient(feats=self.class_emb).norm(dim=-1) - 1) ** 2).mean()
+            total = total + LOSS_WEIGHTS["sdf_gradient"] * eikonal
+        return dict(loss=total, losses=parts, posed=shape.v_pos, normals=nrm, prior_normals=prior_nrm)
+
     def step(self, backward=True, optimizer_step=None, sdf_reg=True, module=None):
         """One iteration (forward, backward, Adam).  ``module`` = the DDP wrapper of this scene when data-parallel."""
         optimizer_step = backward if optimizer_step is None else optimizer_step
@@ -351,6 +394,8 @@ class SyntheticScene(torch.nn.Module):
             out["loss"].backward()
             if optimizer_step:
                 self.optimizer.step()
+        if render_mod.ALLOCATOR_TRIM_MODE == "step_end":  # the allocator valve, between two steps instead of inside a forward (render.py)
+            render_mod.allocator_trim_at_step_end(self.dev)
         return out
 
 

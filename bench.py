@@ -361,6 +361,19 @@ def parity_and_cpu_baseline(scene, args, threads):
     sec = secs[len(secs) // 2]
     cpu = lambda t: t.detach().float().cpu()
     parity = dict(frames=n, resolution=list(scene.resolution), faces_equal=rep["faces_equal"], num_faces=rep["num_faces"])
+    if rep["faces_equal"] and rep.get("geometry_only"):  # the step without rendering: the geometry stages are all there is
+        parity.update(stages=dict(dmtet_vertices=rep["max_abs_vert_err"], prior_normals=rep["max_abs_prior_normal_err"], skinning=rep["max_abs_skin_err"],
+                                  posed_normals=rep["max_abs_posed_normal_err"], posed_normal_err_vs_float64=rep["posed_normal_err_vs_float64"]),
+                      loss_rel_err={k: round(abs(float(cpu(out["losses"][k])) - float(v)) / max(abs(float(v)), 1e-12), 7) for k, v in res["losses"].items()
+                                    if k in out["losses"] and v.dim() == 0 and k != "mesh"},
+                      note="no rendering in this step: DMTet index buffers bit-exact, vertices, skinning and both normals passes re-done by the CPU oracle "
+                           "from the HIP output of the stage before")
+        parity["pass"] = bool(rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 1e-5 and rep["max_abs_posed_normal_err"] < 1e-4)
+        cpu_baseline = dict(value=round(n / sec, 4), unit="images/s", cores=threads, kind="port",
+                            sample=f"oracle/step_ref.cpu_step fwd+bwd on {n} of the {scene.frames} frames (ponymation stage 2, no rendering: grid {grid_name(args)} DMTet, "
+                                   f"deformation, LBS, normals), 1 warm-up + median of {args.cpu_runs} runs, torch {threads} threads of {os.cpu_count()} logical cores, "
+                                   f"{sec:.1f} s per run")
+        return parity, cpu_baseline
     if rep["faces_equal"]:
         stage_keys = [k for k in rep if k.endswith(("clip", "raster", "gbuffer", "gbuffer_flow"))]
         parity.update(
@@ -465,6 +478,9 @@ def main():
                     "line carries it as extra_legs.spiky anyway")
     ap.add_argument("--no-spiky-leg", action="store_true", help="skip the extra leg on the trained-like mesh (default line, 1 GPU, magicpony)")
     ap.add_argument("--no-fingerprint", action="store_true", help="skip the box fingerprint (clocks, 92 MB fill / read probe, GPU-busy time per step)")
+    ap.add_argument("--no-render", action="store_true", help="ponymation only: the step config/train_ponymation_horse_stage2.yaml really runs (enable_render "
+                    "false; combine with --batch 20 --frames 10): DMTet + instance deformation + [B,F] LBS + the make_mesh passes on B x F meshes + backward, "
+                    "no rasteriser")
     ap.add_argument("--no-deform", action="store_true", help="magicpony without the instance deformation (the round-1 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (parity and cpu_baseline = null)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
@@ -482,6 +498,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="--gpus N > 1 only: skip the two extra timed legs of the line (per-rank poses; the "
                     "Fauna per-rank step) that follow the headline leg")
     args = ap.parse_args()
+    assert not args.no_render or args.workload == "ponymation", "--no-render is the ponymation stage-2 configuration"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: spawn the ranks ourselves
         sys.exit(self_launch(args.gpus))
@@ -515,8 +532,8 @@ def main():
         b = batch if (workload == args.workload or args.workload != "ponymation") else 16  # (ponymation's --batch counts sequences)
         return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=b, resolution=(args.resolution, args.resolution), device=dev, seed=0,
                                        data_seed=1000 * rank, workload=workload, num_frames=frames if workload == "ponymation" else 1,
-                                       deform=(workload == "magicpony" and not args.no_deform),
-                                       pose_seed=(rank if per_rank_poses else 0), mesh=mesh)
+                                       deform=((workload == "magicpony" or (workload == "ponymation" and args.no_render)) and not args.no_deform),
+                                       pose_seed=(rank if per_rank_poses else 0), mesh=mesh, render=not (args.no_render and workload == "ponymation"))
 
     scene = make_scene()
     scene.netShape.capture_sdf_gradient_graph()  # HIP graphs are captured before any RCCL thread exists; the steps only replay them
@@ -686,8 +703,11 @@ def main():
                              "+ SDF/texture/DINO/light/deform MLPs + photometric/mask/DINO losses + regularisers, fwd+bwd+Adam" % grid_name(args),
                 "fauna": "train_fauna per-rank synthetic step: conditioned SDF (CoordMLP_Mod, 128-d embedding) + DMTet(%s) + bones re-estimated "
                          "every iteration (bone_y_threshold 0.4) + LBS + main render + random-view mask render + losses, fwd+bwd+Adam" % grid_name(args),
-                "ponymation": "train_ponymation stage-2-like synthetic step with rendering: DMTet(%s) + [B,F] LBS + B*F frames rendered with "
-                              "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % grid_name(args)}[args.workload]
+                "ponymation": ("train_ponymation stage 2 as configured (enable_render false, train_ponymation_horse_stage2.yaml:16-27): DMTet(%s) + instance "
+                               "deformation + [B,F] LBS + make_mesh (vertex normals) of B*F meshes, teacher / regulariser losses + a linear functional of the "
+                               "posed meshes (so that the path's backward runs), fwd+bwd+Adam" % grid_name(args)) if args.no_render else
+                              ("train_ponymation stage-2-like synthetic step with rendering: DMTet(%s) + [B,F] LBS + B*F frames rendered with "
+                               "'shaded','dino_pred','flow' + photometric/mask/DINO/flow losses, fwd+bwd+Adam" % grid_name(args))}[args.workload]
         line = {
             "metric": "train images/sec fwd+bwd @256x256 b16" if train else "test images/sec forward only @256x256 b8 (BASELINE configs[1])",
             "value": round(images / elapsed, 3),
@@ -709,7 +729,7 @@ def main():
             "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
                        "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "mesh": args.mesh, "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
-                       "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)",
+                       "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)", "render": not args.no_render,
                        "per_rank_data": ("per-rank poses/cameras, image features and targets (covered pixels differ per rank)" if args.per_rank_poses else
                                          "same poses/cameras on every rank (equal work per GPU: covered-pixel imbalance across ranks is NOT in this "
                                          "figure), per-rank image features and targets")},

@@ -178,6 +178,10 @@ def compare_step(scene, out, n_images=None, end_to_end=True):
     nrm64 = mesh_ref.vertex_normals(posed.double(), faces)
     rep["posed_normal_err_vs_float64"] = dict(hip=float((nrm_hip.double() - nrm64).abs().max()), oracle_float32=float((nrm_ref.double() - nrm64).abs().max()))
 
+    if scene.last.get("points") is None and scene.last.get("rast") is None:  # a step without rendering (ponymation stage 2 as configured)
+        rep.update(images={}, max_abs_image_err=0.0, raster_ids_equal=True, geometry_only=True)
+        return rep
+
     # ---- the main render, stage by stage
     scene.netLight.light_params = None  # non-leaf cache of the last forward; not deep-copyable
     tex, dino, lgt = (copy.deepcopy(m).cpu() for m in (scene.netTexture, scene.netDINO, scene.netLight))

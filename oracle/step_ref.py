@@ -37,7 +37,10 @@ def snapshot(scene, n_images=None):
     st["class_emb"] = _cpu(scene.class_emb) if getattr(scene, "class_emb", None) is not None else None
     st["spikes"] = getattr(scene, "spike_params", None)  # the trained-like mesh (pipeline.synthetic_spikes: an input generator)
     st["bones"] = _cpu(scene.bones)
-    for k in ("mvp", "w2c", "campos", "feat", "image_gt", "dino_gt", "mask_gt", "mask_dt", "mask_valid", "background"):
+    st["render"] = bool(getattr(scene, "render", True))
+    if not st["render"]:  # the sequence step without rendering: angle targets and the stand-in functional of the posed meshes instead of images
+        st["arti_gt"], st["mesh_w"], st["mesh_loss"] = _cpu(scene._arti_gt)[:nb], [_cpu(w) for w in scene._mesh_w], bool(scene.mesh_loss)
+    for k in ("mvp", "w2c", "campos", "feat") + (("image_gt", "dino_gt", "mask_gt", "mask_dt", "mask_valid", "background") if st["render"] else ()):
         st[k] = _cpu(getattr(scene, k))[:n]
     st["arti"] = _cpu(scene.arti)[:nb]
     st["flow_gt"] = _cpu(scene.flow_gt)[:nb] if getattr(scene, "flow_gt", None) is not None else None
@@ -105,6 +108,29 @@ def _cpu_step(st, backward):
         posed, _ = skinning_ref.skinning(rest, st["bones"], st["tree"], leaves["arti"], st["temperature"])
         posed = posed.reshape(n, -1, 3)
         nrm = mesh_ref.vertex_normals(posed, faces)
+        if not st.get("render", True):  # config/train_ponymation_horse_stage2.yaml: enable_render false (pipeline.SyntheticScene._forward_no_render)
+            parts = dict(arti_recon=torch.nn.functional.mse_loss(leaves["arti"], st["arti_gt"]), arti_reg=(leaves["arti"] ** 2).mean())
+            loss = parts["arti_recon"] + pipeline.REG_WEIGHTS["arti_reg"] * parts["arti_reg"]
+            if deformation is not None:
+                parts["deform_reg"] = (deformation ** 2).mean()
+                loss = loss + pipeline.REG_WEIGHTS["deform_reg"] * parts["deform_reg"]
+            pn = mesh_ref.vertex_normals(verts[None], faces)[0][torch.cat([faces[:, 0:2], faces[:, 1:3]], 0)]
+            parts["prior_normal_reg"] = (1 - (pn[:, 0] * pn[:, 1]).sum(-1)).mean()
+            if st.get("mesh_loss"):
+                parts["mesh"] = (posed * st["mesh_w"][0]).mean() + (nrm * st["mesh_w"][1]).mean()
+                loss = loss + parts["mesh"]
+            grads = {}
+            nets = [("sdf_mlp", st["sdf_mlp"])] + ([("deform", st["deform"])] if st.get("deform") is not None else [])
+            if backward:
+                for _, m in nets:
+                    m.zero_grad(set_to_none=True)
+                loss.backward()
+                grads = {k: v.grad for k, v in leaves.items()}
+                for name, m in nets:
+                    for pname, p in m.named_parameters():
+                        grads[f"{name}.{pname}"] = p.grad
+            return dict(loss=loss.detach(), losses={k: v.detach() for k, v in parts.items()}, grads=grads, num_faces=int(faces.shape[0]), faces=faces,
+                        verts=verts.detach(), posed=posed.detach(), normals=nrm.detach(), seconds=time.perf_counter() - t0)
         modes = ("shaded", "dino_pred") + (("flow",) if (workload == "ponymation" and F > 1) else ())
         rendered = render_ref.render_mesh(posed, faces, nrm, leaves["mvp"], leaves["w2c"], leaves["campos"], st["tex"], st["lgt"],
                                           st["resolution"], background=st["background"], feat=leaves["feat"], render_modes=modes,
