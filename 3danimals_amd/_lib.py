@@ -57,11 +57,11 @@ SIGNATURES = {
     "a3d_mesh_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     "a3d_mesh_topology_finalize_max_vertices": (_c_int, []),
     "a3d_mesh_topology_finalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
-    "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p]),
+    "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p]),
     "a3d_cover_gbuffer_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, ctypes.c_int64, _p, _p, _p, _p, _p, _c_int, _p, _p, _c_int,
-                                       _p, _p, _p, _p]),
+                                       _p, _p, _p]),
     "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int,
-                                 _c_int, _p, _c_int, _p, _p, _p]),
+                                 _c_int, _p, _c_int, _p, _p]),
     "a3d_gemm_nn_relumask": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p]),
     "a3d_harmonic_embed_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),
     "a3d_harmonic_embed_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),

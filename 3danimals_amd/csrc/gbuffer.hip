@@ -38,7 +38,7 @@ __device__ __forceinline__ float gb_mix(float u, float a, float v, float b, floa
 __device__ __forceinline__ void gb_row(const float4 r, long long i, long long p, const int* __restrict__ tri, const float* __restrict__ v_pos,
                                        const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch, int V, int F,
                                        long long hw, float* __restrict__ out, const float* __restrict__ extra, int E,
-                                       float* __restrict__ extra_out, int4* __restrict__ rec = nullptr) {
+                                       float* __restrict__ extra_out) {
     const int f = (int)r.w - 1;
     float4* o4 = reinterpret_cast<float4*>(out + p * 12);  // rows are 48 bytes: three aligned 16-byte stores
     float o[12];
@@ -46,15 +46,11 @@ __device__ __forceinline__ void gb_row(const float4 r, long long i, long long p,
         o4[0] = o4[1] = o4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (extra)
             for (int c = 0; c < E; ++c) extra_out[p * E + c] = 0.f;
-        if (rec) { rec[2 * p] = make_int4(0, 0, (int)i, -1); rec[2 * p + 1] = make_int4(0, 0, 0, 0); }
         return;
     }
     const long long b = i / hw;
     const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     const float u = r.x, v = r.y, w = 1.f - u - v;
-    // (round 5) the backward's record of this point -- barycentrics, pixel, face, the three vertex ids: 32 bytes it reads in ONE coalesced
-    // round trip instead of the chain list entry -> texel -> index row (three dependent round trips before its first gather)
-    if (rec) { rec[2 * p] = make_int4(__float_as_int(u), __float_as_int(v), (int)i, f); rec[2 * p + 1] = make_int4(i0, i1, i2, 0); }
     const float* vp = v_pos + b * V * 3;
     float ax, ay, az, bx, by, bz, cx, cy, cz;
     gb_load3(vp + 3ll * i0, ax, ay, az);
@@ -95,13 +91,13 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
                                                      long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                      const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
                                                      float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4, int4* __restrict__ rec) {
+                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // the backward's gradient rows cleared here, while this launch is waiting for its gathers anyway (saves the backward its memset)
     for (long long z = p; z < n_zero4; z += (long long)gridDim.x * blockDim.x) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p >= P) return;
     const long long i = pix[p];
-    gb_row(rast[i], i, p, tri, v_pos, v_nrm, prior, prior_batch, V, F, hw, out, extra, E, extra_out, rec);
+    gb_row(rast[i], i, p, tri, v_pos, v_nrm, prior, prior_batch, V, F, hw, out, extra, E, extra_out);
 }
 
 // The covered-pixel list AND its G-buffer rows in one launch (a3d_cover_emit + a3d_gbuffer_fwd): thread = position k of the tile-ordered
@@ -114,7 +110,7 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
                                                            const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                            const float* __restrict__ prior, int prior_batch, int V, int F,
                                                            float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                           float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4, int4* __restrict__ rec) {
+                                                           float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
     __shared__ int wave_n[4];
     __shared__ int s_off;
     A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = gb_cover_fwd_kernel, 1 = gb_bwd_kernel)
@@ -149,7 +145,7 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
     for (int w = 0; w < wave; ++w) o += wave_n[w];
     pix[o] = flat;
     if (inv) inv[flat] = o;
-    gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out, rec);
+    gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out);
     A3D_STAMP(0, 5);
 }
 
@@ -299,7 +295,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
                                                      const float4* __restrict__ clip, int V, int F, int H, int W, float* __restrict__ g_rows,
                                                      int want_prior, const float* __restrict__ extra, int E,
-                                                     const float* __restrict__ g_extra, const int4* __restrict__ rec) {
+                                                     const float* __restrict__ g_extra) {
     constexpr int ST = NC == 12 ? 13 : 17;  // floats per staged entry: NC sums + the previous entry of the same slot, odd stride
     __shared__ int s_key[GB_SLOTS];    // vertex row (b*V + v) of a slot, -1 = free
     __shared__ int s_head[GB_SLOTS];   // last staged entry of the slot's list
@@ -312,20 +308,8 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
     __syncthreads();
     const bool want_clip = clip != nullptr;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long i = 0;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    int4 rv = make_int4(0, 0, 0, 0);
-    if (rec) {  // the forward's record of the point: one coalesced round trip (see gb_row)
-        if (p < P) {
-            const int4 ra = rec[2 * p];
-            rv = rec[2 * p + 1];
-            i = ra.z;
-            r = make_float4(__int_as_float(ra.x), __int_as_float(ra.y), 0.f, (float)(ra.w + 1));
-        }
-    } else {
-        i = p < P ? pix[p] : 0;
-        if (p < P) r = rast[i];
-    }
+    const long long i = p < P ? pix[p] : 0;
+    const float4 r = p < P ? rast[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int f = (int)r.w - 1;
     const bool live = p < P && f >= 0 && f < F;
     float acc[3][NC];
@@ -340,8 +324,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         b = (int)((unsigned)i / hw);
         const unsigned rem = (unsigned)i - (unsigned)b * hw;
         const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * (unsigned)W);
-        if (rec) { i0 = rv.x; i1 = rv.y; i2 = rv.z; }
-        else { i0 = tri[3 * f]; i1 = tri[3 * f + 1]; i2 = tri[3 * f + 2]; }
+        i0 = tri[3 * f]; i1 = tri[3 * f + 1]; i2 = tri[3 * f + 2];
         const long long vb3 = (long long)b * V * 3, pb3 = prior_batch == 1 ? 0ll : vb3;
         GbTri t;
         gb_load_tri(t, v_pos, v_nrm, prior, vb3, pb3, i0, i1, i2);
@@ -453,10 +436,9 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 
 extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                                const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null,
-                               int E, float* extra_out_or_null, float* g_rows_to_clear_or_null, int32_t* rec_out_or_null, a3d_stream_t stream) {
+                               int E, float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
-    A3D_CHECK_ARG(!rec_out_or_null || (((uintptr_t)rec_out_or_null & 15) == 0 && (long long)B * H * W < 0x7fffffffll));
     A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || P == 0)));  // (an empty list has no output storage)
     A3D_CHECK_ARG(!g_rows_to_clear_or_null || ((uintptr_t)g_rows_to_clear_or_null & 63) == 0);
     const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * (GB_ROW / 4) : 0;
@@ -467,7 +449,7 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
                        (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null,
-                       (float4*)g_rows_to_clear_or_null, n_zero4, (int4*)rec_out_or_null);
+                       (float4*)g_rows_to_clear_or_null, n_zero4);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -475,8 +457,7 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
 extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int B, int V, int F, int H, int W, const void* cover_scratch,
                                      int64_t P, int64_t* pix, int32_t* inv_or_null, const float* v_pos, const float* v_nrm, const float* prior,
                                      int prior_batch, float* out, const float* extra_or_null, int E, float* extra_out_or_null,
-                                     float* g_rows_to_clear_or_null, int32_t* rec_out_or_null, a3d_stream_t stream) {
-    A3D_CHECK_ARG(!rec_out_or_null || ((uintptr_t)rec_out_or_null & 15) == 0);
+                                     float* g_rows_to_clear_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(rast && cover_scratch && P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG(H % 8 == 0 && W % 8 == 0);  // the tile-ordered list (a3d_cover_count / a3d_rast_fwd's resolve with tile = 8)
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
@@ -489,7 +470,7 @@ extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int 
     const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * (GB_ROW / 4) : 0;
     hipLaunchKernelGGL(gb_cover_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, n, H, W, (const int*)cover_scratch,
                        (const int*)cover_scratch + nb, (long long*)pix, inv_or_null, tri, v_pos, v_nrm, prior, prior_batch, V, F, out,
-                       extra_or_null, E, extra_out_or_null, (float4*)g_rows_to_clear_or_null, n_zero4, (int4*)rec_out_or_null);
+                       extra_or_null, E, extra_out_or_null, (float4*)g_rows_to_clear_or_null, n_zero4);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -497,21 +478,20 @@ extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int 
 template <int NC>
 static void gb_launch_bwd(bool big, hipStream_t s, const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P,
                           const float* v_pos, const float* v_nrm, const float* prior, int prior_batch, const float* clip, int V, int F, int H, int W,
-                          float* g_rows, int want_prior, const float* extra, int E, const float* g_extra, const int32_t* rec) {
+                          float* g_rows, int want_prior, const float* extra, int E, const float* g_extra) {
     const dim3 grid(a3d_div_up(P, 256)), block(256);
     if (!big)
         hipLaunchKernelGGL((gb_bwd_kernel<512, 640, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
-                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra, (const int4*)rec);
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
     else
         hipLaunchKernelGGL((gb_bwd_kernel<1024, 768, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
-                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra, (const int4*)rec);
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
 }
 
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                                const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
                                float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E,
-                               const float* g_extra_out_or_null, const int32_t* rec_or_null, a3d_stream_t stream) {
-    A3D_CHECK_ARG(!rec_or_null || ((uintptr_t)rec_or_null & 15) == 0);
+                               const float* g_extra_out_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
@@ -520,15 +500,15 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     hipStream_t s = (hipStream_t)stream;
     if (!g_rows_are_clear) A3D_HIP(hipMemsetAsync(g_rows, 0, sizeof(float) * GB_ROW * (size_t)B * V, s));
     if (P == 0) return A3D_OK;
-    A3D_CHECK_ARG(g_out && v_pos && v_nrm && prior && (rec_or_null || (rast && tri && pix)));
+    A3D_CHECK_ARG(g_out && rast && tri && pix && v_pos && v_nrm && prior);
     // covered pixels per triangle of the call (all triangles, visible or not): below ~0.6 most pixels own their three vertices
     const bool big = (double)P < 0.6 * (double)B * (double)F;
     if (extra_or_null)
         gb_launch_bwd<15>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior,
-                          extra_or_null, E, g_extra_out_or_null, rec_or_null);
+                          extra_or_null, E, g_extra_out_or_null);
     else
         gb_launch_bwd<12>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior, nullptr, 0,
-                          nullptr, rec_or_null);
+                          nullptr);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

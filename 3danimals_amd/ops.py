@@ -892,7 +892,6 @@ def interpolate_da(attr, rast, tri, rast_db, diff_attrs="all"):
 
 # ---------------------------------------------------------------------------------------------- fused G-buffer
 GBUFFER_GRAD_COLS = 16  # A3D_GBUFFER_GRAD_COLS of include/a3d.h
-GBUFFER_RECORDS = os.environ.get("A3D_GBUFFER_RECORDS", "1") != "0"  # the forward leaves a 32-byte record per point for the backward (one round trip instead of three)
 
 
 class _GBuffer(torch.autograd.Function):
@@ -922,16 +921,14 @@ class _GBuffer(torch.autograd.Function):
         # cleared by the forward launch: one memset less on the backward path
         needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
         rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device) if needs_grad else None
-        # ... and so is its record of every point (barycentrics, pixel, face, vertex ids: 32 bytes), which the forward writes while it has them
-        rec = torch.empty((P, 8), dtype=torch.int32, device=rast.device) if (needs_grad and GBUFFER_RECORDS) else None
         if listed:
             call("a3d_cover_gbuffer_fwd", ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(cover_scratch), P, ptr(pix), ptr(inv), ptr(v_pos),
-                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), ptr(rec), stream())
+                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
         else:
             call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), ptr(rec), stream())
+                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
         ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
-        ctx.rows, ctx.rec = rows, rec
+        ctx.rows = rows
         ctx.listed = listed
         if listed:  # (out[, extra_out], pix, inv): the list rides along as non-differentiable outputs
             ctx.mark_non_differentiable(pix, inv)
@@ -958,7 +955,7 @@ class _GBuffer(torch.autograd.Function):
             rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_bwd", ptr(f32h(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
              ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(clear), int(want_prior), ptr(extra), E,
-             None if extra is None else ptr(f32h(g_extra_out)), ptr(getattr(ctx, "rec", None)), stream())
+             None if extra is None else ptr(f32h(g_extra_out)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None

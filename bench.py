@@ -364,8 +364,8 @@ def parity_and_cpu_baseline(scene, args, threads):
     if rep["faces_equal"] and rep.get("geometry_only"):  # the step without rendering: the geometry stages are all there is
         parity.update(stages=dict(dmtet_vertices=rep["max_abs_vert_err"], prior_normals=rep["max_abs_prior_normal_err"], skinning=rep["max_abs_skin_err"],
                                   posed_normals=rep["max_abs_posed_normal_err"], posed_normal_err_vs_float64=rep["posed_normal_err_vs_float64"]),
-                      loss_rel_err={k: round(abs(float(cpu(out["losses"][k])) - float(v)) / max(abs(float(v)), 1e-12), 7) for k, v in res["losses"].items()
-                                    if k in out["losses"] and v.dim() == 0 and k != "mesh"},
+                      loss_rel_err={k: round(abs(float(cpu(out["losses"][k])) - float(res["losses"][k])) / max(abs(float(res["losses"][k])), 1e-12), 7)
+                                    for k in ("prior_normal_reg",)},  # (the other terms run over all frames here and over the CPU sample there)
                       note="no rendering in this step: DMTet index buffers bit-exact, vertices, skinning and both normals passes re-done by the CPU oracle "
                            "from the HIP output of the stage before")
         parity["pass"] = bool(rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 1e-5 and rep["max_abs_posed_normal_err"] < 1e-4)

@@ -377,23 +377,20 @@ int a3d_mesh_topology_finalize(const int32_t* tri, int V, int F, int32_t* count,
 #define A3D_GBUFFER_GRAD_COLS 16
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                     const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null, int E,
-                    float* extra_out_or_null, float* g_rows_to_clear_or_null, int32_t* rec_out_or_null, a3d_stream_t stream);
-/* rec_out (forward, optional, 16-byte aligned, [P,8] int32; round 5): the backward's record of every point -- (u, v) as float bits, the flat
- * pixel, the face, the three vertex ids, 0 -- which a3d_gbuffer_bwd(rec = ...) reads in one coalesced round trip instead of walking
- * list entry -> texel -> index row (rast / tri / pix may then be NULL there).
- * g_rows_to_clear (forward, optional): the backward's g_rows buffer, cleared by the forward launch; the backward is then called with
+                    float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream);
+/* g_rows_to_clear (forward, optional): the backward's g_rows buffer, cleared by the forward launch; the backward is then called with
  * g_rows_are_clear = 1 and skips its memset (a caller that runs the backward twice clears the second time itself: flag 0). */
 int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                     const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
                     float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null,
-                    const int32_t* rec_or_null, a3d_stream_t stream);
+                    a3d_stream_t stream);
 /* The covered-pixel list AND its G-buffer rows in one launch (= a3d_cover_emit + a3d_gbuffer_fwd; render.py:139-221 on the covered
  * pixels): cover_scratch as for a3d_cover_emit (tile = 8: H, W multiples of 8), P = the list's length (sum of the group sums, read
  * back by the caller), pix[P] / inv[B*H*W] and out[P,12] (+ extra_out[P,E]) written together; every texel is read once. */
 int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int B, int V, int F, int H, int W, const void* cover_scratch, int64_t P,
                           int64_t* pix, int32_t* inv_or_null, const float* v_pos, const float* v_nrm, const float* prior, int prior_batch,
                           float* out, const float* extra_or_null, int E, float* extra_out_or_null, float* g_rows_to_clear_or_null,
-                          int32_t* rec_out_or_null, a3d_stream_t stream);
+                          a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of

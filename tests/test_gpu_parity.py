@@ -3045,7 +3045,8 @@ def test_ponymation_stage2_without_rendering_gradients_vs_float64_oracle(dev):
     out = scene.step(backward=True, optimizer_step=False, sdf_reg=False)
     ref = step_ref.cpu_step(step_ref.snapshot(scene), backward=True, dtype=torch.float64)
     assert torch.equal(ref["faces"], scene.last["prior"].t_pos_idx[0].cpu())
-    assert float((out["posed"].detach().cpu() - ref["posed"]).abs().max()) < 1e-5 and float((out["normals"].detach().cpu() - ref["normals"]).abs().max()) < 5e-5
+    # (float32 against the float64 chain: the normals of the coarse grid's sliver fans are conditioned no better than ~1e-4, see compare_step)
+    assert float((out["posed"].detach().cpu() - ref["posed"]).abs().max()) < 1e-5 and float((out["normals"].detach().cpu() - ref["normals"]).abs().max()) < 3e-4
     np.testing.assert_allclose(float(out["loss"]), float(ref["loss"]), rtol=5e-5, atol=1e-7)
     for k, v in ref["losses"].items():
         np.testing.assert_allclose(float(out["losses"][k]), float(v), rtol=5e-4, atol=1e-6, err_msg=k)

@@ -55,7 +55,7 @@ def main():
         g = torch.rand(P, 12, device=dev)
         rows = torch.empty(B * V, 16, device=dev)
         fn = lambda: L.call("a3d_gbuffer_bwd", ptr(g), ptr(rast), ptr(tri32), ptr(pix), P, ptr(vpos), ptr(nrm), ptr(pv), 1, ptr(clip), B, V, F, H, W,
-                            ptr(rows), 0, 1, None, 0, None, None, stream())
+                            ptr(rows), 0, 1, None, 0, None, stream())
     elif what == "rast_fwd":
         out = torch.empty(B, H, W, 4, device=dev)
         scratch = torch.empty(L.lib().a3d_rast_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)

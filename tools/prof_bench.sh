@@ -11,8 +11,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-timing --networks fast "$@" > /tmp/prof_$TAG.log 2>&1 || (tail -20 /tmp/prof_$TAG.log; exit 1)
-tail -1 /tmp/prof_$TAG.log > $REPO/gpurun_out/${TAG}_bench_line.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-kernel-timing --no-fingerprint --networks fast "$@" > /tmp/prof_$TAG.log 2>&1 || (tail -20 /tmp/prof_$TAG.log; exit 1)
+grep '^{"metric"' /tmp/prof_$TAG.log | tail -1 > $REPO/gpurun_out/${TAG}_bench_line.json   # (the JSON line, not the profiler's last log line)
 cp /tmp/prof_$TAG/${TAG}_kernel_stats.csv $REPO/gpurun_out/${TAG}_kernel_stats.csv
 python $REPO/tools/rocprof_summary.py /tmp/prof_$TAG/${TAG}_kernel_stats.csv $((STEPS + WARM)) 30 > $REPO/gpurun_out/${TAG}_kernel_summary.txt
 head -60 $REPO/gpurun_out/${TAG}_kernel_summary.txt

@@ -1,13 +1,20 @@
 #!/bin/bash
 # Everything under profiles/ for one round, in the order that makes the committed lines self-consistent (run on the GPU box from the repo
 # root, then copy gpurun_out/<tag>_* into profiles/):   bash tools/regen_profiles.sh r04
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 bash tools/pmc_traffic.sh $TAG > gpurun_out/${TAG}_pmc.log 2>&1
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # (on the box: bench.py then finds the stamp of the sources it runs on)
 bash tools/run_bench_lines.sh $TAG > gpurun_out/${TAG}_lines.log 2>&1
 bash tools/prof_bench.sh ${TAG}_bench 20 5 > /dev/null 2>&1
 bash tools/prof_bench.sh ${TAG}_bcc51s 20 5 --grid bcc51s > /dev/null 2>&1
+# (round 5) rocprofv3 summaries of the other committed lines too: R = 128, ponymation (rendered and as configured), fauna, the trained-like mesh, the long run
+bash tools/prof_bench.sh ${TAG}_grid128 10 3 --grid-res 128 > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_ponymation 10 3 --workload ponymation > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_ponymation_norender 10 3 --workload ponymation --no-render --batch 20 --frames 10 > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_fauna 20 5 --workload fauna > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_spiky 20 5 --mesh spiky > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_long400 400 100 > /dev/null 2>&1
 python tools/bench_dmtet.py --grid kuhn64 bcc51s kuhn128 bcc102s --surf --passes plain auto --json gpurun_out/${TAG}_dmtet_grids.json > gpurun_out/${TAG}_dmtet_grids.txt 2>&1
 python tools/numbering_diag.py --grids kuhn64 kuhn64s bcc51 bcc51s --json gpurun_out/${TAG}_numbering.json > /dev/null 2>&1
 python tools/long_run_diag.py 600 2>&1 | grep "^[0-9]" > gpurun_out/${TAG}_long_run_diag.txt

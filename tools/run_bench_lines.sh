@@ -1,6 +1,6 @@
 #!/bin/bash
 # every committed bench line of a round (run on the GPU box from the repo root):  bash tools/run_bench_lines.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 run() { name=$1; shift; python bench.py "$@" > gpurun_out/${TAG}_bench_${name}.json 2> gpurun_out/${TAG}_bench_${name}.err || (echo "$name FAILED"; tail -5 gpurun_out/${TAG}_bench_${name}.err); tail -c 300 gpurun_out/${TAG}_bench_${name}.json | head -c 0; echo "$name done"; }
 run default
@@ -16,3 +16,6 @@ run fwd_b8_bcc102s --grid bcc102s --forward-only --batch 8 --networks fast --cpu
 # the long run: 400 timed steps after 100 of warm-up (the mesh the synthetic training drifts into; README quotes it beside the 25-step figure)
 run long400 --steps 400 --warmup 100 --networks fast --no-cpu-baseline
 run long400_fauna --workload fauna --steps 400 --warmup 100 --networks fast --no-cpu-baseline
+# (round 5) ponymation stage 2 as configured: 20 sequences x 10 frames, enable_render false (train_ponymation_horse_stage2.yaml:16-27); the trained-like mesh as the headline
+run ponymation_norender --workload ponymation --no-render --batch 20 --frames 10 --networks fast --cpu-sample-images 20 --cpu-runs 1
+run spiky --mesh spiky --networks fast
