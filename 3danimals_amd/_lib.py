@@ -50,6 +50,9 @@ SIGNATURES = {
     "a3d_cover_emit": (_c_int, [_p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_rast_bins_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "a3d_rast_resolve": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_rast_resolve_gbuffer_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _p, _p,
+                                              _c_int, _p, _p, _c_int, _p, _p, _p]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
@@ -105,7 +108,8 @@ class RastOpts(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("lists_stride", ctypes.c_int32), ("prev_rast", _p), ("cover_scratch", _p), ("aa_screen", _p),
                 ("aa_count", _p), ("topo_off", _p), ("topo_adj", _p), ("topo_opp", _p), ("normals_v_a", _p), ("normals_v_b", _p),
                 ("normals_off", _p), ("normals_adj", _p), ("normals_acc_a", _p), ("normals_a", _p), ("normals_acc_b", _p), ("normals_b", _p),
-                ("normals_B_a", ctypes.c_int32), ("normals_B_b", ctypes.c_int32), ("bins", _p), ("bin_cap", ctypes.c_int32), ("bins_clean", ctypes.c_int32)]
+                ("normals_B_a", ctypes.c_int32), ("normals_B_b", ctypes.c_int32), ("bins", _p), ("bin_cap", ctypes.c_int32), ("bins_clean", ctypes.c_int32),
+                ("defer_resolve", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class AaRide(ctypes.Structure):

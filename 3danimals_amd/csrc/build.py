@@ -64,7 +64,7 @@ def build(force=False, verbose=True, profile=False, exp=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(HERE, "topo_common.h"), os.path.join(HERE, "raster_common.h"), os.path.join(HERE, "cover_common.h"), os.path.join(HERE, "bones_common.h"), os.path.join(HERE, "normals_common.h"), os.path.join(HERE, "shade_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(HERE, "topo_common.h"), os.path.join(HERE, "raster_common.h"), os.path.join(HERE, "cover_common.h"), os.path.join(HERE, "bones_common.h"), os.path.join(HERE, "normals_common.h"), os.path.join(HERE, "shade_common.h"), os.path.join(HERE, "gbuffer_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

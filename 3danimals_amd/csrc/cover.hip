@@ -65,7 +65,9 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_emit_kernel(const float4* __restr
 extern "C" size_t a3d_cover_scratch_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t nb = (size_t)a3d_div_up((long long)B * H * W, CV_BLOCK);
-    return sizeof(int) * (nb + (size_t)a3d_div_up((long long)nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE);
+    // block counts | group sums (one per 64-byte line) | (round 5) the look-back flags of a3d_rast_resolve_gbuffer_fwd: one per block, one per group
+    const size_t ng = (size_t)a3d_div_up((long long)nb, A3D_COVER_GROUP);
+    return sizeof(int) * (nb + ng * A3D_COVER_GROUP_STRIDE + nb + ng);
 }
 
 extern "C" int a3d_cover_blocks(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : a3d_div_up((long long)B * H * W, CV_BLOCK); }

@@ -27,6 +27,8 @@
 #include "raster_common.h"
 #include "topo_common.h"
 #include "normals_common.h"
+#include "cover_common.h"
+#include "gbuffer_common.h"
 
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define RS_BIG 512          // boxes above this many pixels go through the tile stage
@@ -612,6 +614,134 @@ __global__ __launch_bounds__(256) void rs_fine_kernel(const float4* __restrict__
     A3D_STAMP(2, 5);
 }
 
+// ---- resolve + covered-pixel list + G-buffer rows in ONE launch (round 5): the atomic path's second launch and a3d_cover_gbuffer_fwd
+// are both one work-group per 256-pixel block in the list's tile order, the second one reading back the texels the first has just
+// written; what kept them apart is that a block's place in the list is the number of covered pixels in all blocks before it.  Here
+// every work-group counts its own (the keys say: covered <=> key != EMPTY), PUBLISHES the count, and its first wave looks the earlier
+// ones up -- two levels, like the sums the resolve used to leave: the counts of the earlier blocks of its group of 64 and the totals of
+// the earlier groups (published by each group's last block), <= 63 + nb / 64 flags, all requested at once, each awaited with an
+// agent-scope load in a sleep loop.  Work-groups are dispatched in the order of their linear index (x fastest), the list's order, and
+// a flag is published before its work-group waits for anything: the lowest-numbered unfinished work-group never waits on an
+// undispatched one, so the loop ends.  (A spin budget backs that up: when it runs out the work-group raises a status word and goes on
+// with what it has -- the caller re-runs through the two-launch path; nothing hangs.)  The gathers of the resolve and the look-up
+// are issued together, so the look-up hides behind them.
+// ``p_cap``: rows the caller allocated for the list (it does not know P yet: the previous frame's + a margin); entries past it are
+// dropped and the caller, who reads P from the group sums as before, re-runs a3d_cover_gbuffer_fwd when P > p_cap (the texels, the
+// block counts and the sums are complete either way).
+__device__ __forceinline__ int rs_await(const int* p, int* timeout, int exp = 0) {
+#ifdef A3D_EXPERIMENT
+    if (exp == 61) {  // measurement: poll with agent-scope LOADS (see below)
+        int w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; w == 0 && spin < (1 << 12); ++spin) {
+            __builtin_amdgcn_s_sleep(8);
+            w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (w == 0) { *timeout = 1; return 0; }
+        return w - 1;
+    }
+#endif
+    // (a RETURNING atomic, not a load: the flags live in ordinary device memory, which an XCD's L2 caches without cross-XCD coherence inside
+    // a kernel -- an sc1 load that has once fetched the line keeps answering from it, and the first version of this loop spun for
+    // seconds on flags that had long been published; atomics are performed at the memory side, where the publishers' adds land)
+    int v = __hip_atomic_fetch_add(const_cast<int*>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; v == 0 && spin < (1 << 15); ++spin) {  // (~50 ms: a correct run waits microseconds)
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_fetch_add(const_cast<int*>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (v == 0) { *timeout = 1; return 0; }
+    return v - 1;
+}
+
+__global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri, int V,
+                                                               int F, int H, int W, unsigned long long* __restrict__ keys,
+                                                               float4* __restrict__ rast, int* __restrict__ block_count,
+                                                               int* __restrict__ group_sum, int* blk_flag, int* grp_flag, int nb_total,
+                                                               long long* __restrict__ pix, int* __restrict__ inv, long long p_cap,
+                                                               const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
+                                                               const float* __restrict__ prior, int prior_batch, float* __restrict__ out,
+                                                               const float* __restrict__ extra, int E, float* __restrict__ extra_out,
+                                                               float4* __restrict__ zero_rows, long long n_zero4, int exp) {
+    __shared__ int wave_n[4];
+    __shared__ int s_off;
+    A3D_STAMP(3, 0);  // (kernel id 3 = rs_resolve_cover_kernel)
+    const int b = blockIdx.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned hw = (unsigned)H * (unsigned)W;
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    const unsigned in_tile = k & 63u, t = k >> 6, tw = (unsigned)W >> 3;
+    const unsigned ty = t / tw, tx = t - ty * tw;
+    const int py = (int)(ty * 8u + (in_tile >> 3)), px = (int)(tx * 8u + (in_tile & 7u));
+    const long long flat = (long long)b * hw + (unsigned)py * (unsigned)W + (unsigned)px;
+    for (long long z = (long long)L * 256 + threadIdx.x; z < n_zero4; z += (long long)nb_total * 256) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long key = keys[flat];
+    const bool on = key != RS_EMPTY;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wave_n[wave] = __popcll(m);
+    __syncthreads();
+    const int cnt = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    if (threadIdx.x == 0) {  // published before this work-group waits for anything
+        block_count[L] = cnt;
+        // (an atomic ADD onto the zeroed flag, not a store: device atomics are performed at the memory side, where every XCD's waiters look;
+        // a plain agent-scope store may sit in this XCD's L2 until the kernel ends)
+        __hip_atomic_fetch_add(blk_flag + L, cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the winner's texel: gathers requested now, the look-up below runs while they are in flight
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+        keys[flat] = RS_EMPTY;  // re-armed for the next call (scratch_is_clean)
+        const float4* pb = clip + (clip_batch == 1 ? 0ll : (long long)b * V);
+        const int f = (int)(unsigned)(key & 0xFFFFFFFFull);
+        const float4 p0 = pb[tri[3 * f]], p1 = pb[tri[3 * f + 1]], p2 = pb[tri[3 * f + 2]];
+        const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+        const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+        const RsFrag fr = rs_frag(p0, p1, p2, __builtin_fmaf(xs, (float)px, xo), __builtin_fmaf(ys, (float)py, yo));
+        o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+    }
+    rast[flat] = o;
+    const int g = L / A3D_COVER_GROUP, r = L - g * A3D_COVER_GROUP;
+    const bool last_of_group = r == A3D_COVER_GROUP - 1 || L == nb_total - 1;
+    if (wave == 0 && (cnt > 0 || last_of_group)) {
+        int timeout = 0;
+        int own = lane < r ? rs_await(blk_flag + g * A3D_COVER_GROUP + lane, &timeout, exp) : 0;  // earlier blocks of my group
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d, 64);
+        // (a group's total depends on its own blocks' counts ONLY and is published before this wave waits for the totals of earlier groups: no
+        // chain from group to group)
+        if (last_of_group && lane == 0) {
+            group_sum[(long long)g * A3D_COVER_GROUP_STRIDE] = own + cnt;  // (plain: what the host adds up, as before)
+            __hip_atomic_fetch_add(grp_flag + g, own + cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cnt > 0) {
+            int before = 0;
+            for (int j = lane; j < g; j += 64) before += rs_await(grp_flag + j, &timeout, exp);  // earlier groups
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+            if (lane == 0) s_off = before + own;
+        }
+        if (__ballot(timeout != 0) && lane == 0) atomicOr(group_sum + 3, 1);  // status word (never in the sums: word 3 of the first line)
+    }
+    A3D_STAMP(3, 1);
+    if (cnt == 0) {  // (uniform) background only: the map entries and out
+        if (inv) inv[flat] = -1;
+        A3D_STAMP(3, 5);
+        return;
+    }
+    __syncthreads();
+    if (!on) {
+        if (inv) inv[flat] = -1;
+        A3D_STAMP(3, 5);
+        return;
+    }
+    int oidx = s_off + a3d_wave_prefix(m);
+    for (int w = 0; w < wave; ++w) oidx += wave_n[w];
+    if (inv) inv[flat] = oidx;
+    if (oidx < p_cap) {
+        pix[oidx] = flat;
+        gb_row(o, flat, oidx, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)hw, out, extra, E, extra_out);
+    }
+    A3D_STAMP(3, 5);
+}
+
 // backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; FOUR lanes per pixel, lane = component of the 16-byte gradient
 // row of a vertex (x, y, -, w): every lane repeats the pixel's small algebra and adds its own component, so the three adds of a
 // (pixel, vertex) pair are one request to the L2's atomic unit instead of three (line-coalesced atomics)
@@ -694,7 +824,11 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
     const long long npix = (long long)B * H * W;
     // the covered-pixel block counts ride along when the list's tile order applies and its blocks do not cross images
     A3D_CHECK_ARG(!cover_scratch_or_null || (H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0));
-    const int cover_nb = (int)(npix / 256), cover_ng = a3d_div_up(cover_nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE;  // (words of the group-sum area)
+    const int cover_nb = (int)(npix / 256);
+    // (words zeroed behind the block counts by the triangle launch: the group-sum area, and -- defer_resolve -- the look-back flags after it)
+    const bool defer = o.defer_resolve != 0 && cover_scratch_or_null && !binned && !prev_rast_or_null && F > 0;
+    A3D_CHECK_ARG(!o.defer_resolve || defer);
+    const int cover_ng = a3d_div_up(cover_nb, A3D_COVER_GROUP) * A3D_COVER_GROUP_STRIDE + (defer ? cover_nb + a3d_div_up(cover_nb, A3D_COVER_GROUP) : 0);
     A3D_CHECK_ARG(F > 0 || !normals_v_a_or_null);  // (no triangle launch to ride in)
     if (F == 0) {
         A3D_HIP(hipMemsetAsync(rast, 0, sizeof(float) * 4 * (size_t)npix, s));
@@ -745,12 +879,49 @@ extern "C" int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tr
         A3D_LAUNCH_CHECK();
         return A3D_OK;
     }
+    if (defer) return A3D_OK;  // (the caller resolves: a3d_rast_resolve_gbuffer_fwd, or a3d_rast_resolve)
     if (cover_scratch_or_null)
         hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
                            V, H, W, keys, (float4*)rast, (int*)cover_scratch_or_null);
     else
         hipLaunchKernelGGL(rs_resolve_kernel<false>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, s, (const float4*)clip, clip_batch, tri,
                            V, H, W, keys, (float4*)rast, (int*)nullptr);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+// the second half of a3d_rast_fwd(defer_resolve = 1), stand-alone: the resolve launch (texels, block counts, group sums)
+extern "C" int a3d_rast_resolve(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
+                                void* cover_scratch, a3d_stream_t stream) {
+    A3D_CHECK_ARG(clip && tri && rast && scratch && cover_scratch && B > 0 && V > 0 && F > 0 && H > 0 && W > 0 && B <= 65535);
+    A3D_CHECK_ARG((clip_batch == 1 || clip_batch == B) && H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0 && (long long)B * H * W < 0x7fffffffll);
+    hipLaunchKernelGGL(rs_resolve_kernel<true>, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, (const float4*)clip, clip_batch,
+                       tri, V, H, W, (unsigned long long*)scratch, (float4*)rast, (int*)cover_scratch);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+// ... or fused with the covered-pixel list and its G-buffer rows (rs_resolve_cover_kernel)
+extern "C" int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
+                                            void* scratch, void* cover_scratch, int64_t p_cap, int64_t* pix, int32_t* inv_or_null,
+                                            const float* v_pos, const float* v_nrm, const float* prior, int prior_batch, float* out,
+                                            const float* extra_or_null, int E, float* extra_out_or_null, float* g_rows_to_clear_or_null,
+                                            a3d_stream_t stream) {
+    A3D_CHECK_ARG(clip && tri && rast && scratch && cover_scratch && B > 0 && V > 0 && F > 0 && H > 0 && W > 0 && B <= 65535 && p_cap >= 0);
+    A3D_CHECK_ARG((clip_batch == 1 || clip_batch == B) && H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0 && (long long)B * H * W < 0x7fffffffll);
+    A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
+    A3D_CHECK_ARG(p_cap == 0 || (pix && v_pos && v_nrm && prior && out));
+    A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || p_cap == 0)));
+    A3D_CHECK_ARG(!g_rows_to_clear_or_null || ((uintptr_t)g_rows_to_clear_or_null & 63) == 0);
+    const int nb = (int)((long long)B * H * W / 256), ng = a3d_div_up(nb, A3D_COVER_GROUP);
+    int* cs = (int*)cover_scratch;
+    int* group_sum = cs + nb;
+    int* blk_flag = group_sum + (size_t)ng * A3D_COVER_GROUP_STRIDE;
+    const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * 4 : 0;  // (A3D_GBUFFER_GRAD_COLS / 4 float4 per (image, vertex))
+    hipLaunchKernelGGL(rs_resolve_cover_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, (const float4*)clip, clip_batch,
+                       tri, V, F, H, W, (unsigned long long*)scratch, (float4*)rast, cs, group_sum, blk_flag, blk_flag + nb, nb, (long long*)pix,
+                       inv_or_null, (long long)p_cap, v_pos, v_nrm, prior, prior_batch, out, extra_or_null, E, extra_out_or_null,
+                       (float4*)g_rows_to_clear_or_null, n_zero4, a3d_exp());
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

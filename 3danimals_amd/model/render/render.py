@@ -36,6 +36,7 @@ LAST_RAST = [None]
 LAST_POINTS = [None]  # introspection hook like LAST_RAST: what the fused path handed from stage to stage in the last render_mesh call
 FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused HIP kernel (csrc/gbuffer.hip)
 FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
+DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"  # ... and the rasteriser's resolve in that launch too (a3d_rast_resolve_gbuffer_fwd)
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
 FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
 FUSED_SHADING = True
@@ -425,13 +426,19 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         return _render_mesh_layers(mesh, clip_f, tri, w2c, view_pos, material, lgt, resolution, spp, num_layers, msaa, background, bsdf, feat,
                                    render_modes, prior_mesh, two_sided_shading, dino_net, class_vector, delta_xy)
     job = mesh.normals_job() if hasattr(mesh, "normals_job") else None  # pending auto_normals: extra work-groups of the triangle launch
-    rast = ops.rasterize(clip_f, tri, full_res, normals_job=job)
+    mask_only = (FUSED_MASK_RENDER and FUSED_COMPOSITE and material is None and lgt is None and dino_net is None and list(render_modes) == ["shaded"]
+                 and spp == 1 and (background is None or not background.requires_grad))
+    # when render_layer's fused path is certain to come next, the rasteriser's resolve waits for it: ONE launch then writes the texels,
+    # the covered-pixel list and the G-buffer rows (ops.DEFER_RESOLVE; the conditions are render_layer's own)
+    defer = (DEFER_RESOLVE and not mask_only and FUSED_GBUFFER and FUSED_COVER_GBUFFER and SHADE_COVERED_ONLY and PIXEL_TILE == 8 and spp == 1
+             and not ({"tangent", "depth"} & set(render_modes)) and clip_f.shape[0] == mesh.v_pos.shape[0]
+             and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr() and full_res[0] % 8 == 0 and full_res[1] % 8 == 0)
+    rast = ops.rasterize(clip_f, tri, full_res, normals_job=job, defer_resolve=defer)
     if job is not None:
         mesh.take_normals(job)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     LAST_POINTS[0] = None
-    if (FUSED_MASK_RENDER and FUSED_COMPOSITE and material is None and lgt is None and dino_net is None and list(render_modes) == ["shaded"]
-            and spp == 1 and (background is None or not background.requires_grad)):
+    if mask_only:
         _resolve_bsdf(bsdf, material)  # the reference's asserts come first (render.py:79,85): bsdf None without a material, 'pbr' without a light
         # shade() gives every covered pixel kd = (1,1,1) here (render.py:57-60, :84-85 with lgt None): the image is the coverage, and the only
         # gradient is the silhouette's.  Fauna's random-view mask (Fauna.py:111-173).  No covered-pixel list, no G-buffer, no read-back.

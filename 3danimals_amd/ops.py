@@ -654,12 +654,13 @@ def _cover_counted(rast, tile):
     """(scratch, length of the list): block counts + group sums left by the rasteriser's resolve (same launch), otherwise a counting pass
     of our own; the ONE read-back: the group sums (a few KB; unused words are zero), added up on the host."""
     B, H, W = rast.shape[:3]
+    ensure_resolved(rast)
     scratch = _cover_counts.peek(rast) if tile == 8 else None
     if scratch is None:
         scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=rast.device)
         call("a3d_cover_count", ptr(rast), B, H, W, tile, ptr(scratch), stream())
     nb = _lib.lib().a3d_cover_blocks(B, H, W)
-    tail = _lib.read_back(scratch[nb:])  # THE read-back: one sum per group of 64 blocks, one per 64-byte line; words 1, 2 of the first line: the binned rasteriser's status
+    tail = _lib.read_back(scratch[nb:nb + _lib.lib().a3d_cover_groups(B, H, W) * _lib.lib().a3d_cover_group_stride()])  # THE read-back: one sum per group of 64 blocks, one per 64-byte line; words 1, 2 of the first line: the binned rasteriser's status
     if tail.shape[0] > 2 and int(tail[1]) > 0:
         _rast_bins_grow((rast.device, B, H, W), int(tail[1]), int(tail[2]))
     return scratch, int(tail[::_lib.lib().a3d_cover_group_stride()].sum())
@@ -685,6 +686,29 @@ def covered_pixels(rast, tile=8, return_inverse=False):
 
 # ---------------------------------------------------------------------------------------------- rasterise
 _rast_keys = {}
+# (round 5) rasterize(defer_resolve=True): only the triangle launch runs; the raster buffer is WRITTEN by the covered_gbuffer call that
+# follows (a3d_rast_resolve_gbuffer_fwd: resolve + covered-pixel list + G-buffer rows in one launch, the list offsets by decoupled
+# look-back) -- or, for any other reader, by ensure_resolved (the stand-alone resolve).  The list's length is not known when that launch
+# is enqueued: its rows are allocated for the previous frame's length + 25 % (per device and frame size) and the exact two-launch path
+# re-runs when the frame outgrew them.
+DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"
+_pending_resolve = _IdentityCache(maxsize=2)  # raster buffer -> what its resolve needs (clip, triangle list, key buffer)
+_cover_last_len = {}  # (device, B, H, W) -> length of the last covered-pixel list
+resolve_events = dict(fused=0, outgrown=0, standalone=0)
+
+
+def ensure_resolved(rast):
+    """Run the stand-alone resolve launch now if ``rast`` came out of rasterize(defer_resolve=True) and nothing has resolved it yet."""
+    pend = _pending_resolve.take(rast)
+    if pend is None:
+        return
+    B, H, W = rast.shape[:3]
+    clip, tri32 = pend["clip"], pend["tri32"]
+    call("a3d_rast_resolve", ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W, ptr(pend["rast"]), ptr(pend["keys"]),
+         ptr(_cover_counts.peek(rast)), stream())
+    _rast_keys[pend["key"]] = pend["keys"]  # (re-armed by the resolve)
+    resolve_events["standalone"] += 1
+
 # the binned path (a3d_rast_opts.bins: per-tile triangle lists + a fine pass, no memory-side atomics): its scratch is kept per (device,
 # stream, frame) like the key buffer (the fine pass leaves the tile counts at zero), the capacity of a tile list per (device, frame):
 # 1024 entries to start with, 4 x the largest count ever reported above half the capacity (the covered-pixel read-back carries the
@@ -713,7 +737,7 @@ def _rast_bins_grow(key, max_count, overflowed):
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, clip, tri32, B, H, W, prev, job):
+    def forward(ctx, clip, tri32, B, H, W, prev, job, defer=False):
         require_device(clip, tri32, what="rasterize")
         clip = f32c(clip)
         V, F = clip.shape[1], tri32.shape[0]
@@ -772,8 +796,10 @@ class _Rasterize(torch.autograd.Function):
         opts.lists_stride = stride
         if bins is not None:
             opts.bins, opts.bin_cap, opts.bins_clean = ptr(bins[0]), bins[1], int(bins[2])
+        defer = bool(defer) and DEFER_RESOLVE and cover is not None and bins is None and prev is None and F > 0
+        opts.defer_resolve = int(defer)
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ctypes.addressof(opts), stream(),
-             tag="" if job is None else f"[N{opts.normals_B_a}+{opts.normals_B_b}]")
+             tag=("" if job is None else f"[N{opts.normals_B_a}+{opts.normals_B_b}]") + ("[defer]" if defer else ""))
         if bins is not None:
             if len(_rast_bins) >= 4:
                 _rast_bins.clear()
@@ -789,7 +815,9 @@ class _Rasterize(torch.autograd.Function):
             _aa_prepared.put(rast.detach(), (_IdentityCache.key(clip), aa_screen, aa_count, clip.detach()))
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
-        if scratch is not None and (F > 0 or clean):  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching
+        if defer:  # the keys are full until a resolve has consumed them: they travel with the raster buffer, not back into the cache
+            _pending_resolve.put(rast.detach(), dict(clip=clip, tri32=tri32, keys=scratch, key=key, rast=rast))
+        elif scratch is not None and (F > 0 or clean):  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching
             _rast_keys[key] = scratch  # them: a fresh torch.empty buffer must not come back as "clean"; a failed call leaves the buffer out too)
         ctx.save_for_backward(clip, tri32, rast)
         return rast
@@ -801,17 +829,19 @@ class _Rasterize(torch.autograd.Function):
         g_clip = torch.empty_like(clip)
         call("a3d_rast_bwd", ptr(f32h(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
              ptr(g_clip), stream())
-        return g_clip, None, None, None, None, None, None
+        return g_clip, None, None, None, None, None, None, None
 
 
-def rasterize(clip, tri, resolution, batch=None, prev=None, normals_job=None):
+def rasterize(clip, tri, resolution, batch=None, prev=None, normals_job=None, defer_resolve=False):
     """clip [B|1,V,4] -> rast [B,H,W,4] = (u, v, z/w, triangle_id+1); differentiable through (u,v).  ``prev`` = the previous
     depth layer (DepthPeeler.rasterize_next_layer for layer n > 0): the nearest surface strictly behind it is returned.
-    ``normals_job``: a NormalsJob over the same triangle list, run as extra work-groups of the triangle launch."""
+    ``normals_job``: a NormalsJob over the same triangle list, run as extra work-groups of the triangle launch.
+    ``defer_resolve``: the caller promises that covered_gbuffer(..., rast, ...) comes next (render_mesh's fused path): the texels are then
+    written by THAT launch (see DEFER_RESOLVE); any other reader must call ensure_resolved(rast) first (covered_pixels does)."""
     if clip.dim() == 2:
         clip = clip[None]
     B = clip.shape[0] if batch is None else batch
-    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]), prev, normals_job)
+    return _Rasterize.apply(clip, tri_int32(tri), B, int(resolution[0]), int(resolution[1]), prev, normals_job, defer_resolve)
 
 
 def rasterize_db(clip, tri, rast):
@@ -904,24 +934,61 @@ class _GBuffer(torch.autograd.Function):
         assert clip.shape[:2] == (B, V) and v_pos.shape[0] == B and v_nrm.shape == v_pos.shape and prior.shape[0] in (1, B)
         listed = pix is None  # no list given: build it in the same launch (a3d_cover_gbuffer_fwd) and return it with the rows
         inv = cover_scratch = None
-        if listed:
-            cover_scratch, P = _cover_counted(rast, 8)
-            pix = torch.empty(P, dtype=torch.int64, device=rast.device)
-            inv = torch.empty(B * H * W, dtype=torch.int32, device=rast.device)
-        P = pix.shape[0]
-        assert pix.dtype == torch.int64 and pix.is_contiguous()
-        out = torch.empty((P, 12), dtype=torch.float32, device=rast.device)
-        E, extra_out = 0, None
+        dev = rast.device
+        E = 0
         if extra is not None:
             extra = f32c(extra)
             E = extra.shape[2]
             assert extra.shape[:2] == (B, V) and 1 <= E <= 3
-            extra_out = torch.empty((P, E), dtype=torch.float32, device=rast.device)
         # when a backward will follow, its gradient rows (one 64-byte row per (image, vertex), see backward) are allocated now and
         # cleared by the forward launch: one memset less on the backward path
         needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
-        rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device) if needs_grad else None
-        if listed:
+        rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=dev) if needs_grad else None
+        out = extra_out = None
+        cap_key = (dev, B, H, W)
+        pend = _pending_resolve.peek(rast) if listed else None
+        if pend is not None and cap_key in _cover_last_len:
+            # the raster buffer is still keys (rasterize(defer_resolve=True)): resolve, list and rows from ONE launch, the rows allocated for
+            # the previous frame's list length + 25 %; the read-back of the true length comes after the launch is enqueued
+            _pending_resolve.take(rast)
+            cap = max(1024, -(-int(1.25 * _cover_last_len[cap_key] + 1) // 1024) * 1024)
+            clip_r, tri_r = pend["clip"], pend["tri32"]
+            cover_scratch = _cover_counts.peek(rast)
+            pix_c = torch.empty(cap, dtype=torch.int64, device=dev)
+            inv = torch.empty(B * H * W, dtype=torch.int32, device=dev)
+            out_c = torch.empty((cap, 12), dtype=torch.float32, device=dev)
+            extra_c = torch.empty((cap, E), dtype=torch.float32, device=dev) if extra is not None else None
+            call("a3d_rast_resolve_gbuffer_fwd", ptr(clip_r), clip_r.shape[0], ptr(tri_r), B, V, tri_r.shape[0], H, W, ptr(rast), ptr(pend["keys"]),
+                 ptr(cover_scratch), cap, ptr(pix_c), ptr(inv), ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out_c), ptr(extra), E,
+                 ptr(extra_c), ptr(rows), stream())
+            _rast_keys[pend["key"]] = pend["keys"]  # (every key the launch consumed is re-armed)
+            nb = _lib.lib().a3d_cover_blocks(B, H, W)
+            tail = _lib.read_back(cover_scratch[nb:nb + _lib.lib().a3d_cover_groups(B, H, W) * _lib.lib().a3d_cover_group_stride()])
+            P = int(tail[::_lib.lib().a3d_cover_group_stride()].sum())
+            if int(tail[3]) != 0:
+                raise _lib.A3DError("a3d_rast_resolve_gbuffer_fwd: a look-back ran out of its spin budget (work-groups not dispatched in order?)")
+            _cover_last_len[cap_key] = P
+            resolve_events["fused"] += 1
+            if P <= cap:
+                pix, out, extra_out = pix_c[:P], out_c[:P], (extra_c[:P] if extra_c is not None else None)
+            else:  # outgrown: texels, block counts and sums are complete -- the exact list + rows through the two-launch path's second half
+                resolve_events["outgrown"] += 1
+                pix = torch.empty(P, dtype=torch.int64, device=dev)
+        elif listed:
+            cover_scratch, P = _cover_counted(rast, 8)  # (resolves a deferred buffer first)
+            _cover_last_len[cap_key] = P
+            pix = torch.empty(P, dtype=torch.int64, device=dev)
+            inv = torch.empty(B * H * W, dtype=torch.int32, device=dev)
+        P = pix.shape[0]
+        assert pix.dtype == torch.int64 and pix.is_contiguous()
+        fused_done = out is not None
+        if out is None:
+            out = torch.empty((P, 12), dtype=torch.float32, device=dev)
+            if extra is not None:
+                extra_out = torch.empty((P, E), dtype=torch.float32, device=dev)
+        if fused_done:
+            pass
+        elif listed:
             call("a3d_cover_gbuffer_fwd", ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(cover_scratch), P, ptr(pix), ptr(inv), ptr(v_pos),
                  ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
         else:

@@ -99,6 +99,8 @@ def algorithmic_bytes(name, d):
     """
     B, V, F, HW, Nv, Ne, Nt, K = d["B"], d["V"], d["F"], d["H"] * d["W"], d["Nv"], d["Ne"], d["Nt"], d["K"]
     Bv = int(d.get("skin_v_batch", 1))
+    if "[defer]" in name:  # the rasteriser's triangle launch alone: the texels are written (and credited) by a3d_rast_resolve_gbuffer_fwd
+        return algorithmic_bytes(name.replace("[defer]", ""), d) - 16 * B * HW
     if "[+shade]" in name:  # the colour computed on the spot: G-buffer row + kd in (60 B per point) instead of the shaded row (12 B)
         return algorithmic_bytes(name.replace("[+shade]", ""), d) + 48 * int(d.get("P", 0))
     if name.endswith("[+analysis]"):  # the silhouette analysis rode in this call's first launch: both passes' bytes
@@ -159,6 +161,10 @@ def algorithmic_bytes(name, d):
         # list + map + rows in one launch: the texels of the 256-pixel blocks that hold a covered pixel in (16 B/pixel; the empty blocks are
         # known from the rasteriser's block counts, 4 B each), list + pixel -> entry map + rows out
         "a3d_cover_gbuffer_fwd": 16 * 256 * int(d.get("cover_blocks", B * HW // 256)) + 4 * (B * HW // 256) + 8 * P + 4 * B * HW + 48 * P,
+        # resolve + list + rows in one launch: texels out (16 B/pixel), list + pixel -> entry map + rows out; the 8-byte keys it consumes
+        # and re-arms are staging (not credited), the texels are not read back at all
+        "a3d_rast_resolve_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P,
+        "a3d_rast_resolve": 16 * B * HW,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2

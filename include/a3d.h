@@ -323,8 +323,27 @@ typedef struct a3d_rast_opts {
     void* bins;                    /* a3d_rast_bins_bytes(B, H, W, bin_cap) bytes */
     int32_t bin_cap;               /* entries per tile list (>= 16) */
     int32_t bins_clean;
+    /* (402) defer_resolve: only the triangle launch runs (cover_scratch required; its look-back flags are zeroed); `rast` is written by the
+     * caller's next call -- a3d_rast_resolve_gbuffer_fwd (resolve + covered-pixel list + G-buffer rows in one launch) or a3d_rast_resolve. */
+    int32_t defer_resolve;
+    int32_t reserved;
 } a3d_rast_opts;
 size_t a3d_rast_bins_bytes(int B, int H, int W, int bin_cap); /* 0: the frame cannot take the binned path */
+/* The second half of a3d_rast_fwd(defer_resolve = 1) on the same `scratch` (keys) and `cover_scratch`:
+ * a3d_rast_resolve = the resolve launch alone (texels + block counts + group sums);
+ * a3d_rast_resolve_gbuffer_fwd = resolve AND a3d_cover_gbuffer_fwd in ONE launch: every 256-pixel block counts its covered pixels from the
+ *   keys, publishes the count and looks the earlier blocks' counts up itself (two-level decoupled look-back over agent-scope flags in
+ *   cover_scratch), so the texels are never read back and no launch boundary separates the two.  p_cap = rows allocated for pix / out /
+ *   extra_out (the caller does not know P yet): entries past it are dropped; the caller reads P from the group sums as usual and, when
+ *   P > p_cap, re-runs a3d_cover_gbuffer_fwd (texels, block counts and sums are complete either way).  Word 3 of the group-sum area is
+ *   a status word: non-zero = a look-back ran out of its spin budget (never observed; the caller then re-runs likewise).
+ * Replaces the same reference lines as a3d_rast_fwd + a3d_cover_gbuffer_fwd (render.py:292-294, 139-221). */
+int a3d_rast_resolve(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
+                     void* cover_scratch, a3d_stream_t stream);
+int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
+                                 void* scratch, void* cover_scratch, int64_t p_cap, int64_t* pix, int32_t* inv_or_null, const float* v_pos,
+                                 const float* v_nrm, const float* prior, int prior_batch, float* out, const float* extra_or_null, int E,
+                                 float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream);
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,

@@ -1135,7 +1135,8 @@ def test_training_step_runs_in_twelve_hot_path_calls(dev):
         return {n: c for n, (c, _) in timer.summary().items() if n.startswith(hot)}
 
     train = calls(True)
-    assert train == {"a3d_dmtet_count": 1, "a3d_dmtet_emit": 1, "a3d_skin_pose_fwd": 1, "a3d_rast_fwd[N16+1]": 1, "a3d_cover_gbuffer_fwd": 1,
+    # (round 5: the rasteriser's resolve, the covered-pixel list and the G-buffer rows are ONE launch now -- still twelve calls, two kernels less)
+    assert train == {"a3d_dmtet_count": 1, "a3d_dmtet_emit": 1, "a3d_skin_pose_fwd": 1, "a3d_rast_fwd[N16+1][defer]": 1, "a3d_rast_resolve_gbuffer_fwd": 1,
                      "a3d_composite_aa_fwd[C4+C17][+shade][+analysis]": 1, "a3d_composite_aa_bwd[C4+C17]": 1, "a3d_shade_bwd": 1,
                      "a3d_gbuffer_bwd": 1, "a3d_normals_bwd[B16]": 1, "a3d_skin_pose_bwd": 1, "a3d_dmtet_bwd": 1}, train
     with torch.no_grad():
@@ -1382,7 +1383,7 @@ def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(see
     switches = [(ops, "DMTET_CULL_MIN_VERTS", 0, 1 << 30), (ops, "DMTET_EMIT_LISTS", True, False), (ops, "DMTET_SPECULATIVE_EMIT", True, False),
                 (ops, "DMTET_TOPOLOGY", True, False), (M, "RIDE_NORMALS", True, False), (R, "FUSED_COVER_GBUFFER", True, False),
                 (R, "DEFER_ANALYSIS", True, False), (R, "FUSED_COMPOSITE", True, False), (R, "SHADE_IN_COMPOSITOR", True, False),
-                (R, "FUSED_MASK_RENDER", True, False)]
+                (R, "FUSED_MASK_RENDER", True, False), (R, "DEFER_RESOLVE", True, False)]
 
     def run(on):
         for mod, name, a, b in switches:
@@ -2717,7 +2718,7 @@ def test_texture_less_render_through_the_mask_compositor_equals_the_general_path
     assert float((out_f[:, 3] > 0).float().mean()) > 0.05 and float(((out_f[:, 3] > 0.01) & (out_f[:, 3] < 0.99)).float().mean()) > 1e-3
     assert float(g_g.abs().max()) > 0 and float((g_f - g_g).abs().max()) <= 1e-4 * float(g_g.abs().max())
     assert calls_f == ["a3d_mask_aa_bwd[C4]", "a3d_mask_aa_fwd[C4][+analysis]", "a3d_rast_fwd"], calls_f
-    assert any(c.startswith("a3d_cover_gbuffer_fwd") for c in calls_g) and any(c.startswith("a3d_composite_aa_fwd") for c in calls_g)
+    assert any(c.startswith(("a3d_cover_gbuffer_fwd", "a3d_rast_resolve_gbuffer_fwd")) for c in calls_g) and any(c.startswith("a3d_composite_aa_fwd") for c in calls_g)
 
 
 def test_shading_inside_the_compositor_equals_the_separate_launch(dev, mods, monkeypatch):
@@ -2995,7 +2996,7 @@ def test_binned_rasteriser_equals_the_atomic_path_bit_for_bit(case, dev, ops, mo
         for _ in range(2):  # twice: the second call finds its scratch re-armed by the first (bins_clean / scratch_is_clean)
             rast = ops.rasterize(clip_d, tri_d, (H, W))
             cover = ops._cover_counts.peek(rast.detach())
-            outs.append((rast.cpu(), cover[:nb].cpu(), cover[nb:].cpu()))
+            outs.append((rast.cpu(), cover[:nb].cpu(), cover[nb:nb + L.lib().a3d_cover_groups(B, H, W) * 16].cpu()))
         return outs
 
     a, b = run(True), run(False)
@@ -3083,3 +3084,46 @@ def test_empty_leg_quadrant_on_the_gpu_is_a_python_exception_at_the_next_read_ba
     with pytest.raises(RuntimeError, match="no vertex in a leg quadrant"):
         S.estimate_bones(half, compute_kinematic_chain=True, **kw)
     del L._deferred[:]
+
+
+# ------------------------------------------------------------------------------------------------ resolve + list + rows in one launch (round 5)
+@pytest.mark.parametrize("B,hw,E", [(16, (256, 256), 0), (3, (64, 96), 2), (5, (512, 384), 0), (1, (16, 16), 0)])
+def test_resolve_cover_gbuffer_in_one_launch_equals_the_two_launch_path(B, hw, E, dev, ops, mods):
+    """rasterize(defer_resolve=True) + covered_gbuffer (a3d_rast_resolve_gbuffer_fwd: the list offsets by decoupled look-back) against
+    rasterize + covered_gbuffer (a3d_rast_fwd's resolve, then a3d_cover_gbuffer_fwd): the same texels, list, pixel -> entry map, rows (bit
+    for bit) and gradients, over several frames of a moving mesh -- the first frame has no list length to allocate by (stand-alone
+    resolve), one frame is made to OUTGROW the capacity the frame before left (exact re-run), frames with nothing on screen in between."""
+    H, W = hw
+    _, faces, clip0, _ = _scene(B, res=32 if B == 16 else 16)
+    tri = faces.to(dev)
+    V = clip0.shape[1]
+    g = torch.Generator().manual_seed(3)
+    v_pos = torch.randn(B, V, 3, generator=g).to(dev)
+    v_nrm = torch.nn.functional.normalize(torch.randn(B, V, 3, generator=g), dim=-1).to(dev)
+    prior = torch.randn(1, V, 3, generator=g).to(dev)
+    extra = torch.randn(B, V, E, generator=g).to(dev) if E else None
+    before = dict(ops.resolve_events)
+    ops._cover_last_len.clear()
+    scales = [1.0, 1.03, 0.4, 1.6, 1e-3 if B > 1 else 1.0, 1.0]  # 0.4 -> 1.6: the list grows ~16x, far beyond + 25 %; 1e-3: (nearly) nothing covered
+
+    def frame(scale, defer):
+        clip = clip0.clone()
+        clip[..., :2] *= scale
+        clip = clip.to(dev).requires_grad_(True)
+        vp = v_pos.clone().requires_grad_(True)
+        rast = ops.rasterize(clip, tri, (H, W), defer_resolve=defer)
+        res = ops.covered_gbuffer(clip, vp, v_nrm, prior, rast, tri, extra=extra)
+        gb, pix, inv = res[0], res[-2], res[-1]
+        wgt = seeded((gb.shape[0], 12), 5, -1, 1).to(dev)
+        loss = (gb * wgt).sum() + (0 if extra is None else res[1].sum())
+        grads = torch.autograd.grad(loss, [clip, vp]) if gb.shape[0] else (torch.zeros_like(clip), torch.zeros_like(vp))
+        return rast.detach().clone(), gb.detach().clone(), pix.clone(), inv.clone(), (res[1].detach().clone() if extra is not None else None), grads
+
+    for scale in scales:
+        a, b_ = frame(scale, True), frame(scale, False)
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2]) and torch.equal(a[3], b_[3]), scale  # texels, list, map
+        assert torch.equal(a[1], b_[1]) and (extra is None or torch.equal(a[4], b_[4])), scale  # rows
+        for x, y in zip(a[5], b_[5]):
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(float(y.abs().max()), 1e-12))
+    ev = {k: ops.resolve_events[k] - before[k] for k in before}
+    assert ev["fused"] >= 4 and ev["standalone"] >= 1 and (ev["outgrown"] >= 1 or B < 16), ev  # (small frames sit below the 1024-row minimum)
