@@ -32,6 +32,7 @@ KERNELS = {
     "sk_bwd": ("skin", 1, {1: "stage + weights + g_v (phase 1)", 2: "matrix phase", 3: "tiles to LDS + barrier", 4: "share of g_T + barrier", 5: "chain adjoint + atomics"}),
     "rs_tri": ("raster", 0, {1: "set-up: indices, vertices, box, prefix (-> barrier)", 2: "pooled fragment tests + atomics", 5: "barrier (big boxes listed)"}),
     "rs_resolve": ("raster", 1, {5: "whole kernel"}),
+    "rs_resolve_cover": ("raster", 3, {1: "keys, count published, winner's gathers, texel, look-up of the earlier counts", 5: "list entry + G-buffer row (uncovered: -1)"}),
     "gb_cover_fwd": ("gbuffer", 0, {1: "texel + block offset (-> barrier)", 5: "row: 3 gathers x 3 arrays, stores (uncovered: -1)"}),
     "gb_bwd": ("gbuffer", 1, {1: "loads + pixel adjoint", 2: "DPP merges", 3: "stage into LDS lists (-> barrier)", 4: "slot compaction (-> barrier)", 5: "list walks + row atomics"}),
     "sh_bwd": ("shade", 0, {1: "per-point adjoint + stores", 5: "per-image row reduction + atomics"}),

@@ -38,6 +38,8 @@ ENTRY = {
     "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel", "nr_face_bwd_kernel", "nr_sum_bwd_kernel"], "nr_sum_bwd_kernel"),
     # (the triangle launch also carries the vertex normals of the step: nr_fwd's work as extra work-groups)
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
+    # (round 5: the resolve of a deferred rasterisation + the covered-pixel list + the G-buffer rows, one launch)
+    "a3d_rast_resolve_gbuffer_fwd": (["rs_resolve_cover_kernel"], "rs_resolve_cover_kernel"),
     "a3d_cover_count": (["cv_count_kernel"], "cv_count_kernel"),
     "a3d_cover_emit": (["cv_emit_kernel"], "cv_emit_kernel"),
     "a3d_gbuffer_fwd": (["gb_fwd_kernel"], "gb_fwd_kernel"),
