@@ -87,14 +87,28 @@ SPIKES = dict(omega=8.0, tau=0.93, length=3.0, gamma=1.0, phase=(0.3, 1.1, 2.0),
               centre=(0.0, 0.45, 0.0))
 
 
+_SPIKE_CONSTANTS = {}
+
+
+def _spike_constant(pts, values):
+    """A small constant as a tensor of pts' device / dtype, uploaded once (a per-call new_tensor is a pageable host -> device copy that
+    blocks the host until the stream drains: three of them made the trained-like step five read-backs long instead of two)."""
+    key = (pts.device, pts.dtype, tuple(values))
+    if key not in _SPIKE_CONSTANTS:
+        if len(_SPIKE_CONSTANTS) > 64:
+            _SPIKE_CONSTANTS.clear()
+        _SPIKE_CONSTANTS[key] = torch.tensor(values, dtype=pts.dtype, device=pts.device)
+    return _SPIKE_CONSTANTS[key]
+
+
 def synthetic_spikes(pts, params=None):
     """[...,3] canonical positions -> [...,3] displacement (zero off the peaks).  Pure torch, any device / dtype."""
     q = dict(SPIKES, **(params or {}))
     amp = 0.0
     for om, tau, length, ph in ((q["omega"], q["tau"], q["length"], q["phase"]), (q["omega2"], q["tau2"], q["length2"], q["phase2"])):
-        g = torch.sin(om * pts + pts.new_tensor(ph)).prod(-1).abs()
+        g = torch.sin(om * pts + _spike_constant(pts, ph)).prod(-1).abs()
         amp = amp + length * ((g - tau) / (1.0 - tau)).clamp(min=0.0) ** q["gamma"]
-    d = pts - pts.new_tensor(q["centre"])
+    d = pts - _spike_constant(pts, q["centre"])
     return amp[..., None] * d / d.norm(dim=-1, keepdim=True).clamp(min=1e-6)
 
 

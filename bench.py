@@ -57,7 +57,8 @@ PMC_WORKLOAD = "magicpony grid64 batch16 256x256 train"  # what tools/pmc_traffi
 
 
 def workload_signature(args, batch):
-    return f"{args.workload} grid{grid_name(args).replace('kuhn', '')} batch{batch} {args.resolution}x{args.resolution} {'forward' if args.forward_only else 'train'}"
+    return (f"{args.workload} grid{grid_name(args).replace('kuhn', '')} batch{batch} {args.resolution}x{args.resolution} {'forward' if args.forward_only else 'train'}"
+            + ("" if getattr(args, "mesh", "quadruped") == "quadruped" else f" mesh-{args.mesh}") + (" no-render" if getattr(args, "no_render", False) else ""))
 
 
 def grid_name(args):
