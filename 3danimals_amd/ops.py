@@ -695,6 +695,7 @@ DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"
 _pending_resolve = _IdentityCache(maxsize=2)  # raster buffer -> what its resolve needs (clip, triangle list, key buffer)
 _cover_last_len = {}  # (device, B, H, W) -> length of the last covered-pixel list
 resolve_events = dict(fused=0, outgrown=0, standalone=0)
+_debug_force_lookback_timeout = False  # tests: take the recovery path of a timed-out look-back
 
 
 def ensure_resolved(rast):
@@ -965,10 +966,23 @@ class _GBuffer(torch.autograd.Function):
             nb = _lib.lib().a3d_cover_blocks(B, H, W)
             tail = _lib.read_back(cover_scratch[nb:nb + _lib.lib().a3d_cover_groups(B, H, W) * _lib.lib().a3d_cover_group_stride()])
             P = int(tail[::_lib.lib().a3d_cover_group_stride()].sum())
-            if int(tail[3]) != 0:
-                raise _lib.A3DError("a3d_rast_resolve_gbuffer_fwd: a look-back ran out of its spin budget (work-groups not dispatched in order?)")
-            _cover_last_len[cap_key] = P
             resolve_events["fused"] += 1
+            if int(tail[3]) != 0 or _debug_force_lookback_timeout:
+                # a look-back ran out of its spin budget (never observed; it would mean work-groups were not dispatched in the order of their
+                # index): offsets and sums of this launch are not to be trusted -- but the TEXELS are complete (they do not depend on the
+                # look-up).  Count from the texels, take the two-launch path's second half, and stop deferring in this process.
+                import warnings
+
+                globals()["DEFER_RESOLVE"] = False
+                resolve_events["timeouts"] = resolve_events.get("timeouts", 0) + 1
+                warnings.warn("a3d_rast_resolve_gbuffer_fwd: look-back timed out; recovered through a3d_cover_count + a3d_cover_gbuffer_fwd, "
+                              "deferred resolve switched off for this process")
+                cover_scratch = torch.empty(_lib.lib().a3d_cover_scratch_bytes(B, H, W) // 4, dtype=torch.int32, device=dev)
+                call("a3d_cover_count", ptr(rast), B, H, W, 8, ptr(cover_scratch), stream())
+                _cover_counts.put(rast, cover_scratch)
+                tail = _lib.read_back(cover_scratch[nb:nb + _lib.lib().a3d_cover_groups(B, H, W) * _lib.lib().a3d_cover_group_stride()])
+                P, cap = int(tail[::_lib.lib().a3d_cover_group_stride()].sum()), -1
+            _cover_last_len[cap_key] = P
             if P <= cap:
                 pix, out, extra_out = pix_c[:P], out_c[:P], (extra_c[:P] if extra_c is not None else None)
             else:  # outgrown: texels, block counts and sums are complete -- the exact list + rows through the two-launch path's second half

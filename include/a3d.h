@@ -336,7 +336,8 @@ size_t a3d_rast_bins_bytes(int B, int H, int W, int bin_cap); /* 0: the frame ca
  *   cover_scratch), so the texels are never read back and no launch boundary separates the two.  p_cap = rows allocated for pix / out /
  *   extra_out (the caller does not know P yet): entries past it are dropped; the caller reads P from the group sums as usual and, when
  *   P > p_cap, re-runs a3d_cover_gbuffer_fwd (texels, block counts and sums are complete either way).  Word 3 of the group-sum area is
- *   a status word: non-zero = a look-back ran out of its spin budget (never observed; the caller then re-runs likewise).
+ *   a status word: non-zero = a look-back ran out of its spin budget (never observed): the list offsets and sums of that call are not to be
+ *   trusted, the texels are -- the caller counts from them (a3d_cover_count) and calls a3d_cover_gbuffer_fwd.
  * Replaces the same reference lines as a3d_rast_fwd + a3d_cover_gbuffer_fwd (render.py:292-294, 139-221). */
 int a3d_rast_resolve(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
                      void* cover_scratch, a3d_stream_t stream);

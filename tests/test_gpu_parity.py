@@ -3133,3 +3133,14 @@ def test_resolve_cover_gbuffer_in_one_launch_equals_the_two_launch_path(B, hw, E
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(float(y.abs().max()), 1e-12))
     ev = {k: ops.resolve_events[k] - before[k] for k in before}
     assert ev["fused"] >= 4 and ev["standalone"] >= 1 and (ev["outgrown"] >= 1 or B < 16), ev  # (small frames sit below the 1024-row minimum)
+    # a look-back that ran out of its spin budget (never observed; forced here): the texels do not depend on the look-up, so the frame is
+    # recovered by counting from them + the two-launch path's second half, with a warning, and the process stops deferring
+    ops._debug_force_lookback_timeout = True
+    try:
+        with pytest.warns(UserWarning, match="look-back timed out"):
+            a = frame(1.0, True)
+        assert ops.DEFER_RESOLVE is False
+    finally:
+        ops._debug_force_lookback_timeout, ops.DEFER_RESOLVE = False, True
+    b_ = frame(1.0, False)
+    assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2]) and torch.equal(a[3], b_[3])
