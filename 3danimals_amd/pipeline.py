@@ -78,12 +78,13 @@ def synthetic_quadruped_device(pts, leg_radius):
 
 # A "trained-like" mesh the driver can see (bench.py --mesh spiky): what the synthetic training drifts into after a few hundred optimiser
 # steps is the quadruped with a percent of its vertices pulled out into thin spikes (profiles/r04_long_run_diag.txt, step 600: mean
-# pixel box 36, a few boxes of 9e3 pixels, 3.1e5 covered pixels where the fresh mesh has 14 / 129 / 2.0e5) -- and the rasteriser's and
+# pixel box 36-46, a few boxes of 9e3-1.7e4 pixels, 3.1-3.6e5 covered pixels where the fresh mesh has 14 / 129 / 2.0e5; tools/spiky_diag.py:
+# 36 / 9.5e3 / 2.75e5 for these parameters, 6 % of the boxes above 64 pixels) -- and the rasteriser's and
 # the compositor backward's cost follow depth complexity and silhouette length.  The spikes are a fixed, smooth displacement field of
 # the CANONICAL position (sparse peaks of a product of sines, pushed radially away from the body axis), added to the rest vertices where
 # the instance deformation is added (InstancePredictorBase.py:306-313): an input generator like the quadruped SDF, shared with the oracle.
 # (two scales: narrow peaks = the few spikes of thousands of pixels; broad, low bumps = the tenth of the triangles stretched above 64)
-SPIKES = dict(omega=8.0, tau=0.93, length=3.0, gamma=1.0, phase=(0.3, 1.1, 2.0), omega2=3.5, tau2=0.5, length2=0.5, phase2=(1.7, 0.2, 0.9),
+SPIKES = dict(omega=8.0, tau=0.94, length=3.0, gamma=1.0, phase=(0.3, 1.1, 2.0), omega2=3.0, tau2=0.3, length2=1.0, phase2=(1.7, 0.2, 0.9),
               centre=(0.0, 0.45, 0.0))
 
 
