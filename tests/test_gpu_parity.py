@@ -3151,3 +3151,15 @@ def test_resolve_cover_gbuffer_in_one_launch_equals_the_two_launch_path(B, hw, E
         ops._debug_force_lookback_timeout, ops.DEFER_RESOLVE = False, True
     b_ = frame(1.0, False)
     assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2]) and torch.equal(a[3], b_[3])
+
+
+@pytest.mark.parametrize("case", [(1, 3, (40, 72), 16, 1.0), (5, 4, (256, 256), 28, 1.6), (7, 3, (96, 96), -20, 1.0)])
+def test_switch_matrix_under_guard_mode(case, dev, ops, mods, monkeypatch, guard):
+    """The A/B matrix of every launch-folding switch (all on, all off, two mixed settings) once more with every library buffer between
+    canaries and poisoned (guard level 2): the modular entry points behind the switches -- a3d_cover_count / _emit, a3d_gbuffer_fwd,
+    a3d_aa_analyze, a3d_aa_fwd / _bwd, a3d_mesh_topology, the streaming DMTet count -- get the same scrutiny as the fused path."""
+    L = importlib.import_module("3danimals_amd._lib")
+    guard(2)
+    before = L.guard_stats["checks"]
+    test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(*case, dev, ops, mods, monkeypatch)
+    assert L.guard_stats["checks"] - before > 100
