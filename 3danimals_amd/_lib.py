@@ -42,6 +42,9 @@ SIGNATURES = {
     "a3d_normals_bwd": (_c_int, [_p, _c_int, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_shade_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _p, _c_int, _p]),
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _c_int, _p]),
+    "a3d_shade_bwd_rows": (_c_int, [_p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _c_int, ctypes.c_int64, _p]),
+    "a3d_xfm_points_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_xfm_points_bwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_cover_blocks": (_c_int, [_c_int, _c_int, _c_int]),
     "a3d_cover_groups": (_c_int, [_c_int, _c_int, _c_int]),
@@ -52,7 +55,7 @@ SIGNATURES = {
     "a3d_rast_bins_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "a3d_rast_resolve": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_rast_resolve_gbuffer_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _p, _p,
-                                              _c_int, _p, _p, _c_int, _p, _p, _p]),
+                                              _c_int, _p, _p, _c_int, _p, _p, _p, _p]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
@@ -60,19 +63,19 @@ SIGNATURES = {
     "a3d_mesh_topology": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     "a3d_mesh_topology_finalize_max_vertices": (_c_int, []),
     "a3d_mesh_topology_finalize": (_c_int, [_p, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
-    "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p]),
+    "a3d_gbuffer_fwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p]),
     "a3d_cover_gbuffer_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, ctypes.c_int64, _p, _p, _p, _p, _p, _c_int, _p, _p, _c_int,
-                                       _p, _p, _p]),
+                                       _p, _p, _p, _p]),
     "a3d_gbuffer_bwd": (_c_int, [_p, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int,
-                                 _c_int, _p, _c_int, _p, _p]),
+                                 _c_int, _p, _c_int, _p, _p, _p]),
     "a3d_gemm_nn_relumask": (_c_int, [_p, _p, _p, ctypes.c_int64, _c_int, _c_int, _p, _p]),
     "a3d_harmonic_embed_fwd": (_c_int, [_p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),
     "a3d_harmonic_embed_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, ctypes.c_int64, _p, _p]),
     "a3d_recon_losses_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_recon_losses_mask_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_recon_losses_columns": (_c_int, []),
-    "a3d_recon_losses_fwd": (_c_int, [_p, _p, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
-    "a3d_recon_losses_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_recon_losses_fwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    "a3d_recon_losses_bwd": (_c_int, [_p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_flow_loss_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "a3d_flow_loss_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p]),
     "a3d_flow_loss_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
@@ -123,14 +126,29 @@ class CaBuffer(ctypes.Structure):
     """a3d_ca_buffer of include/a3d.h."""
 
     _fields_ = [("size", ctypes.c_uint32), ("C", ctypes.c_int32), ("vals", _p), ("bg", _p), ("out", _p), ("g_out", _p), ("g_vals", _p),
-                ("bg_batch", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("bg_batch", ctypes.c_int32), ("reserved", ctypes.c_int32), ("bg_channels", ctypes.c_int32), ("g_stride", ctypes.c_int32),
+                ("g_channels", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("vals_rows", ctypes.c_int64)]
 
 
 class CaShade(ctypes.Structure):
     """a3d_ca_shade of include/a3d.h."""
 
     _fields_ = [("size", ctypes.c_uint32), ("kd_stride", ctypes.c_int32), ("gb", _p), ("par", _p), ("kd", _p), ("clear", _p),
-                ("n_clear", ctypes.c_int32), ("two_sided", ctypes.c_int32)]
+                ("n_clear", ctypes.c_int32), ("two_sided", ctypes.c_int32), ("params", _p)]
+
+
+class ShadeParams(ctypes.Structure):
+    """a3d_shade_params of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("rot_row_stride", ctypes.c_int32), ("rot", _p), ("view", _p), ("light", _p),
+                ("rot_image_stride", ctypes.c_int64), ("view_image_stride", ctypes.c_int64), ("light_image_stride", ctypes.c_int64)]
+
+
+class GbAux(ctypes.Structure):
+    """a3d_gb_aux of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("reserved", ctypes.c_int32), ("tex_out", _p), ("img_out", _p), ("rows", ctypes.c_int64),
+                ("pad_to", ctypes.c_int64)]
 
 
 class DmtetEmitOpts(ctypes.Structure):
@@ -142,7 +160,7 @@ class DmtetEmitOpts(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
-ABI_VERSION = 402  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 403  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

@@ -379,11 +379,12 @@ struct CaSrc {
     // vals == null with sh_gb (C == 3): the value of point q is kd[q] * shading(q), computed on the spot from the G-buffer row, the image's
     // camera / light row and kd -- a3d_shade_fwd's arithmetic (shade_common.h) without its launch and without the [P,3] round trip
     const float* sh_gb;   // [P,12]
-    const float* sh_par;  // [B,17]
+    ShPar sh_par;         // the images' camera / light rows (a [B,17] table, or the caller's own tensors: a3d_shade_params)
     const float* sh_kd;   // [P,3], row stride sh_kd_stride
     int sh_kd_stride, sh_two_sided;
-    const float* bg;    // [bg_batch, H, W, C+1] or null (zeros)
+    const float* bg;    // [bg_batch, H, W, bgC] or null (zeros); channels bgC .. C read as 0
     int bg_shared;      // bg_batch == 1
+    int bgC;
     int C;
     unsigned hw;
 };
@@ -393,7 +394,7 @@ __device__ __forceinline__ int ca_point(const CaSrc& s, unsigned p) {  // >= 0: 
 }
 
 __device__ __forceinline__ float3 ca_shaded(const CaSrc& s, int q, unsigned p) {  // (sh_gb given) the shaded colour of point q = pixel p
-    const ShFwd f = sh_forward(s.sh_gb + 12ll * q, s.sh_par + 17ll * (p / s.hw), 17, s.sh_two_sided);
+    const ShFwd f = sh_forward(s.sh_gb + 12ll * q, s.sh_par.row(p / s.hw), s.sh_two_sided);
     const float* k = s.sh_kd + (long long)s.sh_kd_stride * q;
     return make_float3(k[0] * f.shading, k[1] * f.shading, k[2] * f.shading);
 }
@@ -405,9 +406,9 @@ __device__ __forceinline__ float ca_pre(const CaSrc& s, unsigned p, int c) {
         return c == 0 ? v.x : (c == 1 ? v.y : v.z);
     }
     if (q >= 0) return (c < s.C && s.vals) ? s.vals[(long long)q * s.C + c] : 1.f;
-    if (!s.bg) return 0.f;
+    if (!s.bg || c >= s.bgC) return 0.f;
     const unsigned r = s.bg_shared ? p % s.hw : p;
-    return s.bg[(long long)r * (s.C + 1) + c];
+    return s.bg[(long long)r * s.bgC + c];
 }
 
 // One or two buffers per launch (blockIdx.y picks the job): the render path composites and antialiases the colour image and the
@@ -418,8 +419,10 @@ struct CaJob {
     float* clear;        // forward: n_clear floats zeroed by the compose launch (a3d_ca_shade: the shading backward's per-image rows)
     int n_clear;
     float* out;          // forward: [B,H,W,C+1]
-    const float* g_out;  // backward: [B,H,W,C+1]
-    float* g_vals;       // backward: [P,C]
+    const float* g_out;  // backward: [B,H,W,gS] of which the first gC channels are the gradient of the image's (the rest: zero)
+    int gS, gC;
+    float* g_vals;       // backward: [vals_rows >= P, C], rows past P zero
+    long long vals_rows;
 };
 
 // 256 pixels per work-group: the pixel -> source map goes through LDS once, then the work-group writes the pixels' C+1 floats as one
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned base = bx * 256u, p = base + threadIdx.x;
     for (unsigned z = p; z < (unsigned)job.n_clear; z += nb_compose * 256u) job.clear[z] = 0.f;
-    if (s.C == 3 && (((uintptr_t)out | (uintptr_t)s.bg) & 15) == 0) {
+    if (s.C == 3 && (((uintptr_t)out | (s.bgC == 4 ? (uintptr_t)s.bg : 0)) & 15) == 0) {
         if (p >= n_pix) return;
         const int q = ca_point(s, p);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -465,7 +468,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             else if (s.sh_gb) { const float3 c3 = ca_shaded(s, q, p); v = make_float4(c3.x, c3.y, c3.z, 1.f); }
             else v = make_float4(1.f, 1.f, 1.f, 1.f);
         }
-        else if (s.bg) v = reinterpret_cast<const float4*>(s.bg)[s.bg_shared ? p % s.hw : p];
+        else if (s.bg) {
+            const unsigned r = s.bg_shared ? p % s.hw : p;
+            if (s.bgC == 4) v = reinterpret_cast<const float4*>(s.bg)[r];
+            else {  // the reference's 3-channel background as it is: alpha 0 (render.py:254-256 appends it per call)
+                const float* g = s.bg + (long long)r * s.bgC;
+                v = make_float4(s.bgC > 0 ? g[0] : 0.f, s.bgC > 1 ? g[1] : 0.f, s.bgC > 2 ? g[2] : 0.f, 0.f);
+            }
+        }
         v4f nt; nt.x = v.x; nt.y = v.y; nt.z = v.z; nt.w = v.w;
         __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(out) + p);
         A3D_STAMP(0, 5);
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const int src = s_src[pl];
             v[k] = 0.f;
             if (src >= 0) v[k] = (c < s.C && s.vals) ? s.vals[(long long)src * s.C + c] : 1.f;
-            else if (src <= -2) v[k] = s.bg[(long long)(-2 - src) * C1 + c];
+            else if (src <= -2) v[k] = c < s.bgC ? s.bg[(long long)(-2 - src) * s.bgC + c] : 0.f;
         }
         v4f q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
         __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(o + j0));
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int src = s_src[pl];
         float v = 0.f;
         if (src >= 0) v = (c < s.C && s.vals) ? s.vals[(long long)src * s.C + c] : 1.f;
-        else if (src <= -2) v = s.bg[(long long)(-2 - src) * C1 + c];
+        else if (src <= -2) v = c < s.bgC ? s.bg[(long long)(-2 - src) * s.bgC + c] : 0.f;
         o[j] = v;
     }
     if (blockIdx.y) A3D_STAMP(0, 3);
@@ -556,8 +566,12 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, cons
         for (long long i = p; i < nz; i += (long long)gridDim.x * 256) zero[i] = 0.f;
     __syncthreads();
     A3D_STAMP(2, 1);
+    {   // rows past P (the padding rows of a field's point list): zeros
+        const long long z0 = max(base, P) * C, z1 = min(base + 256, job.vals_rows) * C;
+        for (long long j = z0 + threadIdx.x; j < z1; j += 256) job.g_vals[j] = 0.f;
+    }
     if (base >= P) return;
-    const int nloc = (int)min(256ll, P - base) * C, C1 = C + 1;
+    const int nloc = (int)min(256ll, P - base) * C, gS = job.gS, gC = job.gC;
     const float rc = 1.f / (float)C;
     float* o = job.g_vals + base * C;
     // four elements per thread in flight: written as a plain loop every load waited for the store before it (the compiler cannot rule
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(256) void ca_gather_kernel(CaJob ja, CaJob jb, cons
         for (int k = 0; k < 4; ++k) {
             const int j = j0 + 256 * k, jc = j < nloc ? j : j0;
             const int pl = (int)(((float)jc + 0.5f) * rc), c = jc - pl * C;
-            v[k] = g_out[(long long)s_pix[pl] * C1 + c];
+            v[k] = c < gC ? g_out[(long long)s_pix[pl] * gS + c] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
     const int n = aa_segment_offsets(count, capacity, s_off);
     A3D_STAMP(3, 1);
     const float xh = 0.5f * W, yh = 0.5f * H;
-    const int C = s.C, C1 = s.C + 1;
+    const int C = s.C, C1 = min(s.C + 1, job.gC), gS = job.gS;  // (channels without a gradient contribute nothing)
     const int sub = threadIdx.x & 31, groups = (gridDim.x * blockDim.x) >> 5;
     for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; r < n; r += groups) {
         const AaRec rec = work[aa_record_slot(r, s_off, capacity)];
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
         const int q0 = ca_point(s, p0), q1 = ca_point(s, p1);
         float dd = 0.f;
         for (int c = sub; c < C1; c += 32) {
-            const float gd = g_out[(long long)dst * C1 + c];
+            const float gd = g_out[(long long)dst * gS + c];
             if (gd != 0.f) {
                 if (c < C && g_vals) {  // (a constant colour has no adjoint)
                     if (q1 >= 0) atomicAdd(g_vals + (long long)q1 * C + c, rec.alpha * gd);
@@ -717,23 +731,37 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
 }
 
 static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* bg, int bg_batch, int H, int W, float* out, const float* g_out,
-                    float* g_vals) {
+                    float* g_vals, const a3d_ca_buffer* ext = nullptr, long long P = 0) {
     CaJob j;
-    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = nullptr; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0;
+    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = ShPar{}; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0;
     j.s.sh_two_sided = 0; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
+    j.s.bgC = (ext && ext->bg_channels > 0) ? ext->bg_channels : C + 1;
     j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0;
+    j.gS = (ext && ext->g_stride > 0) ? ext->g_stride : C + 1;
+    j.gC = (ext && ext->g_channels > 0) ? ext->g_channels : C + 1;
+    j.vals_rows = (ext && ext->vals_rows > P) ? ext->vals_rows : P;
     return j;
+}
+static bool ca_ext_ok(const a3d_ca_buffer* b) {
+    return b->bg_channels >= 0 && b->bg_channels <= b->C + 1 && b->g_channels >= 0 && b->g_channels <= b->C + 1 && b->g_stride >= 0 &&
+           (b->g_stride == 0 || b->g_stride >= (b->g_channels > 0 ? b->g_channels : b->C + 1)) && b->vals_rows >= 0;
 }
 
 // the deferred shading of a compositor call's first buffer (a3d_ca_shade): the job's values come from sh_forward instead of vals
 static int ca_shade(const a3d_ca_shade* sh, int C, const float* vals, CaJob* j, bool forward) {
     if (!sh) return A3D_OK;
     A3D_CHECK_ARG(sh->size >= sizeof(a3d_ca_shade));
-    A3D_CHECK_ARG(!vals && C == 3 && sh->gb && sh->par && sh->kd && sh->kd_stride >= 3 && sh->n_clear >= 0 && (sh->n_clear == 0 || sh->clear));
-    // (the colour computed on the spot exists only on the compose kernel's 16-byte path: a forward call whose image or background is not
-    // 16-byte aligned would take the general path, which has no shading source -- refused instead of composited wrongly)
-    A3D_CHECK_ARG(!forward || ((((uintptr_t)j->out | (uintptr_t)j->s.bg) & 15) == 0));
-    j->s.sh_gb = sh->gb; j->s.sh_par = sh->par; j->s.sh_kd = sh->kd; j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
+    A3D_CHECK_ARG(!vals && C == 3 && sh->gb && (sh->par || sh->params) && sh->kd && sh->kd_stride >= 3 && sh->n_clear >= 0 && (sh->n_clear == 0 || sh->clear));
+    if (sh->params) {
+        const a3d_shade_params* q = sh->params;
+        A3D_CHECK_ARG(q->size >= sizeof(a3d_shade_params) && q->rot && q->view && q->light && (q->rot_row_stride == 3 || q->rot_row_stride == 4));
+        A3D_CHECK_ARG(q->rot_image_stride >= 0 && q->view_image_stride >= 0 && q->light_image_stride >= 0);
+    }
+    // (the colour computed on the spot exists only on the compose kernel's 16-byte path: a forward call whose image or 4-channel background
+    // is not 16-byte aligned would take the general path, which has no shading source -- refused instead of composited wrongly)
+    A3D_CHECK_ARG(!forward || ((((uintptr_t)j->out | (j->s.bgC == 4 ? (uintptr_t)j->s.bg : 0)) & 15) == 0));
+    j->s.sh_gb = sh->gb; j->s.sh_par = sh->params ? sh_par_of(sh->params) : sh_par_table(sh->par, 17); j->s.sh_kd = sh->kd;
+    j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
     if (forward) { j->clear = sh->clear; j->n_clear = sh->n_clear; }
     return A3D_OK;
 }
@@ -773,9 +801,10 @@ extern "C" int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buf
     const bool two = out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 + 1 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B)));
     hipStream_t s = (hipStream_t)stream;
-    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr);
+    A3D_CHECK_ARG(ca_ext_ok(first) && (!second_or_null || ca_ext_ok(second_or_null)));
+    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, out, nullptr, nullptr, first);
     if (int rc = ca_shade(shade_or_null, C, vals, &ja, true)) return rc;
-    const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr) : ja;
+    const CaJob jb = two ? ca_job(vals2_or_null, C2, inv, bg2_or_null, bg2_batch, H, W, out2_or_null, nullptr, nullptr, second_or_null) : ja;
     const unsigned n_pix = (unsigned)B * ja.s.hw;
     const unsigned nb_compose = (unsigned)a3d_div_up(n_pix, 256), rows = two ? 2u : 1u;
     hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + (nb_an + rows - 1) / rows, rows), dim3(256), 0, s, ja, jb, n_pix, nb_compose, an, a3d_exp() == 43 ? 0 : 1);
@@ -804,12 +833,13 @@ extern "C" int a3d_composite_aa_bwd(const a3d_ca_buffer* first, const a3d_ca_buf
     const bool two = g_out2_or_null != nullptr;
     A3D_CHECK_ARG(!two || (C2 > 0 && C2 <= 4096 && (!bg2_or_null || bg2_batch == 1 || bg2_batch == B) && (P == 0 || (vals2 && g_vals2))));
     hipStream_t s = (hipStream_t)stream;
-    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, nullptr, g_out, g_vals);
+    A3D_CHECK_ARG(ca_ext_ok(first) && (!second_or_null || ca_ext_ok(second_or_null)));
+    CaJob ja = ca_job(vals, C, inv, bg_or_null, bg_batch, H, W, nullptr, g_out, g_vals, first, (long long)P);
     if (int rc = ca_shade(shade_or_null, C, vals, &ja, false)) return rc;
-    const CaJob jb = two ? ca_job(vals2, C2, inv, bg2_or_null, bg2_batch, H, W, nullptr, g_out2_or_null, g_vals2) : ja;
+    const CaJob jb = two ? ca_job(vals2, C2, inv, bg2_or_null, bg2_batch, H, W, nullptr, g_out2_or_null, g_vals2, second_or_null, (long long)P) : ja;
     {
         const long long nz = 4ll * clip_batch * V;
-        long long blocks = a3d_div_up((long long)P, 256);
+        long long blocks = a3d_div_up(ja.vals_rows > jb.vals_rows ? ja.vals_rows : jb.vals_rows, 256);
         if (blocks < 64) blocks = 64;  // enough work-groups to zero g_clip when the point list is short
         hipLaunchKernelGGL(ca_gather_kernel, dim3((unsigned)blocks, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const long long*)pix, (long long)P, g_clip, nz);
         A3D_LAUNCH_CHECK();

@@ -34,6 +34,7 @@ SOURCES = {
     "gemm.hip": [],
     "antialias.hip": ["-ffp-contract=off"],
     "topology.hip": [],
+    "xfm.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",
           "-Wno-unused-function"]

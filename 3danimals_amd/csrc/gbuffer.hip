@@ -33,13 +33,17 @@ __global__ __launch_bounds__(256) void gb_fwd_kernel(const float4* __restrict__ 
                                                      long long P, const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                      const float* __restrict__ prior, int prior_batch, int V, int F, long long hw,
                                                      float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
+                                                     float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4,
+                                                     const GbAux aux, int last_image) {
+    float* __restrict__ tex_out = aux.tex_out;
+    long long* __restrict__ img_out = aux.img_out;
+    if (blockIdx.x == 0) gb_fill_padding(aux, P, last_image);
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // the backward's gradient rows cleared here, while this launch is waiting for its gathers anyway (saves the backward its memset)
     for (long long z = p; z < n_zero4; z += (long long)gridDim.x * blockDim.x) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p >= P) return;
     const long long i = pix[p];
-    gb_row(rast[i], i, p, tri, v_pos, v_nrm, prior, prior_batch, V, F, hw, out, extra, E, extra_out);
+    gb_row(rast[i], i, p, tri, v_pos, v_nrm, prior, prior_batch, V, F, hw, out, extra, E, extra_out, tex_out, img_out);
 }
 
 // The covered-pixel list AND its G-buffer rows in one launch (a3d_cover_emit + a3d_gbuffer_fwd): thread = position k of the tile-ordered
@@ -52,7 +56,11 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
                                                            const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                            const float* __restrict__ prior, int prior_batch, int V, int F,
                                                            float* __restrict__ out, const float* __restrict__ extra, int E,
-                                                           float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4) {
+                                                           float* __restrict__ extra_out, float4* __restrict__ zero_rows, long long n_zero4,
+                                                           const GbAux aux, long long P, int last_image) {
+    float* __restrict__ tex_out = aux.tex_out;
+    long long* __restrict__ img_out = aux.img_out;
+    if (blockIdx.x == 0) gb_fill_padding(aux, P, last_image);
     __shared__ int wave_n[4];
     __shared__ int s_off;
     A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = gb_cover_fwd_kernel, 1 = gb_bwd_kernel)
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void gb_cover_fwd_kernel(const float4* __restr
     for (int w = 0; w < wave; ++w) o += wave_n[w];
     pix[o] = flat;
     if (inv) inv[flat] = o;
-    gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out);
+    gb_row(r, flat, o, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra, E, extra_out, tex_out, img_out);
     A3D_STAMP(0, 5);
 }
 
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch,
                                                      const float4* __restrict__ clip, int V, int F, int H, int W, float* __restrict__ g_rows,
                                                      int want_prior, const float* __restrict__ extra, int E,
-                                                     const float* __restrict__ g_extra) {
+                                                     const float* __restrict__ g_extra, const float* __restrict__ g_tex) {
     constexpr int ST = NC == 12 ? 13 : 17;  // floats per staged entry: NC sums + the previous entry of the same slot, odd stride
     __shared__ int s_key[GB_SLOTS];    // vertex row (b*V + v) of a slot, -1 = free
     __shared__ int s_head[GB_SLOTS];   // last staged entry of the slot's list
@@ -274,7 +282,10 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
         if (want_clip) { const float4* cb = clip + (long long)b * V; p0 = cb[i0]; p1 = cb[i1]; p2 = cb[i2]; }
         const float4* gp = reinterpret_cast<const float4*>(g_out + p * 12);
         const float4 ga = gp[0], gb4 = gp[1], gc = gp[2];
-        const float g[12] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z, gc.w};
+        float g[12] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z, gc.w};
+        if (g_tex) {  // the canonical position's gradient arrives as rows of its own (the fields' input gradient): columns 9..11 of g_out are not read
+            g[9] = g_tex[3 * p]; g[10] = g_tex[3 * p + 1]; g[11] = g_tex[3 * p + 2];
+        }
         float ex[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, ge[3] = {0.f, 0.f, 0.f};
         if (NC > 12) {
             const float* eb = extra + (long long)b * V * E;
@@ -378,8 +389,9 @@ __global__ __launch_bounds__(256) void gb_bwd_kernel(const float* __restrict__ g
 
 extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                                const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null,
-                               int E, float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream) {
+                               int E, float* extra_out_or_null, float* g_rows_to_clear_or_null, const a3d_gb_aux* aux_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0);
+    A3D_CHECK_ARG(!aux_or_null || (aux_or_null->size >= sizeof(a3d_gb_aux) && aux_or_null->rows >= P && aux_or_null->pad_to >= 0));
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
     A3D_CHECK_ARG(!extra_or_null || (E >= 1 && E <= 3 && (extra_out_or_null || P == 0)));  // (an empty list has no output storage)
     A3D_CHECK_ARG(!g_rows_to_clear_or_null || ((uintptr_t)g_rows_to_clear_or_null & 63) == 0);
@@ -391,7 +403,7 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
     A3D_CHECK_ARG(rast && tri && pix && v_pos && v_nrm && prior && out);
     hipLaunchKernelGGL(gb_fwd_kernel, dim3(a3d_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, tri, (const long long*)pix,
                        (long long)P, v_pos, v_nrm, prior, prior_batch, V, F, (long long)H * W, out, extra_or_null, E, extra_out_or_null,
-                       (float4*)g_rows_to_clear_or_null, n_zero4);
+                       (float4*)g_rows_to_clear_or_null, n_zero4, gb_aux_of(aux_or_null), B - 1);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -399,7 +411,8 @@ extern "C" int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int6
 extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int B, int V, int F, int H, int W, const void* cover_scratch,
                                      int64_t P, int64_t* pix, int32_t* inv_or_null, const float* v_pos, const float* v_nrm, const float* prior,
                                      int prior_batch, float* out, const float* extra_or_null, int E, float* extra_out_or_null,
-                                     float* g_rows_to_clear_or_null, a3d_stream_t stream) {
+                                     float* g_rows_to_clear_or_null, const a3d_gb_aux* aux_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(!aux_or_null || (aux_or_null->size >= sizeof(a3d_gb_aux) && aux_or_null->rows >= P && aux_or_null->pad_to >= 0));
     A3D_CHECK_ARG(rast && cover_scratch && P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG(H % 8 == 0 && W % 8 == 0);  // the tile-ordered list (a3d_cover_count / a3d_rast_fwd's resolve with tile = 8)
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
@@ -412,7 +425,7 @@ extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int 
     const long long n_zero4 = g_rows_to_clear_or_null ? (long long)B * V * (GB_ROW / 4) : 0;
     hipLaunchKernelGGL(gb_cover_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4*)rast, n, H, W, (const int*)cover_scratch,
                        (const int*)cover_scratch + nb, (long long*)pix, inv_or_null, tri, v_pos, v_nrm, prior, prior_batch, V, F, out,
-                       extra_or_null, E, extra_out_or_null, (float4*)g_rows_to_clear_or_null, n_zero4);
+                       extra_or_null, E, extra_out_or_null, (float4*)g_rows_to_clear_or_null, n_zero4, gb_aux_of(aux_or_null), (long long)P, B - 1);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -420,20 +433,20 @@ extern "C" int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int 
 template <int NC>
 static void gb_launch_bwd(bool big, hipStream_t s, const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P,
                           const float* v_pos, const float* v_nrm, const float* prior, int prior_batch, const float* clip, int V, int F, int H, int W,
-                          float* g_rows, int want_prior, const float* extra, int E, const float* g_extra) {
+                          float* g_rows, int want_prior, const float* extra, int E, const float* g_extra, const float* g_tex) {
     const dim3 grid(a3d_div_up(P, 256)), block(256);
     if (!big)
         hipLaunchKernelGGL((gb_bwd_kernel<512, 640, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
-                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra, g_tex);
     else
         hipLaunchKernelGGL((gb_bwd_kernel<1024, 768, NC>), grid, block, 0, s, g_out, (const float4*)rast, tri, (const long long*)pix, (long long)P, v_pos,
-                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra);
+                           v_nrm, prior, prior_batch, (const float4*)clip, V, F, H, W, g_rows, want_prior, extra, E, g_extra, g_tex);
 }
 
 extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                                const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
                                float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E,
-                               const float* g_extra_out_or_null, a3d_stream_t stream) {
+                               const float* g_extra_out_or_null, const float* g_tex_or_null, a3d_stream_t stream) {
     A3D_CHECK_ARG(P >= 0 && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG((long long)B * V < 0x7fffffffll && (long long)B * (F + 1) < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
@@ -447,10 +460,10 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     const bool big = (double)P < 0.6 * (double)B * (double)F;
     if (extra_or_null)
         gb_launch_bwd<15>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior,
-                          extra_or_null, E, g_extra_out_or_null);
+                          extra_or_null, E, g_extra_out_or_null, g_tex_or_null);
     else
         gb_launch_bwd<12>(big, s, g_out, rast, tri, pix, P, v_pos, v_nrm, prior, prior_batch, clip_or_null, V, F, H, W, g_rows, want_prior, nullptr, 0,
-                          nullptr);
+                          nullptr, g_tex_or_null);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

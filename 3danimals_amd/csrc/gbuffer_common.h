@@ -11,21 +11,46 @@ __device__ __forceinline__ void gb_load3(const float* __restrict__ p, float& x, 
 // contraction the compiler would pick in either context
 __device__ __forceinline__ float gb_mix(float u, float a, float v, float b, float w, float c) { return __builtin_fmaf(u, a, __builtin_fmaf(v, b, w * c)); }
 
+// what the fields take from the G-buffer (a3d_gb_aux): dense rows of the canonical position + the point -> image index, padded
+struct GbAux {
+    float* tex_out;
+    long long* img_out;
+    long long rows, pad_to;
+};
+__host__ __device__ inline GbAux gb_aux_of(const a3d_gb_aux* a) {
+    GbAux g = {nullptr, nullptr, 0, 0};
+    if (a) { g.tex_out = a->tex_out; g.img_out = (long long*)a->img_out; g.rows = a->rows; g.pad_to = a->pad_to; }
+    return g;
+}
+// the padding rows behind a list of P points: zeros / the last image (whole work-group; call from ONE work-group of the launch)
+__device__ __forceinline__ void gb_fill_padding(const GbAux& a, long long P, int last_image) {
+    if (a.pad_to <= 0 || (!a.tex_out && !a.img_out)) return;
+    long long end = (P + a.pad_to - 1) / a.pad_to * a.pad_to;
+    if (end > a.rows) end = a.rows;
+    if (a.tex_out)
+        for (long long j = 3 * P + threadIdx.x; j < 3 * end; j += blockDim.x) a.tex_out[j] = 0.f;
+    if (a.img_out)
+        for (long long j = P + threadIdx.x; j < end; j += blockDim.x) a.img_out[j] = last_image;
+}
+
 // the G-buffer row of one covered pixel: texel r of flat pixel i -> out row p (+ the optional extra attribute)
 __device__ __forceinline__ void gb_row(const float4 r, long long i, long long p, const int* __restrict__ tri, const float* __restrict__ v_pos,
                                        const float* __restrict__ v_nrm, const float* __restrict__ prior, int prior_batch, int V, int F,
                                        long long hw, float* __restrict__ out, const float* __restrict__ extra, int E,
-                                       float* __restrict__ extra_out) {
+                                       float* __restrict__ extra_out, float* __restrict__ tex_out = nullptr,
+                                       long long* __restrict__ img_out = nullptr) {
     const int f = (int)r.w - 1;
+    const long long b = i / hw;
+    if (img_out) img_out[p] = b;  // point -> image: the index of the fields' per-image feature rows
     float4* o4 = reinterpret_cast<float4*>(out + p * 12);  // rows are 48 bytes: three aligned 16-byte stores
     float o[12];
     if (f < 0 || f >= F) {
         o4[0] = o4[1] = o4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (extra)
             for (int c = 0; c < E; ++c) extra_out[p * E + c] = 0.f;
+        if (tex_out) { tex_out[3 * p] = 0.f; tex_out[3 * p + 1] = 0.f; tex_out[3 * p + 2] = 0.f; }
         return;
     }
-    const long long b = i / hw;
     const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     const float u = r.x, v = r.y, w = 1.f - u - v;
     const float* vp = v_pos + b * V * 3;
@@ -58,6 +83,9 @@ __device__ __forceinline__ void gb_row(const float4 r, long long i, long long p,
     o4[0] = make_float4(o[0], o[1], o[2], o[3]);
     o4[1] = make_float4(o[4], o[5], o[6], o[7]);
     o4[2] = make_float4(o[8], o[9], o[10], o[11]);
+    // the canonical position once more as a row of its own: the [P,3] input of the texture / feature fields (render.py:53-57,209), dense,
+    // so that their input gradient comes back dense too (no column slice of the 12-wide row and no padded gradient of that slice)
+    if (tex_out) { tex_out[3 * p] = o[9]; tex_out[3 * p + 1] = o[10]; tex_out[3 * p + 2] = o[11]; }
     if (extra) {  // one more per-vertex attribute (the sequence models' 2-D motion, render.py:281-288), E <= 3 channels
         const float* eb = extra + b * V * E;
         for (int c = 0; c < E; ++c) extra_out[p * E + c] = gb_mix(u, eb[(long long)i0 * E + c], v, eb[(long long)i1 * E + c], w, eb[(long long)i2 * E + c]);

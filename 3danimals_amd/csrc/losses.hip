@@ -19,7 +19,9 @@ constexpr int LS_BLOCK = 256;
 constexpr int LS_NL = 5;  // loss columns: mask, mask_inv_dt, rgb, dino, mask_dt
 
 // partial[(b*nblk + blk)*4 + k]: per-block sums of the four summands
-__global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D,
+// (round 6) ``ds``: floats between two pixels of ``dino`` (D = contiguous; D + 1 = the renderer's 17-channel feature image read in place,
+// its alpha channel skipped -- render.py:330-331 slices it off, here nobody copies the 16 channels out first)
+__global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D, int ds,
                                                           const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
                                                           const float* __restrict__ mask_gt, const float* __restrict__ dt0,
                                                           const float* __restrict__ dt1, long long dt_stride,
@@ -78,13 +80,16 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
             const int D4 = D >> 2, lane = threadIdx.x & 63;
             const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);  // first pixel of this wave inside image b
             const long long img_px = (long long)b * HW;
-            const float4* chunk = reinterpret_cast<const float4*>(dino + (img_px + px0) * D);
+            const float* cbase = dino + (img_px + px0) * ds;
+            const bool vec = ds == D && (((uintptr_t)dino & 15) == 0);
             float acc = 0.f;
             for (int t = 0; t < D4; ++t) {
                 const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
                 const float both_pl = __shfl(both, pl, 64);  // pixel pl's mask lives in lane pl (all lanes take part)
                 if (px < HW) {
-                    const float4 q = chunk[f];
+                    float4 q;
+                    if (vec) q = reinterpret_cast<const float4*>(cbase)[f];
+                    else { const float* qp = cbase + (long long)pl * ds + 4 * cg; q = make_float4(qp[0], qp[1], qp[2], qp[3]); }
                     const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
                     const float e0 = q.x - dg[0], e1 = q.y - dg[HW], e2 = q.z - dg[2ll * HW], e3 = q.w - dg[3ll * HW];
                     acc += (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3) * both_pl;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
             v[3] = acc;
         } else if (i < HW) {
             const long long p = (long long)b * HW + i;
-            const float* dp = dino + p * D;
+            const float* dp = dino + p * ds;
             const float* dg = dino_gt + (long long)b * D * HW + i;
             float acc = 0.f;
             for (int c = 0; c < D; ++c) {
@@ -127,8 +132,10 @@ __global__ __launch_bounds__(64) void ls_finish_kernel(const float* __restrict__
     }
 }
 
+// ``gds``: floats between two pixels of g_dino (D + 1: the gradient is laid out like the 17-channel image it belongs to, so that the
+// compositor's backward reads it in place; the alpha channel's slot is not written -- it has no gradient, a3d_ca_buffer.g_channels)
 __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ shaded,
-                                                          const float* __restrict__ dino, int D, const float* __restrict__ image_gt,
+                                                          const float* __restrict__ dino, int D, int ds, int gds, const float* __restrict__ image_gt,
                                                           const float* __restrict__ dino_gt, const float* __restrict__ mask_gt,
                                                           const float* __restrict__ dt0, const float* __restrict__ dt1, long long dt_stride,
                                                           const float* __restrict__ valid, int H, int W, const unsigned char* __restrict__ both_in,
@@ -159,32 +166,39 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
     if ((D & 3) == 0) {  // wave-cooperative, fully coalesced float4 loads and stores (see ls_fwd_kernel)
         const int D4 = D >> 2, lane = threadIdx.x & 63;
         const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);
-        const float4* chunk = reinterpret_cast<const float4*>(dino + (img_px + px0) * D);
-        float4* gchunk = reinterpret_cast<float4*>(g_dino + (img_px + px0) * D);
+        const float* cbase = dino + (img_px + px0) * ds;
+        float* gbase = g_dino + (img_px + px0) * gds;
+        const bool vec = ds == D && (((uintptr_t)dino & 15) == 0), gvec = gds == D && (((uintptr_t)g_dino & 15) == 0);
         for (int t = 0; t < D4; ++t) {
             const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
             const float gq = gq0 * __shfl(both, pl, 64);
             if (px < HW) {
-                const float4 q = chunk[f];
+                float4 q;
+                if (vec) q = reinterpret_cast<const float4*>(cbase)[f];
+                else { const float* qp = cbase + (long long)pl * ds + 4 * cg; q = make_float4(qp[0], qp[1], qp[2], qp[3]); }
                 const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
                 float4 o4;
                 o4.x = gq * (q.x - dg[0]);
                 o4.y = gq * (q.y - dg[HW]);
                 o4.z = gq * (q.z - dg[2ll * HW]);
                 o4.w = gq * (q.w - dg[3ll * HW]);
-                {  // streamed: 67 MB that only the compositor's gather reads back, sparsely
+                if (gvec) {  // streamed: 67 MB that only the compositor's gather reads back, sparsely
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f nt; nt.x = o4.x; nt.y = o4.y; nt.z = o4.z; nt.w = o4.w;
-                    __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(gchunk + f));
+                    __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(gbase) + f);
+                } else {
+                    float* gp = gbase + (long long)pl * gds + 4 * cg;
+                    __builtin_nontemporal_store(o4.x, gp); __builtin_nontemporal_store(o4.y, gp + 1);
+                    __builtin_nontemporal_store(o4.z, gp + 2); __builtin_nontemporal_store(o4.w, gp + 3);
                 }
             }
         }
     } else if (i < HW) {
         const long long p = img_px + i;
         const float gq = gq0 * both;
-        const float* dp = dino + p * D;
+        const float* dp = dino + p * ds;
         const float* dg = dino_gt + (long long)b * D * HW + i;
-        float* go = g_dino + p * D;
+        float* go = g_dino + p * gds;
         for (int c = 0; c < D; ++c) go[c] = gq * (dp[c] - dg[(long long)c * HW]);
     }
 }
@@ -268,14 +282,14 @@ extern "C" size_t a3d_recon_losses_mask_bytes(int B, int H, int W) {
 
 extern "C" int a3d_recon_losses_columns(void) { return LS_NL; }
 
-extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
+extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, int dino_stride, const float* image_gt, const float* dino_gt,
                                     const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B,
                                     int H, int W, void* scratch, uint8_t* both, float* loss, a3d_stream_t stream) {
     A3D_CHECK_ARG(shaded && image_gt && mask_gt && dt0 && valid && scratch && both && loss && B > 0 && H > 0 && W > 0 && D >= 0);
-    A3D_CHECK_ARG(D == 0 || (dino && dino_gt));
+    A3D_CHECK_ARG(D == 0 || (dino && dino_gt && dino_stride >= D));
     hipStream_t s = (hipStream_t)stream;
     const int nblk = a3d_div_up((long long)H * W, LS_BLOCK);
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, dt1_or_null,
+    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, dino_stride, image_gt, dino_gt, mask_gt, dt0, dt1_or_null,
                        (long long)dt_stride, valid, H, W, (float*)scratch, both);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ls_finish_kernel, dim3(B, LS_NL), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
@@ -283,14 +297,14 @@ extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int 
     return A3D_OK;
 }
 
-extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt,
+extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, int dino_stride, int g_dino_stride, const float* image_gt,
                                     const float* dino_gt, const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride,
                                     const float* valid, int B, int H, int W, const uint8_t* both, float* g_shaded, float* g_dino,
                                     a3d_stream_t stream) {
     A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && both && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
-    A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino));
+    A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino && dino_stride >= D && g_dino_stride >= D));
     hipLaunchKernelGGL(ls_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
-                       D ? dino : nullptr, D, image_gt, dino_gt, mask_gt, dt0, dt1_or_null, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
+                       D ? dino : nullptr, D, dino_stride, g_dino_stride, image_gt, dino_gt, mask_gt, dt0, dt1_or_null, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

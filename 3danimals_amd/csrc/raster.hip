@@ -660,9 +660,13 @@ __global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __r
                                                                const float* __restrict__ v_pos, const float* __restrict__ v_nrm,
                                                                const float* __restrict__ prior, int prior_batch, float* __restrict__ out,
                                                                const float* __restrict__ extra, int E, float* __restrict__ extra_out,
-                                                               float4* __restrict__ zero_rows, long long n_zero4, int exp) {
+                                                               float4* __restrict__ zero_rows, long long n_zero4, int exp,
+                                                               const GbAux aux) {
+    float* __restrict__ tex_out = aux.tex_out;
+    long long* __restrict__ img_out = aux.img_out;
     __shared__ int wave_n[4];
     __shared__ int s_off;
+    __shared__ int s_total;
     A3D_STAMP(3, 0);  // (kernel id 3 = rs_resolve_cover_kernel)
     const int b = blockIdx.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -700,6 +704,9 @@ __global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __r
     rast[flat] = o;
     const int g = L / A3D_COVER_GROUP, r = L - g * A3D_COVER_GROUP;
     const bool last_of_group = r == A3D_COVER_GROUP - 1 || L == nb_total - 1;
+    // the launch's LAST work-group also learns the length of the whole list (it looks every earlier group up anyway when it holds a
+    // covered pixel; with padding rows to fill it does so regardless) and fills the fields' padding rows behind it
+    const bool pads = L == nb_total - 1 && aux.pad_to > 0 && (aux.tex_out || aux.img_out);
     if (wave == 0 && (cnt > 0 || last_of_group)) {
         int timeout = 0;
         int own = lane < r ? rs_await(blk_flag + g * A3D_COVER_GROUP + lane, &timeout, exp) : 0;  // earlier blocks of my group
@@ -711,16 +718,21 @@ __global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __r
             group_sum[(long long)g * A3D_COVER_GROUP_STRIDE] = own + cnt;  // (plain: what the host adds up, as before)
             __hip_atomic_fetch_add(grp_flag + g, own + cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (cnt > 0) {
+        if (cnt > 0 || pads) {
             int before = 0;
             for (int j = lane; j < g; j += 64) before += rs_await(grp_flag + j, &timeout, exp);  // earlier groups
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
-            if (lane == 0) s_off = before + own;
+            if (lane == 0) { s_off = before + own; s_total = before + own + cnt; }
         }
         if (__ballot(timeout != 0) && lane == 0) atomicOr(group_sum + 3, 1);  // status word (never in the sums: word 3 of the first line)
     }
     A3D_STAMP(3, 1);
+    if (pads) {  // (uniform)
+        __syncthreads();
+        const long long total = s_total;
+        gb_fill_padding(aux, total < p_cap ? total : p_cap, (int)gridDim.y - 1);
+    }
     if (cnt == 0) {  // (uniform) background only: the map entries and out
         if (inv) inv[flat] = -1;
         A3D_STAMP(3, 5);
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __r
     if (inv) inv[flat] = oidx;
     if (oidx < p_cap) {
         pix[oidx] = flat;
-        gb_row(o, flat, oidx, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)hw, out, extra, E, extra_out);
+        gb_row(o, flat, oidx, tri, v_pos, v_nrm, prior, prior_batch, V, F, (long long)hw, out, extra, E, extra_out, tex_out, img_out);
     }
     A3D_STAMP(3, 5);
 }
@@ -906,7 +918,8 @@ extern "C" int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, c
                                             void* scratch, void* cover_scratch, int64_t p_cap, int64_t* pix, int32_t* inv_or_null,
                                             const float* v_pos, const float* v_nrm, const float* prior, int prior_batch, float* out,
                                             const float* extra_or_null, int E, float* extra_out_or_null, float* g_rows_to_clear_or_null,
-                                            a3d_stream_t stream) {
+                                            const a3d_gb_aux* aux_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(!aux_or_null || (aux_or_null->size >= sizeof(a3d_gb_aux) && aux_or_null->rows >= p_cap && aux_or_null->pad_to >= 0));
     A3D_CHECK_ARG(clip && tri && rast && scratch && cover_scratch && B > 0 && V > 0 && F > 0 && H > 0 && W > 0 && B <= 65535 && p_cap >= 0);
     A3D_CHECK_ARG((clip_batch == 1 || clip_batch == B) && H % 8 == 0 && W % 8 == 0 && ((long long)H * W) % 256 == 0 && (long long)B * H * W < 0x7fffffffll);
     A3D_CHECK_ARG(prior_batch == 1 || prior_batch == B);
@@ -921,7 +934,7 @@ extern "C" int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, c
     hipLaunchKernelGGL(rs_resolve_cover_kernel, dim3(a3d_div_up((long long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, (const float4*)clip, clip_batch,
                        tri, V, F, H, W, (unsigned long long*)scratch, (float4*)rast, cs, group_sum, blk_flag, blk_flag + nb, nb, (long long*)pix,
                        inv_or_null, (long long)p_cap, v_pos, v_nrm, prior, prior_batch, out, extra_or_null, E, extra_out_or_null,
-                       (float4*)g_rows_to_clear_or_null, n_zero4, a3d_exp());
+                       (float4*)g_rows_to_clear_or_null, n_zero4, a3d_exp(), gb_aux_of(aux_or_null));
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -1,0 +1,97 @@
+// Clip-space transform of the posed vertices on gfx950 -- xfm_points(points, matrix, use_python=True),
+// /root/reference/model/render/renderutils/ops.py:515-531: out = matmul(pad(points, (0, 1), value=1), matrix^T), the first thing
+// render_mesh does (render.py:279).  As torch ops that is a pad, a batched [V,4] x [4,4] GEMM and -- backward -- two more GEMMs of that
+// shape and the pad's slice: six launches of a GEMM library whose smallest tile is larger than the problem (27 us for one of them on the
+// bench workload, tools/glue_attribution.py).  Here: one thread per (image, vertex) each way; the backward reduces the 16 entries of
+// d/d matrix per work-group (wave sums -> LDS -> 16 atomics per work-group and image).
+//   fwd : out[b,v,i] = M[b,i,0] x + M[b,i,1] y + M[b,i,2] z + M[b,i,3]
+//   bwd : g_points[b,v,j] = sum_i g[b,v,i] M[b,i,j]  (j < 3);   g_M[b,i,j] += sum_v g[b,v,i] [x,y,z,1]_j
+#include "a3d_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void xf_fwd_kernel(const float* __restrict__ points, int points_batch, const float* __restrict__ M, int m_batch, int V,
+                                                     float4* __restrict__ out, float* __restrict__ clear, int n_clear) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n_clear; i += gridDim.x * gridDim.y * 256) clear[i] = 0.f;
+    if (v >= V) return;
+    const float* p = points + ((points_batch == 1 ? 0ll : (long long)b * V) + v) * 3;
+    const float* m = M + (m_batch == 1 ? 0 : 16 * b);
+    const float x = p[0], y = p[1], z = p[2];
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(m[4 * i], x, __builtin_fmaf(m[4 * i + 1], y, __builtin_fmaf(m[4 * i + 2], z, m[4 * i + 3])));
+    out[(long long)b * V + v] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g, int g_stride, const float* __restrict__ points, int points_batch,
+                                                     const float* __restrict__ M, int m_batch, int V, float* __restrict__ g_points,
+                                                     float* __restrict__ g_M) {
+    __shared__ float s_red[4][16];
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    const bool live = v < V;
+    float gm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gm[k] = 0.f;
+    if (live) {
+        const float* gp = g + ((long long)b * V + v) * g_stride;
+        const float gi[4] = {gp[0], gp[1], gp[2], gp[3]};
+        const float* m = M + (m_batch == 1 ? 0 : 16 * b);
+        if (g_points) {
+            float* o = g_points + ((long long)b * V + v) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = gi[0] * m[j] + gi[1] * m[4 + j] + gi[2] * m[8 + j] + gi[3] * m[12 + j];
+        }
+        if (g_M) {
+            const float* p = points + ((points_batch == 1 ? 0ll : (long long)b * V) + v) * 3;
+            const float h[4] = {p[0], p[1], p[2], 1.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gm[4 * i + j] = gi[i] * h[j];
+        }
+    }
+    if (!g_M) return;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gm[k] = a3d_wave_sum(gm[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_red[threadIdx.x >> 6][k] = gm[k];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float t = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        if (t != 0.f) atomicAdd(g_M + (m_batch == 1 ? 0 : 16 * b) + threadIdx.x, t);
+    }
+}
+
+}  // namespace
+
+extern "C" int a3d_xfm_points_fwd(const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V, float* out,
+                                  float* g_matrix_to_clear_or_null, a3d_stream_t stream) {
+    A3D_CHECK_ARG(B > 0 && V >= 0 && B <= 65535 && (points_batch == 1 || points_batch == B) && (matrix_batch == 1 || matrix_batch == B));
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 0) {
+        if (g_matrix_to_clear_or_null) A3D_HIP(hipMemsetAsync(g_matrix_to_clear_or_null, 0, sizeof(float) * 16 * (size_t)matrix_batch, s));
+        return A3D_OK;
+    }
+    A3D_CHECK_ARG(points && matrix && out && ((uintptr_t)out & 15) == 0);
+    hipLaunchKernelGGL(xf_fwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, points, points_batch, matrix, matrix_batch, V, (float4*)out,
+                       g_matrix_to_clear_or_null, g_matrix_to_clear_or_null ? 16 * matrix_batch : 0);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, int points_batch, const float* matrix, int matrix_batch,
+                                  int B, int V, float* g_points_or_null, float* g_matrix_or_null, int g_matrix_is_clear, a3d_stream_t stream) {
+    A3D_CHECK_ARG(B > 0 && V >= 0 && B <= 65535 && g_stride >= 4 && (points_batch == 1 || points_batch == B) && (matrix_batch == 1 || matrix_batch == B));
+    hipStream_t s = (hipStream_t)stream;
+    if (g_matrix_or_null && !g_matrix_is_clear) A3D_HIP(hipMemsetAsync(g_matrix_or_null, 0, sizeof(float) * 16 * (size_t)matrix_batch, s));
+    if (V == 0 || (!g_points_or_null && !g_matrix_or_null)) return A3D_OK;
+    A3D_CHECK_ARG(g_out && points && matrix);
+    hipLaunchKernelGGL(xf_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_out, g_stride, points, points_batch, matrix, matrix_batch, V,
+                       g_points_or_null, g_matrix_or_null);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+A3D_PROFILE_TU(xfm)

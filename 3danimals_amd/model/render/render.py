@@ -40,6 +40,7 @@ DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"  # ... and the r
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
 FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
 FUSED_SHADING = True
+FIELD_INPUTS_FROM_GBUFFER = os.environ.get("A3D_FIELD_INPUTS", "1") != "0"  # the fields' padded input rows + image index written by the G-buffer launch (round 6)
 SHADE_IN_COMPOSITOR = os.environ.get("A3D_SHADE_IN_COMPOSITOR", "1") != "0"  # no a3d_shade_fwd launch when only the composited colour reads its output  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
 
@@ -207,22 +208,29 @@ def _shade_covered(gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_tex_po
 
 
 class SparseBuffers(dict):
-    """mode -> [P,C] values at the covered pixels ``pix`` (flat indices into [B,H,W]); what the fused path hands to the compositor."""
+    """mode -> [>= P,C] values at the covered pixels ``pix`` (flat indices into [B,H,W]); what the fused path hands to the compositor.
+    A value may carry more rows than the list (the fields' point list is padded to a bucket size; the padding rows are never read):
+    ``self[mode]`` returns the P rows, ``peek(mode)`` the tensor as it is (what the compositor takes, so that no row slice -- and no
+    zero-padded gradient of one -- stands between the fields and the compositor)."""
 
     def __init__(self, pix, bhw, inv=None):
         super().__init__()
         self.pix, self.bhw, self.inv = pix, bhw, inv  # inv: pixel -> row (int32 [B*H*W], -1 = uncovered) when the list came with it
-        self.shade_recipe = None  # ops.ShadeRecipe when self['shaded'] has not been computed yet (the fused compositor does it on the fly)
+        self.shade_recipe = None  # ops.ShadeRecipe: self['shaded'] has not been computed (the fused compositor does it on the fly)
+
+    def __contains__(self, mode):
+        return super().__contains__(mode) or (mode == "shaded" and self.shade_recipe is not None)
 
     def __getitem__(self, mode):
-        # a caller that indexes the colour directly (outside render_mesh, which hands the recipe to the compositor through ``peek``) must
-        # not see the unwritten rows of a deferred shading launch
-        if mode == "shaded" and self.shade_recipe is not None:
-            self.shade_recipe.materialize()
-        return super().__getitem__(mode)
+        # a caller that indexes the colour directly (outside render_mesh, which hands the recipe to the compositor) gets the stand-alone
+        # shading launch's result
+        if mode == "shaded" and self.shade_recipe is not None and not super().__contains__(mode):
+            super().__setitem__(mode, self.shade_recipe.materialize()[2])
+        vals = super().__getitem__(mode)
+        return vals if vals.shape[0] == self.pix.shape[0] else vals[: self.pix.shape[0]]
 
     def peek(self, mode):
-        """self[mode] without materialising a deferred colour (for the compositor call that computes it on the fly)."""
+        """The stored tensor (possibly with padding rows), without materialising a deferred colour."""
         return super().__getitem__(mode)
 
     def dense(self, mode):
@@ -234,59 +242,80 @@ class SparseBuffers(dict):
 
 
 def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lgt, material, bsdf, feat, render_modes, two_sided_shading,
-                  dino_net, class_vector, sparse=False, gb=None, inv=None):
+                  dino_net, class_vector, sparse=False, gb=None, inv=None, tex_in=None, img_p=None):
     """The arithmetic of shade() (reference render.py:30-132) on compact [P,.] arrays; scatters into dense [B,H,W,C+1]
-    buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points."""
+    buffers (zeros, alpha 0, where nothing was rasterised).  ``pix`` = flat pixel indices of the P points.
+    ``tex_in`` [Pp,3] / ``img_p`` [Pp] (from the G-buffer launch, ops.covered_gbuffer(field_inputs=...)): the fields' input rows and
+    point -> image index, already padded to the bucket size; without them they are derived here with torch ops."""
     b, h, w = bhw
-    dev = pos.device
-    img = torch.div(pix, h * w, rounding_mode="floor")
-    per_img = lambda t: None if t is None else (_rows_per_point(t, img, b) if t.shape[0] == b else t.expand(pix.shape[0], -1))
-
+    dev = pix.device
+    n_pts = pix.shape[0]
     # The two coordinate MLPs see the point list padded to a multiple of POINT_BUCKET rows (zeros; outputs sliced off again):
     # the GEMM shapes then repeat from step to step, which is what rocBLAS/hipBLASLt kernel selection and TunableOp key on.
-    n_pts = pix.shape[0]
-    n_pad = (-n_pts) % POINT_BUCKET if POINT_BUCKET else 0
-    _trim_allocator_cache(n_pts + n_pad, pix.device)
-    if n_pad:
-        img_p = torch.cat((img, img.new_full((n_pad,), b - 1)))  # padding rows ride with the last image: the index stays non-decreasing
-        tex_in = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))
-        per_img_p = lambda t: None if t is None else (_rows_per_point(t, img_p, b) if t.shape[0] == b else t.expand(n_pts + n_pad, -1))
+    if tex_in is not None:
+        tex_rows, img_rows = tex_in, img_p
+        n_pad = tex_in.shape[0] - n_pts
     else:
-        tex_in, per_img_p = tex_pos, per_img
+        img_rows = torch.div(pix, h * w, rounding_mode="floor")
+        n_pad = (-n_pts) % POINT_BUCKET if POINT_BUCKET else 0
+        tex_rows = tex_pos
+        if n_pad:
+            img_rows = torch.cat((img_rows, img_rows.new_full((n_pad,), b - 1)))  # padding rows ride with the last image: the index stays non-decreasing
+            tex_rows = torch.nn.functional.pad(tex_pos, (0, 0, 0, n_pad))
+    img = img_rows if n_pad == 0 else img_rows[:n_pts]
+    _trim_allocator_cache(n_pts + n_pad, pix.device)
+
     def field(net, x, f):
         # networks that understand (per-image rows, point -> image index) get that instead of a [P,C] per-point copy of the feature
         if f is not None and f.shape[0] == b and getattr(net, "indexed_feat", False):
-            return net.sample(x, feat=f, feat_index=img_p if n_pad else img)
-        return net.sample(x, feat=per_img_p(f))
+            return net.sample(x, feat=f, feat_index=img_rows)
+        return net.sample(x, feat=None if f is None else (_rows_per_point(f, img_rows, b) if f.shape[0] == b else f.expand(n_pts + n_pad, -1)))
 
-    if material is not None:
-        all_tex = field(material, tex_in, feat)[:n_pts]
-    else:
-        all_tex = torch.ones(n_pts, 9, device=dev)
-    kd, ks = all_tex[..., :3], all_tex[..., 3:6]
-    dino_pred = field(dino_net, tex_in, class_vector)[:n_pts] if dino_net is not None else None
+    # (the fields' outputs keep their padding rows: consumers that need exactly P rows slice, the fused compositor does not)
+    all_tex = field(material, tex_rows, feat) if material is not None else torch.ones(n_pts, 9, device=dev)
+    dino_rows = field(dino_net, tex_rows, class_vector) if dino_net is not None else None
 
-    # the narrow per-image quantities (camera rotation 9, view position 3, light parameters 5) travel to the points as ONE gather
     _resolve_bsdf(bsdf, material)
     if lgt is not None and isinstance(lgt, light.EnvironmentLight):
         raise NotImplementedError("EnvironmentLight is outside the hot path")
+    modes = render_modes if render_modes is not None else ["shaded"]
     view = view_pos.reshape(-1, 3)
+    light_rows = lgt(feat) if lgt is not None else None  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+
+    # ---- the fused training path: nothing is computed here.  The compositor computes the colour on the fly and its backward node runs
+    # the shading adjoint (ops.ShadeRecipe / ops.shade_composite_antialias): no [B,17] table, no kd / ks / row slices, no launch.
+    if (gb is not None and FUSED_SHADING and SHADE_IN_COMPOSITOR and sparse and inv is not None and lgt is not None and material is not None
+            and w2c.dim() == 3 and all(m in ("shaded", "dino_pred", "flow", "kd", "ks") for m in modes)):
+        recipe = ops.ShadeRecipe(gb, w2c, view, light_rows, all_tex, two_sided_shading, img_rows)
+        LAST_POINTS[0] = dict(pix=pix, gb=gb.detach(), all_tex=all_tex.detach(), dino=None if dino_rows is None else dino_rows.detach(),
+                              light=light_rows.detach(), flow=None if flow is None else flow.detach())
+        out = SparseBuffers(pix, (b, h, w), inv)
+        out.shade_recipe = recipe
+        lazy = {"dino_pred": dino_rows, "flow": flow, "kd": lambda: all_tex[:n_pts, :3], "ks": lambda: all_tex[:n_pts, 3:6]}
+        for mode in modes:
+            if mode == "shaded":
+                continue
+            val = lazy[mode]
+            if val is None:
+                raise KeyError(mode)  # like the reference: a mode whose buffer was never produced (render.py:127-128)
+            out[mode] = val() if callable(val) else val
+        return out
+
+    all_tex = all_tex[:n_pts] if n_pad else all_tex
+    kd, ks = all_tex[..., :3], all_tex[..., 3:6]
+    dino_pred = None if dino_rows is None else (dino_rows[:n_pts] if n_pad else dino_rows)
+    # the narrow per-image quantities (camera rotation 9, view position 3, light parameters 5) travel to the points as ONE gather
     cols = [w2c[:, :3, :3].reshape(-1, 9).expand(b, 9), view.expand(b, 3)]
     if lgt is not None:
-        cols.append(lgt(feat))  # DirectionalLight.forward: [B,5] = direction(3), ambient, diffuse (light.py:176-184)
+        cols.append(light_rows)
     per_image = torch.cat(cols, dim=-1)  # [B, 12 | 17]
     shading = None
     if gb is not None and FUSED_SHADING:  # one HIP kernel each way for the ~30 (+~70 backward) elementwise launches below; the kernels
         # read the image's row through the point -> image index (no [P,17] copy) and reduce its gradient per image themselves
-        recipe = None
         if lgt is None:
             nrm, shaded_col = ops.shade_points(gb, per_image, None, two_sided_shading, img=img), kd
         else:
-            modes_now = render_modes if render_modes is not None else ["shaded"]
-            # only the composited colour reads what this launch computes (the training modes): leave it to the compositor
-            if SHADE_IN_COMPOSITOR and sparse and inv is not None and all(m in ("shaded", "dino_pred", "flow", "kd", "ks") for m in modes_now):
-                recipe = ops.ShadeRecipe()
-            nrm, shading, shaded_col = ops.shade_points(gb, per_image, kd, two_sided_shading, img=img, recipe=recipe)
+            nrm, shading, shaded_col = ops.shade_points(gb, per_image, kd, two_sided_shading, img=img)
     else:
         per_point = _rows_per_point(per_image, img, b)
         rot, view_p = per_point[:, 0:9].reshape(-1, 3, 3), per_point[:, 9:12]
@@ -301,13 +330,10 @@ def _shade_points(pos, geo, nrm, tng, tex_pos, flow, pix, bhw, w2c, view_pos, lg
 
     if gb is not None:  # references only (no copies): the stage-wise checkers re-do every stage from the previous stage's HIP output
         LAST_POINTS[0] = dict(pix=pix, gb=gb.detach(), all_tex=all_tex.detach() if material is not None else None,
-                              dino=None if dino_pred is None else dino_pred.detach(), per_image=per_image.detach(),
+                              dino=None if dino_pred is None else dino_pred.detach(), light=None if light_rows is None else light_rows.detach(),
                               flow=None if flow is None else flow.detach())
     buffers = _collect(render_modes, shaded_col, kd, ks, nrm, geo, tng, shading, flow, dino_pred, None)
-    modes = render_modes if render_modes is not None else ["shaded"]
     out = SparseBuffers(pix, (b, h, w), inv)
-    if gb is not None and FUSED_SHADING and recipe is not None and recipe.filled:
-        out.shade_recipe = recipe
     for mode in modes:
         out[mode] = buffers[mode]  # KeyError for an unknown / unavailable mode, like the reference (render.py:127-128)
     return out if sparse else {mode: out.dense(mode) for mode in out}
@@ -353,9 +379,13 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
         flow_fused = "flow" in render_modes and delta_xy.shape[-1] <= 3  # the one extra attribute of the sequence models rides in the same kernels
         if FUSED_COVER_GBUFFER and PIXEL_TILE == 8 and h % 8 == 0 and w % 8 == 0:
             # the covered-pixel list and its G-buffer rows from ONE launch (one host sync before it: the number of covered pixels)
-            res = ops.covered_gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, extra=delta_xy if flow_fused else None)
-            (gb, flow, pix, inv) = res if flow_fused else (res[0], None, res[1], res[2])
+            # (... and what the fields take from it -- canonical positions as dense rows, point -> image index, padded -- from the same launch)
+            res = ops.covered_gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, extra=delta_xy if flow_fused else None,
+                                      field_inputs=POINT_BUCKET if FIELD_INPUTS_FROM_GBUFFER else None)
+            (gb, flow, pix, inv), rest = (res[:4], res[4:]) if flow_fused else ((res[0], None, res[1], res[2]), res[3:])
+            tex_in, img_p = rest if rest else (None, None)
         else:
+            tex_in = img_p = None
             pix, inv = ops.covered_pixels(rast, tile=PIXEL_TILE, return_inverse=True)  # one host sync for the number of covered pixels
             if flow_fused:
                 gb, flow = ops.gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, pix, extra=delta_xy)  # [P,12], [P,2]
@@ -364,7 +394,7 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
         if "flow" in render_modes and not flow_fused:
             flow = interpolate(delta_xy, rast, tri)[0].reshape(b * h * w, -1).index_select(0, pix)
         return _shade_points(gb[:, 0:3], gb[:, 3:6], gb[:, 6:9], None, gb[:, 9:12], flow, pix, (b, h, w), w2c, view_pos, lgt, material, bsdf, feat,
-                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb, inv=inv)
+                             render_modes, two_sided_shading, dino_net, class_vector, sparse=sparse, gb=gb, inv=inv, tex_in=tex_in, img_p=img_p)
 
     rast_s = util.scale_img_nhwc(rast, resolution, mag="nearest", min="nearest") if (spp > 1 and msaa) else rast
     gb_pos, _ = interpolate(mesh.v_pos, rast_s, tri)
@@ -451,43 +481,55 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
                             prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
                             class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
 
-    if background is not None:
-        if spp > 1:
-            background = util.scale_img_nhwc(background, full_res, mag="nearest", min="nearest")
-        background = torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1)
-    else:
-        background = torch.zeros(1, full_res[0], full_res[1], 4, dtype=torch.float32, device=dev)
+    if background is not None and spp > 1:
+        background = util.scale_img_nhwc(background, full_res, mag="nearest", min="nearest")
+    # the reference appends a zero alpha channel to the background on every call (render.py:254-256): the fused compositor reads the
+    # 3-channel tensor as it is (a3d_ca_buffer.bg_channels); only the torch branches further down build the 4-channel copy
+    bg4 = [None]
+
+    def background4():
+        if bg4[0] is None:
+            bg4[0] = (torch.cat((background, torch.zeros_like(background[..., 0:1])), dim=-1) if background is not None
+                      else torch.zeros(1, full_res[0], full_res[1], 4, dtype=torch.float32, device=dev))
+        return bg4[0]
 
     analysis = None
-    coverage = (rast[..., -1:] > 0).float()
     # composite + antialias fused (csrc/antialias.hip): one pass over the image per buffer, same values as the two steps further down;
     # the buffers go through the op two at a time (the colour and the feature image of a training step share its launches)
     fused = {}
-    can_fuse = isinstance(rendered, SparseBuffers) and rendered.inv is not None and FUSED_COMPOSITE and not background.requires_grad
+    can_fuse = isinstance(rendered, SparseBuffers) and rendered.inv is not None and FUSED_COMPOSITE and (background is None or not background.requires_grad)
     fuse_keys = [k for k in dict.fromkeys(render_modes) if can_fuse and k in rendered and k in ANTIALIASED_MODES]
     if fuse_keys:
         tri32 = ops.tri_int32(tri)
         analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]), defer=DEFER_ANALYSIS)  # runs inside the first compositor call
 
         def bg_of(k):
-            if k not in ("shaded", "geo_normal", "shading"):
+            if k not in ("shaded", "geo_normal", "shading") or background is None:
                 return None
-            return background[..., 2:] if (k == "shading" and background.shape[-1] == 4) else background
+            return background4()[..., 2:] if k == "shading" else background  # ('shading': the last two channels of the 4-channel background)
+
+        # channels handed out per mode (render.py:320-331): the op returns the view, so no slice (and no padded gradient of one) follows it
+        keep_of = {"flow": 2, "dino_pred": -1, "shading": 1, "depth": 1}
+
+        def keep(k, vals):
+            n = keep_of.get(k)
+            return None if n is None else (vals.shape[-1] if n == -1 else n)
 
         recipe = getattr(rendered, "shade_recipe", None)
         for i in range(0, len(fuse_keys), 2):
             ka, kb = fuse_keys[i], (fuse_keys[i + 1] if i + 1 < len(fuse_keys) else None)
-            if kb == "shaded" and recipe is not None:
-                recipe.materialize()  # (only the FIRST buffer of a call can be shaded on the fly)
-            sh = recipe if ka == "shaded" else None
-            va = rendered.peek(ka) if sh is not None else rendered[ka]  # (peek: the compositor computes the deferred colour itself)
-            if kb is None:
-                fused[ka] = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, shade=sh)
+            vb = rendered.peek(kb) if (kb is not None and not (kb == "shaded" and recipe is not None)) else (rendered[kb] if kb is not None else None)
+            if ka == "shaded" and recipe is not None and not dict.__contains__(rendered, "shaded"):  # (only the FIRST buffer of a call can be shaded on the fly)
+                res = ops.shade_composite_antialias(recipe, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, vals2=vb,
+                                                    background2=None if kb is None else bg_of(kb), keep2=None if kb is None else keep(kb, vb))
             else:
-                fused[ka], fused[kb] = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis,
-                                                               vals2=rendered[kb], background2=bg_of(kb), shade=sh)
-    if isinstance(rendered, SparseBuffers) and rendered.shade_recipe is not None and "shaded" not in fused:
-        rendered.shade_recipe.materialize()  # nobody computed the colour on the fly: run the launch after all
+                va = rendered.peek(ka) if dict.__contains__(rendered, ka) else rendered[ka]
+                res = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, vals2=vb,
+                                              background2=None if kb is None else bg_of(kb), keep=keep(ka, va), keep2=None if kb is None else keep(kb, vb))
+            if kb is None:
+                fused[ka] = res
+            else:
+                fused[ka], fused[kb] = res
     if LAST_POINTS[0] is not None:
         LAST_POINTS[0]["clip"] = clip_f.detach()
     out_buffers = []
@@ -496,9 +538,12 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
             out_buffers.append(None)
             continue
         fused_aa = key in fused
-        if fused_aa:
-            accum = fused[key]
-        elif isinstance(rendered, SparseBuffers):
+        if fused_aa:  # (already antialiased, and already cut to the channels the mode returns)
+            out_buffers.append(fused[key].permute(0, 3, 1, 2))
+            continue
+        background = background4()
+        coverage = (rast[..., -1:] > 0).float()
+        if isinstance(rendered, SparseBuffers):
             # coverage is 0 or 1, for which lerp(bg, [rgb,1], alpha) (render.py:261-262) returns exactly bg or exactly [rgb,1]:
             # start from the background and overwrite the covered pixels -- same bits, a third of the passes over the image
             vals = rendered[key]
@@ -516,7 +561,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
                 bg = bg[..., 2:]
             alpha = coverage * buf[..., -1:]
             accum = torch.lerp(bg, torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1), alpha)  # render.py:261-262
-        if key in ANTIALIASED_MODES and not fused_aa:
+        if key in ANTIALIASED_MODES:
             if analysis is None:
                 tri32 = ops.tri_int32(tri)
                 analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]))

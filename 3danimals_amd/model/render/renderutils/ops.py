@@ -6,10 +6,20 @@ import torch.nn.functional as F
 from ...._lib import fp32_region
 
 NORMAL_THRESHOLD = 0.1  # reference renderutils/bsdf.py:13
+HIP_XFM_POINTS = True  # xfm_points on the GPU as a3d_xfm_points_fwd / _bwd (False: the padded torch matmul, e.g. for double precision)
 
 
 def _dot(x, y):
     return torch.sum(x * y, -1, keepdim=True)
+
+
+def _hip_xfm_ok(points, matrix):
+    if not (HIP_XFM_POINTS and points.is_cuda and matrix.is_cuda and points.dtype == torch.float32 and matrix.dtype == torch.float32):
+        return False
+    if points.dim() != 3 or matrix.dim() != 3 or points.shape[2] != 3 or tuple(matrix.shape[1:]) != (4, 4):
+        return False
+    b = max(points.shape[0], matrix.shape[0])
+    return points.shape[0] in (1, b) and matrix.shape[0] in (1, b)
 
 
 @fp32_region
@@ -18,7 +28,12 @@ def xfm_points(points, matrix, use_python=False):
 
     One padded batched matmul (rocBLAS); autograd reaches both the points and the matrix (camera pose).
     """
-    out = torch.matmul(F.pad(points, pad=(0, 1), mode="constant", value=1.0), torch.transpose(matrix, 1, 2))
+    if _hip_xfm_ok(points, matrix):
+        from .... import ops  # one launch each way (csrc/xfm.hip) instead of pad + bmm, and two more bmm + a slice backward
+
+        out = ops.xfm_points(points, matrix)
+    else:
+        out = torch.matmul(F.pad(points, pad=(0, 1), mode="constant", value=1.0), torch.transpose(matrix, 1, 2))
     if torch.is_anomaly_enabled():
         assert torch.all(torch.isfinite(out)), "Output of xfm_points contains inf or NaN"
     return out

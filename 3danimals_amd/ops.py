@@ -645,6 +645,49 @@ def vertex_normals(v, tri):
     return _Normals.apply(v, tri32, vertex_face_adjacency(tri32, v.shape[1]))
 
 
+# ---------------------------------------------------------------------------------------------- clip-space transform
+class _XfmPoints(torch.autograd.Function):
+    """xfm_points(points, matrix, use_python=True) (renderutils/ops.py:515-531): [points, 1] . matrix^T as one launch each way
+    (csrc/xfm.hip) instead of pad + bmm (+ two bmm and a slice backward)."""
+
+    @staticmethod
+    def forward(ctx, points, matrix):
+        require_device(points, matrix, what="xfm_points")
+        points, matrix = f32c(points), f32c(matrix)
+        Bp, V, Bm = points.shape[0], points.shape[1], matrix.shape[0]
+        B = max(Bp, Bm)
+        assert points.shape[2] == 3 and matrix.shape[1:] == (4, 4) and Bp in (1, B) and Bm in (1, B)
+        out = torch.empty((B, V, 4), dtype=torch.float32, device=points.device)
+        g_M = torch.empty_like(matrix) if ctx.needs_input_grad[1] else None  # (accumulated by the backward with atomics: cleared here)
+        call("a3d_xfm_points_fwd", ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(out), ptr(g_M), stream())
+        ctx.save_for_backward(points, matrix)
+        ctx.g_M = g_M
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        points, matrix = ctx.saved_tensors
+        Bp, V, Bm = points.shape[0], points.shape[1], matrix.shape[0]
+        B = max(Bp, Bm)
+        # (the gradient may be the clip columns of the G-buffer's 16-float gradient rows: read in place, with its vertex stride)
+        if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(1) < 4 or g.stride(0) != V * g.stride(1):
+            g = f32c(g)
+        g_p = torch.empty((B, V, 3), dtype=torch.float32, device=points.device) if ctx.needs_input_grad[0] else None
+        g_M, ctx.g_M = ctx.g_M, None  # the cleared buffer serves ONE backward
+        clear = g_M is not None
+        if g_M is None and ctx.needs_input_grad[1]:
+            g_M = torch.empty_like(matrix)
+        call("a3d_xfm_points_bwd", ptr(g), g.stride(1), ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(g_p), ptr(g_M), int(clear), stream())
+        if g_p is not None and Bp == 1 and B > 1:
+            g_p = g_p.sum(0, keepdim=True)
+        return g_p, g_M
+
+
+def xfm_points(points, matrix):
+    """points [1|B,V,3], matrix [1|B,4,4] -> [B,V,4] homogeneous clip-space positions."""
+    return _XfmPoints.apply(points, matrix)
+
+
 # ---------------------------------------------------------------------------------------------- covered pixels
 _cover_counts = _IdentityCache(maxsize=2)  # raster buffer -> block counts of its covered-pixel list
 _aa_prepared = _IdentityCache(maxsize=2)  # raster buffer -> (key of its clip tensor, screen positions, zeroed counters)
@@ -925,9 +968,21 @@ def interpolate_da(attr, rast, tri, rast_db, diff_attrs="all"):
 GBUFFER_GRAD_COLS = 16  # A3D_GBUFFER_GRAD_COLS of include/a3d.h
 
 
+def _round_up(n, m):
+    return -(-int(n) // int(m)) * int(m) if m else int(n)
+
+
 class _GBuffer(torch.autograd.Function):
+    """-> (rows [P,12], extra rows [P,E] | None, tex_in [Pp,3] | None, img [Pp] | None, pix [P], inv [B*H*W] | None).
+
+    ``bucket`` > 0 (round 6): the launch also writes what the texture / feature fields take from the G-buffer in the form they take it
+    (a3d_gb_aux): ``tex_in`` = the canonical positions as dense rows, padded with zero rows to a multiple of ``bucket``, and ``img`` =
+    the point -> image index, padded with the last image.  The fields' input gradient then comes back as dense rows too (``g_tex`` of
+    the backward): no column slice of the 12-wide rows, no pad, no padded gradient of either -- no torch kernel between this path and
+    model/networks in either direction."""
+
     @staticmethod
-    def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix, extra):
+    def forward(ctx, clip, v_pos, v_nrm, prior, rast, tri32, pix, extra, bucket=0):
         require_device(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra, what="gbuffer")
         clip, v_pos, v_nrm, prior, rast = f32c(clip), f32c(v_pos), f32c(v_nrm), f32c(prior), f32c(rast)
         B, H, W = rast.shape[:3]
@@ -945,7 +1000,18 @@ class _GBuffer(torch.autograd.Function):
         # cleared by the forward launch: one memset less on the backward path
         needs_grad = any(ctx.needs_input_grad)  # (forward runs with grad mode off: this is what says whether a backward can follow)
         rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=dev) if needs_grad else None
-        out = extra_out = None
+        out = extra_out = tex_in = img = None
+        want_aux = ctx_wants_aux(bucket)  # (-1 / None: the rows alone)
+        bucket = int(bucket) if want_aux else 0
+
+        def aux_for(n_rows):
+            """(struct or None, tex buffer, img buffer) with ``n_rows`` rows behind them."""
+            if not want_aux:
+                return None, None, None
+            t = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)
+            im = torch.empty((n_rows,), dtype=torch.int64, device=dev)
+            return _lib.GbAux(size=ctypes.sizeof(_lib.GbAux), tex_out=ptr(t), img_out=ptr(im), rows=n_rows, pad_to=bucket), t, im
+
         cap_key = (dev, B, H, W)
         pend = _pending_resolve.peek(rast) if listed else None
         if pend is not None and cap_key in _cover_last_len:
@@ -959,9 +1025,10 @@ class _GBuffer(torch.autograd.Function):
             inv = torch.empty(B * H * W, dtype=torch.int32, device=dev)
             out_c = torch.empty((cap, 12), dtype=torch.float32, device=dev)
             extra_c = torch.empty((cap, E), dtype=torch.float32, device=dev) if extra is not None else None
+            aux, tex_c, img_c = aux_for(_round_up(cap, bucket))
             call("a3d_rast_resolve_gbuffer_fwd", ptr(clip_r), clip_r.shape[0], ptr(tri_r), B, V, tri_r.shape[0], H, W, ptr(rast), ptr(pend["keys"]),
                  ptr(cover_scratch), cap, ptr(pix_c), ptr(inv), ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out_c), ptr(extra), E,
-                 ptr(extra_c), ptr(rows), stream())
+                 ptr(extra_c), ptr(rows), None if aux is None else ctypes.addressof(aux), stream())
             _rast_keys[pend["key"]] = pend["keys"]  # (every key the launch consumed is re-armed)
             nb = _lib.lib().a3d_cover_blocks(B, H, W)
             tail = _lib.read_back(cover_scratch[nb:nb + _lib.lib().a3d_cover_groups(B, H, W) * _lib.lib().a3d_cover_group_stride()])
@@ -985,6 +1052,8 @@ class _GBuffer(torch.autograd.Function):
             _cover_last_len[cap_key] = P
             if P <= cap:
                 pix, out, extra_out = pix_c[:P], out_c[:P], (extra_c[:P] if extra_c is not None else None)
+                if want_aux:
+                    tex_in, img = tex_c[:_round_up(P, bucket)], img_c[:_round_up(P, bucket)]
             else:  # outgrown: texels, block counts and sums are complete -- the exact list + rows through the two-launch path's second half
                 resolve_events["outgrown"] += 1
                 pix = torch.empty(P, dtype=torch.int64, device=dev)
@@ -1003,31 +1072,33 @@ class _GBuffer(torch.autograd.Function):
         if fused_done:
             pass
         elif listed:
+            aux, tex_in, img = aux_for(_round_up(P, bucket))
             call("a3d_cover_gbuffer_fwd", ptr(rast), ptr(tri32), B, V, tri32.shape[0], H, W, ptr(cover_scratch), P, ptr(pix), ptr(inv), ptr(v_pos),
-                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+                 ptr(v_nrm), ptr(prior), prior.shape[0], ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows),
+                 None if aux is None else ctypes.addressof(aux), stream())
         else:
+            aux, tex_in, img = aux_for(_round_up(P, bucket))
             call("a3d_gbuffer_fwd", ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0], B, V, tri32.shape[0], H, W,
-                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), stream())
+                 ptr(out), ptr(extra), E, ptr(extra_out), ptr(rows), None if aux is None else ctypes.addressof(aux), stream())
         ctx.save_for_backward(clip, v_pos, v_nrm, prior, rast, tri32, pix, extra)
         ctx.rows = rows
-        ctx.listed = listed
-        if listed:  # (out[, extra_out], pix, inv): the list rides along as non-differentiable outputs
-            ctx.mark_non_differentiable(pix, inv)
-            return (out, pix, inv) if extra is None else (out, extra_out, pix, inv)
-        if extra is None:
-            return out
-        return out, extra_out
+        ctx.set_materialize_grads(False)
+        nondiff = [t for t in (img, pix if listed else None, inv) if t is not None]
+        if nondiff:
+            ctx.mark_non_differentiable(*nondiff)
+        return out, extra_out, tex_in, img, (pix if listed else None), inv
 
     @staticmethod
-    def backward(ctx, g_out, *more):
+    def backward(ctx, g_out, g_extra_out=None, g_tex=None, *_):
         clip, v_pos, v_nrm, prior, rast, tri32, pix, extra = ctx.saved_tensors
-        g_extra_out = more[0] if (extra is not None and more) else None
         B, H, W = rast.shape[:3]
         V, P = v_pos.shape[1], pix.shape[0]
         want_prior, want_clip = ctx.needs_input_grad[3], ctx.needs_input_grad[0]
         E = 0 if extra is None else extra.shape[2]
         if extra is not None and g_extra_out is None:
             g_extra_out = torch.zeros((P, E), dtype=torch.float32, device=rast.device)
+        if g_out is None:  # (only the fields' input had a gradient)
+            g_out = torch.zeros((P, 12), dtype=torch.float32, device=rast.device)
         # one 64-byte gradient row per (image, vertex): the kernel's atomics of a vertex are then one line request; the gradients are
         # strided views of the rows (a3d.h: v_pos 0..2 | v_nrm 3..5 | canonical 6..8 | extra 9..11 | clip 12..15)
         rows, ctx.rows = ctx.rows, None  # the rows the forward cleared serve ONE backward (their views are handed out as gradients)
@@ -1036,7 +1107,7 @@ class _GBuffer(torch.autograd.Function):
             rows = torch.empty((B, V, GBUFFER_GRAD_COLS), dtype=torch.float32, device=rast.device)
         call("a3d_gbuffer_bwd", ptr(f32h(g_out)), ptr(rast), ptr(tri32), ptr(pix), P, ptr(v_pos), ptr(v_nrm), ptr(prior), prior.shape[0],
              ptr(clip) if want_clip else None, B, V, tri32.shape[0], H, W, ptr(rows), int(clear), int(want_prior), ptr(extra), E,
-             None if extra is None else ptr(f32h(g_extra_out)), stream())
+             None if extra is None else ptr(f32h(g_extra_out)), None if g_tex is None else ptr(f32h(g_tex)), stream())
         g_vpos, g_vnrm = rows[..., 0:3], rows[..., 3:6]
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None
@@ -1045,14 +1116,22 @@ class _GBuffer(torch.autograd.Function):
             if prior.shape[0] == 1:
                 g_prior = g_prior.sum(0, keepdim=True)
         g_extra = rows[..., 9:9 + E] if (extra is not None and ctx.needs_input_grad[7]) else None
-        return g_clip, g_vpos, g_vnrm, g_prior, None, None, None, g_extra
+        return g_clip, g_vpos, g_vnrm, g_prior, None, None, None, g_extra, None
 
 
-def covered_gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, extra=None):
+def ctx_wants_aux(bucket):
+    return bucket is not None and int(bucket) >= 0
+
+
+def covered_gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, extra=None, field_inputs=None):
     """covered_pixels(rast, return_inverse=True) + gbuffer(...) as ONE launch: (gb [P,12][, extra [P,E]], pix [P], inv [B*H*W]).
-    H and W must be multiples of 8 (the tile-ordered list)."""
+    H and W must be multiples of 8 (the tile-ordered list).
+    ``field_inputs`` = bucket size (0 = no padding): also (tex_in [Pp,3], img [Pp]) -- see _GBuffer -- appended to the result."""
     assert rast.shape[1] % 8 == 0 and rast.shape[2] % 8 == 0
-    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, f32c(rast.detach()), tri_int32(tri), None, extra)
+    gb, ex, tex_in, img, pix, inv = _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, f32c(rast.detach()), tri_int32(tri), None, extra,
+                                                   -1 if field_inputs is None else int(field_inputs))
+    res = (gb, pix, inv) if extra is None else (gb, ex, pix, inv)
+    return res if field_inputs is None else res + (tex_in, img)
 
 
 def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix, extra=None):
@@ -1062,7 +1141,8 @@ def gbuffer(clip, v_pos, v_nrm, prior_v_pos, rast, tri, pix, extra=None):
     Differentiable w.r.t. v_pos, v_nrm, prior_v_pos, extra and -- through the barycentrics -- clip (x, y, w); pass ``rast.detach()``
     semantics are implied: the gradient to ``clip`` is produced here, not through ``rast``.
     """
-    return _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix, extra)
+    gb, ex = _GBuffer.apply(clip, v_pos, v_nrm, prior_v_pos, rast.detach(), tri_int32(tri), pix, extra, -1)[:2]
+    return gb if extra is None else (gb, ex)
 
 
 # ---------------------------------------------------------------------------------------------- per-point shading
@@ -1070,7 +1150,7 @@ class _ShadePoints(torch.autograd.Function):
     """(shading normal [P,3], shading [P,1], shaded [P,3]) from the G-buffer rows, the camera/light rows and kd."""
 
     @staticmethod
-    def forward(ctx, gb, par, kd, two_sided, img, recipe=None):
+    def forward(ctx, gb, par, kd, two_sided, img):
         require_device(gb, par, img, what="shade_points")
         gb, par = f32c(gb), f32c(par)
         P, ncol = gb.shape[0], par.shape[1]
@@ -1089,16 +1169,12 @@ class _ShadePoints(torch.autograd.Function):
             shaded = torch.empty((P, 3), dtype=torch.float32, device=gb.device)
         # per-image rows: their gradient is accumulated by the backward with atomics -- allocated now, cleared by the forward launch
         g_par = torch.empty_like(par) if (img is not None and ctx.needs_input_grad[1]) else None
-        if recipe is not None and kd is not None and img is not None and ncol == 17:
-            # DEFERRED (ShadeRecipe): no launch -- the compositor computes kd * shading per covered pixel itself (a3d_ca_shade) and clears
-            # g_par in its first launch; any other reader of the outputs calls recipe.materialize() first, which runs this launch after all
-            recipe.fill(gb, par, kd, kd_stride, int(two_sided), img, g_par, (nrm, shading, shaded))
-        else:
-            call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded),
-                 ptr(g_par), par.shape[0], stream())
+        call("a3d_shade_fwd", ptr(gb), ptr(par), ncol, ptr(img), ptr(kd), kd_stride, P, int(two_sided), ptr(nrm), ptr(shading), ptr(shaded),
+             ptr(g_par), par.shape[0], stream())
         ctx.save_for_backward(gb, par, kd, img)
         ctx.g_par = g_par
         ctx.two_sided, ctx.kd_stride = int(two_sided), kd_stride
+        ctx.set_materialize_grads(False)  # (an output nobody differentiated arrives as None = a NULL pointer, not as a tensor of zeros filled for it)
         if kd is None:
             return nrm
         return nrm, shading, shaded
@@ -1116,45 +1192,44 @@ class _ShadePoints(torch.autograd.Function):
         opt = lambda t: None if t is None else f32h(t)
         call("a3d_shade_bwd", ptr(opt(g_nrm)), ptr(opt(g_shading)), ptr(opt(g_shaded)), ptr(gb), ptr(par), ncol, ptr(img), par.shape[0], ptr(kd),
              ctx.kd_stride, P, ctx.two_sided, ptr(g_gb), ptr(g_par), ptr(g_kd), int(clear), stream())
-        return g_gb, g_par, g_kd, None, None, None
+        return g_gb, g_par, g_kd, None, None
 
 
-class ShadeRecipe:
-    """What a3d_shade_fwd would have computed, kept as its inputs: handed to composite_antialias(shade=...) the colour of every covered
-    pixel is computed inside the compositor's launches and a3d_shade_fwd never runs (its [P,3] output stays uninitialised: nobody else
-    may read it before ``materialize()``, which runs the launch after all -- e.g. when the buffer is not composited by the fused op)."""
-
-    def __init__(self):
-        self.filled = self.done = False
-
-    def fill(self, gb, par, kd, kd_stride, two_sided, img, g_par, outs):
-        self.gb, self.par, self.kd, self.kd_stride, self.two_sided, self.img, self.g_par, self.outs = gb, par, kd, kd_stride, two_sided, img, g_par, outs
-        self.filled = True
-
-    def struct(self, clear):
-        """a3d_ca_shade for a compositor call (``clear``: its first launch zeroes g_par -- once: the forward)."""
-        n = self.g_par.numel() if (clear and self.g_par is not None and not self.done) else 0
-        if n:
-            self.done = True  # (the per-image gradient rows are clean from now on, as after a3d_shade_fwd)
-        return _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=self.kd_stride, gb=ptr(self.gb), par=ptr(self.par), kd=ptr(self.kd),
-                            clear=ptr(self.g_par) if n else None, n_clear=n, two_sided=self.two_sided)
-
-    def materialize(self):
-        if self.filled and not getattr(self, "materialized", False):
-            nrm, shading, shaded = self.outs
-            call("a3d_shade_fwd", ptr(self.gb), ptr(self.par), 17, ptr(self.img), ptr(self.kd), self.kd_stride, self.gb.shape[0], self.two_sided,
-                 ptr(nrm), ptr(shading), ptr(shaded), ptr(self.g_par) if not self.done else None, self.par.shape[0], stream())
-            self.materialized = self.done = True
-
-
-def shade_points(gb, par, kd=None, two_sided=True, img=None, recipe=None):
+def shade_points(gb, par, kd=None, two_sided=True, img=None):
     """Shading normal, Lambert shading and shaded colour at the covered pixels (csrc/shade.hip).
 
     gb [P,12] from :func:`gbuffer`; par rows (w2c rotation 9, view position 3[, light direction 3, ambient, diffuse]): one per point
     [P,12|17], or -- with ``img`` [P] (point -> image, int64, non-decreasing) -- one per image [B,12|17], in which case their gradient is
     reduced per image inside the backward kernel; kd [P,3] (any row stride).  Returns nrm, or (nrm, shading [P,1], shaded [P,3]) when a
-    light is given.  ``recipe`` (a ShadeRecipe): defer the launch -- see there."""
-    return _ShadePoints.apply(gb, par, kd, two_sided, img, recipe)
+    light is given."""
+    return _ShadePoints.apply(gb, par, kd, two_sided, img)
+
+
+class ShadeRecipe:
+    """The shaded colour of a fused render, NOT computed yet: what it is computed from.  Handed to shade_composite_antialias the colour of
+    every covered pixel is computed inside the compositor's launches (a3d_ca_shade) and the whole backward -- compositor gather, shading
+    adjoint -- is ONE autograd node that writes the gradients of the G-buffer rows, of the texture field's output rows and of the camera
+    / light tensors where their consumers read them (round 6; a3d_shade_fwd / a3d_shade_bwd and the [B,17] table, its cat and the slices
+    around them are not part of that path).  Any other reader calls ``materialize()``: the classic ops.shade_points on the same inputs.
+
+    gb [P,12]; w2c [1|B,4,4] (or [.,3,3]); view_pos [1|B,3]; light [1|B,5] = DirectionalLight.forward(feat) (direction 3, ambient,
+    diffuse); all_tex [>= P, >= 3]: the texture field's output rows, kd = columns 0..2 (rows past P: padding, never read)."""
+
+    def __init__(self, gb, w2c, view_pos, light, all_tex, two_sided, img):
+        self.gb, self.w2c, self.view_pos, self.light, self.all_tex, self.two_sided, self.img = gb, w2c, view_pos, light, all_tex, bool(two_sided), img
+        self.outs = None
+
+    def per_image(self):
+        """The [B,17] table of a3d_shade_fwd (rotation 9 | view 3 | light 5) from the same tensors (torch ops: the unfused path)."""
+        b = max(self.w2c.shape[0], self.view_pos.shape[0], self.light.shape[0])
+        return torch.cat([self.w2c[:, :3, :3].reshape(-1, 9).expand(b, 9), self.view_pos.reshape(-1, 3).expand(b, 3), self.light.expand(b, 5)], dim=-1)
+
+    def materialize(self):
+        """(shading normal [P,3], shading [P,1], shaded colour [P,3]) through the stand-alone launch."""
+        if self.outs is None:
+            P = self.gb.shape[0]
+            self.outs = shade_points(self.gb, self.per_image(), self.all_tex[:P, :3], self.two_sided, img=self.img[:P])
+        return self.outs
 
 
 # ---------------------------------------------------------------------------------------------- per-image rows <-> points
@@ -1319,86 +1394,174 @@ class _Antialias(torch.autograd.Function):
         return g_color, g_clip, None
 
 
+def _image_gradient_in_place(g, H, W):
+    """(tensor, floats between two pixels, channels) of an NHWC image gradient, read where it is when its pixels are evenly strided (a
+    channel slice of a wider image: the losses write the gradient of 'dino_pred' into the 17-channel layout of the image it was sliced
+    from), else a contiguous copy."""
+    ok = g.dtype == torch.float32 and g.dim() == 4 and (g.shape[3] == 1 or g.stride(3) == 1) and g.stride(2) >= g.shape[3]
+    ok = ok and (g.shape[1] == 1 or g.stride(1) == W * g.stride(2)) and (g.shape[0] == 1 or g.stride(0) == H * W * g.stride(2))
+    if not ok:
+        g = f32c(g)
+    return g, g.stride(2), g.shape[3]
+
+
 class _CompositeAntialias(torch.autograd.Function):
-    """One or two buffers (vals2 None = one) against the same pixel list and crossing records, in the same launches."""
+    """One or two buffers (vals2 None = one) against the same pixel list and crossing records, in the same launches.
+
+    ``keep`` / ``keep2``: leading channels of the composited image handed out (None = all C + 1): render_mesh returns 'dino_pred' and
+    'flow' without their alpha channel (render.py:320-331) -- handed out as a view by this node, their gradient arrives without a
+    SliceBackward (a zero fill and a strided copy of the whole image) in front of it.
+    Shading recipe (``gb`` .. ``all_tex`` given, ``vals`` None): the first buffer's colour is kd * shading computed inside the launches,
+    and the backward of this node runs the shading adjoint too (a3d_shade_bwd_rows): g_gb [P,12], the gradient of the texture field's
+    output rows [rows,T] and of w2c / view_pos / light in their own layouts.
+    ``vals`` / ``vals2`` / ``all_tex`` may have MORE rows than the list (the fields' padded point list): the extra rows are never read and
+    their gradient rows are written as zeros by the same launches."""
 
     @staticmethod
-    def forward(ctx, vals, vals2, clip, pix, inv, bg, bg2, analysis, shade=None):
-        require_device(vals, vals2, pix, inv, what="composite_antialias")
+    def forward(ctx, vals, vals2, clip, pix, inv, bg, bg2, analysis, keep, keep2, gb, w2c, view, light, all_tex, two_sided):
+        require_device(vals, vals2, pix, inv, gb, all_tex, what="composite_antialias")
         a = analysis
-        P = vals.shape[0]
-        assert pix.shape == (P,) and pix.dtype == torch.int64 and inv.shape == (a.B * a.H * a.W,) and inv.dtype == torch.int32
+        P = pix.shape[0]
+        assert pix.dtype == torch.int64 and inv.shape == (a.B * a.H * a.W,) and inv.dtype == torch.int32
+        shade = gb is not None
+        dev = pix.device
 
         def prep(v, g):
             if v is None:
                 return None, None, 0, None
             v = f32c(v)
-            assert v.shape[0] == P
+            assert v.shape[0] >= P
             C = v.shape[1]
             if g is not None:
                 g = f32c(g)
-                assert g.shape[1:] == (a.H, a.W, C + 1) and g.shape[0] in (1, a.B)
-            return v, g, C, torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=v.device)
+                assert g.shape[1:3] == (a.H, a.W) and g.shape[3] <= C + 1 and g.shape[0] in (1, a.B)
+            return v, g, C, torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=dev)
 
-        vals, bg, C, out = prep(vals, bg)
+        par_struct = sh = g_par = None
+        if shade:
+            assert vals is None and light is not None
+            ctx.view_shape = view.shape
+            gb, w2c, view, light, all_tex = f32c(gb), f32c(w2c), f32c(view.reshape(-1, 3)), f32c(light), f32c(all_tex)
+            assert gb.shape == (P, 12) and all_tex.shape[0] >= P and all_tex.shape[1] >= 3 and w2c.shape[1] == w2c.shape[2] and w2c.shape[1] in (3, 4)
+            assert all(t.shape[0] in (1, a.B) for t in (w2c, view, light)) and light.shape[1] == 5
+            bg = None if bg is None else f32c(bg)
+            assert bg is None or (bg.shape[1:3] == (a.H, a.W) and bg.shape[3] <= 4 and bg.shape[0] in (1, a.B))
+            if bg is not None and bg.shape[3] == 4 and bg.data_ptr() % 16:  # (an offset view: the compose kernel reads 4-channel texels as 16-byte loads)
+                bg = bg.clone()
+            C, out = 3, torch.empty((a.B, a.H, a.W, 4), dtype=torch.float32, device=dev)
+            # gradients of the per-image tensors: accumulated by the backward with atomics into ONE buffer (cleared by the forward's
+            # first launch), handed out as views in the tensors' own shapes
+            if any(ctx.needs_input_grad[11:14]):
+                g_par = torch.empty(w2c.numel() + view.numel() + light.numel(), dtype=torch.float32, device=dev)
+            par_struct = _shade_params(w2c, view, light)
+            sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=ptr(g_par),
+                              n_clear=0 if g_par is None else g_par.numel(), two_sided=int(two_sided), params=ctypes.addressof(par_struct))
+        else:
+            vals, bg, C, out = prep(vals, bg)
         vals2, bg2, C2, out2 = prep(vals2, bg2)
         tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
-        use_shade = shade is not None and shade.filled and not getattr(shade, "materialized", False) and C == 3 and shade.outs[2].data_ptr() == vals.data_ptr()
-        if shade is not None and shade.filled and not use_shade:
-            shade.materialize()  # (a recipe this call cannot apply -- copied rows, another channel count: ``vals`` is still unwritten: run the launch)
-        sh = shade.struct(clear=True) if use_shade else None
-        buf = lambda v, c, g, o: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), out=ptr(o), bg_batch=0 if g is None else g.shape[0])
-        first, second = buf(None if use_shade else vals, C, bg, out), (buf(vals2, C2, bg2, out2) if vals2 is not None else None)
+        buf = lambda v, c, g, o: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), out=ptr(o), bg_batch=0 if g is None else g.shape[0],
+                                               bg_channels=0 if g is None else g.shape[3])
+        first, second = buf(None if shade else vals, C, bg, out), (buf(vals2, C2, bg2, out2) if vals2 is not None else None)
         call("a3d_composite_aa_fwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(inv), ptr(a.work), ptr(a.count),
              a.capacity, a.B, a.H, a.W, None if ride is None else ctypes.addressof(ride), None if sh is None else ctypes.addressof(sh), stream(),
-             tag=tag + ("[+shade]" if use_shade else "") + ("[+analysis]" if ride is not None else ""))
-        ctx.shade = shade if use_shade else None
+             tag=tag + ("[+shade]" if shade else "") + ("[+analysis]" if ride is not None else ""))
         if ride is not None:
             a.pending = False  # (only now: the call above raises on a refused argument)
-        ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2)
-        ctx.analysis, ctx.tag = a, tag
+        ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2, gb, w2c, view, light, all_tex)
+        ctx.analysis, ctx.tag, ctx.g_par, ctx.two_sided, ctx.shade = a, tag, g_par, int(bool(two_sided)), shade
+        ctx.set_materialize_grads(False)
+        keep = C + 1 if keep is None else int(keep)
+        keep2 = C2 + 1 if keep2 is None else int(keep2)
+        o1 = out if keep == C + 1 else out[..., :keep]
         if vals2 is None:
-            return out
-        return out, out2
+            return o1, None
+        return o1, (out2 if keep2 == C2 + 1 else out2[..., :keep2])
 
     @staticmethod
     def backward(ctx, g_out, g_out2=None):
-        vals, vals2, pix, inv, bg, bg2 = ctx.saved_tensors
-        a = ctx.analysis
-        P, C = vals.shape
+        vals, vals2, pix, inv, bg, bg2, gb, w2c, view, light, all_tex = ctx.saved_tensors
+        a, shade = ctx.analysis, ctx.shade
+        P = pix.shape[0]
+        dev = pix.device
+        C = 3 if shade else vals.shape[1]
         two = vals2 is not None
         C2 = vals2.shape[1] if two else 0
         if g_out is None:  # (an output nobody differentiated: zero gradient)
-            g_out = torch.zeros((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=vals.device)
+            g_out = torch.zeros((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=dev)
         if two and g_out2 is None:
-            g_out2 = torch.zeros((a.B, a.H, a.W, C2 + 1), dtype=torch.float32, device=vals.device)
-        g_vals = torch.empty_like(vals)
+            g_out2 = torch.zeros((a.B, a.H, a.W, C2 + 1), dtype=torch.float32, device=dev)
+        g_out, gs, gc = _image_gradient_in_place(g_out, a.H, a.W)
+        if two:
+            g_out2, gs2, gc2 = _image_gradient_in_place(g_out2, a.H, a.W)
+        rows = P if shade else vals.shape[0]
+        g_vals = torch.empty((rows, C), dtype=torch.float32, device=dev)  # (shade: the gradient of the shaded colour, consumed below)
         g_vals2 = torch.empty_like(vals2) if two else None
         g_clip = torch.empty_like(a.clip)
-        sh = ctx.shade.struct(clear=False) if ctx.shade is not None else None
-        g_out, g_out2 = f32c(g_out), (f32c(g_out2) if two else None)
-        buf = lambda v, c, g, go, gv: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), g_out=ptr(go), g_vals=ptr(gv),
-                                                    bg_batch=0 if g is None else g.shape[0])
-        first = buf(None if sh is not None else vals, C, bg, g_out, g_vals)
-        second = buf(vals2, C2, bg2, g_out2, g_vals2) if two else None
+        par_struct = sh = None
+        if shade:
+            par_struct = _shade_params(w2c, view, light)
+            sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=None, n_clear=0,
+                              two_sided=ctx.two_sided, params=ctypes.addressof(par_struct))
+        buf = lambda v, c, g, go, gst, gch, gv, nrows: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), g_out=ptr(go), g_vals=ptr(gv),
+                                                                     bg_batch=0 if g is None else g.shape[0], bg_channels=0 if g is None else g.shape[3],
+                                                                     g_stride=gst, g_channels=gch, vals_rows=nrows)
+        first = buf(None if shade else vals, C, bg, g_out, gs, gc, g_vals, rows)
+        second = buf(vals2, C2, bg2, g_out2, gs2, gc2, g_vals2, vals2.shape[0]) if two else None
         call("a3d_composite_aa_bwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(pix), P, ptr(inv), ptr(a.work),
              ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip),
              None if sh is None else ctypes.addressof(sh), stream(), tag=ctx.tag)
-        return g_vals, g_vals2, g_clip, None, None, None, None, None, None
+        if not shade:
+            return (g_vals, g_vals2, g_clip) + (None,) * 13
+        # the shading adjoint in the same node: g_vals -> G-buffer rows, texture rows (kd columns; the other columns and the padding rows
+        # zero), camera / light tensors -- each in the layout its consumer reads
+        g_par, ctx.g_par = ctx.g_par, None  # (cleared by the forward's first launch; serves ONE backward)
+        if g_par is None:
+            g_par = torch.zeros(w2c.numel() + view.numel() + light.numel(), dtype=torch.float32, device=dev)
+        n0, n1 = w2c.numel(), w2c.numel() + view.numel()
+        g_w2c, g_view, g_light = g_par[:n0].view(w2c.shape), g_par[n0:n1].view(view.shape), g_par[n1:].view(light.shape)
+        g_struct = _shade_params(g_w2c, g_view, g_light)
+        g_gb = torch.empty_like(gb)
+        g_tex = torch.empty_like(all_tex)
+        call("a3d_shade_bwd_rows", ptr(g_vals), ptr(gb), ctypes.addressof(par_struct), ctypes.addressof(g_struct), ptr(pix), a.H * a.W, ptr(all_tex),
+             all_tex.stride(0), P, ctx.two_sided, ptr(g_gb), ptr(g_tex), all_tex.shape[1], all_tex.shape[0], stream())
+        return (None, g_vals2, g_clip) + (None,) * 7 + (g_gb, g_w2c, g_view.view(ctx.view_shape), g_light, g_tex, None)
 
 
-def composite_antialias(vals, pix, inv, background, clip, analysis, vals2=None, background2=None, shade=None):
-    """antialias(lerp(background, [vals, 1], coverage)) for a buffer given as rows ``vals`` [P,C] at the covered pixels ``pix`` (``inv`` =
-    the pixel -> row map of covered_pixels(return_inverse=True)): [B,H,W,C+1].  ``background`` [1|B,H,W,C+1] or None (zeros); it gets no
-    gradient (callers with a differentiable background composite with torch and call antialias).  With ``vals2`` (and ``background2``) a
-    second buffer over the same pixels is composited and antialiased by the same launches: returns the pair of images.
-    ``shade`` (the ShadeRecipe ``vals`` came from, deferred): the colour is computed inside the launches of this op instead of being read."""
+def _shade_params(w2c, view, light):
+    """a3d_shade_params over the tensors themselves: w2c [1|B,4,4] / [1|B,3,3], view [1|B,3], light [1|B,5] (contiguous float32)."""
+    n = w2c.shape[1]
+    return _lib.ShadeParams(size=ctypes.sizeof(_lib.ShadeParams), rot_row_stride=n, rot=ptr(w2c), view=ptr(view), light=ptr(light),
+                            rot_image_stride=0 if w2c.shape[0] == 1 else n * n, view_image_stride=0 if view.shape[0] == 1 else 3,
+                            light_image_stride=0 if light.shape[0] == 1 else 5)
+
+
+def composite_antialias(vals, pix, inv, background, clip, analysis, vals2=None, background2=None, keep=None, keep2=None):
+    """antialias(lerp(background, [vals, 1], coverage)) for a buffer given as rows ``vals`` [>= P,C] at the covered pixels ``pix`` (``inv`` =
+    the pixel -> row map of covered_pixels(return_inverse=True)): [B,H,W,C+1].  ``background`` [1|B,H,W,<= C+1] (missing trailing channels
+    = 0: the reference's 3-channel background as it is) or None (zeros); it gets no gradient (callers with a differentiable background
+    composite with torch and call antialias).  With ``vals2`` (and ``background2``) a second buffer over the same pixels is composited
+    and antialiased by the same launches: returns the pair of images.  ``keep`` / ``keep2``: see _CompositeAntialias."""
     assert background is None or not background.requires_grad
     assert background2 is None or not background2.requires_grad
     if clip.dim() == 2:
         clip = clip[None]
-    return _CompositeAntialias.apply(vals, vals2, clip, pix, inv, background, background2, analysis, shade)
+    o1, o2 = _CompositeAntialias.apply(vals, vals2, clip, pix, inv, background, background2, analysis, keep, keep2, None, None, None, None, None, True)
+    return o1 if vals2 is None else (o1, o2)
+
+
+def shade_composite_antialias(recipe, pix, inv, background, clip, analysis, vals2=None, background2=None, keep2=None):
+    """composite_antialias for the shaded colour of ``recipe`` (a ShadeRecipe) as first buffer: the colour is computed inside the launches,
+    and one backward node runs compositor gather + shading adjoint (see _CompositeAntialias)."""
+    assert background is None or not background.requires_grad
+    assert background2 is None or not background2.requires_grad
+    if clip.dim() == 2:
+        clip = clip[None]
+    r = recipe
+    o1, o2 = _CompositeAntialias.apply(None, vals2, clip, pix, inv, background, background2, analysis, None, keep2, r.gb, r.w2c, r.view_pos, r.light,
+                                       r.all_tex, r.two_sided)
+    return o1 if vals2 is None else (o1, o2)
 
 
 def antialias(color, rast, clip, tri, analysis=None):
@@ -1458,16 +1621,17 @@ class _ReconLosses(torch.autograd.Function):
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
         assert shaded.shape == (B, H, W, 4) and shaded.is_contiguous() and image_gt.shape == (B, 3, H, W)
+        ds = D if dino is None else dino.stride(2)  # floats between two pixels (D + 1: the renderer's 17-channel image read in place)
         assert dt0.shape == (B, H, W) and dt0.stride(2) == 1 and dt0.stride(1) == W
         assert dt1 is None or (dt1.shape == dt0.shape and dt1.stride() == dt0.stride())
         image_gt, mask_gt, valid = f32c(image_gt), f32c(mask_gt), f32c(valid)
         if D:
-            assert dino.is_contiguous() and dino_gt.shape == (B, D, H, W)
+            assert dino.stride(3) == 1 and ds >= D and dino.stride(1) == W * ds and dino.stride(0) == H * W * ds and dino_gt.shape == (B, D, H, W)
             dino_gt = f32c(dino_gt)
         loss = torch.empty((B, _lib.lib().a3d_recon_losses_columns()), dtype=torch.float32, device=shaded.device)
         scratch = torch.empty(_lib.lib().a3d_recon_losses_scratch_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
         both = torch.empty(_lib.lib().a3d_recon_losses_mask_bytes(B, H, W), dtype=torch.uint8, device=shaded.device)
-        call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1), dt0.stride(0), ptr(valid),
+        call("a3d_recon_losses_fwd", ptr(shaded), ptr(dino), D, ds, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1), dt0.stride(0), ptr(valid),
              B, H, W, ptr(scratch), ptr(both), ptr(loss), stream())
         ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid, both)
         ctx.mark_non_differentiable(both)
@@ -1479,8 +1643,11 @@ class _ReconLosses(torch.autograd.Function):
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
         g_shaded = torch.empty_like(shaded)
-        g_dino = torch.empty_like(dino) if D else None
-        call("a3d_recon_losses_bwd", ptr(f32h(g_loss)), ptr(shaded), ptr(dino), D, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1),
+        # the feature gradient in the layout of the image the features were sliced from (stride D + 1: the alpha slot stays unwritten, it
+        # has no gradient): the compositor's backward reads it where it is, no zero-padded copy in between
+        ds = dino.stride(2) if D else 0
+        g_dino = torch.empty((B, H, W, ds), dtype=torch.float32, device=shaded.device)[..., :D] if D else None
+        call("a3d_recon_losses_bwd", ptr(f32h(g_loss)), ptr(shaded), ptr(dino), D, ds, ds, ptr(image_gt), ptr(dino_gt), ptr(mask_gt), ptr(dt0), ptr(dt1),
              dt0.stride(0), ptr(valid), B, H, W, ptr(both), ptr(g_shaded), ptr(g_dino), stream())
         return g_shaded, g_dino, None, None, None, None, None, None
 
@@ -1495,7 +1662,10 @@ def reconstruction_losses(shaded_nchw, dino_nchw, image_gt, dino_gt, mask_gt, ma
     dino = None
     if dino_nchw is not None:
         dino = dino_nchw.permute(0, 2, 3, 1)
-        dino = dino if dino.is_contiguous() else dino.contiguous()
+        H, W, S = dino.shape[1], dino.shape[2], dino.stride(2)
+        # (render_mesh's 'dino_pred' = the first 16 channels of its 17-channel image: evenly strided pixels are read in place)
+        if not (dino.dtype == torch.float32 and dino.stride(3) == 1 and S >= dino.shape[3] and dino.stride(1) == W * S and dino.stride(0) == H * W * S):
+            dino = dino.contiguous()
     loss, both = _ReconLosses.apply(shaded, dino, image_gt, dino_gt, mask_gt, mask_dt[:, 0], mask_dt[:, 1], mask_valid)
     return (loss, both) if return_mask else loss
 

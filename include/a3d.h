@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 402 = this header */
+int a3d_version(void); /* 403 = this header */
 const char* a3d_last_error(void);
 
 /* Box fingerprint for the benchmark line (no reference counterpart: the reference's meter, /root/reference/model/utils/meters.py:119, reports
@@ -248,6 +248,30 @@ int a3d_shade_fwd(const float* gb, const float* par, int ncol, const int64_t* im
 int a3d_shade_bwd(const float* g_nrm, const float* g_shading, const float* g_shaded, const float* gb, const float* par, int ncol,
                   const int64_t* img_or_null, int B, const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_par,
                   float* g_kd, int g_par_is_clear, a3d_stream_t stream);
+/* (round 6) The per-image quantities of the shading where the caller keeps them, instead of a [B,17] table assembled for the call: the
+ * camera rotation as the top-left 3x3 of the world-to-camera matrices read in place (rot_row_stride 4; 3 = packed rows), the view
+ * positions, the light rows (direction 3 | ambient | diffuse; NULL = no light) -- each with its own image stride in floats (0 = one row
+ * shared by every image).  The reference builds these per pixel: w2c[:, :3, :3] (render.py:73-74), view_pos (render.py:139-146),
+ * DirectionalLight.forward (light.py:176-184).  The same struct, writable, describes where their gradients are accumulated. */
+typedef struct a3d_shade_params {
+    uint32_t size;           /* sizeof(a3d_shade_params) of the caller's header */
+    int32_t rot_row_stride;  /* floats between two rows of the rotation: 3 or 4 */
+    const float* rot;
+    const float* view;
+    const float* light;      /* NULL: no light */
+    int64_t rot_image_stride;
+    int64_t view_image_stride;
+    int64_t light_image_stride;
+} a3d_shade_params;
+/* a3d_shade_bwd for the fused render (compositor -> shading adjoint -> G-buffer scatter without torch ops in between): g_shaded[P,3] =
+ * the compositor's gradient of the shaded colour; a point's image = pix[p] / pixels_per_image (the covered-pixel list itself: no
+ * point -> image array); the colour gradient is written as rows of the texture field's OUTPUT gradient g_tex[tex_rows, tex_cols] (columns
+ * 0..2 = d/d kd, the other columns -- ks, the unused normal channels, render.py:66-71 -- and the rows past P -- the padding rows of the
+ * field's input -- zero: fully written); g_gb[P,12]; g_par: the rows of par's layout, ACCUMULATED (the caller clears them: the
+ * compositor's forward does, a3d_ca_shade.clear). */
+int a3d_shade_bwd_rows(const float* g_shaded, const float* gb, const a3d_shade_params* par, const a3d_shade_params* g_par, const int64_t* pix,
+                       int64_t pixels_per_image, const float* kd, int kd_stride, int64_t P, int two_sided, float* g_gb, float* g_tex,
+                       int tex_cols, int64_t tex_rows, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Covered-pixel list: flat indices (b*H + y)*W + x of the pixels with rast.w > 0 (triangle_id + 1, as dr.rasterize returns it),
@@ -341,10 +365,12 @@ size_t a3d_rast_bins_bytes(int B, int H, int W, int bin_cap); /* 0: the frame ca
  * Replaces the same reference lines as a3d_rast_fwd + a3d_cover_gbuffer_fwd (render.py:292-294, 139-221). */
 int a3d_rast_resolve(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast, void* scratch,
                      void* cover_scratch, a3d_stream_t stream);
+struct a3d_gb_aux; /* (403; defined with a3d_gbuffer_fwd below) */
 int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                                  void* scratch, void* cover_scratch, int64_t p_cap, int64_t* pix, int32_t* inv_or_null, const float* v_pos,
                                  const float* v_nrm, const float* prior, int prior_batch, float* out, const float* extra_or_null, int E,
-                                 float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream);
+                                 float* extra_out_or_null, float* g_rows_to_clear_or_null, const struct a3d_gb_aux* aux_or_null,
+                                 a3d_stream_t stream);
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
@@ -395,14 +421,31 @@ int a3d_mesh_topology_finalize(const int32_t* tri, int V, int F, int32_t* count,
  * clip is [B,V,4].
  */
 #define A3D_GBUFFER_GRAD_COLS 16
+/* (403) aux: what the texture / feature fields take from the G-buffer, written by the same launch in the form they take it -- so that no
+ * torch op stands between this path and model/networks in either direction (render.py:53-57: material.sample(gb_tex_pos, feat)):
+ * tex_out[>= P, 3] = the canonical position of every listed pixel as dense rows (the fields' input; its gradient comes back as dense
+ * rows too: g_tex of a3d_gbuffer_bwd), img_out[>= P] = the image of every listed pixel (the index into the per-image feature rows).
+ * pad_to > 0: the fields see the list padded to a multiple of pad_to rows (GEMM shapes that repeat from step to step); the launch
+ * fills the padding rows [P, min(round_up(P, pad_to), rows)) itself -- tex_out zeros, img_out = B - 1 (the index stays non-decreasing) --
+ * also where it only learns P on the device (a3d_rast_resolve_gbuffer_fwd: the last work-group of the look-back does it). */
+typedef struct a3d_gb_aux {
+    uint32_t size;
+    int32_t reserved;
+    float* tex_out;
+    int64_t* img_out;
+    int64_t rows;    /* rows allocated behind tex_out / img_out */
+    int64_t pad_to;  /* 0: no padding rows */
+} a3d_gb_aux;
 int a3d_gbuffer_fwd(const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos, const float* v_nrm,
                     const float* prior, int prior_batch, int B, int V, int F, int H, int W, float* out, const float* extra_or_null, int E,
-                    float* extra_out_or_null, float* g_rows_to_clear_or_null, a3d_stream_t stream);
+                    float* extra_out_or_null, float* g_rows_to_clear_or_null, const a3d_gb_aux* aux_or_null, a3d_stream_t stream);
 /* g_rows_to_clear (forward, optional): the backward's g_rows buffer, cleared by the forward launch; the backward is then called with
  * g_rows_are_clear = 1 and skips its memset (a caller that runs the backward twice clears the second time itself: flag 0). */
 int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, const int64_t* pix, int64_t P, const float* v_pos,
                     const float* v_nrm, const float* prior, int prior_batch, const float* clip_or_null, int B, int V, int F, int H, int W,
                     float* g_rows, int g_rows_are_clear, int want_prior, const float* extra_or_null, int E, const float* g_extra_out_or_null,
+                    const float* g_tex_or_null /* (403) [>= P,3]: the gradient of the canonical position as rows of its own (aux.tex_out's);
+                                                  columns 9..11 of g_out are then ignored */,
                     a3d_stream_t stream);
 /* The covered-pixel list AND its G-buffer rows in one launch (= a3d_cover_emit + a3d_gbuffer_fwd; render.py:139-221 on the covered
  * pixels): cover_scratch as for a3d_cover_emit (tile = 8: H, W multiples of 8), P = the list's length (sum of the group sums, read
@@ -410,7 +453,7 @@ int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, c
 int a3d_cover_gbuffer_fwd(const float* rast, const int32_t* tri, int B, int V, int F, int H, int W, const void* cover_scratch, int64_t P,
                           int64_t* pix, int32_t* inv_or_null, const float* v_pos, const float* v_nrm, const float* prior, int prior_batch,
                           float* out, const float* extra_or_null, int E, float* extra_out_or_null, float* g_rows_to_clear_or_null,
-                          a3d_stream_t stream);
+                          const a3d_gb_aux* aux_or_null, a3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out[B,C] (zeroed by callee) = per-image sums of g[P,C] under the point -> image map img[P] (int64): the adjoint of
@@ -496,6 +539,7 @@ typedef struct a3d_ca_shade {
     float* clear;
     int32_t n_clear;
     int32_t two_sided;
+    const a3d_shade_params* params; /* (403) non-NULL: the camera / light rows where the caller keeps them, `par` is ignored */
 } a3d_ca_shade;
 /* One buffer of a compositor call (round 4: the two buffers of a call by name instead of ten / twelve positional arguments). */
 typedef struct a3d_ca_buffer {
@@ -508,6 +552,14 @@ typedef struct a3d_ca_buffer {
     float* g_vals;       /* backward: [P,C], fully written */
     int32_t bg_batch;    /* 1 or B */
     int32_t reserved;
+    /* (403) what a caller needs to hand the reference's own tensors over without torch copies around the call (0 = the defaults above): */
+    int32_t bg_channels; /* channels stored per background pixel (<= C+1; the missing trailing ones read as 0): the reference's background is
+                          * [B,H,W,3] and gets its zero alpha appended per call (render.py:254-256) -- here it is read as it is */
+    int32_t g_stride;    /* backward: floats between two pixels of g_out (default C+1) */
+    int32_t g_channels;  /* backward: leading channels of the image that HAVE a gradient in g_out (default C+1; the rest: zero) -- render_mesh
+                          * returns dino_pred / flow without their alpha channel (render.py:320-331), so their gradient comes without it */
+    int32_t reserved2;
+    int64_t vals_rows;   /* backward: rows of g_vals to write (default P; >= P: the rows past P -- padding rows of a field's point list -- zero) */
 } a3d_ca_buffer;
 int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int32_t* inv, void* work, int32_t* count,
                          int capacity, int B, int H, int W, const a3d_aa_ride* analyze_or_null, const a3d_ca_shade* shade_or_null,
@@ -554,18 +606,23 @@ int a3d_harmonic_embed_bwd(const float* g_out, const float* x, const float* freq
  * mask_gt / valid [B,H,W], dt0 = mask_dt[:,0] and dt1 = mask_dt[:,1] (may be NULL) with image stride dt_stride floats.
  * loss[B,a3d_recon_losses_columns()] = per-image mask, mask_inv_dt, rgb, dino, mask_dt.  bwd: g_loss -> g_shaded[B,H,W,4],
  * g_dino[B,H,W,D] (every element written).  both[B*H*W] = the eroded common mask, written by fwd, read by bwd and by the flow loss.
+ * (403) dino_stride / g_dino_stride: floats between two pixels of dino / g_dino (D = contiguous).  render_mesh returns 'dino_pred' as
+ * the first D channels of a (D+1)-channel image (render.py:330-331): with stride D + 1 the image is read where it is and its gradient
+ * is written in the same layout (the alpha slot untouched), where the compositor's backward reads it (a3d_ca_buffer.g_stride /
+ * g_channels) -- no contiguous copy forward, no zero-padded gradient backward.
  *
  * Flow loss between consecutive frames (AnimalModel.py:285-298): flow = the renderer's 'flow' buffer over B*F frames with pix_stride
  * floats per pixel (3: two flow channels + alpha), flow_gt[B,F-1,2,H,W]; loss[B,F-1]; scale[B,F-1] is kept for the backward;
  * g_flow[B*F,H,W,2] (every element written; the last frame of a sequence gets zeros).
+
  */
 size_t a3d_recon_losses_scratch_bytes(int B, int H, int W);
 size_t a3d_recon_losses_mask_bytes(int B, int H, int W);
 int a3d_recon_losses_columns(void);
-int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt, const float* mask_gt,
+int a3d_recon_losses_fwd(const float* shaded, const float* dino, int D, int dino_stride, const float* image_gt, const float* dino_gt, const float* mask_gt,
                          const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B, int H, int W, void* scratch,
                          uint8_t* both, float* loss, a3d_stream_t stream);
-int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, const float* image_gt, const float* dino_gt,
+int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, const float* dino, int D, int dino_stride, int g_dino_stride, const float* image_gt, const float* dino_gt,
                          const float* mask_gt, const float* dt0, const float* dt1_or_null, int64_t dt_stride, const float* valid, int B, int H,
                          int W, const uint8_t* both, float* g_shaded, float* g_dino, a3d_stream_t stream);
 size_t a3d_flow_loss_scratch_bytes(int B, int F, int H, int W);
@@ -573,6 +630,18 @@ int a3d_flow_loss_fwd(const float* flow, int pix_stride, const float* flow_gt, c
                       float* loss, float* scale, a3d_stream_t stream);
 int a3d_flow_loss_bwd(const float* g_loss, const float* scale, const float* flow, int pix_stride, const float* flow_gt, const uint8_t* both,
                       int B, int F, int H, int W, float* g_flow, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Clip-space transform (403): xfm_points(points, matrix, use_python=True), /root/reference/model/render/renderutils/ops.py:515-531, the
+ * first line of render_mesh (render.py:279): out[B,V,4] = [points,1] . matrix^T, points[points_batch,V,3], matrix[matrix_batch,4,4]
+ * (batches 1 or B).  bwd: g_out with a vertex stride of g_stride floats (4 = contiguous; 16 = the clip columns of a3d_gbuffer_bwd's
+ * gradient rows read in place), g_points[B,V,3] (per image also when points are shared: the caller sums), g_matrix[matrix_batch,4,4]
+ * accumulated with atomics (zeroed by the callee unless g_matrix_is_clear: the forward clears it when handed the buffer).
+ */
+int a3d_xfm_points_fwd(const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V, float* out,
+                       float* g_matrix_to_clear_or_null, a3d_stream_t stream);
+int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V,
+                       float* g_points_or_null, float* g_matrix_or_null, int g_matrix_is_clear, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -96,7 +96,7 @@ def _render_stage(rep, tag, points, rast_hip, posed, nrm, prior_verts, faces, ca
         dense_dino, _ = _dense(points, "dino", n, H, W)
         dino_net = _InjectedField(dense_dino)
     if lgt_cpu is not None:
-        lgt = _InjectedLight(_cpu(points["per_image"])[:n, 12:17])
+        lgt = _InjectedLight(_cpu(points["light"])[:n])  # DirectionalLight.forward's rows as the GPU step computed them
     taps = {}
     with torch.no_grad():
         outs = render_ref.render_mesh(posed, faces, nrm, mvp, w2c, campos, material, lgt, resolution, background=background, feat=None,

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 402
+    assert lib.a3d_version() == L.ABI_VERSION == 403
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000
@@ -687,7 +687,7 @@ def test_spatial_order_tables_reproduce_the_planes_of_the_file_order(grid):
     assert culled_any
 
 
-@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide"), ("a3d_ca_shade", "CaShade"), ("a3d_ca_buffer", "CaBuffer")])
+@pytest.mark.parametrize("struct,cls", [("a3d_dmtet_order", "DmtetOrder"), ("a3d_dmtet_emit_opts", "DmtetEmitOpts"), ("a3d_rast_opts", "RastOpts"), ("a3d_aa_ride", "AaRide"), ("a3d_ca_shade", "CaShade"), ("a3d_ca_buffer", "CaBuffer"), ("a3d_shade_params", "ShadeParams"), ("a3d_gb_aux", "GbAux")])
 def test_abi_structs_match_the_header_field_for_field(struct, cls):
     """The option structs of include/a3d.h against their ctypes mirrors: names, order, pointer / int32 / uint32 kind; `size` first."""
     L = importlib.import_module("3danimals_amd._lib")
@@ -695,7 +695,7 @@ def test_abi_structs_match_the_header_field_for_field(struct, cls):
     body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [(re.sub(r"\s+", " ", d.strip()).rsplit(" ", 1)) for d in body.split(";") if d.strip()]
-    kinds = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32}
+    kinds = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64}
     want = [(name.lstrip("*"), ctypes.c_void_p if "*" in decl + name else kinds[decl]) for decl, name in fields]
     assert [(n, t) for n, t in getattr(L, cls)._fields_] == want and want[0] == ("size", ctypes.c_uint32)
 
