@@ -25,6 +25,7 @@ SIGNATURES = {
     "a3d_dmtet_word_group_bits": (_c_int, []),
     "a3d_dmtet_block_items": (_c_int, []),
     "a3d_dmtet_vertex_scratch_bytes": (_c_size_t, [_c_int]),
+    "a3d_dmtet_gather_rows": (_c_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, _c_int, _p, _p]),
     "a3d_dmtet_emit": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_dmtet_emit_sparse": (_c_int, [_p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     "a3d_dmtet_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _p, _p, _c_int, _p]),
@@ -127,7 +128,7 @@ class CaBuffer(ctypes.Structure):
 
     _fields_ = [("size", ctypes.c_uint32), ("C", ctypes.c_int32), ("vals", _p), ("bg", _p), ("out", _p), ("g_out", _p), ("g_vals", _p),
                 ("bg_batch", ctypes.c_int32), ("reserved", ctypes.c_int32), ("bg_channels", ctypes.c_int32), ("g_stride", ctypes.c_int32),
-                ("g_channels", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("vals_rows", ctypes.c_int64)]
+                ("g_channels", ctypes.c_int32), ("out_channels", ctypes.c_int32), ("vals_rows", ctypes.c_int64)]
 
 
 class CaShade(ctypes.Structure):
@@ -408,11 +409,34 @@ def _raise_deferred(items, flags):
 
 
 def poll_deferred():
-    """Read every pending flag now (one small transfer)."""
+    """Read every pending flag now (one small transfer per device that has any).  Training loops call this once per iteration, before
+    the optimiser step (pipeline.SyntheticScene.step does): a step whose skeleton was estimated from an empty leg
+    quadrant must not update the weights, and a step without any read-back of its own (evaluation, a mask-only render) must not keep
+    the failure pending.  Also registered with atexit."""
     if _deferred:
         items = list(_deferred)
         del _deferred[:]
-        _raise_deferred(items, torch.stack([ok.to(torch.bool) for ok, _ in items]).cpu().tolist())
+        by_device = {}
+        for it in items:
+            by_device.setdefault(it[0].device, []).append(it)
+        for group in by_device.values():
+            _raise_deferred(group, torch.stack([ok.to(torch.bool) for ok, _ in group]).cpu().tolist())
+
+
+def _poll_at_exit():
+    try:
+        poll_deferred()
+    except A3DError as e:  # (cannot raise usefully at interpreter exit: say it)
+        import sys
+
+        print(f"3danimals_amd: {e}", file=sys.stderr)
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_poll_at_exit)
 
 
 def read_back(t):

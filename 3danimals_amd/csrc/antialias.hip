@@ -418,7 +418,8 @@ struct CaJob {
     CaSrc s;
     float* clear;        // forward: n_clear floats zeroed by the compose launch (a3d_ca_shade: the shading backward's per-image rows)
     int n_clear;
-    float* out;          // forward: [B,H,W,C+1]
+    float* out;          // forward: [B,H,W,oC], the first oC <= C+1 channels of the composited image
+    int oC;
     const float* g_out;  // backward: [B,H,W,gS] of which the first gC channels are the gradient of the image's (the rest: zero)
     int gS, gC;
     float* g_vals;       // backward: [vals_rows >= P, C], rows past P zero
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned base = bx * 256u, p = base + threadIdx.x;
     for (unsigned z = p; z < (unsigned)job.n_clear; z += nb_compose * 256u) job.clear[z] = 0.f;
-    if (s.C == 3 && (((uintptr_t)out | (s.bgC == 4 ? (uintptr_t)s.bg : 0)) & 15) == 0) {
+    if (s.C == 3 && job.oC == 4 && (((uintptr_t)out | (s.bgC == 4 ? (uintptr_t)s.bg : 0)) & 15) == 0) {
         if (p >= n_pix) return;
         const int q = ca_point(s, p);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         A3D_STAMP(0, 5);
         return;
     }
-    const int C1 = s.C + 1;
+    const int C1 = job.oC;  // (floats per pixel of the image as it is stored)
     if (p < n_pix) {
         const int q = ca_point(s, p);
         s_src[threadIdx.x] = q >= 0 ? q : (s.bg ? -2 - (int)(s.bg_shared ? p % s.hw : p) : -1);
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void ca_blend_kernel(CaJob ja, CaJob jb, const
     float* __restrict__ out = job.out;
     const int n = aa_segment_offsets(count, capacity, s_off);
     A3D_STAMP(1, 1);
-    const unsigned C1 = (unsigned)s.C + 1u;
+    const unsigned C1 = (unsigned)job.oC;
     const unsigned total = (unsigned)n * C1;  // (n <= capacity records, C1 <= 4096)
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned ru = idx / C1;
@@ -737,6 +738,7 @@ static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* b
     j.s.sh_two_sided = 0; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
     j.s.bgC = (ext && ext->bg_channels > 0) ? ext->bg_channels : C + 1;
     j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0;
+    j.oC = (ext && ext->out_channels > 0) ? ext->out_channels : C + 1;
     j.gS = (ext && ext->g_stride > 0) ? ext->g_stride : C + 1;
     j.gC = (ext && ext->g_channels > 0) ? ext->g_channels : C + 1;
     j.vals_rows = (ext && ext->vals_rows > P) ? ext->vals_rows : P;
@@ -744,7 +746,8 @@ static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* b
 }
 static bool ca_ext_ok(const a3d_ca_buffer* b) {
     return b->bg_channels >= 0 && b->bg_channels <= b->C + 1 && b->g_channels >= 0 && b->g_channels <= b->C + 1 && b->g_stride >= 0 &&
-           (b->g_stride == 0 || b->g_stride >= (b->g_channels > 0 ? b->g_channels : b->C + 1)) && b->vals_rows >= 0;
+           (b->g_stride == 0 || b->g_stride >= (b->g_channels > 0 ? b->g_channels : b->C + 1)) && b->vals_rows >= 0 && b->out_channels >= 0 &&
+           b->out_channels <= b->C + 1;
 }
 
 // the deferred shading of a compositor call's first buffer (a3d_ca_shade): the job's values come from sh_forward instead of vals
@@ -759,7 +762,7 @@ static int ca_shade(const a3d_ca_shade* sh, int C, const float* vals, CaJob* j, 
     }
     // (the colour computed on the spot exists only on the compose kernel's 16-byte path: a forward call whose image or 4-channel background
     // is not 16-byte aligned would take the general path, which has no shading source -- refused instead of composited wrongly)
-    A3D_CHECK_ARG(!forward || ((((uintptr_t)j->out | (j->s.bgC == 4 ? (uintptr_t)j->s.bg : 0)) & 15) == 0));
+    A3D_CHECK_ARG(!forward || (j->oC == 4 && (((uintptr_t)j->out | (j->s.bgC == 4 ? (uintptr_t)j->s.bg : 0)) & 15) == 0));
     j->s.sh_gb = sh->gb; j->s.sh_par = sh->params ? sh_par_of(sh->params) : sh_par_table(sh->par, 17); j->s.sh_kd = sh->kd;
     j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
     if (forward) { j->clear = sh->clear; j->n_clear = sh->n_clear; }

@@ -1182,4 +1182,26 @@ extern "C" int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float
     return A3D_OK;
 }
 
+// out[i, :] = src[idx[i], :] for i < n, zeros for n <= i < rows: the surface-adjacent grid vertices' rows gathered into the bucket-padded
+// list the SDF field is re-evaluated on (DMTetGeometry._get_mesh_surface_backward: pos[idx] + pad forward, g_sdf[idx] + pad backward --
+// an index kernel, a pad copy and the slice's zero-fill + copy each way as torch ops)
+__global__ __launch_bounds__(256) void dm_gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long n,
+                                                             long long rows, int C, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * C) return;
+    const long long i = t / C;
+    const int c = (int)(t - i * C);
+    out[t] = i < n ? src[idx[i] * C + c] : 0.f;
+}
+
+extern "C" int a3d_dmtet_gather_rows(const float* src, const int64_t* idx, int64_t n, int64_t rows, int C, float* out, a3d_stream_t stream) {
+    A3D_CHECK_ARG(n >= 0 && rows >= n && C >= 1 && C <= 16);
+    if (rows == 0) return A3D_OK;
+    A3D_CHECK_ARG(out && (n == 0 || (src && idx)));
+    hipLaunchKernelGGL(dm_gather_rows_kernel, dim3(a3d_div_up(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, src, (const long long*)idx,
+                       (long long)n, (long long)rows, C, out);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
 A3D_PROFILE_TU(dmtet)

@@ -21,6 +21,7 @@ constexpr int LS_NL = 5;  // loss columns: mask, mask_inv_dt, rgb, dino, mask_dt
 // partial[(b*nblk + blk)*4 + k]: per-block sums of the four summands
 // (round 6) ``ds``: floats between two pixels of ``dino`` (D = contiguous; D + 1 = the renderer's 17-channel feature image read in place,
 // its alpha channel skipped -- render.py:330-331 slices it off, here nobody copies the 16 channels out first)
+template <bool VEC>  // VEC: dino is contiguous in its D channels and 16-byte aligned (the float4 form); else any pixel stride, four scalar loads
 __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restrict__ shaded, const float* __restrict__ dino, int D, int ds,
                                                           const float* __restrict__ image_gt, const float* __restrict__ dino_gt,
                                                           const float* __restrict__ mask_gt, const float* __restrict__ dt0,
@@ -80,15 +81,14 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_fwd_kernel(const float* __restric
             const int D4 = D >> 2, lane = threadIdx.x & 63;
             const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);  // first pixel of this wave inside image b
             const long long img_px = (long long)b * HW;
-            const float* cbase = dino + (img_px + px0) * ds;
-            const bool vec = ds == D && (((uintptr_t)dino & 15) == 0);
+            const float* cbase = dino + (img_px + px0) * (VEC ? D : ds);
             float acc = 0.f;
             for (int t = 0; t < D4; ++t) {
                 const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
                 const float both_pl = __shfl(both, pl, 64);  // pixel pl's mask lives in lane pl (all lanes take part)
                 if (px < HW) {
                     float4 q;
-                    if (vec) q = reinterpret_cast<const float4*>(cbase)[f];
+                    if (VEC) q = reinterpret_cast<const float4*>(cbase)[f];
                     else { const float* qp = cbase + (long long)pl * ds + 4 * cg; q = make_float4(qp[0], qp[1], qp[2], qp[3]); }
                     const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
                     const float e0 = q.x - dg[0], e1 = q.y - dg[HW], e2 = q.z - dg[2ll * HW], e3 = q.w - dg[3ll * HW];
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64) void ls_finish_kernel(const float* __restrict__
 
 // ``gds``: floats between two pixels of g_dino (D + 1: the gradient is laid out like the 17-channel image it belongs to, so that the
 // compositor's backward reads it in place; the alpha channel's slot is not written -- it has no gradient, a3d_ca_buffer.g_channels)
+template <bool VEC>
 __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ shaded,
                                                           const float* __restrict__ dino, int D, int ds, int gds, const float* __restrict__ image_gt,
                                                           const float* __restrict__ dino_gt, const float* __restrict__ mask_gt,
@@ -166,15 +167,14 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
     if ((D & 3) == 0) {  // wave-cooperative, fully coalesced float4 loads and stores (see ls_fwd_kernel)
         const int D4 = D >> 2, lane = threadIdx.x & 63;
         const int px0 = blockIdx.x * LS_BLOCK + (threadIdx.x & ~63);
-        const float* cbase = dino + (img_px + px0) * ds;
-        float* gbase = g_dino + (img_px + px0) * gds;
-        const bool vec = ds == D && (((uintptr_t)dino & 15) == 0), gvec = gds == D && (((uintptr_t)g_dino & 15) == 0);
+        const float* cbase = dino + (img_px + px0) * (VEC ? D : ds);
+        float* gbase = g_dino + (img_px + px0) * (VEC ? D : gds);
         for (int t = 0; t < D4; ++t) {
             const int f = t * 64 + lane, pl = f / D4, cg = f - pl * D4, px = px0 + pl;
             const float gq = gq0 * __shfl(both, pl, 64);
             if (px < HW) {
                 float4 q;
-                if (vec) q = reinterpret_cast<const float4*>(cbase)[f];
+                if (VEC) q = reinterpret_cast<const float4*>(cbase)[f];
                 else { const float* qp = cbase + (long long)pl * ds + 4 * cg; q = make_float4(qp[0], qp[1], qp[2], qp[3]); }
                 const float* dg = dino_gt + ((long long)b * D + 4 * cg) * HW + px;
                 float4 o4;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_bwd_kernel(const float* __restric
                 o4.y = gq * (q.y - dg[HW]);
                 o4.z = gq * (q.z - dg[2ll * HW]);
                 o4.w = gq * (q.w - dg[3ll * HW]);
-                if (gvec) {  // streamed: 67 MB that only the compositor's gather reads back, sparsely
+                if (VEC) {  // streamed: 67 MB that only the compositor's gather reads back, sparsely
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f nt; nt.x = o4.x; nt.y = o4.y; nt.z = o4.z; nt.w = o4.w;
                     __builtin_nontemporal_store(nt, reinterpret_cast<v4f*>(gbase) + f);
@@ -289,7 +289,8 @@ extern "C" int a3d_recon_losses_fwd(const float* shaded, const float* dino, int 
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt && dino_stride >= D));
     hipStream_t s = (hipStream_t)stream;
     const int nblk = a3d_div_up((long long)H * W, LS_BLOCK);
-    hipLaunchKernelGGL(ls_fwd_kernel, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, dino_stride, image_gt, dino_gt, mask_gt, dt0, dt1_or_null,
+    const bool vec = D > 0 && dino_stride == D && (((uintptr_t)dino & 15) == 0);
+    hipLaunchKernelGGL(vec ? ls_fwd_kernel<true> : ls_fwd_kernel<false>, dim3(nblk, B), dim3(LS_BLOCK), 0, s, shaded, D ? dino : nullptr, D, dino_stride, image_gt, dino_gt, mask_gt, dt0, dt1_or_null,
                        (long long)dt_stride, valid, H, W, (float*)scratch, both);
     A3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(ls_finish_kernel, dim3(B, LS_NL), dim3(64), 0, s, (const float*)scratch, nblk, H * W, D, loss);
@@ -303,7 +304,8 @@ extern "C" int a3d_recon_losses_bwd(const float* g_loss, const float* shaded, co
                                     a3d_stream_t stream) {
     A3D_CHECK_ARG(g_loss && shaded && image_gt && mask_gt && dt0 && valid && both && g_shaded && B > 0 && H > 0 && W > 0 && D >= 0);
     A3D_CHECK_ARG(D == 0 || (dino && dino_gt && g_dino && dino_stride >= D && g_dino_stride >= D));
-    hipLaunchKernelGGL(ls_bwd_kernel, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
+    const bool vec = D > 0 && dino_stride == D && g_dino_stride == D && ((((uintptr_t)dino | (uintptr_t)g_dino) & 15) == 0);
+    hipLaunchKernelGGL(vec ? ls_bwd_kernel<true> : ls_bwd_kernel<false>, dim3(a3d_div_up((long long)H * W, LS_BLOCK), B), dim3(LS_BLOCK), 0, (hipStream_t)stream, g_loss, shaded,
                        D ? dino : nullptr, D, dino_stride, g_dino_stride, image_gt, dino_gt, mask_gt, dt0, dt1_or_null, (long long)dt_stride, valid, H, W, both, g_shaded, g_dino);
     A3D_LAUNCH_CHECK();
     return A3D_OK;

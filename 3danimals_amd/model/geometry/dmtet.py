@@ -476,19 +476,28 @@ class DMTetGeometry(torch.nn.Module):
         # idx = the grid vertices at the ends of crossing edges, sorted and unique; their count arrives with the DMTet counts (the
         # mask + torch.nonzero this replaces was a second host synchronisation per step)
         verts0, faces, uv_idx, vert_edge, idx = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True, for_backward=True)
-        pts = pos[idx]
         n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0
-        if n_pad:  # pad (zeros, sliced off again) so the MLP's GEMM shapes repeat from step to step
-            pts = torch.nn.functional.pad(pts, (0, 0, 0, n_pad))
-        sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)[: idx.shape[0]]
-        self.current_sdf = sdf0.index_add(0, idx, sdf_sub - sdf_sub.detach())
+        if pos.is_cuda and pos.dtype == torch.float32 and sdf0.dim() == 2 and sdf0.shape[1] == 1:
+            # (round 6) one launch gathers the positions into the bucket-padded list (zero rows behind, so that the MLP's GEMM shapes repeat
+            # from step to step), and one node splices the re-evaluated values in: forward no kernel at all, backward one gather
+            pts = ops.gather_rows_padded(pos, idx, idx.shape[0] + n_pad)
+            sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)
+            self.current_sdf = ops.surface_sdf(sdf0, idx, sdf_sub)
+        else:
+            pts = pos[idx]
+            if n_pad:
+                pts = torch.nn.functional.pad(pts, (0, 0, 0, n_pad))
+            sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)[: idx.shape[0]]
+            self.current_sdf = sdf0.index_add(0, idx, sdf_sub - sdf_sub.detach())
         return ops.dmtet_verts(pos, self.current_sdf, verts0, vert_edge, self.topology), faces, uv_idx
 
     # ---- mesh extraction (reference dmtet.py:294-310) ---------------------------------------------
     def getMesh(self, material=None, total_iter=0, jitter_grid=True, feats=None):
         v_deformed = self.verts
         if jitter_grid and self.jitter_grid > 0:
-            jitter = (torch.rand(1, device=v_deformed.device) * 2 - 1) * self.jitter_grid * self.grid_scale
+            # U(-1, 1) * jitter_grid * grid_scale (dmtet.py:297-299) drawn in ONE launch instead of rand, * 2, - 1, * scale
+            amp = float(self.jitter_grid) * float(self.grid_scale)
+            jitter = torch.empty(1, device=v_deformed.device).uniform_(-amp, amp)
             v_deformed = v_deformed + jitter
         self.current_pos = v_deformed  # (extra attribute: the jittered grid this mesh was extracted on)
         if self.surface_only_backward and torch.is_grad_enabled() and any(p.requires_grad for p in self.mlp.parameters()):

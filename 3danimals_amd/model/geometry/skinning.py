@@ -160,18 +160,18 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
             CPU; on the GPU the flag stays on the device and travels in the next read-back the path performs anyway (_lib.defer_check
             -- NOT a device-side assert: a failed torch._assert_async ends a ROCm process as an anonymous "HSA hardware exception").
             Until then the foot of an empty quadrant is vertex 0: a wrong skeleton for one step, never an out-of-range index."""
-            populated = quadrant.any(dim=-1)
-            if seq_shape.is_cuda:
-                from ..._lib import defer_check
-
-                defer_check(populated.all(), "estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
-            elif not bool(populated.all()):
+            if not seq_shape.is_cuda and not bool(quadrant.any(dim=-1).all()):
                 raise RuntimeError("estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
             y_in = torch.where(quadrant, ys, torch.full_like(ys, float("inf")))
             return torch.gather(seq_shape, 2, y_in.argmin(dim=-1)[..., None, None].expand(-1, -1, 1, 3))  # [B,F,1,3]
 
         if QUADRANT_POPULATION is not None:  # diagnostic hook (tools/fauna_quadrant_diag.py): vertices per leg quadrant, kept on the device
             QUADRANT_POPULATION.append(torch.stack([q.sum(dim=-1).min() for q in quadrants]))
+        if seq_shape.is_cuda:  # ONE flag for the four quadrants (one stack, one any, one all -- not four of each)
+            from ..._lib import defer_check
+
+            defer_check(torch.stack(quadrants).any(dim=-1).all(),
+                        "estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
         feet = [foot_of(q) for q in quadrants]
         ramp = torch.linspace(0.0, 1.0, n_leg_bones + 1, device=seq_shape.device)[None, None, :, None]
         if legs_to_body_joint_indices is None:
@@ -356,20 +356,24 @@ def bone_transforms_torch(bones, kinematic_tree, deform_params):
 
 
 class _LazyAux(dict):
-    """aux dict whose 'vertices_to_bones' ([K,B,F,V], unused by any caller on the training path) is computed on first access."""
+    """aux dict whose 'vertices_to_bones' ([K,B,F,V], unused by any caller on the training path) and 'posed_bones' (read by the bone
+    smoothness terms of the sequence models and by the visualisation only: AnimalModel.py:348-352,604-605) are computed on first access --
+    differentiable like the reference's, from the transforms the skinning launch returned."""
 
-    def __init__(self, make_weights):
+    def __init__(self, make_weights, make_posed=None):
         super().__init__()
-        self._make_weights = make_weights
+        self._lazy = {"vertices_to_bones": make_weights}
+        if make_posed is not None:
+            self._lazy["posed_bones"] = make_posed
 
     def __missing__(self, key):
-        if key == "vertices_to_bones":
-            self[key] = self._make_weights()
+        if key in self._lazy:
+            self[key] = self._lazy[key]()
             return self[key]
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == "vertices_to_bones" or super().__contains__(key)
+        return key in self._lazy or super().__contains__(key)
 
     def get(self, key, default=None):
         try:
@@ -416,11 +420,12 @@ def skinning(v_pos, bones_pred, kinematic_tree, deform_params, output_posed_bone
         bx, fx = max(v_pos.shape[0], bones_pred.shape[0]), max(v_pos.shape[1], bones_pred.shape[1])
         return w.view(K, B, Fr, V)[:, :bx, :fx]  # broadcast dims hold duplicates
 
-    aux = _LazyAux(weights)
-    aux["bones_pred"] = bones_pred
-    if output_posed_bones:
+    def posed_bones():
         ends = bones_pred.detach().expand(B, Fr, K, 2, 3).reshape(B * Fr, K, 2, 3)
         T34 = T.view(B * Fr, K, 3, 4)
         posed = torch.einsum("nkij,nkej->nkei", T34[..., :3], ends) + T34[:, :, None, :, 3]
-        aux["posed_bones"] = posed.view(B, Fr, K, 2, 3)
+        return posed.view(B, Fr, K, 2, 3)
+
+    aux = _LazyAux(weights, fp32_region(posed_bones) if output_posed_bones else None)
+    aux["bones_pred"] = bones_pred
     return out, aux

@@ -477,9 +477,14 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         analysis = ops.AAAnalysis(rast, clip_f, ops.aa_topology(tri32, clip_f.shape[1]), defer=DEFER_ANALYSIS)
         LAST_POINTS[0] = dict(clip=clip_f.detach())
         return [ops.mask_antialias(rast, clip_f, bg, analysis, 3).permute(0, 3, 1, 2)]
-    rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
-                            prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
-                            class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
+    try:
+        rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
+                                prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
+                                class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
+    except BaseException:
+        if defer:  # the consumer the deferred resolve was promised failed: nothing may be left pending (keys pinned, texels unwritten)
+            ops.drop_pending_resolve(rast)
+        raise
 
     if background is not None and spp > 1:
         background = util.scale_img_nhwc(background, full_res, mag="nearest", min="nearest")

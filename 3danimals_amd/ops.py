@@ -335,7 +335,7 @@ class _DMTetVerts(torch.autograd.Function):
         ctx.save_for_backward(pos_c, sdf_c, vert_edge)
         ctx.grid, ctx.sdf_shape = grid, sdf.shape
         ctx.g_sdf = _dm_grad_buffers.take(vert_edge)  # cleared by the emit launch of dmtet_extract(for_backward=True), or None
-        return verts0.clone()
+        return verts0.detach()  # (a fresh tensor over the extraction's own buffer, which nobody else holds: no copy launch)
 
     @staticmethod
     def backward(ctx, g_verts):
@@ -349,6 +349,37 @@ class _DMTetVerts(torch.autograd.Function):
         g = f32c(g_verts) if V > 0 else None
         call("a3d_dmtet_bwd", ptr(g), ptr(pos_c), ptr(sdf_c), ptr(ctx.grid.edges32), ptr(vert_edge), V, Nv, ptr(g_pos), ptr(g_sdf), int(clear), stream())
         return g_pos, g_sdf.reshape(ctx.sdf_shape), None, None, None
+
+
+def gather_rows_padded(src, idx, rows):
+    """[rows,C] = src[idx] followed by zero rows (rows >= len(idx)); src [N,C] float32, idx int64 -- one launch, no autograd."""
+    require_device(src, idx, what="gather_rows_padded")
+    src = f32c(src)
+    C = src.shape[1] if src.dim() == 2 else 1
+    out = torch.empty((rows, C), dtype=torch.float32, device=src.device)
+    call("a3d_dmtet_gather_rows", ptr(src), ptr(idx), idx.shape[0], rows, C, ptr(out), stream())
+    return out
+
+
+class _SurfaceSdf(torch.autograd.Function):
+    """sdf0 with the graph of ``sdf_sub`` attached at the rows ``idx``: forward returns sdf0's values (the reference of this trick,
+    sdf0.index_add(0, idx, sdf_sub - sdf_sub.detach()), adds exact zeros), backward gathers g[idx] into sdf_sub's (padded) shape."""
+
+    @staticmethod
+    def forward(ctx, sdf0, idx, sdf_sub):
+        ctx.save_for_backward(idx)
+        ctx.sub_shape = sdf_sub.shape
+        return sdf0.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return None, None, gather_rows_padded(g.reshape(g.shape[0], -1), idx, ctx.sub_shape[0]).view(ctx.sub_shape)
+
+
+def surface_sdf(sdf0, idx, sdf_sub):
+    """sdf0 [Nv,1] (no graph) whose rows idx [n] carry the graph of sdf_sub [>= n,1] (its first n rows; the rest is padding)."""
+    return _SurfaceSdf.apply(sdf0, idx, sdf_sub)
 
 
 def dmtet_verts(pos, sdf, verts0, vert_edge, grid):
@@ -735,7 +766,33 @@ _rast_keys = {}
 # is enqueued: its rows are allocated for the previous frame's length + 25 % (per device and frame size) and the exact two-launch path
 # re-runs when the frame outgrew them.
 DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"
-_pending_resolve = _IdentityCache(maxsize=2)  # raster buffer -> what its resolve needs (clip, triangle list, key buffer)
+
+
+class _PendingResolves(_IdentityCache):
+    """raster buffer -> what its resolve needs (clip, triangle list, key buffer).  An entry that is pushed out before anybody resolved
+    it is RESOLVED on the way out (stand-alone launch): a raster buffer handed to a reader must never be left as uninitialised texels
+    because a third deferred call came before its consumer did."""
+
+    def put(self, t, val):
+        self.data[self.key(t)] = (t, val)
+        self.data.move_to_end(self.key(t))
+        while len(self.data) > self.maxsize:
+            _, (rast_old, pend) = self.data.popitem(last=False)
+            _run_standalone_resolve(rast_old, pend)
+            resolve_events["evicted"] = resolve_events.get("evicted", 0) + 1
+        return val
+
+
+def _run_standalone_resolve(rast, pend):
+    B, H, W = rast.shape[:3]
+    clip, tri32 = pend["clip"], pend["tri32"]
+    call("a3d_rast_resolve", ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W, ptr(pend["rast"]), ptr(pend["keys"]),
+         ptr(pend["cover"]), stream())
+    _rast_keys[pend["key"]] = pend["keys"]  # (re-armed by the resolve)
+    resolve_events["standalone"] += 1
+
+
+_pending_resolve = _PendingResolves(maxsize=2)
 _cover_last_len = {}  # (device, B, H, W) -> length of the last covered-pixel list
 resolve_events = dict(fused=0, outgrown=0, standalone=0)
 _debug_force_lookback_timeout = False  # tests: take the recovery path of a timed-out look-back
@@ -744,14 +801,13 @@ _debug_force_lookback_timeout = False  # tests: take the recovery path of a time
 def ensure_resolved(rast):
     """Run the stand-alone resolve launch now if ``rast`` came out of rasterize(defer_resolve=True) and nothing has resolved it yet."""
     pend = _pending_resolve.take(rast)
-    if pend is None:
-        return
-    B, H, W = rast.shape[:3]
-    clip, tri32 = pend["clip"], pend["tri32"]
-    call("a3d_rast_resolve", ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W, ptr(pend["rast"]), ptr(pend["keys"]),
-         ptr(_cover_counts.peek(rast)), stream())
-    _rast_keys[pend["key"]] = pend["keys"]  # (re-armed by the resolve)
-    resolve_events["standalone"] += 1
+    if pend is not None:
+        _run_standalone_resolve(rast, pend)
+
+
+def drop_pending_resolve(rast):
+    """A deferred raster buffer whose consumer failed before it ran: resolve it now (keys re-armed, nothing left pinned)."""
+    ensure_resolved(rast)
 
 # the binned path (a3d_rast_opts.bins: per-tile triangle lists + a fine pass, no memory-side atomics): its scratch is kept per (device,
 # stream, frame) like the key buffer (the fine pass leaves the tile counts at zero), the capacity of a tile list per (device, frame):
@@ -860,7 +916,7 @@ class _Rasterize(torch.autograd.Function):
         if len(_rast_keys) >= 4:
             _rast_keys.clear()
         if defer:  # the keys are full until a resolve has consumed them: they travel with the raster buffer, not back into the cache
-            _pending_resolve.put(rast.detach(), dict(clip=clip, tri32=tri32, keys=scratch, key=key, rast=rast))
+            _pending_resolve.put(rast.detach(), dict(clip=clip, tri32=tri32, keys=scratch, key=key, rast=rast, cover=cover))
         elif scratch is not None and (F > 0 or clean):  # only after a successful call whose resolve re-armed the keys (F == 0 returns before touching
             _rast_keys[key] = scratch  # them: a fresh torch.empty buffer must not come back as "clean"; a failed call leaves the buffer out too)
         ctx.save_for_backward(clip, tri32, rast)
@@ -869,6 +925,7 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rast):
         clip, tri32, rast = ctx.saved_tensors
+        ensure_resolved(rast)
         B, H, W = rast.shape[:3]
         g_clip = torch.empty_like(clip)
         call("a3d_rast_bwd", ptr(f32h(g_rast)), ptr(rast), ptr(clip), clip.shape[0], ptr(tri32), B, clip.shape[1], tri32.shape[0], H, W,
@@ -893,6 +950,7 @@ def rasterize_db(clip, tri, rast):
     barycentrics of the stored triangle, from the definition u = a0/s, a_i = q_j x q_k, q_i = p_i.xy - f p_i.w (torch ops, so they are
     differentiable w.r.t. clip like nvdiffrast's; nothing on the training path consumes them: render.py:24 passes rast_db=None)."""
     B, H, W, _ = rast.shape
+    ensure_resolved(rast)
     ids = rast[..., 3].long() - 1
     hit = ids >= 0
     t = tri.long()[ids.clamp(min=0)]
@@ -919,6 +977,7 @@ class _Interpolate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attr, rast, tri32):
         require_device(attr, rast, tri32, what="interpolate")
+        ensure_resolved(rast)
         attr, rast = f32c(attr), f32c(rast)
         B, H, W = rast.shape[:3]
         V, C = attr.shape[1], attr.shape[2]
@@ -1324,6 +1383,7 @@ class AAAnalysis:
 
     def __init__(self, rast, clip, topo: AATopology, defer=False):
         require_device(rast, clip, what="antialias")
+        ensure_resolved(rast)  # (one dictionary miss when nothing is pending -- the render path resolves in its G-buffer launch before this)
         self.rast, self.clip, self.topo = f32c(rast.detach()), f32c(clip.detach()), topo
         B, H, W = rast.shape[:3]
         self.B, self.H, self.W = B, H, W
@@ -1408,9 +1468,10 @@ def _image_gradient_in_place(g, H, W):
 class _CompositeAntialias(torch.autograd.Function):
     """One or two buffers (vals2 None = one) against the same pixel list and crossing records, in the same launches.
 
-    ``keep`` / ``keep2``: leading channels of the composited image handed out (None = all C + 1): render_mesh returns 'dino_pred' and
-    'flow' without their alpha channel (render.py:320-331) -- handed out as a view by this node, their gradient arrives without a
-    SliceBackward (a zero fill and a strided copy of the whole image) in front of it.
+    ``keep`` / ``keep2``: leading channels of the composited image that are materialised and handed out (None = all C + 1): render_mesh
+    returns 'dino_pred' and 'flow' without their alpha channel (render.py:320-331) -- here that channel is never written, the image comes
+    out contiguous in the channels the caller keeps, and its gradient arrives without a SliceBackward (a zero fill and a strided copy of
+    the whole image) in front of it.
     Shading recipe (``gb`` .. ``all_tex`` given, ``vals`` None): the first buffer's colour is kd * shading computed inside the launches,
     and the backward of this node runs the shading adjoint too (a3d_shade_bwd_rows): g_gb [P,12], the gradient of the texture field's
     output rows [rows,T] and of w2c / view_pos / light in their own layouts.
@@ -1426,7 +1487,7 @@ class _CompositeAntialias(torch.autograd.Function):
         shade = gb is not None
         dev = pix.device
 
-        def prep(v, g):
+        def prep(v, g, k):
             if v is None:
                 return None, None, 0, None
             v = f32c(v)
@@ -1435,7 +1496,9 @@ class _CompositeAntialias(torch.autograd.Function):
             if g is not None:
                 g = f32c(g)
                 assert g.shape[1:3] == (a.H, a.W) and g.shape[3] <= C + 1 and g.shape[0] in (1, a.B)
-            return v, g, C, torch.empty((a.B, a.H, a.W, C + 1), dtype=torch.float32, device=dev)
+            k = C + 1 if k is None else int(k)
+            assert 1 <= k <= C + 1
+            return v, g, C, torch.empty((a.B, a.H, a.W, k), dtype=torch.float32, device=dev)  # (only the channels handed out are materialised)
 
         par_struct = sh = g_par = None
         if shade:
@@ -1457,12 +1520,13 @@ class _CompositeAntialias(torch.autograd.Function):
             sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=ptr(g_par),
                               n_clear=0 if g_par is None else g_par.numel(), two_sided=int(two_sided), params=ctypes.addressof(par_struct))
         else:
-            vals, bg, C, out = prep(vals, bg)
-        vals2, bg2, C2, out2 = prep(vals2, bg2)
-        tag = f"[C{C + 1}]" if vals2 is None else f"[C{C + 1}+C{C2 + 1}]"
+            vals, bg, C, out = prep(vals, bg, keep)
+        vals2, bg2, C2, out2 = prep(vals2, bg2, keep2)
+        ctag = lambda c, o: f"C{c + 1}" if o.shape[3] == c + 1 else f"C{c + 1}>{o.shape[3]}"  # (C17>16: a 17-channel composite of which 16 channels are materialised)
+        tag = f"[{ctag(C, out)}]" if vals2 is None else f"[{ctag(C, out)}+{ctag(C2, out2)}]"
         ride = a.ride_args()  # a deferred analysis runs inside the first launch of this call
         buf = lambda v, c, g, o: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), out=ptr(o), bg_batch=0 if g is None else g.shape[0],
-                                               bg_channels=0 if g is None else g.shape[3])
+                                               bg_channels=0 if g is None else g.shape[3], out_channels=o.shape[3])
         first, second = buf(None if shade else vals, C, bg, out), (buf(vals2, C2, bg2, out2) if vals2 is not None else None)
         call("a3d_composite_aa_fwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(inv), ptr(a.work), ptr(a.count),
              a.capacity, a.B, a.H, a.W, None if ride is None else ctypes.addressof(ride), None if sh is None else ctypes.addressof(sh), stream(),
@@ -1472,12 +1536,7 @@ class _CompositeAntialias(torch.autograd.Function):
         ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2, gb, w2c, view, light, all_tex)
         ctx.analysis, ctx.tag, ctx.g_par, ctx.two_sided, ctx.shade = a, tag, g_par, int(bool(two_sided)), shade
         ctx.set_materialize_grads(False)
-        keep = C + 1 if keep is None else int(keep)
-        keep2 = C2 + 1 if keep2 is None else int(keep2)
-        o1 = out if keep == C + 1 else out[..., :keep]
-        if vals2 is None:
-            return o1, None
-        return o1, (out2 if keep2 == C2 + 1 else out2[..., :keep2])
+        return out, out2
 
     @staticmethod
     def backward(ctx, g_out, g_out2=None):
@@ -1635,6 +1694,7 @@ class _ReconLosses(torch.autograd.Function):
              B, H, W, ptr(scratch), ptr(both), ptr(loss), stream())
         ctx.save_for_backward(shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid, both)
         ctx.mark_non_differentiable(both)
+        ctx.set_materialize_grads(False)  # (no zero tensor filled for the mask output's "gradient")
         return loss, both
 
     @staticmethod
@@ -1642,6 +1702,8 @@ class _ReconLosses(torch.autograd.Function):
         shaded, dino, image_gt, dino_gt, mask_gt, dt0, dt1, valid, both = ctx.saved_tensors
         B, H, W = shaded.shape[:3]
         D = 0 if dino is None else dino.shape[3]
+        if g_loss is None:
+            return (None,) * 8
         g_shaded = torch.empty_like(shaded)
         # the feature gradient in the layout of the image the features were sliced from (stride D + 1: the alpha slot stays unwritten, it
         # has no gradient): the compositor's backward reads it where it is, no zero-padded copy in between

@@ -267,7 +267,7 @@ class SyntheticScene(torch.nn.Module):
         verts, aux = skinning_mod.skinning(rest, self.bones, self.kinematic_tree, arti, output_posed_bones=True, temperature=self.temperature)
         verts = verts.view(N, *verts.shape[2:])
         shape = mesh_mod.make_mesh(verts, prior.t_pos_idx, prior.v_tex.expand(N, -1, -1), prior.t_tex_idx, None)
-        self.last.update(prior=prior, shape=shape, posed_bones=aux["posed_bones"], deformation=deformation)
+        self.last.update(prior=prior, shape=shape, skinning_aux=aux, deformation=deformation)  # (aux["posed_bones"]: on first read, like the reference's consumers)
         if not self.render and with_nets:
             self.last.pop("rast", None)
             self.last.pop("points", None)
@@ -408,10 +408,17 @@ class SyntheticScene(torch.nn.Module):
                     leaf.grad = None
             out["loss"].backward()
             if optimizer_step:
+                _lib_poll_deferred()  # a device-side check that failed in this step (empty leg quadrant) stops it BEFORE the weights move
                 self.optimizer.step()
         if render_mod.ALLOCATOR_TRIM_MODE == "step_end":  # the allocator valve, between two steps instead of inside a forward (render.py)
             render_mod.allocator_trim_at_step_end(self.dev)
         return out
+
+
+def _lib_poll_deferred():
+    from . import _lib
+
+    _lib.poll_deferred()
 
 
 def prior_normal_regulariser(prior):

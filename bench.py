@@ -88,7 +88,7 @@ def pmc_traffic(signature=PMC_WORKLOAD):
 # what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
 # (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
 IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
-            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_")
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_")
 F3 = ("a3d_recon_losses_",)
 
 
@@ -109,7 +109,8 @@ def algorithmic_bytes(name, d):
     if "+C" in name:  # two buffers in one call of the compositor: [C17+C4] = the sum of the single-buffer figures
         base, tags = name.split("[")[0], name.split("[")[1].rstrip("]").split("+")
         return sum(algorithmic_bytes(f"{base}[{t}]", d) for t in tags)
-    C = int(name.split("[C")[1].split("]")[0]) if "[C" in name else 0
+    Ck = name.split("[C")[1].split("]")[0] if "[C" in name else "0"
+    C, Cout = (int(Ck.split(">")[0]), int(Ck.split(">")[1])) if ">" in Ck else (int(Ck), int(Ck))  # [C17>16]: 17 composited channels, 16 materialised
     if name.startswith("a3d_normals_fwd_pair["):  # two vertex arrays in one launch, e.g. [B16+B1]: the index data once, the per-image bytes for all
         Bn = sum(int(t.lstrip("B")) for t in name.split("[")[1].rstrip("]").split("+"))
         return 4 * V + 24 * F + Bn * (36 * F + 24 * V)
@@ -164,7 +165,7 @@ def algorithmic_bytes(name, d):
         "a3d_cover_gbuffer_fwd": 16 * 256 * int(d.get("cover_blocks", B * HW // 256)) + 4 * (B * HW // 256) + 8 * P + 4 * B * HW + 48 * P,
         # resolve + list + rows in one launch: texels out (16 B/pixel), list + pixel -> entry map + rows out; the 8-byte keys it consumes
         # and re-arms are staging (not credited), the texels are not read back at all
-        "a3d_rast_resolve_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P,
+        "a3d_rast_resolve_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P + 20 * Pp,  # (round 6: + the fields' input rows and image index, 12 + 8 B per padded point)
         "a3d_rast_resolve": 16 * B * HW,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
@@ -179,13 +180,19 @@ def algorithmic_bytes(name, d):
         "a3d_cover_emit": 4 * B * HW + 8 * P + 4 * B * HW,  # id channel in; list + pixel -> entry map out
         # C = channels of the composited image (values + alpha): point rows in, image out (+ the crossing pixels); backward: image
         # gradient read at the covered pixels, point-row gradient out, vertex gradient out
-        "a3d_composite_aa_fwd": 4 * B * HW + 4 * P * max(C - 1, 0) + 4 * C * B * HW,
+        "a3d_composite_aa_fwd": 4 * B * HW + 4 * P * max(C - 1, 0) + 4 * Cout * B * HW,
         "a3d_composite_aa_bwd": 8 * P + 8 * P * max(C - 1, 0) + 16 * B * V,
         # texture-less render: raster texels in, image out; backward: the silhouette records' share of the image gradient in, vertex gradient out
         "a3d_mask_aa_fwd": 16 * B * HW + 4 * C * B * HW,
         "a3d_mask_aa_bwd": 32 * B * V,
         "a3d_shade_fwd": P * (48 + 8 + 12 + 12 + 4 + 12),  # G-buffer row, image index, kd in; normal, shading, shaded out (camera/light rows: 1 KB table)
         "a3d_shade_bwd": P * (48 + 8 + 12 + 28 + 48 + 12),  # + the three incoming gradients; G-buffer and kd gradients out
+        # the adjoint inside the compositor's backward node: colour gradient, G-buffer row, list entry, kd in; G-buffer gradient and the
+        # texture field's 9-column output gradient (padded rows) out
+        "a3d_shade_bwd_rows": P * (12 + 48 + 8 + 12 + 48) + 36 * Pp,
+        "a3d_xfm_points_fwd": B * V * (12 + 16) + 64 * B,
+        "a3d_xfm_points_bwd": B * V * (16 + 12 + 12) + 128 * B,
+        "a3d_dmtet_gather_rows": 0,  # (a few thousand rows: latency only; credited nothing)
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,
         "a3d_bone_transforms_bwd": B * K * (12 + 48 + 12) + 24 * K,
         "a3d_aa_topology": 12 * F + 12 * F,
@@ -488,6 +495,8 @@ def main():
     ap.add_argument("--no-render", action="store_true", help="ponymation only: the step config/train_ponymation_horse_stage2.yaml really runs (enable_render "
                     "false; combine with --batch 20 --frames 10): DMTet + instance deformation + [B,F] LBS + the make_mesh passes on B x F meshes + backward, "
                     "no rasteriser")
+    ap.add_argument("--no-attribution", action="store_true", help="skip the launch attribution (tools/glue_attribution.py: every GPU kernel of 3 steps "
+                    "attributed to the code that launched it -- the path's entry points, the torch kernels its own modules launch, networks, ...)")
     ap.add_argument("--no-deform", action="store_true", help="magicpony without the instance deformation (the round-1 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (parity and cpu_baseline = null)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass (roofline = null); for PMC runs")
@@ -634,6 +643,18 @@ def main():
                                         "3.07e5 covered pixels")
         del sp
 
+    # ---- who launched what (round 6): in_scope_us_per_step above sums the C-ABI entry points only; the torch kernels the path's own
+    # modules launch (copies, slices and their padded gradients, accumulations) belong to the path too.  torch.profiler, 3 steps.
+    attribution = None
+    if rank == 0 and world == 1 and not args.no_attribution and not args.no_kernel_timing:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import glue_attribution
+
+            attribution = glue_attribution.profile_steps(lambda: scene.step(backward=train), 3)
+        except Exception as e:  # (a profiler that cannot start must not cost the line)
+            attribution = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+
     fingerprint = None
     if rank == 0 and not args.no_fingerprint:
         fingerprint = box_fingerprint(L, dev, (lambda: scene.step(module=module, backward=train)) if world == 1 else None, elapsed / args.steps * 1e3)
@@ -746,10 +767,16 @@ def main():
             "in_scope_frac": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["frac"],
             "in_scope_frac_bytes_weighted": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["frac_bytes_weighted"],
             "in_scope_calls_per_step": None if not roofline or not roofline.get("in_scope") else roofline["in_scope"]["entry_point_calls_per_step"],
+            # (round 6) the path's GPU time as the profiler attributes it: kernels of the in-scope entry points + the torch kernels launched
+            # from inside the path's own modules (model/geometry, model/render, ops.py) -- THE figure to compare across rounds from now on
+            # (first honest value, same step before the glue was removed: 212 + 380 = 591 us, profiles/r06_glue_before.json)
+            "in_scope_glue_us_per_step": None if not attribution or "error" in attribution else attribution["in_scope_glue_us_per_step"],
+            "in_scope_total_us_per_step": None if not attribution or "error" in attribution else attribution["in_scope_total_us_per_step"],
             "dropin_images_per_s": None if dropin is None else dropin["value"],
             "parity_pass": None if parity is None else bool(parity.get("pass")),
             "box": fingerprint,
             "roofline": roofline,
+            "attribution": attribution,
             "host_syncs": host_syncs,
             "parity": parity,
             "dropin": dropin,

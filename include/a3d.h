@@ -150,6 +150,10 @@ int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edg
  * again: a caller that hands the same vertex_scratch to the next count on the same stream passes vertex_scratch_is_clean = 1 and
  * saves its memset.  Replaces a mask + torch.nonzero and its own host synchronisation. */
 size_t a3d_dmtet_vertex_scratch_bytes(int Nv);
+/* (403) ... and the rows of that list gathered into a zero-padded block: out[rows,C] = src[idx[i],:] for i < n, zeros behind (the grid
+ * positions the field is re-evaluated at, forward; the SDF gradient at those vertices, backward -- dmtet.py:228-250 evaluates the field
+ * on every grid vertex with a graph; see DMTetGeometry._get_mesh_surface_backward). */
+int a3d_dmtet_gather_rows(const float* src, const int64_t* idx, int64_t n, int64_t rows, int C, float* out, a3d_stream_t stream);
 int a3d_dmtet_bwd(const float* g_verts, const float* pos, const float* sdf, const int32_t* edges, const int32_t* vert_edge,
                   int V, int Nv, float* g_pos_or_null, float* g_sdf, int g_sdf_is_clear,
                   a3d_stream_t stream); /* (g_sdf_to_clear of a3d_dmtet_emit + g_sdf_is_clear = 1: the emit launch cleared the buffer) */
@@ -558,7 +562,8 @@ typedef struct a3d_ca_buffer {
     int32_t g_stride;    /* backward: floats between two pixels of g_out (default C+1) */
     int32_t g_channels;  /* backward: leading channels of the image that HAVE a gradient in g_out (default C+1; the rest: zero) -- render_mesh
                           * returns dino_pred / flow without their alpha channel (render.py:320-331), so their gradient comes without it */
-    int32_t reserved2;
+    int32_t out_channels;/* forward: leading channels of the composited image that are MATERIALISED: out is [B,H,W,out_channels] (default C+1).
+                          * A mode whose alpha channel the caller cuts off anyway (dino_pred, flow: render.py:326-331) is written without it. */
     int64_t vals_rows;   /* backward: rows of g_vals to write (default P; >= P: the rows past P -- padding rows of a field's point list -- zero) */
 } a3d_ca_buffer;
 int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int32_t* inv, void* work, int32_t* count,
