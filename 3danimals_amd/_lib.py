@@ -58,6 +58,7 @@ SIGNATURES = {
     "a3d_rast_resolve_gbuffer_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, ctypes.c_int64, _p, _p, _p, _p, _p,
                                               _c_int, _p, _p, _c_int, _p, _p, _p, _p]),
     "a3d_rast_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p]),
+    "a3d_dispatch_order_probe": (_c_int, [_c_int, _c_int, _p, _p]),
     "a3d_rast_bwd": (_c_int, [_p, _p, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_fwd": (_c_int, [_p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_interp_bwd": (_c_int, [_p, _p, _c_int, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),

@@ -798,6 +798,32 @@ resolve_events = dict(fused=0, outgrown=0, standalone=0)
 _debug_force_lookback_timeout = False  # tests: take the recovery path of a timed-out look-back
 
 
+_dispatch_probe = {}  # device -> dict(ok, workgroups, stride, ms): the look-back's dispatch-order property as probed on that device
+
+
+def dispatch_order_ok(device, n_workgroups=16384, stride=64):
+    """Probe (once per device and process) that work-groups are dispatched in the order of their linear index -- what the fused resolve's
+    look-back rests on (a3d_dispatch_order_probe) -- and remember the answer; rasterize defers its resolve only where it holds."""
+    key = torch.device(device)
+    hit = _dispatch_probe.get(key)
+    if hit is None:
+        import time
+
+        with torch.cuda.device(key):
+            scratch = torch.empty(n_workgroups + 1, dtype=torch.int32, device=key)
+            torch.cuda.synchronize(key)
+            t0 = time.perf_counter()
+            call("a3d_dispatch_order_probe", n_workgroups, stride, ptr(scratch), stream())
+            status = int(scratch[n_workgroups].item())
+            ms = (time.perf_counter() - t0) * 1e3
+        hit = _dispatch_probe[key] = dict(ok=status == 2, status=status, workgroups=n_workgroups, stride=stride, ms=round(ms, 3))
+        if not hit["ok"]:
+            import warnings
+
+            warnings.warn(f"a3d_dispatch_order_probe on {key}: status {status} (2 = in order): the rasteriser's resolve will not be deferred on this device")
+    return hit["ok"]
+
+
 def ensure_resolved(rast):
     """Run the stand-alone resolve launch now if ``rast`` came out of rasterize(defer_resolve=True) and nothing has resolved it yet."""
     pend = _pending_resolve.take(rast)
@@ -897,6 +923,7 @@ class _Rasterize(torch.autograd.Function):
         if bins is not None:
             opts.bins, opts.bin_cap, opts.bins_clean = ptr(bins[0]), bins[1], int(bins[2])
         defer = bool(defer) and DEFER_RESOLVE and cover is not None and bins is None and prev is None and F > 0
+        defer = defer and not torch.cuda.is_current_stream_capturing() and dispatch_order_ok(clip.device)  # (probed once per device)
         opts.defer_resolve = int(defer)
         call("a3d_rast_fwd", ptr(clip), clip.shape[0], ptr(tri32), B, V, F, H, W, ptr(rast), ptr(scratch), int(clean), ctypes.addressof(opts), stream(),
              tag=("" if job is None else f"[N{opts.normals_B_a}+{opts.normals_B_b}]") + ("[defer]" if defer else ""))

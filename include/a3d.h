@@ -377,6 +377,11 @@ int a3d_rast_resolve_gbuffer_fwd(const float* clip, int clip_batch, const int32_
                                  a3d_stream_t stream);
 int a3d_rast_fwd(const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                  void* scratch, int scratch_is_clean, const a3d_rast_opts* opts_or_null, a3d_stream_t stream);
+/* (403) Probe of the property a3d_rast_resolve_gbuffer_fwd's look-back rests on -- work-groups are dispatched in the order of their
+ * linear index -- on this box: n_workgroups work-groups, each waiting (seat held, the resolve's own spin budget) for the flag of the one
+ * `stride` before it.  scratch[n_workgroups + 1] ints (cleared by the callee); afterwards scratch[n_workgroups] == 2 <=> every wait
+ * ended and the last work-group ran (bit 0 set: a wait timed out -- do not defer the resolve on this device). */
+int a3d_dispatch_order_probe(int n_workgroups, int stride, int32_t* scratch, a3d_stream_t stream);
 int a3d_rast_bwd(const float* g_rast, const float* rast, const float* clip, int clip_batch, const int32_t* tri, int B, int V,
                  int F, int H, int W, float* g_clip, a3d_stream_t stream);
 

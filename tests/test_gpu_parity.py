@@ -1108,8 +1108,10 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     e2e = workload == "magicpony" and kw == dict(deform=True)
     rep = check.compare_step(scene, out, n_images=4 if e2e else n, end_to_end=e2e)
     if e2e:
-        assert rep["frac_pixels_owner_flip"] < 1e-3 and rep["frac_pixels_gt_1e-4_end_to_end"] < 2e-3, (rep["frac_pixels_owner_flip"], rep["end_to_end"])
-        assert rep["max_abs_image_err_end_to_end"] < 5e-2, rep["end_to_end"]  # (a flipped silhouette decision moves a pixel by a colour contrast: section 2)
+        # north_star's bar, literally, on the oracle's OWN chain too (round 6; measured 5.2e-5 / 0 pixels / 7.6e-6 of the frame): every
+        # rendered buffer within 1e-4 on the pixels both chains give to the same triangle, and those are all but 1e-4 of the frame
+        assert rep["frac_pixels_owner_flip"] < 1e-4, (rep["frac_pixels_owner_flip"], rep["end_to_end"])
+        assert rep["max_abs_image_err_end_to_end"] <= 1e-4 and rep["frac_pixels_gt_1e-4_end_to_end"] == 0.0, rep["end_to_end"]
     assert rep["faces_equal"] and rep["num_faces"] > 8000, rep
     assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 5e-6, rep
     # vertex normals: within 2e-5 of the float32 oracle, or -- on the BCC surface, whose sliver triangles make some sums ill-conditioned
@@ -2412,6 +2414,30 @@ def test_bench_two_ranks_on_one_gpu_through_both_command_shapes(launcher):
     assert set(legs) == {"per_rank_poses", "fauna"} and all(v["value"] > 0 and len(v["ms_per_step_per_rank"]) == 2 for v in legs.values())
     assert len(set(legs["per_rank_poses"]["covered_pixels_per_rank"])) == 2 and min(legs["fauna"]["covered_pixels_per_rank"]) > 0
     assert legs["fauna"]["workload"] == "fauna" and len(line["ms_per_step_per_rank"]) == 2 and line["dmtet_pass"] in ("plain", "culled", "ordered")
+
+
+def test_bench_eight_ranks_on_one_gpu_report_their_host_side_figures():
+    """Multi-GPU readiness without the node: bench.py --gpus 8, eight processes on cuda:0, DDP over gloo -- the launch the
+    driver uses at N = 8, with the only scaling risk SURVEY 8e names (eight Python processes issuing their launches and stalling at their
+    read-backs side by side) exercised for real.  The line carries per-rank step times and, per rank, the blocking host synchronisations
+    of a step and the GPU time of its own kernels against its wall time."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", "--steps", "3", "--warmup", "1", "--grid-res", "32",
+           "--resolution", "128", "--batch", "2", "--no-cpu-baseline", "--no-tuned-gemms", "--no-extra-legs", "--no-fingerprint"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["backend"] == "gloo" and line["value"] > 0 and line["config"]["global_batch"] == 16
+    assert len(line["ms_per_step_per_rank"]) == 8 and len(line["covered_pixels_per_rank"]) == 8 and min(line["covered_pixels_per_rank"]) > 0
+    diag = line["rank_diagnostics"]["per_rank"]
+    assert sorted(d["rank"] for d in diag) == list(range(8))
+    # the magicpony step reads back twice (DMTet counts, covered-pixel sums) on every rank, wherever it runs
+    assert all(2 <= d["host_syncs_per_step"] <= 4 and d["own_kernels_ms_per_step"] > 0 and 0.0 <= d["host_bound_frac"] <= 1.0 for d in diag), diag
+    assert "no N > 1 RCCL scaling curve" in line["scaling_curve_note"]
 
 
 def test_render_uv_bake_and_material_export(tmp_path, dev, mods):

@@ -30,7 +30,8 @@ KERNELS = {
     "dm_bwd": ("dmtet", 4, {5: "whole kernel"}),
     "sk_fwd": ("skin", 0, {1: "links + bones into LDS", 2: "chain products", 3: "logits of the first group + barrier", 5: "softmax, blend, store"}),
     "sk_bwd": ("skin", 1, {1: "stage + weights + g_v (phase 1)", 2: "matrix phase", 3: "tiles to LDS + barrier", 4: "share of g_T + barrier", 5: "chain adjoint + atomics"}),
-    "rs_tri": ("raster", 0, {1: "set-up: indices, vertices, box, prefix (-> barrier)", 2: "pooled fragment tests + atomics", 5: "barrier (big boxes listed)"}),
+    "rs_tri": ("raster", 0, {1: "set-up: indices, vertices, box, prefix (-> barrier)", 2: "pooled fragment tests + atomics", 3: "barrier (big boxes listed)",
+                             5: "tile stage of the big boxes"}),
     "rs_resolve": ("raster", 1, {5: "whole kernel"}),
     "rs_resolve_cover": ("raster", 3, {1: "keys, count published, winner's gathers, texel, look-up of the earlier counts", 5: "list entry + G-buffer row (uncovered: -1)"}),
     "gb_cover_fwd": ("gbuffer", 0, {1: "texel + block offset (-> barrier)", 5: "row: 3 gathers x 3 arrays, stores (uncovered: -1)"}),
@@ -78,7 +79,8 @@ def report(name, st, labels):
         print(f"    {labels[k]:62s} median {d[len(d) // 2]:6.2f}  p90 {d[len(d) * 9 // 10]:6.2f}  max {d[-1]:6.2f} us   ({have.sum()} work-groups)")
         prev = k
     life = np.sort((s[:, :6].max(axis=1) - s[:, 0]) * 0.01)
-    print(f"    {'work-group lifetime (first -> last stamp)':62s} median {life[len(life) // 2]:6.2f}  p90 {life[len(life) * 9 // 10]:6.2f}  max {life[-1]:6.2f} us")
+    print(f"    {'work-group lifetime (first -> last stamp)':62s} median {life[len(life) // 2]:6.2f}  p90 {life[len(life) * 9 // 10]:6.2f}  p99 {life[len(life) * 99 // 100]:6.2f}  max {life[-1]:6.2f} us"
+          f"   (sum over work-groups {life.sum():.0f} us)")
 
 
 def main():
@@ -88,6 +90,7 @@ def main():
     ap.add_argument("--grid", default=None)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--workload", default="magicpony")
+    ap.add_argument("--mesh", default="quadruped", choices=("quadruped", "spiky"))
     ap.add_argument("--steps", type=int, default=25, help="warm-up steps before the stamped ones (bench.py's default warm-up + steps)")
     args = ap.parse_args()
     if not os.path.exists(PROF):
@@ -97,7 +100,7 @@ def main():
     handle = _lib.lib()
     dev = torch.device("cuda:0")
     scene = pipeline.SyntheticScene(grid_res=args.grid_res, batch=args.batch, resolution=(256, 256), device=dev, seed=0, workload=args.workload,
-                                    deform=args.workload == "magicpony", grid=args.grid)
+                                    deform=args.workload == "magicpony", grid=args.grid, mesh=args.mesh)
     for _ in range(args.steps):
         scene.step(backward=True, optimizer_step=True)
     torch.cuda.synchronize()
