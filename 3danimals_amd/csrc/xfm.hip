@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void xf_fwd_kernel(const float* __restrict__ p
 __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g, int g_stride, const float* __restrict__ points, int points_batch,
                                                      const float* __restrict__ M, int m_batch, int V, float* __restrict__ g_points,
                                                      float* __restrict__ g_M) {
-    __shared__ float s_red[4][16];
+    __shared__ float s_red[16][17];
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     const bool live = v < V;
     float gm[16];
@@ -52,14 +52,23 @@ __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g
         }
     }
     if (!g_M) return;
+    // 16 sums over the work-group: 16-lane DPP rows first (four register moves per value, no LDS traffic), the 16 rows meet in LDS
+    // (a full-wave butterfly through ds_bpermute -- 16 values x 6 steps -- was most of this kernel's 5.6 us)
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) gm[k] = a3d_wave_sum(gm[k]);
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s_red[threadIdx.x >> 6][k] = gm[k];
+    for (int k = 0; k < 16; ++k) {
+        float r = gm[k];
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x140, 0xF, 0xF, true));  // row_mirror
+        if ((lane & 15) == 0) s_red[row][k] = r;
+    }
     __syncthreads();
     if (threadIdx.x < 16) {
-        const float t = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += s_red[r][threadIdx.x];
         if (t != 0.f) atomicAdd(g_M + (m_batch == 1 ? 0 : 16 * b) + threadIdx.x, t);
     }
 }

@@ -259,7 +259,7 @@ def attribute_trace(trace, steps):
     return dict(steps=steps, us_per_step=per_step, in_scope_a3d_us_per_step=per_step.get("a3d_in_scope", 0.0), in_scope_glue_us_per_step=round(glue, 2),
                 in_scope_total_us_per_step=round(per_step.get("a3d_in_scope", 0.0) + glue, 2),
                 glue_launches_per_step=launches(("glue_fwd", "glue_bwd")), a3d_in_scope_launches_per_step=launches(("a3d_in_scope",)),
-                gpu_us_per_step=round(sum(totals.values()) / steps, 1), glue_top=top(("glue_fwd", "glue_bwd"), 80), f3_glue_top=top(("f3_glue",), 6),
+                gpu_us_per_step=round(sum(totals.values()) / steps, 1), a3d_top=top(("a3d_in_scope", "f3_losses"), 60), glue_top=top(("glue_fwd", "glue_bwd"), 80), f3_glue_top=top(("f3_glue",), 6),
                 other_top=top(("other", "consumer"), 8), gpu_events_without_launch_site=unplaced,
                 note="kernel durations from torch.profiler's trace (the same clock rocprofv3 reads); a kernel belongs to the innermost range around its "
                      "LAUNCH; engine-launched kernels follow their backward node's sequence number to the forward op that created it")
