@@ -468,4 +468,29 @@ extern "C" int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int3
     return A3D_OK;
 }
 
+// d/d canonical position of a SHARED canonical mesh: the sum over the images of columns 6..8 of the gradient rows (the backward
+// accumulates them per image: sixteen images' atomics on one row would serialise) -- a strided torch reduction of 7 us otherwise
+__global__ __launch_bounds__(256) void gb_prior_sum_kernel(const float* __restrict__ rows, int B, int V, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * V) return;
+    const int v = i / 3, c = i - 3 * v;
+    const float* p = rows + (long long)v * GB_ROW + 6 + c;
+    float s = 0.f;
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {  // (four rows in flight; ascending image order: the order torch's sum over dim 0 is NOT bound to, the result is a float sum either way)
+        const float a0 = p[(long long)b * V * GB_ROW], a1 = p[(long long)(b + 1) * V * GB_ROW], a2 = p[(long long)(b + 2) * V * GB_ROW],
+                    a3 = p[(long long)(b + 3) * V * GB_ROW];
+        s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < B; ++b) s += p[(long long)b * V * GB_ROW];
+    out[i] = s;
+}
+
+extern "C" int a3d_gbuffer_prior_grad(const float* g_rows, int B, int V, float* g_prior, a3d_stream_t stream) {
+    A3D_CHECK_ARG(g_rows && g_prior && B > 0 && V > 0 && (long long)3 * V < 0x7fffffffll);
+    hipLaunchKernelGGL(gb_prior_sum_kernel, dim3(a3d_div_up(3ll * V, 256)), dim3(256), 0, (hipStream_t)stream, g_rows, B, V, g_prior);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
 A3D_PROFILE_TU(gbuffer)

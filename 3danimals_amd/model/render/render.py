@@ -40,6 +40,7 @@ DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"  # ... and the r
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
 FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
 FUSED_SHADING = True
+ALIAS_POSITIONS = os.environ.get("A3D_ALIAS_POSITIONS", "1") != "0"  # the clip transform's node feeds the G-buffer's position attribute too (one accumulation launch less)
 FIELD_INPUTS_FROM_GBUFFER = os.environ.get("A3D_FIELD_INPUTS", "1") != "0"  # the fields' padded input rows + image index written by the G-buffer launch (round 6)
 SHADE_IN_COMPOSITOR = os.environ.get("A3D_SHADE_IN_COMPOSITOR", "1") != "0"  # no a3d_shade_fwd launch when only the composited colour reads its output  # shading normal + camera normal + directional light of the covered pixels in one HIP kernel (csrc/shade.hip)
 
@@ -357,7 +358,7 @@ FUSED_GBUFFER_MODES = frozenset(("shaded", "kd", "ks", "normal", "geo_normal", "
 
 
 def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat, render_modes=None, prior_mesh=None,
-                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None, clip=None, sparse=False):
+                 two_sided_shading=True, delta_xy=None, dino_net=None, class_vector=None, clip=None, sparse=False, v_pos_attr=None):
     """G-buffer interpolation + shading of one depth layer (reference render.py:139-221).
 
     ``clip`` (the [B,V,4] clip-space vertices, not in the reference signature) enables the fused path: one HIP kernel builds
@@ -380,7 +381,8 @@ def render_layer(rast, rast_deriv, mesh, w2c, view_pos, material, lgt, resolutio
         if FUSED_COVER_GBUFFER and PIXEL_TILE == 8 and h % 8 == 0 and w % 8 == 0:
             # the covered-pixel list and its G-buffer rows from ONE launch (one host sync before it: the number of covered pixels)
             # (... and what the fields take from it -- canonical positions as dense rows, point -> image index, padded -- from the same launch)
-            res = ops.covered_gbuffer(clip, mesh.v_pos, mesh.v_nrm, prior_mesh.v_pos, rast, tri, extra=delta_xy if flow_fused else None,
+            res = ops.covered_gbuffer(clip, mesh.v_pos if v_pos_attr is None else v_pos_attr, mesh.v_nrm, prior_mesh.v_pos, rast, tri,
+                                      extra=delta_xy if flow_fused else None,
                                       field_inputs=POINT_BUCKET if FIELD_INPUTS_FROM_GBUFFER else None)
             (gb, flow, pix, inv), rest = (res[:4], res[4:]) if flow_fused else ((res[0], None, res[1], res[2]), res[3:])
             tex_in, img_p = rest if rest else (None, None)
@@ -441,7 +443,14 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     view_pos = torch.tensor(view_pos, dtype=torch.float32, device=dev) if not torch.is_tensor(view_pos) else view_pos
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
 
-    v_pos_clip = ru.xfm_points(mesh.v_pos, mtx_in, use_python=True)  # [B,V,4]
+    v_pos_attr = None
+    if ALIAS_POSITIONS and spp == 1 and num_layers == 1 and mesh.v_pos.is_cuda and ru.ops._hip_xfm_ok(mesh.v_pos, mtx_in) and mesh.v_pos.shape[0] == mtx_in.shape[0] \
+            and not torch.is_autocast_enabled():
+        # the clip transform's node hands the positions out once more for the G-buffer's position attribute: their two gradients (through
+        # clip space, through the interpolated position) meet inside that node's ONE backward launch, not in an accumulation kernel
+        v_pos_clip, v_pos_attr = ops.xfm_points(mesh.v_pos, mtx_in, alias=True)  # [B,V,4]
+    else:
+        v_pos_clip = ru.xfm_points(mesh.v_pos, mtx_in, use_python=True)  # [B,V,4]
 
     delta_xy = None
     if "flow" in render_modes:  # 2-D motion of each vertex to the next frame (render.py:281-288)
@@ -480,7 +489,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     try:
         rendered = render_layer(rast, None, mesh, w2c, view_pos, material, lgt, resolution, spp, msaa, bsdf, feat=feat, render_modes=render_modes,
                                 prior_mesh=prior_mesh, two_sided_shading=two_sided_shading, delta_xy=delta_xy, dino_net=dino_net,
-                                class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True)
+                                class_vector=class_vector, clip=clip_f if FUSED_GBUFFER else None, sparse=True, v_pos_attr=v_pos_attr)
     except BaseException:
         if defer:  # the consumer the deferred resolve was promised failed: nothing may be left pending (keys pinned, texels unwritten)
             ops.drop_pending_resolve(rast)

@@ -682,7 +682,7 @@ class _XfmPoints(torch.autograd.Function):
     (csrc/xfm.hip) instead of pad + bmm (+ two bmm and a slice backward)."""
 
     @staticmethod
-    def forward(ctx, points, matrix):
+    def forward(ctx, points, matrix, alias=False):
         require_device(points, matrix, what="xfm_points")
         points, matrix = f32c(points), f32c(matrix)
         Bp, V, Bm = points.shape[0], points.shape[1], matrix.shape[0]
@@ -693,30 +693,45 @@ class _XfmPoints(torch.autograd.Function):
         call("a3d_xfm_points_fwd", ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(out), ptr(g_M), stream())
         ctx.save_for_backward(points, matrix)
         ctx.g_M = g_M
-        return out
+        ctx.set_materialize_grads(False)
+        # ``alias``: the points once more as a second output (no copy) for their OTHER consumer in render_mesh (the G-buffer's position
+        # attribute): both gradients then arrive at this node and are summed inside its one backward launch, instead of by an accumulation
+        # kernel of the autograd engine in front of it
+        return (out, points.detach()) if alias and Bp == B else (out, None)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias=None):
         points, matrix = ctx.saved_tensors
         Bp, V, Bm = points.shape[0], points.shape[1], matrix.shape[0]
         B = max(Bp, Bm)
+        if g is None:
+            if g_alias is None:
+                return None, None, None
+            g = torch.zeros((B, V, 4), dtype=torch.float32, device=points.device)
         # (the gradient may be the clip columns of the G-buffer's 16-float gradient rows: read in place, with its vertex stride)
         if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(1) < 4 or g.stride(0) != V * g.stride(1):
             g = f32c(g)
+        if g_alias is not None and (g_alias.dtype != torch.float32 or g_alias.stride(2) != 1 or g_alias.stride(1) < 3 or g_alias.stride(0) != V * g_alias.stride(1)):
+            g_alias = f32c(g_alias)
         g_p = torch.empty((B, V, 3), dtype=torch.float32, device=points.device) if ctx.needs_input_grad[0] else None
         g_M, ctx.g_M = ctx.g_M, None  # the cleared buffer serves ONE backward
         clear = g_M is not None
         if g_M is None and ctx.needs_input_grad[1]:
             g_M = torch.empty_like(matrix)
-        call("a3d_xfm_points_bwd", ptr(g), g.stride(1), ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(g_p), ptr(g_M), int(clear), stream())
+        if g_alias is not None and g_p is None:
+            g_p = torch.empty((B, V, 3), dtype=torch.float32, device=points.device)
+        call("a3d_xfm_points_bwd", ptr(g), g.stride(1), ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(g_p), ptr(g_M), int(clear), ptr(g_alias),
+             0 if g_alias is None else g_alias.stride(1), stream())
         if g_p is not None and Bp == 1 and B > 1:
             g_p = g_p.sum(0, keepdim=True)
-        return g_p, g_M
+        return g_p, g_M, None
 
 
-def xfm_points(points, matrix):
-    """points [1|B,V,3], matrix [1|B,4,4] -> [B,V,4] homogeneous clip-space positions."""
-    return _XfmPoints.apply(points, matrix)
+def xfm_points(points, matrix, alias=False):
+    """points [1|B,V,3], matrix [1|B,4,4] -> [B,V,4] homogeneous clip-space positions.  ``alias``: -> (clip, the points as a second output
+    of the same node or None): see _XfmPoints."""
+    out, again = _XfmPoints.apply(points, matrix, alias)
+    return (out, again) if alias else out
 
 
 # ---------------------------------------------------------------------------------------------- covered pixels
@@ -1198,9 +1213,11 @@ class _GBuffer(torch.autograd.Function):
         g_clip = rows[..., 12:16] if want_clip else None
         g_prior = None
         if want_prior:
-            g_prior = rows[..., 6:9]
-            if prior.shape[0] == 1:
-                g_prior = g_prior.sum(0, keepdim=True)
+            if prior.shape[0] == 1:  # shared canonical mesh: the per-image partials summed by one small launch
+                g_prior = torch.empty((1, V, 3), dtype=torch.float32, device=rast.device)
+                call("a3d_gbuffer_prior_grad", ptr(rows), B, V, ptr(g_prior), stream())
+            else:
+                g_prior = rows[..., 6:9]
         g_extra = rows[..., 9:9 + E] if (extra is not None and ctx.needs_input_grad[7]) else None
         return g_clip, g_vpos, g_vnrm, g_prior, None, None, None, g_extra, None
 

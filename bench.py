@@ -168,6 +168,7 @@ def algorithmic_bytes(name, d):
         "a3d_rast_resolve_gbuffer_fwd": 16 * B * HW + 8 * P + 4 * B * HW + 48 * P + 20 * Pp,  # (round 6: + the fields' input rows and image index, 12 + 8 B per padded point)
         "a3d_rast_resolve": 16 * B * HW,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
+        "a3d_gbuffer_prior_grad": 12 * B * V + 12 * V,
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums

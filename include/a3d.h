@@ -456,6 +456,9 @@ int a3d_gbuffer_bwd(const float* g_out, const float* rast, const int32_t* tri, c
                     const float* g_tex_or_null /* (403) [>= P,3]: the gradient of the canonical position as rows of its own (aux.tex_out's);
                                                   columns 9..11 of g_out are then ignored */,
                     a3d_stream_t stream);
+/* (403) g_prior[V,3] = the sum over the B images of columns 6..8 of g_rows: the gradient of a canonical mesh that all images share
+ * (prior_batch == 1; render.py:209 interpolates prior_mesh.v_pos for every image). */
+int a3d_gbuffer_prior_grad(const float* g_rows, int B, int V, float* g_prior, a3d_stream_t stream);
 /* The covered-pixel list AND its G-buffer rows in one launch (= a3d_cover_emit + a3d_gbuffer_fwd; render.py:139-221 on the covered
  * pixels): cover_scratch as for a3d_cover_emit (tile = 8: H, W multiples of 8), P = the list's length (sum of the group sums, read
  * back by the caller), pix[P] / inv[B*H*W] and out[P,12] (+ extra_out[P,E]) written together; every texel is read once. */
@@ -651,7 +654,11 @@ int a3d_flow_loss_bwd(const float* g_loss, const float* scale, const float* flow
 int a3d_xfm_points_fwd(const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V, float* out,
                        float* g_matrix_to_clear_or_null, a3d_stream_t stream);
 int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V,
-                       float* g_points_or_null, float* g_matrix_or_null, int g_matrix_is_clear, a3d_stream_t stream);
+                       float* g_points_or_null, float* g_matrix_or_null, int g_matrix_is_clear,
+                       const float* g_points_addend_or_null /* [B,V,3] with a vertex stride of addend_stride floats, added to g_points: the
+                                                               gradient the same points get from their other consumer in render_mesh (the
+                                                               position columns of a3d_gbuffer_bwd's rows) -- no accumulation launch */,
+                       int addend_stride, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }
