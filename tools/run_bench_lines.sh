@@ -1,6 +1,6 @@
 #!/bin/bash
 # every committed bench line of a round (run on the GPU box from the repo root):  bash tools/run_bench_lines.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 run() { name=$1; shift; python bench.py "$@" > gpurun_out/${TAG}_bench_${name}.json 2> gpurun_out/${TAG}_bench_${name}.err || (echo "$name FAILED"; tail -5 gpurun_out/${TAG}_bench_${name}.err); tail -c 300 gpurun_out/${TAG}_bench_${name}.json | head -c 0; echo "$name done"; }
 run default
