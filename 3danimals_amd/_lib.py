@@ -33,6 +33,7 @@ SIGNATURES = {
     "a3d_skin_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_float, _p, _p, _c_int, _p]),
     "a3d_bone_transforms_fwd": (_c_int, [_p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_bone_transforms_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_estimate_bones": (_c_int, [_p, _p]),
     "a3d_skin_pose_max_bones": (_c_int, []),
     "a3d_skin_pose_products_floats": (_c_size_t, [_c_int, _c_int]),
     "a3d_skin_pose_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_float, _p, _p, _p, _p, _p]),
@@ -137,7 +138,7 @@ class CaShade(ctypes.Structure):
     """a3d_ca_shade of include/a3d.h."""
 
     _fields_ = [("size", ctypes.c_uint32), ("kd_stride", ctypes.c_int32), ("gb", _p), ("par", _p), ("kd", _p), ("clear", _p),
-                ("n_clear", ctypes.c_int32), ("two_sided", ctypes.c_int32), ("params", _p)]
+                ("n_clear", ctypes.c_int32), ("two_sided", ctypes.c_int32), ("params", _p), ("shaded_out", _p)]
 
 
 class ShadeParams(ctypes.Structure):
@@ -145,6 +146,14 @@ class ShadeParams(ctypes.Structure):
 
     _fields_ = [("size", ctypes.c_uint32), ("rot_row_stride", ctypes.c_int32), ("rot", _p), ("view", _p), ("light", _p),
                 ("rot_image_stride", ctypes.c_int64), ("view_image_stride", ctypes.c_int64), ("light_image_stride", ctypes.c_int64)]
+
+
+class EstimateBonesArgs(ctypes.Structure):
+    """a3d_estimate_bones_args of include/a3d.h."""
+
+    _fields_ = [("size", ctypes.c_uint32), ("N", ctypes.c_int32), ("pos", _p), ("bones", _p), ("nearest", _p), ("ok", _p), ("V", ctypes.c_int32),
+                ("n_body", ctypes.c_int32), ("n_leg", ctypes.c_int32), ("body_mode_y_plus", ctypes.c_int32), ("use_y_threshold", ctypes.c_int32),
+                ("y_threshold", ctypes.c_float), ("attach", ctypes.c_int32 * 4), ("blend", ctypes.c_float * 17), ("ramp", ctypes.c_float * 9)]
 
 
 class GbAux(ctypes.Structure):

@@ -382,6 +382,7 @@ struct CaSrc {
     ShPar sh_par;         // the images' camera / light rows (a [B,17] table, or the caller's own tensors: a3d_shade_params)
     const float* sh_kd;   // [P,3], row stride sh_kd_stride
     int sh_kd_stride, sh_two_sided;
+    float* sh_out;        // compose launch only: [P,3] the colour it computed, kept for the blend launch and the backward (or null)
     const float* bg;    // [bg_batch, H, W, bgC] or null (zeros); channels bgC .. C read as 0
     int bg_shared;      // bg_batch == 1
     int bgC;
@@ -466,7 +467,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q >= 0) {
             if (s.vals) { const float* r = s.vals + 3ll * q; v = make_float4(r[0], r[1], r[2], 1.f); }
-            else if (s.sh_gb) { const float3 c3 = ca_shaded(s, q, p); v = make_float4(c3.x, c3.y, c3.z, 1.f); }
+            else if (s.sh_gb) {
+                const float3 c3 = ca_shaded(s, q, p);
+                v = make_float4(c3.x, c3.y, c3.z, 1.f);
+                if (s.sh_out) { float* so = s.sh_out + 3ll * q; so[0] = c3.x; so[1] = c3.y; so[2] = c3.z; }
+            }
             else v = make_float4(1.f, 1.f, 1.f, 1.f);
         }
         else if (s.bg) {
@@ -760,7 +765,7 @@ extern "C" int a3d_aa_bwd(const float* g_out, const float* color, int C, const v
 static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* bg, int bg_batch, int H, int W, float* out, const float* g_out,
                     float* g_vals, const a3d_ca_buffer* ext = nullptr, long long P = 0) {
     CaJob j;
-    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = ShPar{}; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0;
+    j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = ShPar{}; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0; j.s.sh_out = nullptr;
     j.s.sh_two_sided = 0; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
     j.s.bgC = (ext && ext->bg_channels > 0) ? ext->bg_channels : C + 1;
     j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0;
@@ -791,6 +796,7 @@ static int ca_shade(const a3d_ca_shade* sh, int C, const float* vals, CaJob* j, 
     A3D_CHECK_ARG(!forward || (j->oC == 4 && (((uintptr_t)j->out | (j->s.bgC == 4 ? (uintptr_t)j->s.bg : 0)) & 15) == 0));
     j->s.sh_gb = sh->gb; j->s.sh_par = sh->params ? sh_par_of(sh->params) : sh_par_table(sh->par, 17); j->s.sh_kd = sh->kd;
     j->s.sh_kd_stride = sh->kd_stride; j->s.sh_two_sided = sh->two_sided;
+    j->s.sh_out = forward ? sh->shaded_out : nullptr;
     if (forward) { j->clear = sh->clear; j->n_clear = sh->n_clear; }
     return A3D_OK;
 }
@@ -838,7 +844,11 @@ extern "C" int a3d_composite_aa_fwd(const a3d_ca_buffer* first, const a3d_ca_buf
     const unsigned nb_compose = (unsigned)a3d_div_up(n_pix, 256), rows = two ? 2u : 1u;
     hipLaunchKernelGGL(ca_compose_kernel, dim3(nb_compose + (nb_an + rows - 1) / rows, rows), dim3(256), 0, s, ja, jb, n_pix, nb_compose, an, a3d_exp() == 43 ? 0 : 1);
     A3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ca_blend_kernel, dim3(512, two ? 2 : 1), dim3(256), 0, s, ja, jb, (const AaRec*)work, count, capacity, W);
+    if (ja.s.sh_gb && ja.s.sh_out) {  // the colours the compose launch kept: the blends read them as plain value rows
+        ja.s.vals = ja.s.sh_out;
+        ja.s.sh_gb = nullptr;
+    }
+    hipLaunchKernelGGL(ca_blend_kernel, dim3(512, two ? 2 : 1), dim3(256), 0, s, ja, two ? jb : ja, (const AaRec*)work, count, capacity, W);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -15,6 +15,7 @@ kinematic chain composing 4x4 matrices one link at a time, then transforms a ful
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -75,6 +76,71 @@ def _masked_quantiles(x, mask, qs):
     return out
 
 
+DEVICE_ESTIMATE_BONES = os.environ.get("A3D_DEVICE_ESTIMATE_BONES", "1") != "0"  # estimate_bones as one HIP launch (a3d_estimate_bones); off: the torch restatement below
+
+
+def _body_chain(n_body_bones):
+    """(bones_to_joints, kinematic_chain) of the spine (reference :128-141)."""
+    half = n_body_bones // 2
+    bones_to_joints, kinematic_chain, bone = [], [], 0
+    below = []
+    for i in range(half):  # point_a -> mid
+        bones_to_joints.append((i + 1, i))
+        kinematic_chain.insert(0, (bone, below))
+        below = below + [bone]
+        bone += 1
+    below = []
+    for i in range(n_body_bones - 1, half - 1, -1):  # point_b -> mid
+        bones_to_joints.append((i, i + 1))
+        kinematic_chain.insert(0, (bone, below))
+        below = below + [bone]
+        bone += 1
+    return bones_to_joints, kinematic_chain
+
+
+def _estimate_bones_device(seq_shape, n_body_bones, n_leg_bones, body_bones_mode, compute_kinematic_chain, aux, attach_legs_to_body,
+                           legs_to_body_joint_indices, bone_y_threshold):
+    """estimate_bones through a3d_estimate_bones (csrc/bones.hip): ONE launch for the ~245 torch launches of the restatement below; the
+    kinematic chain -- a Python structure -- is built here from the two attachment joints the launch hands back (the one read-back of a
+    chain rebuild, as before; none with a cached chain).  None: a cached ``aux`` this form does not cover (the caller takes the torch path)."""
+    from ..._lib import defer_check, read_back
+
+    b2j_body, chain_body = _body_chain(n_body_bones)
+    leg_b2j = [(i + 1, i) for i in range(n_leg_bones)]
+    if compute_kinematic_chain:
+        given = list(legs_to_body_joint_indices) if legs_to_body_joint_indices is not None else [None] * 4
+        attach = [(-1 if given[0] is None else int(given[0])), (-1 if given[1] is None else int(given[1])), -1, -1]  # legs 2 / 3 reuse 1 / 0 (:213-216)
+    else:
+        if list(aux["bones_to_joints"]) != b2j_body or (n_leg_bones > 0 and any(list(l["leg_bones_to_joints"]) != leg_b2j for l in aux["legs"])):
+            return None
+        attach = [int(l["body_bone_idx"]) for l in aux["legs"]] if n_leg_bones > 0 else [0, 0, 0, 0]
+    bones, nearest, ok = ops.estimate_bones_device(seq_shape, n_body_bones, n_leg_bones, body_bones_mode == "z_minmax_y+", bone_y_threshold, attach)
+    if n_leg_bones > 0:
+        defer_check(ok[0], "estimate_bones: no vertex in a leg quadrant (the reference drops into pdb here, skinning.py:183)")
+    if not compute_kinematic_chain:
+        return bones
+    aux = {"bones_to_joints": b2j_body}
+    kinematic_chain = chain_body
+    if n_leg_bones > 0:
+        idx = [attach[0], attach[1]]
+        if attach[0] < 0 or attach[1] < 0:  # THE read-back of a chain rebuild (it also carries the quadrant flag deferred above)
+            got = read_back(nearest).tolist()
+            idx = [int(got[0]), int(got[1])]
+        if legs_to_body_joint_indices is None:
+            legs_to_body_joint_indices = [None, None, None, None]
+        leg_auxs, start = [], n_body_bones
+        for i in range(4):
+            body_bone_idx = idx[1] if i == 2 else (idx[0] if i == 3 else idx[i])
+            legs_to_body_joint_indices[i] = body_bone_idx  # written back into the caller's list, as the reference does (:220)
+            b2j, leg_chain, leg_ids = build_kinematic_chain(n_leg_bones, start_bone_idx=start)
+            kinematic_chain = update_body_kinematic_chain(kinematic_chain, leg_chain, body_bone_idx, leg_ids, attach_legs_to_body)
+            leg_auxs.append({"body_bone_idx": body_bone_idx, "leg_bones_to_joints": b2j})
+            start += n_leg_bones
+        aux["legs"] = leg_auxs
+    aux["kinematic_chain"] = kinematic_chain
+    return bones, kinematic_chain, aux
+
+
 # ------------------------------------------------------------------------------------------------ bone estimation
 @torch.no_grad()
 @fp32_region
@@ -91,6 +157,13 @@ def estimate_bones(seq_shape, n_body_bones, resample=False, n_legs=4, n_leg_bone
         b, _, n, _ = seq_shape.shape
         pts = util.sample_farthest_points(seq_shape.reshape(-1, n, 3).transpose(1, 2), n // 4)
         seq_shape = pts.transpose(1, 2).reshape(b, -1, n // 4, 3)
+
+    if (DEVICE_ESTIMATE_BONES and QUADRANT_POPULATION is None and body_bones_mode in ("z_minmax", "z_minmax_y+")
+            and ops.estimate_bones_device_ok(seq_shape, n_body_bones, n_leg_bones, n_legs)):
+        out = _estimate_bones_device(seq_shape, n_body_bones, n_leg_bones, body_bones_mode, compute_kinematic_chain, aux, attach_legs_to_body,
+                                     legs_to_body_joint_indices, bone_y_threshold)
+        if out is not None:
+            return out
 
     def pick(idx):
         return seq_shape.gather(2, idx[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)

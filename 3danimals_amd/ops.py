@@ -422,6 +422,48 @@ def bone_transforms(bones, angles, chain):
     return _BoneTransforms.apply(bones, angles, chain)
 
 
+_linspace_cache = {}
+
+
+def _linspace01(n):
+    """torch.linspace(0, 1, n) as Python floats (float32 values, computed once per n on the CPU: what the reference's tensors hold)."""
+    if n not in _linspace_cache:
+        _linspace_cache[n] = [float(v) for v in torch.linspace(0.0, 1.0, n, dtype=torch.float32)]
+    return _linspace_cache[n]
+
+
+def estimate_bones_device(seq_shape, n_body_bones, n_leg_bones, body_mode_y_plus, y_threshold, attach):
+    """a3d_estimate_bones: seq_shape [B,F,V,3] (float32, on the GPU) -> (bones [B,F,K,2,3], nearest int32 [2], ok int32 [1]) -- one launch,
+    no host synchronisation.  ``attach``: the four legs' body joints (negative = found on the device, see include/a3d.h); ``y_threshold``
+    None or Fauna's bone_y_threshold."""
+    require_device(seq_shape, what="estimate_bones")
+    pos = f32c(seq_shape)
+    B, Fr, V = pos.shape[:3]
+    K = n_body_bones + 4 * n_leg_bones
+    dev = pos.device
+    bones = torch.empty((B, Fr, K, 2, 3), dtype=torch.float32, device=dev)
+    nearest = torch.empty(2, dtype=torch.int32, device=dev)
+    ok = torch.empty(1, dtype=torch.int32, device=dev)
+    a = _lib.EstimateBonesArgs(size=ctypes.sizeof(_lib.EstimateBonesArgs), N=B * Fr, pos=ptr(pos), bones=ptr(bones), nearest=ptr(nearest), ok=ptr(ok), V=V,
+                               n_body=n_body_bones, n_leg=n_leg_bones, body_mode_y_plus=int(bool(body_mode_y_plus)),
+                               use_y_threshold=int(y_threshold is not None), y_threshold=float(y_threshold or 0.0))
+    for i, v in enumerate(attach):
+        a.attach[i] = int(v)
+    for i, v in enumerate(_linspace01(math.ceil((n_body_bones + 1) / 2))):
+        a.blend[i] = v
+    for i, v in enumerate(_linspace01(n_leg_bones + 1)):
+        a.ramp[i] = v
+    call("a3d_estimate_bones", ctypes.addressof(a), stream())
+    return bones, nearest, ok
+
+
+def estimate_bones_device_ok(seq_shape, n_body_bones, n_leg_bones, n_legs):
+    """Whether a3d_estimate_bones takes this call (else: the torch restatement)."""
+    return (seq_shape.is_cuda and seq_shape.dtype == torch.float32 and seq_shape.dim() == 4 and seq_shape.shape[3] == 3
+            and seq_shape.shape[0] * seq_shape.shape[1] <= 32 and seq_shape.shape[0] * seq_shape.shape[1] * seq_shape.shape[2] <= (1 << 22)
+            and seq_shape.shape[2] > 0 and n_body_bones % 2 == 0 and 2 <= n_body_bones <= 32 and 0 <= n_leg_bones <= 8 and (n_leg_bones == 0 or n_legs == 4))
+
+
 # ---------------------------------------------------------------------------------------------- skinning
 class _Skin(torch.autograd.Function):
     @staticmethod
@@ -1308,6 +1350,9 @@ def shade_points(gb, par, kd=None, two_sided=True, img=None):
     return _ShadePoints.apply(gb, par, kd, two_sided, img)
 
 
+KEEP_SHADED_COLOUR = os.environ.get("A3D_KEEP_SHADED", "1") != "0"  # the compositor keeps the colours it computes on the fly for its blend launch and its backward
+
+
 class ShadeRecipe:
     """The shaded colour of a fused render, NOT computed yet: what it is computed from.  Handed to shade_composite_antialias the colour of
     every covered pixel is computed inside the compositor's launches (a3d_ca_shade) and the whole backward -- compositor gather, shading
@@ -1561,8 +1606,11 @@ class _CompositeAntialias(torch.autograd.Function):
             if any(ctx.needs_input_grad[11:14]):
                 g_par = torch.empty(w2c.numel() + view.numel() + light.numel(), dtype=torch.float32, device=dev)
             par_struct = _shade_params(w2c, view, light)
+            # (the colours the compose launch computes are kept, 12 B per point: the blend launch and the backward read them as value rows)
+            shaded = torch.empty((P, 3), dtype=torch.float32, device=dev) if KEEP_SHADED_COLOUR else None
             sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=ptr(g_par),
-                              n_clear=0 if g_par is None else g_par.numel(), two_sided=int(two_sided), params=ctypes.addressof(par_struct))
+                              n_clear=0 if g_par is None else g_par.numel(), two_sided=int(two_sided), params=ctypes.addressof(par_struct),
+                              shaded_out=ptr(shaded))
         else:
             vals, bg, C, out = prep(vals, bg, keep)
         vals2, bg2, C2, out2 = prep(vals2, bg2, keep2)
@@ -1577,7 +1625,7 @@ class _CompositeAntialias(torch.autograd.Function):
              tag=tag + ("[+shade]" if shade else "") + ("[+analysis]" if ride is not None else ""))
         if ride is not None:
             a.pending = False  # (only now: the call above raises on a refused argument)
-        ctx.save_for_backward(vals, vals2, pix, inv, bg, bg2, gb, w2c, view, light, all_tex)
+        ctx.save_for_backward(shaded if shade else vals, vals2, pix, inv, bg, bg2, gb, w2c, view, light, all_tex)
         ctx.analysis, ctx.tag, ctx.g_par, ctx.two_sided, ctx.shade = a, tag, g_par, int(bool(two_sided)), shade
         ctx.set_materialize_grads(False)
         return out, out2
@@ -1605,12 +1653,13 @@ class _CompositeAntialias(torch.autograd.Function):
         par_struct = sh = None
         if shade:
             par_struct = _shade_params(w2c, view, light)
-            sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=None, n_clear=0,
-                              two_sided=ctx.two_sided, params=ctypes.addressof(par_struct))
+            if vals is None:  # (no kept colours: the backward's kernels re-derive them from the recipe)
+                sh = _lib.CaShade(size=ctypes.sizeof(_lib.CaShade), kd_stride=all_tex.stride(0), gb=ptr(gb), par=None, kd=ptr(all_tex), clear=None, n_clear=0,
+                                  two_sided=ctx.two_sided, params=ctypes.addressof(par_struct))
         buf = lambda v, c, g, go, gst, gch, gv, nrows: _lib.CaBuffer(size=ctypes.sizeof(_lib.CaBuffer), C=c, vals=ptr(v), bg=ptr(g), g_out=ptr(go), g_vals=ptr(gv),
                                                                      bg_batch=0 if g is None else g.shape[0], bg_channels=0 if g is None else g.shape[3],
                                                                      g_stride=gst, g_channels=gch, vals_rows=nrows)
-        first = buf(None if shade else vals, C, bg, g_out, gs, gc, g_vals, rows)
+        first = buf(vals, C, bg, g_out, gs, gc, g_vals, rows)  # (shade: ``vals`` = the colours the forward kept, or None)
         second = buf(vals2, C2, bg2, g_out2, gs2, gc2, g_vals2, vals2.shape[0]) if two else None
         call("a3d_composite_aa_bwd", ctypes.addressof(first), None if second is None else ctypes.addressof(second), ptr(pix), P, ptr(inv), ptr(a.work),
              ptr(a.count), a.capacity, ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip),

@@ -88,7 +88,7 @@ def pmc_traffic(signature=PMC_WORKLOAD):
 # what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
 # (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
 IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
-            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_")
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_", "a3d_estimate_bones")
 F3 = ("a3d_recon_losses_",)
 
 
@@ -169,6 +169,7 @@ def algorithmic_bytes(name, d):
         "a3d_rast_resolve": 16 * B * HW,
         "a3d_gbuffer_bwd": P * (8 + 16 + 48) + B * V * (36 + 16),
         "a3d_gbuffer_prior_grad": 12 * B * V + 12 * V,
+        "a3d_estimate_bones": 12 * V + 24 * K,  # the canonical mesh's vertices in (once: the passes over them hit the cache), the bones out
         "a3d_rows_segsum": 4 * Pp * C + 4 * B * C,  # P here = the padded point list the fields see
         "a3d_rows_add_relu_fwd": 8 * Pp * C,  # y read + written in place; rows[B,C] stay in L2
         "a3d_rows_add_relu_bwd": 12 * Pp * C + 4 * B * C,  # g, y in; g_pre out; per-image sums

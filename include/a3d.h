@@ -176,6 +176,35 @@ int a3d_skin_bwd(const float* g_out, const float* v, int v_batch, const float* b
  * The same pair exists for a3d_shade_fwd / _bwd (g_par) and a3d_gbuffer_fwd / _bwd (g_rows).) */
 
 /* ------------------------------------------------------------------------------------------------
+ * (403) estimate_bones on the device -- the heuristic skeleton of /root/reference/model/geometry/skinning.py:50-248 as ONE
+ * launch: pos[N,V,3] (N = B x F instances, <= 32) -> bones[N, n_body + 4 n_leg, 2, 3].  Spine: the extreme-z vertices (body_mode_y_plus:
+ * among those not far below the centroid, 'z_minmax_y+'), snapped to x = 0, joined through the lifted centroid; blend[ceil((n_body+1)/2)] =
+ * linspace(0, 1, .) of the caller.  Legs (n_leg > 0): the lowest vertex of each top-view quadrant -- margins from the 5 % / 95 % quantiles of
+ * x over ALL values of the call, or (use_y_threshold: Fauna) quadrants centred on the medians of x and z among the vertices below the
+ * y_threshold quantile of y -- joined to body joint attach[l] by n_leg bones, ramp[n_leg + 1] = linspace(0, 1, .).  attach[0], attach[1] < 0:
+ * found here (nearest body bone end in z, instance 0) and attach[2], attach[3] < 0: copies of attach[1], attach[0] (skinning.py:187-216).
+ * nearest[2] = the attachment joints of legs 0 / 1 as used (what the caller's kinematic chain needs: its ONE read-back), ok[1] = 0 when a
+ * quadrant held no vertex (the reference drops into pdb there, :183; the foot is then vertex 0). */
+typedef struct a3d_estimate_bones_args {
+    uint32_t size;
+    int32_t N;
+    const float* pos;
+    float* bones;
+    int32_t* nearest;
+    int32_t* ok;
+    int32_t V;
+    int32_t n_body;
+    int32_t n_leg;
+    int32_t body_mode_y_plus;
+    int32_t use_y_threshold;
+    float y_threshold;
+    int32_t attach[4];
+    float blend[17];
+    float ramp[9];
+} a3d_estimate_bones_args;
+int a3d_estimate_bones(const a3d_estimate_bones_args* args, a3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-bone world transforms from the kinematic chain -- replaces the chain-composition loops of skinning(),
  * /root/reference/model/geometry/skinning.py:389-417 (+ _estimate_bone_rotation :251-270, euler_angles_to_matrix :315-340,
  * _prepare/_invert_transform_mtx :343-366).  bones[bones_batch,K,2,3] (no gradient), angles[N,K,3] radians (Euler 'XYZ'),
@@ -552,6 +581,9 @@ typedef struct a3d_ca_shade {
     int32_t n_clear;
     int32_t two_sided;
     const a3d_shade_params* params; /* (403) non-NULL: the camera / light rows where the caller keeps them, `par` is ignored */
+    float* shaded_out;  /* (403) forward, optional [P,3]: the colour of every covered pixel as the compose launch computed it, kept (12 B per
+                         * point) so that the blend launch and the whole backward read it as plain value rows (first buffer's `vals`, no
+                         * `shade` struct) instead of re-deriving the shading per crossing record and channel */
 } a3d_ca_shade;
 /* One buffer of a compositor call (round 4: the two buffers of a call by name instead of ten / twelve positional arguments). */
 typedef struct a3d_ca_buffer {

@@ -2342,6 +2342,55 @@ def test_estimate_bones_on_device_matches_golden_without_host_sync(bone_y_thresh
     assert torch.allclose(bones_dev.cpu(), bones_cpu, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode,thr,shape", [("z_minmax_y+", None, (1, 1)), ("z_minmax_y+", 0.4, (1, 1)), ("z_minmax", None, (3, 2)), ("z_minmax_y+", 0.4, (2, 3)),
+                                            ("z_minmax_y+", None, (1, 1, 0))])
+def test_estimate_bones_kernel_equals_the_torch_restatement(mode, thr, shape, dev, mods, monkeypatch):
+    """a3d_estimate_bones (round 6: the whole heuristic skeleton as ONE launch of one work-group -- centroid, spine ends, quantiles by radix
+    select, the four feet, joints, bones) against the torch restatement it replaces (~245 launches; itself pinned by the reference's
+    goldens): bones within 1e-6, the same kinematic chain and attachment joints, chain rebuilt and chain cached, several instances at once
+    (the quantiles run over ALL values of the call, as the reference's tensor.quantile() does), with and without legs."""
+    sk = mods["skinning"]
+    _lib = importlib.import_module("3danimals_amd._lib")
+    n_leg = 0 if len(shape) == 3 else 3
+    B, Fr = shape[0], shape[1]
+    verts, _, _, _ = _scene(1, seed=5)
+    seq = (verts[None, None] + 0.02 * seeded((B, Fr, *verts.shape), 9, -1, 1)).to(dev)
+    kw = dict(n_body_bones=8, n_legs=4, n_leg_bones=n_leg, body_bones_mode=mode, bone_y_threshold=thr)
+
+    def run(device_kernel):
+        monkeypatch.setattr(sk, "DEVICE_ESTIMATE_BONES", device_kernel)
+        with _lib.KernelTimer() as timer:
+            bones, chain, aux = sk.estimate_bones(seq.clone(), compute_kinematic_chain=True, **kw)
+            again = sk.estimate_bones(seq.clone(), compute_kinematic_chain=False, aux=aux, **kw)
+        return bones, chain, aux, again, timer.summary()
+
+    b_k, chain_k, aux_k, again_k, calls_k = run(True)
+    b_t, chain_t, aux_t, again_t, calls_t = run(False)
+    assert calls_k.get("a3d_estimate_bones", (0,))[0] == 2 and "a3d_estimate_bones" not in calls_t
+    assert b_k.shape == b_t.shape == (B, Fr, 8 + 4 * n_leg, 2, 3)
+    assert float((b_k - b_t).abs().max()) <= 1e-6 and float((again_k - again_t).abs().max()) <= 1e-6 and float((again_k - b_k).abs().max()) == 0.0
+    assert repr(chain_k) == repr(chain_t) and aux_k["bones_to_joints"] == aux_t["bones_to_joints"]
+    if n_leg:
+        assert [l["body_bone_idx"] for l in aux_k["legs"]] == [l["body_bone_idx"] for l in aux_t["legs"]]
+    _lib.poll_deferred()  # (every quadrant holds a vertex: nothing pending raises)
+
+
+def test_estimate_bones_kernel_reports_an_empty_quadrant_through_the_deferred_check(dev, mods):
+    """A shape without a vertex in one leg quadrant: the kernel's ``ok`` word travels as a deferred check and raises the reference's message at
+    the next poll / read-back (the reference drops into pdb there, skinning.py:183)."""
+    sk = mods["skinning"]
+    _lib = importlib.import_module("3danimals_amd._lib")
+    verts, _, _, _ = _scene(1, seed=5)
+    v = verts.clone()
+    v[:, 0] = v[:, 0].abs() * 0.01 + 0.5  # everything on the +x side: the two -x quadrants are empty
+    _lib.poll_deferred()
+    bones = sk.estimate_bones(v[None, None].to(dev), n_body_bones=8, n_legs=4, n_leg_bones=3, body_bones_mode="z_minmax_y+",
+                              compute_kinematic_chain=True, legs_to_body_joint_indices=[2, 7, 7, 2])[0]
+    assert torch.isfinite(bones).all()
+    with pytest.raises(_lib.A3DError, match="no vertex in a leg quadrant"):
+        _lib.poll_deferred()
+
+
 @pytest.mark.parametrize("tag,kw", [("default", dict(attach_legs_to_body=True)), ("fauna", dict(attach_legs_to_body=True, bone_y_threshold=0.4)),
                                     ("fixed", dict(attach_legs_to_body=True, legs_to_body_joint_indices=[2, 7, 7, 2]))])
 def test_estimate_bones_on_device_against_reference_golden(tag, kw, dev, mods):

@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
-            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_")
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_", "a3d_estimate_bones")
 F3 = ("a3d_recon_losses_", "a3d_flow_loss_")
 
 PATH_FUNCTIONS = [  # (module under 3danimals_amd, attribute path)

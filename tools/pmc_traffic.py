@@ -48,6 +48,8 @@ ENTRY = {
     "a3d_shade_bwd": (["sh_bwd_kernel"], "sh_bwd_kernel"),
     # (round 6: the same kernel launched by the compositor's backward node, gradients written in the consumers' layouts)
     "a3d_shade_bwd_rows": (["sh_bwd_kernel"], "sh_bwd_kernel"),
+    "a3d_estimate_bones": (["eb_kernel"], "eb_kernel"),
+    "a3d_gbuffer_prior_grad": (["gb_prior_sum_kernel"], "gb_prior_sum_kernel"),
     "a3d_xfm_points_fwd": (["xf_fwd_kernel"], "xf_fwd_kernel"),
     "a3d_xfm_points_bwd": (["xf_bwd_kernel"], "xf_bwd_kernel"),
     "a3d_dmtet_gather_rows": (["dm_gather_rows_kernel"], "dm_gather_rows_kernel"),
