@@ -153,7 +153,7 @@ class EstimateBonesArgs(ctypes.Structure):
 
     _fields_ = [("size", ctypes.c_uint32), ("N", ctypes.c_int32), ("pos", _p), ("bones", _p), ("nearest", _p), ("ok", _p), ("V", ctypes.c_int32),
                 ("n_body", ctypes.c_int32), ("n_leg", ctypes.c_int32), ("body_mode_y_plus", ctypes.c_int32), ("use_y_threshold", ctypes.c_int32),
-                ("y_threshold", ctypes.c_float), ("attach", ctypes.c_int32 * 4), ("blend", ctypes.c_float * 17), ("ramp", ctypes.c_float * 9)]
+                ("y_threshold", ctypes.c_float), ("attach", ctypes.c_int32 * 4), ("blend", ctypes.c_float * 17), ("ramp", ctypes.c_float * 9), ("workspace", _p)]
 
 
 class GbAux(ctypes.Structure):

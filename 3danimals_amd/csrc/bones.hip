@@ -80,13 +80,15 @@ extern "C" int a3d_bone_transforms_bwd(const float* g_M, const float* bones, int
 //            the six quantiles of x and z among the vertices below it (the reference's xs[low].quantile(.), skinning.py:160-166)
 //   phase C  per instance and quadrant: the lowest vertex (arg-min of y among the quadrant's vertices; an empty quadrant -- where the
 //            reference drops into pdb, :183 -- yields vertex 0 and clears the ``ok`` flag: a deferred check of the caller)
-//   phase D  one thread per instance: spine joints, body bones, the attachment joints of legs 0 / 1 (instance 0, unless prescribed;
+//   phase D  one thread per bone end: spine joints, body bones, the attachment joints of legs 0 / 1 (instance 0, unless prescribed;
 //            handed out for the caller's kinematic chain), leg joints, leg bones.
 // Same operations as the torch restatement up to the summation order of the centroid (a float32 tree sum here): the goldens taken from the
 // reference itself hold to 1e-6 (tests/test_gpu_parity.py::test_estimate_bones_on_device_against_reference_golden).
 #define EB_THREADS 1024
 #define EB_MAXN 32
 #define EB_MAXSEL 12
+#define EB_MAXGROUP 6
+#define EB_COPIES 16
 
 __device__ __forceinline__ unsigned eb_key(float f) {  // monotone float -> uint
     const unsigned u = __float_as_uint(f);
@@ -96,24 +98,6 @@ __device__ __forceinline__ float eb_unkey(unsigned k) { return __uint_as_float((
 __device__ __forceinline__ float eb_lerp(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w); }  // torch.lerp
 
 struct EbArg { float v; int i; };
-// arg-max (MAX) / arg-min over the work-group, first index on ties; every thread gets the result
-template <bool MAX>
-__device__ __forceinline__ EbArg eb_block_arg(EbArg a, EbArg* s_w) {
-    auto better = [](const EbArg& x, const EbArg& y) { return MAX ? (x.v > y.v || (x.v == y.v && x.i < y.i)) : (x.v < y.v || (x.v == y.v && x.i < y.i)); };
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        EbArg b;
-        b.v = __shfl_xor(a.v, o, 64); b.i = __shfl_xor(a.i, o, 64);
-        if (better(b, a)) a = b;
-    }
-    __syncthreads();  // (s_w free)
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
-    __syncthreads();
-    EbArg r = s_w[0];
-    for (int w = 1; w < EB_THREADS / 64; ++w)
-        if (better(s_w[w], r)) r = s_w[w];
-    return r;
-}
 __device__ __forceinline__ float eb_block_sum(float v, float* s_f) {
     v = a3d_wave_sum(v);
     __syncthreads();
@@ -124,29 +108,96 @@ __device__ __forceinline__ float eb_block_sum(float v, float* s_f) {
     return t;
 }
 
-// the values of ranks s_rank[0..m) (0-based, ascending order) among f(0..total): radix select, all m targets in the same four passes
-template <class F>
-__device__ __forceinline__ void eb_multiselect(F f, int total, int m, int* s_rank, unsigned* s_prefix, int (*s_hist)[256]) {
+// the values of ranks s_rank[0..NG*mg) (0-based, ascending order): targets [g mg, (g+1) mg) among the values f(i, g), i in 0..total -- a
+// radix select, all targets in the same four passes over the data.  Targets whose prefixes agree so far (the two neighbours a quantile
+// interpolates between nearly always do, to the last pass) share one histogram: s_rep[t] = the first target of t's group with t's prefix.
+template <int NG, class F>
+__device__ __forceinline__ void eb_multiselect(F f, int total, int mg, int* s_rank, unsigned* s_prefix, int (*s_hist)[256], int (*s_h0)[256][EB_COPIES]) {
+    __shared__ int s_wtot[EB_THREADS / 64];
+    __shared__ int s_rep[EB_MAXSEL], s_urep[NG][EB_MAXGROUP], s_nu[NG];
+    __shared__ unsigned s_upre[NG][EB_MAXGROUP];
+    const int m = NG * mg;  // (mg <= EB_MAXGROUP)
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
+        if ((int)threadIdx.x < NG) {  // the distinct prefixes of a group and the targets that own their histograms (padded: no match)
+            const int g = threadIdx.x;
+            int nu = 0;
+            for (int t = g * mg; t < (g + 1) * mg; ++t) {
+                int rep = t;
+                for (int u = t - 1; u >= g * mg; --u)
+                    if (pass == 0 || s_prefix[u] == s_prefix[t]) rep = u;
+                s_rep[t] = rep;
+                if (rep == t) { s_upre[g][nu] = pass == 0 ? 0u : s_prefix[t]; s_urep[g][nu] = t; ++nu; }
+            }
+            s_nu[g] = nu;
+            for (; nu < EB_MAXGROUP; ++nu) { s_upre[g][nu] = 0xffffffffu; s_urep[g][nu] = g * mg; }
+        }
         for (int i = threadIdx.x; i < m * 256; i += EB_THREADS) s_hist[i >> 8][i & 255] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < total; i += EB_THREADS) {
-            const unsigned k = eb_key(f(i));
-            for (int t = 0; t < m; ++t)
-                if (pass == 0 || (k >> (shift + 8)) == s_prefix[t]) atomicAdd(&s_hist[t][(k >> shift) & 255u], 1);
+        if (pass == 0) {
+            // every target of a group sees the same histogram in the first pass, and the top byte of a float (sign + 7 exponent bits)
+            // takes a handful of values over a mesh: plain LDS atomics would serialise 64 lanes on one address (90 us of this kernel as
+            // first written).  EB_COPIES copies of the histogram, one per lane residue: four lanes per address at worst.
+            for (int i = threadIdx.x; i < NG * 256 * EB_COPIES; i += EB_THREADS) (&s_h0[0][0][0])[i] = 0;
+            __syncthreads();
+            const int copy = threadIdx.x & (EB_COPIES - 1);
+            for (int i = threadIdx.x; i < total; i += EB_THREADS) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) atomicAdd(&s_h0[g][eb_key(f(i, g)) >> 24][copy], 1);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < NG * 256; i += EB_THREADS) {
+                int c = 0;
+#pragma unroll
+                for (int k = 0; k < EB_COPIES; ++k) c += s_h0[i >> 8][i & 255][(k + i) & (EB_COPIES - 1)];  // (rotated: no bank conflicts)
+                s_hist[(i >> 8) * mg][i & 255] = c;
+            }
+        } else {
+            unsigned upre[NG][EB_MAXGROUP];
+            int urep[NG][EB_MAXGROUP], nu[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                nu[g] = __builtin_amdgcn_readfirstlane(s_nu[g]);
+#pragma unroll
+                for (int u = 0; u < EB_MAXGROUP; ++u) { upre[g][u] = s_upre[g][u]; urep[g][u] = s_urep[g][u]; }
+            }
+            for (int i = threadIdx.x; i < total; i += EB_THREADS) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const unsigned k = eb_key(f(i, g)), hi = k >> (shift + 8), digit = (k >> shift) & 255u;
+#pragma unroll
+                    for (int u = 0; u < EB_MAXGROUP; ++u) {
+                        if (u >= nu[g]) break;  // (uniform: usually one to three distinct prefixes)
+                        if (hi == upre[g][u]) atomicAdd(&s_hist[urep[g][u]][digit], 1);
+                    }
+                }
+            }
         }
         __syncthreads();
-        if ((int)threadIdx.x < m) {
-            const int t = threadIdx.x;
-            int r = s_rank[t], acc = 0, digit = 255;
-            for (int b = 0; b < 256; ++b) {
-                const int c = s_hist[t][b];
-                if (acc + c > r) { digit = b; break; }
-                acc += c;
+        // the bin that holds each target's rank: 256 threads per target (four targets at a time), an inclusive scan of the 256 counts
+        // through wave shuffles + the four wave totals -- ONE thread walking the 256 bins was 12 us per pass, 150 us of the kernel
+        for (int t0 = 0; t0 < m; t0 += EB_THREADS / 256) {  // (uniform trip count: the barriers inside are reached by every thread)
+            const int g = threadIdx.x >> 8, b = threadIdx.x & 255, t = t0 + g;
+            const bool live = t < m;
+            const int c = live ? s_hist[s_rep[t]][b] : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if ((threadIdx.x & 63) >= o) incl += up;
             }
-            s_rank[t] = r - acc;
-            s_prefix[t] = pass == 0 ? (unsigned)digit : ((s_prefix[t] << 8) | (unsigned)digit);
+            if ((threadIdx.x & 63) == 63) s_wtot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            int before = 0;
+            for (int w = g * 4; w < (int)(threadIdx.x >> 6); ++w) before += s_wtot[w];
+            incl += before;
+            const int r = live ? s_rank[t] : -1;
+            const unsigned pre = live ? s_prefix[t] : 0u;
+            __syncthreads();  // (every thread has read its target's rank, prefix and the wave totals)
+            if (live && r >= incl - c && r < incl) {  // exactly one bin per target
+                s_rank[t] = r - (incl - c);
+                s_prefix[t] = pass == 0 ? (unsigned)b : ((pre << 8) | (unsigned)b);
+            }
         }
         __syncthreads();
     }
@@ -161,46 +212,93 @@ struct EbParams {
     float* bones;      // [N, n_body + 4 n_leg, 2, 3]
     int* nearest;      // [2] the attachment joints of legs 0 / 1 as used
     int* ok;           // [1] 1 = every quadrant of every instance holds a vertex
+    float* work;       // [3 N V] scratch
 };
 
 __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
-    __shared__ EbArg s_w[EB_THREADS / 64];
-    __shared__ float s_f[EB_THREADS / 64];
+    __shared__ EbArg s_arg[EB_THREADS / 64][2], s_arg4[EB_THREADS / 64][4];
+    __shared__ float s_sum[EB_THREADS / 64][3];
     __shared__ float s_cent[EB_MAXN][3];
     __shared__ int s_ab[EB_MAXN][2], s_foot[EB_MAXN][4];
     __shared__ int s_rank[EB_MAXSEL];
     __shared__ unsigned s_prefix[EB_MAXSEL];
     __shared__ int s_hist[EB_MAXSEL][256];
+    __shared__ int s_h0[2][256][EB_COPIES];  // first-pass histograms, EB_COPIES copies each
     __shared__ float s_q[8];  // margins / centres of the quadrants
     __shared__ int s_ok;
     const int tid = threadIdx.x, N = a.N, V = a.V, total = N * V;
     const float* __restrict__ pos = a.pos;
-    if (tid == 0) s_ok = 1;
-    // ---- phase A
-    for (int n = 0; n < N; ++n) {
-        const float* p = pos + (long long)n * V * 3;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int v = tid; v < V; v += EB_THREADS) { sx += p[3 * v]; sy += p[3 * v + 1]; sz += p[3 * v + 2]; }
-        sx = eb_block_sum(sx, s_f); sy = eb_block_sum(sy, s_f); sz = eb_block_sum(sz, s_f);
-        const float cx = sx / (float)V, cy = sy / (float)V, cz = sz / (float)V;
-        if (tid == 0) { s_cent[n][0] = cx; s_cent[n][1] = cy; s_cent[n][2] = cz; }
-        EbArg hi = {-INFINITY, 0x7fffffff}, lo = {INFINITY, 0x7fffffff};
-        for (int v = tid; v < V; v += EB_THREADS) {
-            const float z = p[3 * v + 2];
-            float ka = z, kb = z;
-            if (a.yplus) {  // z * upper + (-+1e6) * (1 - upper)   (skinning.py:103-107)
-                const float up = p[3 * v + 1] > (cy - 0.5f) ? 1.f : 0.f;
-                ka = z * up + (-1e6f) * (1.f - up);
-                kb = z * up + 1e6f * (1.f - up);
-            }
-            if (ka > hi.v) { hi.v = ka; hi.i = v; }
-            if (kb < lo.v) { lo.v = kb; lo.i = v; }
+    float* ranked = a.work;         // [total]
+    float* lowxz = a.work + total;  // [<= total][2] Fauna: x, z of the vertices below the y threshold
+    __shared__ int s_nlow;
+    __shared__ float s_blend[17], s_ramp[9];
+    if (tid < 17) s_blend[tid] = a.blend[tid];
+    if (tid < 9) s_ramp[tid] = a.ramp[tid];
+    if (tid == 0) { s_ok = 1; s_nlow = 0; }
+    A3D_STAMP(0, 0);
+    // ---- phase A: the 16 waves spread over the instances (wpi waves each, ipr instances per round): the sums and arg-extrema of an
+    // instance meet in LDS, one exchange per reduction for all instances of the round
+    const int wave = tid >> 6, lane = tid & 63;
+    int wpi = EB_THREADS / 64;
+    while (wpi > 1 && (EB_THREADS / 64) / wpi < N) wpi >>= 1;
+    const int ipr = (EB_THREADS / 64) / wpi, sub = wave % wpi, w0 = wave - sub;
+    auto arg_better = [](bool want_max, const EbArg& x, const EbArg& y) {  // first index on ties, as torch.argmax / argmin
+        return want_max ? (x.v > y.v || (x.v == y.v && x.i < y.i)) : (x.v < y.v || (x.v == y.v && x.i < y.i));
+    };
+    auto wave_arg = [&](bool want_max, EbArg x) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            EbArg y;
+            y.v = __shfl_xor(x.v, o, 64); y.i = __shfl_xor(x.i, o, 64);
+            if (arg_better(want_max, y, x)) x = y;
         }
-        hi = eb_block_arg<true>(hi, s_w);
-        lo = eb_block_arg<false>(lo, s_w);
-        if (tid == 0) { s_ab[n][0] = hi.i < V ? hi.i : 0; s_ab[n][1] = lo.i < V ? lo.i : 0; }
+        return x;
+    };
+    for (int n0 = 0; n0 < N; n0 += ipr) {
+        const int n = n0 + wave / wpi;
+        const bool have = n < N;
+        const float* p = pos + (long long)(have ? n : 0) * V * 3;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        if (have)
+            for (int v = sub * 64 + lane; v < V; v += wpi * 64) {
+                const float x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
+                sx += x; sy += y; sz += z;
+                ranked[(long long)n * V + v] = a.fauna ? y : x;  // the coordinate phase B ranks first, planar: a third of the bytes per pass
+            }
+        sx = a3d_wave_sum(sx); sy = a3d_wave_sum(sy); sz = a3d_wave_sum(sz);
+        __syncthreads();  // (s_sum free)
+        if (lane == 0) { s_sum[wave][0] = sx; s_sum[wave][1] = sy; s_sum[wave][2] = sz; }
+        __syncthreads();
+        sx = sy = sz = 0.f;
+        for (int k = 0; k < wpi; ++k) { sx += s_sum[w0 + k][0]; sy += s_sum[w0 + k][1]; sz += s_sum[w0 + k][2]; }
+        const float cx = sx / (float)V, cy = sy / (float)V, cz = sz / (float)V;
+        if (have && sub == 0 && lane == 0) { s_cent[n][0] = cx; s_cent[n][1] = cy; s_cent[n][2] = cz; }
+        EbArg hi = {-INFINITY, 0x7fffffff}, lo = {INFINITY, 0x7fffffff};
+        if (have)
+            for (int v = sub * 64 + lane; v < V; v += wpi * 64) {
+                const float z = p[3 * v + 2];
+                float ka = z, kb = z;
+                if (a.yplus) {  // z * upper + (-+1e6) * (1 - upper)   (skinning.py:103-107)
+                    const float up = p[3 * v + 1] > (cy - 0.5f) ? 1.f : 0.f;
+                    ka = z * up + (-1e6f) * (1.f - up);
+                    kb = z * up + 1e6f * (1.f - up);
+                }
+                if (ka > hi.v) { hi.v = ka; hi.i = v; }
+                if (kb < lo.v) { lo.v = kb; lo.i = v; }
+            }
+        hi = wave_arg(true, hi); lo = wave_arg(false, lo);
+        if (lane == 0) { s_arg[wave][0] = hi; s_arg[wave][1] = lo; }  // (s_arg: not read since the previous round's barriers)
+        __syncthreads();
+        if (have && sub == 0 && lane == 0) {
+            for (int k = 1; k < wpi; ++k) {
+                if (arg_better(true, s_arg[w0 + k][0], hi)) hi = s_arg[w0 + k][0];
+                if (arg_better(false, s_arg[w0 + k][1], lo)) lo = s_arg[w0 + k][1];
+            }
+            s_ab[n][0] = hi.i < V ? hi.i : 0; s_ab[n][1] = lo.i < V ? lo.i : 0;
+        }
     }
     __syncthreads();
+    A3D_STAMP(0, 1);
     if (a.n_leg > 0) {
         // ---- phase B: quantiles over ALL values of the call
         auto ranks_of = [&](float q, int n, int slot, float* w_out) {  // pos = q (n - 1), float32 as torch.quantile computes it
@@ -212,7 +310,7 @@ __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
             float w95 = 0.f, w05 = 0.f;
             if (tid == 0) { ranks_of(0.95f, total, 0, &w95); ranks_of(0.05f, total, 2, &w05); s_q[6] = w95; s_q[7] = w05; }
             __syncthreads();
-            eb_multiselect([&](int i) { return pos[3ll * i]; }, total, 4, s_rank, s_prefix, s_hist);
+            eb_multiselect<1>([&](int i, int) { return ranked[i]; }, total, 4, s_rank, s_prefix, s_hist, s_h0);
             if (tid == 0) {
                 const float q95 = eb_lerp(eb_unkey(s_prefix[0]), eb_unkey(s_prefix[1]), s_q[6]);
                 const float q05 = eb_lerp(eb_unkey(s_prefix[2]), eb_unkey(s_prefix[3]), s_q[7]);
@@ -223,12 +321,22 @@ __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
             float w = 0.f;
             if (tid == 0) { ranks_of(a.y_q, total, 0, &w); s_q[6] = w; }
             __syncthreads();
-            eb_multiselect([&](int i) { return pos[3ll * i + 1]; }, total, 2, s_rank, s_prefix, s_hist);
+            eb_multiselect<1>([&](int i, int) { return ranked[i]; }, total, 2, s_rank, s_prefix, s_hist, s_h0);
             const float thr = eb_lerp(eb_unkey(s_prefix[0]), eb_unkey(s_prefix[1]), s_q[6]);
-            int cnt = 0;
-            for (int i = tid; i < total; i += EB_THREADS) cnt += pos[3ll * i + 1] < thr ? 1 : 0;
-            const int nlow = (int)(eb_block_sum((float)cnt, s_f) + 0.5f);  // (exact: counts below 2^24)
+            A3D_STAMP(0, 2);
+            // the low vertices' x and z, compacted (in any order: they are only ranked): the six quantiles read 8 bytes per LOW vertex
+            for (int base = 0; base < total; base += EB_THREADS) {
+                const int i = base + tid;
+                const bool low = i < total && ranked[i] < thr;
+                const unsigned long long lows = __ballot(low);
+                int at = 0;
+                if (lane == 0 && lows) at = atomicAdd(&s_nlow, __popcll(lows));
+                at = __shfl(at, 0, 64) + __popcll(lows & ((1ull << lane) - 1ull));
+                if (low) { lowxz[2ll * at] = pos[3ll * i]; lowxz[2ll * at + 1] = pos[3ll * i + 2]; }
+            }
             __syncthreads();
+            const int nlow = s_nlow;
+            if (nlow == 0 && tid == 0) s_ok = 0;  // (torch.quantile of an empty tensor raises in the reference)
             if (tid == 0) {
                 float w0, w1, w2;
                 ranks_of(0.5f, nlow, 0, &w0); ranks_of(0.95f, nlow, 2, &w1); ranks_of(0.05f, nlow, 4, &w2);
@@ -237,8 +345,7 @@ __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
             }
             __syncthreads();
             // x among the low vertices in slots 0..5, z in slots 6..11: one set of four passes for both
-            eb_multiselect([&](int i) { return pos[3ll * i + 1] < thr ? pos[3ll * i] : INFINITY; }, total, 6, s_rank, s_prefix, s_hist);
-            eb_multiselect([&](int i) { return pos[3ll * i + 1] < thr ? pos[3ll * i + 2] : INFINITY; }, total, 6, s_rank + 6, s_prefix + 6, s_hist + 6);
+            eb_multiselect<2>([&](int i, int g) { return lowxz[2ll * i + g]; }, nlow, 6, s_rank, s_prefix, s_hist, s_h0);
             if (tid == 0) {
                 float q[2][3];
                 for (int c = 0; c < 2; ++c)
@@ -248,110 +355,114 @@ __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
             }
             __syncthreads();
         }
-        // ---- phase C: the foot of every quadrant of every instance
-        for (int n = 0; n < N; ++n) {
-            const float* p = pos + (long long)n * V * 3;
+        A3D_STAMP(0, 3);
+        // ---- phase C: the foot of every quadrant of every instance (waves over instances, as phase A)
+        for (int n0 = 0; n0 < N; n0 += ipr) {
+            const int n = n0 + wave / wpi;
+            const bool have = n < N;
+            const float* p = pos + (long long)(have ? n : 0) * V * 3;
             EbArg best[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { best[k].v = INFINITY; best[k].i = 0x7fffffff; }
-            for (int v = tid; v < V; v += EB_THREADS) {
-                const float x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
-                bool in[4];
-                if (!a.fauna) {
-                    const float m = s_q[0];
-                    in[0] = x > m && z > 0.f; in[1] = x > m && z < 0.f; in[2] = x < -m && z < 0.f; in[3] = x < -m && z > 0.f;
-                } else {
-                    const float x0 = s_q[0], z0 = s_q[1], mx = s_q[2], mz = s_q[3];
-                    in[0] = (x - x0 > mx) && (z - z0 > mz); in[1] = (x - x0 > mx) && (z < z0);
-                    in[2] = (x - x0 < -mx) && (z < z0); in[3] = (x - x0 < -mx) && (z - z0 > mz);
-                }
+            if (have)
+                for (int v = sub * 64 + lane; v < V; v += wpi * 64) {
+                    const float x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
+                    bool in[4];
+                    if (!a.fauna) {
+                        const float m = s_q[0];
+                        in[0] = x > m && z > 0.f; in[1] = x > m && z < 0.f; in[2] = x < -m && z < 0.f; in[3] = x < -m && z > 0.f;
+                    } else {
+                        const float x0 = s_q[0], z0 = s_q[1], mx = s_q[2], mz = s_q[3];
+                        in[0] = (x - x0 > mx) && (z - z0 > mz); in[1] = (x - x0 > mx) && (z < z0);
+                        in[2] = (x - x0 < -mx) && (z < z0); in[3] = (x - x0 < -mx) && (z - z0 > mz);
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (in[k] && y < best[k].v) { best[k].v = y; best[k].i = v; }
-            }
+                    for (int k = 0; k < 4; ++k)
+                        if (in[k] && y < best[k].v) { best[k].v = y; best[k].i = v; }
+                }
+            __syncthreads();  // (s_arg4 free)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const EbArg r = eb_block_arg<false>(best[k], s_w);
-                if (tid == 0) {
-                    s_foot[n][k] = r.i < V ? r.i : 0;  // (an empty quadrant: vertex 0, like argmin over all-inf)
-                    if (r.i >= V) s_ok = 0;
-                }
+                best[k] = wave_arg(false, best[k]);
+                if (lane == 0) s_arg4[wave][k] = best[k];
+            }
+            __syncthreads();
+            if (have && sub == 0 && lane < 4) {
+                EbArg r = s_arg4[w0][lane];
+                for (int k = 1; k < wpi; ++k)
+                    if (arg_better(false, s_arg4[w0 + k][lane], r)) r = s_arg4[w0 + k][lane];
+                s_foot[n][lane] = r.i < V ? r.i : 0;  // (an empty quadrant: vertex 0, like argmin over all-inf)
+                if (r.i >= V) s_ok = 0;               // (same value from every writer)
             }
         }
         __syncthreads();
     }
-    // ---- phase D: joints and bones, one thread per instance (instance 0 first: its attachment joints serve all)
+    A3D_STAMP(0, 4);
+    // ---- phase D: joints and bones, one thread per bone end; every joint is a closed form of the spine ends and the centroid
     __shared__ int s_attach[4];
     const int nj = a.n_body + 1, half = a.n_body / 2, nb2 = (nj + 1) / 2, K = a.n_body + 4 * a.n_leg;
-    for (int round = 0; round < 2; ++round) {
-        const int n = round == 0 ? 0 : tid;
-        if ((round == 0 ? tid == 0 : (tid > 0 && tid < N))) {
-            const float* p = pos + (long long)n * V * 3;
-            float pa[3] = {0.f, p[3 * s_ab[n][0] + 1], p[3 * s_ab[n][0] + 2]}, pb[3] = {0.f, p[3 * s_ab[n][1] + 1], p[3 * s_ab[n][1] + 2]};
-            float mid[3] = {0.f, s_cent[n][1] + (a.n_leg > 0 ? 0.5f : 0.f), s_cent[n][2]};
-            float joints[33][3];
-            for (int i = 0; i < nb2; ++i) {
-                const float bl = a.blend[i];
-                for (int c = 0; c < 3; ++c) {
-                    const float ja = pa[c] * (1.f - bl) + mid[c] * bl, jb = pb[c] * bl + mid[c] * (1.f - bl);
-                    if (i < nb2 - 1) joints[i][c] = ja;  // joints_a[:-1]
-                    joints[nb2 - 1 + i][c] = jb;
+    auto joint = [&](int n, int j, float* o) {  // joints_a[:-1] ++ joints_b   (skinning.py:118-126)
+        const float* p = pos + (long long)n * V * 3;
+        const bool head = j < nb2 - 1;
+        const int i = head ? j : j - (nb2 - 1), vi = s_ab[n][head ? 0 : 1];
+        const float e[3] = {0.f, p[3 * vi + 1], p[3 * vi + 2]}, mid[3] = {0.f, s_cent[n][1] + (a.n_leg > 0 ? 0.5f : 0.f), s_cent[n][2]};
+        const float bl = s_blend[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = head ? e[c] * (1.f - bl) + mid[c] * bl : e[c] * bl + mid[c] * (1.f - bl);
+    };
+    // body bones: (i + 1, i) for the first half, then (i, i + 1) for i = n_body - 1 .. half   (skinning.py:128-141)
+    auto body_end = [&](int n, int bone, int e, float* o) {
+        const int i = bone < half ? bone : a.n_body - 1 - (bone - half);
+        joint(n, bone < half ? (e == 0 ? i + 1 : i) : (e == 0 ? i : i + 1), o);
+    };
+    if (a.n_leg > 0) {
+        if (tid < 2) {  // attachment joints (instance 0): nearest body bone end in z to the foot, first index on ties
+            int att = a.attach[tid];
+            if (att < 0) {
+                const float fz = pos[3 * s_foot[0][tid] + 2];
+                float bd = INFINITY;
+                att = 0;
+                for (int k = 0; k < a.n_body; ++k) {
+                    float o[3];
+                    body_end(0, k, 1, o);
+                    const float d = fabsf(o[2] - fz);
+                    if (d < bd) { bd = d; att = k; }
                 }
             }
-            float* out = a.bones + (long long)n * K * 6;
-            // body bones: (i + 1, i) for the first half, then (i, i + 1) for i = n_body - 1 .. half   (skinning.py:128-141)
-            int bone = 0;
-            for (int i = 0; i < half; ++i, ++bone)
-                for (int c = 0; c < 3; ++c) { out[6 * bone + c] = joints[i + 1][c]; out[6 * bone + 3 + c] = joints[i][c]; }
-            for (int i = a.n_body - 1; i >= half; --i, ++bone)
-                for (int c = 0; c < 3; ++c) { out[6 * bone + c] = joints[i][c]; out[6 * bone + 3 + c] = joints[i + 1][c]; }
-            if (a.n_leg > 0) {
-                if (round == 0) {  // attachment joints (instance 0): nearest body bone end in z to the foot, first index on ties
-                    int att[4] = {a.attach[0], a.attach[1], a.attach[2], a.attach[3]};
-                    for (int l = 0; l < 2; ++l)
-                        if (att[l] < 0) {
-                            const float fz = p[3 * s_foot[0][l] + 2];
-                            float bd = INFINITY;
-                            int bi = 0;
-                            for (int k = 0; k < a.n_body; ++k) {
-                                const float d = fabsf(out[6 * k + 3 + 2] - fz);
-                                if (d < bd) { bd = d; bi = k; }
-                            }
-                            att[l] = bi;
-                        }
-                    if (a.attach[2] < 0) att[2] = att[1];
-                    if (a.attach[3] < 0) att[3] = att[0];
-                    for (int l = 0; l < 4; ++l) s_attach[l] = att[l];
-                    a.nearest[0] = att[0]; a.nearest[1] = att[1];
-                    a.ok[0] = s_ok;
-                }
-            } else if (round == 0) {
-                a.ok[0] = 1;
-            }
+            s_attach[tid] = att;
         }
         __syncthreads();
-        if (a.n_leg > 0 && (round == 0 ? tid == 0 : (tid > 0 && tid < N))) {
-            const float* p = pos + (long long)n * V * 3;
-            float* out = a.bones + (long long)n * K * 6;
-            for (int l = 0; l < 4; ++l) {
-                const float* foot = p + 3 * s_foot[n][l];
-                const float* anchor = out + 6 * s_attach[l] + 3;  // bones_pred[:, :, body_bone_idx, 1]
-                float lj[9][3];
-                for (int j = 0; j <= a.n_leg; ++j)
-                    for (int c = 0; c < 3; ++c) lj[j][c] = foot[c] * (1.f - a.ramp[j]) + anchor[c] * a.ramp[j];
-                for (int i = 0; i < a.n_leg; ++i) {  // leg bone i = (joint i + 1, joint i)
-                    float* o = out + 6 * (a.n_body + l * a.n_leg + i);
-                    for (int c = 0; c < 3; ++c) { o[c] = lj[i + 1][c]; o[3 + c] = lj[i][c]; }
-                }
-            }
+        if (tid == 0) {
+            s_attach[2] = a.attach[2] < 0 ? s_attach[1] : a.attach[2];
+            s_attach[3] = a.attach[3] < 0 ? s_attach[0] : a.attach[3];
+            a.nearest[0] = s_attach[0]; a.nearest[1] = s_attach[1];
         }
         __syncthreads();
     }
+    if (tid == 0) a.ok[0] = a.n_leg > 0 ? s_ok : 1;
+    for (int idx = tid; idx < N * K * 2; idx += EB_THREADS) {
+        const int n = idx / (2 * K), r = idx - n * 2 * K, bone = r >> 1, e = r & 1;
+        float o[3];
+        if (bone < a.n_body) {
+            body_end(n, bone, e, o);
+        } else {  // leg bone i = (joint i + 1, joint i) of the ramp foot -> attachment   (skinning.py:196-215)
+            const int l = (bone - a.n_body) / a.n_leg, i = (bone - a.n_body) - l * a.n_leg;
+            const float* foot = pos + (long long)n * V * 3 + 3 * s_foot[n][l];
+            float anchor[3];
+            body_end(n, s_attach[l], 1, anchor);  // bones_pred[:, :, body_bone_idx, 1]
+            const float rm = s_ramp[e == 0 ? i + 1 : i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = foot[c] * (1.f - rm) + anchor[c] * rm;
+        }
+        float* out = a.bones + ((long long)n * K + bone) * 6 + 3 * e;
+        out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+    }
+    A3D_STAMP(0, 5);
 }
 
 extern "C" int a3d_estimate_bones(const a3d_estimate_bones_args* args, a3d_stream_t stream) {
     A3D_CHECK_ARG(args && args->size >= sizeof(a3d_estimate_bones_args));
-    A3D_CHECK_ARG(args->pos && args->bones && args->nearest && args->ok && args->N > 0 && args->N <= EB_MAXN && args->V > 0);
+    A3D_CHECK_ARG(args->pos && args->bones && args->nearest && args->ok && args->workspace && args->N > 0 && args->N <= EB_MAXN && args->V > 0);
     A3D_CHECK_ARG((long long)args->N * args->V <= (1 << 22) && args->n_body >= 2 && args->n_body % 2 == 0 && args->n_body <= 32 && args->n_leg >= 0 && args->n_leg <= 8);
     EbParams p;
     p.pos = args->pos; p.N = args->N; p.V = args->V; p.n_body = args->n_body; p.n_leg = args->n_leg; p.yplus = args->body_mode_y_plus;
@@ -360,8 +471,10 @@ extern "C" int a3d_estimate_bones(const a3d_estimate_bones_args* args, a3d_strea
     for (int i = 0; i < 9; ++i) p.ramp[i] = args->ramp[i];
     for (int i = 0; i < 4; ++i) p.attach[i] = args->attach[i];
     A3D_CHECK_ARG(args->n_leg == 0 || ((p.attach[0] < args->n_body && p.attach[1] < args->n_body && p.attach[2] < args->n_body && p.attach[3] < args->n_body)));
-    p.bones = args->bones; p.nearest = args->nearest; p.ok = args->ok;
+    p.bones = args->bones; p.nearest = args->nearest; p.ok = args->ok; p.work = args->workspace;
     hipLaunchKernelGGL(eb_kernel, dim3(1), dim3(EB_THREADS), 0, (hipStream_t)stream, p);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(bones)

@@ -444,7 +444,9 @@ def estimate_bones_device(seq_shape, n_body_bones, n_leg_bones, body_mode_y_plus
     bones = torch.empty((B, Fr, K, 2, 3), dtype=torch.float32, device=dev)
     nearest = torch.empty(2, dtype=torch.int32, device=dev)
     ok = torch.empty(1, dtype=torch.int32, device=dev)
+    work = torch.empty(3 * B * Fr * V, dtype=torch.float32, device=dev)
     a = _lib.EstimateBonesArgs(size=ctypes.sizeof(_lib.EstimateBonesArgs), N=B * Fr, pos=ptr(pos), bones=ptr(bones), nearest=ptr(nearest), ok=ptr(ok), V=V,
+                               workspace=ptr(work),
                                n_body=n_body_bones, n_leg=n_leg_bones, body_mode_y_plus=int(bool(body_mode_y_plus)),
                                use_y_threshold=int(y_threshold is not None), y_threshold=float(y_threshold or 0.0))
     for i, v in enumerate(attach):

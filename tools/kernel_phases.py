@@ -43,6 +43,8 @@ KERNELS = {
                                     4: "analysis work-groups (whole)", 5: "movers of the first buffer (4 floats per pixel: whole; else loads + stores)"}),
     "ca_blend": ("antialias", 1, {1: "segment offsets", 5: "blends (atomics)"}),
     "ca_gather": ("antialias", 2, {1: "list -> LDS (-> barrier)", 5: "gather + store"}),
+    "eb": ("bones", 0, {1: "A: centroids, spine ends, planar copy", 2: "B: first select (4 radix passes)", 3: "B: compaction + second select",
+                        4: "C: feet of the quadrants", 5: "D: joints and bones"}),
     "ca_bwd": ("antialias", 3, {1: "segment offsets", 5: "records: colour adjoints + edge adjoints (atomics)"}),
 }
 MAX_WG = 65536

@@ -24,5 +24,5 @@ python 3danimals_amd/csrc/build.py --profile > /dev/null 2>&1 && python tools/ke
 # (round 6) who launched what: every GPU kernel of the step attributed to the code that launched it, for the three workloads
 for w in magicpony fauna ponymation; do python tools/glue_attribution.py --workload $w --steps 3 --out gpurun_out/${TAG}_glue_attribution_$w.json > /dev/null 2>&1; done
 # (round 6) eight ranks on ONE GPU (gloo): the N = 8 launch path and the host-side contention of eight Python processes, measured; no scaling claim
-python bench.py --gpus 8 --backend gloo --share-gpu --batch 2 --steps 10 --warmup 3 --no-cpu-baseline --no-fingerprint > gpurun_out/${TAG}_bench_ranks8_one_gpu.json 2> gpurun_out/${TAG}_bench_ranks8_one_gpu.err
+python bench.py --gpus 8 --backend gloo --share-gpu --steps 10 --warmup 3 --no-cpu-baseline --no-fingerprint > gpurun_out/${TAG}_bench_ranks8_one_gpu.json 2> gpurun_out/${TAG}_bench_ranks8_one_gpu.err
 tail -3 gpurun_out/${TAG}_lines.log
