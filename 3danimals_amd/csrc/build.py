@@ -65,7 +65,9 @@ def build(force=False, verbose=True, profile=False, exp=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, "a3d_common.h"), os.path.join(HERE, "topo_common.h"), os.path.join(HERE, "raster_common.h"), os.path.join(HERE, "cover_common.h"), os.path.join(HERE, "bones_common.h"), os.path.join(HERE, "normals_common.h"), os.path.join(HERE, "shade_common.h"), os.path.join(HERE, "gbuffer_common.h"), os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
+    # every header of csrc/ (a kernel's object is stale when ANY of them is newer: a header left out of a hand-kept list once kept a
+    # stale interp.o in the library), the public header and this script
+    headers = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join(os.path.dirname(PKG), "include", "a3d.h"), os.path.abspath(__file__)]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -5,6 +5,7 @@
 // (G lanes per pixel, lane = channel) and emits d/du, d/dv for the rasteriser's backward.
 // HBM traffic per pixel: 16 B (rast) + 4C B (out); backward 16 + 4C B in, 16 B out (+ atomics in L2).
 #include "a3d_common.h"
+#include "tile_scatter.h"
 
 #define IP_MAXC 64
 
@@ -69,6 +70,86 @@ __global__ __launch_bounds__(256) void ip_bwd_kernel(const float* __restrict__ g
     if (sub == 0) g_rast[i] = make_float4(gu, gv, 0.f, 0.f);
 }
 
+// Round 6, C <= 16: one thread per pixel of a 16 x 16 tile; pixels on the same triangle merge their three bary-weighted gradient rows
+// inside the wave (ts_merge), the survivors meet their neighbours' in the work-group's LDS table (tile_scatter.h) and leave as one row
+// of adjacent atomics per vertex and tile.  Kernel us at B = 16, 256 x 256 (rocprofv3, tools/shim_bwd_prof.sh; per-pixel form ->
+// this one): 3 channels 50.7 -> 27.6 on the fresh mesh, 115 -> 30 on the trained-like one (its long thin triangles make the per-pixel
+// form's atomics collide); 16 channels 137 -> 92.  105 VGPRs (4 waves per SIMD): forcing 6 spills and loses (33 us).
+// CM = the channel count rounded up (register rows), ROUNDS = merge rounds.
+template <int CM, int ROUNDS>
+__global__ __launch_bounds__(256) void ip_bwd_tile_kernel(const float* __restrict__ g_out, const float* __restrict__ attr, int attr_batch, int C,
+                                                          const float4* __restrict__ rast, const int* __restrict__ tri, int V, int F, int H, int W,
+                                                          int tiles_x, float* __restrict__ g_attr, float4* __restrict__ g_rast) {
+    extern __shared__ __align__(16) unsigned char ip_bwd_lds[];
+    A3D_STAMP(0, 0);
+    const int b = blockIdx.y, tile = blockIdx.x;
+    int px, py;
+    ts_pixel((tile % tiles_x) * TS_TILE, (tile / tiles_x) * TS_TILE, px, py);
+    const bool inside = px < W && py < H;
+    const long long i = ((long long)b * H + py) * W + px;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) r = rast[i];
+    const int f = (int)r.w - 1;
+    const bool live = inside && f >= 0 && f < F;
+    if (!__syncthreads_or(live)) {
+        if (inside) g_rast[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    TileScatter ts;
+    if (g_attr) ts.init(ip_bwd_lds, C);
+    float gu = 0.f, gv = 0.f;
+    float c[3 * CM];
+#pragma unroll
+    for (int n = 0; n < 3 * CM; ++n) c[n] = 0.f;
+    int row[3] = {0, 0, 0}, key = -1;
+    if (live) {
+        const int vb = attr_batch == 1 ? 0 : b * V;
+        row[0] = vb + tri[3 * f]; row[1] = vb + tri[3 * f + 1]; row[2] = vb + tri[3 * f + 2];
+        const float* a0 = attr + (long long)row[0] * C;
+        const float* a1 = attr + (long long)row[1] * C;
+        const float* a2 = attr + (long long)row[2] * C;
+        const float w2 = 1.f - r.x - r.y;
+        const float* g = g_out + i * C;
+#pragma unroll
+        for (int ch = 0; ch < CM; ++ch) {
+            if (ch < C) {
+                const float gc = g[ch], x2 = a2[ch];
+                gu += gc * (a0[ch] - x2);
+                gv += gc * (a1[ch] - x2);
+                c[ch] = r.x * gc; c[CM + ch] = r.y * gc; c[2 * CM + ch] = w2 * gc;
+            }
+        }
+        key = f;
+    }
+    if (inside) g_rast[i] = make_float4(gu, gv, 0.f, 0.f);
+    if (!g_attr) return;
+    A3D_STAMP(0, 1);
+    ts_merge<3 * CM, ROUNDS>(key, c);
+    A3D_STAMP(0, 2);
+    __syncthreads();  // (table initialised)
+    const int e0 = ts.entries(key >= 0, 3);
+    if (key >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int sl = ts.slot(row[k]);
+#pragma unroll
+            for (int ch = 0; ch < CM; ++ch) {
+                if (ch < C) {
+                    const float v = c[k * CM + ch];
+                    if (sl >= 0) ts.e_val[(e0 + k) * C + ch] = v;
+                    else if (v != 0.f) atomicAdd(g_attr + (long long)row[k] * C + ch, v);
+                }
+            }
+            if (sl >= 0) ts.link(e0 + k, sl);
+        }
+    }
+    A3D_STAMP(0, 3);
+    __syncthreads();
+    A3D_STAMP(0, 4);
+    ts.flush<CM>(g_attr, C, -1);
+    A3D_STAMP(0, 5);
+}
+
 extern "C" int a3d_interp_fwd(const float* attr, int attr_batch, int C, const float* rast, const int32_t* tri, int B, int V, int F, int H,
                               int W, float* out, a3d_stream_t stream) {
     A3D_CHECK_ARG(attr && rast && out && B > 0 && V > 0 && F >= 0 && H > 0 && W > 0 && C > 0 && C <= IP_MAXC);
@@ -89,7 +170,14 @@ extern "C" int a3d_interp_bwd(const float* g_out, const float* attr, int attr_ba
     hipStream_t s = (hipStream_t)stream;
     if (g_attr_or_null) A3D_HIP(hipMemsetAsync(g_attr_or_null, 0, sizeof(float) * (size_t)attr_batch * V * C, s));
     const long long hw = (long long)H * W, npix = hw * B;
-    if (C <= 4)
+    if (C <= 16 && B <= 65535 && (long long)attr_batch * V < 0x7fffffffll && a3d_exp() != 140) {
+        const int tiles_x = a3d_div_up(W, TS_TILE), tiles_y = a3d_div_up(H, TS_TILE);
+#define IP_TILE(CM_, R_)                                                                                                                      \
+    hipLaunchKernelGGL((ip_bwd_tile_kernel<CM_, R_>), dim3(tiles_x * tiles_y, B), dim3(256), g_attr_or_null ? TileScatter::lds_bytes(C) : 0, s, g_out, \
+                       attr, attr_batch, C, (const float4*)rast, tri, V, F, H, W, tiles_x, g_attr_or_null, (float4*)g_rast)
+        if (C <= 4) IP_TILE(4, 6); else if (C <= 8) IP_TILE(8, 4); else IP_TILE(16, 4);
+#undef IP_TILE
+    } else if (C <= 4)
         hipLaunchKernelGGL(ip_bwd_kernel<4>, dim3(a3d_div_up(4 * npix, 256)), dim3(256), 0, s, g_out, attr, attr_batch, C, (const float4*)rast, tri,
                            V, F, hw, npix, g_attr_or_null, (float4*)g_rast);
     else if (C <= 8)
@@ -101,3 +189,5 @@ extern "C" int a3d_interp_bwd(const float* g_out, const float* attr, int attr_ba
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
+
+A3D_PROFILE_TU(interp)

@@ -24,6 +24,7 @@
 // compiled with -ffp-contract=off so that the edge functions of a shared edge are exact negations (watertight)
 // and the triangle ids match the oracle bit for bit.
 #include "a3d_common.h"
+#include "tile_scatter.h"
 #include "raster_common.h"
 #include "topo_common.h"
 #include "normals_common.h"
@@ -817,10 +818,87 @@ __global__ __launch_bounds__(256) void rs_resolve_cover_kernel(const float4* __r
     A3D_STAMP(3, 5);
 }
 
-// backward of (u,v) w.r.t. clip-space x, y, w of the three vertices; FOUR lanes per pixel, lane = component of the 16-byte gradient
-// row of a vertex (x, y, -, w): every lane repeats the pixel's small algebra and adds its own component, so the three adds of a
-// (pixel, vertex) pair are one request to the L2's atomic unit instead of three (line-coalesced atomics)
+// backward of (u,v) w.r.t. clip-space x, y, w of the three vertices.  Round 6: one thread per pixel of a 16 x 16 tile; the three
+// (x, y, -, w) gradient rows of a pixel meet their neighbours' in the work-group's LDS table (tile_scatter.h) and leave as one row of
+// adjacent atomics per vertex and tile.  (Until round 5: four lanes per pixel, one line-coalesced atomic request per (pixel, vertex),
+// bound by the 6e5 requests to the memory-side atomic units.  Kernel us at B = 16, 256 x 256, rocprofv3: 42.6 -> 18.6 on the fresh
+// mesh, 74.4 -> 20.3 on the trained-like one; where the 18.6 go: tile_scatter.h and tools/shim_bwd_phases.py.)
 __global__ __launch_bounds__(256) void rs_bwd_kernel(const float4* __restrict__ g_rast, const float4* __restrict__ rast,
+                                                     const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
+                                                     int V, int F, int H, int W, int tiles_x, float* __restrict__ g_clip) {
+    extern __shared__ __align__(16) unsigned char rs_bwd_lds[];
+    A3D_STAMP(4, 0);
+    const int b = blockIdx.y, tile = blockIdx.x;
+    int px, py;
+    ts_pixel((tile % tiles_x) * TS_TILE, (tile / tiles_x) * TS_TILE, px, py);
+    const bool inside = px < W && py < H;
+    const long long i = ((long long)b * H + py) * W + px;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), g = r;
+    if (inside) r = rast[i];
+    const int f = (int)r.w - 1;
+    bool live = inside && f >= 0 && f < F;
+    if (live) {
+        g = g_rast[i];
+        live = g.x != 0.f || g.y != 0.f;
+    }
+    if (!__syncthreads_or(live)) return;
+    TileScatter ts;
+    ts.init(rs_bwd_lds, 4);
+    const int vb = clip_batch == 1 ? 0 : b * V;
+    int i0 = 0, i1 = 0, i2 = 0, key = -1;
+    float c[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (x, y, w) of the three corners
+    if (live) {
+        i0 = tri[3 * f]; i1 = tri[3 * f + 1]; i2 = tri[3 * f + 2];
+        const float4 p0 = clip[vb + i0], p1 = clip[vb + i1], p2 = clip[vb + i2];
+        const float fx = ((float)px + 0.5f) * (2.f / (float)W) - 1.f;
+        const float fy = ((float)py + 0.5f) * (2.f / (float)H) - 1.f;
+        const float q0x = p0.x - fx * p0.w, q0y = p0.y - fy * p0.w;
+        const float q1x = p1.x - fx * p1.w, q1y = p1.y - fy * p1.w;
+        const float q2x = p2.x - fx * p2.w, q2y = p2.y - fy * p2.w;
+        const float a0 = q1x * q2y - q1y * q2x, a1 = q2x * q0y - q2y * q0x, a2 = q0x * q1y - q0y * q1x;
+        const float s = a0 + a1 + a2;
+        if (s != 0.f) {
+            const float is = 1.f / s;
+            const float u = a0 * is, v = a1 * is;
+            const float t = g.x * u + g.y * v;
+            const float ga0 = (g.x - t) * is, ga1 = (g.y - t) * is, ga2 = -t * is;
+            c[0] = -ga1 * q2y + ga2 * q1y; c[1] = ga1 * q2x - ga2 * q1x;
+            c[3] = ga0 * q2y - ga2 * q0y;  c[4] = -ga0 * q2x + ga2 * q0x;
+            c[6] = -ga0 * q1y + ga1 * q0y; c[7] = ga0 * q1x - ga1 * q0x;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[3 * k + 2] = -fx * c[3 * k] - fy * c[3 * k + 1];
+            key = f;
+        }
+    }
+    A3D_STAMP(4, 1);
+    ts_merge<9, 6>(key, c);
+    A3D_STAMP(4, 2);
+    __syncthreads();  // (table initialised)
+    const int e0 = ts.entries(key >= 0, 3);
+    if (key >= 0) {
+        const int row[3] = {vb + i0, vb + i1, vb + i2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int sl = ts.slot(row[k]);
+            if (sl >= 0) {
+                *reinterpret_cast<float4*>(ts.e_val + 4 * (e0 + k)) = make_float4(c[3 * k], c[3 * k + 1], 0.f, c[3 * k + 2]);
+                ts.link(e0 + k, sl);
+            } else {
+                float* o = g_clip + (long long)row[k] * 4;
+                atomicAdd(o, c[3 * k]); atomicAdd(o + 1, c[3 * k + 1]); atomicAdd(o + 3, c[3 * k + 2]);
+            }
+        }
+    }
+    A3D_STAMP(4, 3);
+    __syncthreads();
+    A3D_STAMP(4, 4);
+    ts.flush<4>(g_clip, 4, 2);
+    A3D_STAMP(4, 5);
+}
+
+// the per-pixel form of rounds 1-5 (four lanes per pixel, one line-coalesced request per (pixel, vertex)): kept for the A/B of
+// tools/shim_bwd_bench.py in the experiment build (A3D_EXP=140); the product library never launches it
+__global__ __launch_bounds__(256) void rs_bwd_pixel_kernel(const float4* __restrict__ g_rast, const float4* __restrict__ rast,
                                                      const float4* __restrict__ clip, int clip_batch, const int* __restrict__ tri,
                                                      int V, int F, int H, int W, long long npix, float* __restrict__ g_clip) {
     const long long t4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1038,9 +1116,16 @@ extern "C" int a3d_rast_bwd(const float* g_rast, const float* rast, const float*
     A3D_HIP(hipMemsetAsync(g_clip, 0, sizeof(float) * 4 * (size_t)clip_batch * V, s));
     if (F == 0) return A3D_OK;
     const long long npix = (long long)B * H * W;
-    A3D_CHECK_ARG(npix < 0x7fffffffll);
-    hipLaunchKernelGGL(rs_bwd_kernel, dim3(a3d_div_up(4 * npix, 256)), dim3(256), 0, s, (const float4*)g_rast, (const float4*)rast,
-                       (const float4*)clip, clip_batch, tri, V, F, H, W, npix, g_clip);
+    A3D_CHECK_ARG(npix < 0x7fffffffll && B <= 65535 && (long long)clip_batch * V < 0x7fffffffll);
+    const int tiles_x = a3d_div_up(W, TS_TILE), tiles_y = a3d_div_up(H, TS_TILE);
+    if (a3d_exp() == 140) {
+        hipLaunchKernelGGL(rs_bwd_pixel_kernel, dim3(a3d_div_up(4 * npix, 256)), dim3(256), 0, s, (const float4*)g_rast, (const float4*)rast,
+                           (const float4*)clip, clip_batch, tri, V, F, H, W, npix, g_clip);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
+    hipLaunchKernelGGL(rs_bwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256), TileScatter::lds_bytes(4), s, (const float4*)g_rast, (const float4*)rast,
+                       (const float4*)clip, clip_batch, tri, V, F, H, W, tiles_x, g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

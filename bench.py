@@ -520,6 +520,9 @@ def main():
                     help="fast: the output-identical field evaluation of hostnets (headline); reference: model/networks' own formulation "
                          "(per-point feature concat, per-call frequency upload, no TunableOp, no fused kernels); both: headline = fast, and "
                          "the reference formulation is measured too (single GPU only) and reported under 'dropin'")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic scene's networks, cameras and poses (0: every committed line but the "
+                    "long Fauna run, whose random trajectory empties a leg quadrant at seed 0: estimate_bones then raises where the "
+                    "reference drops into pdb, skinning.py:183)")
     ap.add_argument("--mesh", choices=("quadruped", "spiky"), default="quadruped", help="spiky: the trained-like mesh (pipeline.synthetic_spikes: the "
                     "quadruped with a percent of its vertices pulled into thin spikes, tuned to the step-600 statistics of the long run); the default "
                     "line carries it as extra_legs.spiky anyway")
@@ -581,8 +584,8 @@ def main():
 
     def make_scene(workload=args.workload, per_rank_poses=args.per_rank_poses, mesh=args.mesh):
         b = batch if (workload == args.workload or args.workload != "ponymation") else 16  # (ponymation's --batch counts sequences)
-        return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=b, resolution=(args.resolution, args.resolution), device=dev, seed=0,
-                                       data_seed=1000 * rank, workload=workload, num_frames=frames if workload == "ponymation" else 1,
+        return pipeline.SyntheticScene(grid=args.grid, grid_res=args.grid_res, batch=b, resolution=(args.resolution, args.resolution), device=dev, seed=args.seed,
+                                       data_seed=1000 * rank + args.seed, workload=workload, num_frames=frames if workload == "ponymation" else 1,
                                        deform=((workload == "magicpony" or (workload == "ponymation" and args.no_render)) and not args.no_deform),
                                        pose_seed=(rank if per_rank_poses else 0), mesh=mesh, render=not (args.no_render and workload == "ponymation"))
 
@@ -830,7 +833,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": what, "name": args.workload, "batch_per_gpu": batch, "frames_per_sequence": frames, "global_batch": world * batch,
-                       "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "mesh": args.mesh, "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
+                       "resolution": [args.resolution, args.resolution], "grid": grid_name(args), "mesh": args.mesh, "seed": args.seed, "dmtet_pass": getattr(scene.netShape.topology, "_last_count_pass", None), "parallelism": f"dp{world}",
                        "networks": headline_networks, "tuned_mlp_gemms": bool(tuned),
                        "mode": "train (fwd+bwd+Adam)" if train else "forward only (no_grad)", "render": not args.no_render,
                        "per_rank_data": ("per-rank poses/cameras, image features and targets (covered pixels differ per rank)" if args.per_rank_poses else

@@ -15,7 +15,14 @@ run fwd_b8_bcc51s --grid bcc51s --forward-only --batch 8 --networks fast
 run fwd_b8_bcc102s --grid bcc102s --forward-only --batch 8 --networks fast --cpu-sample-images 2 --cpu-runs 1
 # the long run: 400 timed steps after 100 of warm-up (the mesh the synthetic training drifts into; README quotes it beside the 25-step figure)
 run long400 --steps 400 --warmup 100 --networks fast --no-cpu-baseline
-run long400_fauna --workload fauna --steps 400 --warmup 100 --networks fast --no-cpu-baseline
+# The Fauna step on random targets is a chaotic trajectory that passes within ONE vertex of an empty leg quadrant (profiles/r05_fauna_quadrants.txt:
+# 1 vertex around step 50); float atomics decide on which side a run falls, and when a quadrant empties estimate_bones raises, as the
+# reference stops in pdb (skinning.py:183).  Such a run says nothing about 500 steps of the path: it is repeated, the attempts are counted.
+for attempt in 1 2 3; do
+  run long400_fauna --workload fauna --steps 400 --warmup 100 --networks fast --no-cpu-baseline
+  [ -s gpurun_out/${TAG}_bench_long400_fauna.json ] && break
+  echo "long400_fauna: attempt $attempt emptied a leg quadrant" >> gpurun_out/${TAG}_long400_fauna_attempts.txt
+done
 # (round 5) ponymation stage 2 as configured: 20 sequences x 10 frames, enable_render false (train_ponymation_horse_stage2.yaml:16-27); the trained-like mesh as the headline
 run ponymation_norender --workload ponymation --no-render --batch 20 --frames 10 --networks fast --cpu-sample-images 20 --cpu-runs 1
 run spiky --mesh spiky --networks fast
