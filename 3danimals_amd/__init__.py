@@ -16,4 +16,4 @@ HIP device.
 from . import synthetic, tetgrid  # noqa: F401  (pure numpy/torch helpers; no native code needed)
 
 __all__ = ["synthetic", "tetgrid"]
-__version__ = "0.6.0"  # round 6 (C ABI: a3d_version() = 403)
+__version__ = "0.6.0"  # round 6 (C ABI: a3d_version() = 404)

@@ -169,10 +169,10 @@ class DmtetEmitOpts(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("Nv", ctypes.c_int32), ("vertex_scratch", _p), ("surf_idx", _p), ("g_sdf_to_clear", _p), ("tri32", _p),
                 ("topo_count", _p), ("topo_adj", _p), ("device_counts", _p), ("n_surf", ctypes.c_int32), ("topo_stride", ctypes.c_int32),
                 ("use_block_lists", ctypes.c_int32), ("n_edge_blocks_listed", ctypes.c_int32), ("n_tet_blocks_listed", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("surf_bucket", ctypes.c_int32), ("surf_pts", _p)]
 
 
-ABI_VERSION = 403  # a3d_version() of the library these signatures belong to (include/a3d.h)
+ABI_VERSION = 404  # a3d_version() of the library these signatures belong to (include/a3d.h)
 _lib = None
 
 

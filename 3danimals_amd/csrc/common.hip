@@ -14,7 +14,7 @@ void a3d_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* a3d_last_error(void) { return g_err; }
-extern "C" int a3d_version(void) { return 403; /* 0.4.x: round-4 ABI (403, round 6: the glue-free fused render -- a3d_shade_params / a3d_shade_bwd_rows, a3d_ca_shade.params, the appended fields of a3d_ca_buffer (bg_channels, g_stride, g_channels, vals_rows), a3d_gb_aux + g_tex of the G-buffer calls, a3d_xfm_points_fwd / _bwd, pixel strides of a3d_recon_losses_*, a3d_dmtet_surface_points; 402, round 5: a3d_bw_probe_fill / a3d_bw_probe_read -- the box fingerprint of bench.py -- and a3d_rast_opts.defer_resolve + a3d_rast_resolve / a3d_rast_resolve_gbuffer_fwd; 400: a3d_dmtet_count_ordered -- the culled count pass for grids in any numbering; 401: a3d_dmtet_emit_sparse, a3d_mask_aa_*, the optional groups of a3d_rast_fwd / a3d_dmtet_emit / a3d_composite_aa_fwd in structs); 0.3.x: round-3 ABI (skin_pose, scan-free covered-pixel list and DMTet, topology inside the DMTet emit; 301: culled DMTet count; 302: normals ride in the rasteriser launch; 303: the silhouette analysis rides in the compositor launch; 304: the DMTet emit writes the vertex -> face lists itself; 305: ... and covers only the blocks the count pass listed; 306: skin_pose_bwd without ticket; 307: link derivatives from the forward; 308: speculative DMTet emit) */ }
+extern "C" int a3d_version(void) { return 404; /* 0.4.x: round-4 ABI (404, round 6: a3d_dmtet_emit_opts.surf_pts / surf_bucket -- the surface rows of the SDF re-evaluation written by the emit launch --, the scan of a3d_dmtet_count inside its count launch; 403, round 6: the glue-free fused render -- a3d_shade_params / a3d_shade_bwd_rows, a3d_ca_shade.params, the appended fields of a3d_ca_buffer (bg_channels, g_stride, g_channels, vals_rows), a3d_gb_aux + g_tex of the G-buffer calls, a3d_xfm_points_fwd / _bwd, pixel strides of a3d_recon_losses_*, a3d_dmtet_surface_points; 402, round 5: a3d_bw_probe_fill / a3d_bw_probe_read -- the box fingerprint of bench.py -- and a3d_rast_opts.defer_resolve + a3d_rast_resolve / a3d_rast_resolve_gbuffer_fwd; 400: a3d_dmtet_count_ordered -- the culled count pass for grids in any numbering; 401: a3d_dmtet_emit_sparse, a3d_mask_aa_*, the optional groups of a3d_rast_fwd / a3d_dmtet_emit / a3d_composite_aa_fwd in structs); 0.3.x: round-3 ABI (skin_pose, scan-free covered-pixel list and DMTet, topology inside the DMTet emit; 301: culled DMTet count; 302: normals ride in the rasteriser launch; 303: the silhouette analysis rides in the compositor launch; 304: the DMTet emit writes the vertex -> face lists itself; 305: ... and covers only the blocks the count pass listed; 306: skin_pose_bwd without ticket; 307: link derivatives from the forward; 308: speculative DMTet emit) */ }
 
 // experiment knob: only the experiment / profile builds of the library (build.py --exp / --profile) read the environment; the product
 // library answers 0, so no switch of a measurement can change what it computes

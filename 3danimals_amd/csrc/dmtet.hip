@@ -58,11 +58,13 @@ __device__ __forceinline__ bool dm_edge_cross(const void* __restrict__ src, int2
 
 // every wave leaves DM_SIGN_WORDS words: lane l reads the vertices base + 64 j + l, all loads in flight, one ballot per word
 #define DM_SIGN_WORDS 4
+#define DM_TICKET_SLOT 8  // list_len[8]: work-groups of the culled count launch that have finished (dm_scan_tail)
 __global__ __launch_bounds__(256) void dm_sign_kernel(const float* __restrict__ sdf, int Nv, unsigned long long* __restrict__ bits,
                                                       int* __restrict__ list_len) {
     A3D_STAMP(0, 0);  // (A3D_STAMP kernel ids of this file: 0 = dm_sign_kernel, 1 = dm_count_cull_kernel, 3 = dm_emit_kernel, 4 = dm_bwd_kernel)
     const int lane = threadIdx.x & 63;
-    if (list_len && blockIdx.x == 0 && threadIdx.x < 2) list_len[16 * threadIdx.x] = 0;  // (the two append counters of the count launch)
+    // (the two append counters of the count launch and, 32 bytes into the first one's line, the arrival ticket of its folded scan)
+    if (list_len && blockIdx.x == 0 && threadIdx.x < 3) list_len[threadIdx.x == 2 ? DM_TICKET_SLOT : 16 * threadIdx.x] = 0;
     const long long w0 = ((long long)blockIdx.x * (256 / 64) + (threadIdx.x >> 6)) * DM_SIGN_WORDS;  // first word of this wave
     float x[DM_SIGN_WORDS];
 #pragma unroll
@@ -99,6 +101,15 @@ __device__ __forceinline__ void dm_flag_vertex(unsigned* __restrict__ vbits, uns
 
 // One 1024-item block (16 words; wave w owns the words k*4 + w).  ``skip`` (wave-uniform): bit k set = word k of this wave is known to
 // hold no crossing (dm_count_cull_kernel below) -- its index rows are not loaded, its bits are written as zeros.
+// a block sum: a plain store, or (publish: the scan rides in this launch, dm_scan_tail) a device-scope atomic, performed at the memory
+// side like the plane's ORs and the list appends -- the scanning work-group sits on another XCD, whose L2 this XCD's stores do not reach
+// inside a kernel.  (A release fence per work-group instead -- plain stores + __threadfence() -- writes the XCD's L2 back 841 times:
+// the count call went from 20 to 88 us.)
+__device__ __forceinline__ void dm_put(int* p, int v, bool publish) {
+    if (publish) __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 template <bool BITS>
 __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, const int2* __restrict__ edges, const int4* __restrict__ tets,
                                                int Ne, int Nt, bool is_edge, int blk, unsigned skip, int* __restrict__ blk_e,
@@ -106,7 +117,7 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
                                                unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
                                                unsigned* __restrict__ vbits, int (*s_cnt)[DM_THREADS / A3D_WAVE], int* s_pc,
                                                int* __restrict__ list_len = nullptr, int* __restrict__ list = nullptr,
-                                               unsigned* s_vwin = nullptr) {
+                                               unsigned* s_vwin = nullptr, bool publish = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c0 = 0, c1 = 0;
     const long long base = (long long)blk * DM_BLOCK_ITEMS;
@@ -205,8 +216,8 @@ __device__ __forceinline__ void dm_count_block(const void* __restrict__ sdf, con
     if (tid == 0) {
         int a = 0, b = 0;
         for (int w = 0; w < DM_THREADS / A3D_WAVE; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
-        if (is_edge) blk_e[blk] = a;
-        else { blk_t1[blk] = a; blk_t2[blk] = b; }
+        if (is_edge) dm_put(blk_e + blk, a, publish);
+        else { dm_put(blk_t1 + blk, a, publish); dm_put(blk_t2 + blk, b, publish); }
         // the blocks that hold something, in any order: the emit launch then has one work-group set per listed block instead of one
         // per block of the grid (R = 128: ~1.4k of 27k)
         if (list && (a | b) != 0) list[atomicAdd(list_len, 1)] = blk;
@@ -232,6 +243,87 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
                          edge_bits, tet_bits, wlocal, vbits, s_cnt, s_pc);
 }
 
+// ---- the scan inside the count launch (round 6, VERDICT r5 item 3: built, measured, kept OFF -- see a3d_dmtet_count).  dm_scan_kernel
+// below is four tiny scans in a launch of their own: 6.3 us of kernel for ~5k integers, plus the gap in front of it, on the critical
+// path between the count and the emit.  Here every work-group of the culled count launch publishes its block sums as device-scope
+// atomics (dm_put) and takes a ticket; the one that draws the LAST ticket acquires and scans: wave w owns
+// array w (edge blocks, one-triangle tets, two-triangle tets, 1024-vertex chunks of the surface-vertex plane) as rows of 64 consecutive
+// sums -- every row loaded up front (coalesced), scanned with shuffles, chained through a wave-uniform carry: no LDS, no barrier, for
+// up to DM_TAIL_ROWS * 64 sums per array.  Larger grids keep the separate launch (its 1024 threads and 96 KB of LDS are what 15k sums need).
+// The chunk popcounts of the vertex plane are taken by all four waves first (8 lanes per 128-byte chunk) into LDS.
+#define DM_TAIL_ROWS 32
+#define DM_TAIL_MAX (DM_TAIL_ROWS * 64)
+
+// in-place exclusive scan of arr[0, n) (global, or LDS for the chunk counts -> written to `dst`) by ONE wave; returns the total
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (within rows of 16: row_shr 1, 2, 4, 8; across rows: row_bcast 15,
+// 31) -- VALU only.  (The shuffle form, six ds_bpermute round trips per row of sums, chained row after row behind wave-uniform branches,
+// made the folded scan 17 us slower than the launch it replaces.)
+__device__ __forceinline__ int dm_wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// in-place exclusive scan of arr[0, n) (global, or LDS for the chunk counts -> written to `dst`) by ONE wave; returns the total
+template <bool COHERENT>
+__device__ __forceinline__ int dm_wave_scan_rows(const int* src, int* dst, int n) {
+    const int lane = threadIdx.x & 63;
+    int v[DM_TAIL_ROWS];
+#pragma unroll
+    for (int j = 0; j < DM_TAIL_ROWS; ++j) {
+        const int i = j * 64 + lane;
+        v[j] = i < n ? (COHERENT ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i]) : 0;
+    }
+    int carry = 0;
+#pragma unroll
+    for (int j = 0; j < DM_TAIL_ROWS; ++j) {  // (every row, no branch: the rows' chains interleave; rows past n hold zeros)
+        const int incl = dm_wave_incl_scan(v[j]);
+        const int i = j * 64 + lane;
+        if (i < n) dst[i] = carry + incl - v[j];
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    return carry;
+}
+
+__device__ __forceinline__ void dm_scan_tail(int* __restrict__ blk_e, int* __restrict__ blk_t1, int* __restrict__ blk_t2, int nbe, int nbt,
+                                             int* __restrict__ counts, const unsigned* __restrict__ vbits, int* __restrict__ vchunk, int nvc,
+                                             const int* __restrict__ list_len, int* s_chunk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (vbits) {  // chunk popcounts -> LDS (nvc <= DM_VWIN, checked by the host)
+        const uint4* plane = reinterpret_cast<const uint4*>(vbits);
+        const int n16 = nvc * 8;
+        for (int i0 = tid; i0 < n16; i0 += 8 * DM_THREADS) {
+            uint4 x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = plane[i0 + DM_THREADS * k < n16 ? i0 + DM_THREADS * k : i0];  // (first touch after the acquire)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int c = __popc(x[k].x) + __popc(x[k].y) + __popc(x[k].z) + __popc(x[k].w);
+                c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+                if ((lane & 7) == 0 && i0 + DM_THREADS * k < n16) s_chunk[(i0 + DM_THREADS * k) >> 3] = c;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 3) {
+        const int total = vbits ? dm_wave_scan_rows<false>(s_chunk, vchunk, nvc) : 0;
+        if (lane == 0) counts[3] = total;
+    } else {
+        int* arr = wave == 0 ? blk_e : (wave == 1 ? blk_t1 : blk_t2);
+        const int total = dm_wave_scan_rows<true>(arr, arr, wave == 0 ? nbe : nbt);
+        if (lane == 0) {
+            counts[wave] = total;
+            // how many edge / tet blocks the count launch listed as non-empty
+            if (wave == 1) counts[4] = __hip_atomic_load(list_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 2) counts[5] = __hip_atomic_load(list_len + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // The same pass with a cull in front.  ~99 % of the words hold no crossing, and which vertices a word's 64 rows touch is a property of
 // the grid: ``groups`` [words x 8] (built once per grid, model/geometry/dmtet.py: TetGridTopology.word_groups) lists the <= 8 aligned
 // 16-vertex groups that cover them -- on a grid numbered along its rows (the Kuhn grids; any grid whose generator walks space) 64
@@ -252,12 +344,18 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
                                                                    unsigned long long* __restrict__ edge_bits,
                                                                    unsigned long long* __restrict__ tet_bits, int* __restrict__ wlocal,
                                                                    unsigned* __restrict__ vbits, int* __restrict__ list_len,
-                                                                   int* __restrict__ elist, int* __restrict__ tlist) {
+                                                                   int* __restrict__ elist, int* __restrict__ tlist, int fold_scan,
+                                                                   int* __restrict__ counts, int* __restrict__ vchunk, int nvc,
+                                                                   int* __restrict__ clear, int n_clear) {
     __shared__ int s_cnt[2][DM_THREADS / A3D_WAVE];
     __shared__ int s_pc[DM_BLOCK_ITEMS / 64];
     __shared__ unsigned s_nib[G][DM_THREADS / A3D_WAVE];
     __shared__ unsigned s_vwin[DM_VWIN];
+    __shared__ int s_last;
     A3D_STAMP(1, 0);
+    // (folded scan only) the valence counters of the mesh the emit launch is about to build, zeroed here as dm_scan_kernel does
+    if (fold_scan)
+        for (int z = blockIdx.x * DM_THREADS + threadIdx.x; z < n_clear; z += gridDim.x * DM_THREADS) clear[z] = 0;
     // SLOTS = 8 (grids numbered along their rows: the Kuhn grids) or 16 (round 4: spatially coherent files whose words touch more groups
     // -- a BCC lattice in its generator's order: 10-13 -- at 64 instead of 32 bytes of table per word)
     constexpr int WPB = DM_BLOCK_ITEMS / 64, WPR = 64 / SLOTS, ROUNDS = (G * DM_SLABS * SLOTS + 63) / 64;
@@ -308,19 +406,33 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_cull_kernel(const unsigne
             // ballots, no barrier
             if (is_edge) {
                 if (tid < WPB) { edge_bits[(long long)blk * WPB + tid] = 0ull; wlocal[(long long)blk * WPB + tid] = 0; }
-                if (tid == 0) blk_e[blk] = 0;
+                if (tid == 0) dm_put(blk_e + blk, 0, fold_scan);
             } else {
                 if (tid < 4 * WPB) tet_bits[(long long)blk * 4 * WPB + tid] = 0ull;
-                if (tid == 0) { blk_t1[blk] = 0; blk_t2[blk] = 0; }
+                if (tid == 0) { dm_put(blk_t1 + blk, 0, fold_scan); dm_put(blk_t2 + blk, 0, fold_scan); }
             }
             continue;
         }
         if (lds_used) __syncthreads();  // s_cnt / s_pc of the previous processed block consumed
         lds_used = true;
         dm_count_block<true>(sign, edges, tets, Ne, Nt, is_edge, blk, (skip >> (DM_SLABS * g)) & 15u, blk_e, blk_t1, blk_t2, edge_bits, tet_bits,
-                             wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist, s_vwin);
+                             wlocal, vbits, s_cnt, s_pc, list_len + (is_edge ? 0 : 16), is_edge ? elist : tlist, s_vwin, fold_scan != 0);
     }
     A3D_STAMP(1, 5);
+    if (fold_scan) {
+        // everything the scan reads -- block sums, plane words, list lengths -- left this work-group as device-scope atomics: once every
+        // thread's have been acknowledged (vmcnt) the work-group draws its ticket; no fence, no cache write-back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(list_len + DM_TICKET_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        __syncthreads();
+        A3D_STAMP(1, 6);
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (this XCD's L2 forgets what it may hold of those lines)
+            dm_scan_tail(blk_e, blk_t1, blk_t2, nbe, nbt, counts, vbits, vchunk, nvc, list_len, reinterpret_cast<int*>(s_vwin));
+            A3D_STAMP(1, 7);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ count, grid in any numbering
@@ -607,8 +719,16 @@ __global__ __launch_bounds__(1024) void dm_scan_kernel(int* __restrict__ blk_e, 
 // sorted list of the flagged grid vertices: chunk c = vertices [1024 c, 1024 c + 1024); entry = chunk prefix + bits below.  Runs as
 // extra work-groups of the emit launch; every work-group clears the 32 words it consumed, which leaves the bit plane armed for the
 // next count (vertex_scratch_is_clean: no memset).
+// (round 6) ``pts`` (optional): the grid positions of the listed vertices, row for row -- pts[i] = pos[idx[i]] -- and zero rows behind up to
+// the next multiple of ``bucket`` (n_true = the length of the list): the block the SDF network is re-evaluated on
+// (DMTetGeometry._get_mesh_surface_backward), which was a gather launch of its own (a3d_dmtet_gather_rows) right behind this one.
 __device__ __forceinline__ void dm_surface_vertices_chunk(int c, unsigned* __restrict__ vbits, const int* __restrict__ vchunk, int Nv,
-                                                          long long* __restrict__ idx, int* s_pre) {
+                                                          long long* __restrict__ idx, int* s_pre, const float* __restrict__ pos = nullptr,
+                                                          float* __restrict__ pts = nullptr, int bucket = 0, int n_true = 0) {
+    if (pts && c == 0 && bucket > 0) {  // the padding rows
+        const int rows = (n_true + bucket - 1) / bucket * bucket;
+        for (int z = threadIdx.x; z < 3 * (rows - n_true); z += blockDim.x) pts[3ll * n_true + z] = 0.f;
+    }
     unsigned mine = 0;
     if (threadIdx.x < 64) {  // (first wave) exclusive prefix of the 32 word popcounts through shuffles
         mine = threadIdx.x < 32 ? vbits[32ll * c + threadIdx.x] : 0u;
@@ -627,7 +747,14 @@ __device__ __forceinline__ void dm_surface_vertices_chunk(int c, unsigned* __res
     for (int k = 0; k < 4; ++k) {
         const int local = k * 256 + threadIdx.x, v = c * 1024 + local;
         const unsigned word = vbits[32ll * c + (local >> 5)];
-        if (v < Nv && ((word >> (local & 31)) & 1u)) idx[base + s_pre[local >> 5] + __popc(word & ((1u << (local & 31)) - 1u))] = v;
+        if (v < Nv && ((word >> (local & 31)) & 1u)) {
+            const long long slot = base + s_pre[local >> 5] + __popc(word & ((1u << (local & 31)) - 1u));
+            idx[slot] = v;
+            if (pts) {
+                const float x = pos[3ll * v], y = pos[3ll * v + 1], z = pos[3ll * v + 2];
+                pts[3 * slot] = x; pts[3 * slot + 1] = y; pts[3 * slot + 2] = z;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 32 && mine) vbits[32ll * c + threadIdx.x] = 0u;
@@ -723,7 +850,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
                                                              int* __restrict__ topo_adj, int topo_stride, int F,
                                                              const int* __restrict__ elist, const int* __restrict__ tlist, int n_eblocks,
                                                              int n_tblocks, int nvc, const int* __restrict__ dev_counts, int cap_V,
-                                                             int cap_F, int cap_surf) {
+                                                             int cap_F, int cap_surf, float* __restrict__ surf_pts, int surf_bucket) {
     __shared__ int s_pre[32];
     A3D_STAMP(3, 0);  // (only work-groups that reach a stage stamp it: most leave at one of the early exits)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -739,6 +866,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
         F = d1 + 2 * d2;
         live_e = dE;
         live_t = (d1 + d2) > 0 ? dT : 0;
+        cap_surf = dS;  // (from here on: the true length of the surface-vertex list)
     }
     // the backward's dense SDF gradient (scattered into with atomics) cleared here: one memset less on the backward path
     for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
@@ -751,7 +879,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_kernel(const float* __rest
     // listed as non-empty (any order: a block's outputs go to places its prefixes name)
     if ((int)blockIdx.x >= wg_per_block * (n_eblocks + n_tblocks)) {
         const int c = (int)blockIdx.x - wg_per_block * (n_eblocks + n_tblocks);
-        if (c < nvc) dm_surface_vertices_chunk(c, vbits, vchunk, Nv, surf_idx, s_pre);  // (past the chunks: work-groups that only clear)
+        if (c < nvc) dm_surface_vertices_chunk(c, vbits, vchunk, Nv, surf_idx, s_pre, pos, surf_pts, surf_bucket, cap_surf);  // (past the chunks: work-groups that only clear)
         return;
     }
     constexpr int WPS = DM_THREADS / A3D_WAVE;  // words per slab
@@ -832,7 +960,7 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* 
                                                                    float* __restrict__ clear, int n_clear, int* __restrict__ tri32,
                                                                    int* __restrict__ topo_cnt, int* __restrict__ topo_adj, int topo_stride, int F,
                                                                    int wg_e, int wg_t, int nvc, const int* __restrict__ dev_counts, int cap_V,
-                                                                   int cap_F, int cap_surf) {
+                                                                   int cap_F, int cap_surf, float* __restrict__ surf_pts, int surf_bucket) {
     __shared__ int s_pre[32];
     __shared__ unsigned short s_items[DM_THREADS * 64];  // (word of this work-group) << 6 | bit, 32 KB
     __shared__ int s_wave[DM_THREADS / A3D_WAVE];
@@ -844,11 +972,12 @@ __global__ __launch_bounds__(DM_THREADS) void dm_emit_words_kernel(const float* 
         n1 = d1;
         F = d1 + 2 * d2;
         faces_live = F > 0;
+        cap_surf = dS;  // (from here on: the true length of the surface-vertex list)
     }
     for (int z = blockIdx.x * blockDim.x + tid; z < n_clear; z += gridDim.x * blockDim.x) clear[z] = 0.f;
     const int b = blockIdx.x;
     if (b >= wg_e + wg_t) {
-        if (b - wg_e - wg_t < nvc) dm_surface_vertices_chunk(b - wg_e - wg_t, vbits, vchunk, Nv, surf_idx, s_pre);
+        if (b - wg_e - wg_t < nvc) dm_surface_vertices_chunk(b - wg_e - wg_t, vbits, vchunk, Nv, surf_idx, s_pre, pos, surf_pts, surf_bucket, cap_surf);
         return;
     }
     // The set bits of the work-group's 256 words are POOLED: every thread lists its word's bits in LDS (pure ALU + LDS stores), then
@@ -1008,13 +1137,24 @@ extern "C" int a3d_dmtet_count(const float* sdf, const int32_t* edges, const int
         list_len = d.list_len;
         // (G = 1, 2, 4, 8 blocks per work-group measured within 1 us of each other once the blocks of a work-group are strided)
         const int nge = a3d_div_up(d.nbe, DM_CULL_BLOCKS), ngt = a3d_div_up(d.nbt, DM_CULL_BLOCKS);
+        // (experiment builds only, A3D_EXP=44) the scan rides in the count launch -- dm_scan_tail.  MEASURED AND DROPPED in round 6: the
+        // call went from 20.5 to 28.7 us at the bench size (in-kernel stamps: every work-group spends a median of 4.4 us between its last
+        // store and its ticket -- acknowledgements of its stores + one returning device atomic --, and the last one another 6.7 us on
+        // the scans: an acquire, two dependent round trips to memory, the stores), against 6.2 us of kernel + the gap for the launch it
+        // replaces; with release fences instead of atomics 88 us (841 L2 write-backs)
+        const int fold = d.nbe <= DM_TAIL_MAX && d.nbt <= DM_TAIL_MAX && nvc <= DM_VWIN && a3d_exp() == 44;
 #define DM_CULL_LAUNCH(SLOTS)                                                                                                                  \
     hipLaunchKernelGGL((dm_count_cull_kernel<DM_CULL_BLOCKS, SLOTS>), dim3(nge + ngt), dim3(DM_THREADS), 0, s, (const unsigned*)sign,           \
                        (const int2*)edges, (const int4*)tets, Ne, Nt, d.nbe, d.nbt, nge, edge_groups_or_null, tet_groups_or_null, d.be, d.b1,    \
-                       d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits, d.list_len, d.elist, d.tlist)
+                       d.b2, d.edge_bits, d.tet_bits, d.wlocal, vbits, d.list_len, d.elist, d.tlist, fold, counts, vchunk, nvc,                  \
+                       words_to_clear_or_null, words_to_clear_or_null ? n_words_to_clear : 0)
         if (group_slots == 16) DM_CULL_LAUNCH(16);
         else DM_CULL_LAUNCH(8);
 #undef DM_CULL_LAUNCH
+        if (fold) {
+            A3D_LAUNCH_CHECK();
+            return A3D_OK;
+        }
     } else if (Nv >= DM_SIGN_PLANE_MIN_NV && (long long)Nv <= 2ll * Ne) {
         unsigned long long* sign = (unsigned long long*)((char*)scratch + d.sign_off);
         hipLaunchKernelGGL(dm_sign_kernel, dim3(a3d_div_up(Nv, 256 * DM_SIGN_WORDS)), dim3(256), 0, s, sdf, Nv, sign, (int*)nullptr);
@@ -1098,6 +1238,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
     A3D_CHECK_ARG(!vertex_scratch_or_null || (Nv > 0 && n_surf >= 0 && (n_surf == 0 || surf_idx_or_null)));
+    A3D_CHECK_ARG(!o.surf_pts || (surf_idx_or_null && o.surf_bucket > 0 && (!spec || n_surf % o.surf_bucket == 0)));
     A3D_CHECK_ARG(!g_sdf_to_clear_or_null || Nv > 0);
     A3D_CHECK_ARG((tri32_or_null == nullptr) == (topo_count_or_null == nullptr));
     A3D_CHECK_ARG(!topo_adj_or_null || (tri32_or_null && topo_stride > 0 && (long long)V * topo_stride < 0x7fffffffll));
@@ -1123,7 +1264,7 @@ extern "C" int a3d_dmtet_emit(const float* pos, const float* sdf, const int32_t*
                        (long long*)uv_idx, nbt, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, Nv, (long long*)surf_idx_or_null,
                        g_sdf_to_clear_or_null, g_sdf_to_clear_or_null ? Nv : 0, tri32_or_null, topo_count_or_null, wgpb, topo_adj_or_null,
                        topo_stride, n1 + 2 * n2, listed ? (const int*)d.elist : nullptr, listed ? (const int*)d.tlist : nullptr, ne, nt, nvc,
-                       device_counts_or_null, V, cap_F, n_surf);
+                       device_counts_or_null, V, cap_F, n_surf, o.surf_pts, o.surf_bucket);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }
@@ -1144,6 +1285,7 @@ extern "C" int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const i
     A3D_CHECK_ARG(V == 0 || (verts && vert_edge));
     A3D_CHECK_ARG((n1 + n2) == 0 || (faces && uv_idx));
     A3D_CHECK_ARG(!o.vertex_scratch || (o.Nv > 0 && o.n_surf >= 0 && (o.n_surf == 0 || o.surf_idx)));
+    A3D_CHECK_ARG(!o.surf_pts || (o.surf_idx && o.surf_bucket > 0 && (!spec || o.n_surf % o.surf_bucket == 0)));
     A3D_CHECK_ARG(!o.g_sdf_to_clear || o.Nv > 0);
     A3D_CHECK_ARG((o.tri32 == nullptr) == (o.topo_count == nullptr));
     A3D_CHECK_ARG(!o.topo_adj || (o.tri32 && o.topo_stride > 0 && (long long)V * o.topo_stride < 0x7fffffffll));
@@ -1162,7 +1304,7 @@ extern "C" int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const i
                        (const int2*)edges, tet2edge, nwe, nwt, d.be, d.b1, d.b2, d.edge_bits, d.tet_bits, d.wlocal, d.tlocal, n1, verts, vert_edge,
                        (long long*)faces, (long long*)uv_idx, vbits, vbits ? (const int*)(vbits + 32ll * nvc) : nullptr, o.Nv,
                        (long long*)o.surf_idx, o.g_sdf_to_clear, o.g_sdf_to_clear ? o.Nv : 0, o.tri32, o.topo_count, o.topo_adj, o.topo_stride,
-                       n1 + 2 * n2, wg_e, wg_t, nvc, o.device_counts, V, n1 + 2 * n2, o.n_surf);
+                       n1 + 2 * n2, wg_e, wg_t, nvc, o.device_counts, V, n1 + 2 * n2, o.n_surf, o.surf_pts, o.surf_bucket);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

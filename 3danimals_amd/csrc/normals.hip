@@ -216,6 +216,82 @@ __global__ __launch_bounds__(256) void nr_sum_bwd_kernel(const float* __restrict
     A3D_STAMP(1, 5);
 }
 
+// ---- experiment (round 6; experiment builds only, A3D_EXP=45): the face kernel keeps ONE vector per (image, face) -- the
+// adjoint of the face's un-normalised normal, g0 + g1 + g2 as nr_bwd_entry sums it (12 B instead of 36) -- and the vertex kernel rebuilds
+// its corner's term from the three positions of the face (the gather form's arithmetic, so the same bits).  Scratch traffic falls from
+// 72 to 24 B per (image, face); the vertex kernel grows a round trip (key -> index row -> positions).
+__global__ __launch_bounds__(256) void nr_face12_bwd_kernel(const float* __restrict__ g_nrm, int g_stride, const float* __restrict__ acc,
+                                                            const int* __restrict__ tri, int V, int F, float* __restrict__ fadj) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long vb = (long long)blockIdx.y * V;
+    const float* ap = acc + vb * 3;
+    const float* np = g_nrm + vb * g_stride;
+    const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+    const float *a0 = ap + 3ll * i0, *a1 = ap + 3ll * i1, *a2 = ap + 3ll * i2;
+    const float *n0 = np + (long long)g_stride * i0, *n1 = np + (long long)g_stride * i1, *n2 = np + (long long)g_stride * i2;
+    const float x0 = a0[0], y0 = a0[1], z0 = a0[2], x1 = a1[0], y1 = a1[1], z1 = a1[2], x2 = a2[0], y2 = a2[1], z2 = a2[2];
+    const float gx0 = n0[0], gy0 = n0[1], gz0 = n0[2], gx1 = n1[0], gy1 = n1[1], gz1 = n1[2], gx2 = n2[0], gy2 = n2[1], gz2 = n2[2];
+    float g0[3], g1[3], g2[3];
+    nr_vert_adjoint(x0, y0, z0, gx0, gy0, gz0, g0);
+    nr_vert_adjoint(x1, y1, z1, gx1, gy1, gz1, g1);
+    nr_vert_adjoint(x2, y2, z2, gx2, gy2, gz2, g2);
+    float* o = fadj + ((long long)blockIdx.y * F + f) * 3;
+    o[0] = g0[0] + g1[0] + g2[0]; o[1] = g0[1] + g1[1] + g2[1]; o[2] = g0[2] + g1[2] + g2[2];
+}
+
+__global__ __launch_bounds__(256) void nr_sum12_bwd_kernel(const float* __restrict__ fadj, const float* __restrict__ v, const int* __restrict__ tri,
+                                                           const int* __restrict__ off, const int* __restrict__ adj, int V, int F,
+                                                           float* __restrict__ g_v, int stride) {
+    const int vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= V) return;
+    const float* fa = fadj + (long long)blockIdx.y * F * 3;
+    const float* vp = v + (long long)blockIdx.y * V * 3;
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    int lo, cnt;
+    vf_list(off, stride, vi, lo, cnt);
+    const float zero[3] = {0.f, 0.f, 0.f};
+    if (cnt > 0) {
+        int keys[NR_SLOTS];
+        nr_first_keys(adj, lo, cnt, keys);
+        NrFace t[NR_SLOTS];
+        float g[NR_SLOTS][3];
+#pragma unroll
+        for (int k = 0; k < NR_SLOTS; ++k) {
+            const int key = k < cnt ? keys[k] : keys[0];
+            t[k] = nr_decode(key, F, tri);
+            const float* s = fa + 3ll * (key - t[k].c * F);
+            g[k][0] = s[0]; g[k][1] = s[1]; g[k][2] = s[2];
+        }
+#pragma unroll
+        for (int h = 0; h < NR_SLOTS; h += 4) {
+            float p[4][9];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i0 = t[h + k].i0, i1 = t[h + k].i1, i2 = t[h + k].i2;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { p[k][q] = vp[3ll * i0 + q]; p[k][3 + q] = vp[3ll * i1 + q]; p[k][6 + q] = vp[3ll * i2 + q]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)  // (g0 + 0 + 0 inside nr_bwd_entry: the stored sum, exactly)
+                if (h + k < cnt) nr_bwd_entry(t[h + k].c, g[h + k], zero, zero, p[k], p[k] + 3, p[k] + 6, ox, oy, oz);
+        }
+        int last = keys[NR_SLOTS - 1];
+        for (int e = NR_SLOTS; e < cnt; ++e) {
+            last = nr_next_key_mem(adj, lo, cnt, last);
+            const NrFace tt = nr_decode(last, F, tri);
+            const float* s = fa + 3ll * (last - tt.c * F);
+            const float gg[3] = {s[0], s[1], s[2]};
+            float p[9];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { p[q] = vp[3ll * tt.i0 + q]; p[3 + q] = vp[3ll * tt.i1 + q]; p[6 + q] = vp[3ll * tt.i2 + q]; }
+            nr_bwd_entry(tt.c, gg, zero, zero, p, p + 3, p + 6, ox, oy, oz);
+        }
+    }
+    const long long o = ((long long)blockIdx.y * V + vi) * 3;
+    g_v[o] = ox; g_v[o + 1] = oy; g_v[o + 2] = oz;
+}
+
 }  // namespace
 
 extern "C" int a3d_normals_adjacency(const int32_t* tri, int V, int F, int32_t* off, int32_t* adj, int32_t* cursor, a3d_stream_t stream) {
@@ -266,6 +342,14 @@ extern "C" int a3d_normals_bwd(const float* g_nrm, int g_nrm_stride, const float
     A3D_CHECK_ARG(g_acc_scratch || face_scratch_or_null);
     A3D_CHECK_ARG(F == 0 || (tri && adj));
     hipStream_t s = (hipStream_t)stream;
+    if (face_scratch_or_null && F > 0 && a3d_exp() == 45) {  // (experiment builds only) one 12-byte vector per face in the same scratch
+        hipLaunchKernelGGL(nr_face12_bwd_kernel, dim3(a3d_div_up(F, 256), B), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, tri, V, F, face_scratch_or_null);
+        A3D_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nr_sum12_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, (const float*)face_scratch_or_null, v, tri, off, adj, V, F,
+                           g_v, lists_stride);
+        A3D_LAUNCH_CHECK();
+        return A3D_OK;
+    }
     if (face_scratch_or_null && F > 0) {  // faces first: every face once, then a sum per vertex (same bits as the gather form below)
         hipLaunchKernelGGL(nr_face_bwd_kernel, dim3(a3d_div_up(F, 256), B), dim3(256), 0, s, g_nrm, g_nrm_stride, acc, v, tri, V, F, face_scratch_or_null);
         A3D_LAUNCH_CHECK();

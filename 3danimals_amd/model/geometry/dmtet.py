@@ -32,6 +32,7 @@ except ImportError:  # stand-alone: same classes / state_dict layout from hostne
 
 
 SURFACE_BUCKET = 1024  # row padding of the surface-adjacent SDF re-evaluation (0 = off)
+SURFACE_POINTS_IN_EMIT = os.environ.get("A3D_SURFACE_POINTS_IN_EMIT", "1") != "0"  # the rows of that block written by the DMTet emit launch
 
 
 class TetGridTopology:
@@ -475,11 +476,18 @@ class DMTetGeometry(torch.nn.Module):
             sdf0 = self.get_sdf(pos, total_iter=total_iter, feats=feats)
         # idx = the grid vertices at the ends of crossing edges, sorted and unique; their count arrives with the DMTet counts (the
         # mask + torch.nonzero this replaces was a second host synchronisation per step)
+        fused = pos.is_cuda and pos.dtype == torch.float32 and sdf0.dim() == 2 and sdf0.shape[1] == 1
+        if fused and SURFACE_BUCKET and SURFACE_POINTS_IN_EMIT and pos.is_contiguous():
+            # (round 6) the emit launch itself leaves the positions as the bucket-padded block (zero rows behind, so that the MLP's GEMM
+            # shapes repeat from step to step), and one node splices the re-evaluated values in: forward no launch at all, backward one gather
+            verts0, faces, uv_idx, vert_edge, idx, pts = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True, for_backward=True,
+                                                                           surface_points=SURFACE_BUCKET)
+            sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)
+            self.current_sdf = ops.surface_sdf(sdf0, idx, sdf_sub)
+            return ops.dmtet_verts(pos, self.current_sdf, verts0, vert_edge, self.topology), faces, uv_idx
         verts0, faces, uv_idx, vert_edge, idx = ops.dmtet_extract(pos, sdf0, self.topology, surface_vertices=True, for_backward=True)
         n_pad = (-idx.shape[0]) % SURFACE_BUCKET if SURFACE_BUCKET else 0
-        if pos.is_cuda and pos.dtype == torch.float32 and sdf0.dim() == 2 and sdf0.shape[1] == 1:
-            # (round 6) one launch gathers the positions into the bucket-padded list (zero rows behind, so that the MLP's GEMM shapes repeat
-            # from step to step), and one node splices the re-evaluated values in: forward no kernel at all, backward one gather
+        if fused:
             pts = ops.gather_rows_padded(pos, idx, idx.shape[0] + n_pad)
             sdf_sub = self.get_sdf(pts, total_iter=total_iter, feats=feats)
             self.current_sdf = ops.surface_sdf(sdf0, idx, sdf_sub)

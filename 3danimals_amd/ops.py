@@ -195,12 +195,15 @@ def dmtet_count_only(pos, sdf, grid, surface_vertices=False):
     return counts
 
 
-def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
+def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False, surface_points=0):
     """Topology + vertex placement, no autograd: (verts [V,3], faces int64 [F,3], uv_idx int64 [F,3], vert_edge int32 [V]).
     ``surface_vertices``: also the sorted int64 list of the grid vertices at the ends of sign-crossing edges (their count rides in the
     same read-back as V, n1, n2: no torch.nonzero, no second host synchronisation).
     ``for_backward``: a dmtet_verts(...) on this extraction will be differentiated -- its dense SDF gradient buffer is allocated now and
-    cleared by the emit launch (picked up by dmtet_verts through the returned vert_edge tensor)."""
+    cleared by the emit launch (picked up by dmtet_verts through the returned vert_edge tensor).
+    ``surface_points`` = bucket > 0 (with surface_vertices): a sixth result, pos[idx] as a block of round_up(len(idx), bucket) rows with
+    zero rows behind, written by the emit launch itself (a3d_dmtet_emit_opts.surf_pts)."""
+    assert not surface_points or surface_vertices
     require_device(pos, sdf, grid.edges32, what="dmtet")
     pos_c, sdf_c = f32c(pos.detach()), f32c(sdf.detach()).reshape(-1)
     Ne, Nt, Nv = grid.edges32.shape[0], grid.tets32.shape[0], pos_c.shape[0]
@@ -230,9 +233,11 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     which = _dmtet_count(sdf_c, pos_c, grid, scratch, counts, vscratch, vclean, counters)
 
     def alloc(Vn, Fn, n_surf_n):
+        rows = -(-n_surf_n // surface_points) * surface_points if surface_points else 0
         return (torch.empty((Vn, 3), dtype=torch.float32, device=dev), torch.empty((Vn,), dtype=torch.int32, device=dev),
                 torch.empty((Fn, 3), dtype=torch.int64, device=dev), torch.empty((Fn, 3), dtype=torch.int64, device=dev),
-                torch.empty((n_surf_n,), dtype=torch.int64, device=dev) if surface_vertices else None)
+                torch.empty((n_surf_n,), dtype=torch.int64, device=dev) if surface_vertices else None,
+                torch.empty((rows, 3), dtype=torch.float32, device=dev) if surface_points else None)
 
     g_sdf = torch.empty((Nv,), dtype=torch.float32, device=dev) if for_backward else None
 
@@ -243,7 +248,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
                                   g_sdf_to_clear=ptr(g_sdf), tri32=ptr(tri32_t), topo_count=ptr(cnt_t), topo_adj=ptr(adj_t),
                                   device_counts=ptr(dev_counts), n_surf=n_surf_n if surface_vertices else 0, topo_stride=stride_n,
                                   use_block_lists=int(use_lists), n_edge_blocks_listed=listed[0] if use_lists else 0,
-                                  n_tet_blocks_listed=listed[1] if use_lists else 0)
+                                  n_tet_blocks_listed=listed[1] if use_lists else 0, surf_bucket=int(surface_points), surf_pts=ptr(bufs[5]))
         call("a3d_dmtet_emit_sparse" if which == "ordered" else "a3d_dmtet_emit", ptr(pos_c), ptr(sdf_c), ptr(grid.edges32), ptr(grid.tet2edge32), Ne, Nt,
              ptr(scratch), Vn, n1n, n2n, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ctypes.addressof(opts), stream())
 
@@ -257,7 +262,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         cap = lambda n, unit: max(unit, -(-int(1.25 * n) // unit) * unit)
         items = _lib.lib().a3d_dmtet_block_items()
         nbe, nbt = -(-Ne // items), -(-Nt // items)
-        capV, capF, capS = min(cap(last[0], 256), counters.shape[0]), cap(last[1] + 2 * last[2], 256), cap(last[3], 256)
+        capV, capF, capS = min(cap(last[0], 256), counters.shape[0]), cap(last[1] + 2 * last[2], 256), cap(last[3], max(256, int(surface_points)))
         capE, capT = min(cap(last[4], 16), nbe), min(cap(last[5], 16), nbt)
         if last[0] > 0 and last[1] + last[2] > 0 and (last[4] >= 0 or which == "ordered") and capV * stride < 2 ** 31:
             bufs = alloc(capV, capF, capS)
@@ -277,13 +282,14 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         bufs, tri32_b, adj_b = spec[5], spec[6], spec[7]
         verts, vert_edge, faces, uv_idx = bufs[0][:V], bufs[1][:V], bufs[2][:F], bufs[3][:F]
         idx = bufs[4][:n_surf] if surface_vertices else None
+        pts = bufs[5][:-(-n_surf // surface_points) * surface_points] if surface_points else None
         tri32 = tri32_b[:F]
         adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, adj_b, stride))
         _adj_cache.put(tri32, adj)
         _topo_cache.put(tri32, AATopology(tri32, V, build=False, lists=adj))
         _tri32_cache.put(faces, tri32)
     else:
-        verts, vert_edge, faces, uv_idx, idx = alloc(V, F, n_surf)
+        verts, vert_edge, faces, uv_idx, idx, pts = alloc(V, F, n_surf)
         emit_lists = counters is not None and F > 0 and 0 < V <= counters.shape[0] and V * stride < 2 ** 31
         # fallback (the guess at V was too small, or a grid with very many tets around an edge): the emit launch only counts the valences
         # and ONE more launch (a3d_mesh_topology_finalize) scans them and fills CSR lists -- instead of the conversion kernel + the four
@@ -299,7 +305,7 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
         if cur is not None:
             tri32 = torch.empty((F, 3), dtype=torch.int32, device=dev)
         try:
-            emit(V, n1, n2, (verts, vert_edge, faces, uv_idx, idx), n_surf, tri32, cur, lists_adj, stride if emit_lists else 0, (listed_e, listed_t), None)
+            emit(V, n1, n2, (verts, vert_edge, faces, uv_idx, idx, pts), n_surf, tri32, cur, lists_adj, stride if emit_lists else 0, (listed_e, listed_t), None)
             adj = None
             if emit_lists:
                 adj = VertexFaceAdjacency(tri32, V, build=False, lists=(counters, lists_adj, stride))
@@ -323,6 +329,8 @@ def dmtet_extract(pos, sdf, grid, surface_vertices=False, for_backward=False):
     if len(_dm_vertex_scratch) >= 4:
         _dm_vertex_scratch.clear()
     _dm_vertex_scratch[vkey] = vscratch  # only after a completed count + emit pair (a failed call leaves the buffer out of the cache)
+    if surface_points:
+        return verts, faces, uv_idx, vert_edge, idx, pts
     return verts, faces, uv_idx, vert_edge, idx
 
 

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef void* a3d_stream_t;
 
-int a3d_version(void); /* 403 = this header */
+int a3d_version(void); /* 404 = this header */
 const char* a3d_last_error(void);
 
 /* Box fingerprint for the benchmark line (no reference counterpart: the reference's meter, /root/reference/model/utils/meters.py:119, reports
@@ -123,7 +123,8 @@ typedef struct a3d_dmtet_emit_opts {
     int32_t use_block_lists;      /* a3d_dmtet_emit only: 1 = cover only the non-empty blocks the culled count pass listed ... */
     int32_t n_edge_blocks_listed; /* ... = counts[4] of that a3d_dmtet_count call (speculative launch: a capacity) */
     int32_t n_tet_blocks_listed;  /* ... = counts[5] */
-    int32_t reserved;
+    int32_t surf_bucket;          /* (404) with surf_pts: the row padding of that block (> 0; a speculative n_surf must be a multiple of it) */
+    float* surf_pts;              /* (404) [round_up(n_surf, surf_bucket), 3] = pos[surf_idx[i]], zero rows behind -- or NULL (see below) */
 } a3d_dmtet_emit_opts;
 int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edges, const int32_t* tet2edge, int Ne, int Nt,
                           const void* scratch, int V, int n1, int n2, float* verts, int32_t* vert_edge, int64_t* faces, int64_t* uv_idx,
@@ -150,6 +151,9 @@ int a3d_dmtet_emit_sparse(const float* pos, const float* sdf, const int32_t* edg
  * again: a caller that hands the same vertex_scratch to the next count on the same stream passes vertex_scratch_is_clean = 1 and
  * saves its memset.  Replaces a mask + torch.nonzero and its own host synchronisation. */
 size_t a3d_dmtet_vertex_scratch_bytes(int Nv);
+/* (404) surf_pts / surf_bucket: the emit launch also leaves the grid POSITIONS of the listed vertices as a zero-padded block (the rows
+ * the SDF network is re-evaluated on, dmtet.py:228-250 through DMTetGeometry._get_mesh_surface_backward) -- the forward one of the two
+ * a3d_dmtet_gather_rows launches below is then not needed. */
 /* (403) ... and the rows of that list gathered into a zero-padded block: out[rows,C] = src[idx[i],:] for i < n, zeros behind (the grid
  * positions the field is re-evaluated at, forward; the SDF gradient at those vertices, backward -- dmtet.py:228-250 evaluates the field
  * on every grid vertex with a graph; see DMTetGeometry._get_mesh_surface_backward). */

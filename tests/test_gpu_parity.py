@@ -1464,12 +1464,17 @@ def test_speculative_dmtet_emit_equals_the_exact_one(numbering, dev, ops, mods, 
     for trial, r in enumerate(radii):
         sdf = (r - pos.norm(dim=-1) + 0.05 * seeded((pos.shape[0],), 90 + trial, -1, 1)).to(dev)
         monkeypatch.setattr(ops, "DMTET_SPECULATIVE_EMIT", True)
-        a = ops.dmtet_extract(pos_d, sdf, spec_topo, surface_vertices=True)
+        a = ops.dmtet_extract(pos_d, sdf, spec_topo, surface_vertices=True, surface_points=512)
         tri_a = ops._tri32_cache.peek(a[1]) if a[1].shape[0] else None
         monkeypatch.setattr(ops, "DMTET_SPECULATIVE_EMIT", False)
-        b = ops.dmtet_extract(pos_d, sdf, exact_topo, surface_vertices=True)
+        b = ops.dmtet_extract(pos_d, sdf, exact_topo, surface_vertices=True, surface_points=512)
         for x, y in zip(a, b):
             assert x.shape == y.shape and torch.equal(x, y), (trial, r)
+        # (round 6) the surface rows the emit launch leaves for the SDF re-evaluation: pos[idx], zero rows up to the bucket
+        idx, pts = a[4], a[5]
+        assert pts.shape == (-(-idx.shape[0] // 512) * 512, 3) and torch.equal(pts[: idx.shape[0]], pos_d[idx])
+        assert pts.shape[0] == idx.shape[0] or float(pts[idx.shape[0]:].abs().max()) == 0.0
+        assert torch.equal(pts, ops.gather_rows_padded(pos_d, idx, pts.shape[0]))
         took.append(a[0].shape[0] > 0 and a[0].untyped_storage().nbytes() > a[0].numel() * 4)  # a view into a larger buffer = speculative
         if a[1].shape[0]:
             n_a = ops.vertex_normals(a[0][None], a[1])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()  # loads here without a GPU (links libamdhip64 only)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.a3d_version() == L.ABI_VERSION == 403
+    assert lib.a3d_version() == L.ABI_VERSION == 404
     assert isinstance(lib.a3d_last_error(), bytes)
     assert lib.a3d_dmtet_scratch_bytes(238688, 196608) >= 4 * (234 + 2 * 192)
     assert lib.a3d_aa_hash_bytes(1000) >= 16 * 6000

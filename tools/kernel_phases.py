@@ -25,7 +25,7 @@ import torch  # noqa: E402
 # name -> (translation unit, kernel id, {slot: label of the phase that ENDS at that slot})
 KERNELS = {
     "dm_sign": ("dmtet", 0, {5: "whole kernel"}),
-    "dm_count_cull": ("dmtet", 1, {1: "group fields of the sign plane (2 dependent loads) + ballots", 2: "barrier", 5: "blocks that hold crossings"}),
+    "dm_count_cull": ("dmtet", 1, {1: "group fields of the sign plane (2 dependent loads) + ballots", 2: "barrier", 5: "blocks that hold crossings", 6: "acknowledgements + ticket (folded scan)", 7: "scan tail (the last work-group only)"}),
     "dm_emit": ("dmtet", 3, {1: "counts from the device + clear", 5: "a slab with surface: planes -> rows -> vertices / faces"}),
     "dm_bwd": ("dmtet", 4, {5: "whole kernel"}),
     "sk_fwd": ("skin", 0, {1: "links + bones into LDS", 2: "chain products", 3: "logits of the first group + barrier", 5: "softmax, blend, store"}),

@@ -21,7 +21,8 @@ from collections import defaultdict
 # entry point -> (kernels of one call, kernel whose dispatch count = number of calls)
 ENTRY = {
     # (the culled form -- sign plane, culled count, scan -- on grids with word groups; the plain count otherwise)
-    "a3d_dmtet_count": (["dm_sign_kernel", "dm_count_cull_kernel", "dm_count_kernel", "dm_scan_kernel"], "dm_scan_kernel"),
+    # (round 6: the scan rides in the culled count launch -- one dm_sign_kernel per call there; the plain form has no sign pre-pass below 2^20 vertices)
+    "a3d_dmtet_count": (["dm_sign_kernel", "dm_count_cull_kernel", "dm_count_kernel", "dm_scan_kernel"], "dm_sign_kernel"),
     "a3d_dmtet_emit": (["dm_emit_kernel"], "dm_emit_kernel"),
     "a3d_dmtet_bwd": (["dm_bwd_kernel"], "dm_bwd_kernel"),
     "a3d_skin_fwd": (["sk_fwd_kernel<20, false>", "sk_fwd_kernel<32, false>", "sk_fwd_kernel<64, false>"], None),
@@ -35,7 +36,7 @@ ENTRY = {
     "a3d_mesh_topology": (["tp_init_kernel", "tp_count_insert_kernel", "nr_adj_scan_kernel", "tp_fill_lookup_kernel", "nr_adj_sort_kernel"],
                           "nr_adj_scan_kernel"),
     "a3d_normals_fwd": (["nr_fwd_kernel"], "nr_fwd_kernel"),
-    "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel", "nr_face_bwd_kernel", "nr_sum_bwd_kernel"], "nr_sum_bwd_kernel"),
+    "a3d_normals_bwd": (["nr_vert_bwd_kernel", "nr_bwd_kernel", "nr_face_bwd_kernel", "nr_sum_bwd_kernel", "nr_face12_bwd_kernel", "nr_sum12_bwd_kernel"], ("nr_sum_bwd_kernel", "nr_sum12_bwd_kernel", "nr_bwd_kernel")),
     # (the triangle launch also carries the vertex normals of the step: nr_fwd's work as extra work-groups)
     "a3d_rast_fwd": (["rs_clear_kernel", "rs_tri_kernel", "rs_resolve_kernel"], "rs_tri_kernel"),
     # (round 5: the resolve of a deferred rasterisation + the covered-pixel list + the G-buffer rows, one launch)
@@ -100,7 +101,8 @@ def main():
                 return None
             # (the kernel that runs once per call, by PREFIX: template arguments are part of the name -- an exact match missed
             # rs_tri_kernel<4> and the sum was divided by the dispatches of both kernels, i.e. halved: round 3's 27 MB for a3d_rast_fwd)
-            calls = sum(cnt[k] for k in cnt if k == main_k or k.startswith(main_k + "<")) if main_k else sum(cnt[k] for k in ks)
+            mains = (main_k,) if isinstance(main_k, str) else (main_k or ())
+            calls = sum(cnt[k] for k in cnt if any(k == m or k.startswith(m + "<") for m in mains)) if mains else sum(cnt[k] for k in ks)
             calls = calls or sum(cnt[k] for k in ks)
             return sum(tot[k] for k in ks) / calls
         fe, wr = pick(fetch, fcnt), pick(write, wcnt)
