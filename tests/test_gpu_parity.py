@@ -1132,7 +1132,8 @@ def test_full_size_workloads_stagewise_parity(workload, kw, n, dev):
 
 def test_training_step_hot_path_calls_are_pinned(dev):
     """The structure DESIGN.md section 4 describes, pinned: a steady-state magicpony training step at the bench size calls exactly these
-    16 hot-path entry points (8 forward, 9 backward; the row gather of the surface-adjacent grid vertices once each way), once each -- no topology launch (the DMTet emit writes the lists), no normals
+    16 hot-path entry points (7 forward, 9 backward; the row gather of the surface-adjacent grid vertices only backward -- ABI 404: the DMTet emit
+    leaves the forward rows itself), once each -- no topology launch (the DMTet emit writes the lists), no normals
     launch (they ride in the rasteriser's), no analysis launch (it rides in the compositor's), no shading launch forward (round 4: the
     compositor computes the colour of a covered pixel itself) -- and the forward-only step 7.  Round 6: the clip transform is a call of
     the path (it was a torch bmm each way that nobody counted), and the shading adjoint is launched by the compositor's backward node
@@ -1154,7 +1155,7 @@ def test_training_step_hot_path_calls_are_pinned(dev):
     assert train == {"a3d_dmtet_count": 1, "a3d_dmtet_emit": 1, "a3d_skin_pose_fwd": 1, "a3d_xfm_points_fwd": 1, "a3d_rast_fwd[N16+1][defer]": 1,
                      "a3d_rast_resolve_gbuffer_fwd": 1, "a3d_composite_aa_fwd[C4+C17>16][+shade][+analysis]": 1, "a3d_composite_aa_bwd[C4+C17>16]": 1,
                      "a3d_shade_bwd_rows": 1, "a3d_gbuffer_bwd": 1, "a3d_xfm_points_bwd": 1, "a3d_normals_bwd[B16]": 1, "a3d_skin_pose_bwd": 1,
-                     "a3d_dmtet_bwd": 1, "a3d_dmtet_gather_rows": 2, "a3d_gbuffer_prior_grad": 1}, train
+                     "a3d_dmtet_bwd": 1, "a3d_dmtet_gather_rows": 1, "a3d_gbuffer_prior_grad": 1}, train
     with torch.no_grad():
         fwd = calls(False)
     # (forward only: no graph is wanted, the field is evaluated on the whole grid once -- no surface re-evaluation, no row gather)
