@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void xf_fwd_kernel(const float* __restrict__ p
 
 __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g, int g_stride, const float* __restrict__ points, int points_batch,
                                                      const float* __restrict__ M, int m_batch, int V, float* __restrict__ g_points,
-                                                     float* __restrict__ g_M, const float* __restrict__ addend, int addend_stride) {
+                                                     float* __restrict__ g_M, const float* __restrict__ addend, int addend_stride,
+                                                     const float* __restrict__ addend2, int addend2_stride, const float* __restrict__ g2, int g2_stride) {
     __shared__ float s_red[16][17];
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     const bool live = v < V;
@@ -35,7 +36,12 @@ __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g
     for (int k = 0; k < 16; ++k) gm[k] = 0.f;
     if (live) {
         const float* gp = g + ((long long)b * V + v) * g_stride;
-        const float gi[4] = {gp[0], gp[1], gp[2], gp[3]};
+        float gi[4] = {gp[0], gp[1], gp[2], gp[3]};
+        if (g2) {  // (404) the clip positions' second gradient -- the antialiasing's, render.py:264-268 -- summed here, not by the engine
+            const float* q = g2 + ((long long)b * V + v) * g2_stride;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gi[i] = q[i] + gi[i];
+        }
         const float* m = M + (m_batch == 1 ? 0 : 16 * b);
         if (g_points) {
             float* o = g_points + ((long long)b * V + v) * 3;
@@ -43,6 +49,11 @@ __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g
             for (int j = 0; j < 3; ++j) o[j] = gi[0] * m[j] + gi[1] * m[4 + j] + gi[2] * m[8 + j] + gi[3] * m[12 + j];
             if (addend) {  // a second gradient of the same points (their other consumer's), summed on the way out: no accumulation launch
                 const float* a = addend + ((long long)b * V + v) * addend_stride;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o[j] += a[j];
+            }
+            if (addend2) {  // ... and a third (404: the one the vertex normals' backward produced for the same points)
+                const float* a = addend2 + ((long long)b * V + v) * addend2_stride;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) o[j] += a[j];
             }
@@ -97,15 +108,18 @@ extern "C" int a3d_xfm_points_fwd(const float* points, int points_batch, const f
 
 extern "C" int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, int points_batch, const float* matrix, int matrix_batch,
                                   int B, int V, float* g_points_or_null, float* g_matrix_or_null, int g_matrix_is_clear,
-                                  const float* g_points_addend_or_null, int addend_stride, a3d_stream_t stream) {
+                                  const float* g_points_addend_or_null, int addend_stride, const float* g_points_addend2_or_null,
+                                  int addend2_stride, const float* g_out2_or_null, int g2_stride, a3d_stream_t stream) {
+    A3D_CHECK_ARG(!g_out2_or_null || g2_stride >= 4);
     A3D_CHECK_ARG(!g_points_addend_or_null || (addend_stride >= 3 && g_points_or_null && points_batch == B));
+    A3D_CHECK_ARG(!g_points_addend2_or_null || (addend2_stride >= 3 && g_points_or_null && points_batch == B));
     A3D_CHECK_ARG(B > 0 && V >= 0 && B <= 65535 && g_stride >= 4 && (points_batch == 1 || points_batch == B) && (matrix_batch == 1 || matrix_batch == B));
     hipStream_t s = (hipStream_t)stream;
     if (g_matrix_or_null && !g_matrix_is_clear) A3D_HIP(hipMemsetAsync(g_matrix_or_null, 0, sizeof(float) * 16 * (size_t)matrix_batch, s));
     if (V == 0 || (!g_points_or_null && !g_matrix_or_null)) return A3D_OK;
     A3D_CHECK_ARG(g_out && points && matrix);
     hipLaunchKernelGGL(xf_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_out, g_stride, points, points_batch, matrix, matrix_batch, V,
-                       g_points_or_null, g_matrix_or_null, g_points_addend_or_null, addend_stride);
+                       g_points_or_null, g_matrix_or_null, g_points_addend_or_null, addend_stride, g_points_addend2_or_null, addend2_stride, g_out2_or_null, g2_stride);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -89,13 +89,16 @@ class Mesh:
             job.v_b = ops.f32c(job.partner.v_pos.detach())
         return job
 
-    def take_normals(self, job):
-        """Adopt the results of a job the rasteriser ran (nothing happens if it did not: the lazy path stays armed)."""
+    def take_normals(self, job, graph_pos=None):
+        """Adopt the results of a job the rasteriser ran (nothing happens if it did not: the lazy path stays armed).  ``graph_pos``: the
+        same positions as another output of the clip transform's node (ops.xfm_points(alias=2)) -- the normals' gradient then arrives at
+        that node's backward launch instead of at an accumulation kernel in front of it."""
         if not job.done or self._v_nrm is not None:
             return
         partner = job.partner
+        v_self = self.v_pos if graph_pos is None or graph_pos.shape != self.v_pos.shape else graph_pos
         with torch.set_grad_enabled(self._lazy_nrm):
-            nrm_a, nrm_b = ops.vertex_normals_attach(self.v_pos, None if partner is None else partner.v_pos, job)
+            nrm_a, nrm_b = ops.vertex_normals_attach(v_self, None if partner is None else partner.v_pos, job)
         self._v_nrm, self._lazy_nrm = nrm_a, None
         if partner is not None and partner._v_nrm is None and partner._lazy_nrm is not None:
             partner._v_nrm, partner._lazy_nrm = nrm_b, None

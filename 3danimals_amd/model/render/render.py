@@ -443,12 +443,14 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
     view_pos = torch.tensor(view_pos, dtype=torch.float32, device=dev) if not torch.is_tensor(view_pos) else view_pos
     view_pos = view_pos[:, None, None, :] if view_pos.dim() == 2 else view_pos
 
-    v_pos_attr = None
+    v_pos_attr = v_pos_nrm = clip_aa = None
     if ALIAS_POSITIONS and spp == 1 and num_layers == 1 and mesh.v_pos.is_cuda and ru.ops._hip_xfm_ok(mesh.v_pos, mtx_in) and mesh.v_pos.shape[0] == mtx_in.shape[0] \
             and not torch.is_autocast_enabled():
         # the clip transform's node hands the positions out once more for the G-buffer's position attribute: their two gradients (through
         # clip space, through the interpolated position) meet inside that node's ONE backward launch, not in an accumulation kernel
-        v_pos_clip, v_pos_attr = ops.xfm_points(mesh.v_pos, mtx_in, alias=True)  # [B,V,4]
+        # (... and a third time for the pending vertex normals, whose backward is the positions' third gradient)
+        # (... and the clip positions themselves a second time, for the antialiasing, whose gradient w.r.t. them is their second one)
+        v_pos_clip, v_pos_attr, v_pos_nrm, clip_aa = ops.xfm_points(mesh.v_pos, mtx_in, alias=3)  # [B,V,4]
     else:
         v_pos_clip = ru.xfm_points(mesh.v_pos, mtx_in, use_python=True)  # [B,V,4]
 
@@ -474,7 +476,7 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
              and mesh.t_nrm_idx.data_ptr() == mesh.t_pos_idx.data_ptr() and full_res[0] % 8 == 0 and full_res[1] % 8 == 0)
     rast = ops.rasterize(clip_f, tri, full_res, normals_job=job, defer_resolve=defer)
     if job is not None:
-        mesh.take_normals(job)
+        mesh.take_normals(job, graph_pos=v_pos_nrm)
     LAST_RAST[0] = rast.detach()  # introspection hook for benchmarks / debugging (coverage, ids)
     LAST_POINTS[0] = None
     if mask_only:
@@ -530,15 +532,17 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
             return None if n is None else (vals.shape[-1] if n == -1 else n)
 
         recipe = getattr(rendered, "shade_recipe", None)
+        # (the antialiasing differentiates w.r.t. the clip positions: it takes them as the clip transform's OTHER clip output, same storage)
+        clip_of_aa = clip_f if clip_aa is None or clip_aa.dtype != clip_f.dtype else clip_aa
         for i in range(0, len(fuse_keys), 2):
             ka, kb = fuse_keys[i], (fuse_keys[i + 1] if i + 1 < len(fuse_keys) else None)
             vb = rendered.peek(kb) if (kb is not None and not (kb == "shaded" and recipe is not None)) else (rendered[kb] if kb is not None else None)
             if ka == "shaded" and recipe is not None and not dict.__contains__(rendered, "shaded"):  # (only the FIRST buffer of a call can be shaded on the fly)
-                res = ops.shade_composite_antialias(recipe, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, vals2=vb,
+                res = ops.shade_composite_antialias(recipe, rendered.pix, rendered.inv, bg_of(ka), clip_of_aa, analysis, vals2=vb,
                                                     background2=None if kb is None else bg_of(kb), keep2=None if kb is None else keep(kb, vb))
             else:
                 va = rendered.peek(ka) if dict.__contains__(rendered, ka) else rendered[ka]
-                res = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_f, analysis, vals2=vb,
+                res = ops.composite_antialias(va, rendered.pix, rendered.inv, bg_of(ka), clip_of_aa, analysis, vals2=vb,
                                               background2=None if kb is None else bg_of(kb), keep=keep(ka, va), keep2=None if kb is None else keep(kb, vb))
             if kb is None:
                 fused[ka] = res

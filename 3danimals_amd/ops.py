@@ -748,14 +748,21 @@ class _XfmPoints(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # ``alias``: the points once more as a second output (no copy) for their OTHER consumer in render_mesh (the G-buffer's position
         # attribute): both gradients then arrive at this node and are summed inside its one backward launch, instead of by an accumulation
-        # kernel of the autograd engine in front of it
-        return (out, points.detach()) if alias and Bp == B else (out, None)
+        # kernel of the autograd engine in front of it.  alias = 2: ... and a third output for their third consumer, the vertex normals.
+        # alias = 3: ... and the CLIP positions a second time, for the consumer beside the rasteriser / G-buffer: the antialiasing.
+        if alias and Bp == B:
+            return out, points.detach(), (points.detach() if int(alias) >= 2 else None), (out.detach() if int(alias) >= 3 else None)
+        return out, None, None, None
 
     @staticmethod
-    def backward(ctx, g, g_alias=None):
+    def backward(ctx, g, g_alias=None, g_alias2=None, g_second=None):
         points, matrix = ctx.saved_tensors
         Bp, V, Bm = points.shape[0], points.shape[1], matrix.shape[0]
         B = max(Bp, Bm)
+        if g_alias is None and g_alias2 is not None:
+            g_alias, g_alias2 = g_alias2, None
+        if g is None and g_second is not None:
+            g, g_second = g_second, None
         if g is None:
             if g_alias is None:
                 return None, None, None
@@ -765,6 +772,10 @@ class _XfmPoints(torch.autograd.Function):
             g = f32c(g)
         if g_alias is not None and (g_alias.dtype != torch.float32 or g_alias.stride(2) != 1 or g_alias.stride(1) < 3 or g_alias.stride(0) != V * g_alias.stride(1)):
             g_alias = f32c(g_alias)
+        if g_second is not None and (g_second.dtype != torch.float32 or g_second.stride(2) != 1 or g_second.stride(1) < 4 or g_second.stride(0) != V * g_second.stride(1)):
+            g_second = f32c(g_second)
+        if g_alias2 is not None and (g_alias2.dtype != torch.float32 or g_alias2.stride(2) != 1 or g_alias2.stride(1) < 3 or g_alias2.stride(0) != V * g_alias2.stride(1)):
+            g_alias2 = f32c(g_alias2)
         g_p = torch.empty((B, V, 3), dtype=torch.float32, device=points.device) if ctx.needs_input_grad[0] else None
         g_M, ctx.g_M = ctx.g_M, None  # the cleared buffer serves ONE backward
         clear = g_M is not None
@@ -773,7 +784,8 @@ class _XfmPoints(torch.autograd.Function):
         if g_alias is not None and g_p is None:
             g_p = torch.empty((B, V, 3), dtype=torch.float32, device=points.device)
         call("a3d_xfm_points_bwd", ptr(g), g.stride(1), ptr(points), Bp, ptr(matrix), Bm, B, V, ptr(g_p), ptr(g_M), int(clear), ptr(g_alias),
-             0 if g_alias is None else g_alias.stride(1), stream())
+             0 if g_alias is None else g_alias.stride(1), ptr(g_alias2), 0 if g_alias2 is None else g_alias2.stride(1), ptr(g_second),
+             0 if g_second is None else g_second.stride(1), stream())
         if g_p is not None and Bp == 1 and B > 1:
             g_p = g_p.sum(0, keepdim=True)
         return g_p, g_M, None
@@ -781,8 +793,12 @@ class _XfmPoints(torch.autograd.Function):
 
 def xfm_points(points, matrix, alias=False):
     """points [1|B,V,3], matrix [1|B,4,4] -> [B,V,4] homogeneous clip-space positions.  ``alias``: -> (clip, the points as a second output
-    of the same node or None): see _XfmPoints."""
-    out, again = _XfmPoints.apply(points, matrix, alias)
+    of the same node or None); alias = 2: -> (clip, second output, third output); alias = 3: -> (..., clip once more): see _XfmPoints."""
+    out, again, third, out_again = _XfmPoints.apply(points, matrix, alias)
+    if int(alias) >= 3:
+        return out, again, third, out_again
+    if int(alias) == 2:
+        return out, again, third
     return (out, again) if alias else out
 
 

@@ -696,7 +696,15 @@ int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, in
                        const float* g_points_addend_or_null /* [B,V,3] with a vertex stride of addend_stride floats, added to g_points: the
                                                                gradient the same points get from their other consumer in render_mesh (the
                                                                position columns of a3d_gbuffer_bwd's rows) -- no accumulation launch */,
-                       int addend_stride, a3d_stream_t stream);
+                       int addend_stride,
+                       const float* g_points_addend2_or_null /* (404) a third gradient of the same points, added after the second: the one
+                                                                a3d_normals_bwd wrote for the posed mesh (mesh.py:276-304 reads v_pos too) */,
+                       int addend2_stride,
+                       const float* g_out2_or_null /* (404) a second gradient of the clip positions themselves, [B,V,4] with a vertex stride of
+                                                      g2_stride floats: g_out2 + g_out is what is transformed (the antialiasing's gradient
+                                                      w.r.t. the clip positions, render.py:264-268, which otherwise meets the rasteriser's in
+                                                      an accumulation launch of the caller's autograd engine) */,
+                       int g2_stride, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }

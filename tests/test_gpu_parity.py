@@ -2845,6 +2845,51 @@ def test_xfm_points_kernel_matches_the_float64_matmul_and_its_gradients(Bp, Bm, 
         assert float((gm.double() - rm).abs().max()) < 1e-4 * max(1.0, float(rm.abs().max()))
 
 
+def test_xfm_points_aliases_sum_their_gradients_inside_the_backward_launch(dev, ops):
+    """ops.xfm_points(alias=True / 2): the points come back as a second (and third) output of the clip transform's node for their other
+    consumers in render_mesh -- the G-buffer's position attribute (gradient = columns of 16-float rows, read in place) and the vertex
+    normals (contiguous) -- and every gradient is added inside a3d_xfm_points_bwd: the same sum as autograd's accumulation of three
+    separate consumers, in float64; any subset of the three may be missing."""
+    B, V = 3, 515
+    pts = seeded((B, V, 3), 3, -1, 1).to(dev).requires_grad_(True)
+    mtx = (torch.eye(4)[None] + 0.3 * seeded((B, 4, 4), 4, -1, 1)).to(dev).requires_grad_(True)
+    rows = seeded((B, V, 16), 5, -1, 1).to(dev)
+    g_n = seeded((B, V, 3), 6, -1, 1).to(dev)
+    p64, m64 = pts.detach().double().requires_grad_(True), mtx.detach().double().requires_grad_(True)
+    ref = torch.matmul(torch.nn.functional.pad(p64, (0, 1), value=1.0), m64.transpose(1, 2))
+    for use in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (0, 0, 1), (0, 1, 0)):
+        clip, again, third = ops.xfm_points(pts, mtx, alias=2)
+        assert again.data_ptr() == pts.data_ptr() == third.data_ptr() and again is not third
+        loss = 0.0
+        loss64 = 0.0
+        if use[0]:
+            loss, loss64 = loss + (clip * rows[..., 12:16]).sum(), loss64 + (ref * rows[..., 12:16].double()).sum()
+        if use[1]:
+            loss, loss64 = loss + (again * rows[..., 0:3]).sum(), loss64 + (p64 * rows[..., 0:3].double()).sum()
+        if use[2]:
+            loss, loss64 = loss + (third * g_n).sum(), loss64 + (p64 * g_n.double()).sum()
+        (gp,) = torch.autograd.grad(loss, [pts])
+        (rp,) = torch.autograd.grad(loss64, [p64], retain_graph=True)
+        assert float((gp.double() - rp).abs().max()) < 1e-5 * max(1.0, float(rp.abs().max())), use
+    clip, again = ops.xfm_points(pts, mtx, alias=True)  # (the two-output form is unchanged)
+    assert again.data_ptr() == pts.data_ptr()
+    # alias = 3: the clip positions a second time (the antialiasing's operand): both clip gradients summed before the transform, also d/d matrix
+    g2 = seeded((B, V, 4), 7, -1, 1).to(dev)
+    for use in ((1, 1), (0, 1), (1, 0)):
+        clip, again, third, clip2 = ops.xfm_points(pts, mtx, alias=3)
+        assert clip2.data_ptr() == clip.data_ptr() and clip2 is not clip
+        loss = (again * rows[..., 0:3]).sum() + (third * g_n).sum()
+        loss64 = (p64 * rows[..., 0:3].double()).sum() + (p64 * g_n.double()).sum()
+        if use[0]:
+            loss, loss64 = loss + (clip * rows[..., 12:16]).sum(), loss64 + (ref * rows[..., 12:16].double()).sum()
+        if use[1]:
+            loss, loss64 = loss + (clip2 * g2).sum(), loss64 + (ref * g2.double()).sum()
+        gp, gm = torch.autograd.grad(loss, [pts, mtx])
+        rp, rm = torch.autograd.grad(loss64, [p64, m64], retain_graph=True)
+        assert float((gp.double() - rp).abs().max()) < 1e-5 * max(1.0, float(rp.abs().max())), use
+        assert float((gm.double() - rm).abs().max()) < 1e-4 * max(1.0, float(rm.abs().max())), use
+
+
 def test_compositor_hands_out_kept_channels_reads_strided_gradients_and_short_backgrounds(dev, ops, mods):
     """Round 6 plumbing of a3d_composite_aa_*: ``keep`` materialises only the leading channels a mode returns (dino_pred / flow without
     alpha) -- same values as the slice of the full image, same gradients as through the slice; value rows may carry padding rows behind
