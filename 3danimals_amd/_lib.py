@@ -46,6 +46,8 @@ SIGNATURES = {
     "a3d_shade_bwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _p, _c_int, _p]),
     "a3d_shade_bwd_rows": (_c_int, [_p, _p, _p, _p, _p, ctypes.c_int64, _p, _c_int, ctypes.c_int64, _c_int, _p, _p, _c_int, ctypes.c_int64, _p]),
     "a3d_xfm_points_fwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _p]),
+    "a3d_flow_delta_fwd": (_c_int, [_p, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_flow_delta_bwd": (_c_int, [_p, _c_int, _p, _c_int, _c_int, _c_int, _p, _p]),
     "a3d_xfm_points_bwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _p, _c_int, _p]),
     "a3d_cover_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "a3d_cover_blocks": (_c_int, [_c_int, _c_int, _c_int]),

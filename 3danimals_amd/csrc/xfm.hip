@@ -89,6 +89,44 @@ __global__ __launch_bounds__(256) void xf_bwd_kernel(const float* __restrict__ g
     }
 }
 
+// ---- per-vertex 2-D motion to the next frame (render.py:281-288): ndc = clip.xy / clip.w per frame, delta[b,f] = ndc[b,f+1] - ndc[b,f],
+// zeros for a sequence's last frame.  As torch ops: a slice, a division, a view, two slices, a subtraction, a zeros_like and a cat forward and
+// eleven slice / division / subtraction adjoints backward -- ~25 launches of 4-5 us for 2.4 MB (tools/glue_attribution.py, the Ponymation
+// step: ~100 us).  Here one thread per (frame, vertex) each way.
+__global__ __launch_bounds__(256) void xf_flow_fwd_kernel(const float4* __restrict__ clip, int N, int F, int V, float2* __restrict__ delta) {
+    const int n = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int f = n % F;
+    float2 d = make_float2(0.f, 0.f);
+    if (f + 1 < F) {
+        const float4 a = clip[(long long)n * V + v], b = clip[(long long)(n + 1) * V + v];
+        d.x = b.x / b.w - a.x / a.w;
+        d.y = b.y / b.w - a.y / a.w;
+    }
+    delta[(long long)n * V + v] = d;
+}
+
+// g_ndc[n] = g_delta[n-1] (not for a sequence's first frame) - g_delta[n] (not for its last);  ndc = xy / w:  g_xy = g_ndc / w,
+// g_w = -(g_ndc . xy / w) / w  (torch's div backward: -grad * (a / b) / b), g_z = 0
+// (g_delta with a vertex stride of g_stride floats: the gradient may be two columns of the G-buffer backward's 16-float rows, read in place)
+__global__ __launch_bounds__(256) void xf_flow_bwd_kernel(const float* __restrict__ g_delta, int g_stride, const float4* __restrict__ clip, int N, int F,
+                                                          int V, float4* __restrict__ g_clip) {
+    const int n = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int f = n % F;
+    const long long i = (long long)n * V + v;
+    float gx = 0.f, gy = 0.f;
+    if (f > 0) { const float* g = g_delta + (i - V) * g_stride; gx = g[0]; gy = g[1]; }
+    if (f + 1 < F) { const float* g = g_delta + i * g_stride; gx -= g[0]; gy -= g[1]; }
+    const float4 c = clip[i];
+    float4 o;
+    o.x = gx / c.w;
+    o.y = gy / c.w;
+    o.z = 0.f;
+    o.w = -(gx * (c.x / c.w)) / c.w + -(gy * (c.y / c.w)) / c.w;
+    g_clip[i] = o;
+}
+
 }  // namespace
 
 extern "C" int a3d_xfm_points_fwd(const float* points, int points_batch, const float* matrix, int matrix_batch, int B, int V, float* out,
@@ -120,6 +158,25 @@ extern "C" int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float*
     A3D_CHECK_ARG(g_out && points && matrix);
     hipLaunchKernelGGL(xf_bwd_kernel, dim3(a3d_div_up(V, 256), B), dim3(256), 0, s, g_out, g_stride, points, points_batch, matrix, matrix_batch, V,
                        g_points_or_null, g_matrix_or_null, g_points_addend_or_null, addend_stride, g_points_addend2_or_null, addend2_stride, g_out2_or_null, g2_stride);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_flow_delta_fwd(const float* clip, int N, int F, int V, float* delta, a3d_stream_t stream) {
+    A3D_CHECK_ARG(N > 0 && F > 0 && N % F == 0 && N <= 65535 && V >= 0);
+    if (V == 0) return A3D_OK;
+    A3D_CHECK_ARG(clip && delta && ((uintptr_t)clip & 15) == 0 && ((uintptr_t)delta & 7) == 0);
+    hipLaunchKernelGGL(xf_flow_fwd_kernel, dim3(a3d_div_up(V, 256), N), dim3(256), 0, (hipStream_t)stream, (const float4*)clip, N, F, V, (float2*)delta);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+}
+
+extern "C" int a3d_flow_delta_bwd(const float* g_delta, int g_stride, const float* clip, int N, int F, int V, float* g_clip, a3d_stream_t stream) {
+    A3D_CHECK_ARG(N > 0 && F > 0 && N % F == 0 && N <= 65535 && V >= 0 && g_stride >= 2);
+    if (V == 0) return A3D_OK;
+    A3D_CHECK_ARG(g_delta && clip && g_clip && ((uintptr_t)clip & 15) == 0 && ((uintptr_t)g_clip & 15) == 0);
+    hipLaunchKernelGGL(xf_flow_bwd_kernel, dim3(a3d_div_up(V, 256), N), dim3(256), 0, (hipStream_t)stream, g_delta, g_stride, (const float4*)clip, N, F, V,
+                       (float4*)g_clip);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
 }

@@ -38,6 +38,7 @@ FUSED_GBUFFER = True  # build the G-buffer of the covered pixels with one fused 
 FUSED_COVER_GBUFFER = True  # ... and the covered-pixel list in the same launch (a3d_cover_gbuffer_fwd) instead of a3d_cover_emit before it
 DEFER_RESOLVE = os.environ.get("A3D_DEFER_RESOLVE", "1") != "0"  # ... and the rasteriser's resolve in that launch too (a3d_rast_resolve_gbuffer_fwd)
 DEFER_ANALYSIS = os.environ.get("A3D_DEFER_ANALYSIS", "1") != "0"  # the silhouette analysis as extra work-groups of the compositor's first launch
+FUSED_FLOW_DELTA = os.environ.get("A3D_FUSED_FLOW_DELTA", "1") != "0"  # 'flow': the per-vertex motion to the next frame as one launch each way (ops.flow_delta)
 FUSED_MASK_RENDER = True  # a render without material, light and feature field whose only mode is 'shaded' skips the G-buffer: ops.mask_antialias
 FUSED_SHADING = True
 ALIAS_POSITIONS = os.environ.get("A3D_ALIAS_POSITIONS", "1") != "0"  # the clip transform's node feeds the G-buffer's position attribute too (one accumulation launch less)
@@ -455,7 +456,10 @@ def render_mesh(ctx, mesh, mtx_in, w2c, view_pos, material, lgt, resolution, spp
         v_pos_clip = ru.xfm_points(mesh.v_pos, mtx_in, use_python=True)  # [B,V,4]
 
     delta_xy = None
-    if "flow" in render_modes:  # 2-D motion of each vertex to the next frame (render.py:281-288)
+    if "flow" in render_modes and FUSED_FLOW_DELTA and v_pos_clip.is_cuda and v_pos_clip.dtype == torch.float32 and num_frames > 1 and v_pos_clip.shape[0] % num_frames == 0 \
+            and not torch.is_autocast_enabled():
+        delta_xy = ops.flow_delta(v_pos_clip, num_frames)  # the expression below as ONE launch each way (a3d_flow_delta_*)
+    elif "flow" in render_modes:  # 2-D motion of each vertex to the next frame (render.py:281-288)
         ndc = v_pos_clip[..., :2] / v_pos_clip[..., -1:]
         ndc = ndc.view(-1, num_frames, *ndc.shape[1:])
         delta_xy = ndc[:, 1:] - ndc[:, :-1]

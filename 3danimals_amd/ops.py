@@ -802,6 +802,37 @@ def xfm_points(points, matrix, alias=False):
     return (out, again) if alias else out
 
 
+class _FlowDelta(torch.autograd.Function):
+    """delta_xy of render_mesh (render.py:281-288) from the clip positions: one launch each way (csrc/xfm.hip)."""
+
+    @staticmethod
+    def forward(ctx, clip, num_frames):
+        require_device(clip, what="flow_delta")
+        clip = f32c(clip)
+        N, V = clip.shape[0], clip.shape[1]
+        delta = torch.empty((N, V, 2), dtype=torch.float32, device=clip.device)
+        call("a3d_flow_delta_fwd", ptr(clip), N, int(num_frames), V, ptr(delta), stream())
+        ctx.save_for_backward(clip)
+        ctx.num_frames = int(num_frames)
+        return delta
+
+    @staticmethod
+    def backward(ctx, g):
+        (clip,) = ctx.saved_tensors
+        N, V = clip.shape[0], clip.shape[1]
+        g_clip = torch.empty_like(clip)
+        # (the gradient may be two columns of the G-buffer backward's 16-float rows: read in place, with its vertex stride)
+        if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(1) < 2 or g.stride(0) != V * g.stride(1):
+            g = f32c(g)
+        call("a3d_flow_delta_bwd", ptr(g), g.stride(1), ptr(clip), N, ctx.num_frames, V, ptr(g_clip), stream())
+        return g_clip, None
+
+
+def flow_delta(clip, num_frames):
+    """clip [B*F,V,4] -> [B*F,V,2]: ndc of the next frame minus ndc of this one, zeros for a sequence's last frame."""
+    return _FlowDelta.apply(clip, num_frames)
+
+
 # ---------------------------------------------------------------------------------------------- covered pixels
 _cover_counts = _IdentityCache(maxsize=2)  # raster buffer -> block counts of its covered-pixel list
 _aa_prepared = _IdentityCache(maxsize=2)  # raster buffer -> (key of its clip tensor, screen positions, zeroed counters)

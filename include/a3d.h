@@ -705,6 +705,13 @@ int a3d_xfm_points_bwd(const float* g_out, int g_stride, const float* points, in
                                                       w.r.t. the clip positions, render.py:264-268, which otherwise meets the rasteriser's in
                                                       an accumulation launch of the caller's autograd engine) */,
                        int g2_stride, a3d_stream_t stream);
+/* (404) The 2-D motion of every vertex to the next frame of its sequence -- /root/reference/model/render/render.py:281-288:
+ * ndc = clip[..., :2] / clip[..., -1:], delta[b,f] = ndc[b,f+1] - ndc[b,f], zeros for the last frame of a sequence.  clip[N,V,4] with
+ * N = B*F frames (sequence-major), delta[N,V,2]; bwd: g_clip[N,V,4] fully written (z column zero).  One launch each way for the ~25 torch
+ * launches of the expression (the Ponymation step renders 'flow'). */
+int a3d_flow_delta_fwd(const float* clip, int N, int F, int V, float* delta, a3d_stream_t stream);
+int a3d_flow_delta_bwd(const float* g_delta, int g_stride /* floats between two vertices of g_delta (2 = contiguous) */, const float* clip, int N,
+                       int F, int V, float* g_clip, a3d_stream_t stream);
 
 #ifdef __cplusplus
 }

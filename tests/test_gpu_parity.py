@@ -2890,6 +2890,36 @@ def test_xfm_points_aliases_sum_their_gradients_inside_the_backward_launch(dev, 
         assert float((gm.double() - rm).abs().max()) < 1e-4 * max(1.0, float(rm.abs().max())), use
 
 
+@pytest.mark.parametrize("B,F", [(3, 4), (5, 2), (1, 8)])
+def test_flow_delta_equals_the_reference_expression_and_its_gradients(B, F, dev, ops):
+    """ops.flow_delta (a3d_flow_delta_fwd / _bwd): the per-vertex motion to the next frame of render.py:281-288 -- ndc = clip.xy / clip.w,
+    ndc[f+1] - ndc[f], zeros for the last frame of a sequence -- against the torch expression the reference writes: the same values
+    (the same float32 divisions and subtraction: bit for bit) and the expression's own gradient in float64."""
+    V, N = 333, B * F
+    clip = seeded((N, V, 4), 11, -1, 1)
+    clip[..., 3] = 5.0 + clip[..., 3]  # (w of a vertex in front of the camera)
+    clip = clip.to(dev).requires_grad_(True)
+
+    def expression(c, frames):
+        ndc = c[..., :2] / c[..., -1:]
+        ndc = ndc.view(-1, frames, *ndc.shape[1:])
+        d = ndc[:, 1:] - ndc[:, :-1]
+        return torch.cat([d, torch.zeros_like(d[:, :1])], dim=1).view(-1, *ndc.shape[2:])
+
+    got = ops.flow_delta(clip, F)
+    ref = expression(clip, F)
+    assert got.shape == ref.shape == (N, V, 2) and torch.equal(got, ref)
+    rows = seeded((N, V, 16), 12, -1, 1).to(dev)
+    w = rows[..., 9:11]  # (strided, as the G-buffer backward hands the attribute's gradient out: read in place)
+    (g,) = torch.autograd.grad(got, [clip], grad_outputs=w, retain_graph=True)
+    (g_c,) = torch.autograd.grad(got, [clip], grad_outputs=w.contiguous())
+    assert torch.equal(g, g_c)
+    c64 = clip.detach().double().requires_grad_(True)
+    (r,) = torch.autograd.grad((expression(c64, F) * w.double()).sum(), [c64])
+    assert g.shape == clip.shape and float(g[..., 2].abs().max()) == 0.0
+    assert float((g.double() - r).abs().max()) < 1e-6 * max(1.0, float(r.abs().max()))
+
+
 def test_compositor_hands_out_kept_channels_reads_strided_gradients_and_short_backgrounds(dev, ops, mods):
     """Round 6 plumbing of a3d_composite_aa_*: ``keep`` materialises only the leading channels a mode returns (dino_pred / flow without
     alpha) -- same values as the slice of the full image, same gradients as through the slice; value rows may carry padding rows behind

@@ -85,7 +85,7 @@ def test_product_library_carries_no_phase_stamps():
     tus = ("dmtet", "skin", "raster", "gbuffer", "shade", "normals", "antialias")
     assert not any(hasattr(lib, f"a3d_profile_set_{t}") for t in tus)
     prof = os.path.join(ROOT, "3danimals_amd", "lib", "liba3d_hip_prof.so")
-    if os.path.exists(prof) and os.path.getmtime(prof) >= os.path.getmtime(L.LIB_PATH) - 3600:
+    if os.path.exists(prof) and os.path.getmtime(prof) >= os.path.getmtime(L.LIB_PATH):  # (a twin older than the library is a stale build: says nothing)
         twin = ctypes.CDLL(prof)
         assert all(hasattr(twin, f"a3d_profile_set_{t}") for t in tus)
         assert all(hasattr(twin, name) for name in L.SIGNATURES)
