@@ -88,7 +88,7 @@ def pmc_traffic(signature=PMC_WORKLOAD):
 # what the hot path consists of.  f3 = the fused reconstruction losses ("next" row, built).  Everything else
 # (rows_*, harmonic_embed, gemm) serves the texture / DINO / SDF fields = model/networks: out of scope.
 IN_SCOPE = ("a3d_dmtet_", "a3d_skin_", "a3d_bone_transforms_", "a3d_normals_", "a3d_mesh_topology", "a3d_rast_", "a3d_interp_", "a3d_cover_",
-            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_", "a3d_estimate_bones")
+            "a3d_gbuffer_", "a3d_shade_", "a3d_aa_", "a3d_composite_aa_", "a3d_mask_aa_", "a3d_xfm_", "a3d_flow_delta_", "a3d_estimate_bones")
 F3 = ("a3d_recon_losses_",)
 
 
@@ -194,6 +194,10 @@ def algorithmic_bytes(name, d):
         "a3d_shade_bwd_rows": P * (12 + 48 + 8 + 12 + 48) + 36 * Pp,
         "a3d_xfm_points_fwd": B * V * (12 + 16) + 64 * B,
         "a3d_xfm_points_bwd": B * V * (16 + 12 + 12) + 128 * B,
+        # render_mesh's per-vertex motion to the next frame ('flow'): clip positions in (every frame once), the 2-D differences out; backward:
+        # their gradient and the clip positions in, the clip gradient out
+        "a3d_flow_delta_fwd": B * V * (16 + 8),
+        "a3d_flow_delta_bwd": B * V * (8 + 16 + 16),
         "a3d_dmtet_gather_rows": 0,  # (a few thousand rows: latency only; credited nothing)
         "a3d_bone_transforms_fwd": B * K * (12 + 48) + 24 * K,
         "a3d_bone_transforms_bwd": B * K * (12 + 48 + 12) + 24 * K,

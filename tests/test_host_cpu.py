@@ -599,6 +599,8 @@ def test_bench_credit_table_is_frozen_against_the_survey_formulas():
         "a3d_shade_bwd_rows": P * (12 + 48 + 8 + 12 + 48) + 36 * (-(-P // 8192) * 8192),
         "a3d_xfm_points_fwd": B * V * 28 + 64 * B,
         "a3d_xfm_points_bwd": B * V * 40 + 128 * B,
+        "a3d_flow_delta_fwd": B * V * 24,
+        "a3d_flow_delta_bwd": B * V * 40,
         "a3d_composite_aa_bwd[C4]": 8 * P + 8 * P * 3 + 16 * B * V,
         "a3d_aa_analyze": B * 16 * HW + B * 16 * V,
     }

@@ -54,6 +54,8 @@ ENTRY = {
     "a3d_xfm_points_fwd": (["xf_fwd_kernel"], "xf_fwd_kernel"),
     "a3d_xfm_points_bwd": (["xf_bwd_kernel"], "xf_bwd_kernel"),
     "a3d_dmtet_gather_rows": (["dm_gather_rows_kernel"], "dm_gather_rows_kernel"),
+    "a3d_flow_delta_fwd": (["xf_flow_fwd_kernel"], "xf_flow_fwd_kernel"),
+    "a3d_flow_delta_bwd": (["xf_flow_bwd_kernel"], "xf_flow_bwd_kernel"),
     "a3d_rows_add_relu_fwd": (["ss_add_relu4_kernel", "ss_add_relu1_kernel"], "ss_add_relu4_kernel"),
     "a3d_rows_add_relu_bwd": (["ss_kernel<4, true", "ss_kernel<1, true"], None),
     "a3d_rows_segsum": (["ss_kernel<4, false>", "ss_kernel<1, false>"], None),
