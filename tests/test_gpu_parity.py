@@ -1402,7 +1402,7 @@ def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(see
     switches = [(ops, "DMTET_CULL_MIN_VERTS", 0, 1 << 30), (ops, "DMTET_EMIT_LISTS", True, False), (ops, "DMTET_SPECULATIVE_EMIT", True, False),
                 (ops, "DMTET_TOPOLOGY", True, False), (M, "RIDE_NORMALS", True, False), (R, "FUSED_COVER_GBUFFER", True, False),
                 (R, "DEFER_ANALYSIS", True, False), (R, "FUSED_COMPOSITE", True, False), (R, "SHADE_IN_COMPOSITOR", True, False),
-                (R, "FUSED_MASK_RENDER", True, False), (R, "DEFER_RESOLVE", True, False)]
+                (R, "FUSED_MASK_RENDER", True, False), (R, "DEFER_RESOLVE", True, False), (R, "ALIAS_POSITIONS", True, False)]
 
     def run(on):
         """on: True / False = every switch on / off; a tuple of booleans = one setting per switch (mixed)."""
@@ -1430,10 +1430,11 @@ def test_every_launch_folding_switch_off_gives_the_same_frames_and_gradients(see
         return frames
 
     a, b = run(True), run(False)
-    # (round 5) ... and MIXED settings: the switches are independent knobs of a deployment (eleven A3D_* environment variables), so two
+    # (round 5) ... and MIXED settings: the switches are independent knobs of a deployment (A3D_* environment variables), so two
     # random subsets per case go through the same comparison -- a switch that only works next to another one would show here
     rng = np.random.RandomState(100 + seed)
-    mixed = [run(tuple(bool(v) for v in rng.randint(0, 2, len(switches)))) for _ in range(2)] if seed in (1, 2, 5, 7) else []
+    # (round 6: every case, and the clip transform's aliases -- ALIAS_POSITIONS -- are one of the knobs)
+    mixed = [run(tuple(bool(v) for v in rng.randint(0, 2, len(switches)))) for _ in range(2)]
     for other in [a] + mixed:
       for t, (fa, fb) in enumerate(zip(other, b)):
           assert fa[1].shape[0] > 50 and torch.equal(fa[0], fb[0]) and torch.equal(fa[1], fb[1]), t
