@@ -156,6 +156,18 @@ __device__ __forceinline__ int a3d_run_scan(int* a, int* dst, int lo, int hi, in
     return run;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (within rows of 16: row_shr 1, 2, 4, 8; across rows: row_bcast 15,
+// 31) -- VALU only, no LDS crossbar (six ds_bpermute round trips in the __shfl_up form)
+__device__ __forceinline__ int a3d_wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 __device__ __forceinline__ float a3d_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

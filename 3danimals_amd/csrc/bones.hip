@@ -113,7 +113,6 @@ __device__ __forceinline__ float eb_block_sum(float v, float* s_f) {
 // interpolates between nearly always do, to the last pass) share one histogram: s_rep[t] = the first target of t's group with t's prefix.
 template <int NG, class F>
 __device__ __forceinline__ void eb_multiselect(F f, int total, int mg, int* s_rank, unsigned* s_prefix, int (*s_hist)[256], int (*s_h0)[256][EB_COPIES]) {
-    __shared__ int s_wtot[EB_THREADS / 64];
     __shared__ int s_rep[EB_MAXSEL], s_urep[NG][EB_MAXGROUP], s_nu[NG];
     __shared__ unsigned s_upre[NG][EB_MAXGROUP];
     const int m = NG * mg;  // (mg <= EB_MAXGROUP)
@@ -174,29 +173,33 @@ __device__ __forceinline__ void eb_multiselect(F f, int total, int mg, int* s_ra
             }
         }
         __syncthreads();
-        // the bin that holds each target's rank: 256 threads per target (four targets at a time), an inclusive scan of the 256 counts
-        // through wave shuffles + the four wave totals -- ONE thread walking the 256 bins was 12 us per pass, 150 us of the kernel
-        for (int t0 = 0; t0 < m; t0 += EB_THREADS / 256) {  // (uniform trip count: the barriers inside are reached by every thread)
-            const int g = threadIdx.x >> 8, b = threadIdx.x & 255, t = t0 + g;
-            const bool live = t < m;
-            const int c = live ? s_hist[s_rep[t]][b] : 0;
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o, 64);
-                if ((threadIdx.x & 63) >= o) incl += up;
-            }
-            if ((threadIdx.x & 63) == 63) s_wtot[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            int before = 0;
-            for (int w = g * 4; w < (int)(threadIdx.x >> 6); ++w) before += s_wtot[w];
-            incl += before;
-            const int r = live ? s_rank[t] : -1;
-            const unsigned pre = live ? s_prefix[t] : 0u;
-            __syncthreads();  // (every thread has read its target's rank, prefix and the wave totals)
-            if (live && r >= incl - c && r < incl) {  // exactly one bin per target
-                s_rank[t] = r - (incl - c);
-                s_prefix[t] = pass == 0 ? (unsigned)b : ((pre << 8) | (unsigned)b);
+        // the bin that holds each target's rank: ONE WAVE per target (m <= 12 targets, 16 waves) -- a lane sums four neighbouring bins
+        // (one 16-byte LDS read), the wave scans the 64 sums with DPP and the lane whose range holds the rank walks its four bins: no
+        // work-group barrier inside.  (256 threads per target, four targets at a time, an inclusive scan through shuffles + the wave totals
+        // through LDS was two barriers per round of four targets: six per pass, 24 per select -- the call took 52.8 us, 41.5 with this; ONE
+        // thread walking the 256 bins, before that, 12 us per pass.  Also measured: the values in the REGISTERS of their owners instead of
+        // a planar scratch array, no compaction of the low vertices -- 41.5 -> 38.0 us in the kernel for 128 VGPRs and a 24-byte spill, and the
+        // spill's scratch set-up made the Fauna tests run ten times longer end to end: not kept.)
+        {
+            const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            for (int t = w; t < m; t += EB_THREADS / 64) {
+                const int4 c = reinterpret_cast<const int4*>(s_hist[s_rep[t]])[ln];
+                const int s4 = c.x + c.y + c.z + c.w;
+                const int incl = a3d_wave_incl_scan(s4), excl = incl - s4;
+                const int r = s_rank[t];
+                const unsigned pre = s_prefix[t];
+                if (r >= excl && r < incl) {  // exactly one lane per target
+                    int b = 4 * ln, base = excl;
+                    if (r >= base + c.x) {
+                        base += c.x; ++b;
+                        if (r >= base + c.y) {
+                            base += c.y; ++b;
+                            if (r >= base + c.z) { base += c.z; ++b; }
+                        }
+                    }
+                    s_rank[t] = r - base;
+                    s_prefix[t] = pass == 0 ? (unsigned)b : ((pre << 8) | (unsigned)b);
+                }
             }
         }
         __syncthreads();
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(EB_THREADS) void eb_kernel(const EbParams a) {
     __shared__ int s_ab[EB_MAXN][2], s_foot[EB_MAXN][4];
     __shared__ int s_rank[EB_MAXSEL];
     __shared__ unsigned s_prefix[EB_MAXSEL];
-    __shared__ int s_hist[EB_MAXSEL][256];
+    __shared__ __attribute__((aligned(16))) int s_hist[EB_MAXSEL][256];  // (rows read as int4 by the bin search)
     __shared__ int s_h0[2][256][EB_COPIES];  // first-pass histograms, EB_COPIES copies each
     __shared__ float s_q[8];  // margins / centres of the quadrants
     __shared__ int s_ok;

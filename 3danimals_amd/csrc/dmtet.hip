@@ -254,21 +254,9 @@ __global__ __launch_bounds__(DM_THREADS) void dm_count_kernel(const void* __rest
 #define DM_TAIL_ROWS 32
 #define DM_TAIL_MAX (DM_TAIL_ROWS * 64)
 
-// in-place exclusive scan of arr[0, n) (global, or LDS for the chunk counts -> written to `dst`) by ONE wave; returns the total
-// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (within rows of 16: row_shr 1, 2, 4, 8; across rows: row_bcast 15,
-// 31) -- VALU only.  (The shuffle form, six ds_bpermute round trips per row of sums, chained row after row behind wave-uniform branches,
-// made the folded scan 17 us slower than the launch it replaces.)
-__device__ __forceinline__ int dm_wave_incl_scan(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
-    return x;
-}
-
-// in-place exclusive scan of arr[0, n) (global, or LDS for the chunk counts -> written to `dst`) by ONE wave; returns the total
+// in-place exclusive scan of arr[0, n) (global, or LDS for the chunk counts -> written to `dst`) by ONE wave; returns the total.  (The rows'
+// inclusive scans: a3d_wave_incl_scan, six DPP additions.  The shuffle form -- six ds_bpermute round trips per row of sums, chained row
+// after row behind wave-uniform branches -- made the folded scan 17 us slower than the launch it replaces.)
 template <bool COHERENT>
 __device__ __forceinline__ int dm_wave_scan_rows(const int* src, int* dst, int n) {
     const int lane = threadIdx.x & 63;
@@ -281,7 +269,7 @@ __device__ __forceinline__ int dm_wave_scan_rows(const int* src, int* dst, int n
     int carry = 0;
 #pragma unroll
     for (int j = 0; j < DM_TAIL_ROWS; ++j) {  // (every row, no branch: the rows' chains interleave; rows past n hold zeros)
-        const int incl = dm_wave_incl_scan(v[j]);
+        const int incl = a3d_wave_incl_scan(v[j]);
         const int i = j * 64 + lane;
         if (i < n) dst[i] = carry + incl - v[j];
         carry += __builtin_amdgcn_readlane(incl, 63);
