@@ -1659,6 +1659,24 @@ def test_surface_only_sdf_backward_is_output_identical(dev, mods):
     for a, b in zip(g1, g0):
         scale = float(b.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale
+    # (round 6) the rows of the re-evaluation written by the DMTet emit launch (dmtet.SURFACE_POINTS_IN_EMIT) against the gather launch:
+    # the same rows, so the same mesh and the same gradients up to the order of the backward's float atomics
+    _lib = importlib.import_module("3danimals_amd._lib")
+    D = mods["dmtet"]
+    assert D.SURFACE_POINTS_IN_EMIT
+    with _lib.KernelTimer() as t_on:
+        run(True)
+    D.SURFACE_POINTS_IN_EMIT = False
+    try:
+        with _lib.KernelTimer() as t_off:
+            m2, g2, s2 = run(True)
+    finally:
+        D.SURFACE_POINTS_IN_EMIT = True
+    count = lambda t: sum(c for n, (c, _) in t.summary().items() if n.startswith("a3d_dmtet_gather_rows"))
+    assert count(t_on) == 1 and count(t_off) == 2  # (backward only | forward and backward)
+    assert torch.equal(m2.v_pos, m1.v_pos) and torch.equal(s2, s1)
+    for a, b in zip(g2, g1):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
 
 
 def test_nvdiffrast_shim_end_to_end(dev):
@@ -2889,6 +2907,38 @@ def test_xfm_points_aliases_sum_their_gradients_inside_the_backward_launch(dev, 
         rp, rm = torch.autograd.grad(loss64, [p64, m64], retain_graph=True)
         assert float((gp.double() - rp).abs().max()) < 1e-5 * max(1.0, float(rp.abs().max())), use
         assert float((gm.double() - rm).abs().max()) < 1e-4 * max(1.0, float(rm.abs().max())), use
+
+
+def test_render_mesh_flow_mode_with_the_fused_motion_equals_the_torch_expression(dev, mods):
+    """render.FUSED_FLOW_DELTA: render_mesh(render_modes=[..., 'flow']) with the per-vertex motion from a3d_flow_delta_* against the same
+    call with the reference's torch expression (render.py:281-288): the same 'flow' image (the same float32 operations) and the same
+    gradient on the posed vertices up to the order of the backward's float atomics."""
+    M, R = mods["mesh"], mods["render"]
+    Bs, Fr, H, W = 2, 3, 48, 48
+    N = Bs * Fr
+    verts, faces, _, (mvp, w2c, campos) = _scene(N, seed=9)
+    uvs = torch.zeros(1, 4, 2, device=dev)
+    uvi = torch.zeros(1, faces.shape[0], 3, dtype=torch.int64, device=dev)
+    tri = faces[None].to(dev)
+
+    def run(fused):
+        R.FUSED_FLOW_DELTA = fused
+        try:
+            posed = (verts[None] + 0.05 * seeded((N, *verts.shape), 33, -1, 1)).to(dev).requires_grad_(True)
+            prior = M.make_mesh(verts[None].to(dev), tri, uvs, uvi, None)
+            shape = M.make_mesh(posed, tri, uvs.expand(N, -1, -1), uvi, None)
+            out = R.render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), bsdf="diffuse",
+                                render_modes=["shaded", "flow"], prior_mesh=prior, num_frames=Fr)
+            (g,) = torch.autograd.grad(sum((o * seeded(tuple(o.shape), 40 + i, -1, 1).to(dev)).sum() for i, o in enumerate(out)), posed)
+            return out, g
+        finally:
+            R.FUSED_FLOW_DELTA = True
+
+    (o1, g1), (o0, g0) = run(True), run(False)
+    assert o1[1].shape == o0[1].shape and o1[1].shape[1] == 2 and float(o0[1].detach().abs().max()) > 0
+    assert float((o1[1] - o0[1]).abs().max()) <= 2.4e-7  # (antialiased: two blends on a pixel add in the order the atomics land)
+    assert float((o1[0] - o0[0]).abs().max()) <= 2.4e-7
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(g0.abs().max()))
 
 
 @pytest.mark.parametrize("B,F", [(3, 4), (5, 2), (1, 8)])
