@@ -98,7 +98,7 @@ SIGNATURES = {
     "a3d_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_composite_aa_fwd": (_c_int, [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
     "a3d_mask_aa_fwd": (_c_int, [_p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p]),
-    "a3d_mask_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p]),
+    "a3d_mask_aa_bwd": (_c_int, [_p, _p, _c_int, _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _c_int, _p]),
     "a3d_composite_aa_bwd": (_c_int, [_p, _p, _p, ctypes.c_int64, _p, _p, _p, _c_int, _p, _c_int, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _p, _p, _p]),
 }
 

@@ -423,6 +423,7 @@ struct CaJob {
     int oC;
     const float* g_out;  // backward: [B,H,W,gS] of which the first gC channels are the gradient of the image's (the rest: zero)
     int gS, gC;
+    int gHW;             // backward, a3d_mask_aa_bwd only: > 0 = the gradient is channels-FIRST, [B,gS,H,W] with gHW = H W (0: channels-last)
     float* g_vals;       // backward: [vals_rows >= P, C], rows past P zero
     long long vals_rows;
 };
@@ -647,7 +648,8 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(CaJob ja, CaJob jb, const A
         const int q0 = ca_point(s, p0), q1 = ca_point(s, p1);
         float dd = 0.f;
         for (int c = sub; c < C1; c += 32) {
-            const float gd = g_out[(long long)dst * gS + c];
+            // (channels-first: pixel dst = image b, pixel q  ->  (b gS + c) gHW + q = dst + b (gS - 1) gHW + c gHW)
+            const float gd = job.gHW ? g_out[(long long)dst + ((long long)(dst / (unsigned)job.gHW) * (gS - 1) + c) * job.gHW] : g_out[(long long)dst * gS + c];
             if (gd != 0.f) {
                 if (c < C && g_vals) {  // (a constant colour has no adjoint)
                     if (q1 >= 0) atomicAdd(g_vals + (long long)q1 * C + c, rec.alpha * gd);
@@ -768,7 +770,7 @@ static CaJob ca_job(const float* vals, int C, const int32_t* inv, const float* b
     j.s.vals = vals; j.s.inv = inv; j.s.rast = nullptr; j.s.sh_gb = nullptr; j.s.sh_par = ShPar{}; j.s.sh_kd = nullptr; j.s.sh_kd_stride = 0; j.s.sh_out = nullptr;
     j.s.sh_two_sided = 0; j.s.bg = bg; j.s.bg_shared = bg_batch == 1; j.s.C = C; j.s.hw = (unsigned)H * (unsigned)W;
     j.s.bgC = (ext && ext->bg_channels > 0) ? ext->bg_channels : C + 1;
-    j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0;
+    j.out = out; j.g_out = g_out; j.g_vals = g_vals; j.clear = nullptr; j.n_clear = 0; j.gHW = 0;
     j.oC = (ext && ext->out_channels > 0) ? ext->out_channels : C + 1;
     j.gS = (ext && ext->g_stride > 0) ? ext->g_stride : C + 1;
     j.gC = (ext && ext->g_channels > 0) ? ext->g_channels : C + 1;
@@ -917,7 +919,7 @@ extern "C" int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null
 
 extern "C" int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
                                const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F,
-                               int H, int W, float* g_clip, a3d_stream_t stream) {
+                               int H, int W, float* g_clip, int g_channels_first, a3d_stream_t stream) {
     A3D_CHECK_ARG(g_out && rast && work && count && clip && g_clip && C > 0 && C <= 4096 && B > 0 && V > 0 && H > 0 && W > 0 && capacity > 0);
     A3D_CHECK_ARG((long long)B * H * W < 0x7FFFFFFFll && (clip_batch == 1 || clip_batch == B) && (!bg_or_null || bg_batch == 1 || bg_batch == B));
     hipStream_t s = (hipStream_t)stream;
@@ -926,6 +928,7 @@ extern "C" int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, con
     A3D_CHECK_ARG(tri);
     CaJob ja = ca_job(nullptr, C, nullptr, bg_or_null, bg_batch, H, W, nullptr, g_out, nullptr);
     ja.s.rast = (const float4*)rast;
+    ja.gHW = g_channels_first ? H * W : 0;
     hipLaunchKernelGGL(ca_bwd_kernel, dim3(1024, 1), dim3(256), 0, s, ja, ja, (const AaRec*)work, count, capacity, (const float4*)clip, clip_batch,
                        tri, V, H, W, g_clip);
     A3D_LAUNCH_CHECK();

@@ -1811,8 +1811,14 @@ class _MaskAntialias(torch.autograd.Function):
         rast_c, bg = ctx.saved_tensors
         a, C = ctx.analysis, ctx.C
         g_clip = torch.empty_like(a.clip)
-        call("a3d_mask_aa_bwd", ptr(f32h(g_out)), ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
-             ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip), stream(), tag=f"[C{C + 1}]")
+        # the image usually went on as permute(0, 3, 1, 2) + a channel slice (Fauna.py:166-173): the engine then hands back a channels-FIRST
+        # tensor seen through the inverse permute -- read where it is (its contiguous copy was 10 us of the Fauna step)
+        first = g_out.dtype == torch.float32 and g_out.dim() == 4 and not g_out.is_contiguous() and g_out.permute(0, 3, 1, 2).is_contiguous()
+        if not first:
+            g_out = f32h(g_out)
+        call("a3d_mask_aa_bwd", ptr(g_out), ptr(rast_c), C, ptr(bg), 0 if bg is None else bg.shape[0], ptr(a.work), ptr(a.count), a.capacity,
+             ptr(a.clip), a.clip.shape[0], ptr(a.topo.tri), a.B, a.clip.shape[1], a.topo.tri.shape[0], a.H, a.W, ptr(g_clip), int(first), stream(),
+             tag=f"[C{C + 1}]")
         return None, g_clip, None, None, None
 
 

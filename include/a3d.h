@@ -627,7 +627,10 @@ int a3d_mask_aa_fwd(const float* rast, int C, const float* bg_or_null, int bg_ba
                     int B, int H, int W, const a3d_aa_ride* analyze_or_null /* (its rast = this call's) */, a3d_stream_t stream);
 int a3d_mask_aa_bwd(const float* g_out, const float* rast, int C, const float* bg_or_null, int bg_batch, const void* work,
                     const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B, int V, int F, int H,
-                    int W, float* g_clip, a3d_stream_t stream);
+                    int W, float* g_clip,
+                    int g_channels_first /* (404) 1: g_out is [B,C+1,H,W] -- what the caller's autograd hands back when the image went on as
+                                            permute(0, 3, 1, 2) and a channel slice, Fauna.py:166-173 -- read in place; 0: [B,H,W,C+1] */,
+                    a3d_stream_t stream);
 int a3d_composite_aa_bwd(const a3d_ca_buffer* first, const a3d_ca_buffer* second_or_null, const int64_t* pix, int64_t P, const int32_t* inv,
                          const void* work, const int32_t* count, int capacity, const float* clip, int clip_batch, const int32_t* tri, int B,
                          int V, int F, int H, int W, float* g_clip, const a3d_ca_shade* shade_or_null, a3d_stream_t stream);

@@ -2832,11 +2832,15 @@ def test_texture_less_render_through_the_mask_compositor_equals_the_general_path
         with _lib.KernelTimer() as timer:
             out = R.render_mesh(None, shape, mvp.to(dev), w2c.to(dev), campos.to(dev), None, None, (H, W), background=bg, bsdf="diffuse",
                                 render_modes=["shaded"], two_sided_shading=False)[0]
-            (g,) = torch.autograd.grad((out * wgt).sum(), posed)
-        return out.detach(), g, sorted(timer.summary())
+            (g,) = torch.autograd.grad((out * wgt).sum(), posed, retain_graph=True)
+        # Fauna's use of it (Fauna.py:166-173): the alpha channel alone, clamped -- the engine hands the op a channels-FIRST zero-padded
+        # gradient seen through the inverse permute, which a3d_mask_aa_bwd reads in place (g_channels_first)
+        (g_alpha,) = torch.autograd.grad((out[:, 3:].clamp(0, 1) * wgt[:, 3:]).sum(), posed)
+        return out.detach(), g, sorted(timer.summary()), g_alpha
 
-    out_f, g_f, calls_f = run(True)
-    out_g, g_g, calls_g = run(False)
+    out_f, g_f, calls_f, ga_f = run(True)
+    out_g, g_g, calls_g, ga_g = run(False)
+    assert float(ga_g.abs().max()) > 0 and float((ga_f - ga_g).abs().max()) <= 1e-4 * float(ga_g.abs().max())
     assert out_f.shape == (B, 4, H, W) and float((out_f - out_g).abs().max()) < 1e-6
     assert float((out_f[:, 3] > 0).float().mean()) > 0.05 and float(((out_f[:, 3] > 0.01) & (out_f[:, 3] < 0.99)).float().mean()) > 1e-3
     assert float(g_g.abs().max()) > 0 and float((g_f - g_g).abs().max()) <= 1e-4 * float(g_g.abs().max())
